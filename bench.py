@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: batched NV12 -> RGB 3840x2160 on MI355X.
+
+Metric (BASELINE.json): frames/s + achieved HBM GB/s, NV12->RGB 2160p, 1/2/4/8 GPUs.
+A "step" is ONE launch of the hot path (PySurfaceConverter.RunBatchAsync ->
+vali_nv12_to_rgb_batch) over one batch of `--frames` distinct 2160p surfaces per GPU
+(default 512 = BASELINE config 5's 4096 frames / 8 GPUs; 19.1 GB of surfaces per GPU,
+far beyond the 256 MiB Infinity Cache).  Inputs are resident in HBM before the timed
+region.  One process per GPU; frames are sharded, never exchanged: the only
+collective is the RCCL broadcast of the 32-byte colour-coefficient block.
+
+  python bench.py                      # 1 GPU
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task brief): value = whole-job frames/s,
+`roofline` = algorithmic bytes / HIP-event kernel time vs the 8 TB/s HBM peak,
+`cpu_baseline` = the C oracle (port of the same arithmetic) timed on the host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_CEILING_GBPS = 6290.0  # measured float4 copy ceiling (same guide)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=512, help="frames per GPU per step")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--dst", default="RGB", choices=["RGB", "BGR", "RGB_PLANAR"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0,
+                    help="budget of the CPU baseline sample (rank 0, N=1 only); 0 disables")
+    ap.add_argument("--no-parity", action="store_true")
+    return ap.parse_args()
+
+
+def synth_nv12(width, height, seed):
+    """SURVEY 8(d) recipe: seeded limited-range noise; frame 0 = full-excursion gradient."""
+    rows = height * 3 // 2
+    if seed == 0:
+        yy, xx = np.mgrid[0:rows, 0:width]
+        return ((xx * 255 // (width - 1) + yy * 3) % 256).astype(np.uint8)
+    rng = np.random.default_rng(1234 + seed)
+    a = np.empty((rows, width), np.uint8)
+    a[:height] = rng.integers(16, 236, (height, width), dtype=np.uint8)
+    a[height:] = rng.integers(16, 241, (rows - height, width), dtype=np.uint8)
+    return a
+
+
+def cpu_baseline(width, height, coeffs, budget_s):
+    """Time the C oracle (same arithmetic as the HIP kernel) on the host cores:
+    one frame on one thread, then `cores` independent frames per pass on all cores,
+    passes repeated until the time budget is used."""
+    from oracle import oracle as o
+
+    k = o.csc_from_tuple(coeffs)
+    cores = os.cpu_count() or 1
+    seeds = [synth_nv12(width, height, s) for s in range(1, 1 + min(cores, 8))]
+    batch = [seeds[i % len(seeds)] for i in range(cores)]          # inputs are read-only
+    outs = [np.zeros((height, 3 * width), np.uint8) for _ in range(cores)]
+    o.nv12_to_rgb_mt(batch, width, height, k, cores, outs)         # untimed: page in buffers
+    t0 = time.perf_counter()
+    o.nv12_to_rgb_mt(batch[:1], width, height, k, 1, outs[:1])
+    t_single = time.perf_counter() - t0
+    done, t0 = 0, time.perf_counter()
+    while True:
+        o.nv12_to_rgb_mt(batch, width, height, k, cores, outs)
+        done += cores
+        if time.perf_counter() - t0 >= budget_s:
+            break
+    t_all = time.perf_counter() - t0
+    return {
+        "value": round(done / t_all, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+        "sample": f"{done} frames {width}x{height} NV12->RGB by oracle/vali_oracle.c, "
+                  f"{cores} OpenMP threads over independent frames, {t_all:.1f} s",
+        "single_thread_fps": round(1.0 / t_single, 3),
+        "note": "the reference's CPU path is FFmpeg libswscale (not available offline); this "
+                "is the build's own C restatement of the GPU arithmetic",
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+
+    import vali_amd as vali
+    from vali_amd._native import shim
+
+    ngpu = vali.GetNumGpus()
+    if ngpu == 0:
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback by design)")
+    dev = local_rank % ngpu
+    torch.cuda.set_device(dev)
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", dev))
+
+    W, H, F = args.width, args.height, args.frames
+    dst_fmt = vali.PixelFormat[args.dst]
+    # this rank's shard of the global batch (weak scaling: F frames per GPU)
+    begin, end = vali.shard_frames(F * world, rank, world)
+    assert end - begin == F
+    pipe = vali.BatchedFramePipeline(dev, W, H, F, dst_fmt)
+    # the one collective of the path: rank 0 resolves the colour context to a matrix,
+    # everyone receives the 32-byte block over RCCL/xGMI
+    cc = vali.ColorspaceConversionContext(vali.ColorSpace.BT_709, vali.ColorRange.MPEG)
+    coeffs = pipe.set_coefficients(cc if rank == 0 else None, src=0, device=f"cuda:{dev}")
+    stream = pipe.Stream
+
+    # distinct content in the first NSEED frames (uploaded), cycled device-to-device into
+    # the rest: every frame is a distinct HBM allocation, content repeats.
+    upl = vali.PyFrameUploader(dev, stream)
+    nseed = min(F, 8)
+    host = [synth_nv12(W, H, (begin + s) if rank else s) for s in range(nseed)]
+    for i in range(nseed):
+        ok, info = upl.Run(host[i].reshape(-1), pipe.srcs[i])
+        assert ok, info
+    for i in range(nseed, F):
+        s, d = pipe.srcs[i % nseed]._planes[0], pipe.srcs[i]._planes[0]
+        shim.memcpy2d_async(dev, d.GpuMem, d.Pitch, s.GpuMem, s.Pitch, s.Width, s.Height, 2, stream)
+    shim.stream_sync(dev, stream)
+
+    def step():
+        ok, info = pipe.run_async()
+        assert ok, info
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev = [(shim.event_create(dev), shim.event_create(dev)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:                      # HIP events on the stream the kernel runs on
+        shim.event_record(dev, a, stream)
+        step()
+        shim.event_record(dev, b, stream)
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = [shim.event_elapsed_ms(a, b) for a, b in ev]
+    for a, b in ev:
+        shim.event_destroy(dev, a)
+        shim.event_destroy(dev, b)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{dev}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    parity = None
+    if not args.no_parity and rank == 0:
+        from oracle import oracle as o
+
+        dwn = vali.PySurfaceDownloader(dev, stream)
+        worst = 0
+        checked = sorted({0, min(1, F - 1), F - 1})
+        for i in checked:
+            got = np.zeros(pipe.dsts[i].HostSize, np.uint8)
+            ok, _ = dwn.Run(pipe.dsts[i], got)
+            assert ok
+            want = o.nv12_to_rgb(host[i % nseed], W, H, o.csc_from_tuple(coeffs), args.dst)
+            worst = max(worst, int(np.abs(got.astype(np.int16)
+                                          - want.reshape(-1).astype(np.int16)).max()))
+        parity = {"frames_checked": len(checked), "max_abs_diff_lsb": worst}
+
+    if rank == 0:
+        bytes_per_frame = W * H * 3 // 2 + W * H * 3            # algorithmic: read NV12 + write RGB
+        avg_kernel_ms = float(np.mean(kernel_ms))
+        achieved = bytes_per_frame * F / (avg_kernel_ms * 1e-3) / 1e9
+        fps = world * F * args.steps / elapsed
+        out = {
+            "metric": "nv12_to_rgb_2160p_frames_per_s" if (W, H) == (3840, 2160)
+                      else f"nv12_to_rgb_{W}x{H}_frames_per_s",
+            "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": f"BatchedFramePipeline / PySurfaceConverter.RunBatch "
+                                   f"NV12->{args.dst} {W}x{H}, BT.709 limited range, "
+                                   f"{F} frames/GPU per step (BASELINE configs[4] geometry)",
+                       "frames_per_gpu": F, "global_batch": F * world,
+                       "bytes_per_frame": bytes_per_frame,
+                       "parallelism": f"frame-sharded x{world}, RCCL broadcast of coefficients"},
+            "achieved_hbm_GBps_whole_job": round(bytes_per_frame * fps / 1e9, 1),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBPS, 4),
+                         "traffic": None, "kernel": "k_nv12_rgb8",
+                         "avg_kernel_ms": round(avg_kernel_ms, 4),
+                         "min_kernel_ms": round(float(np.min(kernel_ms)), 4)},
+        }
+        if parity is not None:
+            out["parity_vs_oracle"] = parity
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(W, H, coeffs, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

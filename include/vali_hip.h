@@ -1,0 +1,176 @@
+/*
+ * vali_hip.h -- C ABI of libvali_hip.so, the MI355X (gfx950) surface-processing
+ * kernel library behind the python_vali Surface/Task API.
+ *
+ * This header is the drop-in boundary of the hot path.  In the reference the
+ * same boundary is the table of dlsym'd NVIDIA NPP entry points
+ * (reference: src/TC/inc/LibNpp.hpp:35-198, loader src/TC/src/LibNpp.cpp:20-51)
+ * plus the two first-party launchers UD_NV12 / UD_NV12_HBD
+ * (reference: src/TC/inc/ResizeUtils.hpp:30-50) and the CUDA driver calls of
+ * src/TC/inc/LibCuda.hpp.  Conventions are the NPP ones:
+ *   - raw device pointers + byte pitches, sizes in pixels, no allocation and no
+ *     ownership transfer inside an operator;
+ *   - every operator is asynchronous on `stream` (a hipStream_t passed as void*);
+ *   - return 0 on success, a negative VALI_ERR_* otherwise; the text of the last
+ *     failure on the calling thread is vali_last_error().
+ * No torch / pybind11 / C++ types appear in any signature.
+ */
+#ifndef VALI_HIP_H
+#define VALI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VALI_API __attribute__((visibility("default")))
+
+/* ---- status codes ------------------------------------------------------- */
+#define VALI_OK 0
+#define VALI_ERR_INVALID_ARG (-1) /* null pointer, bad size, bad enum value      */
+#define VALI_ERR_UNSUPPORTED (-2) /* format pair / parameter combination absent  */
+#define VALI_ERR_RUNTIME (-3)     /* a HIP runtime call failed                   */
+#define VALI_ERR_NO_DEVICE (-4)   /* no usable GPU                               */
+
+/* ---- pixel formats: numbering identical to the reference's Pixel_Format
+ *      (reference: src/TC/inc/MemoryInterfaces.hpp:29-46) ------------------- */
+enum vali_pixel_format {
+  VALI_FMT_UNDEFINED = 0,
+  VALI_FMT_Y = 1,
+  VALI_FMT_RGB = 2,
+  VALI_FMT_NV12 = 3,
+  VALI_FMT_YUV420 = 4,
+  VALI_FMT_RGB_PLANAR = 5,
+  VALI_FMT_BGR = 6,
+  VALI_FMT_YUV444 = 7,
+  VALI_FMT_RGB_32F = 8,
+  VALI_FMT_RGB_32F_PLANAR = 9,
+  VALI_FMT_YUV422 = 10,
+  VALI_FMT_P10 = 11,
+  VALI_FMT_P12 = 12,
+  VALI_FMT_YUV444_10BIT = 13,
+  VALI_FMT_YUV420_10BIT = 14,
+  VALI_FMT_GRAY12 = 15
+};
+
+typedef void* vali_stream_t; /* hipStream_t */
+typedef void* vali_event_t;  /* hipEvent_t  */
+
+/*
+ * A borrowed view of one surface: what the reference hands to NPP as
+ * pSrc[]/nSrcStep/oSizeROI (e.g. TaskConvertSurface.cpp:120-136).
+ * plane[c] is the device pointer of COMPONENT c, i.e. Surface::PixelPtr(c):
+ *   NV12/P10/P12   plane[0]=Y, plane[1]=interleaved UV (= Y + height*pitch)
+ *   YUV420/422/444 plane[0..2] = Y,U,V allocations
+ *   RGB/BGR/RGB_32F plane[0]    = packed pixels
+ *   RGB_PLANAR/RGB_32F_PLANAR plane[c] = base + c*height*pitch
+ *   Y              plane[0]
+ * width/height are in pixels of the full-resolution (luma) grid.
+ */
+typedef struct vali_surface {
+  void* plane[3];
+  int32_t pitch[3]; /* bytes */
+  int32_t width;
+  int32_t height;
+  int32_t format; /* enum vali_pixel_format */
+} vali_surface;
+
+/*
+ * YUV -> RGB colour matrix.  One instance per NPP colour variant the reference
+ * selects between in nv12_rgb / yuv420_rgb / yuv444_rgb
+ * (reference: src/TC/src/TaskConvertSurface.cpp:128-149, 271-292, 360-383).
+ *   Yf = cy * (Y - y0);  Uc = U - 128;  Vc = V - 128
+ *   R = Yf + crv*Vc ;  G = Yf + (cgu*Uc + cgv*Vc) ;  B = Yf + cbu*Uc
+ * exact operation order and rounding: oracle/vali_oracle.c (the specification).
+ * This 32-byte block is what the multi-GPU pipeline broadcasts over RCCL.
+ */
+typedef struct vali_csc {
+  float y0, cy, crv, cgu, cgv, cbu;
+  float reserved[2];
+} vali_csc;
+
+/* ---- runtime: replaces the LibCuda dlsym table
+ *      (reference: src/TC/inc/LibCuda.hpp, src/TC/src/CudaUtils.cpp) --------- */
+
+VALI_API const char* vali_last_error(void);
+VALI_API const char* vali_version(void);
+
+/* cuDeviceGetCount (CudaUtils.cpp:185-205) */
+VALI_API int vali_device_count(int* count);
+/* device of a device pointer: GetDeviceIdByDptr (CudaUtils.cpp:150-163) */
+VALI_API int vali_ptr_device(const void* dptr, int* device);
+
+/* one non-blocking stream per call: cuStreamCreate(CU_STREAM_NON_BLOCKING)
+ * (CudaUtils.cpp:222-238) */
+VALI_API int vali_stream_create(int device, vali_stream_t* stream);
+VALI_API int vali_stream_destroy(int device, vali_stream_t stream);
+VALI_API int vali_stream_sync(int device, vali_stream_t stream);
+
+/* CudaStreamEvent (CudaUtils.cpp:35-68); timing enabled so bench.py can use them */
+VALI_API int vali_event_create(int device, vali_event_t* event);
+VALI_API int vali_event_destroy(int device, vali_event_t event);
+VALI_API int vali_event_record(int device, vali_event_t event, vali_stream_t stream);
+VALI_API int vali_event_sync(int device, vali_event_t event);
+VALI_API int vali_event_elapsed_ms(vali_event_t start, vali_event_t stop, float* ms);
+
+/* cuMemAllocPitch / cuMemAlloc / cuMemFree (SurfacePlane.cpp:186-213).
+ * Pitch policy: width_bytes rounded up to 256 B, so every row starts on two
+ * 128-byte lines and 16-byte vector access is always legal. */
+VALI_API int vali_mem_alloc_pitch(int device, size_t width_bytes, size_t height,
+                                  void** dptr, size_t* pitch);
+VALI_API int vali_mem_alloc(int device, size_t bytes, void** dptr);
+VALI_API int vali_mem_free(int device, void* dptr);
+
+/* cuMemcpy2DAsync (TaskCudaUploadFrame.cpp:54-72, TaskCudaDownloadSurface.cpp:54-72,
+ * MemoryInterfaces.cpp:413-431).  kind: 0 = host->device, 1 = device->host,
+ * 2 = device->device. */
+VALI_API int vali_memcpy2d_async(int device, void* dst, size_t dst_pitch,
+                                 const void* src, size_t src_pitch,
+                                 size_t width_bytes, size_t height, int kind,
+                                 vali_stream_t stream);
+VALI_API int vali_memset2d_async(int device, void* dst, size_t dst_pitch, int value,
+                                 size_t width_bytes, size_t height,
+                                 vali_stream_t stream);
+
+/* ---- colour conversion: replaces the NPP nppicc entry points ---------------- */
+
+/*
+ * NV12 -> RGB / BGR (packed u8), RGB_PLANAR (u8), RGB_32F / RGB_32F_PLANAR
+ * (f32 = value/255 of the rounded u8 result, i.e. the fused form of the
+ * reference's NV12->RGB->RGB_32F(->PLANAR) chain).
+ * Replaces nppiNV12ToRGB_709HDTV_8u_P2C3R_Ctx, nppiNV12ToRGB_709CSC_8u_P2C3R_Ctx,
+ * nppiNV12ToRGB_8u_P2C3R_Ctx and their BGR twins
+ * (reference call sites: TaskConvertSurface.cpp:61-156; LibNpp.hpp table).
+ * dst->format selects the output layout; src->format must be VALI_FMT_NV12.
+ */
+VALI_API int vali_nv12_to_rgb(const vali_surface* src, const vali_surface* dst,
+                              const vali_csc* csc, vali_stream_t stream);
+
+/*
+ * Batched form: ONE launch over n independent frames of identical geometry.
+ * d_src / d_dst are DEVICE arrays of n vali_surface descriptors (upload them
+ * once with vali_memcpy2d_async or hipMemcpy); width/height/dst_format restate
+ * the common geometry for grid sizing.  Semantics per frame are exactly those
+ * of vali_nv12_to_rgb.  Precedent for the list-in / one-sync idiom:
+ * reference src/python_vali/src/PyNvJpegEncoder.cpp:31-81.
+ */
+VALI_API int vali_nv12_to_rgb_batch(const vali_surface* d_src,
+                                    const vali_surface* d_dst, int n, int width,
+                                    int height, int dst_format, const vali_csc* csc,
+                                    vali_stream_t stream);
+
+/* ---- diagnostics (used by tests only) --------------------------------------- */
+
+/* out[i] = float->u8 quantiser of the colour kernels applied to in[i]. */
+VALI_API int vali_debug_quantize_u8(const float* d_in, uint8_t* d_out, int n,
+                                    vali_stream_t stream);
+/* same with the instruction-independent formulation (rint, clamp, convert). */
+VALI_API int vali_debug_quantize_u8_portable(const float* d_in, uint8_t* d_out, int n,
+                                             vali_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VALI_HIP_H */

@@ -1,0 +1,141 @@
+"""ctypes front-end of the C oracle (oracle/vali_oracle.c) with numpy in/out.
+
+TEST INFRASTRUCTURE ONLY -- may be imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py, never by vali_amd.  Every function operates on HOST arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+LIB = HERE / "libvali_oracle.so"
+
+FMT = dict(Y=1, RGB=2, NV12=3, YUV420=4, RGB_PLANAR=5, BGR=6, YUV444=7, RGB_32F=8,
+           RGB_32F_PLANAR=9, YUV422=10, P10=11, P12=12, YUV444_10bit=13, YUV420_10bit=14)
+
+CSC_YUV, CSC_709CSC, CSC_709HDTV, CSC_YCBCR = 0, 1, 2, 3
+
+
+class Surface(C.Structure):
+    _fields_ = [("plane", C.c_void_p * 3), ("pitch", C.c_int32 * 3), ("width", C.c_int32),
+                ("height", C.c_int32), ("format", C.c_int32)]
+
+
+class Csc(C.Structure):
+    _fields_ = [("y0", C.c_float), ("cy", C.c_float), ("crv", C.c_float), ("cgu", C.c_float),
+                ("cgv", C.c_float), ("cbu", C.c_float), ("reserved", C.c_float * 2)]
+
+    def astuple(self):
+        return (self.y0, self.cy, self.crv, self.cgu, self.cgv, self.cbu)
+
+
+def build(force: bool = False) -> Path:
+    src = HERE / "vali_oracle.c"
+    hdr = HERE / "vali_oracle.h"
+    if force or not LIB.exists() or LIB.stat().st_mtime < max(src.stat().st_mtime,
+                                                             hdr.stat().st_mtime):
+        subprocess.run(["make", "-C", str(HERE), "-s", "libvali_oracle.so"], check=True)
+    return LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(str(LIB))
+        _lib.vali_oracle_q_u8.restype = C.c_uint8
+        _lib.vali_oracle_q_u8.argtypes = [C.c_float]
+    return _lib
+
+
+def csc(variant: int) -> Csc:
+    k = Csc()
+    rc = lib().vali_oracle_csc(variant, C.byref(k))
+    if rc:
+        raise ValueError(f"unknown csc variant {variant}")
+    return k
+
+
+def csc_from_tuple(t) -> Csc:
+    k = Csc()
+    k.y0, k.cy, k.crv, k.cgu, k.cgv, k.cbu = t
+    return k
+
+
+def q_u8(values) -> np.ndarray:
+    v = np.asarray(values, dtype=np.float32).ravel()
+    f = lib().vali_oracle_q_u8
+    return np.array([f(float(x)) for x in v], dtype=np.uint8)
+
+
+def _ptr(a: np.ndarray, byte_offset: int = 0) -> int:
+    return a.ctypes.data + byte_offset
+
+
+def surf_nv12(a: np.ndarray, width: int, height: int) -> Surface:
+    """a: (height*3/2, pitch) uint8 array holding Y rows then interleaved UV rows."""
+    assert a.dtype == np.uint8 and a.ndim == 2 and a.flags.c_contiguous
+    s = Surface()
+    pitch = a.strides[0]
+    s.plane[0] = _ptr(a)
+    s.plane[1] = _ptr(a, height * pitch)
+    s.pitch[0] = s.pitch[1] = pitch
+    s.width, s.height, s.format = width, height, FMT["NV12"]
+    return s
+
+
+def surf_packed3(a: np.ndarray, width: int, height: int, fmt: str) -> Surface:
+    assert a.ndim == 2 and a.flags.c_contiguous
+    s = Surface()
+    s.plane[0] = _ptr(a)
+    s.pitch[0] = a.strides[0]
+    s.width, s.height, s.format = width, height, FMT[fmt]
+    return s
+
+
+def surf_planar3(a: np.ndarray, width: int, height: int, fmt: str) -> Surface:
+    """a: (3*height, pitch_elems) stacked planes in one allocation."""
+    assert a.ndim == 2 and a.flags.c_contiguous
+    s = Surface()
+    pitch = a.strides[0]
+    for c in range(3):
+        s.plane[c] = _ptr(a, c * height * pitch)
+        s.pitch[c] = pitch
+    s.width, s.height, s.format = width, height, FMT[fmt]
+    return s
+
+
+def nv12_to_rgb(nv12: np.ndarray, width: int, height: int, k: Csc, dst_fmt: str = "RGB"
+                ) -> np.ndarray:
+    """nv12: (height*3/2, >=width) uint8.  Returns (H, 3W) packed or (3H, W) planar uint8."""
+    src = surf_nv12(nv12, width, height)
+    if dst_fmt == "RGB_PLANAR":
+        out = np.zeros((3 * height, width), np.uint8)
+        dst = surf_planar3(out, width, height, dst_fmt)
+    else:
+        out = np.zeros((height, 3 * width), np.uint8)
+        dst = surf_packed3(out, width, height, dst_fmt)
+    rc = lib().vali_oracle_nv12_to_rgb(C.byref(src), C.byref(dst), C.byref(k))
+    if rc:
+        raise RuntimeError(f"vali_oracle_nv12_to_rgb -> {rc}")
+    return out
+
+
+def nv12_to_rgb_mt(frames, width, height, k: Csc, threads: int, outs=None):
+    """frames: list of NV12 arrays; converts all with `threads` OpenMP threads (baseline)."""
+    n = len(frames)
+    outs = outs if outs is not None else [np.zeros((height, 3 * width), np.uint8) for _ in range(n)]
+    S = (Surface * n)(*[surf_nv12(f, width, height) for f in frames])
+    D = (Surface * n)(*[surf_packed3(o, width, height, "RGB") for o in outs])
+    rc = lib().vali_oracle_nv12_to_rgb_mt(S, D, n, C.byref(k), int(threads))
+    if rc:
+        raise RuntimeError(f"vali_oracle_nv12_to_rgb_mt -> {rc}")
+    return outs

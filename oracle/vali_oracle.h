@@ -1,0 +1,64 @@
+/*
+ * vali_oracle.h -- CPU restatement of the surface-processing hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under vali_amd/ may include, link, import or
+ * call this.  Allowed users: tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py (as the checker / the timed CPU baseline).
+ *
+ * Same descriptor types as include/vali_hip.h, but every pointer is a HOST
+ * pointer.  Each function cites the reference lines whose behaviour it restates.
+ *
+ * PARITY STATUS (see DESIGN.md "Oracle pinning"):
+ *   - the arithmetic of the reference's colour conversions, resize and rotate
+ *     lives in NVIDIA NPP (closed source, CUDA Toolkit >= 11.2, dlopen'd at
+ *     src/TC/src/LibNpp.cpp:20-51) and its CPU converter in FFmpeg n7.1
+ *     libswscale (src/CMakeLists.txt:25-40); neither is under /root/reference
+ *     and neither can be built here -> NPP-backed paths are "parity unpinned"
+ *     beyond the published NPP matrices and the reference tests' PSNR >= 42 dB;
+ *   - the UD (upsample+downscale) kernels are first-party reference code
+ *     (src/TC/src/ResizeUtils.cu:21-158) and are restated exactly, with the
+ *     output stage pinned against the reference's own golden files;
+ *   - k*90-degree rotation is pinned against the reference's JPEG etalons.
+ */
+#ifndef VALI_ORACLE_H
+#define VALI_ORACLE_H
+
+#include <stdint.h>
+
+#include "../include/vali_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* round-half-even + saturate: the quantiser of every colour kernel */
+VALI_API uint8_t vali_oracle_q_u8(float v);
+
+/*
+ * Colour-matrix table.  variant:
+ *   0 = NPP "YUV"      (nppiNV12ToRGB_8u_P2C3R, nppiYUV420ToRGB, nppiYUVToRGB;
+ *                       BT.601 + JPEG in the reference)
+ *   1 = NPP "709CSC"   (nppiNV12ToRGB_709CSC_8u_P2C3R; BT.709 + MPEG)
+ *   2 = NPP "709HDTV"  (nppiNV12ToRGB_709HDTV_8u_P2C3R; BT.709 + JPEG, the default)
+ *   3 = NPP "YCbCr"    (nppiYCbCr420ToRGB / nppiYCbCrToBGR; BT.601 + MPEG)
+ * Values are the constants published in NVIDIA's NPP documentation (recalled,
+ * see SURVEY.md Appendix A.3); selection logic restates
+ * reference src/TC/src/TaskConvertSurface.cpp:128-149.
+ */
+VALI_API int vali_oracle_csc(int variant, vali_csc* out);
+
+/* NV12 -> RGB/BGR/RGB_PLANAR u8.  dst->format picks the layout.
+ * Restates nv12_rgb / nv12_bgr (TaskConvertSurface.cpp:61-156) with the NPP
+ * per-pixel model: nearest chroma (one UV sample per 2x2 luma block). */
+VALI_API int vali_oracle_nv12_to_rgb(const vali_surface* src, const vali_surface* dst,
+                                     const vali_csc* csc);
+
+/* same conversion over n frames using `threads` OpenMP threads (frames are
+ * independent): the multi-core CPU baseline of bench.py */
+VALI_API int vali_oracle_nv12_to_rgb_mt(const vali_surface* src, const vali_surface* dst,
+                                        int n, const vali_csc* csc, int threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

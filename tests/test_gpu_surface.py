@@ -1,0 +1,79 @@
+"""Surface / SurfacePlane behaviour on the device.
+
+Mirrors reference tests/test_PySurface.py (:77-96 plane DLPack, :137-166 surface DLPack,
+:168-197 from_dlpack, :293-346 Make for all formats) and tests/test_GpuMem.py:58-62."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ALL = ["Y", "RGB", "NV12", "YUV420", "RGB_PLANAR", "BGR", "YUV444", "YUV444_10bit",
+       "YUV420_10bit", "RGB_32F", "RGB_32F_PLANAR", "YUV422", "P10", "P12"]
+ONE_PLANE = {"Y", "RGB", "BGR", "RGB_32F", "NV12", "P10", "P12", "RGB_PLANAR", "RGB_32F_PLANAR"}
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_surface_make_all_formats(vali, gpu, name):
+    fmt = vali.PixelFormat[name]
+    s = vali.Surface.Make(fmt, 1920, 1080, gpu)
+    assert (s.Width, s.Height, s.Format) == (1920, 1080, fmt)
+    assert s.HostSize > 0 and not s.IsEmpty and s.IsOwnMemory
+    assert s.NumPlanes == (1 if name in ONE_PLANE else 3)
+    for p in s.Planes:                                   # test_GpuMem.py:58-62
+        assert p.GpuMem == p.__cuda_array_interface__["data"][0]
+        assert p.Pitch >= p.Width * p.ElemSize and p.Pitch % 256 == 0
+
+
+def test_upload_download_roundtrip(vali, gpu):
+    for name in ("NV12", "YUV420", "RGB", "RGB_32F_PLANAR", "P10"):
+        s = vali.Surface.Make(vali.PixelFormat[name], 130, 66, gpu)
+        src = np.random.default_rng(1).integers(0, 256, s.HostSize, dtype=np.uint8)
+        assert vali.PyFrameUploader(gpu).Run(src, s) == (True, vali.TaskExecInfo.SUCCESS)
+        dst = np.zeros_like(src)
+        assert vali.PySurfaceDownloader(gpu).Run(s, dst) == (True, vali.TaskExecInfo.SUCCESS)
+        assert np.array_equal(src, dst)
+        ok, info = vali.PyFrameUploader(gpu).Run(src[:-1], s)
+        assert not ok and info == vali.TaskExecInfo.SRC_DST_SIZE_MISMATCH
+        c = s.Clone()
+        dst2 = np.zeros_like(src)
+        assert vali.PySurfaceDownloader(gpu).Run(c, dst2)[0] and np.array_equal(src, dst2)
+
+
+def test_dlpack_export_plane_and_surface(vali, gpu):
+    import torch
+
+    w, h = 200, 100
+    s = vali.Surface.Make(vali.RGB, w, h, gpu)
+    src = np.random.default_rng(2).integers(0, 256, s.HostSize, dtype=np.uint8)
+    assert vali.PyFrameUploader(gpu).Run(src, s)[0]
+    t_plane = torch.from_dlpack(s.Planes[0])
+    assert tuple(t_plane.shape) == (h, 3 * w) and t_plane.shape[0] * t_plane.shape[1] == s.HostSize
+    assert np.array_equal(t_plane.cpu().numpy().ravel(), src)
+    t = torch.from_dlpack(s)
+    assert tuple(t.shape) == (h, w, 3) and t.is_cuda
+    assert np.array_equal(t.cpu().numpy().ravel(), src)
+    assert s.__dlpack_device__() == (10, gpu)            # kDLROCM
+    p = vali.Surface.Make(vali.RGB_32F_PLANAR, w, h, gpu)
+    tp = torch.from_dlpack(p)
+    assert tuple(tp.shape) == (3, h, w) and tp.dtype == torch.float32
+    with pytest.raises(RuntimeError):
+        vali.Surface.Make(vali.YUV420, w, h, gpu).__dlpack__()
+
+
+def test_surface_from_tensor(vali, gpu):
+    import torch
+
+    w, h = 96, 40
+    rgb = np.random.default_rng(3).integers(0, 256, (h, w * 3), dtype=np.uint8)
+    t = torch.from_numpy(rgb).to("cuda")
+    s = vali.Surface.from_dlpack(torch.utils.dlpack.to_dlpack(t))
+    assert not s.IsEmpty and not s.IsOwnMemory and s.Format == vali.RGB
+    assert (s.Width, s.Height, s.HostSize) == (w, h, rgb.size)
+    out = np.zeros(s.HostSize, np.uint8)
+    torch.cuda.synchronize()
+    assert vali.PySurfaceDownloader(gpu).Run(s, out)[0]
+    assert np.array_equal(out, rgb.ravel())
+    with pytest.raises(RuntimeError):
+        s.__dlpack_device__()                            # PySurface.cpp:389-393
+    s2 = vali.Surface.from_cai(t, vali.Y)
+    assert (s2.Width, s2.Height) == (w * 3, h)

@@ -1,0 +1,97 @@
+"""Host-side API behaviour that needs no GPU: enums, format table, dispatch tables."""
+import pytest
+
+import vali_amd as vali
+from vali_amd.surface import FORMATS
+from vali_amd import tasks
+
+
+def test_enum_values_match_reference():
+    # reference: src/TC/inc/MemoryInterfaces.hpp:29-58, TC_CORE.hpp:38-52
+    P = vali.PixelFormat
+    assert [P.UNDEFINED, P.Y, P.RGB, P.NV12, P.YUV420, P.RGB_PLANAR, P.BGR, P.YUV444, P.RGB_32F,
+            P.RGB_32F_PLANAR, P.YUV422, P.P10, P.P12, P.YUV444_10bit, P.YUV420_10bit,
+            P.GRAY12] == list(range(16))
+    T = vali.TaskExecInfo
+    assert (T.SUCCESS, T.FAIL, T.INVALID_INPUT, T.UNSUPPORTED_FMT_CONV_PARAMS, T.NOT_SUPPORTED,
+            T.SRC_DST_SIZE_MISMATCH, T.SRC_DST_FMT_MISMATCH) == (0, 1, 5, 6, 7, 9, 10)
+    assert (vali.ColorSpace.BT_601, vali.ColorSpace.BT_709, vali.ColorSpace.UNSPEC) == (0, 1, 2)
+    assert (vali.ColorRange.MPEG, vali.ColorRange.JPEG, vali.ColorRange.UDEF) == (0, 1, 2)
+
+
+def test_export_values_like_pybind11():
+    assert vali.NV12 is vali.PixelFormat.NV12
+    assert vali.BT_709 is vali.ColorSpace.BT_709
+    assert vali.kDLROCM == 10
+    import python_vali
+
+    assert python_vali.PySurfaceConverter is vali.PySurfaceConverter
+
+
+def test_cc_ctx_defaults():
+    c = vali.ColorspaceConversionContext()
+    assert c.color_space == vali.ColorSpace.UNSPEC and c.color_range == vali.ColorRange.UDEF
+    c = vali.ColorspaceConversionContext(vali.ColorSpace.BT_601, vali.ColorRange.MPEG)
+    assert (c.color_space, c.color_range) == (0, 0)
+
+
+@pytest.mark.parametrize("fmt,planes,host_size", [
+    # reference: tests/test_PySurface.py:293-346 + SURVEY 2.3; W=1920,H=1080
+    ("Y", 1, 1920 * 1080), ("NV12", 1, 1920 * 1620), ("P10", 1, 1920 * 1620 * 2),
+    ("P12", 1, 1920 * 1620 * 2), ("YUV420", 3, 1920 * 1620), ("YUV420_10bit", 3, 1920 * 1620 * 2),
+    ("YUV422", 3, 1920 * 1080 * 2), ("YUV444", 3, 1920 * 1080 * 3),
+    ("YUV444_10bit", 3, 1920 * 1080 * 6), ("RGB", 1, 1920 * 1080 * 3), ("BGR", 1, 1920 * 1080 * 3),
+    ("RGB_32F", 1, 1920 * 1080 * 12), ("RGB_PLANAR", 1, 1920 * 1080 * 3),
+    ("RGB_32F_PLANAR", 1, 1920 * 1080 * 12)])
+def test_format_table_geometry(fmt, planes, host_size):
+    spec = FORMATS[vali.PixelFormat[fmt]]
+    geo = spec.plane_geometry(1920, 1080)
+    assert spec.num_planes == planes == len(geo)
+    assert sum(w * h * spec.elem_size for w, h in geo) == host_size
+
+
+def test_nv12_colour_variant_selection():
+    # reference: TaskConvertSurface.cpp:117-149
+    C, S, R = vali.ColorspaceConversionContext, vali.ColorSpace, vali.ColorRange
+    assert tasks._nv12_variant(None) == tasks.CSC_NPP_709HDTV
+    assert tasks._nv12_variant(C(S.BT_709, R.JPEG)) == tasks.CSC_NPP_709HDTV
+    assert tasks._nv12_variant(C(S.BT_709, R.MPEG)) == tasks.CSC_NPP_709CSC
+    assert tasks._nv12_variant(C(S.BT_709, R.UDEF)) == tasks.CSC_NPP_709CSC
+    assert tasks._nv12_variant(C(S.BT_601, R.JPEG)) == tasks.CSC_NPP_YUV
+    assert tasks._nv12_variant(C(S.BT_601, R.MPEG)) is None
+    assert tasks._nv12_variant(C(S.UNSPEC, R.JPEG)) is None
+
+
+def test_product_tables_match_oracle_tables(oracle):
+    """The product's coefficient table (vali_amd/tasks.py) and the oracle's are written
+    independently; they must agree to the last float bit."""
+    import numpy as np
+
+    for variant, coeffs in ((oracle.CSC_YUV, tasks.CSC_NPP_YUV),
+                            (oracle.CSC_709CSC, tasks.CSC_NPP_709CSC),
+                            (oracle.CSC_709HDTV, tasks.CSC_NPP_709HDTV),
+                            (oracle.CSC_YCBCR, tasks.CSC_NPP_YCBCR)):
+        assert np.array_equal(np.array(oracle.csc(variant).astuple(), np.float32),
+                              np.array(coeffs, np.float32))
+        assert tasks._csc(coeffs).astuple() == oracle.csc(variant).astuple()
+
+
+def test_conversions_list_contains_reference_pairs():
+    convs = vali.PySurfaceConverter.Conversions()
+    assert (vali.NV12, vali.RGB) in convs and (vali.NV12, vali.BGR) in convs
+
+
+def test_product_does_not_import_oracle():
+    """No file under vali_amd/ may reference the oracle (CPU restatement)."""
+    from pathlib import Path
+
+    root = Path(vali.__file__).resolve().parent
+    offenders = []
+    for p in list(root.rglob("*.py")) + list(root.rglob("*.hip")) + list(root.rglob("*.cpp")) + \
+            list(root.rglob("*.hpp")):
+        if p.name == "build.py":
+            continue  # builds the oracle .so, does not use it
+        text = p.read_text()
+        if "import oracle" in text or "from oracle" in text or "vali_oracle.h" in text:
+            offenders.append(str(p))
+    assert not offenders

@@ -1,0 +1,18 @@
+"""vali_amd -- MI355X-native surface processing behind the python_vali API.
+
+`import vali_amd as vali` (or `import python_vali as vali`) gives the reference's
+names: Surface, SurfacePlane, PixelFormat, PySurfaceConverter, PyFrameUploader, ...
+(reference: src/python_vali/__init__.py:14-16 re-exporting _python_vali).
+"""
+from ._native import shim as _shim  # noqa: F401  (fails loudly if the HIP library is absent)
+from .enums import (ColorRange, ColorSpace, ColorspaceConversionContext, DLDeviceType,
+                    PixelFormat, TaskExecDetails, TaskExecInfo, TaskExecStatus, export_values)
+from .runtime import CudaStreamEvent, GetNumGpus, HipResMgr
+from .surface import Surface, SurfacePlane
+from .tasks import PySurfaceConverter, SurfaceBatch
+from .pipeline import BatchedFramePipeline, broadcast_coefficients, shard_frames
+from .transfer import PyFrameUploader, PySurfaceDownloader
+
+export_values(globals())
+
+__version__ = "0.1.0"

@@ -1,0 +1,64 @@
+// Host-side helpers shared by every translation unit of libvali_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/vali_hip.h"
+
+namespace vali {
+
+// Text of the last failure on this thread (returned by vali_last_error()).
+std::string& last_error();
+
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// Make `device` current for the scope; restores the previous one on exit.
+// One process per GPU is the intended deployment, so this is normally a no-op
+// pair of hipGetDevice calls.
+class DeviceScope {
+public:
+  explicit DeviceScope(int device);
+  ~DeviceScope();
+  bool ok() const { return m_ok; }
+
+private:
+  int m_prev = -1;
+  bool m_switched = false;
+  bool m_ok = true;
+};
+
+// Device a launch on `stream` must be issued from (the stream's device, or the
+// current device for the null stream).
+int stream_device(hipStream_t stream);
+
+inline hipStream_t as_stream(vali_stream_t s) { return (hipStream_t)s; }
+
+inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+} // namespace vali
+
+#define VALI_HIP_CHECK(expr)                                                   \
+  do {                                                                         \
+    hipError_t _e = (expr);                                                    \
+    if (_e != hipSuccess)                                                      \
+      return ::vali::fail(VALI_ERR_RUNTIME, "%s failed: %s (%s:%d)", #expr,    \
+                          hipGetErrorString(_e), __FILE__, __LINE__);          \
+  } while (0)
+
+#define VALI_REQUIRE(cond, msg)                                                \
+  do {                                                                         \
+    if (!(cond))                                                               \
+      return ::vali::fail(VALI_ERR_INVALID_ARG, "%s: %s", __func__, msg);      \
+  } while (0)
+
+// Kernel launches cannot fail asynchronously here in a way hipGetLastError sees
+// immediately, but a bad configuration does.
+#define VALI_LAUNCH_CHECK()                                                    \
+  do {                                                                         \
+    hipError_t _e = hipGetLastError();                                         \
+    if (_e != hipSuccess)                                                      \
+      return ::vali::fail(VALI_ERR_RUNTIME, "%s: kernel launch failed: %s",    \
+                          __func__, hipGetErrorString(_e));                    \
+  } while (0)

@@ -1,0 +1,342 @@
+// NV12 -> RGB / BGR (packed u8) and RGB_PLANAR (u8): the headline kernel.
+//
+// Replaces nppiNV12ToRGB_709HDTV/709CSC/(601)_8u_P2C3R_Ctx and the BGR twins the
+// reference calls from nv12_rgb / nv12_bgr
+// (reference: src/TC/src/TaskConvertSurface.cpp:61-156), plus the fused
+// NV12 -> RGB_PLANAR pair BASELINE config 2 names (the reference needs the
+// two-step chain NV12->RGB->RGB_PLANAR, TaskConvertSurface.cpp:737-766).
+//
+// Algorithmic traffic per pixel: 1.5 B read (Y + half a UV pair), 3 B written.
+// Work decomposition: one lane = 16 px x 2 rows (the 2x2 chroma footprint of
+// 8 UV pairs): loads 16 B Y(row0) + 16 B Y(row1) + 16 B UV, stores 2 x 48 B.
+// One 256-thread workgroup = one row pair x 4096 px; grid = (x segments,
+// row pairs, frames).  Packed stores go through a per-wave LDS strip so each
+// store instruction writes 1 KiB contiguous (dev_util.hpp).
+// Arithmetic (bit-exact with oracle/vali_oracle.c: vali_oracle_nv12_to_rgb):
+//   Yf = cy*(Y-y0); Uc=U-128; Vc=V-128
+//   R = Yf + crv*Vc ; G = Yf + fma(cgu,Uc,cgv*Vc) ; B = Yf + cbu*Uc
+//   u8 = saturate(round-half-even(.)).   Chroma siting: nearest (2x2 block).
+#include "common.hpp"
+#include "dev_util.hpp"
+
+#include <stdlib.h>
+
+namespace vali {
+
+enum : int { LAYOUT_RGB = 0, LAYOUT_BGR = 1, LAYOUT_PLANAR = 2 };
+
+struct Nv12RgbArgs {
+  const vali_surface* d_src; // device descriptor arrays (batch) or nullptr
+  const vali_surface* d_dst;
+  vali_surface src;          // by-value descriptors (single frame)
+  vali_surface dst;
+  vali_csc csc;
+  int groups;                // ceil(width / 16)
+};
+
+struct ChromaTerm {
+  float rv, guv, bu;
+};
+
+__device__ __forceinline__ ChromaTerm chroma_term(float u, float v, const vali_csc& k) {
+  const float uc = u - 128.0f, vc = v - 128.0f;
+  ChromaTerm t;
+  t.rv = k.crv * vc;
+  t.guv = __builtin_fmaf(k.cgu, uc, k.cgv * vc);
+  t.bu = k.cbu * uc;
+  return t;
+}
+
+__device__ __forceinline__ float luma_term(float y, const vali_csc& k) {
+  return k.cy * (y - k.y0);
+}
+
+// 4 pixels of one row: y4 = 4 luma bytes, chroma terms c01 (px 0,1) / c23 (px 2,3).
+// Packed: writes dwords o[0..2] of the 12-byte group.  Planar: r/g/b dwords.
+template <int LAYOUT>
+__device__ __forceinline__ void emit4(u32 y4, const ChromaTerm& c01, const ChromaTerm& c23,
+                                      const vali_csc& k, u32* o3, u32& pr, u32& pg,
+                                      u32& pb) {
+  const float y0 = luma_term(ubyte_f32<0>(y4), k), y1 = luma_term(ubyte_f32<1>(y4), k),
+              y2 = luma_term(ubyte_f32<2>(y4), k), y3 = luma_term(ubyte_f32<3>(y4), k);
+  const float r0 = y0 + c01.rv, g0 = y0 + c01.guv, b0 = y0 + c01.bu;
+  const float r1 = y1 + c01.rv, g1 = y1 + c01.guv, b1 = y1 + c01.bu;
+  const float r2 = y2 + c23.rv, g2 = y2 + c23.guv, b2 = y2 + c23.bu;
+  const float r3 = y3 + c23.rv, g3 = y3 + c23.guv, b3 = y3 + c23.bu;
+  if constexpr (LAYOUT == LAYOUT_PLANAR) {
+    u32 r = 0, g = 0, b = 0;
+    r = pack_u8<0>(r0, r); r = pack_u8<1>(r1, r); r = pack_u8<2>(r2, r); r = pack_u8<3>(r3, r);
+    g = pack_u8<0>(g0, g); g = pack_u8<1>(g1, g); g = pack_u8<2>(g2, g); g = pack_u8<3>(g3, g);
+    b = pack_u8<0>(b0, b); b = pack_u8<1>(b1, b); b = pack_u8<2>(b2, b); b = pack_u8<3>(b3, b);
+    pr = r; pg = g; pb = b;
+  } else {
+    // first/last channel in memory order
+    const float f0 = LAYOUT == LAYOUT_RGB ? r0 : b0, l0 = LAYOUT == LAYOUT_RGB ? b0 : r0;
+    const float f1 = LAYOUT == LAYOUT_RGB ? r1 : b1, l1 = LAYOUT == LAYOUT_RGB ? b1 : r1;
+    const float f2 = LAYOUT == LAYOUT_RGB ? r2 : b2, l2 = LAYOUT == LAYOUT_RGB ? b2 : r2;
+    const float f3 = LAYOUT == LAYOUT_RGB ? r3 : b3, l3 = LAYOUT == LAYOUT_RGB ? b3 : r3;
+    u32 d0 = 0, d1 = 0, d2 = 0;
+    d0 = pack_u8<0>(f0, d0); d0 = pack_u8<1>(g0, d0); d0 = pack_u8<2>(l0, d0); d0 = pack_u8<3>(f1, d0);
+    d1 = pack_u8<0>(g1, d1); d1 = pack_u8<1>(l1, d1); d1 = pack_u8<2>(f2, d1); d1 = pack_u8<3>(g2, d1);
+    d2 = pack_u8<0>(l2, d2); d2 = pack_u8<1>(f3, d2); d2 = pack_u8<2>(g3, d2); d2 = pack_u8<3>(l3, d2);
+    o3[0] = d0; o3[1] = d1; o3[2] = d2;
+  }
+}
+
+// STAGED: packed rows leave through the per-wave LDS strip (3 x 1 KiB contiguous per
+// wave and row); !STAGED: each lane stores its own 3 x 16 B at a 48 B lane stride
+// (kept as the measured alternative, see DESIGN.md "store path A/B").
+template <int LAYOUT, bool STAGED>
+__global__ void __launch_bounds__(kBlock) k_nv12_rgb8(const Nv12RgbArgs a) {
+  __shared__ PackedStrip strips[(LAYOUT == LAYOUT_PLANAR || !STAGED) ? 1 : kWavesPerBlock];
+
+  const uint8_t* py;
+  const uint8_t* puv;
+  uint8_t* pd0;
+  uint8_t* pd1;
+  uint8_t* pd2;
+  int sp_y, sp_uv, dp, W, H;
+  if (a.d_src) {
+    const vali_surface* s = a.d_src + blockIdx.z;
+    const vali_surface* d = a.d_dst + blockIdx.z;
+    py = (const uint8_t*)s->plane[0]; puv = (const uint8_t*)s->plane[1];
+    sp_y = s->pitch[0]; sp_uv = s->pitch[1]; W = s->width; H = s->height;
+    pd0 = (uint8_t*)d->plane[0]; pd1 = (uint8_t*)d->plane[1]; pd2 = (uint8_t*)d->plane[2];
+    dp = d->pitch[0];
+  } else {
+    py = (const uint8_t*)a.src.plane[0]; puv = (const uint8_t*)a.src.plane[1];
+    sp_y = a.src.pitch[0]; sp_uv = a.src.pitch[1]; W = a.src.width; H = a.src.height;
+    pd0 = (uint8_t*)a.dst.plane[0]; pd1 = (uint8_t*)a.dst.plane[1]; pd2 = (uint8_t*)a.dst.plane[2];
+    dp = a.dst.pitch[0];
+  }
+  const vali_csc k = a.csc;
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const int wave_g0 = blockIdx.x * blockDim.x + wave * kWave; // first group of this wave
+  const int groups = (W + kLanePx - 1) / kLanePx;
+  if (wave_g0 >= groups)
+    return; // whole wave out of the row: nothing to cooperate on
+  const int g = wave_g0 + lane;
+  const int x0 = g * kLanePx;
+  const int row0 = blockIdx.y * 2;
+  const bool has_row1 = row0 + 1 < H;
+
+  // Uniform (per frame) fast-path test: full 16-px groups and 16-B aligned rows.
+  uintptr_t align_bits = (uintptr_t)py | (uintptr_t)puv | (uintptr_t)sp_y |
+                         (uintptr_t)sp_uv | (uintptr_t)pd0 | (uintptr_t)dp;
+  if constexpr (LAYOUT == LAYOUT_PLANAR)
+    align_bits |= (uintptr_t)pd1 | (uintptr_t)pd2;
+  const bool fast = ((W & (kLanePx - 1)) == 0) && ((align_bits & 15u) == 0);
+
+  if (fast) {
+    const bool lane_valid = g < groups;
+    u32 o0[12], o1[12];          // packed rows (or r[4] g[4] b[4] when planar)
+    if (lane_valid) {
+      const uint4 ya = *reinterpret_cast<const uint4*>(py + (size_t)row0 * sp_y + x0);
+      // odd height: the last pair re-reads row0 (always a valid address)
+      const uint4 yb =
+          *reinterpret_cast<const uint4*>(py + (size_t)(row0 + (has_row1 ? 1 : 0)) * sp_y + x0);
+      const uint4 uv = *reinterpret_cast<const uint4*>(puv + (size_t)blockIdx.y * sp_uv + x0);
+      const u32 yw0[4] = {ya.x, ya.y, ya.z, ya.w};
+      const u32 yw1[4] = {yb.x, yb.y, yb.z, yb.w};
+      const u32 uvw[4] = {uv.x, uv.y, uv.z, uv.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const ChromaTerm c01 = chroma_term(ubyte_f32<0>(uvw[j]), ubyte_f32<1>(uvw[j]), k);
+        const ChromaTerm c23 = chroma_term(ubyte_f32<2>(uvw[j]), ubyte_f32<3>(uvw[j]), k);
+        if constexpr (LAYOUT == LAYOUT_PLANAR) {
+          emit4<LAYOUT>(yw0[j], c01, c23, k, nullptr, o0[j], o0[4 + j], o0[8 + j]);
+          emit4<LAYOUT>(yw1[j], c01, c23, k, nullptr, o1[j], o1[4 + j], o1[8 + j]);
+        } else {
+          u32 dummy;
+          emit4<LAYOUT>(yw0[j], c01, c23, k, &o0[3 * j], dummy, dummy, dummy);
+          emit4<LAYOUT>(yw1[j], c01, c23, k, &o1[3 * j], dummy, dummy, dummy);
+        }
+      }
+    }
+    if constexpr (LAYOUT == LAYOUT_PLANAR) {
+      if (lane_valid) {
+        uint8_t* const planes[3] = {pd0, pd1, pd2};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          uint8_t* p = planes[c] + (size_t)row0 * dp + x0;
+          *reinterpret_cast<uint4*>(p) =
+              make_uint4(o0[4 * c], o0[4 * c + 1], o0[4 * c + 2], o0[4 * c + 3]);
+          if (has_row1)
+            *reinterpret_cast<uint4*>(p + dp) =
+                make_uint4(o1[4 * c], o1[4 * c + 1], o1[4 * c + 2], o1[4 * c + 3]);
+        }
+      }
+    } else if constexpr (!STAGED) {
+      if (lane_valid) {
+        uint4* p = reinterpret_cast<uint4*>(pd0 + (size_t)row0 * dp + (size_t)g * 48);
+        p[0] = make_uint4(o0[0], o0[1], o0[2], o0[3]);
+        p[1] = make_uint4(o0[4], o0[5], o0[6], o0[7]);
+        p[2] = make_uint4(o0[8], o0[9], o0[10], o0[11]);
+        if (has_row1) {
+          uint4* q = reinterpret_cast<uint4*>(pd0 + (size_t)(row0 + 1) * dp + (size_t)g * 48);
+          q[0] = make_uint4(o1[0], o1[1], o1[2], o1[3]);
+          q[1] = make_uint4(o1[4], o1[5], o1[6], o1[7]);
+          q[2] = make_uint4(o1[8], o1[9], o1[10], o1[11]);
+        }
+      }
+    } else {
+      PackedStrip& strip = strips[wave];
+      const int valid_lanes = min(kWave, groups - wave_g0);
+      const int valid_bytes = valid_lanes * 48;
+      uint8_t* rb = pd0 + (size_t)row0 * dp + (size_t)wave_g0 * 48;
+      strip_store_row(strip, lane, o0, lane_valid, rb, valid_bytes);
+      if (has_row1)
+        strip_store_row(strip, lane, o1, lane_valid, rb + dp, valid_bytes);
+    }
+    return;
+  }
+
+  // Generic path: any width / alignment, byte granular.  Same arithmetic.
+  if (g >= groups)
+    return;
+  for (int r = 0; r < 2; ++r) {
+    const int y = row0 + r;
+    if (y >= H)
+      break;
+    for (int p = 0; p < kLanePx; ++p) {
+      const int x = x0 + p;
+      if (x >= W)
+        break;
+      const float yv = (float)py[(size_t)y * sp_y + x];
+      const uint8_t* c = puv + (size_t)blockIdx.y * sp_uv + (x & ~1);
+      const ChromaTerm t = chroma_term((float)c[0], (float)c[1], k);
+      const float yf = luma_term(yv, k);
+      const uint8_t R = (uint8_t)quantize_u8(yf + t.rv), G = (uint8_t)quantize_u8(yf + t.guv),
+                    B = (uint8_t)quantize_u8(yf + t.bu);
+      if constexpr (LAYOUT == LAYOUT_PLANAR) {
+        pd0[(size_t)y * dp + x] = R;
+        pd1[(size_t)y * dp + x] = G;
+        pd2[(size_t)y * dp + x] = B;
+      } else {
+        uint8_t* q = pd0 + (size_t)y * dp + (size_t)x * 3;
+        q[0] = LAYOUT == LAYOUT_RGB ? R : B;
+        q[1] = G;
+        q[2] = LAYOUT == LAYOUT_RGB ? B : R;
+      }
+    }
+  }
+}
+
+static int launch_nv12_rgb(const Nv12RgbArgs& a, int width, int height, int n, int dst_format,
+                           hipStream_t stream) {
+  const int groups = (width + kLanePx - 1) / kLanePx;
+  // workgroup width: smallest multiple of a wave covering the row, capped at 256
+  int block = ((groups + kWave - 1) / kWave) * kWave;
+  if (block > kBlock)
+    block = kBlock;
+  const dim3 grid((groups + block - 1) / block, (height + 1) / 2, n);
+  // tuning knob for A/B measurements only (not part of the API)
+  static const bool direct = [] {
+    const char* e = getenv("VALI_NV12_DIRECT_STORE");
+    return e && e[0] == '1';
+  }();
+  switch (dst_format) {
+  case VALI_FMT_RGB:
+    if (direct)
+      hipLaunchKernelGGL((k_nv12_rgb8<LAYOUT_RGB, false>), grid, dim3(block), 0, stream, a);
+    else
+      hipLaunchKernelGGL((k_nv12_rgb8<LAYOUT_RGB, true>), grid, dim3(block), 0, stream, a);
+    break;
+  case VALI_FMT_BGR:
+    if (direct)
+      hipLaunchKernelGGL((k_nv12_rgb8<LAYOUT_BGR, false>), grid, dim3(block), 0, stream, a);
+    else
+      hipLaunchKernelGGL((k_nv12_rgb8<LAYOUT_BGR, true>), grid, dim3(block), 0, stream, a);
+    break;
+  case VALI_FMT_RGB_PLANAR:
+    hipLaunchKernelGGL((k_nv12_rgb8<LAYOUT_PLANAR, true>), grid, dim3(block), 0, stream, a);
+    break;
+  default:
+    return fail(VALI_ERR_UNSUPPORTED, "nv12_to_rgb: unsupported dst format %d", dst_format);
+  }
+  VALI_LAUNCH_CHECK();
+  return VALI_OK;
+}
+
+} // namespace vali
+
+using namespace vali;
+
+extern "C" {
+
+int vali_nv12_to_rgb(const vali_surface* src, const vali_surface* dst, const vali_csc* csc,
+                     vali_stream_t stream) {
+  VALI_REQUIRE(src && dst && csc, "null argument");
+  VALI_REQUIRE(src->format == VALI_FMT_NV12, "src must be NV12");
+  VALI_REQUIRE(src->width > 0 && src->height > 0, "empty src");
+  VALI_REQUIRE(src->width == dst->width && src->height == dst->height, "src/dst size mismatch");
+  VALI_REQUIRE(src->plane[0] && src->plane[1] && dst->plane[0], "null plane");
+  if (dst->format == VALI_FMT_RGB_PLANAR)
+    VALI_REQUIRE(dst->plane[1] && dst->plane[2], "null planar plane");
+  Nv12RgbArgs a = {};
+  a.src = *src;
+  a.dst = *dst;
+  a.csc = *csc;
+  hipStream_t s = as_stream(stream);
+  DeviceScope scope(stream_device(s));
+  return launch_nv12_rgb(a, src->width, src->height, 1, dst->format, s);
+}
+
+int vali_nv12_to_rgb_batch(const vali_surface* d_src, const vali_surface* d_dst, int n, int width,
+                           int height, int dst_format, const vali_csc* csc,
+                           vali_stream_t stream) {
+  VALI_REQUIRE(d_src && d_dst && csc, "null argument");
+  VALI_REQUIRE(width > 0 && height > 0, "empty geometry");
+  VALI_REQUIRE(n >= 0 && n <= 65535, "batch size out of range (0..65535)");
+  if (n == 0)
+    return VALI_OK;
+  Nv12RgbArgs a = {};
+  a.d_src = d_src;
+  a.d_dst = d_dst;
+  a.csc = *csc;
+  hipStream_t s = as_stream(stream);
+  DeviceScope scope(stream_device(s));
+  return launch_nv12_rgb(a, width, height, n, dst_format, s);
+}
+
+// ---- diagnostics ------------------------------------------------------------
+
+__global__ void k_debug_quantize(const float* in, uint8_t* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    out[i] = (uint8_t)quantize_u8(in[i]);
+}
+
+__global__ void k_debug_quantize_portable(const float* in, uint8_t* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    out[i] = (uint8_t)quantize_u8_portable(in[i]);
+}
+
+int vali_debug_quantize_u8(const float* d_in, uint8_t* d_out, int n, vali_stream_t stream) {
+  VALI_REQUIRE(d_in && d_out && n >= 0, "bad argument");
+  if (!n)
+    return VALI_OK;
+  hipStream_t s = as_stream(stream);
+  DeviceScope scope(stream_device(s));
+  hipLaunchKernelGGL(k_debug_quantize, dim3((n + 255) / 256), dim3(256), 0, s, d_in, d_out, n);
+  VALI_LAUNCH_CHECK();
+  return VALI_OK;
+}
+
+int vali_debug_quantize_u8_portable(const float* d_in, uint8_t* d_out, int n,
+                                    vali_stream_t stream) {
+  VALI_REQUIRE(d_in && d_out && n >= 0, "bad argument");
+  if (!n)
+    return VALI_OK;
+  hipStream_t s = as_stream(stream);
+  DeviceScope scope(stream_device(s));
+  hipLaunchKernelGGL(k_debug_quantize_portable, dim3((n + 255) / 256), dim3(256), 0, s, d_in,
+                     d_out, n);
+  VALI_LAUNCH_CHECK();
+  return VALI_OK;
+}
+
+} // extern "C"

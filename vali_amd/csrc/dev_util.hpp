@@ -1,0 +1,167 @@
+// Device-side building blocks shared by the colour/geometry kernels (gfx950).
+//
+// Conventions used by every kernel in this library:
+//  * a lane owns 16 horizontally adjacent pixels (one 16-byte luma vector), so
+//    every global access of a u8 plane is a dwordx4 and a full wave touches
+//    1 KiB contiguous per instruction;
+//  * packed 3-byte pixels are staged through a per-wave LDS strip so that the
+//    wave's 64 x 48 B = 3 KiB of a row leave (or enter) the CU as three fully
+//    contiguous 1 KiB dwordx4 instructions instead of 64 strided 16 B pieces;
+//  * no MFMA: these are HBM-bound per-pixel ops.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vali {
+
+typedef uint32_t u32;
+
+constexpr int kLanePx = 16;   // pixels per lane per row
+constexpr int kWave = 64;     // gfx950 wavefront
+constexpr int kBlock = 256;   // default workgroup
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+// byte i (0..3) of a dword as float: lowers to v_cvt_f32_ubyte{i}
+template <int I> __device__ __forceinline__ float ubyte_f32(u32 w) {
+  return (float)((w >> (8 * I)) & 0xffu);
+}
+
+template <int I> __device__ __forceinline__ u32 ubyte(u32 w) {
+  return (w >> (8 * I)) & 0xffu;
+}
+
+// The float -> u8 quantiser of every colour kernel: round to nearest even,
+// saturate to [0,255] (oracle: vali_q_u8 in oracle/vali_oracle.c).
+// v_cvt_pk_u8_f32 does exactly that in one instruction and also merges the
+// byte into `old`; tests/test_gpu_quantizer.py pins the instruction against
+// the portable form over a dense sweep of inputs.
+#ifndef VALI_USE_CVT_PK_U8
+#define VALI_USE_CVT_PK_U8 1
+#endif
+
+__device__ __forceinline__ u32 quantize_u8_portable(float v) {
+  float r = __builtin_rintf(v);
+  r = __builtin_fminf(__builtin_fmaxf(r, 0.0f), 255.0f);
+  return (u32)r;
+}
+
+template <int SEL> __device__ __forceinline__ u32 pack_u8(float v, u32 old) {
+#if VALI_USE_CVT_PK_U8
+  return __builtin_amdgcn_cvt_pk_u8_f32(v, SEL, old);
+#else
+  return old | (quantize_u8_portable(v) << (8 * SEL));
+#endif
+}
+
+__device__ __forceinline__ u32 quantize_u8(float v) {
+#if VALI_USE_CVT_PK_U8
+  return __builtin_amdgcn_cvt_pk_u8_f32(v, 0, 0u);
+#else
+  return quantize_u8_portable(v);
+#endif
+}
+
+// Order LDS traffic of ONE wave: DS instructions of a wave execute in issue
+// order, so a compiler-level fence is all that is needed between the strided
+// writes and the transposed reads of the same wave-private strip.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---------------------------------------------------------------------------
+// Packed-3-channel row strip (u8): 64 lanes x 48 B.
+//
+// store: lane l owns bytes [48l, 48l+48) of the strip (its 16 RGB pixels) as
+// three uint4; the wave writes them to global memory as 3 x 1 KiB contiguous
+// pieces.  `valid_bytes` (multiple of 16) trims the last wave of a row.
+// LDS banking: ds_write_b128 is serviced in 8-lane groups; at a 48 B lane
+// stride the 8 lanes of a group cover 8 distinct 4-bank slots -> conflict free.
+// ds_read_b128 of consecutive uint4 is conflict free by construction.
+// ---------------------------------------------------------------------------
+struct alignas(16) PackedStrip {
+  uint4 v[kWave * 3];
+};
+
+__device__ __forceinline__ void strip_store_row(PackedStrip& strip, int lane,
+                                                const u32 (&o)[12], bool lane_valid,
+                                                uint8_t* row_base, int valid_bytes) {
+  if (lane_valid) {
+    strip.v[lane * 3 + 0] = make_uint4(o[0], o[1], o[2], o[3]);
+    strip.v[lane * 3 + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+    strip.v[lane * 3 + 2] = make_uint4(o[8], o[9], o[10], o[11]);
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int off = (k * kWave + lane) * 16;
+    if (off < valid_bytes)
+      *reinterpret_cast<uint4*>(row_base + off) = strip.v[k * kWave + lane];
+  }
+  wave_lds_sync();
+}
+
+// load: the inverse -- 3 x 1 KiB contiguous global reads, then each lane picks
+// up its own 48 bytes.
+__device__ __forceinline__ void strip_load_row(PackedStrip& strip, int lane,
+                                               u32 (&o)[12], bool lane_valid,
+                                               const uint8_t* row_base,
+                                               int valid_bytes) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int off = (k * kWave + lane) * 16;
+    if (off < valid_bytes)
+      strip.v[k * kWave + lane] = *reinterpret_cast<const uint4*>(row_base + off);
+  }
+  wave_lds_sync();
+  if (lane_valid) {
+    const uint4 a = strip.v[lane * 3 + 0], b = strip.v[lane * 3 + 1],
+                c = strip.v[lane * 3 + 2];
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
+    o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    o[8] = c.x; o[9] = c.y; o[10] = c.z; o[11] = c.w;
+  }
+  wave_lds_sync();
+}
+
+// Scatter 16 pixels (3 channels, already quantised into per-channel dwords
+// c0/c1/c2, 4 pixels per dword) into the 12 dwords of a packed row segment.
+// v_perm_b32 does an arbitrary 4-of-8 byte pick in one instruction.
+//   packed bytes of 4 pixels: a0 b0 c0 a1 | b1 c1 a2 b2 | c2 a3 b3 c3
+__device__ __forceinline__ void interleave3(const u32 (&a)[4], const u32 (&b)[4],
+                                            const u32 (&c)[4], u32 (&o)[12]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    // __builtin_amdgcn_perm(hi, lo, sel): byte k of result = bytes{hi:7..4, lo:3..0}[sel.k]
+    const u32 ab_lo = __builtin_amdgcn_perm(b[j], a[j], 0x05010400u); // a0 b0 a1 b1
+    const u32 ab_hi = __builtin_amdgcn_perm(b[j], a[j], 0x07030602u); // a2 b2 a3 b3
+    // d0 = a0 b0 c0 a1
+    o[3 * j + 0] = __builtin_amdgcn_perm(c[j], ab_lo, 0x02040100u);
+    // d1 = b1 c1 a2 b2 : b1 = ab_lo.3, c1 = c.1, a2 = ab_hi.0, b2 = ab_hi.1
+    const u32 t = __builtin_amdgcn_perm(c[j], ab_lo, 0x00000503u);    // b1 c1 . .
+    o[3 * j + 1] = __builtin_amdgcn_perm(ab_hi, t, 0x05040100u);
+    // d2 = c2 a3 b3 c3
+    o[3 * j + 2] = __builtin_amdgcn_perm(c[j], ab_hi, 0x07030206u);
+  }
+}
+
+// Inverse of interleave3.
+__device__ __forceinline__ void deinterleave3(const u32 (&o)[12], u32 (&a)[4],
+                                              u32 (&b)[4], u32 (&c)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const u32 d0 = o[3 * j], d1 = o[3 * j + 1], d2 = o[3 * j + 2];
+    // a = d0.0 d0.3 d1.2 d2.1
+    const u32 a01 = __builtin_amdgcn_perm(d1, d0, 0x00060300u); // a0 a1 a2 .
+    a[j] = __builtin_amdgcn_perm(d2, a01, 0x05020100u);
+    // b = d0.1 d1.0 d1.3 d2.2
+    const u32 b01 = __builtin_amdgcn_perm(d1, d0, 0x00070401u); // b0 b1 b2 .
+    b[j] = __builtin_amdgcn_perm(d2, b01, 0x06020100u);
+    // c = d0.2 d1.1 d2.0 d2.3
+    const u32 c01 = __builtin_amdgcn_perm(d1, d0, 0x00000502u); // c0 c1 . .
+    c[j] = __builtin_amdgcn_perm(d2, c01, 0x07040100u);
+  }
+}
+
+} // namespace vali

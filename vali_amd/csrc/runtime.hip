@@ -1,0 +1,219 @@
+// Runtime half of the C ABI: devices, streams, events, pitched memory, 2-D copies.
+// HIP-native replacement for the reference's dlsym'd CUDA driver table
+// (reference: src/TC/inc/LibCuda.hpp, src/TC/src/CudaUtils.cpp:20-299,
+//  src/TC/src/SurfacePlane.cpp:186-213).  There is no context push/pop on HIP:
+// a device is selected per call and a stream carries its device.
+#include "common.hpp"
+
+#include <stdarg.h>
+
+namespace vali {
+
+std::string& last_error() {
+  static thread_local std::string s;
+  return s;
+}
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  last_error() = buf;
+  return code;
+}
+
+DeviceScope::DeviceScope(int device) {
+  if (device < 0)
+    return;
+  if (hipGetDevice(&m_prev) != hipSuccess) {
+    m_ok = false;
+    (void)hipGetLastError();
+    return;
+  }
+  if (m_prev != device) {
+    if (hipSetDevice(device) != hipSuccess) {
+      m_ok = false;
+      (void)hipGetLastError();
+      return;
+    }
+    m_switched = true;
+  }
+}
+
+DeviceScope::~DeviceScope() {
+  if (m_switched)
+    (void)hipSetDevice(m_prev);
+}
+
+int stream_device(hipStream_t stream) {
+  int dev = -1;
+  if (stream) {
+    hipDevice_t d;
+    if (hipStreamGetDevice(stream, &d) == hipSuccess)
+      return (int)d;
+    (void)hipGetLastError();
+  }
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  return dev;
+}
+
+} // namespace vali
+
+using namespace vali;
+
+#define VALI_DEVICE(device)                                                    \
+  DeviceScope _scope(device);                                                  \
+  if (!_scope.ok())                                                            \
+  return fail(VALI_ERR_NO_DEVICE, "%s: cannot select device %d", __func__, device)
+
+extern "C" {
+
+const char* vali_last_error(void) { return last_error().c_str(); }
+
+const char* vali_version(void) { return "vali_hip 0.1 (gfx950)"; }
+
+int vali_device_count(int* count) {
+  VALI_REQUIRE(count, "null count");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    *count = 0;
+    return fail(VALI_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return VALI_OK;
+}
+
+int vali_ptr_device(const void* dptr, int* device) {
+  VALI_REQUIRE(dptr && device, "null argument");
+  hipPointerAttribute_t attr;
+  VALI_HIP_CHECK(hipPointerGetAttributes(&attr, dptr));
+  *device = attr.device;
+  return VALI_OK;
+}
+
+int vali_stream_create(int device, vali_stream_t* stream) {
+  VALI_REQUIRE(stream, "null stream");
+  VALI_DEVICE(device);
+  hipStream_t s = nullptr;
+  VALI_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = (vali_stream_t)s;
+  return VALI_OK;
+}
+
+int vali_stream_destroy(int device, vali_stream_t stream) {
+  VALI_DEVICE(device);
+  if (stream)
+    VALI_HIP_CHECK(hipStreamDestroy(as_stream(stream)));
+  return VALI_OK;
+}
+
+int vali_stream_sync(int device, vali_stream_t stream) {
+  VALI_DEVICE(device);
+  VALI_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+  return VALI_OK;
+}
+
+int vali_event_create(int device, vali_event_t* event) {
+  VALI_REQUIRE(event, "null event");
+  VALI_DEVICE(device);
+  hipEvent_t e = nullptr;
+  VALI_HIP_CHECK(hipEventCreate(&e));
+  *event = (vali_event_t)e;
+  return VALI_OK;
+}
+
+int vali_event_destroy(int device, vali_event_t event) {
+  VALI_DEVICE(device);
+  if (event)
+    VALI_HIP_CHECK(hipEventDestroy((hipEvent_t)event));
+  return VALI_OK;
+}
+
+int vali_event_record(int device, vali_event_t event, vali_stream_t stream) {
+  VALI_REQUIRE(event, "null event");
+  VALI_DEVICE(device);
+  VALI_HIP_CHECK(hipEventRecord((hipEvent_t)event, as_stream(stream)));
+  return VALI_OK;
+}
+
+int vali_event_sync(int device, vali_event_t event) {
+  VALI_REQUIRE(event, "null event");
+  VALI_DEVICE(device);
+  VALI_HIP_CHECK(hipEventSynchronize((hipEvent_t)event));
+  return VALI_OK;
+}
+
+int vali_event_elapsed_ms(vali_event_t start, vali_event_t stop, float* ms) {
+  VALI_REQUIRE(start && stop && ms, "null argument");
+  VALI_HIP_CHECK(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return VALI_OK;
+}
+
+int vali_mem_alloc_pitch(int device, size_t width_bytes, size_t height, void** dptr,
+                         size_t* pitch) {
+  VALI_REQUIRE(dptr && pitch, "null argument");
+  VALI_REQUIRE(width_bytes > 0 && height > 0, "empty plane");
+  VALI_DEVICE(device);
+  const size_t p = (width_bytes + 255u) & ~(size_t)255u;
+  void* mem = nullptr;
+  VALI_HIP_CHECK(hipMalloc(&mem, p * height));
+  *dptr = mem;
+  *pitch = p;
+  return VALI_OK;
+}
+
+int vali_mem_alloc(int device, size_t bytes, void** dptr) {
+  VALI_REQUIRE(dptr, "null argument");
+  VALI_REQUIRE(bytes > 0, "zero-size allocation");
+  VALI_DEVICE(device);
+  void* mem = nullptr;
+  VALI_HIP_CHECK(hipMalloc(&mem, bytes));
+  *dptr = mem;
+  return VALI_OK;
+}
+
+int vali_mem_free(int device, void* dptr) {
+  VALI_DEVICE(device);
+  if (dptr)
+    VALI_HIP_CHECK(hipFree(dptr));
+  return VALI_OK;
+}
+
+int vali_memcpy2d_async(int device, void* dst, size_t dst_pitch, const void* src,
+                        size_t src_pitch, size_t width_bytes, size_t height,
+                        int kind, vali_stream_t stream) {
+  VALI_REQUIRE(dst && src, "null pointer");
+  VALI_REQUIRE(kind >= 0 && kind <= 2, "bad copy kind");
+  VALI_REQUIRE(dst_pitch >= width_bytes && src_pitch >= width_bytes,
+               "pitch smaller than row");
+  if (width_bytes == 0 || height == 0)
+    return VALI_OK;
+  VALI_DEVICE(device);
+  const hipMemcpyKind k = kind == 0   ? hipMemcpyHostToDevice
+                          : kind == 1 ? hipMemcpyDeviceToHost
+                                      : hipMemcpyDeviceToDevice;
+  VALI_HIP_CHECK(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width_bytes, height,
+                                  k, as_stream(stream)));
+  return VALI_OK;
+}
+
+int vali_memset2d_async(int device, void* dst, size_t dst_pitch, int value,
+                        size_t width_bytes, size_t height, vali_stream_t stream) {
+  VALI_REQUIRE(dst, "null pointer");
+  VALI_REQUIRE(dst_pitch >= width_bytes, "pitch smaller than row");
+  if (width_bytes == 0 || height == 0)
+    return VALI_OK;
+  VALI_DEVICE(device);
+  VALI_HIP_CHECK(
+      hipMemset2DAsync(dst, dst_pitch, value, width_bytes, height, as_stream(stream)));
+  return VALI_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,207 @@
+"""PySurfaceConverter / PySurfaceResizer / PySurfaceRotator / PySurfaceUD.
+
+Host-side mirror of the reference's L3 tasks + L4 Py* wrappers: validation, format-pair
+dispatch, colour-variant selection and error codes are restated here in Python; the
+per-pixel work is one C-ABI call into libvali_hip.so per Run
+(reference: src/TC/src/TaskConvertSurface.cpp:966-1095, src/python_vali/src/PySurfaceConverter.cpp:26-161).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+from ._native import shim
+from .enums import (ColorRange, ColorSpace, ColorspaceConversionContext, PixelFormat,
+                    TaskExecDetails, TaskExecInfo)
+from .runtime import CudaStreamEvent, HipResMgr
+from .surface import Surface
+
+F = PixelFormat
+
+# ---- colour matrices ------------------------------------------------------------------
+# The constants NVIDIA documents for the NPP functions the reference calls;
+# the CSC struct layout is include/vali_hip.h:vali_csc.  (y0, cy, crv, cgu, cgv, cbu)
+CSC_NPP_YUV = (0.0, 1.0, 1.140, -0.394, -0.581, 2.032)          # nppiNV12ToRGB / YUV420ToRGB / YUVToRGB
+CSC_NPP_709CSC = (16.0, 1.164, 1.793, -0.213, -0.533, 2.112)    # nppiNV12ToRGB_709CSC
+CSC_NPP_709HDTV = (0.0, 1.0, 1.5748, -0.1873, -0.4681, 1.8556)  # nppiNV12ToRGB_709HDTV
+CSC_NPP_YCBCR = (16.0, 1.164, 1.596, -0.392, -0.813, 2.017)     # nppiYCbCr420ToRGB / YCbCrToBGR
+
+_csc_cache = {}
+
+
+def _csc(coeffs):
+    c = _csc_cache.get(coeffs)
+    if c is None:
+        c = _csc_cache[coeffs] = shim.Csc(*coeffs)
+    return c
+
+
+def _status(rc: int) -> TaskExecDetails:
+    """C status -> TaskExecDetails (the reference maps NppStatus the same way, e.g.
+    TaskConvertSurface.cpp:151-155)."""
+    if rc == shim.OK:
+        return TaskExecDetails.ok()
+    if rc == shim.ERR_INVALID_ARG:
+        return TaskExecDetails.failed(TaskExecInfo.INVALID_INPUT, shim.last_error())
+    if rc == shim.ERR_UNSUPPORTED:
+        return TaskExecDetails.failed(TaskExecInfo.NOT_SUPPORTED, shim.last_error())
+    raise RuntimeError("HIP failure: " + shim.last_error())
+
+
+_S_INVALID = TaskExecDetails.failed(TaskExecInfo.INVALID_INPUT, "invalid src / dst")
+_S_UNSUPP_CC = TaskExecDetails.failed(TaskExecInfo.UNSUPPORTED_FMT_CONV_PARAMS,
+                                      "unsupported cc_ctx params")
+
+
+def _nv12_variant(cc_ctx: Optional[ColorspaceConversionContext]):
+    """Colour-variant switch of nv12_rgb (TaskConvertSurface.cpp:117-149):
+    default BT709+JPEG; BT709: JPEG -> 709HDTV else 709CSC; BT601: JPEG -> 'YUV',
+    otherwise unsupported; any other colour space unsupported."""
+    space = cc_ctx.color_space if cc_ctx else ColorSpace.BT_709
+    rng = cc_ctx.color_range if cc_ctx else ColorRange.JPEG
+    if space == ColorSpace.BT_709:
+        return CSC_NPP_709HDTV if rng == ColorRange.JPEG else CSC_NPP_709CSC
+    if space == ColorSpace.BT_601 and rng == ColorRange.JPEG:
+        return CSC_NPP_YUV
+    return None
+
+
+def _nv12_rgb(src: Surface, dst: Surface, stream: int, cc_ctx) -> TaskExecDetails:
+    """nv12_rgb / nv12_bgr (TaskConvertSurface.cpp:61-156).  The reference's nv12_bgr
+    falls off the end of the function (its return sits after `break`, :100-105); here
+    BGR simply follows the RGB logic with the channel order reversed."""
+    coeffs = _nv12_variant(cc_ctx)
+    if coeffs is None:
+        return _S_UNSUPP_CC
+    return _status(shim.nv12_to_rgb(src.desc(), dst.desc(), _csc(coeffs), stream))
+
+
+# (src, dst) -> implementation; order follows GetSupportedConversions()
+# (TaskConvertSurface.cpp:966-994).  NV12 -> RGB_PLANAR is an extension: the fused form
+# of the reference's NV12->RGB->RGB_PLANAR chain (BASELINE config 2).
+_CONVERSIONS = {
+    (F.NV12, F.RGB): _nv12_rgb,
+    (F.NV12, F.BGR): _nv12_rgb,
+    (F.NV12, F.RGB_PLANAR): _nv12_rgb,
+}
+
+
+class _SurfaceTask:
+    def __init__(self, gpu_id: int, stream=None):
+        self._gpu_id = int(gpu_id)
+        self._stream = (int(stream) if stream is not None
+                        else HipResMgr.Instance().GetStream(self._gpu_id))
+        self._event = CudaStreamEvent(self._stream, self._gpu_id)
+
+    @property
+    def Stream(self) -> int:
+        return self._stream
+
+    def _sync(self):
+        self._event.Record()
+        self._event.Wait()
+
+
+class PySurfaceConverter(_SurfaceTask):
+    """GPU colour-space / pixel-format conversion.
+
+    reference: src/python_vali/src/PySurfaceConverter.cpp:26-161 (ctor, Run, RunAsync,
+    Conversions, Stream); dispatch ConvertSurface::Run (TaskConvertSurface.cpp:1009-1095).
+    RunBatch is new: one launch over a list of same-shaped surfaces.
+    """
+
+    def __init__(self, gpu_id: int, stream=None):
+        super().__init__(gpu_id, stream)
+        self._batch_cache = {}
+
+    @staticmethod
+    def Conversions() -> List[Tuple[PixelFormat, PixelFormat]]:
+        return list(_CONVERSIONS.keys())
+
+    def _run(self, src: Surface, dst: Surface, cc_ctx) -> TaskExecDetails:
+        if src.Width != dst.Width or src.Height != dst.Height:   # Validate(), :1001-1015
+            return _S_INVALID
+        impl = _CONVERSIONS.get((src.Format, dst.Format))
+        if impl is None:                                          # :1085-1089
+            raise ValueError(f"Unsupported pixel format conversion: {src.Format.name} -> "
+                             f"{dst.Format.name}")
+        return impl(src, dst, self._stream, cc_ctx)
+
+    def RunAsync(self, src: Surface, dst: Surface,
+                 cc_ctx: Optional[ColorspaceConversionContext] = None) -> Tuple[bool, TaskExecInfo]:
+        d = self._run(src, dst, cc_ctx)
+        return d.success, d.info
+
+    def Run(self, src: Surface, dst: Surface,
+            cc_ctx: Optional[ColorspaceConversionContext] = None) -> Tuple[bool, TaskExecInfo]:
+        d = self._run(src, dst, cc_ctx)
+        self._sync()
+        return d.success, d.info
+
+    # -- batched form ------------------------------------------------------------------
+    def PrepareBatch(self, srcs: Sequence[Surface], dsts: Sequence[Surface]) -> "SurfaceBatch":
+        """Upload the descriptor arrays of a (srcs, dsts) batch once; reuse with RunBatch."""
+        return SurfaceBatch(self._gpu_id, self._stream, srcs, dsts)
+
+    def RunBatchAsync(self, batch, dsts=None, cc_ctx=None, csc=None) -> Tuple[bool, TaskExecInfo]:
+        """RunBatchAsync(batch, cc_ctx=...) or RunBatchAsync(srcs, dsts, cc_ctx).
+        All-or-nothing, no per-item sync (idiom of PyNvJpegEncoder.Run,
+        src/python_vali/src/PyNvJpegEncoder.cpp:31-81).  `csc` overrides the matrix
+        cc_ctx would select (the multi-GPU pipeline passes the broadcast block)."""
+        if not isinstance(batch, SurfaceBatch):
+            batch = SurfaceBatch(self._gpu_id, self._stream, batch, dsts)
+        if (batch.src_format, batch.dst_format) not in _CONVERSIONS:
+            raise ValueError(f"Unsupported pixel format conversion: {batch.src_format.name} -> "
+                             f"{batch.dst_format.name}")
+        if batch.src_size != batch.dst_size:
+            return False, TaskExecInfo.INVALID_INPUT
+        if batch.src_format == F.NV12:
+            if csc is None:
+                coeffs = _nv12_variant(cc_ctx)
+                if coeffs is None:
+                    return False, TaskExecInfo.UNSUPPORTED_FMT_CONV_PARAMS
+                csc = _csc(coeffs)
+            d = _status(shim.nv12_to_rgb_batch(batch.d_src, batch.d_dst, batch.n,
+                                               batch.src_size[0], batch.src_size[1],
+                                               int(batch.dst_format), csc, self._stream))
+            return d.success, d.info
+        raise ValueError("RunBatch: conversion has no batched kernel yet")
+
+    def RunBatch(self, batch, dsts=None, cc_ctx=None, csc=None) -> Tuple[bool, TaskExecInfo]:
+        r = self.RunBatchAsync(batch, dsts, cc_ctx, csc)
+        self._sync()
+        return r
+
+
+class SurfaceBatch:
+    """Device-resident descriptor arrays for n (src, dst) surface pairs of one geometry."""
+
+    def __init__(self, gpu_id: int, stream: int, srcs: Sequence[Surface], dsts: Sequence[Surface]):
+        srcs, dsts = list(srcs), list(dsts)
+        if not srcs or len(srcs) != len(dsts):
+            raise ValueError("SurfaceBatch: need equally long, non-empty src and dst lists")
+        for group in (srcs, dsts):
+            f0, s0 = group[0].Format, (group[0].Width, group[0].Height)
+            for s in group:
+                if s.Format != f0 or (s.Width, s.Height) != s0 or s.IsEmpty:
+                    raise ValueError("SurfaceBatch: surfaces of a batch must share format and size")
+        self.gpu_id = gpu_id
+        self.n = len(srcs)
+        self.src_format, self.dst_format = srcs[0].Format, dsts[0].Format
+        self.src_size = (srcs[0].Width, srcs[0].Height)
+        self.dst_size = (dsts[0].Width, dsts[0].Height)
+        self._keep = (srcs, dsts)
+        self.d_src = shim.descs_upload(gpu_id, [s.desc() for s in srcs], stream)
+        self.d_dst = shim.descs_upload(gpu_id, [s.desc() for s in dsts], stream)
+
+    def __len__(self):
+        return self.n
+
+    def __del__(self):
+        for name in ("d_src", "d_dst"):
+            p = getattr(self, name, 0)
+            if p:
+                try:
+                    shim.mem_free(self.gpu_id, p)
+                except Exception:
+                    pass
+                setattr(self, name, 0)
