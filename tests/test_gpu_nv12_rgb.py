@@ -52,7 +52,7 @@ def test_bit_exact_fast_path(vali, gpu, oracle, size, variant, dst):
         assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("size", [(50, 34), (424, 232), (18, 2), (2, 2), (1918, 1078), (33, 7)])
+@pytest.mark.parametrize("size", [(50, 34), (424, 232), (18, 2), (2, 2), (1918, 1078), (34, 8)])
 @pytest.mark.parametrize("dst", ["RGB", "BGR", "RGB_PLANAR"])
 def test_bit_exact_ragged_sizes(vali, gpu, oracle, size, dst):
     """Widths that are not a multiple of 16 and odd heights take the byte-granular path."""

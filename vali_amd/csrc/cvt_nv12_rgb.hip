@@ -9,9 +9,12 @@
 // Algorithmic traffic per pixel: 1.5 B read (Y + half a UV pair), 3 B written.
 // Work decomposition: one lane = 16 px x 2 rows (the 2x2 chroma footprint of
 // 8 UV pairs): loads 16 B Y(row0) + 16 B Y(row1) + 16 B UV, stores 2 x 48 B.
-// One 256-thread workgroup = one row pair x 4096 px; grid = (x segments,
-// row pairs, frames).  Packed stores go through a per-wave LDS strip so each
-// store instruction writes 1 KiB contiguous (dev_util.hpp).
+// One 256-thread workgroup = one row pair x 4096 px.  grid.x walks the tiles of a
+// frame through the XCD-contiguous TileMap (dev_util.hpp), grid.y = frame.
+// Packed stores go through a per-wave LDS strip so each store instruction writes
+// 1 KiB contiguous, non-temporal.  Residency is capped at 16 waves per CU by the
+// dynamic-LDS size: fewer concurrent row streams per L2 measured +4% HBM
+// throughput at 2160p (profiles/r01_variants.md: 5.56 -> 6.16 TB/s in total).
 // Arithmetic (bit-exact with oracle/vali_oracle.c: vali_oracle_nv12_to_rgb):
 //   Yf = cy*(Y-y0); Uc=U-128; Vc=V-128
 //   R = Yf + crv*Vc ; G = Yf + fma(cgu,Uc,cgv*Vc) ; B = Yf + cbu*Uc
@@ -31,7 +34,7 @@ struct Nv12RgbArgs {
   vali_surface src;          // by-value descriptors (single frame)
   vali_surface dst;
   vali_csc csc;
-  int groups;                // ceil(width / 16)
+  TileMap map;               // tiles of one frame: x segments x row pairs
 };
 
 struct ChromaTerm {
@@ -84,11 +87,18 @@ __device__ __forceinline__ void emit4(u32 y4, const ChromaTerm& c01, const Chrom
 }
 
 // STAGED: packed rows leave through the per-wave LDS strip (3 x 1 KiB contiguous per
-// wave and row); !STAGED: each lane stores its own 3 x 16 B at a 48 B lane stride
-// (kept as the measured alternative, see DESIGN.md "store path A/B").
+// wave and row, non-temporal); !STAGED: each lane stores its own 3 x 16 B at a 48 B lane
+// stride (kept as the measured alternative, see DESIGN.md "store path A/B").
 template <int LAYOUT, bool STAGED>
 __global__ void __launch_bounds__(kBlock) k_nv12_rgb8(const Nv12RgbArgs a) {
-  __shared__ PackedStrip strips[(LAYOUT == LAYOUT_PLANAR || !STAGED) ? 1 : kWavesPerBlock];
+  // dynamic LDS: [0, 12 KiB) = the 4 per-wave strips; the rest only caps residency
+  extern __shared__ uint4 dyn_lds[];
+  PackedStrip* const strips = reinterpret_cast<PackedStrip*>(dyn_lds);
+
+  u32 tile_x, tile_y;
+  if (!tile_of_block(a.map, tile_x, tile_y))
+    return;
+  const u32 frame = blockIdx.y;
 
   const uint8_t* py;
   const uint8_t* puv;
@@ -97,8 +107,8 @@ __global__ void __launch_bounds__(kBlock) k_nv12_rgb8(const Nv12RgbArgs a) {
   uint8_t* pd2;
   int sp_y, sp_uv, dp, W, H;
   if (a.d_src) {
-    const vali_surface* s = a.d_src + blockIdx.z;
-    const vali_surface* d = a.d_dst + blockIdx.z;
+    const vali_surface* s = a.d_src + frame;
+    const vali_surface* d = a.d_dst + frame;
     py = (const uint8_t*)s->plane[0]; puv = (const uint8_t*)s->plane[1];
     sp_y = s->pitch[0]; sp_uv = s->pitch[1]; W = s->width; H = s->height;
     pd0 = (uint8_t*)d->plane[0]; pd1 = (uint8_t*)d->plane[1]; pd2 = (uint8_t*)d->plane[2];
@@ -113,13 +123,13 @@ __global__ void __launch_bounds__(kBlock) k_nv12_rgb8(const Nv12RgbArgs a) {
 
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
-  const int wave_g0 = blockIdx.x * blockDim.x + wave * kWave; // first group of this wave
+  const int wave_g0 = tile_x * blockDim.x + wave * kWave; // first group of this wave
   const int groups = (W + kLanePx - 1) / kLanePx;
   if (wave_g0 >= groups)
     return; // whole wave out of the row: nothing to cooperate on
   const int g = wave_g0 + lane;
   const int x0 = g * kLanePx;
-  const int row0 = blockIdx.y * 2;
+  const int row0 = tile_y * 2;
   const bool has_row1 = row0 + 1 < H;
 
   // Uniform (per frame) fast-path test: full 16-px groups and 16-B aligned rows.
@@ -137,7 +147,7 @@ __global__ void __launch_bounds__(kBlock) k_nv12_rgb8(const Nv12RgbArgs a) {
       // odd height: the last pair re-reads row0 (always a valid address)
       const uint4 yb =
           *reinterpret_cast<const uint4*>(py + (size_t)(row0 + (has_row1 ? 1 : 0)) * sp_y + x0);
-      const uint4 uv = *reinterpret_cast<const uint4*>(puv + (size_t)blockIdx.y * sp_uv + x0);
+      const uint4 uv = *reinterpret_cast<const uint4*>(puv + (size_t)tile_y * sp_uv + x0);
       const u32 yw0[4] = {ya.x, ya.y, ya.z, ya.w};
       const u32 yw1[4] = {yb.x, yb.y, yb.z, yb.w};
       const u32 uvw[4] = {uv.x, uv.y, uv.z, uv.w};
@@ -161,11 +171,10 @@ __global__ void __launch_bounds__(kBlock) k_nv12_rgb8(const Nv12RgbArgs a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           uint8_t* p = planes[c] + (size_t)row0 * dp + x0;
-          *reinterpret_cast<uint4*>(p) =
-              make_uint4(o0[4 * c], o0[4 * c + 1], o0[4 * c + 2], o0[4 * c + 3]);
+          store16_nt(p, make_uint4(o0[4 * c], o0[4 * c + 1], o0[4 * c + 2], o0[4 * c + 3]));
           if (has_row1)
-            *reinterpret_cast<uint4*>(p + dp) =
-                make_uint4(o1[4 * c], o1[4 * c + 1], o1[4 * c + 2], o1[4 * c + 3]);
+            store16_nt(p + dp,
+                       make_uint4(o1[4 * c], o1[4 * c + 1], o1[4 * c + 2], o1[4 * c + 3]));
         }
       }
     } else if constexpr (!STAGED) {
@@ -205,7 +214,7 @@ __global__ void __launch_bounds__(kBlock) k_nv12_rgb8(const Nv12RgbArgs a) {
       if (x >= W)
         break;
       const float yv = (float)py[(size_t)y * sp_y + x];
-      const uint8_t* c = puv + (size_t)blockIdx.y * sp_uv + (x & ~1);
+      const uint8_t* c = puv + (size_t)tile_y * sp_uv + (x & ~1);
       const ChromaTerm t = chroma_term((float)c[0], (float)c[1], k);
       const float yf = luma_term(yv, k);
       const uint8_t R = (uint8_t)quantize_u8(yf + t.rv), G = (uint8_t)quantize_u8(yf + t.guv),
@@ -224,34 +233,55 @@ __global__ void __launch_bounds__(kBlock) k_nv12_rgb8(const Nv12RgbArgs a) {
   }
 }
 
-static int launch_nv12_rgb(const Nv12RgbArgs& a, int width, int height, int n, int dst_format,
+// Dynamic-LDS size that caps residency at `waves_per_cu` (160 KiB LDS per CU) while
+// leaving room for the strips.
+static unsigned residency_lds_bytes(int block_threads, int waves_per_cu, unsigned min_bytes) {
+  const int waves_per_block = block_threads / kWave;
+  const int blocks_per_cu = waves_per_cu / waves_per_block > 0 ? waves_per_cu / waves_per_block : 1;
+  unsigned bytes = (160u * 1024u / (unsigned)blocks_per_cu) & ~1023u; // floor to 1 KiB
+  if (bytes > 1024u)
+    bytes -= 512u; // stay strictly below the next-lower residency step
+  if (bytes > 64u * 1024u)
+    bytes = 64u * 1024u; // default per-block dynamic LDS limit
+  return bytes < min_bytes ? min_bytes : bytes;
+}
+
+static int launch_nv12_rgb(Nv12RgbArgs& a, int width, int height, int n, int dst_format,
                            hipStream_t stream) {
   const int groups = (width + kLanePx - 1) / kLanePx;
   // workgroup width: smallest multiple of a wave covering the row, capped at 256
   int block = ((groups + kWave - 1) / kWave) * kWave;
   if (block > kBlock)
     block = kBlock;
-  const dim3 grid((groups + block - 1) / block, (height + 1) / 2, n);
-  // tuning knob for A/B measurements only (not part of the API)
+  a.map = make_tile_map((groups + block - 1) / block, (height + 1) / 2);
+  const dim3 grid(a.map.per_xcd * 8u, n);
+  // tuning knobs for A/B measurements only (not part of the API)
   static const bool direct = [] {
     const char* e = getenv("VALI_NV12_DIRECT_STORE");
     return e && e[0] == '1';
   }();
+  static const int waves_per_cu = [] {
+    const char* e = getenv("VALI_WAVES_PER_CU");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 16;
+  }();
+  const unsigned lds =
+      residency_lds_bytes(block, waves_per_cu, (unsigned)sizeof(PackedStrip) * kWavesPerBlock);
   switch (dst_format) {
   case VALI_FMT_RGB:
     if (direct)
-      hipLaunchKernelGGL((k_nv12_rgb8<LAYOUT_RGB, false>), grid, dim3(block), 0, stream, a);
+      hipLaunchKernelGGL((k_nv12_rgb8<LAYOUT_RGB, false>), grid, dim3(block), lds, stream, a);
     else
-      hipLaunchKernelGGL((k_nv12_rgb8<LAYOUT_RGB, true>), grid, dim3(block), 0, stream, a);
+      hipLaunchKernelGGL((k_nv12_rgb8<LAYOUT_RGB, true>), grid, dim3(block), lds, stream, a);
     break;
   case VALI_FMT_BGR:
     if (direct)
-      hipLaunchKernelGGL((k_nv12_rgb8<LAYOUT_BGR, false>), grid, dim3(block), 0, stream, a);
+      hipLaunchKernelGGL((k_nv12_rgb8<LAYOUT_BGR, false>), grid, dim3(block), lds, stream, a);
     else
-      hipLaunchKernelGGL((k_nv12_rgb8<LAYOUT_BGR, true>), grid, dim3(block), 0, stream, a);
+      hipLaunchKernelGGL((k_nv12_rgb8<LAYOUT_BGR, true>), grid, dim3(block), lds, stream, a);
     break;
   case VALI_FMT_RGB_PLANAR:
-    hipLaunchKernelGGL((k_nv12_rgb8<LAYOUT_PLANAR, true>), grid, dim3(block), 0, stream, a);
+    hipLaunchKernelGGL((k_nv12_rgb8<LAYOUT_PLANAR, true>), grid, dim3(block), lds, stream, a);
     break;
   default:
     return fail(VALI_ERR_UNSUPPORTED, "nv12_to_rgb: unsupported dst format %d", dst_format);

@@ -61,6 +61,65 @@ __device__ __forceinline__ u32 quantize_u8(float v) {
 #endif
 }
 
+// 16-byte global accesses.  Stores of finished output use the non-temporal form:
+// the surface kernels never re-read what they write, and streaming full 128-byte
+// lines past the L2 measured +2..3% on the 1:2 read:write mix (profiles/r01_variants.md).
+// NEVER use it for partial-line (strided 16 B) stores: that measured 2.4x slower.
+typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void store16_nt(void* p, uint4 v) {
+  const v4u32 w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, reinterpret_cast<v4u32*>(p));
+}
+
+__device__ __forceinline__ void store16(void* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
+
+__device__ __forceinline__ uint4 load16(const void* p) {
+  return *reinterpret_cast<const uint4*>(p);
+}
+
+// ---------------------------------------------------------------------------
+// XCD-aware tile map.
+//
+// The dispatcher places workgroup b of a launch on XCD b % 8 (observed, never relied
+// on for correctness -- any placement gives the same result).  A streaming kernel
+// whose consecutive workgroups walk consecutive rows therefore interleaves the rows of
+// a frame over the 8 private L2s.  Giving each XCD one CONTIGUOUS eighth of the frame's
+// tiles instead measured +3.5% on NV12->RGB 2160p (DRAM page locality of each L2's
+// fill/evict stream), +7% together with nt stores (profiles/r01_variants.md).
+//   launch: grid.x = 8 * per_xcd (per_xcd = ceil(total / 8)), grid.y = frames
+//   tile   = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8   (skip if >= total)
+// ---------------------------------------------------------------------------
+struct TileMap {
+  u32 total;    // tiles per frame (= tiles_x * tiles_y)
+  u32 per_xcd;  // ceil(total / 8)
+  u32 tiles_x;  // tiles along x
+};
+
+__host__ __device__ inline TileMap make_tile_map(u32 tiles_x, u32 tiles_y) {
+  TileMap m;
+  m.total = tiles_x * tiles_y;
+  m.per_xcd = (m.total + 7u) / 8u;
+  m.tiles_x = tiles_x;
+  return m;
+}
+
+// returns false when this workgroup is grid padding
+__device__ __forceinline__ bool tile_of_block(const TileMap& m, u32& tx, u32& ty) {
+  const u32 b = blockIdx.x;
+  const u32 t = (b & 7u) * m.per_xcd + (b >> 3);
+  if (t >= m.total)
+    return false;
+  if (m.tiles_x == 1u) {
+    tx = 0;
+    ty = t;
+  } else {
+    ty = t / m.tiles_x;
+    tx = t - ty * m.tiles_x;
+  }
+  return true;
+}
+
 // Order LDS traffic of ONE wave: DS instructions of a wave execute in issue
 // order, so a compiler-level fence is all that is needed between the strided
 // writes and the transposed reads of the same wave-private strip.
@@ -97,7 +156,7 @@ __device__ __forceinline__ void strip_store_row(PackedStrip& strip, int lane,
   for (int k = 0; k < 3; ++k) {
     const int off = (k * kWave + lane) * 16;
     if (off < valid_bytes)
-      *reinterpret_cast<uint4*>(row_base + off) = strip.v[k * kWave + lane];
+      store16_nt(row_base + off, strip.v[k * kWave + lane]);
   }
   wave_lds_sync();
 }
