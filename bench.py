@@ -95,6 +95,20 @@ def cpu_baseline(width, height, coeffs, budget_s):
     }
 
 
+def measured_traffic(bytes_per_frame, frames, dst, W, H):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*.json), when
+    one exists for exactly this workload; PMC counters cannot be read from inside the run."""
+    for f in sorted((ROOT / "profiles").glob("*.json"), reverse=True):
+        try:
+            j = json.loads(f.read_text())
+        except Exception:
+            continue
+        if (j.get("bytes_per_frame") == bytes_per_frame and j.get("frames_per_gpu") == frames
+                and f"NV12->{dst} {W}x{H}" in j.get("workload", "")):
+            return j["hbm_bytes_per_launch"], f"profiles/{f.name}"
+    return None, None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -197,6 +211,7 @@ def main():
         avg_kernel_ms = float(np.mean(kernel_ms))
         achieved = bytes_per_frame * F / (avg_kernel_ms * 1e-3) / 1e9
         fps = world * F * args.steps / elapsed
+        traffic, traffic_src = measured_traffic(bytes_per_frame, F, args.dst, W, H)
         out = {
             "metric": "nv12_to_rgb_2160p_frames_per_s" if (W, H) == (3840, 2160)
                       else f"nv12_to_rgb_{W}x{H}_frames_per_s",
@@ -214,7 +229,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBPS, 4),
-                         "traffic": None, "kernel": "k_nv12_rgb8",
+                         "traffic": traffic, "traffic_unit": "B per launch",
+                         "traffic_source": traffic_src, "kernel": "k_nv12_rgb8",
                          "avg_kernel_ms": round(avg_kernel_ms, 4),
                          "min_kernel_ms": round(float(np.min(kernel_ms)), 4)},
         }
