@@ -161,6 +161,23 @@ VALI_API int vali_nv12_to_rgb_batch(const vali_surface* d_src,
                                     int height, int dst_format, const vali_csc* csc,
                                     vali_stream_t stream);
 
+/* ---- UD: chroma upsample + resize (+ YUV->RGB) in one pass ---------------------- */
+
+/*
+ * Replaces the reference's first-party launchers UD_NV12 / UD_NV12_HBD
+ * (reference: src/TC/inc/ResizeUtils.hpp:30-50, src/TC/src/ResizeUtils.cu:98-176; callers
+ * src/TC/src/UDSurface.cpp:84-115).  src->format: NV12 or P10; dst->format one of
+ * YUV444, RGB, RGB_PLANAR, RGB_32F, RGB_32F_PLANAR (NV12) / YUV444_10BIT, RGB_32F,
+ * RGB_32F_PLANAR (P10) -- the semi-planar rows of UDSurface::SupportedConversions()
+ * (UDSurface.cpp:117-133); anything else returns VALI_ERR_UNSUPPORTED.
+ * As in the reference the dst size alone defines the scale (no size validation).
+ */
+VALI_API int vali_ud_nv12(const vali_surface* src, const vali_surface* dst,
+                          vali_stream_t stream);
+VALI_API int vali_ud_nv12_batch(const vali_surface* d_src, const vali_surface* d_dst, int n,
+                                int src_format, int dst_width, int dst_height,
+                                int dst_format, vali_stream_t stream);
+
 /* ---- diagnostics (used by tests only) --------------------------------------- */
 
 /* out[i] = float->u8 quantiser of the colour kernels applied to in[i]. */

@@ -139,3 +139,50 @@ def nv12_to_rgb_mt(frames, width, height, k: Csc, threads: int, outs=None):
     if rc:
         raise RuntimeError(f"vali_oracle_nv12_to_rgb_mt -> {rc}")
     return outs
+
+
+def surf_semiplanar(a: np.ndarray, width: int, height: int, fmt: str) -> Surface:
+    """NV12 (uint8) or P10/P12 (uint16) array of shape (height*3/2, >=width)."""
+    assert a.ndim == 2 and a.flags.c_contiguous
+    s = Surface()
+    pitch = a.strides[0]
+    s.plane[0] = _ptr(a)
+    s.plane[1] = _ptr(a, height * pitch)
+    s.pitch[0] = s.pitch[1] = pitch
+    s.width, s.height, s.format = width, height, FMT[fmt]
+    return s
+
+
+def surf_planes3(planes, width: int, height: int, fmt: str) -> Surface:
+    """three separate 2-D arrays (YUV444 / YUV420 ...)."""
+    s = Surface()
+    for c, a in enumerate(planes):
+        assert a.ndim == 2 and a.flags.c_contiguous
+        s.plane[c] = _ptr(a)
+        s.pitch[c] = a.strides[0]
+    s.width, s.height, s.format = width, height, FMT[fmt]
+    return s
+
+
+_UD_DTYPE = {"YUV444": np.uint8, "YUV444_10bit": np.uint16, "RGB": np.uint8, "RGB_PLANAR": np.uint8,
+             "RGB_32F": np.float32, "RGB_32F_PLANAR": np.float32}
+
+
+def ud_nv12(src: np.ndarray, sw: int, sh: int, src_fmt: str, dw: int, dh: int, dst_fmt: str):
+    """Returns the dst image in the reference's host layout: YUV444 -> (3, dh, dw) stacked
+    planes, packed RGB -> (dh, 3*dw), planar RGB -> (3*dh, dw)."""
+    s = surf_semiplanar(src, sw, sh, src_fmt)
+    dt = _UD_DTYPE[dst_fmt]
+    if dst_fmt in ("YUV444", "YUV444_10bit"):
+        out = np.zeros((3, dh, dw), dt)
+        d = surf_planes3([out[0], out[1], out[2]], dw, dh, dst_fmt)
+    elif dst_fmt in ("RGB", "RGB_32F"):
+        out = np.zeros((dh, 3 * dw), dt)
+        d = surf_packed3(out, dw, dh, dst_fmt)
+    else:
+        out = np.zeros((3 * dh, dw), dt)
+        d = surf_planar3(out, dw, dh, dst_fmt)
+    rc = lib().vali_oracle_ud_nv12(C.byref(s), C.byref(d))
+    if rc:
+        raise RuntimeError(f"vali_oracle_ud_nv12 -> {rc}")
+    return out

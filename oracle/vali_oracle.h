@@ -58,6 +58,20 @@ VALI_API int vali_oracle_nv12_to_rgb(const vali_surface* src, const vali_surface
 VALI_API int vali_oracle_nv12_to_rgb_mt(const vali_surface* src, const vali_surface* dst,
                                         int n, const vali_csc* csc, int threads);
 
+/*
+ * UD: chroma upsample + resize (+ YUV->RGB) of NV12 / P10.
+ * Restates RescaleConvertYUV<T> / RescaleConvertRGB<T> and their launcher Impl<T>
+ * (reference: src/TC/src/ResizeUtils.cu:21-158) with CUDA's documented linear texture
+ * filter (unnormalised coordinates, clamp addressing, normalised-float reads, 8-bit
+ * fractional weights).  Supported pairs: UDSurface.cpp:117-133 (semi-planar rows).
+ * Pinned by the reference's 640x360 goldens through their internal identities
+ * (tests/test_oracle_ud.py); the goldens' INPUT frame is not available offline.
+ */
+VALI_API int vali_oracle_ud_nv12(const vali_surface* src, const vali_surface* dst);
+/* the two output stages on their own (ResizeUtils.cu:45-54, 71-77) */
+VALI_API void vali_oracle_ud_rgb_from_yuv(float ny, float nu, float nv, float* rgb);
+VALI_API uint8_t vali_oracle_ud_store_u8(float normalised);
+
 #ifdef __cplusplus
 }
 #endif

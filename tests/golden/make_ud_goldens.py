@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Crop the reference's own UD golden files (tests/data/640x360_*.raw, produced by
+reference tests/test_PySurfaceUD.py from frame 0 of test.mp4 / test_hevc10.mkv) to their
+first ROWS rows and store them compressed.  Run in the build container only
+(/root/reference is not on the GPU box).  These are DATA fixtures of the reference's
+test-suite; the source frame they were computed from needs a video decoder and is not
+reproducible offline, so the tests use them through pixel-wise identities."""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+REF = Path("/root/reference/tests/data")
+OUT = Path(__file__).resolve().parent
+W, H, ROWS = 640, 360, 120
+
+
+def load(name, dtype):
+    return np.fromfile(REF / f"640x360_PixelFormat.{name}.raw", dtype)
+
+
+nv12 = {
+    "rgb": load("NV12_PixelFormat.RGB", np.uint8).reshape(H, W, 3)[:ROWS],
+    "rgb_planar": load("NV12_PixelFormat.RGB_PLANAR", np.uint8).reshape(3, H, W)[:, :ROWS],
+    "rgb_32f": load("NV12_PixelFormat.RGB_32F", np.float32).reshape(H, W, 3)[:ROWS],
+    "rgb_32f_planar": load("NV12_PixelFormat.RGB_32F_PLANAR", np.float32).reshape(3, H, W)[:, :ROWS],
+    "yuv444": load("NV12_PixelFormat.YUV444", np.uint8).reshape(3, H, W)[:, :ROWS],
+}
+p10 = {
+    "rgb_32f": load("P10_PixelFormat.RGB_32F", np.float32).reshape(H, W, 3)[:ROWS],
+    "rgb_32f_planar": load("P10_PixelFormat.RGB_32F_PLANAR", np.float32).reshape(3, H, W)[:, :ROWS],
+    "yuv444_10bit": load("P10_PixelFormat.YUV444_10bit", np.uint16).reshape(3, H, W)[:, :ROWS],
+}
+# whole-file identities, checked here once on the full files (recorded in DESIGN.md)
+full_rgb = load("NV12_PixelFormat.RGB", np.uint8)
+full_f = load("NV12_PixelFormat.RGB_32F", np.float32)
+print("full-file RGB == clip(trunc(RGB_32F*256)):",
+      np.array_equal(full_rgb, np.clip(np.trunc(full_f * 256.0), 0, 255).astype(np.uint8)))
+print("test_small.yuv444 == NV12->YUV444 golden:",
+      np.array_equal(np.fromfile(REF / "test_small.yuv444", np.uint8), load("NV12_PixelFormat.YUV444", np.uint8)))
+np.savez_compressed(OUT / "ud_640x360_nv12_rows120.npz", **nv12)
+np.savez_compressed(OUT / "ud_640x360_p10_rows120.npz", **p10)
+for f in ("ud_640x360_nv12_rows120.npz", "ud_640x360_p10_rows120.npz"):
+    print(f, (OUT / f).stat().st_size)

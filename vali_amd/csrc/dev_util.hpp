@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/vali_hip.h"
+
 namespace vali {
 
 typedef uint32_t u32;
@@ -118,6 +120,31 @@ __device__ __forceinline__ bool tile_of_block(const TileMap& m, u32& tx, u32& ty
     tx = t - ty * m.tiles_x;
   }
   return true;
+}
+
+// Device-side copy of a vali_surface descriptor: from the batch's device array when
+// there is one, from the kernel argument otherwise (explicit branches keep the two
+// address spaces apart -- a pointer select between them costs scratch + flat loads).
+struct SurfRef {
+  uint8_t* p[3];
+  int pitch[3];
+  int width, height;
+};
+
+__device__ __forceinline__ SurfRef load_surface(const vali_surface* arr, const vali_surface& one,
+                                                u32 index) {
+  SurfRef r;
+  if (arr) {
+    const vali_surface* s = arr + index;
+    r.p[0] = (uint8_t*)s->plane[0]; r.p[1] = (uint8_t*)s->plane[1]; r.p[2] = (uint8_t*)s->plane[2];
+    r.pitch[0] = s->pitch[0]; r.pitch[1] = s->pitch[1]; r.pitch[2] = s->pitch[2];
+    r.width = s->width; r.height = s->height;
+  } else {
+    r.p[0] = (uint8_t*)one.plane[0]; r.p[1] = (uint8_t*)one.plane[1]; r.p[2] = (uint8_t*)one.plane[2];
+    r.pitch[0] = one.pitch[0]; r.pitch[1] = one.pitch[1]; r.pitch[2] = one.pitch[2];
+    r.width = one.width; r.height = one.height;
+  }
+  return r;
 }
 
 // Order LDS traffic of ONE wave: DS instructions of a wave execute in issue

@@ -323,6 +323,19 @@ PYBIND11_MODULE(_vali_shim, m) {
         },
         py::call_guard<py::gil_scoped_release>());
 
+  m.def("ud_nv12",
+        [](const SurfaceDesc& src, const SurfaceDesc& dst, uintptr_t stream) {
+          return vali_ud_nv12(&src.s, &dst.s, P(stream));
+        },
+        py::call_guard<py::gil_scoped_release>());
+  m.def("ud_nv12_batch",
+        [](uintptr_t d_src, uintptr_t d_dst, int n, int src_format, int dst_w, int dst_h,
+           int dst_format, uintptr_t stream) {
+          return vali_ud_nv12_batch((const vali_surface*)P(d_src), (const vali_surface*)P(d_dst),
+                                    n, src_format, dst_w, dst_h, dst_format, P(stream));
+        },
+        py::call_guard<py::gil_scoped_release>());
+
   m.def("debug_quantize_u8", [](uintptr_t in, uintptr_t out, int n, uintptr_t stream) {
     return vali_debug_quantize_u8((const float*)P(in), (uint8_t*)P(out), n, P(stream));
   });

@@ -1,0 +1,296 @@
+// UD ("upsample chroma + downscale/resize + optional YUV->RGB") of NV12 / P10 surfaces.
+//
+// Replaces the reference's only first-party CUDA kernels, RescaleConvertYUV<T> and
+// RescaleConvertRGB<T> with their launchers UD_NV12 / UD_NV12_HBD
+// (reference: src/TC/src/ResizeUtils.cu:21-176, src/TC/inc/ResizeUtils.hpp:30-50; callers
+// UDSemiPlanar / UDSemiPlanarHBD, src/TC/src/UDSurface.cpp:84-115).
+//
+// The reference samples two CUDA texture objects (Y: WxH 1-ch, UV: W/2 x H/2 2-ch) with
+// cudaFilterModeLinear + cudaReadModeNormalizedFloat at unnormalised coordinates
+// X = x / scale_x (no half-pixel centring), address mode clamp.  gfx950 has no texture
+// sampler path worth using here, so the filter is restated arithmetically
+// (CUDA programming guide, "Linear Filtering"):
+//   xB = X - 0.5 ; i = floor(xB) ; alpha = frac(xB) rounded to 8 fractional bits
+//   tex = sum_{ij} w_ij * T[clamp(i+di), clamp(j+dj)],  w from alpha/beta, sum(w) = 65536
+// evaluated EXACTLY in integers, then normalised with one float multiply
+//   val = float(S) * float(1 / (65536 * max))        max = 255 (u8) or 65535 (u16)
+// Output stage exactly as the reference: YUV: (T)(val * 2^bits); RGB: u -= .5, v -= .5,
+//   r = y + 1.140 v ; g = y - 0.394 u - 0.581 v ; b = y + 2.032 u   (nvcc contracts these
+//   into FMAs; restated with explicit fmaf), u8: x256, truncate toward zero, saturate
+//   (what cvt.rzi.u8.f32 does; pinned by the reference goldens: RGB == trunc(RGB_32F*256)).
+// Oracle: vali_oracle_ud_nv12 (oracle/vali_oracle.c), bit-exact.
+//
+// Work decomposition: one lane = 4 adjacent dst pixels of one row, so u8 planar output is
+// a dword, u8 packed 12 B (dwordx3), f32 16/48 B per lane; a 64x4 workgroup = 256x4 dst
+// pixels.  Source texels are gathered with byte/short loads served by L1/L2 (each texel is
+// touched by <= 2 lanes at <= 2x downscale); tiles walk the frame through the
+// XCD-contiguous TileMap.  HBM traffic = touched source rows + the dst surface.
+#include "common.hpp"
+#include "dev_util.hpp"
+
+namespace vali {
+
+enum : int {
+  UD_YUV444 = 0,      // 3 planes, same element type as the source
+  UD_RGB_U8 = 1,      // packed
+  UD_RGB_U8_PLANAR = 2,
+  UD_RGB_F32 = 3,     // packed
+  UD_RGB_F32_PLANAR = 4
+};
+
+struct UdArgs {
+  const vali_surface* d_src;
+  const vali_surface* d_dst;
+  vali_surface src, dst;
+  TileMap map;
+};
+
+template <typename T> struct TexelTraits;
+template <> struct TexelTraits<uint8_t> {
+  static constexpr float kInvDen = 1.0f / 16711680.0f;    // 1 / (65536 * 255)
+  static constexpr float kMax = 256.0f;
+};
+template <> struct TexelTraits<uint16_t> {
+  static constexpr float kInvDen = 1.0f / 4294901760.0f;  // 1 / (65536 * 65535)
+  static constexpr float kMax = 65536.0f;
+};
+
+struct Tap {
+  int i0, i1;   // clamped texel indices
+  u32 w0, w1;   // 8.8 weights, w0 + w1 = 256
+};
+
+// coordinate -> two taps; `coord` is the unnormalised texture coordinate.
+__device__ __forceinline__ Tap make_tap(float coord, int size) {
+  const float b = coord - 0.5f;
+  const float fl = __builtin_floorf(b);
+  const float frac = b - fl;
+  const u32 q = (u32)(frac * 256.0f + 0.5f); // 0..256
+  int i = (int)fl;
+  Tap t;
+  t.i0 = min(max(i, 0), size - 1);
+  t.i1 = min(max(i + 1, 0), size - 1);
+  t.w1 = q;
+  t.w0 = 256u - q;
+  return t;
+}
+
+// float -> integer conversion of the reference (cvt.rzi + saturation)
+template <typename T> __device__ __forceinline__ u32 trunc_sat(float v) {
+  constexpr float hi = sizeof(T) == 1 ? 255.0f : 65535.0f;
+  const float c = __builtin_fminf(__builtin_fmaxf(v, 0.0f), hi); // NaN -> 0 like cvt.rzi
+  return (u32)c;                                                  // v_cvt_u32_f32 truncates
+}
+
+template <typename T, int OUT>
+__global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
+  u32 tile_x, tile_y;
+  if (!tile_of_block(a.map, tile_x, tile_y))
+    return;
+  const SurfRef s = load_surface(a.d_src, a.src, blockIdx.y);
+  const SurfRef d = load_surface(a.d_dst, a.dst, blockIdx.y);
+  const uint8_t* py = s.p[0];
+  const uint8_t* puv = s.p[1];
+  const int sp_y = s.pitch[0], sp_uv = s.pitch[1], sw = s.width, sh = s.height;
+  uint8_t* pd0 = d.p[0];
+  uint8_t* pd1 = d.p[1];
+  uint8_t* pd2 = d.p[2];
+  const int dp0 = d.pitch[0], dp1 = d.pitch[1], dp2 = d.pitch[2], dw = d.width, dh = d.height;
+
+  const int x0 = (tile_x * 64 + (threadIdx.x & 63)) * 4;
+  const int y = tile_y * 4 + (threadIdx.x >> 6);
+  if (x0 >= dw || y >= dh)
+    return;
+
+  // ResizeUtils.cu:135-136: scale = 1.0f * dst / src ; :36-37: coord = x / scale
+  const float scale_x = 1.0f * (float)dw / (float)sw;
+  const float scale_y = 1.0f * (float)dh / (float)sh;
+  const Tap ty = make_tap((float)y / scale_y, sh);
+  const Tap tcy = make_tap((float)y / (scale_y * 2.0f), sh / 2);
+  const T* yrow0 = (const T*)(py + (size_t)ty.i0 * sp_y);
+  const T* yrow1 = (const T*)(py + (size_t)ty.i1 * sp_y);
+  const T* crow0 = (const T*)(puv + (size_t)tcy.i0 * sp_uv);
+  const T* crow1 = (const T*)(puv + (size_t)tcy.i1 * sp_uv);
+
+  float c0[4], c1[4], c2[4]; // per pixel: Y,U,V (YUV444) or R,G,B normalised
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int x = x0 + p;
+    const Tap tx = make_tap((float)x / scale_x, sw);
+    const Tap tcx = make_tap((float)x / (scale_x * 2.0f), sw / 2);
+    const u32 sy = ty.w0 * (tx.w0 * (u32)yrow0[tx.i0] + tx.w1 * (u32)yrow0[tx.i1]) +
+                   ty.w1 * (tx.w0 * (u32)yrow1[tx.i0] + tx.w1 * (u32)yrow1[tx.i1]);
+    const u32 su = tcy.w0 * (tcx.w0 * (u32)crow0[2 * tcx.i0] + tcx.w1 * (u32)crow0[2 * tcx.i1]) +
+                   tcy.w1 * (tcx.w0 * (u32)crow1[2 * tcx.i0] + tcx.w1 * (u32)crow1[2 * tcx.i1]);
+    const u32 sv =
+        tcy.w0 * (tcx.w0 * (u32)crow0[2 * tcx.i0 + 1] + tcx.w1 * (u32)crow0[2 * tcx.i1 + 1]) +
+        tcy.w1 * (tcx.w0 * (u32)crow1[2 * tcx.i0 + 1] + tcx.w1 * (u32)crow1[2 * tcx.i1 + 1]);
+    const float ny = (float)sy * TexelTraits<T>::kInvDen;
+    const float nu = (float)su * TexelTraits<T>::kInvDen;
+    const float nv = (float)sv * TexelTraits<T>::kInvDen;
+    if constexpr (OUT == UD_YUV444) {
+      c0[p] = ny; c1[p] = nu; c2[p] = nv;
+    } else {
+      const float u = nu - 0.5f, v = nv - 0.5f;
+      c0[p] = __builtin_fmaf(1.140f, v, ny);
+      c1[p] = __builtin_fmaf(-0.581f, v, __builtin_fmaf(-0.394f, u, ny));
+      c2[p] = __builtin_fmaf(2.032f, u, ny);
+    }
+  }
+
+  const int n = min(4, dw - x0); // valid pixels of this lane
+  if constexpr (OUT == UD_YUV444) {
+    T* o0 = (T*)(pd0 + (size_t)y * dp0) + x0;
+    T* o1 = (T*)(pd1 + (size_t)y * dp1) + x0;
+    T* o2 = (T*)(pd2 + (size_t)y * dp2) + x0;
+    for (int p = 0; p < n; ++p) {
+      o0[p] = (T)trunc_sat<T>(c0[p] * TexelTraits<T>::kMax);
+      o1[p] = (T)trunc_sat<T>(c1[p] * TexelTraits<T>::kMax);
+      o2[p] = (T)trunc_sat<T>(c2[p] * TexelTraits<T>::kMax);
+    }
+  } else if constexpr (OUT == UD_RGB_U8 || OUT == UD_RGB_U8_PLANAR) {
+    u32 r[4], g[4], b[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      r[p] = trunc_sat<uint8_t>(c0[p] * 256.0f);
+      g[p] = trunc_sat<uint8_t>(c1[p] * 256.0f);
+      b[p] = trunc_sat<uint8_t>(c2[p] * 256.0f);
+    }
+    if constexpr (OUT == UD_RGB_U8_PLANAR) {
+      uint8_t* o0 = pd0 + (size_t)y * dp0 + x0;
+      uint8_t* o1 = pd1 + (size_t)y * dp0 + x0;
+      uint8_t* o2 = pd2 + (size_t)y * dp0 + x0;
+      if (n == 4 && ((((uintptr_t)o0) | ((uintptr_t)o1) | ((uintptr_t)o2)) & 3u) == 0) {
+        *(u32*)o0 = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
+        *(u32*)o1 = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
+        *(u32*)o2 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+      } else {
+        for (int p = 0; p < n; ++p) { o0[p] = (uint8_t)r[p]; o1[p] = (uint8_t)g[p]; o2[p] = (uint8_t)b[p]; }
+      }
+    } else {
+      uint8_t* o = pd0 + (size_t)y * dp0 + (size_t)x0 * 3;
+      if (n == 4 && (((uintptr_t)o) & 3u) == 0) {
+        struct alignas(4) U3 { u32 a, b, c; };
+        U3 w;
+        w.a = r[0] | (g[0] << 8) | (b[0] << 16) | (r[1] << 24);
+        w.b = g[1] | (b[1] << 8) | (r[2] << 16) | (g[2] << 24);
+        w.c = b[2] | (r[3] << 8) | (g[3] << 16) | (b[3] << 24);
+        *(U3*)o = w; // global_store_dwordx3
+      } else {
+        for (int p = 0; p < n; ++p) { o[3 * p] = (uint8_t)r[p]; o[3 * p + 1] = (uint8_t)g[p]; o[3 * p + 2] = (uint8_t)b[p]; }
+      }
+    }
+  } else if constexpr (OUT == UD_RGB_F32_PLANAR) {
+    float* o0 = (float*)(pd0 + (size_t)y * dp0) + x0;
+    float* o1 = (float*)(pd1 + (size_t)y * dp0) + x0;
+    float* o2 = (float*)(pd2 + (size_t)y * dp0) + x0;
+    if (n == 4 && ((((uintptr_t)o0) | ((uintptr_t)o1) | ((uintptr_t)o2)) & 15u) == 0) {
+      *(float4*)o0 = make_float4(c0[0], c0[1], c0[2], c0[3]);
+      *(float4*)o1 = make_float4(c1[0], c1[1], c1[2], c1[3]);
+      *(float4*)o2 = make_float4(c2[0], c2[1], c2[2], c2[3]);
+    } else {
+      for (int p = 0; p < n; ++p) { o0[p] = c0[p]; o1[p] = c1[p]; o2[p] = c2[p]; }
+    }
+  } else { // UD_RGB_F32 packed
+    float* o = (float*)(pd0 + (size_t)y * dp0) + (size_t)x0 * 3;
+    if (n == 4 && (((uintptr_t)o) & 15u) == 0) {
+      *(float4*)(o + 0) = make_float4(c0[0], c1[0], c2[0], c0[1]);
+      *(float4*)(o + 4) = make_float4(c1[1], c2[1], c0[2], c1[2]);
+      *(float4*)(o + 8) = make_float4(c2[2], c0[3], c1[3], c2[3]);
+    } else {
+      for (int p = 0; p < n; ++p) { o[3 * p] = c0[p]; o[3 * p + 1] = c1[p]; o[3 * p + 2] = c2[p]; }
+    }
+  }
+}
+
+static int ud_out_kind(int src_fmt, int dst_fmt) {
+  // SupportedConversions(), src/TC/src/UDSurface.cpp:117-133 (semi-planar sources)
+  if (src_fmt == VALI_FMT_NV12) {
+    switch (dst_fmt) {
+    case VALI_FMT_YUV444: return UD_YUV444;
+    case VALI_FMT_RGB: return UD_RGB_U8;
+    case VALI_FMT_RGB_PLANAR: return UD_RGB_U8_PLANAR;
+    case VALI_FMT_RGB_32F: return UD_RGB_F32;
+    case VALI_FMT_RGB_32F_PLANAR: return UD_RGB_F32_PLANAR;
+    default: return -1;
+    }
+  }
+  if (src_fmt == VALI_FMT_P10) {
+    switch (dst_fmt) {
+    case VALI_FMT_YUV444_10BIT: return UD_YUV444;
+    case VALI_FMT_RGB_32F: return UD_RGB_F32;
+    case VALI_FMT_RGB_32F_PLANAR: return UD_RGB_F32_PLANAR;
+    default: return -1;
+    }
+  }
+  return -1;
+}
+
+static int launch_ud(UdArgs& a, int src_fmt, int dst_w, int dst_h, int dst_fmt, int n,
+                     hipStream_t stream) {
+  const int kind = ud_out_kind(src_fmt, dst_fmt);
+  if (kind < 0)
+    return fail(VALI_ERR_UNSUPPORTED, "ud_nv12: unsupported format pair %d -> %d", src_fmt, dst_fmt);
+  a.map = make_tile_map((dst_w + 255) / 256, (dst_h + 3) / 4);
+  const dim3 grid(a.map.per_xcd * 8u, n), block(kBlock);
+#define VALI_UD_CASE(T, K)                                                                  \
+  case K:                                                                                   \
+    hipLaunchKernelGGL((k_ud_nv12<T, K>), grid, block, 0, stream, a);                        \
+    break;
+  if (src_fmt == VALI_FMT_NV12) {
+    switch (kind) {
+      VALI_UD_CASE(uint8_t, UD_YUV444)
+      VALI_UD_CASE(uint8_t, UD_RGB_U8)
+      VALI_UD_CASE(uint8_t, UD_RGB_U8_PLANAR)
+      VALI_UD_CASE(uint8_t, UD_RGB_F32)
+      VALI_UD_CASE(uint8_t, UD_RGB_F32_PLANAR)
+    }
+  } else {
+    switch (kind) {
+      VALI_UD_CASE(uint16_t, UD_YUV444)
+      VALI_UD_CASE(uint16_t, UD_RGB_F32)
+      VALI_UD_CASE(uint16_t, UD_RGB_F32_PLANAR)
+    }
+  }
+#undef VALI_UD_CASE
+  VALI_LAUNCH_CHECK();
+  return VALI_OK;
+}
+
+} // namespace vali
+
+using namespace vali;
+
+extern "C" {
+
+int vali_ud_nv12(const vali_surface* src, const vali_surface* dst, vali_stream_t stream) {
+  VALI_REQUIRE(src && dst, "null argument");
+  VALI_REQUIRE(src->width >= 2 && src->height >= 2 && dst->width > 0 && dst->height > 0,
+               "empty surface");
+  VALI_REQUIRE(src->plane[0] && src->plane[1] && dst->plane[0], "null plane");
+  if (dst->format != VALI_FMT_RGB && dst->format != VALI_FMT_RGB_32F)
+    VALI_REQUIRE(dst->plane[1] && dst->plane[2], "null dst plane");
+  UdArgs a = {};
+  a.src = *src;
+  a.dst = *dst;
+  hipStream_t s = as_stream(stream);
+  DeviceScope scope(stream_device(s));
+  return launch_ud(a, src->format, dst->width, dst->height, dst->format, 1, s);
+}
+
+int vali_ud_nv12_batch(const vali_surface* d_src, const vali_surface* d_dst, int n, int src_format,
+                       int dst_width, int dst_height, int dst_format, vali_stream_t stream) {
+  VALI_REQUIRE(d_src && d_dst, "null argument");
+  VALI_REQUIRE(dst_width > 0 && dst_height > 0, "empty geometry");
+  VALI_REQUIRE(n >= 0 && n <= 65535, "batch size out of range (0..65535)");
+  if (n == 0)
+    return VALI_OK;
+  UdArgs a = {};
+  a.d_src = d_src;
+  a.d_dst = d_dst;
+  hipStream_t s = as_stream(stream);
+  DeviceScope scope(stream_device(s));
+  return launch_ud(a, src_format, dst_width, dst_height, dst_format, n, s);
+}
+
+} // extern "C"

@@ -205,3 +205,65 @@ class SurfaceBatch:
                 except Exception:
                     pass
                 setattr(self, name, 0)
+
+
+# ---- PySurfaceUD -------------------------------------------------------------------------
+# UDSurface::SupportedConversions() (src/TC/src/UDSurface.cpp:117-133).  The planar-source
+# rows (YUV420 -> YUV444, YUV420_10bit -> YUV444_10bit) go through NPP Lanczos in the
+# reference (UDPlanar, :84-93); they are listed but not implemented yet (NOT_SUPPORTED).
+_UD_CONVERSIONS = [
+    (F.NV12, F.YUV444), (F.NV12, F.RGB), (F.NV12, F.RGB_32F), (F.NV12, F.RGB_PLANAR),
+    (F.NV12, F.RGB_32F_PLANAR), (F.YUV420, F.YUV444), (F.P10, F.YUV444_10bit), (F.P10, F.RGB_32F),
+    (F.P10, F.RGB_32F_PLANAR), (F.YUV420_10bit, F.YUV444_10bit),
+]
+_UD_SEMIPLANAR = {p for p in _UD_CONVERSIONS if p[0] in (F.NV12, F.P10)}
+
+
+class PySurfaceUD(_SurfaceTask):
+    """Chroma upsample + resize (+ YUV->RGB) in one pass.
+
+    reference: src/python_vali/src/PySurfaceUD.cpp:26-143 (ctor, Run, RunAsync,
+    SupportedFormats, Stream); UDSurface::Run (src/TC/src/UDSurface.cpp:135-177).
+    As in the reference the dst size alone defines the scale (no size validation).
+    """
+
+    @staticmethod
+    def SupportedFormats() -> List[Tuple[PixelFormat, PixelFormat]]:
+        return list(_UD_CONVERSIONS)
+
+    def _run(self, src: Surface, dst: Surface) -> TaskExecDetails:
+        pair = (src.Format, dst.Format)
+        if pair not in _UD_CONVERSIONS:                       # UDSurface.cpp:137-149
+            return TaskExecDetails.failed(TaskExecInfo.NOT_SUPPORTED)
+        if pair not in _UD_SEMIPLANAR:
+            return TaskExecDetails.failed(TaskExecInfo.NOT_SUPPORTED,
+                                          "planar-source UD (NPP Lanczos in the reference) "
+                                          "is not implemented")
+        return _status(shim.ud_nv12(src.desc(), dst.desc(), self._stream))
+
+    def RunAsync(self, src: Surface, dst: Surface) -> Tuple[bool, TaskExecInfo]:
+        d = self._run(src, dst)
+        return d.success, d.info
+
+    def Run(self, src: Surface, dst: Surface) -> Tuple[bool, TaskExecInfo]:
+        d = self._run(src, dst)
+        self._sync()
+        return d.success, d.info
+
+    def RunBatchAsync(self, batch, dsts=None) -> Tuple[bool, TaskExecInfo]:
+        if not isinstance(batch, SurfaceBatch):
+            batch = SurfaceBatch(self._gpu_id, self._stream, batch, dsts)
+        if (batch.src_format, batch.dst_format) not in _UD_SEMIPLANAR:
+            return False, TaskExecInfo.NOT_SUPPORTED
+        d = _status(shim.ud_nv12_batch(batch.d_src, batch.d_dst, batch.n, int(batch.src_format),
+                                       batch.dst_size[0], batch.dst_size[1],
+                                       int(batch.dst_format), self._stream))
+        return d.success, d.info
+
+    def RunBatch(self, batch, dsts=None) -> Tuple[bool, TaskExecInfo]:
+        r = self.RunBatchAsync(batch, dsts)
+        self._sync()
+        return r
+
+    def PrepareBatch(self, srcs: Sequence[Surface], dsts: Sequence[Surface]) -> "SurfaceBatch":
+        return SurfaceBatch(self._gpu_id, self._stream, srcs, dsts)
