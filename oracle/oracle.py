@@ -186,3 +186,26 @@ def ud_nv12(src: np.ndarray, sw: int, sh: int, src_fmt: str, dw: int, dh: int, d
     if rc:
         raise RuntimeError(f"vali_oracle_ud_nv12 -> {rc}")
     return out
+
+
+def rotate_plane(src: np.ndarray, channels: int, dst_w: int, dst_h: int, angle: float,
+                 shift_x: float = 0.0, shift_y: float = 0.0, fill=0) -> np.ndarray:
+    """src: (H, W*channels) array of uint8/uint16/float32.  Untouched dst pixels keep `fill`."""
+    assert src.ndim == 2 and src.flags.c_contiguous
+    elem = src.dtype.itemsize
+    sh, sw = src.shape[0], src.shape[1] // channels
+    out = np.full((dst_h, dst_w * channels), fill, src.dtype)
+    rc = lib().vali_oracle_rotate_plane(C.c_void_p(src.ctypes.data), src.strides[0], sw, sh,
+                                        C.c_void_p(out.ctypes.data), out.strides[0], dst_w, dst_h,
+                                        elem, channels, C.c_double(angle), C.c_double(shift_x),
+                                        C.c_double(shift_y))
+    if rc:
+        raise RuntimeError(f"vali_oracle_rotate_plane -> {rc}")
+    return out
+
+
+def canonical_shifts(angle: float, src_w: int, src_h: int):
+    """Shift normalisation of PySurfaceRotator::Run (PySurfaceRotator.cpp:47-73)."""
+    n = (int(round(angle)) + 360) % 360
+    return {0: (0.0, 0.0, 0.0), 90: (90.0, 0.0, src_w - 1.0), 180: (180.0, src_w - 1.0, src_h - 1.0),
+            270: (270.0, src_h - 1.0, 0.0)}[n]

@@ -285,3 +285,81 @@ void vali_oracle_ud_rgb_from_yuv(float ny, float nu, float nv, float* rgb) {
 uint8_t vali_oracle_ud_store_u8(float normalised) {  /* Denormalize<uint8_t> + (uint8_t) cast */
   return (uint8_t)trunc_sat(normalised * 256.0f, 255.0f);
 }
+
+/* ==========================================================================
+ * Rotation (reference: src/TC/src/RotateSurface.cpp:22-125 -> nppiRotate_*R_Ctx,
+ * NPPI_INTER_LINEAR; shift normalisation src/python_vali/src/PySurfaceRotator.cpp:40-77).
+ * NPP model: x' = x cos a + y sin a + sx ; y' = -x sin a + y cos a + sy ; destination
+ * pixels are inverse-mapped and bilinearly interpolated; those whose source point lies
+ * outside the source plane are left untouched.  NPP's interpolation arithmetic is not
+ * published: the operation order below is this build's definition.  For multiples of
+ * 90 degrees cos/sin are exact, the weights are 0 and the result is the exact pixel
+ * permutation the reference's etalons (frame_0_{90,180,270}_deg.jpg) show.
+ * ========================================================================== */
+static void rotate_coeffs(double angle_deg, float* c, float* s) {
+  const double q = fmod(angle_deg, 360.0);
+  const double n = q < 0 ? q + 360.0 : q;
+  if (n == 0.0) { *c = 1.f; *s = 0.f; }
+  else if (n == 90.0) { *c = 0.f; *s = 1.f; }
+  else if (n == 180.0) { *c = -1.f; *s = 0.f; }
+  else if (n == 270.0) { *c = 0.f; *s = -1.f; }
+  else {
+    const double r = angle_deg * 3.14159265358979323846 / 180.0;
+    *c = (float)cos(r);
+    *s = (float)sin(r);
+  }
+}
+
+static inline float rot_texel(const uint8_t* row, int idx, int elem) {
+  return elem == 1 ? (float)row[idx] : elem == 2 ? (float)((const uint16_t*)row)[idx]
+                                                 : ((const float*)row)[idx];
+}
+
+int vali_oracle_rotate_plane(const void* src, int src_pitch, int src_w, int src_h, void* dst,
+                             int dst_pitch, int dst_w, int dst_h, int elem, int channels,
+                             double angle, double shift_x, double shift_y) {
+  if (!src || !dst || src_w <= 0 || src_h <= 0 || dst_w <= 0 || dst_h <= 0)
+    return VALI_ERR_INVALID_ARG;
+  if ((elem != 1 && elem != 2 && elem != 4) || (channels != 1 && channels != 3))
+    return VALI_ERR_INVALID_ARG;
+  float c, s;
+  rotate_coeffs(angle, &c, &s);
+  const float sx = (float)shift_x, sy = (float)shift_y;
+  const float wmax = (float)(src_w - 1), hmax = (float)(src_h - 1);
+  for (int y = 0; y < dst_h; ++y) {
+    const float dy = (float)y - sy;
+    for (int x = 0; x < dst_w; ++x) {
+      const float dx = (float)x - sx;
+      const float xs = fmaf(-s, dy, c * dx);
+      const float ys = fmaf(c, dy, s * dx);
+      if (!(xs >= 0.0f && xs <= wmax && ys >= 0.0f && ys <= hmax))
+        continue;
+      const float fi = floorf(xs), fj = floorf(ys);
+      const float fa = xs - fi, fb = ys - fj;
+      const int i = (int)fi, j = (int)fj;
+      const int i1 = i + 1 < src_w ? i + 1 : src_w - 1, j1 = j + 1 < src_h ? j + 1 : src_h - 1;
+      const uint8_t* r0 = (const uint8_t*)src + (size_t)j * src_pitch;
+      const uint8_t* r1 = (const uint8_t*)src + (size_t)j1 * src_pitch;
+      uint8_t* drow = (uint8_t*)dst + (size_t)y * dst_pitch;
+      for (int ch = 0; ch < channels; ++ch) {
+        const float t00 = rot_texel(r0, i * channels + ch, elem), t10 = rot_texel(r0, i1 * channels + ch, elem);
+        const float t01 = rot_texel(r1, i * channels + ch, elem), t11 = rot_texel(r1, i1 * channels + ch, elem);
+        const float t0 = fmaf(fa, t10 - t00, t00);
+        const float t1 = fmaf(fa, t11 - t01, t01);
+        const float v = fmaf(fb, t1 - t0, t0);
+        const int o = x * channels + ch;
+        if (elem == 1) {
+          drow[o] = vali_oracle_q_u8(v);
+        } else if (elem == 2) {
+          float r = rintf(v);
+          if (!(r > 0.0f)) r = 0.0f;
+          if (r > 65535.0f) r = 65535.0f;
+          ((uint16_t*)drow)[o] = (uint16_t)r;
+        } else {
+          ((float*)drow)[o] = v;
+        }
+      }
+    }
+  }
+  return VALI_OK;
+}

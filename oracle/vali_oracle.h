@@ -72,6 +72,13 @@ VALI_API int vali_oracle_ud_nv12(const vali_surface* src, const vali_surface* ds
 VALI_API void vali_oracle_ud_rgb_from_yuv(float ny, float nu, float nv, float* rgb);
 VALI_API uint8_t vali_oracle_ud_store_u8(float normalised);
 
+/* Plane rotation, NPP nppiRotate model with bilinear interpolation
+ * (reference: src/TC/src/RotateSurface.cpp:22-125).  Pinned for 90/180/270 degrees by the
+ * reference's rotation etalons (tests/test_oracle_rotate.py); other angles: parity unpinned. */
+VALI_API int vali_oracle_rotate_plane(const void* src, int src_pitch, int src_w, int src_h,
+                                      void* dst, int dst_pitch, int dst_w, int dst_h, int elem,
+                                      int channels, double angle, double shift_x, double shift_y);
+
 #ifdef __cplusplus
 }
 #endif

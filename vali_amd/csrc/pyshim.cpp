@@ -336,6 +336,19 @@ PYBIND11_MODULE(_vali_shim, m) {
         },
         py::call_guard<py::gil_scoped_release>());
 
+  m.def("rotate_plane",
+        [](uintptr_t src, int spitch, int sw, int sh, uintptr_t dst, int dpitch, int dw, int dh,
+           int elem, int channels, double angle, double shx, double shy, uintptr_t stream) {
+          return vali_rotate_plane(P(src), spitch, sw, sh, P(dst), dpitch, dw, dh, elem, channels,
+                                   angle, shx, shy, P(stream));
+        },
+        py::call_guard<py::gil_scoped_release>());
+  m.def("rotate_coeffs", [](double angle) {
+    float c = 0, s = 0;
+    check(vali_rotate_coeffs(angle, &c, &s), "vali_rotate_coeffs");
+    return py::make_tuple(c, s);
+  });
+
   m.def("debug_quantize_u8", [](uintptr_t in, uintptr_t out, int n, uintptr_t stream) {
     return vali_debug_quantize_u8((const float*)P(in), (uint8_t*)P(out), n, P(stream));
   });

@@ -267,3 +267,81 @@ class PySurfaceUD(_SurfaceTask):
 
     def PrepareBatch(self, srcs: Sequence[Surface], dsts: Sequence[Surface]) -> "SurfaceBatch":
         return SurfaceBatch(self._gpu_id, self._stream, srcs, dsts)
+
+
+# ---- PySurfaceRotator --------------------------------------------------------------------
+_ROT_FORMATS = [F.Y, F.GRAY12, F.RGB, F.BGR, F.RGB_PLANAR, F.YUV420, F.YUV422, F.YUV444, F.RGB_32F,
+                F.RGB_32F_PLANAR, F.YUV444_10bit, F.YUV420_10bit]
+# format -> (driver, element size); RotateSurface::Run switch (RotateSurface.cpp:168-208)
+_ROT_IMPL = {
+    F.Y: ("planar", 1), F.RGB: ("packed", 1), F.BGR: ("packed", 1), F.RGB_PLANAR: ("planar", 1),
+    F.YUV420: ("planar", 1), F.YUV422: ("planar", 1), F.YUV444: ("planar", 1),
+    F.RGB_32F: ("packed", 4), F.RGB_32F_PLANAR: ("planar", 4), F.YUV444_10bit: ("planar", 2),
+    F.YUV420_10bit: ("planar", 2),
+}
+
+
+class PySurfaceRotator(_SurfaceTask):
+    """Rotate a Surface by an arbitrary angle (bilinear) with optional shift.
+
+    reference: src/python_vali/src/PySurfaceRotator.cpp:26-200; RotateSurface::Run
+    (src/TC/src/RotateSurface.cpp:161-214).  Multiples of 90 degrees with zero shifts are
+    normalised so the image lands exactly inside the (transposed) destination.
+    Deviation: for that special case the reference hands the LUMA-sized shifts to every
+    plane, which pushes the half-size chroma planes of YUV420/422 out of their
+    destination; here each plane gets the shifts derived from its own size.
+    """
+
+    def __init__(self, gpu_id: int, stream=None):
+        super().__init__(gpu_id, stream)
+
+    @property
+    def SupportedFormats(self) -> List[PixelFormat]:
+        return list(_ROT_FORMATS)
+
+    @staticmethod
+    def _normalise(angle: float, shift_x: float, shift_y: float):
+        """PySurfaceRotator::Run (:40-73): returns (angle, per-plane shift function | None)."""
+        import math
+
+        if math.fmod(angle, 90.0) == 0.0 and shift_x == 0.0 and shift_y == 0.0:
+            n = (int(round(angle)) + 360) % 360
+            return float(n), {0: lambda w, h: (0.0, 0.0), 90: lambda w, h: (0.0, w - 1.0),
+                              180: lambda w, h: (w - 1.0, h - 1.0),
+                              270: lambda w, h: (h - 1.0, 0.0)}[n]
+        return float(angle), None
+
+    def _run(self, src: Surface, dst: Surface, angle: float, shift_x: float, shift_y: float
+             ) -> TaskExecDetails:
+        if src.Format != dst.Format:                                     # RotateSurface.cpp:162-164
+            return TaskExecDetails.failed(TaskExecInfo.SRC_DST_FMT_MISMATCH)
+        impl = _ROT_IMPL.get(src.Format)
+        if impl is None:                                                 # :204-206
+            return TaskExecDetails.failed(TaskExecInfo.NOT_SUPPORTED)
+        kind, elem = impl
+        if kind == "planar" and src.NumComponents != src.NumPlanes:      # RotPlanar, :135-136
+            return TaskExecDetails.failed(TaskExecInfo.INVALID_INPUT)
+        if kind == "packed" and src.NumPlanes != 1:                      # RotPacked, :152-153
+            return TaskExecDetails.failed(TaskExecInfo.INVALID_INPUT)
+        angle, shifts = self._normalise(angle, shift_x, shift_y)
+        channels = 3 if kind == "packed" else 1
+        for i in range(src.NumPlanes):
+            sp, dp = src._planes[i], dst._planes[i]
+            sw, sh, dw, dh = sp.Width // channels, sp.Height, dp.Width // channels, dp.Height
+            sx, sy = shifts(sw, sh) if shifts else (shift_x, shift_y)
+            d = _status(shim.rotate_plane(sp.GpuMem, sp.Pitch, sw, sh, dp.GpuMem, dp.Pitch, dw, dh,
+                                          elem, channels, angle, sx, sy, self._stream))
+            if not d.success:
+                return d
+        return TaskExecDetails.ok()
+
+    def RunAsync(self, src: Surface, dst: Surface, angle: float, shift_x: float = 0.0,
+                 shift_y: float = 0.0) -> Tuple[bool, TaskExecInfo]:
+        d = self._run(src, dst, float(angle), float(shift_x), float(shift_y))
+        return d.success, d.info
+
+    def Run(self, src: Surface, dst: Surface, angle: float, shift_x: float = 0.0,
+            shift_y: float = 0.0) -> Tuple[bool, TaskExecInfo]:
+        d = self._run(src, dst, float(angle), float(shift_x), float(shift_y))
+        self._sync()
+        return d.success, d.info
