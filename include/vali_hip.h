@@ -178,6 +178,26 @@ VALI_API int vali_ud_nv12_batch(const vali_surface* d_src, const vali_surface* d
                                 int src_format, int dst_width, int dst_height,
                                 int dst_format, vali_stream_t stream);
 
+/* ---- resize: replaces nppiResize_{8u,32f}_C{1,3}R_Ctx --------------------------------- */
+
+enum vali_interpolation {
+  VALI_INTERP_LINEAR = 1 /* bilinear, centre-aligned mapping src = (dst + 0.5) * scale - 0.5 */
+};
+
+/*
+ * Resize every plane of a surface in one launch (src->format == dst->format).
+ * Replaces ResizeSurface and its five per-format implementations
+ * (reference: src/TC/src/TaskResizeSurface.cpp:34-286; NV12 via the NV12->YUV420->resize->
+ * YUV420->NV12 round trip :132-188).  Formats: Y, NV12, P10, P12, YUV420(_10BIT), YUV422,
+ * YUV444(_10BIT), RGB, BGR, RGB_32F, RGB_PLANAR, RGB_32F_PLANAR.  The reference's resizer is
+ * Lanczos-only (NPPI_INTER_LANCZOS, :67); bilinear is BASELINE.json's definition.
+ */
+VALI_API int vali_resize(const vali_surface* src, const vali_surface* dst, int interpolation,
+                         vali_stream_t stream);
+VALI_API int vali_resize_batch(const vali_surface* d_src, const vali_surface* d_dst, int n,
+                               int format, int dst_width, int dst_height, int interpolation,
+                               vali_stream_t stream);
+
 /* ---- rotation: replaces nppiRotate_{8u,16u,32f}_{C1,C3}R_Ctx ------------------------ */
 
 /*

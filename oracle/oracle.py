@@ -209,3 +209,45 @@ def canonical_shifts(angle: float, src_w: int, src_h: int):
     n = (int(round(angle)) + 360) % 360
     return {0: (0.0, 0.0, 0.0), 90: (90.0, 0.0, src_w - 1.0), 180: (180.0, src_w - 1.0, src_h - 1.0),
             270: (270.0, src_h - 1.0, 0.0)}[n]
+
+
+def resize_plane(src: np.ndarray, channels: int, dst_w: int, dst_h: int) -> np.ndarray:
+    """src: (H, W*channels) uint8/uint16/float32 -> (dst_h, dst_w*channels), bilinear."""
+    assert src.ndim == 2 and src.flags.c_contiguous
+    sh, sw = src.shape[0], src.shape[1] // channels
+    out = np.zeros((dst_h, dst_w * channels), src.dtype)
+    rc = lib().vali_oracle_resize_plane(C.c_void_p(src.ctypes.data), src.strides[0], sw, sh,
+                                        C.c_void_p(out.ctypes.data), out.strides[0], dst_w, dst_h,
+                                        src.dtype.itemsize, channels)
+    if rc:
+        raise RuntimeError(f"vali_oracle_resize_plane -> {rc}")
+    return out
+
+
+# plane lists in HOST (tightly packed) layout: (rows_fn, cols_fn, channels, subsample_x, subsample_y)
+def host_planes(fmt: str, w: int, h: int):
+    """[(plane_w_pixels, plane_h, channels)] in upload order for a format (vali_amd.surface.FORMATS)."""
+    if fmt in ("NV12", "P10", "P12"):
+        return [(w, h, 1), (w // 2, h // 2, 2)]
+    if fmt in ("YUV420", "YUV420_10bit"):
+        return [(w, h, 1), (w // 2, h // 2, 1), (w // 2, h // 2, 1)]
+    if fmt == "YUV422":
+        return [(w, h, 1), (w // 2, h, 1), (w // 2, h, 1)]
+    if fmt in ("YUV444", "YUV444_10bit", "RGB_PLANAR", "RGB_32F_PLANAR"):
+        return [(w, h, 1)] * 3
+    if fmt in ("RGB", "BGR", "RGB_32F"):
+        return [(w, h, 3)]
+    if fmt == "Y":
+        return [(w, h, 1)]
+    raise ValueError(fmt)
+
+
+def resize_surface(host: np.ndarray, fmt: str, sw: int, sh: int, dw: int, dh: int) -> np.ndarray:
+    """Resize a whole surface given as its flat host image (element dtype = host.dtype)."""
+    out, off = [], 0
+    for (pw, ph, ch), (qw, qh, _) in zip(host_planes(fmt, sw, sh), host_planes(fmt, dw, dh)):
+        n = pw * ph * ch
+        plane = np.ascontiguousarray(host[off: off + n].reshape(ph, pw * ch))
+        out.append(resize_plane(plane, ch, qw, qh).reshape(-1))
+        off += n
+    return np.concatenate(out)

@@ -363,3 +363,61 @@ int vali_oracle_rotate_plane(const void* src, int src_pitch, int src_w, int src_
   }
   return VALI_OK;
 }
+
+/* ==========================================================================
+ * Bilinear resize (reference: src/TC/src/TaskResizeSurface.cpp -> nppiResize_*R_Ctx).
+ * Sampling geometry src = dst * (src_size / dst_size) (no half-pixel shift): pinned by the
+ * reference fixture tests/data/test_small.nv12, which equals src[2y][2x] of its source frame
+ * (tests/test_oracle_resize.py).  The interpolation kernel differs from the reference
+ * (bilinear per BASELINE.json vs NPP Lanczos, input golden missing): operation order below
+ * is this build's definition; on integer scale factors both reduce to the same point sample.
+ * ========================================================================== */
+typedef struct { int i0, i1; float a; } lerp_t;
+
+static inline lerp_t make_lerp(int x, float scale, int size) {
+  const float f = (float)x * scale;
+  const float fl = floorf(f);
+  lerp_t l;
+  l.a = f - fl;
+  const int i = (int)fl;
+  l.i0 = i < size - 1 ? i : size - 1;
+  l.i1 = i + 1 < size - 1 ? i + 1 : size - 1;
+  return l;
+}
+
+int vali_oracle_resize_plane(const void* src, int src_pitch, int src_w, int src_h, void* dst,
+                             int dst_pitch, int dst_w, int dst_h, int elem, int channels) {
+  if (!src || !dst || src_w <= 0 || src_h <= 0 || dst_w <= 0 || dst_h <= 0)
+    return VALI_ERR_INVALID_ARG;
+  if ((elem != 1 && elem != 2 && elem != 4) || channels < 1 || channels > 3)
+    return VALI_ERR_INVALID_ARG;
+  const float scale_x = (float)src_w / (float)dst_w, scale_y = (float)src_h / (float)dst_h;
+  for (int y = 0; y < dst_h; ++y) {
+    const lerp_t ly = make_lerp(y, scale_y, src_h);
+    const uint8_t* r0 = (const uint8_t*)src + (size_t)ly.i0 * src_pitch;
+    const uint8_t* r1 = (const uint8_t*)src + (size_t)ly.i1 * src_pitch;
+    uint8_t* drow = (uint8_t*)dst + (size_t)y * dst_pitch;
+    for (int x = 0; x < dst_w; ++x) {
+      const lerp_t lx = make_lerp(x, scale_x, src_w);
+      for (int ch = 0; ch < channels; ++ch) {
+        const float t00 = rot_texel(r0, lx.i0 * channels + ch, elem), t10 = rot_texel(r0, lx.i1 * channels + ch, elem);
+        const float t01 = rot_texel(r1, lx.i0 * channels + ch, elem), t11 = rot_texel(r1, lx.i1 * channels + ch, elem);
+        const float t0 = fmaf(lx.a, t10 - t00, t00);
+        const float t1 = fmaf(lx.a, t11 - t01, t01);
+        const float v = fmaf(ly.a, t1 - t0, t0);
+        const int o = x * channels + ch;
+        if (elem == 1) {
+          drow[o] = vali_oracle_q_u8(v);
+        } else if (elem == 2) {
+          float r = rintf(v);
+          if (!(r > 0.0f)) r = 0.0f;
+          if (r > 65535.0f) r = 65535.0f;
+          ((uint16_t*)drow)[o] = (uint16_t)r;
+        } else {
+          ((float*)drow)[o] = v;
+        }
+      }
+    }
+  }
+  return VALI_OK;
+}

@@ -79,6 +79,14 @@ VALI_API int vali_oracle_rotate_plane(const void* src, int src_pitch, int src_w,
                                       void* dst, int dst_pitch, int dst_w, int dst_h, int elem,
                                       int channels, double angle, double shift_x, double shift_y);
 
+/* Bilinear plane resize on NPP's sampling grid src = dst * src_size / dst_size.  `channels`
+ * interleaved channels (2 = the UV plane of NV12).  The reference's resizer is NPP Lanczos
+ * (src/TC/src/TaskResizeSurface.cpp:67) whose input golden is missing: interpolation weights
+ * unpinned; the sampling GEOMETRY is pinned by test_small.nv12 (tests/test_oracle_resize.py). */
+VALI_API int vali_oracle_resize_plane(const void* src, int src_pitch, int src_w, int src_h,
+                                      void* dst, int dst_pitch, int dst_w, int dst_h, int elem,
+                                      int channels);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,81 @@
+"""PySurfaceResizer on the GPU vs the oracle (bit-exact; float32 too).
+
+Mirrors reference tests/test_PySurfaceResizer.py:64-140 (NV12 848x464 -> 424x232) with the two
+real NV12 frames that exist offline, plus the other formats ResizeSurface accepts
+(src/TC/src/TaskResizeSurface.cpp:293-309)."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+DT = {"RGB_32F": np.float32, "RGB_32F_PLANAR": np.float32, "P10": np.uint16,
+      "YUV444_10bit": np.uint16, "YUV420_10bit": np.uint16}
+
+
+def roundtrip(vali, gpu, fmt, host, sw, sh, dw, dh, is_async=False):
+    pf = vali.PixelFormat[fmt]
+    src = vali.Surface.Make(pf, sw, sh, gpu)
+    dst = vali.Surface.Make(pf, dw, dh, gpu)
+    assert vali.PyFrameUploader(gpu).Run(host.view(np.uint8), src)[0]
+    rs = vali.PySurfaceResizer(pf, gpu)
+    ok, info = rs.RunAsync(src, dst) if is_async else rs.Run(src, dst)
+    assert ok and info == vali.TaskExecInfo.SUCCESS
+    if is_async:
+        ev = vali.CudaStreamEvent(rs.Stream, gpu)
+        ev.Record()
+        ev.Wait()
+    out = np.zeros(dst.HostSize, np.uint8)
+    assert vali.PySurfaceDownloader(gpu).Run(dst, out)[0]
+    return out.view(host.dtype)
+
+
+@pytest.mark.parametrize("fmt", ["NV12", "YUV420", "YUV444", "RGB", "BGR", "RGB_PLANAR", "RGB_32F",
+                                 "RGB_32F_PLANAR", "Y", "P10", "YUV422", "YUV444_10bit"])
+@pytest.mark.parametrize("geom", [(848, 464, 424, 232), (640, 360, 1000, 500), (130, 70, 58, 34),
+                                  (1920, 1080, 1280, 720)])
+def test_resize_bit_exact(vali, gpu, oracle, fmt, geom):
+    sw, sh, dw, dh = geom
+    dt = DT.get(fmt, np.uint8)
+    n = vali.Surface.Make(vali.PixelFormat[fmt], sw, sh, gpu).HostSize // np.dtype(dt).itemsize
+    rng = np.random.default_rng(21)
+    host = (rng.random(n) * (1000 if dt == np.uint16 else 255)).astype(dt)
+    got = roundtrip(vali, gpu, fmt, host, sw, sh, dw, dh)
+    want = oracle.resize_surface(host, fmt, sw, sh, dw, dh)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("is_async", [True, False])
+def test_resize_nv12_real_frames(vali, gpu, oracle, is_async):
+    raw = np.fromfile(GOLDEN / "test_small_2frames.nv12", np.uint8).reshape(2, -1)
+    for frame in raw:
+        got = roundtrip(vali, gpu, "NV12", frame.copy(), 424, 232, 212, 116, is_async)
+        assert np.array_equal(got, oracle.resize_surface(frame, "NV12", 424, 232, 212, 116))
+
+
+def test_resize_errors(vali, gpu):
+    with pytest.raises(RuntimeError):                      # TaskResizeSurface.cpp:307-308
+        vali.PySurfaceResizer(vali.PixelFormat.UNDEFINED if False else vali.PixelFormat.GRAY12, gpu)
+    rs = vali.PySurfaceResizer(vali.NV12, gpu)
+    a = vali.Surface.Make(vali.NV12, 64, 48, gpu)
+    b = vali.Surface.Make(vali.YUV420, 32, 24, gpu)
+    assert rs.Run(a, b) == (False, vali.TaskExecInfo.INVALID_INPUT)   # :46-48
+
+
+def test_resize_batch_2160p_to_720p(vali, gpu, oracle):
+    """BASELINE config 3 geometry (batch reduced to 4 for the oracle's sake)."""
+    sw, sh, dw, dh, n = 3840, 2160, 1280, 720, 4
+    rs = vali.PySurfaceResizer(vali.NV12, gpu)
+    rng = np.random.default_rng(5)
+    frames = [rng.integers(0, 256, sw * sh * 3 // 2, dtype=np.uint8) for _ in range(2)]
+    srcs = [vali.Surface.Make(vali.NV12, sw, sh, gpu) for _ in range(n)]
+    dsts = [vali.Surface.Make(vali.NV12, dw, dh, gpu) for _ in range(n)]
+    for i, s in enumerate(srcs):
+        assert vali.PyFrameUploader(gpu).Run(frames[i % 2], s)[0]
+    assert rs.RunBatch(srcs, dsts) == (True, vali.TaskExecInfo.SUCCESS)
+    wants = [oracle.resize_surface(f, "NV12", sw, sh, dw, dh) for f in frames]
+    for i, d in enumerate(dsts):
+        out = np.zeros(d.HostSize, np.uint8)
+        assert vali.PySurfaceDownloader(gpu).Run(d, out)[0]
+        assert np.array_equal(out, wants[i % 2])

@@ -336,6 +336,20 @@ PYBIND11_MODULE(_vali_shim, m) {
         },
         py::call_guard<py::gil_scoped_release>());
 
+  m.def("resize",
+        [](const SurfaceDesc& src, const SurfaceDesc& dst, int interp, uintptr_t stream) {
+          return vali_resize(&src.s, &dst.s, interp, P(stream));
+        },
+        py::call_guard<py::gil_scoped_release>());
+  m.def("resize_batch",
+        [](uintptr_t d_src, uintptr_t d_dst, int n, int format, int dst_w, int dst_h, int interp,
+           uintptr_t stream) {
+          return vali_resize_batch((const vali_surface*)P(d_src), (const vali_surface*)P(d_dst), n,
+                                   format, dst_w, dst_h, interp, P(stream));
+        },
+        py::call_guard<py::gil_scoped_release>());
+  m.attr("INTERP_LINEAR") = (int)VALI_INTERP_LINEAR;
+
   m.def("rotate_plane",
         [](uintptr_t src, int spitch, int sw, int sh, uintptr_t dst, int dpitch, int dw, int dh,
            int elem, int channels, double angle, double shx, double shy, uintptr_t stream) {

@@ -1,0 +1,240 @@
+// Surface resize, all planes of a surface in ONE launch.
+//
+// Replaces the reference's ResizeSurface implementations, which call nppiResize_8u_C1R /
+// nppiResize_8u_C3R / nppiResize_32f_C{1,3}R per plane and round-trip NV12 through two
+// temporary YUV420 surfaces: NV12 -> YUV420 -> 3x nppiResize -> YUV420 -> NV12, five kernels
+// and ~41 MB of traffic for a 2160p -> 720p frame
+// (reference: src/TC/src/TaskResizeSurface.cpp:34-286; NV12 path :132-188).  Here the Y
+// plane and the interleaved UV plane (as a 2-channel image) are resized by one kernel.
+//
+// Interpolation: BILINEAR (BASELINE config 3) on NPP's sampling grid.  The reference
+// hard-codes NPPI_INTER_LANCZOS (TaskResizeSurface.cpp:67,116,224,273) and has no switch;
+// Lanczos is listed as "next" (SURVEY.md 8f-4).  GEOMETRY is pinned by the reference's own
+// fixture: tests/data/test_small.nv12 (the expected 848x464 -> 424x232 output of
+// tests/test_PySurfaceResizer.py) equals src[2y][2x] of the frame (41.7 dB through JPEG noise)
+// and NOT the centre-aligned (x+0.5)*s-0.5 sample (26.4 dB) -- tests/test_oracle_resize.py.
+// So nppiResize maps dst -> src as  src = dst * (src_size / dst_size), no half-pixel shift.
+// Specification (oracle: vali_oracle_resize_plane), per plane (sw x sh) -> (dw x dh):
+//   scale = (float)sw / (float)dw
+//   fx = x * scale ; i = floor(fx) ; a = fx - i
+//   i = min(i, sw-1) ; i1 = min(i+1, sw-1)            (same for y -> j, b)
+//   t0 = fma(a, T[j][i1]-T[j][i], T[j][i]) ; t1 on row j1 ; v = fma(b, t1-t0, t0)
+//   u8/u16: round-half-even + saturate ; f32: v
+// One lane = 4 adjacent dst pixels of one plane row; 64x4 lanes per workgroup; plane jobs
+// are concatenated in the XCD-contiguous TileMap.  Source texels are gathered through
+// L1/L2; HBM traffic = touched source lines + dst.
+#include "common.hpp"
+#include "dev_util.hpp"
+
+namespace vali {
+
+struct ResizeJob {
+  int comp;        // component index in vali_surface.plane[] (src and dst)
+  int sub_x, sub_y; // log2 subsampling of this plane relative to the surface size
+  int channels;    // interleaved channels in the plane
+  u32 first_tile;  // index of this job's first tile in the frame's tile list
+  u32 tiles_x;
+};
+
+struct ResizeArgs {
+  const vali_surface* d_src;
+  const vali_surface* d_dst;
+  vali_surface src, dst;
+  ResizeJob job[3];
+  int njobs;
+  TileMap map;
+};
+
+template <typename T> __device__ __forceinline__ float rs_load(const uint8_t* row, int idx) {
+  return (float)((const T*)row)[idx];
+}
+template <typename T> __device__ __forceinline__ T rs_finish(float v);
+template <> __device__ __forceinline__ uint8_t rs_finish<uint8_t>(float v) { return (uint8_t)quantize_u8(v); }
+template <> __device__ __forceinline__ uint16_t rs_finish<uint16_t>(float v) {
+  float r = __builtin_rintf(v);
+  return (uint16_t)__builtin_fminf(__builtin_fmaxf(r, 0.0f), 65535.0f);
+}
+template <> __device__ __forceinline__ float rs_finish<float>(float v) { return v; }
+
+struct Lerp {
+  int i0, i1;
+  float a;
+};
+
+__device__ __forceinline__ Lerp make_lerp(int x, float scale, int size) {
+  const float f = (float)x * scale;
+  const float fl = __builtin_floorf(f);
+  Lerp l;
+  l.a = f - fl;
+  const int i = (int)fl;
+  l.i0 = min(i, size - 1);
+  l.i1 = min(i + 1, size - 1);
+  return l;
+}
+
+template <typename T, int C>
+__device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int sw, int sh,
+                                            uint8_t* dp, int dpitch, int dw, int dh, u32 tx,
+                                            u32 ty) {
+  const int x0 = (tx * 64 + (threadIdx.x & 63)) * 4;
+  const int y = ty * 4 + (threadIdx.x >> 6);
+  if (x0 >= dw || y >= dh)
+    return;
+  const float scale_x = (float)sw / (float)dw, scale_y = (float)sh / (float)dh;
+  const Lerp ly = make_lerp(y, scale_y, sh);
+  const uint8_t* r0 = sp + (size_t)ly.i0 * spitch;
+  const uint8_t* r1 = sp + (size_t)ly.i1 * spitch;
+  T out[4][C];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const Lerp lx = make_lerp(min(x0 + p, dw - 1), scale_x, sw);
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) {
+      const float t00 = rs_load<T>(r0, lx.i0 * C + ch), t10 = rs_load<T>(r0, lx.i1 * C + ch);
+      const float t01 = rs_load<T>(r1, lx.i0 * C + ch), t11 = rs_load<T>(r1, lx.i1 * C + ch);
+      const float t0 = __builtin_fmaf(lx.a, t10 - t00, t00);
+      const float t1 = __builtin_fmaf(lx.a, t11 - t01, t01);
+      out[p][ch] = rs_finish<T>(__builtin_fmaf(ly.a, t1 - t0, t0));
+    }
+  }
+  T* drow = (T*)(dp + (size_t)y * dpitch) + (size_t)x0 * C;
+  const int n = min(4, dw - x0);
+  constexpr int kBytes = 4 * C * (int)sizeof(T);
+  if (n == 4 && (((uintptr_t)drow) & (kBytes % 16 == 0 ? 15u : 3u)) == 0 && kBytes % 4 == 0) {
+    u32 w[kBytes / 4];
+    __builtin_memcpy(w, out, kBytes);
+    if constexpr (kBytes % 16 == 0) {
+#pragma unroll
+      for (int k = 0; k < kBytes / 16; ++k)
+        ((uint4*)drow)[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < kBytes / 4; ++k)
+        ((u32*)drow)[k] = w[k];
+    }
+  } else {
+    for (int p = 0; p < n; ++p)
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch)
+        drow[p * C + ch] = out[p][ch];
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_resize(const ResizeArgs a) {
+  const u32 b = blockIdx.x;
+  const u32 t = (b & 7u) * a.map.per_xcd + (b >> 3);
+  if (t >= a.map.total)
+    return;
+  int j = 0;
+  if (a.njobs > 1 && t >= a.job[1].first_tile)
+    j = 1;
+  if (a.njobs > 2 && t >= a.job[2].first_tile)
+    j = 2;
+  const ResizeJob job = a.job[j];
+  const u32 local = t - job.first_tile;
+  const u32 ty = local / job.tiles_x, tx = local - ty * job.tiles_x;
+  const SurfRef s = load_surface(a.d_src, a.src, blockIdx.y);
+  const SurfRef d = load_surface(a.d_dst, a.dst, blockIdx.y);
+  const int sw = s.width >> job.sub_x, sh = s.height >> job.sub_y;
+  const int dw = d.width >> job.sub_x, dh = d.height >> job.sub_y;
+  const uint8_t* sp = s.p[job.comp];
+  uint8_t* dp = d.p[job.comp];
+  const int spitch = s.pitch[job.comp], dpitch = d.pitch[job.comp];
+  switch (job.channels) {
+  case 1: resize_tile<T, 1>(sp, spitch, sw, sh, dp, dpitch, dw, dh, tx, ty); break;
+  case 2: resize_tile<T, 2>(sp, spitch, sw, sh, dp, dpitch, dw, dh, tx, ty); break;
+  default: resize_tile<T, 3>(sp, spitch, sw, sh, dp, dpitch, dw, dh, tx, ty); break;
+  }
+}
+
+// plane jobs per pixel format: which components, their subsampling and channel count
+static int resize_jobs(int fmt, ResizeJob* j, int* elem) {
+  auto set = [&](int k, int comp, int sx, int sy, int ch) {
+    j[k].comp = comp; j[k].sub_x = sx; j[k].sub_y = sy; j[k].channels = ch;
+  };
+  *elem = 1;
+  switch (fmt) {
+  case VALI_FMT_Y: set(0, 0, 0, 0, 1); return 1;
+  case VALI_FMT_NV12: set(0, 0, 0, 0, 1); set(1, 1, 1, 1, 2); return 2;
+  case VALI_FMT_P10: case VALI_FMT_P12: *elem = 2; set(0, 0, 0, 0, 1); set(1, 1, 1, 1, 2); return 2;
+  case VALI_FMT_YUV420: set(0, 0, 0, 0, 1); set(1, 1, 1, 1, 1); set(2, 2, 1, 1, 1); return 3;
+  case VALI_FMT_YUV420_10BIT: *elem = 2; set(0, 0, 0, 0, 1); set(1, 1, 1, 1, 1); set(2, 2, 1, 1, 1); return 3;
+  case VALI_FMT_YUV422: set(0, 0, 0, 0, 1); set(1, 1, 1, 0, 1); set(2, 2, 1, 0, 1); return 3;
+  case VALI_FMT_YUV444: case VALI_FMT_RGB_PLANAR: set(0, 0, 0, 0, 1); set(1, 1, 0, 0, 1); set(2, 2, 0, 0, 1); return 3;
+  case VALI_FMT_YUV444_10BIT: *elem = 2; set(0, 0, 0, 0, 1); set(1, 1, 0, 0, 1); set(2, 2, 0, 0, 1); return 3;
+  case VALI_FMT_RGB_32F_PLANAR: *elem = 4; set(0, 0, 0, 0, 1); set(1, 1, 0, 0, 1); set(2, 2, 0, 0, 1); return 3;
+  case VALI_FMT_RGB: case VALI_FMT_BGR: set(0, 0, 0, 0, 3); return 1;
+  case VALI_FMT_RGB_32F: *elem = 4; set(0, 0, 0, 0, 3); return 1;
+  default: return 0;
+  }
+}
+
+static int launch_resize(ResizeArgs& a, int fmt, int dst_w, int dst_h, int n, hipStream_t stream) {
+  int elem = 1;
+  a.njobs = resize_jobs(fmt, a.job, &elem);
+  if (!a.njobs)
+    return fail(VALI_ERR_UNSUPPORTED, "resize: unsupported pixel format %d", fmt);
+  u32 total = 0;
+  for (int k = 0; k < a.njobs; ++k) {
+    const int dw = dst_w >> a.job[k].sub_x, dh = dst_h >> a.job[k].sub_y;
+    if (dw <= 0 || dh <= 0)
+      return fail(VALI_ERR_INVALID_ARG, "resize: destination too small for its chroma planes");
+    a.job[k].first_tile = total;
+    a.job[k].tiles_x = (u32)(dw + 255) / 256;
+    total += a.job[k].tiles_x * (u32)((dh + 3) / 4);
+  }
+  a.map.total = total;
+  a.map.per_xcd = (total + 7u) / 8u;
+  a.map.tiles_x = 1;
+  const dim3 grid(a.map.per_xcd * 8u, n), block(kBlock);
+  if (elem == 1)
+    hipLaunchKernelGGL(k_resize<uint8_t>, grid, block, 0, stream, a);
+  else if (elem == 2)
+    hipLaunchKernelGGL(k_resize<uint16_t>, grid, block, 0, stream, a);
+  else
+    hipLaunchKernelGGL(k_resize<float>, grid, block, 0, stream, a);
+  VALI_LAUNCH_CHECK();
+  return VALI_OK;
+}
+
+} // namespace vali
+
+using namespace vali;
+
+extern "C" {
+
+int vali_resize(const vali_surface* src, const vali_surface* dst, int interpolation,
+                vali_stream_t stream) {
+  VALI_REQUIRE(src && dst, "null argument");
+  VALI_REQUIRE(src->format == dst->format, "src/dst format mismatch");
+  VALI_REQUIRE(src->width > 0 && src->height > 0 && dst->width > 0 && dst->height > 0, "empty surface");
+  VALI_REQUIRE(src->plane[0] && dst->plane[0], "null plane");
+  if (interpolation != VALI_INTERP_LINEAR)
+    return fail(VALI_ERR_UNSUPPORTED, "resize: interpolation %d not implemented", interpolation);
+  ResizeArgs a = {};
+  a.src = *src;
+  a.dst = *dst;
+  hipStream_t s = as_stream(stream);
+  DeviceScope scope(stream_device(s));
+  return launch_resize(a, src->format, dst->width, dst->height, 1, s);
+}
+
+int vali_resize_batch(const vali_surface* d_src, const vali_surface* d_dst, int n, int format,
+                      int dst_width, int dst_height, int interpolation, vali_stream_t stream) {
+  VALI_REQUIRE(d_src && d_dst, "null argument");
+  VALI_REQUIRE(dst_width > 0 && dst_height > 0, "empty geometry");
+  VALI_REQUIRE(n >= 0 && n <= 65535, "batch size out of range (0..65535)");
+  if (interpolation != VALI_INTERP_LINEAR)
+    return fail(VALI_ERR_UNSUPPORTED, "resize: interpolation %d not implemented", interpolation);
+  if (n == 0)
+    return VALI_OK;
+  ResizeArgs a = {};
+  a.d_src = d_src;
+  a.d_dst = d_dst;
+  hipStream_t s = as_stream(stream);
+  DeviceScope scope(stream_device(s));
+  return launch_resize(a, format, dst_width, dst_height, n, s);
+}
+
+} // extern "C"

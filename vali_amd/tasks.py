@@ -345,3 +345,67 @@ class PySurfaceRotator(_SurfaceTask):
         d = self._run(src, dst, float(angle), float(shift_x), float(shift_y))
         self._sync()
         return d.success, d.info
+
+
+# ---- PySurfaceResizer --------------------------------------------------------------------
+_RESIZE_FORMATS = (F.RGB, F.BGR, F.YUV420, F.YUV444, F.RGB_PLANAR, F.RGB_32F, F.RGB_32F_PLANAR, F.NV12,
+                   # beyond the reference's list (TaskResizeSurface.cpp:293-309): same kernel
+                   F.Y, F.P10, F.P12, F.YUV422, F.YUV420_10bit, F.YUV444_10bit)
+
+
+class PySurfaceResizer(_SurfaceTask):
+    """Resize a Surface to the size of the destination Surface.
+
+    reference: src/python_vali/src/PySurfaceResizer.cpp:28-147; ResizeSurface
+    (src/TC/src/TaskResizeSurface.cpp:293-328).  One launch resizes every plane (NV12 needs
+    five NPP launches and two temporaries in the reference).  Interpolation is bilinear
+    (BASELINE.json config 3); the reference's NPP Lanczos is not reproduced yet.
+    RGB_PLANAR: the reference resizes the 3 stacked planes as ONE W x 3H image so rows
+    bleed across channel seams (TaskResizeSurface.cpp:298, Surfaces.hpp:409); here each
+    channel is resized on its own.
+    """
+
+    def __init__(self, format: PixelFormat, gpu_id: int, stream=None):
+        fmt = PixelFormat(format)
+        if fmt not in _RESIZE_FORMATS:                       # TaskResizeSurface.cpp:307-308
+            raise RuntimeError("pixel format not supported")
+        super().__init__(gpu_id, stream)
+        self._format = fmt
+
+    @property
+    def Format(self) -> PixelFormat:
+        return self._format
+
+    def _run(self, src: Surface, dst: Surface) -> TaskExecDetails:
+        if src is None or dst is None or src.IsEmpty or dst.IsEmpty:
+            return _S_INVALID
+        if dst.Format != src.Format or src.Format != self._format:   # :46-48, :93-95
+            return _S_INVALID
+        return _status(shim.resize(src.desc(), dst.desc(), shim.INTERP_LINEAR, self._stream))
+
+    def RunAsync(self, src: Surface, dst: Surface) -> Tuple[bool, TaskExecInfo]:
+        d = self._run(src, dst)
+        return d.success, d.info
+
+    def Run(self, src: Surface, dst: Surface) -> Tuple[bool, TaskExecInfo]:
+        d = self._run(src, dst)
+        self._sync()
+        return d.success, d.info
+
+    def PrepareBatch(self, srcs: Sequence[Surface], dsts: Sequence[Surface]) -> "SurfaceBatch":
+        return SurfaceBatch(self._gpu_id, self._stream, srcs, dsts)
+
+    def RunBatchAsync(self, batch, dsts=None) -> Tuple[bool, TaskExecInfo]:
+        if not isinstance(batch, SurfaceBatch):
+            batch = SurfaceBatch(self._gpu_id, self._stream, batch, dsts)
+        if batch.src_format != batch.dst_format or batch.src_format != self._format:
+            return False, TaskExecInfo.INVALID_INPUT
+        d = _status(shim.resize_batch(batch.d_src, batch.d_dst, batch.n, int(self._format),
+                                      batch.dst_size[0], batch.dst_size[1], shim.INTERP_LINEAR,
+                                      self._stream))
+        return d.success, d.info
+
+    def RunBatch(self, batch, dsts=None) -> Tuple[bool, TaskExecInfo]:
+        r = self.RunBatchAsync(batch, dsts)
+        self._sync()
+        return r
