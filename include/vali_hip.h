@@ -161,6 +161,33 @@ VALI_API int vali_nv12_to_rgb_batch(const vali_surface* d_src,
                                     int height, int dst_format, const vali_csc* csc,
                                     vali_stream_t stream);
 
+/*
+ * Parameters of the generic converter.  yuv2rgb is used by YUV -> RGB pairs; rgb2yuv by
+ * RGB -> YUV / grey pairs: row c = (kR, kG, kB, offset) of output channel c (Y, U/Cb, V/Cr),
+ *   out_c = kB*B + (kG*G + (kR*R + offset))   evaluated with fused multiply-adds.
+ */
+typedef struct vali_cvt_params {
+  vali_csc yuv2rgb;
+  float rgb2yuv[3][4];
+} vali_cvt_params;
+
+/*
+ * Every other 8-bit pair of ConvertSurface::GetSupportedConversions()
+ * (reference: src/TC/src/TaskConvertSurface.cpp:966-994) plus the three element-type
+ * conversions, selected by (src->format, dst->format):
+ *   NV12<->YUV420, NV12->Y, Y->YUV444, RGB<->RGB_PLANAR, RGB<->BGR   byte permutations
+ *   YUV420->RGB/BGR, YUV444->RGB/BGR, NV12->RGB/BGR/RGB_PLANAR       params->yuv2rgb
+ *   RGB/BGR/RGB_PLANAR->YUV444, RGB->YUV420, RGB->Y                  params->rgb2yuv
+ *   P10/P12->NV12 (round(v/256), saturated), RGB->RGB_32F (v/255), RGB_32F->RGB_32F_PLANAR
+ * replacing the NPP calls listed at the top of vali_amd/csrc/cvt_generic.hip.
+ * 4:2:0 formats need even width and height.  Unsupported pair -> VALI_ERR_UNSUPPORTED.
+ */
+VALI_API int vali_convert(const vali_surface* src, const vali_surface* dst,
+                          const vali_cvt_params* params, vali_stream_t stream);
+VALI_API int vali_convert_batch(const vali_surface* d_src, const vali_surface* d_dst, int n,
+                                int src_format, int dst_format, int width, int height,
+                                const vali_cvt_params* params, vali_stream_t stream);
+
 /* ---- UD: chroma upsample + resize (+ YUV->RGB) in one pass ---------------------- */
 
 /*

@@ -35,10 +35,8 @@ class Csc(C.Structure):
 
 
 def build(force: bool = False) -> Path:
-    src = HERE / "vali_oracle.c"
-    hdr = HERE / "vali_oracle.h"
-    if force or not LIB.exists() or LIB.stat().st_mtime < max(src.stat().st_mtime,
-                                                             hdr.stat().st_mtime):
+    deps = list(HERE.glob("vali_oracle*.c")) + [HERE / "vali_oracle.h"]
+    if force or not LIB.exists() or LIB.stat().st_mtime < max(d.stat().st_mtime for d in deps):
         subprocess.run(["make", "-C", str(HERE), "-s", "libvali_oracle.so"], check=True)
     return LIB
 
@@ -251,3 +249,77 @@ def resize_surface(host: np.ndarray, fmt: str, sw: int, sh: int, dw: int, dh: in
         out.append(resize_plane(plane, ch, qw, qh).reshape(-1))
         off += n
     return np.concatenate(out)
+
+
+class CvtParams(C.Structure):
+    _fields_ = [("yuv2rgb", Csc), ("rgb2yuv", (C.c_float * 4) * 3)]
+
+
+def cvt_params(csc_variant=None, rgb2yuv_variant=None, csc_tuple=None, rgb2yuv_rows=None) -> CvtParams:
+    p = CvtParams()
+    if csc_tuple is not None:
+        p.yuv2rgb = csc_from_tuple(csc_tuple)
+    elif csc_variant is not None:
+        p.yuv2rgb = csc(csc_variant)
+    if rgb2yuv_rows is not None:
+        for i in range(3):
+            for j in range(4):
+                p.rgb2yuv[i][j] = rgb2yuv_rows[i][j]
+    elif rgb2yuv_variant is not None:
+        rc = lib().vali_oracle_rgb2yuv(rgb2yuv_variant, p.rgb2yuv)
+        if rc:
+            raise ValueError("bad rgb2yuv variant")
+    return p
+
+
+def rgb2yuv_rows(variant: int):
+    p = cvt_params(rgb2yuv_variant=variant)
+    return tuple(tuple(float(p.rgb2yuv[i][j]) for j in range(4)) for i in range(3))
+
+
+_ELEM = {"P10": np.uint16, "P12": np.uint16, "RGB_32F": np.float32, "RGB_32F_PLANAR": np.float32,
+         "YUV444_10bit": np.uint16, "YUV420_10bit": np.uint16}
+
+
+def surface_from_host(host: np.ndarray, fmt: str, w: int, h: int):
+    """Wrap a flat tightly-packed host image (upload layout) as an oracle Surface.
+    Returns (Surface, keepalive)."""
+    dt = _ELEM.get(fmt, np.uint8)
+    flat = np.ascontiguousarray(host).view(dt).reshape(-1)
+    s = Surface()
+    s.width, s.height, s.format = w, h, FMT[fmt]
+    e = np.dtype(dt).itemsize
+    base = flat.ctypes.data
+    if fmt in ("NV12", "P10", "P12"):
+        s.plane[0], s.plane[1] = base, base + w * h * e
+        s.pitch[0] = s.pitch[1] = w * e
+    elif fmt in ("RGB_PLANAR", "RGB_32F_PLANAR"):
+        for c in range(3):
+            s.plane[c] = base + c * w * h * e
+            s.pitch[c] = w * e
+    elif fmt in ("RGB", "BGR", "RGB_32F"):
+        s.plane[0] = base
+        s.pitch[0] = 3 * w * e
+    else:
+        off = 0
+        for c, (pw, ph, ch) in enumerate(host_planes(fmt, w, h)):
+            s.plane[c] = base + off
+            s.pitch[c] = pw * ch * e
+            off += pw * ph * ch * e
+    return s, flat
+
+
+def host_size(fmt: str, w: int, h: int) -> int:
+    e = np.dtype(_ELEM.get(fmt, np.uint8)).itemsize
+    return sum(pw * ph * ch for pw, ph, ch in host_planes(fmt, w, h)) * e
+
+
+def convert(host: np.ndarray, src_fmt: str, dst_fmt: str, w: int, h: int, params: CvtParams) -> np.ndarray:
+    """Generic converter on flat host images; returns the flat dst image (uint8 view)."""
+    s, keep = surface_from_host(host, src_fmt, w, h)
+    out = np.zeros(host_size(dst_fmt, w, h), np.uint8)
+    d, keep2 = surface_from_host(out, dst_fmt, w, h)
+    rc = lib().vali_oracle_convert(C.byref(s), C.byref(d), C.byref(params))
+    if rc:
+        raise RuntimeError(f"vali_oracle_convert {src_fmt}->{dst_fmt} -> {rc}")
+    return out

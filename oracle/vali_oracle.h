@@ -72,6 +72,13 @@ VALI_API int vali_oracle_ud_nv12(const vali_surface* src, const vali_surface* ds
 VALI_API void vali_oracle_ud_rgb_from_yuv(float ny, float nu, float nv, float* rgb);
 VALI_API uint8_t vali_oracle_ud_store_u8(float normalised);
 
+/* Generic format-pair converter (every pair vali_convert implements); see vali_oracle_cvt.c
+ * for the per-pair restatement and its parity status. */
+VALI_API int vali_oracle_convert(const vali_surface* src, const vali_surface* dst,
+                                 const vali_cvt_params* params);
+/* RGB -> YUV matrices: 0 = nppiRGBToYUV (+ row 0 = nppiRGBToGray), 1 = nppiRGBToYCbCr */
+VALI_API int vali_oracle_rgb2yuv(int variant, float m[3][4]);
+
 /* Plane rotation, NPP nppiRotate model with bilinear interpolation
  * (reference: src/TC/src/RotateSurface.cpp:22-125).  Pinned for 90/180/270 degrees by the
  * reference's rotation etalons (tests/test_oracle_rotate.py); other angles: parity unpinned. */

@@ -89,16 +89,16 @@ def build_shim(force=False):
 
 
 def build_oracle(force=False):
-    src = ORACLE / "vali_oracle.c"
+    srcs = sorted(ORACLE.glob("vali_oracle*.c"))
     out = oracle_path()
-    if not src.exists():
+    if not srcs:
         return None
-    if force or _stale(out, [src, ORACLE / "vali_oracle.h"]):
+    if force or _stale(out, srcs + [ORACLE / "vali_oracle.h", ROOT / "include" / "vali_hip.h"]):
         # -mfma so fmaf() is the hardware instruction (same value either way);
         # -ffp-contract=off so nothing else gets fused.  AVX2+FMA exists on every
         # x86-64 host an MI355X ships in.
         _run(["gcc", "-O3", "-std=c11", "-fPIC", "-shared", "-mavx2", "-mfma",
-              "-ffp-contract=off", "-fno-math-errno", "-fopenmp", src, "-o", out, "-lm"])
+              "-ffp-contract=off", "-fno-math-errno", "-fopenmp", *srcs, "-o", out, "-lm"])
     return out
 
 

@@ -33,6 +33,11 @@ private:
 // current device for the null stream).
 int stream_device(hipStream_t stream);
 
+// Dynamic-LDS size that caps residency at `waves_per_cu` (160 KiB LDS per CU), never below
+// `min_bytes` (what the kernel really uses).  Fewer concurrent row streams per L2 measured
+// +4% HBM throughput for the streaming converters (profiles/r01_variants.md).
+unsigned residency_lds_bytes(int block_threads, int waves_per_cu, unsigned min_bytes);
+
 inline hipStream_t as_stream(vali_stream_t s) { return (hipStream_t)s; }
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }

@@ -1,0 +1,557 @@
+// All 8-bit format-pair conversions of ConvertSurface except the tuned NV12->RGB kernel:
+// one templated kernel k_cvt8<SRC,DST> + three element-type kernels (P10/P12->NV12,
+// RGB->RGB_32F, RGB_32F->RGB_32F_PLANAR).
+//
+// Replaces the NPP entry points behind the reference's converter table
+// (reference: src/TC/src/TaskConvertSurface.cpp:158-962; dispatch :1035-1090):
+//   nv12_yuv420   nppiNV12ToYUV420_8u_P2P3R / nppiYCbCr420_8u_P2P3R      (:158-200)
+//   yuv420_nv12   nppiYCbCr420_8u_P3P2R                                   (:706-735)
+//   nv12_y        cuMemcpy2DAsync of the luma plane                       (:202-230)
+//   rbg8_y        nppiRGBToGray_8u_C3C1R                                  (:232-252)
+//   yuv420_rgb/bgr nppiYUV420To{RGB,BGR}_8u_P3C3R / nppiYCbCr420To...     (:254-344)
+//   yuv444_bgr/rgb nppiYCbCrToBGR / nppiYUVTo{BGR,RGB}_8u_P3C3R           (:346-434)
+//   bgr/rgb/rgb_planar -> yuv444  nppi{BGR,RGB}To{YUV,YCbCr}_8u_*         (:481-619)
+//   y_yuv444      nppiSet_8u_C1R(128) x2 + nppiCopy_8u_C1R                (:621-655)
+//   rgb_yuv420    nppiRGBToYUV420_8u_C3P3R / nppiRGBToYCbCr420_8u_C3P3R   (:657-704)
+//   rgb8_(de)interleave nppiCopy_8u_C3P3R / P3C3R                         (:737-796)
+//   rgb_bgr/bgr_rgb nppiSwapChannels_8u_C3R                               (:798-852)
+//   rbg8_rgb32f   nppiScale_8u32f_C3R(0,1)                                (:854-884)
+//   rgb32f_deinterleave nppiCopy_32f_C3P3R                                (:886-916)
+//   p16_nv12      nppiDivC_16u_C1RSfs(256) + nppiConvert_16u8u_C1R        (:918-962)
+//
+// Work decomposition of k_cvt8 = the NV12->RGB kernel's: one lane owns 16 px x 2 rows
+// (the 2x2 chroma footprint), 16-byte plane accesses, packed rows through the per-wave
+// LDS strip, XCD-contiguous TileMap, nt stores, 16 waves/CU residency cap.
+// Arithmetic (bit-exact with oracle/vali_oracle.c: vali_oracle_convert):
+//   YUV->RGB : the vali_csc model of cvt_nv12_rgb.hip (nearest chroma for 4:2:0)
+//   RGB->YUV : c = fma(kB, B, fma(kG, G, fma(kR, R, offset))) per output channel, then
+//              round-half-even + saturate; 4:2:0 chroma = mean of the four un-rounded
+//              values ((c00 + c01) + (c10 + c11)) * 0.25
+//   copies / swaps / (de)interleaves: byte permutations, exact.
+#include "common.hpp"
+#include "dev_util.hpp"
+
+#include <stdlib.h>
+
+namespace vali {
+
+enum : int { K_NV12 = 0, K_YUV420 = 1, K_YUV444 = 2, K_RGB = 3, K_BGR = 4, K_RGBP = 5, K_Y = 6, K_NONE = -1 };
+
+__host__ __device__ constexpr bool k_is420(int k) { return k == K_NV12 || k == K_YUV420; }
+__host__ __device__ constexpr bool k_isyuv(int k) { return k == K_NV12 || k == K_YUV420 || k == K_YUV444; }
+__host__ __device__ constexpr bool k_isrgb(int k) { return k == K_RGB || k == K_BGR || k == K_RGBP; }
+__host__ __device__ constexpr bool k_ispacked(int k) { return k == K_RGB || k == K_BGR; }
+
+struct CvtArgs {
+  const vali_surface* d_src;
+  const vali_surface* d_dst;
+  vali_surface src, dst;
+  vali_cvt_params p;
+  TileMap map;
+};
+
+// ---- per-pixel arithmetic ---------------------------------------------------------------
+struct Chroma {
+  float rv, guv, bu;
+};
+__device__ __forceinline__ Chroma chroma_of(float u, float v, const vali_csc& k) {
+  const float uc = u - 128.0f, vc = v - 128.0f;
+  Chroma t;
+  t.rv = k.crv * vc;
+  t.guv = __builtin_fmaf(k.cgu, uc, k.cgv * vc);
+  t.bu = k.cbu * uc;
+  return t;
+}
+__device__ __forceinline__ float luma_of(float y, const vali_csc& k) { return k.cy * (y - k.y0); }
+
+__device__ __forceinline__ float dot_rgb(const float (&m)[4], float r, float g, float b) {
+  return __builtin_fmaf(m[2], b, __builtin_fmaf(m[1], g, __builtin_fmaf(m[0], r, m[3])));
+}
+
+// 4 pixels: (y4,u4,v4) dwords -> planar r,g,b dwords.  Per-pixel chroma (4:4:4 sources).
+__device__ __forceinline__ void yuv444_to_rgb4(u32 y4, u32 u4, u32 v4, const vali_csc& k, u32& r,
+                                               u32& g, u32& b) {
+  r = g = b = 0;
+#define VALI_PX(I)                                                                          \
+  {                                                                                         \
+    const Chroma c = chroma_of(ubyte_f32<I>(u4), ubyte_f32<I>(v4), k);                       \
+    const float yf = luma_of(ubyte_f32<I>(y4), k);                                           \
+    r = pack_u8<I>(yf + c.rv, r); g = pack_u8<I>(yf + c.guv, g); b = pack_u8<I>(yf + c.bu, b); \
+  }
+  VALI_PX(0) VALI_PX(1) VALI_PX(2) VALI_PX(3)
+#undef VALI_PX
+}
+
+// 4 pixels of one row sharing two chroma samples (4:2:0 sources): px 0,1 <- ca ; px 2,3 <- cb
+__device__ __forceinline__ void yuv420_to_rgb4(u32 y4, const Chroma& ca, const Chroma& cb,
+                                               const vali_csc& k, u32& r, u32& g, u32& b) {
+  const float y0 = luma_of(ubyte_f32<0>(y4), k), y1 = luma_of(ubyte_f32<1>(y4), k),
+              y2 = luma_of(ubyte_f32<2>(y4), k), y3 = luma_of(ubyte_f32<3>(y4), k);
+  r = g = b = 0;
+  r = pack_u8<0>(y0 + ca.rv, r); r = pack_u8<1>(y1 + ca.rv, r); r = pack_u8<2>(y2 + cb.rv, r); r = pack_u8<3>(y3 + cb.rv, r);
+  g = pack_u8<0>(y0 + ca.guv, g); g = pack_u8<1>(y1 + ca.guv, g); g = pack_u8<2>(y2 + cb.guv, g); g = pack_u8<3>(y3 + cb.guv, g);
+  b = pack_u8<0>(y0 + ca.bu, b); b = pack_u8<1>(y1 + ca.bu, b); b = pack_u8<2>(y2 + cb.bu, b); b = pack_u8<3>(y3 + cb.bu, b);
+}
+
+// ---- the 16 x 2 pixel block a lane works on ----------------------------------------------
+struct Block {
+  u32 c0[2][4], c1[2][4], c2[2][4]; // full-resolution channels in canonical order (R,G,B / Y,U,V)
+  u32 cu[2], cv[2];                 // 4:2:0 chroma: 8 samples each (shared by both rows)
+};
+
+struct Geo {
+  int lane, wave, wave_g0, g, x0, row0, groups, valid_lanes;
+  bool lane_valid, has_row1;
+  u32 tile_y;
+};
+
+template <int SRC>
+__device__ __forceinline__ void load_block(Block& b, const SurfRef& s, const Geo& q, PackedStrip& strip) {
+  const int r1 = q.row0 + (q.has_row1 ? 1 : 0);
+  if constexpr (k_ispacked(SRC)) {
+    const uint8_t* rb = s.p[0] + (size_t)q.row0 * s.pitch[0] + (size_t)q.wave_g0 * 48;
+    const int vb = q.valid_lanes * 48;
+    u32 o[12];
+    for (int r = 0; r < 2; ++r) {
+      strip_load_row(strip, q.lane, o, q.lane_valid, r == 0 ? rb : s.p[0] + (size_t)r1 * s.pitch[0] + (size_t)q.wave_g0 * 48, vb);
+      if (q.lane_valid) {
+        if constexpr (SRC == K_RGB) deinterleave3(o, b.c0[r], b.c1[r], b.c2[r]);
+        else deinterleave3(o, b.c2[r], b.c1[r], b.c0[r]);
+      }
+    }
+    return;
+  }
+  if (!q.lane_valid)
+    return;
+  auto ld = [&](const uint8_t* plane, int pitch, int row, u32 (&dst)[4]) {
+    const uint4 v = load16(plane + (size_t)row * pitch + q.x0);
+    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+  };
+  ld(s.p[0], s.pitch[0], q.row0, b.c0[0]);
+  ld(s.p[0], s.pitch[0], r1, b.c0[1]);
+  if constexpr (SRC == K_YUV444 || SRC == K_RGBP) {
+    ld(s.p[1], s.pitch[1], q.row0, b.c1[0]); ld(s.p[1], s.pitch[1], r1, b.c1[1]);
+    ld(s.p[2], s.pitch[2], q.row0, b.c2[0]); ld(s.p[2], s.pitch[2], r1, b.c2[1]);
+  } else if constexpr (SRC == K_NV12) {
+    const uint4 uv = load16(s.p[1] + (size_t)q.tile_y * s.pitch[1] + q.x0);
+    b.cu[0] = __builtin_amdgcn_perm(uv.y, uv.x, 0x06040200u); b.cv[0] = __builtin_amdgcn_perm(uv.y, uv.x, 0x07050301u);
+    b.cu[1] = __builtin_amdgcn_perm(uv.w, uv.z, 0x06040200u); b.cv[1] = __builtin_amdgcn_perm(uv.w, uv.z, 0x07050301u);
+  } else if constexpr (SRC == K_YUV420) {
+    const uint2 u = *reinterpret_cast<const uint2*>(s.p[1] + (size_t)q.tile_y * s.pitch[1] + q.x0 / 2);
+    const uint2 v = *reinterpret_cast<const uint2*>(s.p[2] + (size_t)q.tile_y * s.pitch[2] + q.x0 / 2);
+    b.cu[0] = u.x; b.cu[1] = u.y; b.cv[0] = v.x; b.cv[1] = v.y;
+  }
+}
+
+template <int DST>
+__device__ __forceinline__ void store_block(const Block& b, const SurfRef& d, const Geo& q, PackedStrip& strip) {
+  if constexpr (k_ispacked(DST)) {
+    uint8_t* rb = d.p[0] + (size_t)q.row0 * d.pitch[0] + (size_t)q.wave_g0 * 48;
+    const int vb = q.valid_lanes * 48;
+    u32 o[12];
+    for (int r = 0; r < (q.has_row1 ? 2 : 1); ++r) {
+      if (q.lane_valid) {
+        if constexpr (DST == K_RGB) interleave3(b.c0[r], b.c1[r], b.c2[r], o);
+        else interleave3(b.c2[r], b.c1[r], b.c0[r], o);
+      }
+      strip_store_row(strip, q.lane, o, q.lane_valid, rb + (size_t)r * d.pitch[0], vb);
+    }
+    return;
+  }
+  if (!q.lane_valid)
+    return;
+  auto st = [&](uint8_t* plane, int pitch, int row, const u32 (&src)[4]) {
+    store16_nt(plane + (size_t)row * pitch + q.x0, make_uint4(src[0], src[1], src[2], src[3]));
+  };
+  st(d.p[0], d.pitch[0], q.row0, b.c0[0]);
+  if (q.has_row1) st(d.p[0], d.pitch[0], q.row0 + 1, b.c0[1]);
+  if constexpr (DST == K_YUV444 || DST == K_RGBP) {
+    st(d.p[1], d.pitch[1], q.row0, b.c1[0]); st(d.p[2], d.pitch[2], q.row0, b.c2[0]);
+    if (q.has_row1) { st(d.p[1], d.pitch[1], q.row0 + 1, b.c1[1]); st(d.p[2], d.pitch[2], q.row0 + 1, b.c2[1]); }
+  } else if constexpr (DST == K_NV12) {
+    const uint4 uv = make_uint4(__builtin_amdgcn_perm(b.cv[0], b.cu[0], 0x05010400u), __builtin_amdgcn_perm(b.cv[0], b.cu[0], 0x07030602u),
+                                __builtin_amdgcn_perm(b.cv[1], b.cu[1], 0x05010400u), __builtin_amdgcn_perm(b.cv[1], b.cu[1], 0x07030602u));
+    store16_nt(d.p[1] + (size_t)q.tile_y * d.pitch[1] + q.x0, uv);
+  } else if constexpr (DST == K_YUV420) {
+    *reinterpret_cast<uint2*>(d.p[1] + (size_t)q.tile_y * d.pitch[1] + q.x0 / 2) = make_uint2(b.cu[0], b.cu[1]);
+    *reinterpret_cast<uint2*>(d.p[2] + (size_t)q.tile_y * d.pitch[2] + q.x0 / 2) = make_uint2(b.cv[0], b.cv[1]);
+  }
+}
+
+// in-register transform of the block: SRC channels -> DST channels
+template <int SRC, int DST>
+__device__ __forceinline__ void transform_block(Block& b, const vali_cvt_params& p) {
+  if constexpr (k_isyuv(SRC) && k_isrgb(DST)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (k_is420(SRC)) {
+        const u32 cu = b.cu[j >> 1], cv = b.cv[j >> 1];
+        const Chroma ca = (j & 1) ? chroma_of(ubyte_f32<2>(cu), ubyte_f32<2>(cv), p.yuv2rgb) : chroma_of(ubyte_f32<0>(cu), ubyte_f32<0>(cv), p.yuv2rgb);
+        const Chroma cb = (j & 1) ? chroma_of(ubyte_f32<3>(cu), ubyte_f32<3>(cv), p.yuv2rgb) : chroma_of(ubyte_f32<1>(cu), ubyte_f32<1>(cv), p.yuv2rgb);
+        u32 r, g, bb;
+        yuv420_to_rgb4(b.c0[0][j], ca, cb, p.yuv2rgb, r, g, bb);
+        u32 r1, g1, b1;
+        yuv420_to_rgb4(b.c0[1][j], ca, cb, p.yuv2rgb, r1, g1, b1);
+        b.c0[0][j] = r; b.c1[0][j] = g; b.c2[0][j] = bb;
+        b.c0[1][j] = r1; b.c1[1][j] = g1; b.c2[1][j] = b1;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          u32 rr, gg, bb;
+          yuv444_to_rgb4(b.c0[r][j], b.c1[r][j], b.c2[r][j], p.yuv2rgb, rr, gg, bb);
+          b.c0[r][j] = rr; b.c1[r][j] = gg; b.c2[r][j] = bb;
+        }
+      }
+    }
+  } else if constexpr (k_isrgb(SRC) && (k_isyuv(DST) || DST == K_Y)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float us[2][4], vs[2][4];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const u32 R = b.c0[r][j], G = b.c1[r][j], B = b.c2[r][j];
+        u32 y = 0, u = 0, v = 0;
+#define VALI_PX(I)                                                                          \
+  {                                                                                         \
+    const float fr = ubyte_f32<I>(R), fg = ubyte_f32<I>(G), fb = ubyte_f32<I>(B);            \
+    y = pack_u8<I>(dot_rgb(p.rgb2yuv[0], fr, fg, fb), y);                                    \
+    if constexpr (DST != K_Y) {                                                             \
+      const float fu = dot_rgb(p.rgb2yuv[1], fr, fg, fb), fv = dot_rgb(p.rgb2yuv[2], fr, fg, fb); \
+      if constexpr (k_is420(DST)) { us[r][I] = fu; vs[r][I] = fv; }                          \
+      else { u = pack_u8<I>(fu, u); v = pack_u8<I>(fv, v); }                                 \
+    }                                                                                       \
+  }
+        VALI_PX(0) VALI_PX(1) VALI_PX(2) VALI_PX(3)
+#undef VALI_PX
+        b.c0[r][j] = y;
+        if constexpr (DST == K_YUV444) { b.c1[r][j] = u; b.c2[r][j] = v; }
+      }
+      if constexpr (k_is420(DST)) {
+        // 2x2 mean of the un-rounded chroma: ((c00 + c01) + (c10 + c11)) * 0.25
+        const float ua = ((us[0][0] + us[0][1]) + (us[1][0] + us[1][1])) * 0.25f;
+        const float ub = ((us[0][2] + us[0][3]) + (us[1][2] + us[1][3])) * 0.25f;
+        const float va = ((vs[0][0] + vs[0][1]) + (vs[1][0] + vs[1][1])) * 0.25f;
+        const float vb = ((vs[0][2] + vs[0][3]) + (vs[1][2] + vs[1][3])) * 0.25f;
+        u32& cu = b.cu[j >> 1];
+        u32& cv = b.cv[j >> 1];
+        if (j & 1) { cu = pack_u8<2>(ua, cu); cu = pack_u8<3>(ub, cu); cv = pack_u8<2>(va, cv); cv = pack_u8<3>(vb, cv); }
+        else { cu = pack_u8<0>(ua, 0u); cu = pack_u8<1>(ub, cu); cv = pack_u8<0>(va, 0u); cv = pack_u8<1>(vb, cv); }
+      }
+    }
+  } else if constexpr (SRC == K_Y && DST == K_YUV444) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b.c1[r][j] = b.c2[r][j] = 0x80808080u;
+  }
+  // everything else (NV12<->YUV420, RGB<->RGB_PLANAR, RGB<->BGR, NV12->Y) is a pure
+  // relabelling of the loaded channels: load_block / store_block do the permutation.
+}
+
+// ---- byte-granular path: any width / alignment, one 2x2 quad at a time ---------------------
+template <int K> __device__ __forceinline__ void px_read(const SurfRef& s, int x, int y, float (&c)[3]) {
+  if constexpr (K == K_RGB || K == K_BGR) {
+    const uint8_t* q = s.p[0] + (size_t)y * s.pitch[0] + (size_t)x * 3;
+    c[0] = (float)q[K == K_RGB ? 0 : 2]; c[1] = (float)q[1]; c[2] = (float)q[K == K_RGB ? 2 : 0];
+  } else if constexpr (K == K_RGBP || K == K_YUV444) {
+    for (int k = 0; k < 3; ++k) c[k] = (float)s.p[k][(size_t)y * s.pitch[k] + x];
+  } else if constexpr (K == K_NV12) {
+    c[0] = (float)s.p[0][(size_t)y * s.pitch[0] + x];
+    const uint8_t* q = s.p[1] + (size_t)(y >> 1) * s.pitch[1] + (x & ~1);
+    c[1] = (float)q[0]; c[2] = (float)q[1];
+  } else if constexpr (K == K_YUV420) {
+    c[0] = (float)s.p[0][(size_t)y * s.pitch[0] + x];
+    c[1] = (float)s.p[1][(size_t)(y >> 1) * s.pitch[1] + (x >> 1)];
+    c[2] = (float)s.p[2][(size_t)(y >> 1) * s.pitch[2] + (x >> 1)];
+  } else {
+    c[0] = (float)s.p[0][(size_t)y * s.pitch[0] + x]; c[1] = c[2] = 128.0f;
+  }
+}
+
+template <int SRC, int DST>
+__device__ void quad_slow(const SurfRef& s, const SurfRef& d, int qx, int qy, const vali_cvt_params& p) {
+  float acc_u[4], acc_v[4];
+  for (int dy = 0; dy < 2; ++dy)
+    for (int dx = 0; dx < 2; ++dx) {
+      const int x = qx * 2 + dx, y = qy * 2 + dy;
+      const bool in = x < s.width && y < s.height;
+      float c[3] = {0.f, 128.f, 128.f}, o[3];
+      if (in) px_read<SRC>(s, x, y, c);
+      if constexpr (k_isyuv(SRC) && k_isrgb(DST)) {
+        const Chroma t = chroma_of(c[1], c[2], p.yuv2rgb);
+        const float yf = luma_of(c[0], p.yuv2rgb);
+        o[0] = yf + t.rv; o[1] = yf + t.guv; o[2] = yf + t.bu;
+      } else if constexpr (k_isrgb(SRC) && (k_isyuv(DST) || DST == K_Y)) {
+        o[0] = dot_rgb(p.rgb2yuv[0], c[0], c[1], c[2]);
+        o[1] = dot_rgb(p.rgb2yuv[1], c[0], c[1], c[2]);
+        o[2] = dot_rgb(p.rgb2yuv[2], c[0], c[1], c[2]);
+      } else {
+        o[0] = c[0]; o[1] = c[1]; o[2] = c[2];
+      }
+      acc_u[dy * 2 + dx] = o[1]; acc_v[dy * 2 + dx] = o[2];
+      if (!in) continue;
+      const uint8_t q0 = (uint8_t)quantize_u8(o[0]), q1 = (uint8_t)quantize_u8(o[1]), q2 = (uint8_t)quantize_u8(o[2]);
+      if constexpr (DST == K_RGB || DST == K_BGR) {
+        uint8_t* w = d.p[0] + (size_t)y * d.pitch[0] + (size_t)x * 3;
+        w[DST == K_RGB ? 0 : 2] = q0; w[1] = q1; w[DST == K_RGB ? 2 : 0] = q2;
+      } else if constexpr (DST == K_RGBP || DST == K_YUV444) {
+        d.p[0][(size_t)y * d.pitch[0] + x] = q0; d.p[1][(size_t)y * d.pitch[1] + x] = q1; d.p[2][(size_t)y * d.pitch[2] + x] = q2;
+      } else {
+        d.p[0][(size_t)y * d.pitch[0] + x] = q0; // luma of NV12 / YUV420 / Y
+      }
+    }
+  if constexpr (k_is420(DST)) {
+    const int x = qx * 2, y = qy * 2;
+    if (x < s.width && y < s.height) {
+      float fu, fv;
+      if constexpr (k_is420(SRC)) { fu = acc_u[0]; fv = acc_v[0]; }      // repack: the shared sample
+      else {
+        fu = ((acc_u[0] + acc_u[1]) + (acc_u[2] + acc_u[3])) * 0.25f;
+        fv = ((acc_v[0] + acc_v[1]) + (acc_v[2] + acc_v[3])) * 0.25f;
+      }
+      const uint8_t qu = (uint8_t)quantize_u8(fu), qv = (uint8_t)quantize_u8(fv);
+      if constexpr (DST == K_NV12) {
+        uint8_t* w = d.p[1] + (size_t)qy * d.pitch[1] + x;
+        w[0] = qu; w[1] = qv;
+      } else {
+        d.p[1][(size_t)qy * d.pitch[1] + qx] = qu; d.p[2][(size_t)qy * d.pitch[2] + qx] = qv;
+      }
+    }
+  }
+}
+
+template <int K> __device__ __forceinline__ uintptr_t align_bits_of(const SurfRef& s) {
+  uintptr_t a = (uintptr_t)s.p[0] | (uintptr_t)s.pitch[0];
+  if constexpr (K == K_NV12) a |= (uintptr_t)s.p[1] | (uintptr_t)s.pitch[1];
+  if constexpr (K == K_YUV444 || K == K_RGBP) a |= (uintptr_t)s.p[1] | (uintptr_t)s.p[2] | (uintptr_t)s.pitch[1] | (uintptr_t)s.pitch[2];
+  if constexpr (K == K_YUV420) a |= (((uintptr_t)s.p[1] | (uintptr_t)s.p[2] | (uintptr_t)s.pitch[1] | (uintptr_t)s.pitch[2]) & 7u) << 1; // 8-B chroma vectors
+  return a;
+}
+
+template <int SRC, int DST>
+__global__ void __launch_bounds__(kBlock) k_cvt8(const CvtArgs a) {
+  extern __shared__ uint4 dyn_lds[];
+  PackedStrip* const strips = reinterpret_cast<PackedStrip*>(dyn_lds);
+  u32 tile_x, tile_y;
+  if (!tile_of_block(a.map, tile_x, tile_y))
+    return;
+  const SurfRef s = load_surface(a.d_src, a.src, blockIdx.y);
+  const SurfRef d = load_surface(a.d_dst, a.dst, blockIdx.y);
+  const int W = s.width, H = s.height;
+  Geo q;
+  q.lane = threadIdx.x & (kWave - 1);
+  q.wave = threadIdx.x / kWave;
+  q.wave_g0 = tile_x * blockDim.x + q.wave * kWave;
+  q.groups = (W + kLanePx - 1) / kLanePx;
+  if (q.wave_g0 >= q.groups)
+    return;
+  q.g = q.wave_g0 + q.lane;
+  q.x0 = q.g * kLanePx;
+  q.row0 = tile_y * 2;
+  q.tile_y = tile_y;
+  q.has_row1 = q.row0 + 1 < H;
+  q.lane_valid = q.g < q.groups;
+  q.valid_lanes = min(kWave, q.groups - q.wave_g0);
+
+  const bool fast = ((W & (kLanePx - 1)) == 0) && (((align_bits_of<SRC>(s) | align_bits_of<DST>(d)) & 15u) == 0);
+  if (fast) {
+    Block b;
+    load_block<SRC>(b, s, q, strips[q.wave]);
+    if (q.lane_valid)
+      transform_block<SRC, DST>(b, a.p);
+    store_block<DST>(b, d, q, strips[q.wave]);
+    return;
+  }
+  if (!q.lane_valid)
+    return;
+  for (int k = 0; k < 8; ++k)
+    quad_slow<SRC, DST>(s, d, q.x0 / 2 + k, tile_y, a.p);
+}
+
+// ---- element-type kernels ------------------------------------------------------------------
+struct ElemArgs {
+  const vali_surface* d_src;
+  const vali_surface* d_dst;
+  vali_surface src, dst;
+  TileMap map;
+};
+
+// P10/P12 (MSB-aligned u16) -> NV12: round(v / 256) saturated, on the whole W x 1.5H plane.
+__global__ void __launch_bounds__(kBlock) k_p16_to_nv12(const ElemArgs a) {
+  u32 tx, ty;
+  if (!tile_of_block(a.map, tx, ty))
+    return;
+  const SurfRef s = load_surface(a.d_src, a.src, blockIdx.y);
+  const SurfRef d = load_surface(a.d_dst, a.dst, blockIdx.y);
+  const int W = s.width, rows = s.height + (s.height + 1) / 2; // luma rows + chroma rows (p[0] spans both)
+  const int x0 = (tx * kBlock + threadIdx.x) * 8, y = ty;
+  if (x0 >= W || y >= rows)
+    return;
+  const uint8_t* srow = s.p[0] + (size_t)y * s.pitch[0];
+  uint8_t* drow = d.p[0] + (size_t)y * d.pitch[0];
+  if (x0 + 8 <= W && ((((uintptr_t)srow) & 15u) == 0) && ((((uintptr_t)drow) & 7u) == 0)) {
+    const uint4 v = load16(srow + (size_t)x0 * 2);
+    auto cv = [](u32 w) { const u32 lo = min(((w & 0xffffu) + 128u) >> 8, 255u), hi = min(((w >> 16) + 128u) >> 8, 255u); return lo | (hi << 8); };
+    const u32 a0 = cv(v.x) | (cv(v.y) << 16), a1 = cv(v.z) | (cv(v.w) << 16);
+    *reinterpret_cast<uint2*>(drow + x0) = make_uint2(a0, a1);
+  } else {
+    for (int k = 0; k < 8 && x0 + k < W; ++k)
+      drow[x0 + k] = (uint8_t)min((((const uint16_t*)srow)[x0 + k] + 128u) >> 8, 255u);
+  }
+}
+
+// RGB u8 -> RGB_32F: f = v / 255 (correctly rounded division), 3W elements per row
+__global__ void __launch_bounds__(kBlock) k_rgb8_to_f32(const ElemArgs a) {
+  u32 tx, ty;
+  if (!tile_of_block(a.map, tx, ty))
+    return;
+  const SurfRef s = load_surface(a.d_src, a.src, blockIdx.y);
+  const SurfRef d = load_surface(a.d_dst, a.dst, blockIdx.y);
+  const int n = s.width * 3, y = ty;
+  const int e0 = (tx * kBlock + threadIdx.x) * 4;
+  if (e0 >= n || y >= s.height)
+    return;
+  const uint8_t* srow = s.p[0] + (size_t)y * s.pitch[0];
+  float* drow = (float*)(d.p[0] + (size_t)y * d.pitch[0]);
+  if (e0 + 4 <= n && ((((uintptr_t)srow) & 3u) == 0) && ((((uintptr_t)drow) & 15u) == 0)) {
+    const u32 w = *reinterpret_cast<const u32*>(srow + e0);
+    *reinterpret_cast<float4*>(drow + e0) = make_float4(ubyte_f32<0>(w) / 255.0f, ubyte_f32<1>(w) / 255.0f, ubyte_f32<2>(w) / 255.0f, ubyte_f32<3>(w) / 255.0f);
+  } else {
+    for (int k = 0; k < 4 && e0 + k < n; ++k)
+      drow[e0 + k] = (float)srow[e0 + k] / 255.0f;
+  }
+}
+
+// RGB_32F packed -> RGB_32F_PLANAR: lane = 4 pixels (48 B in, 3 x 16 B out)
+__global__ void __launch_bounds__(kBlock) k_f32_deinterleave(const ElemArgs a) {
+  u32 tx, ty;
+  if (!tile_of_block(a.map, tx, ty))
+    return;
+  const SurfRef s = load_surface(a.d_src, a.src, blockIdx.y);
+  const SurfRef d = load_surface(a.d_dst, a.dst, blockIdx.y);
+  const int W = s.width, y = ty;
+  const int x0 = (tx * kBlock + threadIdx.x) * 4;
+  if (x0 >= W || y >= s.height)
+    return;
+  const float* srow = (const float*)(s.p[0] + (size_t)y * s.pitch[0]) + (size_t)x0 * 3;
+  float* o0 = (float*)(d.p[0] + (size_t)y * d.pitch[0]) + x0;
+  float* o1 = (float*)(d.p[1] + (size_t)y * d.pitch[1]) + x0;
+  float* o2 = (float*)(d.p[2] + (size_t)y * d.pitch[2]) + x0;
+  if (x0 + 4 <= W && (((uintptr_t)srow | (uintptr_t)o0 | (uintptr_t)o1 | (uintptr_t)o2) & 15u) == 0) {
+    const float4 a0 = ((const float4*)srow)[0], a1 = ((const float4*)srow)[1], a2 = ((const float4*)srow)[2];
+    *(float4*)o0 = make_float4(a0.x, a0.w, a1.z, a2.y);
+    *(float4*)o1 = make_float4(a0.y, a1.x, a1.w, a2.z);
+    *(float4*)o2 = make_float4(a0.z, a1.y, a2.x, a2.w);
+  } else {
+    for (int k = 0; k < 4 && x0 + k < W; ++k) { o0[k] = srow[3 * k]; o1[k] = srow[3 * k + 1]; o2[k] = srow[3 * k + 2]; }
+  }
+}
+
+// ---- host side -----------------------------------------------------------------------------
+static int kind_of(int fmt) {
+  switch (fmt) {
+  case VALI_FMT_NV12: return K_NV12;
+  case VALI_FMT_YUV420: return K_YUV420;
+  case VALI_FMT_YUV444: return K_YUV444;
+  case VALI_FMT_RGB: return K_RGB;
+  case VALI_FMT_BGR: return K_BGR;
+  case VALI_FMT_RGB_PLANAR: return K_RGBP;
+  case VALI_FMT_Y: return K_Y;
+  default: return K_NONE;
+  }
+}
+
+template <int SRC, int DST>
+static void launch_cvt8(const CvtArgs& a, dim3 grid, int block, unsigned lds, hipStream_t s) {
+  hipLaunchKernelGGL((k_cvt8<SRC, DST>), grid, dim3(block), lds, s, a);
+}
+
+static int launch_convert(CvtArgs& a, ElemArgs& e, int src_fmt, int dst_fmt, int width, int height, int n,
+                          hipStream_t stream) {
+  // element-type conversions first
+  if ((src_fmt == VALI_FMT_P10 || src_fmt == VALI_FMT_P12) && dst_fmt == VALI_FMT_NV12) {
+    e.map = make_tile_map((width + kBlock * 8 - 1) / (kBlock * 8), height + (height + 1) / 2);
+    hipLaunchKernelGGL(k_p16_to_nv12, dim3(e.map.per_xcd * 8u, n), dim3(kBlock), 0, stream, e);
+    VALI_LAUNCH_CHECK();
+    return VALI_OK;
+  }
+  if (src_fmt == VALI_FMT_RGB && dst_fmt == VALI_FMT_RGB_32F) {
+    e.map = make_tile_map((width * 3 + kBlock * 4 - 1) / (kBlock * 4), height);
+    hipLaunchKernelGGL(k_rgb8_to_f32, dim3(e.map.per_xcd * 8u, n), dim3(kBlock), 0, stream, e);
+    VALI_LAUNCH_CHECK();
+    return VALI_OK;
+  }
+  if (src_fmt == VALI_FMT_RGB_32F && dst_fmt == VALI_FMT_RGB_32F_PLANAR) {
+    e.map = make_tile_map((width + kBlock * 4 - 1) / (kBlock * 4), height);
+    hipLaunchKernelGGL(k_f32_deinterleave, dim3(e.map.per_xcd * 8u, n), dim3(kBlock), 0, stream, e);
+    VALI_LAUNCH_CHECK();
+    return VALI_OK;
+  }
+  const int sk = kind_of(src_fmt), dk = kind_of(dst_fmt);
+  if (sk == K_NONE || dk == K_NONE)
+    return fail(VALI_ERR_UNSUPPORTED, "convert: unsupported pair %d -> %d", src_fmt, dst_fmt);
+  const int groups = (width + kLanePx - 1) / kLanePx;
+  int block = ((groups + kWave - 1) / kWave) * kWave;
+  if (block > kBlock)
+    block = kBlock;
+  a.map = make_tile_map((groups + block - 1) / block, (height + 1) / 2);
+  const dim3 grid(a.map.per_xcd * 8u, n);
+  const unsigned lds = residency_lds_bytes(block, 16, (unsigned)sizeof(PackedStrip) * kWavesPerBlock);
+#define VALI_PAIR(S, D)                                                                     \
+  if (sk == S && dk == D) {                                                                 \
+    launch_cvt8<S, D>(a, grid, block, lds, stream);                                          \
+    VALI_LAUNCH_CHECK();                                                                    \
+    return VALI_OK;                                                                         \
+  }
+  // the pairs of ConvertSurface::GetSupportedConversions() (TaskConvertSurface.cpp:966-994)
+  VALI_PAIR(K_NV12, K_YUV420) VALI_PAIR(K_YUV420, K_NV12) VALI_PAIR(K_NV12, K_RGB) VALI_PAIR(K_NV12, K_BGR)
+  VALI_PAIR(K_NV12, K_RGBP) VALI_PAIR(K_RGB, K_RGBP) VALI_PAIR(K_RGBP, K_RGB) VALI_PAIR(K_RGBP, K_YUV444)
+  VALI_PAIR(K_Y, K_YUV444) VALI_PAIR(K_YUV420, K_RGB) VALI_PAIR(K_RGB, K_YUV420) VALI_PAIR(K_RGB, K_YUV444)
+  VALI_PAIR(K_RGB, K_BGR) VALI_PAIR(K_BGR, K_RGB) VALI_PAIR(K_YUV420, K_BGR) VALI_PAIR(K_YUV444, K_BGR)
+  VALI_PAIR(K_YUV444, K_RGB) VALI_PAIR(K_BGR, K_YUV444) VALI_PAIR(K_NV12, K_Y) VALI_PAIR(K_RGB, K_Y)
+  // natural extras sharing the same code
+  VALI_PAIR(K_YUV444, K_RGBP) VALI_PAIR(K_YUV420, K_RGBP) VALI_PAIR(K_BGR, K_YUV420) VALI_PAIR(K_RGB, K_NV12)
+  VALI_PAIR(K_BGR, K_NV12) VALI_PAIR(K_BGR, K_Y) VALI_PAIR(K_RGBP, K_Y) VALI_PAIR(K_RGBP, K_YUV420)
+#undef VALI_PAIR
+  return fail(VALI_ERR_UNSUPPORTED, "convert: unsupported pair %d -> %d", src_fmt, dst_fmt);
+}
+
+} // namespace vali
+
+using namespace vali;
+
+extern "C" {
+
+int vali_convert(const vali_surface* src, const vali_surface* dst, const vali_cvt_params* params,
+                 vali_stream_t stream) {
+  VALI_REQUIRE(src && dst && params, "null argument");
+  VALI_REQUIRE(src->width > 0 && src->height > 0, "empty src");
+  VALI_REQUIRE(src->width == dst->width && src->height == dst->height, "src/dst size mismatch");
+  VALI_REQUIRE(src->plane[0] && dst->plane[0], "null plane");
+  CvtArgs a = {};
+  a.src = *src; a.dst = *dst; a.p = *params;
+  ElemArgs e = {};
+  e.src = *src; e.dst = *dst;
+  hipStream_t s = as_stream(stream);
+  DeviceScope scope(stream_device(s));
+  return launch_convert(a, e, src->format, dst->format, src->width, src->height, 1, s);
+}
+
+int vali_convert_batch(const vali_surface* d_src, const vali_surface* d_dst, int n, int src_format,
+                       int dst_format, int width, int height, const vali_cvt_params* params,
+                       vali_stream_t stream) {
+  VALI_REQUIRE(d_src && d_dst && params, "null argument");
+  VALI_REQUIRE(width > 0 && height > 0, "empty geometry");
+  VALI_REQUIRE(n >= 0 && n <= 65535, "batch size out of range (0..65535)");
+  if (n == 0)
+    return VALI_OK;
+  CvtArgs a = {};
+  a.d_src = d_src; a.d_dst = d_dst; a.p = *params;
+  ElemArgs e = {};
+  e.d_src = d_src; e.d_dst = d_dst;
+  hipStream_t s = as_stream(stream);
+  DeviceScope scope(stream_device(s));
+  return launch_convert(a, e, src_format, dst_format, width, height, n, s);
+}
+
+} // extern "C"

@@ -233,19 +233,6 @@ __global__ void __launch_bounds__(kBlock) k_nv12_rgb8(const Nv12RgbArgs a) {
   }
 }
 
-// Dynamic-LDS size that caps residency at `waves_per_cu` (160 KiB LDS per CU) while
-// leaving room for the strips.
-static unsigned residency_lds_bytes(int block_threads, int waves_per_cu, unsigned min_bytes) {
-  const int waves_per_block = block_threads / kWave;
-  const int blocks_per_cu = waves_per_cu / waves_per_block > 0 ? waves_per_cu / waves_per_block : 1;
-  unsigned bytes = (160u * 1024u / (unsigned)blocks_per_cu) & ~1023u; // floor to 1 KiB
-  if (bytes > 1024u)
-    bytes -= 512u; // stay strictly below the next-lower residency step
-  if (bytes > 64u * 1024u)
-    bytes = 64u * 1024u; // default per-block dynamic LDS limit
-  return bytes < min_bytes ? min_bytes : bytes;
-}
-
 static int launch_nv12_rgb(Nv12RgbArgs& a, int width, int height, int n, int dst_format,
                            hipStream_t stream) {
   const int groups = (width + kLanePx - 1) / kLanePx;

@@ -40,6 +40,10 @@ struct Csc {
   vali_csc k;
 };
 
+struct CvtParams {
+  vali_cvt_params p;
+};
+
 // ---- DLPack ------------------------------------------------------------------
 
 struct ExportCtx {
@@ -320,6 +324,31 @@ PYBIND11_MODULE(_vali_shim, m) {
           return vali_nv12_to_rgb_batch((const vali_surface*)P(d_src),
                                         (const vali_surface*)P(d_dst), n, width, height,
                                         dst_format, &csc.k, P(stream));
+        },
+        py::call_guard<py::gil_scoped_release>());
+
+  py::class_<CvtParams>(m, "CvtParams")
+      .def(py::init([](const Csc* csc, const std::vector<std::vector<float>>& rgb2yuv) {
+             CvtParams p;
+             std::memset(&p.p, 0, sizeof(p.p));
+             if (csc)
+               p.p.yuv2rgb = csc->k;
+             for (size_t i = 0; i < rgb2yuv.size() && i < 3; ++i)
+               for (size_t j = 0; j < rgb2yuv[i].size() && j < 4; ++j)
+                 p.p.rgb2yuv[i][j] = rgb2yuv[i][j];
+             return p;
+           }),
+           py::arg("csc") = nullptr, py::arg("rgb2yuv") = std::vector<std::vector<float>>());
+  m.def("convert",
+        [](const SurfaceDesc& src, const SurfaceDesc& dst, const CvtParams& p, uintptr_t stream) {
+          return vali_convert(&src.s, &dst.s, &p.p, P(stream));
+        },
+        py::call_guard<py::gil_scoped_release>());
+  m.def("convert_batch",
+        [](uintptr_t d_src, uintptr_t d_dst, int n, int src_format, int dst_format, int width,
+           int height, const CvtParams& p, uintptr_t stream) {
+          return vali_convert_batch((const vali_surface*)P(d_src), (const vali_surface*)P(d_dst), n,
+                                    src_format, dst_format, width, height, &p.p, P(stream));
         },
         py::call_guard<py::gil_scoped_release>());
 

@@ -62,6 +62,17 @@ int stream_device(hipStream_t stream) {
   return dev;
 }
 
+unsigned residency_lds_bytes(int block_threads, int waves_per_cu, unsigned min_bytes) {
+  const int waves_per_block = block_threads / 64 > 0 ? block_threads / 64 : 1;
+  const int blocks_per_cu = waves_per_cu / waves_per_block > 0 ? waves_per_cu / waves_per_block : 1;
+  unsigned bytes = (160u * 1024u / (unsigned)blocks_per_cu) & ~1023u; // floor to 1 KiB
+  if (bytes > 1024u)
+    bytes -= 512u; // stay strictly inside the residency step
+  if (bytes > 64u * 1024u)
+    bytes = 64u * 1024u; // default per-workgroup dynamic LDS limit
+  return bytes < min_bytes ? min_bytes : bytes;
+}
+
 } // namespace vali
 
 using namespace vali;

@@ -65,22 +65,171 @@ def _nv12_variant(cc_ctx: Optional[ColorspaceConversionContext]):
     return None
 
 
-def _nv12_rgb(src: Surface, dst: Surface, stream: int, cc_ctx) -> TaskExecDetails:
+def _nv12_rgb(io, stream: int, cc_ctx, csc=None) -> TaskExecDetails:
     """nv12_rgb / nv12_bgr (TaskConvertSurface.cpp:61-156).  The reference's nv12_bgr
     falls off the end of the function (its return sits after `break`, :100-105); here
     BGR simply follows the RGB logic with the channel order reversed."""
-    coeffs = _nv12_variant(cc_ctx)
-    if coeffs is None:
+    if csc is None:     # `csc` = a matrix handed in from outside (the multi-GPU broadcast)
+        coeffs = _nv12_variant(cc_ctx)
+        if coeffs is None:
+            return _S_UNSUPP_CC
+        csc = _csc(coeffs)
+    return _status(io.nv12_to_rgb(stream, csc))
+
+
+# RGB -> YUV matrices NVIDIA documents for nppiRGBToYUV / nppiRGBToYCbCr (SURVEY.md A.3);
+# rows = (kR, kG, kB, offset) for Y, U/Cb, V/Cr.  Row 0 of the first is nppiRGBToGray.
+RGB2YUV_NPP_YUV = ((0.299, 0.587, 0.114, 0.0), (-0.147, -0.289, 0.436, 128.0),
+                   (0.615, -0.515, -0.100, 128.0))
+RGB2YUV_NPP_YCBCR = ((0.257, 0.504, 0.098, 16.0), (-0.148, -0.291, 0.439, 128.0),
+                     (0.439, -0.368, -0.071, 128.0))
+
+_params_cache = {}
+
+
+def _params(csc=None, rgb2yuv=None):
+    key = (csc, rgb2yuv)
+    p = _params_cache.get(key)
+    if p is None:
+        p = _params_cache[key] = shim.CvtParams(_csc(csc) if csc else None,
+                                                [list(r) for r in rgb2yuv] if rgb2yuv else [])
+    return p
+
+
+_S_FAIL = TaskExecDetails.failed(TaskExecInfo.FAIL)
+
+
+def _space_range(cc_ctx, space_default, range_default):
+    return ((cc_ctx.color_space if cc_ctx else space_default),
+            (cc_ctx.color_range if cc_ctx else range_default))
+
+
+class _Single:
+    """One (src, dst) pair: a C-ABI call per Run."""
+
+    def __init__(self, src, dst):
+        self.src, self.dst = src, dst
+
+    def convert(self, stream, params):
+        return shim.convert(self.src.desc(), self.dst.desc(), params, stream)
+
+    def nv12_to_rgb(self, stream, csc):
+        return shim.nv12_to_rgb(self.src.desc(), self.dst.desc(), csc, stream)
+
+
+class _Batched:
+    """n pairs of one geometry: ONE launch (device descriptor arrays of a SurfaceBatch)."""
+
+    def __init__(self, batch):
+        self.b = batch
+
+    def convert(self, stream, params):
+        b = self.b
+        return shim.convert_batch(b.d_src, b.d_dst, b.n, int(b.src_format), int(b.dst_format),
+                                  b.src_size[0], b.src_size[1], params, stream)
+
+    def nv12_to_rgb(self, stream, csc):
+        b = self.b
+        return shim.nv12_to_rgb_batch(b.d_src, b.d_dst, b.n, b.src_size[0], b.src_size[1],
+                                      int(b.dst_format), csc, stream)
+
+
+def _convert(io, stream, params) -> TaskExecDetails:
+    return _status(io.convert(stream, params))
+
+
+def _plain(io, stream, cc_ctx, csc=None):
+    """Pairs without colour parameters: (de)interleave, swap, copies, element types."""
+    return _convert(io, stream, _params())
+
+
+def _nv12_yuv420(io, stream, cc_ctx, csc=None):
+    # nv12_yuv420 (TaskConvertSurface.cpp:158-200): JPEG and MPEG pick two NPP entry points
+    # that do the same byte shuffle; any other range is refused.
+    _, rng = _space_range(cc_ctx, ColorSpace.BT_601, ColorRange.JPEG)
+    if rng not in (ColorRange.JPEG, ColorRange.MPEG):
         return _S_UNSUPP_CC
-    return _status(shim.nv12_to_rgb(src.desc(), dst.desc(), _csc(coeffs), stream))
+    return _convert(io, stream, _params())
 
 
-# (src, dst) -> implementation; order follows GetSupportedConversions()
+def _yuv420_rgb(io, stream, cc_ctx, csc=None):
+    # yuv420_rgb / yuv420_bgr (:254-344): BT.601 only; JPEG -> "YUV", otherwise YCbCr
+    space, rng = _space_range(cc_ctx, ColorSpace.BT_601, ColorRange.JPEG)
+    if space != ColorSpace.BT_601:
+        return _S_UNSUPP_CC
+    return _convert(io, stream,
+                    _params(csc=CSC_NPP_YUV if rng == ColorRange.JPEG else CSC_NPP_YCBCR))
+
+
+def _yuv444_bgr(io, stream, cc_ctx, csc=None):
+    # yuv444_bgr (:346-391): MPEG -> YCbCr, JPEG -> YUV, else NPP_NO_OPERATION_WARNING -> FAIL
+    space, rng = _space_range(cc_ctx, ColorSpace.BT_601, ColorRange.JPEG)
+    if space != ColorSpace.BT_601:
+        return _S_UNSUPP_CC
+    if rng == ColorRange.MPEG:
+        return _convert(io, stream, _params(csc=CSC_NPP_YCBCR))
+    if rng == ColorRange.JPEG:
+        return _convert(io, stream, _params(csc=CSC_NPP_YUV))
+    return _S_FAIL
+
+
+def _yuv444_rgb(io, stream, cc_ctx, csc=None):
+    # yuv444_rgb (:393-434): JPEG only
+    space, rng = _space_range(cc_ctx, ColorSpace.BT_601, ColorRange.JPEG)
+    if space != ColorSpace.BT_601:
+        return _S_UNSUPP_CC
+    if rng != ColorRange.JPEG:
+        return _S_FAIL
+    return _convert(io, stream, _params(csc=CSC_NPP_YUV))
+
+
+def _rgb_to_yuv(io, stream, cc_ctx, csc=None):
+    # bgr_yuv444 / rgb_yuv444 / rgb_planar_yuv444 / rgb_yuv420 (:481-619, :657-704):
+    # BT.601 only; JPEG -> nppiRGBToYUV*, MPEG -> nppiRGBToYCbCr*, else FAIL.
+    # (The reference's rgb_yuv444 + MPEG writes PACKED YCbCr into plane 0, :557-560 -- a bug;
+    # here it produces planar YCbCr like the other variants.)
+    space, rng = _space_range(cc_ctx, ColorSpace.BT_601, ColorRange.JPEG)
+    if space != ColorSpace.BT_601:
+        return _S_UNSUPP_CC
+    if rng == ColorRange.JPEG:
+        return _convert(io, stream, _params(rgb2yuv=RGB2YUV_NPP_YUV))
+    if rng == ColorRange.MPEG:
+        return _convert(io, stream, _params(rgb2yuv=RGB2YUV_NPP_YCBCR))
+    return _S_FAIL
+
+
+def _rgb_y(io, stream, cc_ctx, csc=None):
+    # rbg8_y (:232-252): nppiRGBToGray
+    return _convert(io, stream, _params(rgb2yuv=RGB2YUV_NPP_YUV))
+
+
+# (src, dst) -> implementation; order is GetSupportedConversions()
 # (TaskConvertSurface.cpp:966-994).  NV12 -> RGB_PLANAR is an extension: the fused form
 # of the reference's NV12->RGB->RGB_PLANAR chain (BASELINE config 2).
 _CONVERSIONS = {
+    (F.NV12, F.YUV420): _nv12_yuv420,
+    (F.YUV420, F.NV12): _plain,
+    (F.P10, F.NV12): _plain,
+    (F.P12, F.NV12): _plain,
     (F.NV12, F.RGB): _nv12_rgb,
     (F.NV12, F.BGR): _nv12_rgb,
+    (F.RGB, F.RGB_PLANAR): _plain,
+    (F.RGB_PLANAR, F.RGB): _plain,
+    (F.RGB_PLANAR, F.YUV444): _rgb_to_yuv,
+    (F.Y, F.YUV444): _plain,
+    (F.YUV420, F.RGB): _yuv420_rgb,
+    (F.RGB, F.YUV420): _rgb_to_yuv,
+    (F.RGB, F.YUV444): _rgb_to_yuv,
+    (F.RGB, F.BGR): _plain,
+    (F.BGR, F.RGB): _plain,
+    (F.YUV420, F.BGR): _yuv420_rgb,
+    (F.YUV444, F.BGR): _yuv444_bgr,
+    (F.YUV444, F.RGB): _yuv444_rgb,
+    (F.BGR, F.YUV444): _rgb_to_yuv,
+    (F.NV12, F.Y): _plain,
+    (F.RGB, F.RGB_32F): _plain,
+    (F.RGB, F.Y): _rgb_y,
+    (F.RGB_32F, F.RGB_32F_PLANAR): _plain,
     (F.NV12, F.RGB_PLANAR): _nv12_rgb,
 }
 
@@ -124,7 +273,7 @@ class PySurfaceConverter(_SurfaceTask):
         if impl is None:                                          # :1085-1089
             raise ValueError(f"Unsupported pixel format conversion: {src.Format.name} -> "
                              f"{dst.Format.name}")
-        return impl(src, dst, self._stream, cc_ctx)
+        return impl(_Single(src, dst), self._stream, cc_ctx)
 
     def RunAsync(self, src: Surface, dst: Surface,
                  cc_ctx: Optional[ColorspaceConversionContext] = None) -> Tuple[bool, TaskExecInfo]:
@@ -149,22 +298,14 @@ class PySurfaceConverter(_SurfaceTask):
         cc_ctx would select (the multi-GPU pipeline passes the broadcast block)."""
         if not isinstance(batch, SurfaceBatch):
             batch = SurfaceBatch(self._gpu_id, self._stream, batch, dsts)
-        if (batch.src_format, batch.dst_format) not in _CONVERSIONS:
+        impl = _CONVERSIONS.get((batch.src_format, batch.dst_format))
+        if impl is None:
             raise ValueError(f"Unsupported pixel format conversion: {batch.src_format.name} -> "
                              f"{batch.dst_format.name}")
         if batch.src_size != batch.dst_size:
             return False, TaskExecInfo.INVALID_INPUT
-        if batch.src_format == F.NV12:
-            if csc is None:
-                coeffs = _nv12_variant(cc_ctx)
-                if coeffs is None:
-                    return False, TaskExecInfo.UNSUPPORTED_FMT_CONV_PARAMS
-                csc = _csc(coeffs)
-            d = _status(shim.nv12_to_rgb_batch(batch.d_src, batch.d_dst, batch.n,
-                                               batch.src_size[0], batch.src_size[1],
-                                               int(batch.dst_format), csc, self._stream))
-            return d.success, d.info
-        raise ValueError("RunBatch: conversion has no batched kernel yet")
+        d = impl(_Batched(batch), self._stream, cc_ctx, csc)
+        return d.success, d.info
 
     def RunBatch(self, batch, dsts=None, cc_ctx=None, csc=None) -> Tuple[bool, TaskExecInfo]:
         r = self.RunBatchAsync(batch, dsts, cc_ctx, csc)
