@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Secondary measurements: BASELINE.json configs[1..3] (the headline configs[4] is bench.py).
+
+  cfg2  PySurfaceConverter NV12->RGB_PLANAR 1920x1080, batch=1 (latency; surface is L3-resident)
+  cfg3  PySurfaceResizer 3840x2160 -> 1280x720 bilinear NV12, batch=64 (one launch)
+  cfg4  PySurfaceUD NV12 2160p -> RGB 1080p, then PySurfaceRotator 90 degrees (chain)
+Prints one JSON object per config.  GB/s figures use the judge's algorithmic bytes of
+SURVEY.md 8(d) / BASELINE.md section 3.  Kernel time = HIP events on the task's stream.
+"""
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import vali_amd as vali  # noqa: E402
+from vali_amd._native import shim  # noqa: E402
+
+DEV = 0
+PEAK = 8000.0
+
+
+def timed(stream, fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    shim.stream_sync(DEV, stream)
+    a, b = shim.event_create(DEV), shim.event_create(DEV)
+    t0 = time.perf_counter()
+    shim.event_record(DEV, a, stream)
+    for _ in range(reps):
+        fn()
+    shim.event_record(DEV, b, stream)
+    shim.event_sync(DEV, b)
+    wall = (time.perf_counter() - t0) / reps
+    ms = shim.event_elapsed_ms(a, b) / reps
+    shim.event_destroy(DEV, a)
+    shim.event_destroy(DEV, b)
+    return ms, wall * 1e3
+
+
+def fill(surfs, seed=0):
+    rng = np.random.default_rng(seed)
+    up = vali.PyFrameUploader(DEV)
+    host = rng.integers(16, 236, surfs[0].HostSize, dtype=np.uint8)
+    for i, s in enumerate(surfs):
+        if i < 4:
+            assert up.Run(np.roll(host, i * 977), s)[0]
+        else:
+            p, q = surfs[i % 4]._planes, s._planes
+            for a, b in zip(p, q):
+                shim.memcpy2d_async(DEV, b.GpuMem, b.Pitch, a.GpuMem, a.Pitch, a.Width * a.ElemSize, a.Height, 2, 0)
+    shim.stream_sync(DEV, 0)
+
+
+def cfg2():
+    w, h = 1920, 1080
+    cvt = vali.PySurfaceConverter(DEV)
+    cc = vali.ColorspaceConversionContext(vali.ColorSpace.BT_709, vali.ColorRange.MPEG)
+    src = [vali.Surface.Make(vali.NV12, w, h, DEV)]
+    fill(src)
+    dst = vali.Surface.Make(vali.RGB_PLANAR, w, h, DEV)
+    mid = vali.Surface.Make(vali.RGB, w, h, DEV)
+    ms_async, wall_async = timed(cvt.Stream, lambda: cvt.RunAsync(src[0], dst, cc), 2000, 50)
+    t0 = time.perf_counter()
+    for _ in range(500):
+        cvt.Run(src[0], dst, cc)
+    wall_sync = (time.perf_counter() - t0) / 500 * 1e3
+    ms_chain, _ = timed(cvt.Stream, lambda: (cvt.RunAsync(src[0], mid, cc), cvt.RunAsync(mid, dst)), 1000, 50)
+    b = 9331200
+    return {"config": "cfg2 PySurfaceConverter NV12->RGB_PLANAR 1920x1080 batch=1 (fused single kernel)",
+            "us_per_frame_stream_time": round(ms_async * 1e3, 3), "us_per_call_host_async": round(wall_async * 1e3, 3),
+            "us_per_call_host_sync_Run": round(wall_sync * 1e3, 3),
+            "GBps_algorithmic": round(b / (ms_async * 1e-3) / 1e9, 1),
+            "note": "batch=1 working set (9.3 MB) lives in the 256 MiB Infinity Cache; time is launch latency, not HBM",
+            "reference_faithful_2step_chain_us": round(ms_chain * 1e3, 3)}
+
+
+def cfg3(n=64):
+    sw, sh, dw, dh = 3840, 2160, 1280, 720
+    rs = vali.PySurfaceResizer(vali.NV12, DEV)
+    srcs = [vali.Surface.Make(vali.NV12, sw, sh, DEV) for _ in range(n)]
+    dsts = [vali.Surface.Make(vali.NV12, dw, dh, DEV) for _ in range(n)]
+    fill(srcs)
+    batch = rs.PrepareBatch(srcs, dsts)
+    ms, wall = timed(rs.Stream, lambda: rs.RunBatchAsync(batch), 50)
+    b = 13824000
+    touched = 720 * 3840 * 2 // 1 // 1  # informational: see note
+    return {"config": f"cfg3 PySurfaceResizer NV12 3840x2160->1280x720 bilinear, batch={n}, one launch",
+            "ms_per_batch": round(ms, 4), "us_per_frame": round(ms * 1e3 / n, 3), "frames_per_s": round(n / (ms * 1e-3), 1),
+            "GBps_judge_bytes(13.824MB/frame)": round(b * n / (ms * 1e-3) / 1e9, 1),
+            "frac_of_8TBps": round(b * n / (ms * 1e-3) / 1e9 / PEAK, 4),
+            "note": "exact 3x: the NPP grid samples src[3y][3x] (weights 1,0); only every third source row/column "
+                    "is touched, so HBM fetch is below the judge figure"}
+
+
+def cfg4(n=64):
+    sw, sh, dw, dh = 3840, 2160, 1920, 1080
+    ud = vali.PySurfaceUD(DEV)
+    rot = vali.PySurfaceRotator(DEV, ud.Stream)
+    srcs = [vali.Surface.Make(vali.NV12, sw, sh, DEV) for _ in range(n)]
+    mids = [vali.Surface.Make(vali.RGB, dw, dh, DEV) for _ in range(n)]
+    outs = [vali.Surface.Make(vali.RGB, dh, dw, DEV) for _ in range(n)]
+    fill(srcs)
+    batch = ud.PrepareBatch(srcs, mids)
+    ms_ud, _ = timed(ud.Stream, lambda: ud.RunBatchAsync(batch), 30)
+
+    def rot_all():
+        for m, o in zip(mids, outs):
+            rot.RunAsync(m, o, 90.0)
+    ms_rot, wall_rot = timed(ud.Stream, rot_all, 10)
+    b_ud, b_rot = 18662400, 12441600
+    return {"config": f"cfg4 PySurfaceUD NV12 2160p->RGB 1080p (batch={n}, one launch) + PySurfaceRotator 90deg per frame",
+            "ud_us_per_frame": round(ms_ud * 1e3 / n, 3), "ud_GBps": round(b_ud * n / (ms_ud * 1e-3) / 1e9, 1),
+            "rot_us_per_frame": round(ms_rot * 1e3 / n, 3), "rot_GBps": round(b_rot * n / (ms_rot * 1e-3) / 1e9, 1),
+            "rot_host_us_per_call": round(wall_rot * 1e3 / n, 3),
+            "chain_us_per_frame": round((ms_ud + ms_rot) * 1e3 / n, 3),
+            "chain_GBps(31.104MB/frame)": round((b_ud + b_rot) * n / ((ms_ud + ms_rot) * 1e-3) / 1e9, 1),
+            "frac_of_8TBps": round((b_ud + b_rot) * n / ((ms_ud + ms_rot) * 1e-3) / 1e9 / PEAK, 4)}
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["cfg2", "cfg3", "cfg4"]
+    for name in which:
+        print(json.dumps(globals()[name]()), flush=True)
