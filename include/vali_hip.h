@@ -228,18 +228,24 @@ VALI_API int vali_resize_batch(const vali_surface* d_src, const vali_surface* d_
 /* ---- rotation: replaces nppiRotate_{8u,16u,32f}_{C1,C3}R_Ctx ------------------------ */
 
 /*
- * Rotate one plane by `angle` degrees and shift (NPP model: x' = x cos a + y sin a +
- * shift_x, y' = -x sin a + y cos a + shift_y; inverse-mapped, bilinear; destination pixels
- * whose source point is outside the source plane are left untouched).
- * Reference call sites: Rot_8U_C1 ... Rot_32F_C3, src/TC/src/RotateSurface.cpp:22-125.
- * elem_size 1/2/4 = u8/u16/f32, channels 1 or 3 (interleaved).  Sizes in pixels.
- * The 90 / 270 degree cases with the shifts PySurfaceRotator derives
- * (src/python_vali/src/PySurfaceRotator.cpp:47-73) take an LDS-tiled transpose path.
+ * Rotate every plane of a surface by `angle` degrees and shift (NPP model: x' = x cos a +
+ * y sin a + shift_x, y' = -x sin a + y cos a + shift_y; inverse-mapped, bilinear; destination
+ * pixels whose source point is outside the source plane are left untouched).
+ * Reference call sites: Rot_8U_C1 ... Rot_32F_C3 via RotPlanar / RotPacked,
+ * src/TC/src/RotateSurface.cpp:22-159 (one NPP call per plane; here one launch per surface
+ * or per batch).  Formats: Y, RGB, BGR, RGB_32F, YUV420(_10BIT), YUV422, YUV444(_10BIT).
+ * per_plane_shifts != 0 (angle must be a multiple of 90): ignore shift_x/shift_y and give
+ * each plane the shifts PySurfaceRotator derives from ITS size
+ * (src/python_vali/src/PySurfaceRotator.cpp:47-73) -- the exact quarter-turn permutation,
+ * done as an LDS-tiled transpose for 90 / 270 degrees.
  */
-VALI_API int vali_rotate_plane(const void* src, int src_pitch, int src_width, int src_height,
-                               void* dst, int dst_pitch, int dst_width, int dst_height,
-                               int elem_size, int channels, double angle, double shift_x,
-                               double shift_y, vali_stream_t stream);
+VALI_API int vali_rotate(const vali_surface* src, const vali_surface* dst, double angle,
+                         double shift_x, double shift_y, int per_plane_shifts,
+                         vali_stream_t stream);
+VALI_API int vali_rotate_batch(const vali_surface* d_src, const vali_surface* d_dst, int n,
+                               int format, int src_width, int src_height, int dst_width,
+                               int dst_height, double angle, double shift_x, double shift_y,
+                               int per_plane_shifts, vali_stream_t stream);
 /* cos/sin of the angle as the kernels use them (exact 0/+-1 for multiples of 90 degrees) */
 VALI_API int vali_rotate_coeffs(double angle_deg, float* c, float* s);
 

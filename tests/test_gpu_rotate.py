@@ -98,3 +98,26 @@ def test_unsupported_params(vali, gpu):
     q = vali.Surface.Make(vali.RGB_PLANAR, 48, 64, gpu)
     assert rot.Run(p, q, 90.0) == (False, vali.TaskExecInfo.INVALID_INPUT)   # RotateSurface.cpp:135-136
     assert vali.PixelFormat.RGB in rot.SupportedFormats and vali.PixelFormat.NV12 not in rot.SupportedFormats
+
+
+@pytest.mark.parametrize("fmt,angle", [("RGB", 90.0), ("RGB", 270.0), ("YUV420", 90.0), ("RGB", 33.0)])
+def test_rotate_batch(vali, gpu, oracle, fmt, angle):
+    """One launch over a batch == per-surface Run."""
+    w, h, n = 320, 180, 5
+    pf = vali.PixelFormat[fmt]
+    rot = vali.PySurfaceRotator(gpu)
+    quarter = angle in (90.0, 270.0)
+    dw, dh = (h, w) if quarter else (w, h)
+    srcs = [vali.Surface.Make(pf, w, h, gpu) for _ in range(n)]
+    dsts = [vali.Surface.Make(pf, dw, dh, gpu) for _ in range(n)]
+    refs = [vali.Surface.Make(pf, dw, dh, gpu) for _ in range(n)]
+    for i, s in enumerate(srcs):
+        host = np.random.default_rng(i).integers(0, 256, s.HostSize, dtype=np.uint8)
+        assert vali.PyFrameUploader(gpu).Run(host, s)[0]
+        for t in (dsts[i], refs[i]):
+            assert vali.PyFrameUploader(gpu).Run(np.full(t.HostSize, 9, np.uint8), t)[0]
+    sx, sy = (0.0, 0.0) if quarter else (20.0, 50.0)
+    assert rot.RunBatch(srcs, dsts, angle, sx, sy) == (True, vali.TaskExecInfo.SUCCESS)
+    for s, d, r in zip(srcs, dsts, refs):
+        assert rot.Run(s, r, angle, sx, sy)[0]
+        assert np.array_equal(download(vali, gpu, d), download(vali, gpu, r))

@@ -81,3 +81,25 @@ def test_batch_2160p_to_1080p(vali, gpu, oracle):
         out = np.zeros(d.HostSize, np.uint8)
         assert vali.PySurfaceDownloader(gpu).Run(d, out)[0]
         assert np.array_equal(out, oracle.ud_nv12(f, sw, sh, "NV12", dw, dh, "RGB").reshape(-1))
+
+
+@pytest.mark.parametrize("src_fmt,dst_fmt,dt", [("YUV420", "YUV444", np.uint8),
+                                                ("YUV420_10bit", "YUV444_10bit", np.uint16)])
+def test_planar_sources(vali, gpu, oracle, src_fmt, dst_fmt, dt):
+    """reference tests/test_PySurfaceUD.py:71-132 (CPU-decoded planar sources)."""
+    sw, sh, dw, dh = 848, 464, 640, 360
+    rng = np.random.default_rng(8)
+    src = vali.Surface.Make(vali.PixelFormat[src_fmt], sw, sh, gpu)
+    host = (rng.random(src.HostSize // np.dtype(dt).itemsize) * 1000).astype(dt)
+    assert vali.PyFrameUploader(gpu).Run(host.view(np.uint8), src)[0]
+    dst = vali.Surface.Make(vali.PixelFormat[dst_fmt], dw, dh, gpu)
+    assert vali.PySurfaceUD(gpu).Run(src, dst) == (True, vali.TaskExecInfo.SUCCESS)
+    out = np.zeros(dst.HostSize, np.uint8)
+    assert vali.PySurfaceDownloader(gpu).Run(dst, out)[0]
+    got = out.view(dt)
+    off, want = 0, []
+    for pw, ph in ((sw, sh), (sw // 2, sh // 2), (sw // 2, sh // 2)):
+        plane = np.ascontiguousarray(host[off: off + pw * ph].reshape(ph, pw))
+        want.append(oracle.resize_plane(plane, 1, dw, dh).reshape(-1))
+        off += pw * ph
+    assert np.array_equal(got, np.concatenate(want))

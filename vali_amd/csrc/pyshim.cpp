@@ -379,11 +379,17 @@ PYBIND11_MODULE(_vali_shim, m) {
         py::call_guard<py::gil_scoped_release>());
   m.attr("INTERP_LINEAR") = (int)VALI_INTERP_LINEAR;
 
-  m.def("rotate_plane",
-        [](uintptr_t src, int spitch, int sw, int sh, uintptr_t dst, int dpitch, int dw, int dh,
-           int elem, int channels, double angle, double shx, double shy, uintptr_t stream) {
-          return vali_rotate_plane(P(src), spitch, sw, sh, P(dst), dpitch, dw, dh, elem, channels,
-                                   angle, shx, shy, P(stream));
+  m.def("rotate",
+        [](const SurfaceDesc& src, const SurfaceDesc& dst, double angle, double shx, double shy,
+           int per_plane, uintptr_t stream) {
+          return vali_rotate(&src.s, &dst.s, angle, shx, shy, per_plane, P(stream));
+        },
+        py::call_guard<py::gil_scoped_release>());
+  m.def("rotate_batch",
+        [](uintptr_t d_src, uintptr_t d_dst, int n, int format, int sw, int sh, int dw, int dh,
+           double angle, double shx, double shy, int per_plane, uintptr_t stream) {
+          return vali_rotate_batch((const vali_surface*)P(d_src), (const vali_surface*)P(d_dst), n,
+                                   format, sw, sh, dw, dh, angle, shx, shy, per_plane, P(stream));
         },
         py::call_guard<py::gil_scoped_release>());
   m.def("rotate_coeffs", [](double angle) {

@@ -156,6 +156,7 @@ static int resize_jobs(int fmt, ResizeJob* j, int* elem) {
   *elem = 1;
   switch (fmt) {
   case VALI_FMT_Y: set(0, 0, 0, 0, 1); return 1;
+  case VALI_FMT_GRAY12: *elem = 2; set(0, 0, 0, 0, 1); return 1; // any single u16 plane
   case VALI_FMT_NV12: set(0, 0, 0, 0, 1); set(1, 1, 1, 1, 2); return 2;
   case VALI_FMT_P10: case VALI_FMT_P12: *elem = 2; set(0, 0, 0, 0, 1); set(1, 1, 1, 1, 2); return 2;
   case VALI_FMT_YUV420: set(0, 0, 0, 0, 1); set(1, 1, 1, 1, 1); set(2, 2, 1, 1, 1); return 3;

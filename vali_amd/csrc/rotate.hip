@@ -1,6 +1,7 @@
-// Plane rotation: replaces nppiRotate_{8u,16u,32f}_{C1,C3}R_Ctx with NPPI_INTER_LINEAR as the
-// reference calls it from Rot_8U_C1 ... Rot_32F_C3
+// Surface rotation: replaces nppiRotate_{8u,16u,32f}_{C1,C3}R_Ctx with NPPI_INTER_LINEAR as the
+// reference calls it from Rot_8U_C1 ... Rot_32F_C3, once per plane
 // (reference: src/TC/src/RotateSurface.cpp:22-125; per-plane / packed drivers :132-159).
+// Here all planes of a surface -- and all surfaces of a batch -- are rotated by ONE launch.
 //
 // NPP's model (NPP documentation of nppiRotate): the source is rotated by `angle` degrees
 // about its origin and then shifted,
@@ -12,14 +13,14 @@
 // rotation etalons pin.
 //
 // Two kernels:
-//  * k_rotate_affine<T,C>: any angle.  cos/sin arrive from the host as floats (snapped to
+//  * k_rotate_affine<T>: any angle.  cos/sin arrive from the host as floats (snapped to
 //    exactly 0/+-1 for multiples of 90 degrees), so the device does only fma/mul/add and is
 //    bit-exact with the oracle.  One lane = 4 adjacent dst pixels (wide stores).
-//  * k_rotate_tile<P>: the canonical 90 / 270 degree permutations as an LDS-tiled transpose:
+//  * k_rotate_tile<P,Q>: the canonical 90 / 270 degree permutations as an LDS-tiled transpose:
 //    a 64x64-pixel tile is read with coalesced row segments, written with coalesced row
 //    segments of the transposed tile; LDS row stride 64*P+4 bytes keeps the column walks
 //    at most 2-way bank conflicted.  P = bytes per pixel (1,2,3,4,6,12).
-// Arithmetic of the affine path (the specification, oracle: vali_oracle_rotate):
+// Arithmetic of the affine path (the specification, oracle: vali_oracle_rotate_plane):
 //   dx = x' - shift_x ; dy = y' - shift_y                      (float)
 //   xs = fma(-s, dy, c*dx) ; ys = fma(c, dy, s*dx)
 //   skip unless 0 <= xs <= W-1 and 0 <= ys <= H-1
@@ -30,26 +31,48 @@
 #include "dev_util.hpp"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace vali {
 
+struct RotJob {
+  int comp;          // component index in vali_surface.plane[]
+  int sub_x, sub_y;  // log2 subsampling of the plane
+  int channels;      // interleaved channels
+  u32 first_tile, tiles_x;
+  float shift_x, shift_y;
+};
+
 struct RotArgs {
-  const uint8_t* src;
-  uint8_t* dst;
-  int src_pitch, dst_pitch;
-  int src_w, src_h, dst_w, dst_h;
-  float c, s, shift_x, shift_y;
+  const vali_surface* d_src;
+  const vali_surface* d_dst;
+  vali_surface src, dst;
+  RotJob job[3];
+  int njobs;
+  float c, s;
   TileMap map;
 };
+
+// tile index -> (job, tile_x, tile_y); false for grid padding
+__device__ __forceinline__ bool rot_tile(const RotArgs& a, int& j, u32& tx, u32& ty) {
+  const u32 b = blockIdx.x;
+  const u32 t = (b & 7u) * a.map.per_xcd + (b >> 3);
+  if (t >= a.map.total)
+    return false;
+  j = 0;
+  if (a.njobs > 1 && t >= a.job[1].first_tile) j = 1;
+  if (a.njobs > 2 && t >= a.job[2].first_tile) j = 2;
+  const u32 local = t - a.job[j].first_tile;
+  ty = local / a.job[j].tiles_x;
+  tx = local - ty * a.job[j].tiles_x;
+  return true;
+}
 
 template <typename T> __device__ __forceinline__ float texel_f(const uint8_t* row, int idx) {
   return (float)((const T*)row)[idx];
 }
-
 template <typename T> __device__ __forceinline__ T finish(float v);
-template <> __device__ __forceinline__ uint8_t finish<uint8_t>(float v) {
-  return (uint8_t)quantize_u8(v);
-}
+template <> __device__ __forceinline__ uint8_t finish<uint8_t>(float v) { return (uint8_t)quantize_u8(v); }
 template <> __device__ __forceinline__ uint16_t finish<uint16_t>(float v) {
   float r = __builtin_rintf(v);
   r = __builtin_fminf(__builtin_fmaxf(r, 0.0f), 65535.0f);
@@ -58,31 +81,30 @@ template <> __device__ __forceinline__ uint16_t finish<uint16_t>(float v) {
 template <> __device__ __forceinline__ float finish<float>(float v) { return v; }
 
 template <typename T, int C>
-__global__ void __launch_bounds__(kBlock) k_rotate_affine(const RotArgs a) {
-  u32 tile_x, tile_y;
-  if (!tile_of_block(a.map, tile_x, tile_y))
-    return;
+__device__ __forceinline__ void affine_tile(const RotArgs& a, const RotJob& job, const uint8_t* sp,
+                                            int spitch, int sw, int sh, uint8_t* dp, int dpitch,
+                                            int dw, int dh, u32 tile_x, u32 tile_y) {
   const int x0 = (tile_x * 64 + (threadIdx.x & 63)) * 4;
   const int y = tile_y * 4 + (threadIdx.x >> 6);
-  if (x0 >= a.dst_w || y >= a.dst_h)
+  if (x0 >= dw || y >= dh)
     return;
-  const float dy = (float)y - a.shift_y;
-  const float wmax = (float)(a.src_w - 1), hmax = (float)(a.src_h - 1);
+  const float dy = (float)y - job.shift_y;
+  const float wmax = (float)(sw - 1), hmax = (float)(sh - 1);
   T out[4][C];
   bool hit[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    const float dx = (float)(x0 + p) - a.shift_x;
+    const float dx = (float)(x0 + p) - job.shift_x;
     const float xs = __builtin_fmaf(-a.s, dy, a.c * dx);
     const float ys = __builtin_fmaf(a.c, dy, a.s * dx);
-    hit[p] = (x0 + p < a.dst_w) && xs >= 0.0f && xs <= wmax && ys >= 0.0f && ys <= hmax;
+    hit[p] = (x0 + p < dw) && xs >= 0.0f && xs <= wmax && ys >= 0.0f && ys <= hmax;
     if (hit[p]) {
       const float fi = __builtin_floorf(xs), fj = __builtin_floorf(ys);
       const float fa = xs - fi, fb = ys - fj;
       const int i = (int)fi, j = (int)fj;
-      const int i1 = min(i + 1, a.src_w - 1), j1 = min(j + 1, a.src_h - 1);
-      const uint8_t* r0 = a.src + (size_t)j * a.src_pitch;
-      const uint8_t* r1 = a.src + (size_t)j1 * a.src_pitch;
+      const int i1 = min(i + 1, sw - 1), j1 = min(j + 1, sh - 1);
+      const uint8_t* r0 = sp + (size_t)j * spitch;
+      const uint8_t* r1 = sp + (size_t)j1 * spitch;
 #pragma unroll
       for (int ch = 0; ch < C; ++ch) {
         const float t00 = texel_f<T>(r0, i * C + ch), t10 = texel_f<T>(r0, i1 * C + ch);
@@ -93,22 +115,20 @@ __global__ void __launch_bounds__(kBlock) k_rotate_affine(const RotArgs a) {
       }
     }
   }
-  T* drow = (T*)(a.dst + (size_t)y * a.dst_pitch) + (size_t)x0 * C;
+  T* drow = (T*)(dp + (size_t)y * dpitch) + (size_t)x0 * C;
   constexpr int kBytes = 4 * C * (int)sizeof(T);
-  if (hit[0] && hit[1] && hit[2] && hit[3] && (((uintptr_t)drow) & (kBytes % 16 == 0 ? 15u : 3u)) == 0 &&
-      kBytes % 4 == 0) {
-    // all four pixels present: one wide store (4, 12, 16, 24 or 48 bytes per lane)
+  if (hit[0] && hit[1] && hit[2] && hit[3] && (((uintptr_t)drow) & (kBytes % 16 == 0 ? 15u : 3u)) == 0) {
+    // all four pixels present: one wide store (4, 8, 12, 16, 24 or 48 bytes per lane)
     u32 w[kBytes / 4];
     __builtin_memcpy(w, out, kBytes);
-    u32* o = (u32*)drow;
     if constexpr (kBytes % 16 == 0) {
 #pragma unroll
       for (int k = 0; k < kBytes / 16; ++k)
-        ((uint4*)o)[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+        ((uint4*)drow)[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
     } else {
 #pragma unroll
       for (int k = 0; k < kBytes / 4; ++k)
-        o[k] = w[k];
+        ((u32*)drow)[k] = w[k];
     }
   } else {
 #pragma unroll
@@ -120,6 +140,23 @@ __global__ void __launch_bounds__(kBlock) k_rotate_affine(const RotArgs a) {
   }
 }
 
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_rotate_affine(const RotArgs a) {
+  int j;
+  u32 tx, ty;
+  if (!rot_tile(a, j, tx, ty))
+    return;
+  const RotJob job = a.job[j];
+  const SurfRef s = load_surface(a.d_src, a.src, blockIdx.y);
+  const SurfRef d = load_surface(a.d_dst, a.dst, blockIdx.y);
+  const int sw = s.width >> job.sub_x, sh = s.height >> job.sub_y;
+  const int dw = d.width >> job.sub_x, dh = d.height >> job.sub_y;
+  if (job.channels == 1)
+    affine_tile<T, 1>(a, job, s.p[job.comp], s.pitch[job.comp], sw, sh, d.p[job.comp], d.pitch[job.comp], dw, dh, tx, ty);
+  else
+    affine_tile<T, 3>(a, job, s.p[job.comp], s.pitch[job.comp], sw, sh, d.p[job.comp], d.pitch[job.comp], dw, dh, tx, ty);
+}
+
 // ---- canonical 90 / 270 degree permutation: LDS-tiled transpose -----------------------------
 // QUARTER = 1: dst(x', y') = src(W-1-y', x')   [angle 90,  shift_y = W-1]
 // QUARTER = 3: dst(x', y') = src(y', H-1-x')   [angle 270, shift_x = H-1]
@@ -129,26 +166,44 @@ template <int P, int QUARTER>
 __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
   constexpr int S = kRotTile * P + 4; // LDS row stride in bytes (dword aligned, odd dwords)
   __shared__ __attribute__((aligned(16))) uint8_t lds[kRotTile * S];
+  int j;
   u32 tile_x, tile_y;
-  if (!tile_of_block(a.map, tile_x, tile_y))
+  if (!rot_tile(a, j, tile_x, tile_y))
     return;
+  const RotJob job = a.job[j];
+  const SurfRef s = load_surface(a.d_src, a.src, blockIdx.y);
+  const SurfRef d = load_surface(a.d_dst, a.dst, blockIdx.y);
+  const int src_w = s.width >> job.sub_x, src_h = s.height >> job.sub_y;
+  const int dst_w = d.width >> job.sub_x, dst_h = d.height >> job.sub_y;
+  const uint8_t* src = s.p[job.comp];
+  uint8_t* dst = d.p[job.comp];
+  const int src_pitch = s.pitch[job.comp], dst_pitch = d.pitch[job.comp];
+
   const int cx = tile_x * kRotTile, ry = tile_y * kRotTile; // src tile origin (col, row)
-  const int tw = min(kRotTile, a.src_w - cx), th = min(kRotTile, a.src_h - ry);
+  const int tw = min(kRotTile, src_w - cx), th = min(kRotTile, src_h - ry);
   const int t = threadIdx.x;
 
-  // phase 1: coalesced row segments -> LDS (dwords when the segment is dword aligned)
-  const uint8_t* sbase = a.src + (size_t)ry * a.src_pitch + (size_t)cx * P;
+  // phase 1: coalesced row segments -> LDS (16-byte / 4-byte vectors when aligned)
+  const uint8_t* sbase = src + (size_t)ry * src_pitch + (size_t)cx * P;
   const int row_bytes = tw * P;
-  if ((((uintptr_t)sbase | (uintptr_t)a.src_pitch) & 3u) == 0 && (row_bytes & 3) == 0) {
+  if ((((uintptr_t)sbase | (uintptr_t)src_pitch) & 15u) == 0 && (row_bytes & 15) == 0) {
+    const int v_per_row = row_bytes / 16;
+    for (int k = t; k < th * v_per_row; k += kBlock) {
+      const int r = k / v_per_row, v = k - r * v_per_row;
+      const uint4 w = load16(sbase + (size_t)r * src_pitch + v * 16);
+      u32* l = (u32*)(lds + r * S + v * 16);
+      l[0] = w.x; l[1] = w.y; l[2] = w.z; l[3] = w.w;
+    }
+  } else if ((((uintptr_t)sbase | (uintptr_t)src_pitch) & 3u) == 0 && (row_bytes & 3) == 0) {
     const int dw_per_row = row_bytes / 4;
     for (int k = t; k < th * dw_per_row; k += kBlock) {
-      const int r = k / dw_per_row, d = k - r * dw_per_row;
-      *(u32*)(lds + r * S + d * 4) = *(const u32*)(sbase + (size_t)r * a.src_pitch + d * 4);
+      const int r = k / dw_per_row, v = k - r * dw_per_row;
+      *(u32*)(lds + r * S + v * 4) = *(const u32*)(sbase + (size_t)r * src_pitch + v * 4);
     }
   } else {
     for (int k = t; k < th * row_bytes; k += kBlock) {
-      const int r = k / row_bytes, d = k - r * row_bytes;
-      lds[r * S + d] = sbase[(size_t)r * a.src_pitch + d];
+      const int r = k / row_bytes, v = k - r * row_bytes;
+      lds[r * S + v] = sbase[(size_t)r * src_pitch + v];
     }
   }
   __syncthreads();
@@ -161,27 +216,26 @@ __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
       continue;
     int dy_, dx0;
     if constexpr (QUARTER == 1) {
-      dy_ = a.src_w - 1 - (cx + lc);
+      dy_ = src_w - 1 - (cx + lc);
       dx0 = ry + chunk * 4;
     } else {
       dy_ = cx + lc;
-      dx0 = a.src_h - 1 - (ry + chunk * 4 + 3);
+      dx0 = src_h - 1 - (ry + chunk * 4 + 3);
     }
-    if (dy_ < 0 || dy_ >= a.dst_h)
+    if (dy_ < 0 || dy_ >= dst_h)
       continue;
-    // the 4 pixels of this lane: dst x = dx0 + q  <-  tile row j(q)
     uint8_t px[4 * P];
     bool ok[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int j = QUARTER == 1 ? chunk * 4 + q : chunk * 4 + 3 - q;
-      ok[q] = j < th && dx0 + q >= 0 && dx0 + q < a.dst_w;
+      const int jj = QUARTER == 1 ? chunk * 4 + q : chunk * 4 + 3 - q;
+      ok[q] = jj < th && dx0 + q >= 0 && dx0 + q < dst_w;
 #pragma unroll
       for (int b = 0; b < P; ++b)
-        px[q * P + b] = ok[q] ? lds[j * S + lc * P + b] : (uint8_t)0;
+        px[q * P + b] = ok[q] ? lds[jj * S + lc * P + b] : (uint8_t)0;
     }
-    uint8_t* o = a.dst + (size_t)dy_ * a.dst_pitch + (size_t)dx0 * P;
-    if (ok[0] && ok[1] && ok[2] && ok[3] && (((uintptr_t)o) & 3u) == 0 && (4 * P) % 4 == 0) {
+    uint8_t* o = dst + (size_t)dy_ * dst_pitch + (size_t)dx0 * P;
+    if (ok[0] && ok[1] && ok[2] && ok[3] && (((uintptr_t)o) & 3u) == 0) {
       u32 w[P];
       __builtin_memcpy(w, px, 4 * P);
 #pragma unroll
@@ -198,8 +252,43 @@ __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
   }
 }
 
-template <int QUARTER> static int launch_tile(const RotArgs& a, int pixel_bytes, hipStream_t s) {
-  const dim3 grid(a.map.per_xcd * 8u), block(kBlock);
+// plane jobs per pixel format (RotateSurface::Run switch, RotateSurface.cpp:168-208)
+static int rotate_jobs(int fmt, RotJob* j, int* elem) {
+  auto set = [&](int k, int comp, int sx, int sy, int ch) {
+    j[k].comp = comp; j[k].sub_x = sx; j[k].sub_y = sy; j[k].channels = ch;
+  };
+  *elem = 1;
+  switch (fmt) {
+  case VALI_FMT_Y: set(0, 0, 0, 0, 1); return 1;
+  case VALI_FMT_RGB: case VALI_FMT_BGR: set(0, 0, 0, 0, 3); return 1;
+  case VALI_FMT_RGB_32F: *elem = 4; set(0, 0, 0, 0, 3); return 1;
+  case VALI_FMT_YUV420: set(0, 0, 0, 0, 1); set(1, 1, 1, 1, 1); set(2, 2, 1, 1, 1); return 3;
+  case VALI_FMT_YUV420_10BIT: *elem = 2; set(0, 0, 0, 0, 1); set(1, 1, 1, 1, 1); set(2, 2, 1, 1, 1); return 3;
+  case VALI_FMT_YUV422: set(0, 0, 0, 0, 1); set(1, 1, 1, 0, 1); set(2, 2, 1, 0, 1); return 3;
+  case VALI_FMT_YUV444: set(0, 0, 0, 0, 1); set(1, 1, 0, 0, 1); set(2, 2, 0, 0, 1); return 3;
+  case VALI_FMT_YUV444_10BIT: *elem = 2; set(0, 0, 0, 0, 1); set(1, 1, 0, 0, 1); set(2, 2, 0, 0, 1); return 3;
+  default: return 0;
+  }
+}
+
+static void rotate_coeffs(double angle_deg, float* c, float* s) {
+  // multiples of 90 degrees: exact 0 / +-1 (cos(pi/2) in floating point is 6e-17, which
+  // would push border pixels outside the source)
+  const double q = fmod(angle_deg, 360.0);
+  const double n = q < 0 ? q + 360.0 : q;
+  if (n == 0.0) { *c = 1.f; *s = 0.f; }
+  else if (n == 90.0) { *c = 0.f; *s = 1.f; }
+  else if (n == 180.0) { *c = -1.f; *s = 0.f; }
+  else if (n == 270.0) { *c = 0.f; *s = -1.f; }
+  else {
+    const double r = angle_deg * 3.14159265358979323846 / 180.0;
+    *c = (float)cos(r);
+    *s = (float)sin(r);
+  }
+}
+
+template <int QUARTER> static int launch_tile(const RotArgs& a, int pixel_bytes, dim3 grid, hipStream_t s) {
+  const dim3 block(kBlock);
   switch (pixel_bytes) {
 #define VALI_ROT_CASE(P)                                                                    \
   case P:                                                                                   \
@@ -218,6 +307,68 @@ template <int QUARTER> static int launch_tile(const RotArgs& a, int pixel_bytes,
   return VALI_OK;
 }
 
+// per_plane_shifts != 0: quarter turns whose shifts are derived from each plane's own size
+// (what PySurfaceRotator's normalisation means for every plane); otherwise the given
+// shifts apply to every plane unchanged (NPP semantics of RotPlanar).
+static int launch_rotate(RotArgs& a, int fmt, int sw, int sh, int dw, int dh, double angle,
+                         double shift_x, double shift_y, int per_plane_shifts, int n,
+                         hipStream_t stream) {
+  int elem = 1;
+  a.njobs = rotate_jobs(fmt, a.job, &elem);
+  if (!a.njobs)
+    return fail(VALI_ERR_UNSUPPORTED, "rotate: unsupported pixel format %d", fmt);
+  rotate_coeffs(angle, &a.c, &a.s);
+  const bool q90 = a.c == 0.f && a.s == 1.f, q180 = a.c == -1.f, q270 = a.c == 0.f && a.s == -1.f;
+  if (per_plane_shifts && !(q90 || q180 || q270 || a.c == 1.f))
+    return fail(VALI_ERR_INVALID_ARG, "rotate: per-plane shifts need a multiple of 90 degrees");
+  bool canonical = per_plane_shifts != 0 ||
+                   (q90 && shift_x == 0.0 && shift_y == (double)(sw - 1) && a.njobs == 1) ||
+                   (q270 && shift_y == 0.0 && shift_x == (double)(sh - 1) && a.njobs == 1);
+  static const bool no_tile = [] { const char* e = getenv("VALI_ROTATE_NO_TILE"); return e && e[0] == '1'; }();
+  const bool tiled = canonical && (q90 || q270) && !no_tile;
+
+  u32 total = 0;
+  for (int k = 0; k < a.njobs; ++k) {
+    RotJob& j = a.job[k];
+    const int psw = sw >> j.sub_x, psh = sh >> j.sub_y, pdw = dw >> j.sub_x, pdh = dh >> j.sub_y;
+    if (psw <= 0 || psh <= 0 || pdw <= 0 || pdh <= 0)
+      return fail(VALI_ERR_INVALID_ARG, "rotate: surface too small for its chroma planes");
+    if (per_plane_shifts) {
+      j.shift_x = q180 ? (float)(psw - 1) : q270 ? (float)(psh - 1) : 0.f;
+      j.shift_y = q90 ? (float)(psw - 1) : q180 ? (float)(psh - 1) : 0.f;
+    } else {
+      j.shift_x = (float)shift_x;
+      j.shift_y = (float)shift_y;
+    }
+    j.first_tile = total;
+    if (tiled) {
+      j.tiles_x = (u32)(psw + kRotTile - 1) / kRotTile;
+      total += j.tiles_x * (u32)((psh + kRotTile - 1) / kRotTile);
+    } else {
+      j.tiles_x = (u32)(pdw + 255) / 256;
+      total += j.tiles_x * (u32)((pdh + 3) / 4);
+    }
+  }
+  a.map.total = total;
+  a.map.per_xcd = (total + 7u) / 8u;
+  a.map.tiles_x = 1;
+  const dim3 grid(a.map.per_xcd * 8u, n), block(kBlock);
+  if (tiled) {
+    const int pixel_bytes = elem * a.job[0].channels; // all jobs of a format share it
+    const int rc = q90 ? launch_tile<1>(a, pixel_bytes, grid, stream) : launch_tile<3>(a, pixel_bytes, grid, stream);
+    if (rc != VALI_OK)
+      return rc;
+  } else if (elem == 1) {
+    hipLaunchKernelGGL(k_rotate_affine<uint8_t>, grid, block, 0, stream, a);
+  } else if (elem == 2) {
+    hipLaunchKernelGGL(k_rotate_affine<uint16_t>, grid, block, 0, stream, a);
+  } else {
+    hipLaunchKernelGGL(k_rotate_affine<float>, grid, block, 0, stream, a);
+  }
+  VALI_LAUNCH_CHECK();
+  return VALI_OK;
+}
+
 } // namespace vali
 
 using namespace vali;
@@ -226,62 +377,40 @@ extern "C" {
 
 int vali_rotate_coeffs(double angle_deg, float* c, float* s) {
   VALI_REQUIRE(c && s, "null argument");
-  // multiples of 90 degrees: exact 0 / +-1 (cos(pi/2) in floating point is 6e-17, which
-  // would push border pixels outside the source)
-  const double q = fmod(angle_deg, 360.0);
-  const double n = q < 0 ? q + 360.0 : q;
-  if (n == 0.0) { *c = 1.f; *s = 0.f; }
-  else if (n == 90.0) { *c = 0.f; *s = 1.f; }
-  else if (n == 180.0) { *c = -1.f; *s = 0.f; }
-  else if (n == 270.0) { *c = 0.f; *s = -1.f; }
-  else {
-    const double r = angle_deg * 3.14159265358979323846 / 180.0;
-    *c = (float)cos(r);
-    *s = (float)sin(r);
-  }
+  rotate_coeffs(angle_deg, c, s);
   return VALI_OK;
 }
 
-int vali_rotate_plane(const void* src, int src_pitch, int src_width, int src_height, void* dst,
-                      int dst_pitch, int dst_width, int dst_height, int elem_size, int channels,
-                      double angle, double shift_x, double shift_y, vali_stream_t stream) {
-  VALI_REQUIRE(src && dst, "null plane");
-  VALI_REQUIRE(src_width > 0 && src_height > 0 && dst_width > 0 && dst_height > 0, "empty plane");
-  VALI_REQUIRE(elem_size == 1 || elem_size == 2 || elem_size == 4, "elem_size must be 1, 2 or 4");
-  VALI_REQUIRE(channels == 1 || channels == 3, "channels must be 1 or 3");
+int vali_rotate(const vali_surface* src, const vali_surface* dst, double angle, double shift_x,
+                double shift_y, int per_plane_shifts, vali_stream_t stream) {
+  VALI_REQUIRE(src && dst, "null argument");
+  VALI_REQUIRE(src->format == dst->format, "src/dst format mismatch");
+  VALI_REQUIRE(src->width > 0 && src->height > 0 && dst->width > 0 && dst->height > 0, "empty surface");
+  VALI_REQUIRE(src->plane[0] && dst->plane[0], "null plane");
   RotArgs a = {};
-  a.src = (const uint8_t*)src;
-  a.dst = (uint8_t*)dst;
-  a.src_pitch = src_pitch; a.dst_pitch = dst_pitch;
-  a.src_w = src_width; a.src_h = src_height; a.dst_w = dst_width; a.dst_h = dst_height;
-  vali_rotate_coeffs(angle, &a.c, &a.s);
-  a.shift_x = (float)shift_x;
-  a.shift_y = (float)shift_y;
+  a.src = *src;
+  a.dst = *dst;
   hipStream_t s = as_stream(stream);
   DeviceScope scope(stream_device(s));
+  return launch_rotate(a, src->format, src->width, src->height, dst->width, dst->height, angle,
+                       shift_x, shift_y, per_plane_shifts, 1, s);
+}
 
-  // canonical quarter turns -> tiled transpose
-  const bool q90 = a.c == 0.f && a.s == 1.f && shift_x == 0.0 && shift_y == (double)(src_width - 1);
-  const bool q270 = a.c == 0.f && a.s == -1.f && shift_y == 0.0 && shift_x == (double)(src_height - 1);
-  static const bool no_tile = [] { const char* e = getenv("VALI_ROTATE_NO_TILE"); return e && e[0] == '1'; }();
-  if ((q90 || q270) && !no_tile) {
-    a.map = make_tile_map((src_width + kRotTile - 1) / kRotTile, (src_height + kRotTile - 1) / kRotTile);
-    const int rc = q90 ? launch_tile<1>(a, elem_size * channels, s) : launch_tile<3>(a, elem_size * channels, s);
-    if (rc != VALI_OK)
-      return rc;
-    VALI_LAUNCH_CHECK();
+int vali_rotate_batch(const vali_surface* d_src, const vali_surface* d_dst, int n, int format,
+                      int src_width, int src_height, int dst_width, int dst_height, double angle,
+                      double shift_x, double shift_y, int per_plane_shifts, vali_stream_t stream) {
+  VALI_REQUIRE(d_src && d_dst, "null argument");
+  VALI_REQUIRE(src_width > 0 && src_height > 0 && dst_width > 0 && dst_height > 0, "empty geometry");
+  VALI_REQUIRE(n >= 0 && n <= 65535, "batch size out of range (0..65535)");
+  if (n == 0)
     return VALI_OK;
-  }
-
-  a.map = make_tile_map((dst_width + 255) / 256, (dst_height + 3) / 4);
-  const dim3 grid(a.map.per_xcd * 8u), block(kBlock);
-#define VALI_ROT_AFFINE(T, C) hipLaunchKernelGGL((k_rotate_affine<T, C>), grid, block, 0, s, a)
-  if (elem_size == 1) { if (channels == 1) VALI_ROT_AFFINE(uint8_t, 1); else VALI_ROT_AFFINE(uint8_t, 3); }
-  else if (elem_size == 2) { if (channels == 1) VALI_ROT_AFFINE(uint16_t, 1); else VALI_ROT_AFFINE(uint16_t, 3); }
-  else { if (channels == 1) VALI_ROT_AFFINE(float, 1); else VALI_ROT_AFFINE(float, 3); }
-#undef VALI_ROT_AFFINE
-  VALI_LAUNCH_CHECK();
-  return VALI_OK;
+  RotArgs a = {};
+  a.d_src = d_src;
+  a.d_dst = d_dst;
+  hipStream_t s = as_stream(stream);
+  DeviceScope scope(stream_device(s));
+  return launch_rotate(a, format, src_width, src_height, dst_width, dst_height, angle, shift_x,
+                       shift_y, per_plane_shifts, n, s);
 }
 
 } // extern "C"

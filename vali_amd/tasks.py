@@ -351,7 +351,7 @@ class SurfaceBatch:
 # ---- PySurfaceUD -------------------------------------------------------------------------
 # UDSurface::SupportedConversions() (src/TC/src/UDSurface.cpp:117-133).  The planar-source
 # rows (YUV420 -> YUV444, YUV420_10bit -> YUV444_10bit) go through NPP Lanczos in the
-# reference (UDPlanar, :84-93); they are listed but not implemented yet (NOT_SUPPORTED).
+# reference (UDPlanar, :84-93); here they use the bilinear plane resizer.
 _UD_CONVERSIONS = [
     (F.NV12, F.YUV444), (F.NV12, F.RGB), (F.NV12, F.RGB_32F), (F.NV12, F.RGB_PLANAR),
     (F.NV12, F.RGB_32F_PLANAR), (F.YUV420, F.YUV444), (F.P10, F.YUV444_10bit), (F.P10, F.RGB_32F),
@@ -377,10 +377,22 @@ class PySurfaceUD(_SurfaceTask):
         if pair not in _UD_CONVERSIONS:                       # UDSurface.cpp:137-149
             return TaskExecDetails.failed(TaskExecInfo.NOT_SUPPORTED)
         if pair not in _UD_SEMIPLANAR:
-            return TaskExecDetails.failed(TaskExecInfo.NOT_SUPPORTED,
-                                          "planar-source UD (NPP Lanczos in the reference) "
-                                          "is not implemented")
+            return self._run_planar(src, dst)
         return _status(shim.ud_nv12(src.desc(), dst.desc(), self._stream))
+
+    def _run_planar(self, src: Surface, dst: Surface) -> TaskExecDetails:
+        """UDPlanar (UDSurface.cpp:84-93): every source plane is resized to the size of the
+        matching destination plane (YUV420 -> YUV444: chroma 2x up + common scale).  The
+        reference uses nppiResize Lanczos; here the bilinear resizer on the same NPP
+        sampling grid (interpolation differs)."""
+        fmt = int(F.Y) if src.ElemSize == 1 else int(F.GRAY12)
+        for sp, dp in zip(src._planes, dst._planes):
+            a = shim.SurfaceDesc([sp.GpuMem], [sp.Pitch], sp.Width, sp.Height, fmt)
+            b = shim.SurfaceDesc([dp.GpuMem], [dp.Pitch], dp.Width, dp.Height, fmt)
+            d = _status(shim.resize(a, b, shim.INTERP_LINEAR, self._stream))
+            if not d.success:
+                return d
+        return TaskExecDetails.ok()
 
     def RunAsync(self, src: Surface, dst: Surface) -> Tuple[bool, TaskExecInfo]:
         d = self._run(src, dst)
@@ -442,39 +454,61 @@ class PySurfaceRotator(_SurfaceTask):
 
     @staticmethod
     def _normalise(angle: float, shift_x: float, shift_y: float):
-        """PySurfaceRotator::Run (:40-73): returns (angle, per-plane shift function | None)."""
+        """PySurfaceRotator::Run (:40-73): multiples of 90 degrees with zero shifts become
+        (normalised angle, per-plane canonical shifts)."""
         import math
 
         if math.fmod(angle, 90.0) == 0.0 and shift_x == 0.0 and shift_y == 0.0:
-            n = (int(round(angle)) + 360) % 360
-            return float(n), {0: lambda w, h: (0.0, 0.0), 90: lambda w, h: (0.0, w - 1.0),
-                              180: lambda w, h: (w - 1.0, h - 1.0),
-                              270: lambda w, h: (h - 1.0, 0.0)}[n]
-        return float(angle), None
+            return float((int(round(angle)) + 360) % 360), True
+        return float(angle), False
+
+    @staticmethod
+    def _check(src_format, dst_format, num_components, num_planes) -> Optional[TaskExecDetails]:
+        if src_format != dst_format:                                     # RotateSurface.cpp:162-164
+            return TaskExecDetails.failed(TaskExecInfo.SRC_DST_FMT_MISMATCH)
+        impl = _ROT_IMPL.get(src_format)
+        if impl is None:                                                 # :204-206
+            return TaskExecDetails.failed(TaskExecInfo.NOT_SUPPORTED)
+        kind, _ = impl
+        if kind == "planar" and num_components != num_planes:            # RotPlanar, :135-136
+            return TaskExecDetails.failed(TaskExecInfo.INVALID_INPUT)
+        if kind == "packed" and num_planes != 1:                         # RotPacked, :152-153
+            return TaskExecDetails.failed(TaskExecInfo.INVALID_INPUT)
+        return None
 
     def _run(self, src: Surface, dst: Surface, angle: float, shift_x: float, shift_y: float
              ) -> TaskExecDetails:
-        if src.Format != dst.Format:                                     # RotateSurface.cpp:162-164
-            return TaskExecDetails.failed(TaskExecInfo.SRC_DST_FMT_MISMATCH)
-        impl = _ROT_IMPL.get(src.Format)
-        if impl is None:                                                 # :204-206
-            return TaskExecDetails.failed(TaskExecInfo.NOT_SUPPORTED)
-        kind, elem = impl
-        if kind == "planar" and src.NumComponents != src.NumPlanes:      # RotPlanar, :135-136
-            return TaskExecDetails.failed(TaskExecInfo.INVALID_INPUT)
-        if kind == "packed" and src.NumPlanes != 1:                      # RotPacked, :152-153
-            return TaskExecDetails.failed(TaskExecInfo.INVALID_INPUT)
-        angle, shifts = self._normalise(angle, shift_x, shift_y)
-        channels = 3 if kind == "packed" else 1
-        for i in range(src.NumPlanes):
-            sp, dp = src._planes[i], dst._planes[i]
-            sw, sh, dw, dh = sp.Width // channels, sp.Height, dp.Width // channels, dp.Height
-            sx, sy = shifts(sw, sh) if shifts else (shift_x, shift_y)
-            d = _status(shim.rotate_plane(sp.GpuMem, sp.Pitch, sw, sh, dp.GpuMem, dp.Pitch, dw, dh,
-                                          elem, channels, angle, sx, sy, self._stream))
-            if not d.success:
-                return d
-        return TaskExecDetails.ok()
+        err = self._check(src.Format, dst.Format, src.NumComponents, src.NumPlanes)
+        if err is not None:
+            return err
+        angle, per_plane = self._normalise(angle, shift_x, shift_y)
+        return _status(shim.rotate(src.desc(), dst.desc(), angle, shift_x, shift_y, int(per_plane),
+                                   self._stream))
+
+    def PrepareBatch(self, srcs: Sequence[Surface], dsts: Sequence[Surface]) -> "SurfaceBatch":
+        return SurfaceBatch(self._gpu_id, self._stream, srcs, dsts)
+
+    def RunBatchAsync(self, batch, dsts=None, angle: float = 0.0, shift_x: float = 0.0,
+                      shift_y: float = 0.0) -> Tuple[bool, TaskExecInfo]:
+        """One launch rotates every plane of every surface of the batch."""
+        if not isinstance(batch, SurfaceBatch):
+            batch = SurfaceBatch(self._gpu_id, self._stream, batch, dsts)
+        s0 = batch._keep[0][0]
+        err = self._check(batch.src_format, batch.dst_format, s0.NumComponents, s0.NumPlanes)
+        if err is not None:
+            return False, err.info
+        angle, per_plane = self._normalise(float(angle), float(shift_x), float(shift_y))
+        d = _status(shim.rotate_batch(batch.d_src, batch.d_dst, batch.n, int(batch.src_format),
+                                      batch.src_size[0], batch.src_size[1], batch.dst_size[0],
+                                      batch.dst_size[1], angle, float(shift_x), float(shift_y),
+                                      int(per_plane), self._stream))
+        return d.success, d.info
+
+    def RunBatch(self, batch, dsts=None, angle: float = 0.0, shift_x: float = 0.0,
+                 shift_y: float = 0.0) -> Tuple[bool, TaskExecInfo]:
+        r = self.RunBatchAsync(batch, dsts, angle, shift_x, shift_y)
+        self._sync()
+        return r
 
     def RunAsync(self, src: Surface, dst: Surface, angle: float, shift_x: float = 0.0,
                  shift_y: float = 0.0) -> Tuple[bool, TaskExecInfo]:
