@@ -147,6 +147,70 @@ __device__ __forceinline__ SurfRef load_surface(const vali_surface* arr, const v
   return r;
 }
 
+// ---------------------------------------------------------------------------
+// Plane jobs: kernels that treat every plane of a surface as an independent image
+// (resize, rotate) concatenate the planes' tiles into one tile list per frame.
+// A job names the component and its subsampling; for single-frame launches the host also
+// resolves the plane pointers into the job (sp/dp), so the device never indexes a
+// register-resident descriptor with a run-time component number (that sends the whole
+// descriptor to scratch memory).  Batched launches read arr[frame].plane[comp] from the
+// device descriptor array with an ordinary dynamically-indexed load.
+// ---------------------------------------------------------------------------
+struct PlaneJob {
+  int comp;           // component index in vali_surface.plane[] / pitch[]
+  int sub_x, sub_y;   // log2 subsampling relative to the surface size
+  int channels;       // interleaved channels in the plane
+  u32 first_tile, tiles_x;
+  float shift_x, shift_y; // rotate only
+  const uint8_t* sp;  // single-frame launches: resolved by the host
+  uint8_t* dp;
+  int spitch, dpitch;
+};
+
+struct PlaneView {
+  const uint8_t* sp;
+  uint8_t* dp;
+  int spitch, dpitch, sw, sh, dw, dh;
+};
+
+// sw/sh/dw/dh: the single-frame SURFACE sizes (ignored for batches)
+__device__ __forceinline__ PlaneView plane_view(const vali_surface* d_src, const vali_surface* d_dst,
+                                                u32 frame, const PlaneJob& job, int sw, int sh,
+                                                int dw, int dh) {
+  PlaneView v;
+  if (d_src) {
+    const vali_surface* s = d_src + frame;
+    const vali_surface* d = d_dst + frame;
+    v.sp = (const uint8_t*)s->plane[job.comp];
+    v.dp = (uint8_t*)d->plane[job.comp];
+    v.spitch = s->pitch[job.comp];
+    v.dpitch = d->pitch[job.comp];
+    sw = s->width; sh = s->height; dw = d->width; dh = d->height;
+  } else {
+    v.sp = job.sp; v.dp = job.dp; v.spitch = job.spitch; v.dpitch = job.dpitch;
+  }
+  v.sw = sw >> job.sub_x; v.sh = sh >> job.sub_y;
+  v.dw = dw >> job.sub_x; v.dh = dh >> job.sub_y;
+  return v;
+}
+
+// tile index of this workgroup -> (job, tile_x, tile_y) through the XCD-contiguous map;
+// false for grid padding.  Conditional copies instead of jobs[j] (no dynamic indexing).
+__device__ __forceinline__ bool plane_tile(const PlaneJob (&jobs)[3], int njobs, const TileMap& map,
+                                           PlaneJob& job, u32& tx, u32& ty) {
+  const u32 b = blockIdx.x;
+  const u32 t = (b & 7u) * map.per_xcd + (b >> 3);
+  if (t >= map.total)
+    return false;
+  job = jobs[0];
+  if (njobs > 1 && t >= jobs[1].first_tile) job = jobs[1];
+  if (njobs > 2 && t >= jobs[2].first_tile) job = jobs[2];
+  const u32 local = t - job.first_tile;
+  ty = local / job.tiles_x;
+  tx = local - ty * job.tiles_x;
+  return true;
+}
+
 // Order LDS traffic of ONE wave: DS instructions of a wave execute in issue
 // order, so a compiler-level fence is all that is needed between the strided
 // writes and the transposed reads of the same wave-private strip.

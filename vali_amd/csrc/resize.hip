@@ -28,18 +28,12 @@
 
 namespace vali {
 
-struct ResizeJob {
-  int comp;        // component index in vali_surface.plane[] (src and dst)
-  int sub_x, sub_y; // log2 subsampling of this plane relative to the surface size
-  int channels;    // interleaved channels in the plane
-  u32 first_tile;  // index of this job's first tile in the frame's tile list
-  u32 tiles_x;
-};
+typedef PlaneJob ResizeJob; // dev_util.hpp
 
 struct ResizeArgs {
-  const vali_surface* d_src;
+  const vali_surface* d_src; // batch: device descriptor arrays
   const vali_surface* d_dst;
-  vali_surface src, dst;
+  int sw, sh, dw, dh;        // single frame: surface sizes (planes are resolved into the jobs)
   ResizeJob job[3];
   int njobs;
   TileMap map;
@@ -122,29 +116,15 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
 
 template <typename T>
 __global__ void __launch_bounds__(kBlock) k_resize(const ResizeArgs a) {
-  const u32 b = blockIdx.x;
-  const u32 t = (b & 7u) * a.map.per_xcd + (b >> 3);
-  if (t >= a.map.total)
+  ResizeJob job;
+  u32 tx, ty;
+  if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty))
     return;
-  int j = 0;
-  if (a.njobs > 1 && t >= a.job[1].first_tile)
-    j = 1;
-  if (a.njobs > 2 && t >= a.job[2].first_tile)
-    j = 2;
-  const ResizeJob job = a.job[j];
-  const u32 local = t - job.first_tile;
-  const u32 ty = local / job.tiles_x, tx = local - ty * job.tiles_x;
-  const SurfRef s = load_surface(a.d_src, a.src, blockIdx.y);
-  const SurfRef d = load_surface(a.d_dst, a.dst, blockIdx.y);
-  const int sw = s.width >> job.sub_x, sh = s.height >> job.sub_y;
-  const int dw = d.width >> job.sub_x, dh = d.height >> job.sub_y;
-  const uint8_t* sp = s.p[job.comp];
-  uint8_t* dp = d.p[job.comp];
-  const int spitch = s.pitch[job.comp], dpitch = d.pitch[job.comp];
+  const PlaneView v = plane_view(a.d_src, a.d_dst, blockIdx.y, job, a.sw, a.sh, a.dw, a.dh);
   switch (job.channels) {
-  case 1: resize_tile<T, 1>(sp, spitch, sw, sh, dp, dpitch, dw, dh, tx, ty); break;
-  case 2: resize_tile<T, 2>(sp, spitch, sw, sh, dp, dpitch, dw, dh, tx, ty); break;
-  default: resize_tile<T, 3>(sp, spitch, sw, sh, dp, dpitch, dw, dh, tx, ty); break;
+  case 1: resize_tile<T, 1>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty); break;
+  case 2: resize_tile<T, 2>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty); break;
+  default: resize_tile<T, 3>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty); break;
   }
 }
 
@@ -214,8 +194,17 @@ int vali_resize(const vali_surface* src, const vali_surface* dst, int interpolat
   if (interpolation != VALI_INTERP_LINEAR)
     return fail(VALI_ERR_UNSUPPORTED, "resize: interpolation %d not implemented", interpolation);
   ResizeArgs a = {};
-  a.src = *src;
-  a.dst = *dst;
+  a.sw = src->width; a.sh = src->height; a.dw = dst->width; a.dh = dst->height;
+  int elem = 1;
+  const int nj = resize_jobs(src->format, a.job, &elem);
+  for (int k = 0; k < nj; ++k) { // resolve the planes on the host (see PlaneJob)
+    const int c = a.job[k].comp;
+    VALI_REQUIRE(src->plane[c] && dst->plane[c], "null plane");
+    a.job[k].sp = (const uint8_t*)src->plane[c];
+    a.job[k].dp = (uint8_t*)dst->plane[c];
+    a.job[k].spitch = src->pitch[c];
+    a.job[k].dpitch = dst->pitch[c];
+  }
   hipStream_t s = as_stream(stream);
   DeviceScope scope(stream_device(s));
   return launch_resize(a, src->format, dst->width, dst->height, 1, s);

@@ -35,37 +35,20 @@
 
 namespace vali {
 
-struct RotJob {
-  int comp;          // component index in vali_surface.plane[]
-  int sub_x, sub_y;  // log2 subsampling of the plane
-  int channels;      // interleaved channels
-  u32 first_tile, tiles_x;
-  float shift_x, shift_y;
-};
+typedef PlaneJob RotJob; // dev_util.hpp
 
 struct RotArgs {
-  const vali_surface* d_src;
+  const vali_surface* d_src; // batch: device descriptor arrays
   const vali_surface* d_dst;
-  vali_surface src, dst;
+  int sw, sh, dw, dh;        // single frame: surface sizes (planes are resolved into the jobs)
   RotJob job[3];
   int njobs;
   float c, s;
   TileMap map;
 };
 
-// tile index -> (job, tile_x, tile_y); false for grid padding
-__device__ __forceinline__ bool rot_tile(const RotArgs& a, int& j, u32& tx, u32& ty) {
-  const u32 b = blockIdx.x;
-  const u32 t = (b & 7u) * a.map.per_xcd + (b >> 3);
-  if (t >= a.map.total)
-    return false;
-  j = 0;
-  if (a.njobs > 1 && t >= a.job[1].first_tile) j = 1;
-  if (a.njobs > 2 && t >= a.job[2].first_tile) j = 2;
-  const u32 local = t - a.job[j].first_tile;
-  ty = local / a.job[j].tiles_x;
-  tx = local - ty * a.job[j].tiles_x;
-  return true;
+__device__ __forceinline__ bool rot_tile(const RotArgs& a, RotJob& job, u32& tx, u32& ty) {
+  return plane_tile(a.job, a.njobs, a.map, job, tx, ty);
 }
 
 template <typename T> __device__ __forceinline__ float texel_f(const uint8_t* row, int idx) {
@@ -142,19 +125,15 @@ __device__ __forceinline__ void affine_tile(const RotArgs& a, const RotJob& job,
 
 template <typename T>
 __global__ void __launch_bounds__(kBlock) k_rotate_affine(const RotArgs a) {
-  int j;
+  RotJob job;
   u32 tx, ty;
-  if (!rot_tile(a, j, tx, ty))
+  if (!rot_tile(a, job, tx, ty))
     return;
-  const RotJob job = a.job[j];
-  const SurfRef s = load_surface(a.d_src, a.src, blockIdx.y);
-  const SurfRef d = load_surface(a.d_dst, a.dst, blockIdx.y);
-  const int sw = s.width >> job.sub_x, sh = s.height >> job.sub_y;
-  const int dw = d.width >> job.sub_x, dh = d.height >> job.sub_y;
+  const PlaneView v = plane_view(a.d_src, a.d_dst, blockIdx.y, job, a.sw, a.sh, a.dw, a.dh);
   if (job.channels == 1)
-    affine_tile<T, 1>(a, job, s.p[job.comp], s.pitch[job.comp], sw, sh, d.p[job.comp], d.pitch[job.comp], dw, dh, tx, ty);
+    affine_tile<T, 1>(a, job, v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty);
   else
-    affine_tile<T, 3>(a, job, s.p[job.comp], s.pitch[job.comp], sw, sh, d.p[job.comp], d.pitch[job.comp], dw, dh, tx, ty);
+    affine_tile<T, 3>(a, job, v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty);
 }
 
 // ---- canonical 90 / 270 degree permutation: LDS-tiled transpose -----------------------------
@@ -166,18 +145,15 @@ template <int P, int QUARTER>
 __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
   constexpr int S = kRotTile * P + 4; // LDS row stride in bytes (dword aligned, odd dwords)
   __shared__ __attribute__((aligned(16))) uint8_t lds[kRotTile * S];
-  int j;
+  RotJob job;
   u32 tile_x, tile_y;
-  if (!rot_tile(a, j, tile_x, tile_y))
+  if (!rot_tile(a, job, tile_x, tile_y))
     return;
-  const RotJob job = a.job[j];
-  const SurfRef s = load_surface(a.d_src, a.src, blockIdx.y);
-  const SurfRef d = load_surface(a.d_dst, a.dst, blockIdx.y);
-  const int src_w = s.width >> job.sub_x, src_h = s.height >> job.sub_y;
-  const int dst_w = d.width >> job.sub_x, dst_h = d.height >> job.sub_y;
-  const uint8_t* src = s.p[job.comp];
-  uint8_t* dst = d.p[job.comp];
-  const int src_pitch = s.pitch[job.comp], dst_pitch = d.pitch[job.comp];
+  const PlaneView v = plane_view(a.d_src, a.d_dst, blockIdx.y, job, a.sw, a.sh, a.dw, a.dh);
+  const int src_w = v.sw, src_h = v.sh, dst_w = v.dw, dst_h = v.dh;
+  const uint8_t* src = v.sp;
+  uint8_t* dst = v.dp;
+  const int src_pitch = v.spitch, dst_pitch = v.dpitch;
 
   const int cx = tile_x * kRotTile, ry = tile_y * kRotTile; // src tile origin (col, row)
   const int tw = min(kRotTile, src_w - cx), th = min(kRotTile, src_h - ry);
@@ -388,8 +364,17 @@ int vali_rotate(const vali_surface* src, const vali_surface* dst, double angle, 
   VALI_REQUIRE(src->width > 0 && src->height > 0 && dst->width > 0 && dst->height > 0, "empty surface");
   VALI_REQUIRE(src->plane[0] && dst->plane[0], "null plane");
   RotArgs a = {};
-  a.src = *src;
-  a.dst = *dst;
+  a.sw = src->width; a.sh = src->height; a.dw = dst->width; a.dh = dst->height;
+  int elem = 1;
+  const int nj = rotate_jobs(src->format, a.job, &elem);
+  for (int k = 0; k < nj; ++k) { // resolve the planes on the host (see PlaneJob)
+    const int c = a.job[k].comp;
+    VALI_REQUIRE(src->plane[c] && dst->plane[c], "null plane");
+    a.job[k].sp = (const uint8_t*)src->plane[c];
+    a.job[k].dp = (uint8_t*)dst->plane[c];
+    a.job[k].spitch = src->pitch[c];
+    a.job[k].dpitch = dst->pitch[c];
+  }
   hipStream_t s = as_stream(stream);
   DeviceScope scope(stream_device(s));
   return launch_rotate(a, src->format, src->width, src->height, dst->width, dst->height, angle,
