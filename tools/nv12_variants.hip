@@ -14,12 +14,16 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 struct Frame { const uint8_t* y; const uint8_t* uv; uint8_t* rgb; };
 struct Csc { float y0, cy, crv, cgu, cgv, cbu; };
 
-template <bool NT> __device__ __forceinline__ uint4 ld(const uint8_t* p) {
-  if constexpr (NT) { v4u v = __builtin_nontemporal_load((const v4u*)p); return make_uint4(v.x, v.y, v.z, v.w); }
+#define GLB __attribute__((address_space(1)))
+template <bool NT, bool G = false> __device__ __forceinline__ uint4 ld(const uint8_t* p) {
+  if constexpr (G) { v4u v = NT ? __builtin_nontemporal_load((const GLB v4u*)p) : *(const GLB v4u*)p; return make_uint4(v.x, v.y, v.z, v.w); }
+  else if constexpr (NT) { v4u v = __builtin_nontemporal_load((const v4u*)p); return make_uint4(v.x, v.y, v.z, v.w); }
   else return *(const uint4*)p;
 }
-template <bool NT> __device__ __forceinline__ void st(uint8_t* p, uint4 v) {
-  if constexpr (NT) { v4u w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, (v4u*)p); }
+template <bool NT, bool G = false> __device__ __forceinline__ void st(uint8_t* p, uint4 v) {
+  v4u w = {v.x, v.y, v.z, v.w};
+  if constexpr (G) { if constexpr (NT) __builtin_nontemporal_store(w, (GLB v4u*)p); else *(GLB v4u*)p = w; }
+  else if constexpr (NT) __builtin_nontemporal_store(w, (v4u*)p);
   else *(uint4*)p = v;
 }
 template <int I> __device__ __forceinline__ float ub(u32 w) { return (float)((w >> (8 * I)) & 0xffu); }
@@ -46,12 +50,12 @@ __device__ __forceinline__ void convert16x2(uint4 ya, uint4 yb, uint4 uv, const 
 __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 
-template <bool NTS>
+template <bool NTS, bool G = false>
 __device__ __forceinline__ void strip_store(uint4* L, int lane, const u32* o, bool valid, uint8_t* rb, int valid_bytes) {
   if (valid) { L[lane * 3] = make_uint4(o[0], o[1], o[2], o[3]); L[lane * 3 + 1] = make_uint4(o[4], o[5], o[6], o[7]); L[lane * 3 + 2] = make_uint4(o[8], o[9], o[10], o[11]); }
   wsync();
 #pragma unroll
-  for (int k = 0; k < 3; ++k) { const int off = (k * 64 + lane) * 16; if (off < valid_bytes) st<NTS>(rb + off, L[k * 64 + lane]); }
+  for (int k = 0; k < 3; ++k) { const int off = (k * 64 + lane) * 16; if (off < valid_bytes) st<NTS, G>(rb + off, L[k * 64 + lane]); }
   wsync();
 }
 
@@ -59,7 +63,7 @@ __device__ __forceinline__ void strip_store(uint4* L, int lane, const u32* o, bo
 //        8 = XCD-contiguous row-pair remap, 16 = skeleton (no math: copy bytes), 32 = direct stores
 template <int FLAGS, int RPT /*row pairs per thread*/>
 __global__ void __launch_bounds__(256) k_conv(const Frame* fr, int W, int H, int sp, int dp, Csc k, int rp_per_xcd) {
-  constexpr bool NTS = FLAGS & 1, NTL = FLAGS & 2, STACK = FLAGS & 4, XCD = FLAGS & 8, SKEL = FLAGS & 16, DIRECT = FLAGS & 32;
+  constexpr bool NTS = FLAGS & 1, NTL = FLAGS & 2, STACK = FLAGS & 4, XCD = FLAGS & 8, SKEL = FLAGS & 16, DIRECT = FLAGS & 32, GL = FLAGS & 64;
   __shared__ uint4 lds[4][192];
   extern __shared__ uint4 dyn_pad[];
   const Frame f = fr[blockIdx.z];
@@ -79,9 +83,9 @@ __global__ void __launch_bounds__(256) k_conv(const Frame* fr, int W, int H, int
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
       const int rp = min(rp0 + r, row_pairs - 1);
-      ya[r] = ld<NTL>(f.y + (size_t)(2 * rp) * sp + x0);
-      yb[r] = ld<NTL>(f.y + (size_t)(2 * rp + 1) * sp + x0);
-      uv[r] = ld<NTL>(f.uv + (size_t)rp * sp + x0);
+      ya[r] = ld<NTL, GL>(f.y + (size_t)(2 * rp) * sp + x0);
+      yb[r] = ld<NTL, GL>(f.y + (size_t)(2 * rp + 1) * sp + x0);
+      uv[r] = ld<NTL, GL>(f.uv + (size_t)rp * sp + x0);
     }
   }
 #pragma unroll
@@ -105,8 +109,8 @@ __global__ void __launch_bounds__(256) k_conv(const Frame* fr, int W, int H, int
         st<NTS>(p, make_uint4(o1[0], o1[1], o1[2], o1[3])); st<NTS>(p + 16, make_uint4(o1[4], o1[5], o1[6], o1[7])); st<NTS>(p + 32, make_uint4(o1[8], o1[9], o1[10], o1[11]));
       }
     } else {
-      strip_store<NTS>(lds[wave], lane, o0, valid, rb, valid_bytes);
-      strip_store<NTS>(lds[wave], lane, o1, valid, rb + dp, valid_bytes);
+      strip_store<NTS, GL>(lds[wave], lane, o0, valid, rb, valid_bytes);
+      strip_store<NTS, GL>(lds[wave], lane, o1, valid, rb + dp, valid_bytes);
     }
   }
 }
@@ -180,24 +184,13 @@ int main(int argc, char** argv) {
 #define L(FL, RPT, grid, rpx) [&] { k_conv<FL, RPT><<<grid, 256>>>(dfr, W, H, sp, dp, k, rpx); }
   auto pad8 = [](int n, int C) { int per = 8 * C; return (n + per - 1) / per * per; };
 #define LD(FL, RPT, grid, rpx, dyn) [&] { k_conv<FL, RPT><<<grid, 256, dyn>>>(dfr, W, H, sp, dp, k, rpx); }
-  run("v0 baseline (library kernel shape)", L(0, 1, GRID_X, 0), true);
-  // LDS cap: blocks/CU = floor(160 KiB / (12 KiB + dyn))
   auto dyn_for = [](int blocks) { return (160 * 1024 / blocks) / 1024 * 1024 - 12 * 1024 - 512; };
-  for (int b : {3, 4, 5, 6, 8}) {
-    char name[96]; snprintf(name, sizeof name, "rowpair xcd135 nts, <=%d blocks/CU", b);
-    run(name, LD(9, 1, dim3(1, rows, F), rows / 8, b >= 8 ? 0 : dyn_for(b)), true);
+  for (int rep = 0; rep < 3; ++rep) {
+    run("flat   : xcd135 nts <=4 blocks/CU", LD(9, 1, dim3(1, rows, F), rows / 8, dyn_for(4)), true);
+    run("global : xcd135 nts <=4 blocks/CU", LD(73, 1, dim3(1, rows, F), rows / 8, dyn_for(4)), true);
   }
-  for (int b : {3, 4, 5, 6, 8}) {
-    char name[96]; snprintf(name, sizeof name, "row xcd270 nts, <=%d blocks/CU", b);
-    const int dyn = b >= 8 ? 0 : dyn_for(b);
-    run(name, [&] { k_conv_row<9><<<dim3(1, H, F), 256, dyn>>>(dfr, W, H, sp, dp, k, H / 8); }, true);
-  }
-  run("rowpair xcd135 nt ld+st, <=4", LD(11, 1, dim3(1, rows, F), rows / 8, dyn_for(4)), true);
-  run("rowpair xcd135 plain st, <=4", LD(8, 1, dim3(1, rows, F), rows / 8, dyn_for(4)), true);
-  run("rowpair no-xcd nts, <=4", LD(1, 1, GRID_X, 0, dyn_for(4)), true);
-  run("rowpair xcd45 nts, <=4", LD(9, 1, dim3(1, pad8(rows, 45), F), 45, dyn_for(4)), true);
-  run("rowpair xcd135 nts 2rp/thread, <=4", LD(9, 2, dim3(1, pad8(rows / 2, 68), F), 68, dyn_for(4)), true);
-  run("rowpair xcd135 nts direct st, <=4", LD(41, 1, dim3(1, rows, F), rows / 8, dyn_for(4)), true);
-  run("v0 again", L(0, 1, GRID_X, 0), true);
+  run("global : xcd135 nts <=5 blocks/CU", LD(73, 1, dim3(1, rows, F), rows / 8, dyn_for(5)), true);
+  run("global : xcd135 nts <=3 blocks/CU", LD(73, 1, dim3(1, rows, F), rows / 8, dyn_for(3)), true);
+  run("global : xcd135 nt ld+st <=4", LD(75, 1, dim3(1, rows, F), rows / 8, dyn_for(4)), true);
   return 0;
 }

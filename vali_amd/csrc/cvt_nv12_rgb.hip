@@ -143,11 +143,11 @@ __global__ void __launch_bounds__(kBlock) k_nv12_rgb8(const Nv12RgbArgs a) {
     const bool lane_valid = g < groups;
     u32 o0[12], o1[12];          // packed rows (or r[4] g[4] b[4] when planar)
     if (lane_valid) {
-      const uint4 ya = *reinterpret_cast<const uint4*>(py + (size_t)row0 * sp_y + x0);
+      const uint4 ya = load16(py + (size_t)row0 * sp_y + x0);
       // odd height: the last pair re-reads row0 (always a valid address)
       const uint4 yb =
-          *reinterpret_cast<const uint4*>(py + (size_t)(row0 + (has_row1 ? 1 : 0)) * sp_y + x0);
-      const uint4 uv = *reinterpret_cast<const uint4*>(puv + (size_t)tile_y * sp_uv + x0);
+          load16(py + (size_t)(row0 + (has_row1 ? 1 : 0)) * sp_y + x0);
+      const uint4 uv = load16(puv + (size_t)tile_y * sp_uv + x0);
       const u32 yw0[4] = {ya.x, ya.y, ya.z, ya.w};
       const u32 yw1[4] = {yb.x, yb.y, yb.z, yb.w};
       const u32 uvw[4] = {uv.x, uv.y, uv.z, uv.w};

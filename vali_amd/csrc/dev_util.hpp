@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/vali_hip.h"
 
 namespace vali {
@@ -67,17 +69,52 @@ __device__ __forceinline__ u32 quantize_u8(float v) {
 // the surface kernels never re-read what they write, and streaming full 128-byte
 // lines past the L2 measured +2..3% on the 1:2 read:write mix (profiles/r01_variants.md).
 // NEVER use it for partial-line (strided 16 B) stores: that measured 2.4x slower.
+//
+// Plane pointers reach the kernels through descriptors in memory, so the compiler only knows
+// them as generic pointers and would emit flat_load/flat_store (which also tick the LDS
+// counter and serialise against ds_* traffic).  Every surface lives in global memory: the
+// helpers below cast to address space 1 so the ISA is global_load/global_store.
+#define VALI_GLOBAL __attribute__((address_space(1)))
 typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
+typedef float v4f32 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void store16_nt(void* p, uint4 v) {
-  const v4u32 w = {v.x, v.y, v.z, v.w};
-  __builtin_nontemporal_store(w, reinterpret_cast<v4u32*>(p));
+template <typename T> __device__ __forceinline__ T gload(const void* p) {
+  return *(const VALI_GLOBAL T*)p;
+}
+template <typename T> __device__ __forceinline__ void gstore(void* p, T v) {
+  *(VALI_GLOBAL T*)p = v;
 }
 
-__device__ __forceinline__ void store16(void* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
-
-__device__ __forceinline__ uint4 load16(const void* p) {
-  return *reinterpret_cast<const uint4*>(p);
+// The streaming converters deliberately keep GENERIC pointers for their 16-byte accesses:
+// an A/B on NV12->RGB 2160p measured flat_load/flat_store 1.2% FASTER than the
+// global_* forms (6.18 vs 6.11 TB/s, 3 interleaved repetitions, profiles/r01_variants.md).
+__device__ __forceinline__ void store16_nt(void* p, uint4 v) {
+  const v4u32 w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, (v4u32*)p);
+}
+__device__ __forceinline__ void store16(void* p, uint4 v) { *(uint4*)p = v; }
+__device__ __forceinline__ uint4 load16(const void* p) { return *(const uint4*)p; }
+// typed (global address space) forms for the gather kernels
+__device__ __forceinline__ uint4 gload16(const void* p) {
+  const v4u32 w = *(const VALI_GLOBAL v4u32*)p;
+  return make_uint4(w.x, w.y, w.z, w.w);
+}
+__device__ __forceinline__ uint2 load8(const void* p) {
+  const v2u32 w = *(const VALI_GLOBAL v2u32*)p;
+  return make_uint2(w.x, w.y);
+}
+__device__ __forceinline__ void store8(void* p, uint2 v) {
+  const v2u32 w = {v.x, v.y};
+  *(VALI_GLOBAL v2u32*)p = w;
+}
+__device__ __forceinline__ void store16f(void* p, float4 v) {
+  const v4f32 w = {v.x, v.y, v.z, v.w};
+  *(VALI_GLOBAL v4f32*)p = w;
+}
+__device__ __forceinline__ float4 load16f(const void* p) {
+  const v4f32 w = *(const VALI_GLOBAL v4f32*)p;
+  return make_float4(w.x, w.y, w.z, w.w);
 }
 
 // ---------------------------------------------------------------------------
@@ -262,7 +299,7 @@ __device__ __forceinline__ void strip_load_row(PackedStrip& strip, int lane,
   for (int k = 0; k < 3; ++k) {
     const int off = (k * kWave + lane) * 16;
     if (off < valid_bytes)
-      strip.v[k * kWave + lane] = *reinterpret_cast<const uint4*>(row_base + off);
+      strip.v[k * kWave + lane] = load16(row_base + off);
   }
   wave_lds_sync();
   if (lane_valid) {
@@ -312,6 +349,69 @@ __device__ __forceinline__ void deinterleave3(const u32 (&o)[12], u32 (&a)[4],
     const u32 c01 = __builtin_amdgcn_perm(d1, d0, 0x00000502u); // c0 c1 . .
     c[j] = __builtin_amdgcn_perm(d2, c01, 0x07040100u);
   }
+}
+
+// ---------------------------------------------------------------------------
+// Finish + store 4 adjacent pixels of C interleaved channels held as floats (geometry
+// kernels: resize, rotate).  u8/u16: round-half-even + saturate; f32: as is.  The 4*C
+// elements are packed into dwords IN REGISTERS (a byte array + memcpy goes through scratch
+// memory and serialises every load behind it) and leave as one wide store when the lane
+// has all 4 pixels and the address is aligned; `mask` = which of the 4 pixels exist.
+// ---------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ u32 finish_bits(float v);
+template <> __device__ __forceinline__ u32 finish_bits<uint8_t>(float v) { return quantize_u8(v); }
+template <> __device__ __forceinline__ u32 finish_bits<uint16_t>(float v) {
+  const float r = __builtin_fminf(__builtin_fmaxf(__builtin_rintf(v), 0.0f), 65535.0f);
+  return (u32)r;
+}
+template <> __device__ __forceinline__ u32 finish_bits<float>(float v) { return __float_as_uint(v); }
+
+template <typename T, int C>
+__device__ __forceinline__ void store_px4(uint8_t* dst, const float (&res)[4][C], u32 mask) {
+  constexpr int E = (int)sizeof(T), N = 4 * C, NB = N * E, PER = 4 / E; // PER elements per dword
+  u32 w[NB / 4];
+#pragma unroll
+  for (int k = 0; k < NB / 4; ++k)
+    w[k] = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const float v = res[k / C][k % C];
+    if constexpr (E == 1)
+      w[k / 4] = __builtin_amdgcn_cvt_pk_u8_f32(v, (u32)(k % 4), w[k / 4]);
+    else
+      w[k / PER] |= finish_bits<T>(v) << (8 * E * (k % PER));
+  }
+  constexpr u32 kAlign = NB % 16 == 0 ? 15u : (NB % 8 == 0 ? 7u : 3u);
+  if (mask == 0xfu && (((uintptr_t)dst) & kAlign) == 0) {
+    if constexpr (NB % 16 == 0) {
+#pragma unroll
+      for (int k = 0; k < NB / 16; ++k) {
+        const v4u32 q = {w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]};
+        ((VALI_GLOBAL v4u32*)dst)[k] = q;
+      }
+    } else if constexpr (NB % 8 == 0) {
+#pragma unroll
+      for (int k = 0; k < NB / 8; ++k) {
+        const v2u32 q = {w[2 * k], w[2 * k + 1]};
+        ((VALI_GLOBAL v2u32*)dst)[k] = q;
+      }
+    } else if constexpr (NB == 12) {
+      typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+      const v3u32 q = {w[0], w[1], w[2]};
+      *(VALI_GLOBAL v3u32*)dst = q; // global_store_dwordx3 (needs 4-byte alignment only)
+    } else {
+#pragma unroll
+      for (int k = 0; k < NB / 4; ++k)
+        ((VALI_GLOBAL u32*)dst)[k] = w[k];
+    }
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+    if (mask & (1u << (k / C))) {
+      const u32 bits = w[k / PER] >> (8 * E * (k % PER));
+      ((VALI_GLOBAL T*)dst)[k] = __builtin_bit_cast(T, (typename std::conditional<E == 1, uint8_t, typename std::conditional<E == 2, uint16_t, u32>::type>::type)bits);
+    }
 }
 
 } // namespace vali

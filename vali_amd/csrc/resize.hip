@@ -66,51 +66,80 @@ __device__ __forceinline__ Lerp make_lerp(int x, float scale, int size) {
   return l;
 }
 
+// Per-wave LDS staging of the two source rows a wave's dst row needs.  A wave (= one dst
+// row x 256 px) reads the source span [byte_begin, byte_begin + nbytes) of rows i0 and i1
+// with 16-byte coalesced loads, then gathers its texels from LDS: every 128-byte line is
+// fetched ONCE instead of once per byte-gather instruction (the direct gather re-requested
+// each line ~8x from L2 and ran at 1.9 TB/s-equivalent; see profiles/r01_secondary.md).
+constexpr int kStageRowBytes = 3072 + 64; // per row slot; span 3072 B = 12x downscale for u8 C1
+struct alignas(16) StageRows {
+  uint8_t row[2][kStageRowBytes];
+};
+
 template <typename T, int C>
 __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int sw, int sh,
                                             uint8_t* dp, int dpitch, int dw, int dh, u32 tx,
-                                            u32 ty) {
-  const int x0 = (tx * 64 + (threadIdx.x & 63)) * 4;
-  const int y = ty * 4 + (threadIdx.x >> 6);
-  if (x0 >= dw || y >= dh)
+                                            u32 ty, StageRows* stage_all) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x0 = (tx * 64 + lane) * 4;
+  const int y = ty * 4 + wave; // wave-uniform
+  if (y >= dh)
     return;
   const float scale_x = (float)sw / (float)dw, scale_y = (float)sh / (float)dh;
   const Lerp ly = make_lerp(y, scale_y, sh);
   const uint8_t* r0 = sp + (size_t)ly.i0 * spitch;
   const uint8_t* r1 = sp + (size_t)ly.i1 * spitch;
-  T out[4][C];
+
+  // wave-uniform source span of this tile row
+  constexpr int PB = C * (int)sizeof(T);
+  const int xt0 = tx * 256, xt1 = min(xt0 + 255, dw - 1);
+  const int sx0 = make_lerp(xt0, scale_x, sw).i0, sx1 = make_lerp(xt1, scale_x, sw).i1;
+  const int byte_begin = (sx0 * PB) & ~15;
+  const int nbytes = (((sx1 + 1) * PB + 15) & ~15) - byte_begin;
+  const bool staged = nbytes <= kStageRowBytes && ((((uintptr_t)sp) | (uintptr_t)spitch) & 15u) == 0;
+  // The sampling code is instantiated twice (LDS rows / global rows) so each copy gets typed
+  // ds_read / global_load instructions; all texels of the lane are fetched before any
+  // arithmetic so the loads overlap.
+  auto sample_and_store = [&](auto fetch) {
+    if (x0 >= dw)
+      return;
+    Lerp lx[4];
+    float t[4][4][C]; // [pixel][00,10,01,11][channel]
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const Lerp lx = make_lerp(min(x0 + p, dw - 1), scale_x, sw);
+    for (int p = 0; p < 4; ++p) {
+      lx[p] = make_lerp(min(x0 + p, dw - 1), scale_x, sw);
 #pragma unroll
-    for (int ch = 0; ch < C; ++ch) {
-      const float t00 = rs_load<T>(r0, lx.i0 * C + ch), t10 = rs_load<T>(r0, lx.i1 * C + ch);
-      const float t01 = rs_load<T>(r1, lx.i0 * C + ch), t11 = rs_load<T>(r1, lx.i1 * C + ch);
-      const float t0 = __builtin_fmaf(lx.a, t10 - t00, t00);
-      const float t1 = __builtin_fmaf(lx.a, t11 - t01, t01);
-      out[p][ch] = rs_finish<T>(__builtin_fmaf(ly.a, t1 - t0, t0));
+      for (int ch = 0; ch < C; ++ch) {
+        t[p][0][ch] = fetch(0, lx[p].i0, ch); t[p][1][ch] = fetch(0, lx[p].i1, ch);
+        t[p][2][ch] = fetch(1, lx[p].i0, ch); t[p][3][ch] = fetch(1, lx[p].i1, ch);
+      }
     }
-  }
-  T* drow = (T*)(dp + (size_t)y * dpitch) + (size_t)x0 * C;
-  const int n = min(4, dw - x0);
-  constexpr int kBytes = 4 * C * (int)sizeof(T);
-  if (n == 4 && (((uintptr_t)drow) & (kBytes % 16 == 0 ? 15u : 3u)) == 0 && kBytes % 4 == 0) {
-    u32 w[kBytes / 4];
-    __builtin_memcpy(w, out, kBytes);
-    if constexpr (kBytes % 16 == 0) {
+    float res[4][C];
 #pragma unroll
-      for (int k = 0; k < kBytes / 16; ++k)
-        ((uint4*)drow)[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
-    } else {
+    for (int p = 0; p < 4; ++p)
 #pragma unroll
-      for (int k = 0; k < kBytes / 4; ++k)
-        ((u32*)drow)[k] = w[k];
+      for (int ch = 0; ch < C; ++ch) {
+        const float t0 = __builtin_fmaf(lx[p].a, t[p][1][ch] - t[p][0][ch], t[p][0][ch]);
+        const float t1 = __builtin_fmaf(lx[p].a, t[p][3][ch] - t[p][2][ch], t[p][2][ch]);
+        res[p][ch] = __builtin_fmaf(ly.a, t1 - t0, t0);
+      }
+    const int n = min(4, dw - x0);
+    store_px4<T, C>(dp + (size_t)y * dpitch + (size_t)x0 * PB, res, (1u << n) - 1u);
+  };
+  if (staged) {
+    StageRows& st = stage_all[wave];
+    for (int k = lane; k < 2 * (nbytes / 16); k += kWave) {
+      const int r = k >= nbytes / 16 ? 1 : 0, v = k - r * (nbytes / 16);
+      *reinterpret_cast<uint4*>(&st.row[r][v * 16]) = gload16((r ? r1 : r0) + byte_begin + v * 16);
     }
+    wave_lds_sync();
+    sample_and_store([&](int r, int i, int ch) {
+      return (float)((const T*)(st.row[r] + (i * PB - byte_begin)))[ch];
+    });
   } else {
-    for (int p = 0; p < n; ++p)
-#pragma unroll
-      for (int ch = 0; ch < C; ++ch)
-        drow[p * C + ch] = out[p][ch];
+    sample_and_store([&](int r, int i, int ch) {
+      return (float)gload<T>((r ? r1 : r0) + (size_t)i * PB + ch * sizeof(T));
+    });
   }
 }
 
@@ -120,11 +149,12 @@ __global__ void __launch_bounds__(kBlock) k_resize(const ResizeArgs a) {
   u32 tx, ty;
   if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty))
     return;
+  __shared__ StageRows stage[kWavesPerBlock];
   const PlaneView v = plane_view(a.d_src, a.d_dst, blockIdx.y, job, a.sw, a.sh, a.dw, a.dh);
   switch (job.channels) {
-  case 1: resize_tile<T, 1>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty); break;
-  case 2: resize_tile<T, 2>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty); break;
-  default: resize_tile<T, 3>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty); break;
+  case 1: resize_tile<T, 1>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage); break;
+  case 2: resize_tile<T, 2>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage); break;
+  default: resize_tile<T, 3>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage); break;
   }
 }
 

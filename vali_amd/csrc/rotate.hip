@@ -51,18 +51,6 @@ __device__ __forceinline__ bool rot_tile(const RotArgs& a, RotJob& job, u32& tx,
   return plane_tile(a.job, a.njobs, a.map, job, tx, ty);
 }
 
-template <typename T> __device__ __forceinline__ float texel_f(const uint8_t* row, int idx) {
-  return (float)((const T*)row)[idx];
-}
-template <typename T> __device__ __forceinline__ T finish(float v);
-template <> __device__ __forceinline__ uint8_t finish<uint8_t>(float v) { return (uint8_t)quantize_u8(v); }
-template <> __device__ __forceinline__ uint16_t finish<uint16_t>(float v) {
-  float r = __builtin_rintf(v);
-  r = __builtin_fminf(__builtin_fmaxf(r, 0.0f), 65535.0f);
-  return (uint16_t)r;
-}
-template <> __device__ __forceinline__ float finish<float>(float v) { return v; }
-
 template <typename T, int C>
 __device__ __forceinline__ void affine_tile(const RotArgs& a, const RotJob& job, const uint8_t* sp,
                                             int spitch, int sw, int sh, uint8_t* dp, int dpitch,
@@ -71,56 +59,48 @@ __device__ __forceinline__ void affine_tile(const RotArgs& a, const RotJob& job,
   const int y = tile_y * 4 + (threadIdx.x >> 6);
   if (x0 >= dw || y >= dh)
     return;
+  constexpr int PB = C * (int)sizeof(T);
   const float dy = (float)y - job.shift_y;
   const float wmax = (float)(sw - 1), hmax = (float)(sh - 1);
-  T out[4][C];
-  bool hit[4];
+  // phase 1: coordinates + all texel loads (clamped to a valid address for missed pixels)
+  float fa[4], fb[4], t[4][4][C];
+  u32 mask = 0;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const float dx = (float)(x0 + p) - job.shift_x;
     const float xs = __builtin_fmaf(-a.s, dy, a.c * dx);
     const float ys = __builtin_fmaf(a.c, dy, a.s * dx);
-    hit[p] = (x0 + p < dw) && xs >= 0.0f && xs <= wmax && ys >= 0.0f && ys <= hmax;
-    if (hit[p]) {
-      const float fi = __builtin_floorf(xs), fj = __builtin_floorf(ys);
-      const float fa = xs - fi, fb = ys - fj;
-      const int i = (int)fi, j = (int)fj;
-      const int i1 = min(i + 1, sw - 1), j1 = min(j + 1, sh - 1);
-      const uint8_t* r0 = sp + (size_t)j * spitch;
-      const uint8_t* r1 = sp + (size_t)j1 * spitch;
+    const bool hit = (x0 + p < dw) && xs >= 0.0f && xs <= wmax && ys >= 0.0f && ys <= hmax;
+    mask |= hit ? (1u << p) : 0u;
+    const float xc = hit ? xs : 0.0f, yc = hit ? ys : 0.0f;
+    const float fi = __builtin_floorf(xc), fj = __builtin_floorf(yc);
+    fa[p] = xc - fi;
+    fb[p] = yc - fj;
+    const int i = (int)fi, j = (int)fj;
+    const int i1 = min(i + 1, sw - 1), j1 = min(j + 1, sh - 1);
+    const uint8_t* r0 = sp + (size_t)j * spitch;
+    const uint8_t* r1 = sp + (size_t)j1 * spitch;
 #pragma unroll
-      for (int ch = 0; ch < C; ++ch) {
-        const float t00 = texel_f<T>(r0, i * C + ch), t10 = texel_f<T>(r0, i1 * C + ch);
-        const float t01 = texel_f<T>(r1, i * C + ch), t11 = texel_f<T>(r1, i1 * C + ch);
-        const float t0 = __builtin_fmaf(fa, t10 - t00, t00);
-        const float t1 = __builtin_fmaf(fa, t11 - t01, t01);
-        out[p][ch] = finish<T>(__builtin_fmaf(fb, t1 - t0, t0));
-      }
+    for (int ch = 0; ch < C; ++ch) {
+      t[p][0][ch] = (float)gload<T>(r0 + (size_t)i * PB + ch * sizeof(T));
+      t[p][1][ch] = (float)gload<T>(r0 + (size_t)i1 * PB + ch * sizeof(T));
+      t[p][2][ch] = (float)gload<T>(r1 + (size_t)i * PB + ch * sizeof(T));
+      t[p][3][ch] = (float)gload<T>(r1 + (size_t)i1 * PB + ch * sizeof(T));
     }
   }
-  T* drow = (T*)(dp + (size_t)y * dpitch) + (size_t)x0 * C;
-  constexpr int kBytes = 4 * C * (int)sizeof(T);
-  if (hit[0] && hit[1] && hit[2] && hit[3] && (((uintptr_t)drow) & (kBytes % 16 == 0 ? 15u : 3u)) == 0) {
-    // all four pixels present: one wide store (4, 8, 12, 16, 24 or 48 bytes per lane)
-    u32 w[kBytes / 4];
-    __builtin_memcpy(w, out, kBytes);
-    if constexpr (kBytes % 16 == 0) {
+  if (!mask)
+    return;
+  // phase 2: interpolate, finish, one wide store when all four pixels exist
+  float res[4][C];
 #pragma unroll
-      for (int k = 0; k < kBytes / 16; ++k)
-        ((uint4*)drow)[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
-    } else {
+  for (int p = 0; p < 4; ++p)
 #pragma unroll
-      for (int k = 0; k < kBytes / 4; ++k)
-        ((u32*)drow)[k] = w[k];
+    for (int ch = 0; ch < C; ++ch) {
+      const float t0 = __builtin_fmaf(fa[p], t[p][1][ch] - t[p][0][ch], t[p][0][ch]);
+      const float t1 = __builtin_fmaf(fa[p], t[p][3][ch] - t[p][2][ch], t[p][2][ch]);
+      res[p][ch] = __builtin_fmaf(fb[p], t1 - t0, t0);
     }
-  } else {
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-      if (hit[p])
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch)
-          drow[p * C + ch] = out[p][ch];
-  }
+  store_px4<T, C>(dp + (size_t)y * dpitch + (size_t)x0 * PB, res, mask);
 }
 
 template <typename T>

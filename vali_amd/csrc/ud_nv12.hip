@@ -82,8 +82,16 @@ template <typename T> __device__ __forceinline__ u32 trunc_sat(float v) {
   return (u32)c;                                                  // v_cvt_u32_f32 truncates
 }
 
+// per-wave staging: the two luma rows and the two chroma rows a dst row samples
+constexpr int kUdRowBytes = 2048 + 64;
+struct alignas(16) UdStage {
+  uint8_t luma[2][kUdRowBytes];
+  uint8_t chroma[2][kUdRowBytes];
+};
+
 template <typename T, int OUT>
 __global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
+  __shared__ UdStage stage[kWavesPerBlock];
   u32 tile_x, tile_y;
   if (!tile_of_block(a.map, tile_x, tile_y))
     return;
@@ -97,9 +105,10 @@ __global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
   uint8_t* pd2 = d.p[2];
   const int dp0 = d.pitch[0], dp1 = d.pitch[1], dp2 = d.pitch[2], dw = d.width, dh = d.height;
 
-  const int x0 = (tile_x * 64 + (threadIdx.x & 63)) * 4;
-  const int y = tile_y * 4 + (threadIdx.x >> 6);
-  if (x0 >= dw || y >= dh)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x0 = (tile_x * 64 + lane) * 4;
+  const int y = tile_y * 4 + wave; // wave-uniform
+  if (y >= dh)
     return;
 
   // ResizeUtils.cu:135-136: scale = 1.0f * dst / src ; :36-37: coord = x / scale
@@ -107,36 +116,82 @@ __global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
   const float scale_y = 1.0f * (float)dh / (float)sh;
   const Tap ty = make_tap((float)y / scale_y, sh);
   const Tap tcy = make_tap((float)y / (scale_y * 2.0f), sh / 2);
-  const T* yrow0 = (const T*)(py + (size_t)ty.i0 * sp_y);
-  const T* yrow1 = (const T*)(py + (size_t)ty.i1 * sp_y);
-  const T* crow0 = (const T*)(puv + (size_t)tcy.i0 * sp_uv);
-  const T* crow1 = (const T*)(puv + (size_t)tcy.i1 * sp_uv);
+  const uint8_t* yrow0 = py + (size_t)ty.i0 * sp_y;
+  const uint8_t* yrow1 = py + (size_t)ty.i1 * sp_y;
+  const uint8_t* crow0 = puv + (size_t)tcy.i0 * sp_uv;
+  const uint8_t* crow1 = puv + (size_t)tcy.i1 * sp_uv;
+
+  // Wave-uniform source spans of this tile row (luma texels / chroma pairs) -> per-wave LDS
+  // staging with 16-byte coalesced loads; texels are then gathered from LDS.  The direct
+  // byte gather re-requested every 128-byte line ~8x from L2 (profiles/r01_secondary.md).
+  constexpr int E = (int)sizeof(T);
+  const int xt0 = tile_x * 256, xt1 = min(xt0 + 255, dw - 1);
+  const int ly0 = make_tap((float)xt0 / scale_x, sw).i0, ly1 = make_tap((float)xt1 / scale_x, sw).i1;
+  const int lc0 = make_tap((float)xt0 / (scale_x * 2.0f), sw / 2).i0,
+            lc1 = make_tap((float)xt1 / (scale_x * 2.0f), sw / 2).i1;
+  const int yb = (ly0 * E) & ~15, yn = (((ly1 + 1) * E + 15) & ~15) - yb;
+  const int cb = (lc0 * 2 * E) & ~15, cn = (((lc1 + 1) * 2 * E + 15) & ~15) - cb;
+  const bool staged = yn <= kUdRowBytes && cn <= kUdRowBytes &&
+                      ((((uintptr_t)py) | ((uintptr_t)puv) | (uintptr_t)sp_y | (uintptr_t)sp_uv) & 15u) == 0;
 
   float c0[4], c1[4], c2[4]; // per pixel: Y,U,V (YUV444) or R,G,B normalised
+  auto sample = [&](auto luma, auto chroma) {
+    Tap tx[4], tcx[4];
+    u32 l[4][4], cu[4][4], cv[4][4]; // [pixel][00,10,01,11]
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int x = x0 + p;
-    const Tap tx = make_tap((float)x / scale_x, sw);
-    const Tap tcx = make_tap((float)x / (scale_x * 2.0f), sw / 2);
-    const u32 sy = ty.w0 * (tx.w0 * (u32)yrow0[tx.i0] + tx.w1 * (u32)yrow0[tx.i1]) +
-                   ty.w1 * (tx.w0 * (u32)yrow1[tx.i0] + tx.w1 * (u32)yrow1[tx.i1]);
-    const u32 su = tcy.w0 * (tcx.w0 * (u32)crow0[2 * tcx.i0] + tcx.w1 * (u32)crow0[2 * tcx.i1]) +
-                   tcy.w1 * (tcx.w0 * (u32)crow1[2 * tcx.i0] + tcx.w1 * (u32)crow1[2 * tcx.i1]);
-    const u32 sv =
-        tcy.w0 * (tcx.w0 * (u32)crow0[2 * tcx.i0 + 1] + tcx.w1 * (u32)crow0[2 * tcx.i1 + 1]) +
-        tcy.w1 * (tcx.w0 * (u32)crow1[2 * tcx.i0 + 1] + tcx.w1 * (u32)crow1[2 * tcx.i1 + 1]);
-    const float ny = (float)sy * TexelTraits<T>::kInvDen;
-    const float nu = (float)su * TexelTraits<T>::kInvDen;
-    const float nv = (float)sv * TexelTraits<T>::kInvDen;
-    if constexpr (OUT == UD_YUV444) {
-      c0[p] = ny; c1[p] = nu; c2[p] = nv;
-    } else {
-      const float u = nu - 0.5f, v = nv - 0.5f;
-      c0[p] = __builtin_fmaf(1.140f, v, ny);
-      c1[p] = __builtin_fmaf(-0.581f, v, __builtin_fmaf(-0.394f, u, ny));
-      c2[p] = __builtin_fmaf(2.032f, u, ny);
+    for (int p = 0; p < 4; ++p) {
+      const int x = min(x0 + p, dw - 1);
+      tx[p] = make_tap((float)x / scale_x, sw);
+      tcx[p] = make_tap((float)x / (scale_x * 2.0f), sw / 2);
+      l[p][0] = luma(0, tx[p].i0); l[p][1] = luma(0, tx[p].i1);
+      l[p][2] = luma(1, tx[p].i0); l[p][3] = luma(1, tx[p].i1);
+      cu[p][0] = chroma(0, tcx[p].i0, 0); cu[p][1] = chroma(0, tcx[p].i1, 0);
+      cu[p][2] = chroma(1, tcx[p].i0, 0); cu[p][3] = chroma(1, tcx[p].i1, 0);
+      cv[p][0] = chroma(0, tcx[p].i0, 1); cv[p][1] = chroma(0, tcx[p].i1, 1);
+      cv[p][2] = chroma(1, tcx[p].i0, 1); cv[p][3] = chroma(1, tcx[p].i1, 1);
     }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const u32 sy = ty.w0 * (tx[p].w0 * l[p][0] + tx[p].w1 * l[p][1]) + ty.w1 * (tx[p].w0 * l[p][2] + tx[p].w1 * l[p][3]);
+      const u32 su = tcy.w0 * (tcx[p].w0 * cu[p][0] + tcx[p].w1 * cu[p][1]) + tcy.w1 * (tcx[p].w0 * cu[p][2] + tcx[p].w1 * cu[p][3]);
+      const u32 sv = tcy.w0 * (tcx[p].w0 * cv[p][0] + tcx[p].w1 * cv[p][1]) + tcy.w1 * (tcx[p].w0 * cv[p][2] + tcx[p].w1 * cv[p][3]);
+      const float ny = (float)sy * TexelTraits<T>::kInvDen;
+      const float nu = (float)su * TexelTraits<T>::kInvDen;
+      const float nv = (float)sv * TexelTraits<T>::kInvDen;
+      if constexpr (OUT == UD_YUV444) {
+        c0[p] = ny; c1[p] = nu; c2[p] = nv;
+      } else {
+        const float u = nu - 0.5f, v = nv - 0.5f;
+        c0[p] = __builtin_fmaf(1.140f, v, ny);
+        c1[p] = __builtin_fmaf(-0.581f, v, __builtin_fmaf(-0.394f, u, ny));
+        c2[p] = __builtin_fmaf(2.032f, u, ny);
+      }
+    }
+  };
+  if (staged) {
+    UdStage& st = stage[wave];
+    const int nyv = yn / 16, ncv = cn / 16;
+    for (int k = lane; k < 2 * (nyv + ncv); k += kWave) {
+      if (k < 2 * nyv) {
+        const int r = k >= nyv ? 1 : 0, v = k - r * nyv;
+        *reinterpret_cast<uint4*>(&st.luma[r][v * 16]) = gload16((r ? yrow1 : yrow0) + yb + v * 16);
+      } else {
+        const int kk = k - 2 * nyv, r = kk >= ncv ? 1 : 0, v = kk - r * ncv;
+        *reinterpret_cast<uint4*>(&st.chroma[r][v * 16]) = gload16((r ? crow1 : crow0) + cb + v * 16);
+      }
+    }
+    wave_lds_sync();
+    if (x0 >= dw)
+      return;
+    sample([&](int r, int i) { return (u32)((const T*)(st.luma[r] + (i * E - yb)))[0]; },
+           [&](int r, int i, int c) { return (u32)((const T*)(st.chroma[r] + (i * 2 * E - cb)))[c]; });
+  } else {
+    if (x0 >= dw)
+      return;
+    sample([&](int r, int i) { return (u32)gload<T>((r ? yrow1 : yrow0) + (size_t)i * E); },
+           [&](int r, int i, int c) { return (u32)gload<T>((r ? crow1 : crow0) + ((size_t)i * 2 + c) * E); });
   }
+
 
   const int n = min(4, dw - x0); // valid pixels of this lane
   if constexpr (OUT == UD_YUV444) {
