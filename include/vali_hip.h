@@ -202,7 +202,7 @@ VALI_API int vali_convert_batch(const vali_surface* d_src, const vali_surface* d
 VALI_API int vali_ud_nv12(const vali_surface* src, const vali_surface* dst,
                           vali_stream_t stream);
 VALI_API int vali_ud_nv12_batch(const vali_surface* d_src, const vali_surface* d_dst, int n,
-                                int src_format, int dst_width, int dst_height,
+                                int src_format, int src_width, int dst_width, int dst_height,
                                 int dst_format, vali_stream_t stream);
 
 /* ---- resize: replaces nppiResize_{8u,32f}_C{1,3}R_Ctx --------------------------------- */

@@ -20,11 +20,12 @@
 //   (what cvt.rzi.u8.f32 does; pinned by the reference goldens: RGB == trunc(RGB_32F*256)).
 // Oracle: vali_oracle_ud_nv12 (oracle/vali_oracle.c), bit-exact.
 //
-// Work decomposition: one lane = 4 adjacent dst pixels of one row, so u8 planar output is
-// a dword, u8 packed 12 B (dwordx3), f32 16/48 B per lane; a 64x4 workgroup = 256x4 dst
-// pixels.  Source texels are gathered with byte/short loads served by L1/L2 (each texel is
-// touched by <= 2 lanes at <= 2x downscale); tiles walk the frame through the
-// XCD-contiguous TileMap.  HBM traffic = touched source rows + the dst surface.
+// Work decomposition: one lane = 4 adjacent dst pixels of a row, so u8 planar output is a
+// dword, u8 packed 12 B (dwordx3), f32 16/48 B per lane; a workgroup = 256 x 16 dst pixels,
+// each wave walking 4 rows with the same column taps.  The source rows a dst row samples are
+// staged per wave in LDS with 16-byte coalesced loads (every 128-byte line fetched once);
+// tiles walk the frame through the XCD-contiguous TileMap.  HBM traffic = touched source
+// rows + the dst surface.
 #include "common.hpp"
 #include "dev_util.hpp"
 
@@ -61,17 +62,19 @@ struct Tap {
 };
 
 // coordinate -> two taps; `coord` is the unnormalised texture coordinate.
-__device__ __forceinline__ Tap make_tap(float coord, int size) {
+__host__ __device__ inline Tap make_tap(float coord, int size) {
   const float b = coord - 0.5f;
   const float fl = __builtin_floorf(b);
   const float frac = b - fl;
   const u32 q = (u32)(frac * 256.0f + 0.5f); // 0..256
-  int i = (int)fl;
+  const int i = (int)fl;
   Tap t;
-  t.i0 = min(max(i, 0), size - 1);
-  t.i1 = min(max(i + 1, 0), size - 1);
-  t.w1 = q;
-  t.w0 = 256u - q;
+  t.i0 = i < 0 ? 0 : (i > size - 1 ? size - 1 : i);
+  t.i1 = i + 1 < 0 ? 0 : (i + 1 > size - 1 ? size - 1 : i + 1);
+  // the masks change no value (q is 0..256); they tell the compiler both weights fit 9 bits
+  // so the bilinear products select the full-rate v_mul_u32_u24 / v_mad_u32_u24
+  t.w1 = q & 0x1ffu;
+  t.w0 = (256u - q) & 0x1ffu;
   return t;
 }
 
@@ -83,125 +86,49 @@ template <typename T> __device__ __forceinline__ u32 trunc_sat(float v) {
 }
 
 // per-wave staging: the two luma rows and the two chroma rows a dst row samples
-constexpr int kUdRowBytes = 2048 + 64;
+constexpr int kUdChunks = 4;                    // 16-byte prefetch registers per lane
+constexpr int kUdRowBytes = 1024;               // per staged row; 4 rows x 1 KiB = kUdChunks x 64 lanes x 16 B
+constexpr int kUdRowsPerWave = 4; // dst rows a wave walks with the same column taps
+constexpr int kUdTileH = kWavesPerBlock * kUdRowsPerWave;
 struct alignas(16) UdStage {
   uint8_t luma[2][kUdRowBytes];
   uint8_t chroma[2][kUdRowBytes];
 };
 
+// store 4 pixels of one dst row (c0/c1/c2 = Y,U,V or R,G,B normalised), n = valid pixels
 template <typename T, int OUT>
-__global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
-  __shared__ UdStage stage[kWavesPerBlock];
-  u32 tile_x, tile_y;
-  if (!tile_of_block(a.map, tile_x, tile_y))
-    return;
-  const SurfRef s = load_surface(a.d_src, a.src, blockIdx.y);
-  const SurfRef d = load_surface(a.d_dst, a.dst, blockIdx.y);
-  const uint8_t* py = s.p[0];
-  const uint8_t* puv = s.p[1];
-  const int sp_y = s.pitch[0], sp_uv = s.pitch[1], sw = s.width, sh = s.height;
+__device__ __forceinline__ void ud_store(const SurfRef& d, int x0, int y, int n, const float (&c0)[4],
+                                         const float (&c1)[4], const float (&c2)[4]) {
   uint8_t* pd0 = d.p[0];
   uint8_t* pd1 = d.p[1];
   uint8_t* pd2 = d.p[2];
-  const int dp0 = d.pitch[0], dp1 = d.pitch[1], dp2 = d.pitch[2], dw = d.width, dh = d.height;
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int x0 = (tile_x * 64 + lane) * 4;
-  const int y = tile_y * 4 + wave; // wave-uniform
-  if (y >= dh)
-    return;
-
-  // ResizeUtils.cu:135-136: scale = 1.0f * dst / src ; :36-37: coord = x / scale
-  const float scale_x = 1.0f * (float)dw / (float)sw;
-  const float scale_y = 1.0f * (float)dh / (float)sh;
-  const Tap ty = make_tap((float)y / scale_y, sh);
-  const Tap tcy = make_tap((float)y / (scale_y * 2.0f), sh / 2);
-  const uint8_t* yrow0 = py + (size_t)ty.i0 * sp_y;
-  const uint8_t* yrow1 = py + (size_t)ty.i1 * sp_y;
-  const uint8_t* crow0 = puv + (size_t)tcy.i0 * sp_uv;
-  const uint8_t* crow1 = puv + (size_t)tcy.i1 * sp_uv;
-
-  // Wave-uniform source spans of this tile row (luma texels / chroma pairs) -> per-wave LDS
-  // staging with 16-byte coalesced loads; texels are then gathered from LDS.  The direct
-  // byte gather re-requested every 128-byte line ~8x from L2 (profiles/r01_secondary.md).
-  constexpr int E = (int)sizeof(T);
-  const int xt0 = tile_x * 256, xt1 = min(xt0 + 255, dw - 1);
-  const int ly0 = make_tap((float)xt0 / scale_x, sw).i0, ly1 = make_tap((float)xt1 / scale_x, sw).i1;
-  const int lc0 = make_tap((float)xt0 / (scale_x * 2.0f), sw / 2).i0,
-            lc1 = make_tap((float)xt1 / (scale_x * 2.0f), sw / 2).i1;
-  const int yb = (ly0 * E) & ~15, yn = (((ly1 + 1) * E + 15) & ~15) - yb;
-  const int cb = (lc0 * 2 * E) & ~15, cn = (((lc1 + 1) * 2 * E + 15) & ~15) - cb;
-  const bool staged = yn <= kUdRowBytes && cn <= kUdRowBytes &&
-                      ((((uintptr_t)py) | ((uintptr_t)puv) | (uintptr_t)sp_y | (uintptr_t)sp_uv) & 15u) == 0;
-
-  float c0[4], c1[4], c2[4]; // per pixel: Y,U,V (YUV444) or R,G,B normalised
-  auto sample = [&](auto luma, auto chroma) {
-    Tap tx[4], tcx[4];
-    u32 l[4][4], cu[4][4], cv[4][4]; // [pixel][00,10,01,11]
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int x = min(x0 + p, dw - 1);
-      tx[p] = make_tap((float)x / scale_x, sw);
-      tcx[p] = make_tap((float)x / (scale_x * 2.0f), sw / 2);
-      l[p][0] = luma(0, tx[p].i0); l[p][1] = luma(0, tx[p].i1);
-      l[p][2] = luma(1, tx[p].i0); l[p][3] = luma(1, tx[p].i1);
-      cu[p][0] = chroma(0, tcx[p].i0, 0); cu[p][1] = chroma(0, tcx[p].i1, 0);
-      cu[p][2] = chroma(1, tcx[p].i0, 0); cu[p][3] = chroma(1, tcx[p].i1, 0);
-      cv[p][0] = chroma(0, tcx[p].i0, 1); cv[p][1] = chroma(0, tcx[p].i1, 1);
-      cv[p][2] = chroma(1, tcx[p].i0, 1); cv[p][3] = chroma(1, tcx[p].i1, 1);
-    }
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const u32 sy = ty.w0 * (tx[p].w0 * l[p][0] + tx[p].w1 * l[p][1]) + ty.w1 * (tx[p].w0 * l[p][2] + tx[p].w1 * l[p][3]);
-      const u32 su = tcy.w0 * (tcx[p].w0 * cu[p][0] + tcx[p].w1 * cu[p][1]) + tcy.w1 * (tcx[p].w0 * cu[p][2] + tcx[p].w1 * cu[p][3]);
-      const u32 sv = tcy.w0 * (tcx[p].w0 * cv[p][0] + tcx[p].w1 * cv[p][1]) + tcy.w1 * (tcx[p].w0 * cv[p][2] + tcx[p].w1 * cv[p][3]);
-      const float ny = (float)sy * TexelTraits<T>::kInvDen;
-      const float nu = (float)su * TexelTraits<T>::kInvDen;
-      const float nv = (float)sv * TexelTraits<T>::kInvDen;
-      if constexpr (OUT == UD_YUV444) {
-        c0[p] = ny; c1[p] = nu; c2[p] = nv;
-      } else {
-        const float u = nu - 0.5f, v = nv - 0.5f;
-        c0[p] = __builtin_fmaf(1.140f, v, ny);
-        c1[p] = __builtin_fmaf(-0.581f, v, __builtin_fmaf(-0.394f, u, ny));
-        c2[p] = __builtin_fmaf(2.032f, u, ny);
-      }
-    }
-  };
-  if (staged) {
-    UdStage& st = stage[wave];
-    const int nyv = yn / 16, ncv = cn / 16;
-    for (int k = lane; k < 2 * (nyv + ncv); k += kWave) {
-      if (k < 2 * nyv) {
-        const int r = k >= nyv ? 1 : 0, v = k - r * nyv;
-        *reinterpret_cast<uint4*>(&st.luma[r][v * 16]) = gload16((r ? yrow1 : yrow0) + yb + v * 16);
-      } else {
-        const int kk = k - 2 * nyv, r = kk >= ncv ? 1 : 0, v = kk - r * ncv;
-        *reinterpret_cast<uint4*>(&st.chroma[r][v * 16]) = gload16((r ? crow1 : crow0) + cb + v * 16);
-      }
-    }
-    wave_lds_sync();
-    if (x0 >= dw)
-      return;
-    sample([&](int r, int i) { return (u32)((const T*)(st.luma[r] + (i * E - yb)))[0]; },
-           [&](int r, int i, int c) { return (u32)((const T*)(st.chroma[r] + (i * 2 * E - cb)))[c]; });
-  } else {
-    if (x0 >= dw)
-      return;
-    sample([&](int r, int i) { return (u32)gload<T>((r ? yrow1 : yrow0) + (size_t)i * E); },
-           [&](int r, int i, int c) { return (u32)gload<T>((r ? crow1 : crow0) + ((size_t)i * 2 + c) * E); });
-  }
-
-
-  const int n = min(4, dw - x0); // valid pixels of this lane
+  const int dp0 = d.pitch[0], dp1 = d.pitch[1], dp2 = d.pitch[2];
   if constexpr (OUT == UD_YUV444) {
-    T* o0 = (T*)(pd0 + (size_t)y * dp0) + x0;
-    T* o1 = (T*)(pd1 + (size_t)y * dp1) + x0;
-    T* o2 = (T*)(pd2 + (size_t)y * dp2) + x0;
-    for (int p = 0; p < n; ++p) {
-      o0[p] = (T)trunc_sat<T>(c0[p] * TexelTraits<T>::kMax);
-      o1[p] = (T)trunc_sat<T>(c1[p] * TexelTraits<T>::kMax);
-      o2[p] = (T)trunc_sat<T>(c2[p] * TexelTraits<T>::kMax);
+    u32 q0[4], q1[4], q2[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      q0[p] = trunc_sat<T>(c0[p] * TexelTraits<T>::kMax);
+      q1[p] = trunc_sat<T>(c1[p] * TexelTraits<T>::kMax);
+      q2[p] = trunc_sat<T>(c2[p] * TexelTraits<T>::kMax);
+    }
+    uint8_t* o0 = pd0 + (size_t)y * dp0 + (size_t)x0 * sizeof(T);
+    uint8_t* o1 = pd1 + (size_t)y * dp1 + (size_t)x0 * sizeof(T);
+    uint8_t* o2 = pd2 + (size_t)y * dp2 + (size_t)x0 * sizeof(T);
+    constexpr u32 kA = sizeof(T) == 1 ? 3u : 7u;
+    if (n == 4 && ((((uintptr_t)o0) | ((uintptr_t)o1) | ((uintptr_t)o2)) & kA) == 0) {
+      if constexpr (sizeof(T) == 1) {
+        gstore<u32>(o0, q0[0] | (q0[1] << 8) | (q0[2] << 16) | (q0[3] << 24));
+        gstore<u32>(o1, q1[0] | (q1[1] << 8) | (q1[2] << 16) | (q1[3] << 24));
+        gstore<u32>(o2, q2[0] | (q2[1] << 8) | (q2[2] << 16) | (q2[3] << 24));
+      } else {
+        store8(o0, make_uint2(q0[0] | (q0[1] << 16), q0[2] | (q0[3] << 16)));
+        store8(o1, make_uint2(q1[0] | (q1[1] << 16), q1[2] | (q1[3] << 16)));
+        store8(o2, make_uint2(q2[0] | (q2[1] << 16), q2[2] | (q2[3] << 16)));
+      }
+    } else {
+      for (int p = 0; p < n; ++p) {
+        gstore<T>(o0 + p * sizeof(T), (T)q0[p]); gstore<T>(o1 + p * sizeof(T), (T)q1[p]); gstore<T>(o2 + p * sizeof(T), (T)q2[p]);
+      }
     }
   } else if constexpr (OUT == UD_RGB_U8 || OUT == UD_RGB_U8_PLANAR) {
     u32 r[4], g[4], b[4];
@@ -216,44 +143,243 @@ __global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
       uint8_t* o1 = pd1 + (size_t)y * dp0 + x0;
       uint8_t* o2 = pd2 + (size_t)y * dp0 + x0;
       if (n == 4 && ((((uintptr_t)o0) | ((uintptr_t)o1) | ((uintptr_t)o2)) & 3u) == 0) {
-        *(u32*)o0 = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
-        *(u32*)o1 = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
-        *(u32*)o2 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+        gstore<u32>(o0, r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24));
+        gstore<u32>(o1, g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24));
+        gstore<u32>(o2, b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24));
       } else {
-        for (int p = 0; p < n; ++p) { o0[p] = (uint8_t)r[p]; o1[p] = (uint8_t)g[p]; o2[p] = (uint8_t)b[p]; }
+        for (int p = 0; p < n; ++p) { gstore<uint8_t>(o0 + p, (uint8_t)r[p]); gstore<uint8_t>(o1 + p, (uint8_t)g[p]); gstore<uint8_t>(o2 + p, (uint8_t)b[p]); }
       }
     } else {
       uint8_t* o = pd0 + (size_t)y * dp0 + (size_t)x0 * 3;
       if (n == 4 && (((uintptr_t)o) & 3u) == 0) {
-        struct alignas(4) U3 { u32 a, b, c; };
-        U3 w;
-        w.a = r[0] | (g[0] << 8) | (b[0] << 16) | (r[1] << 24);
-        w.b = g[1] | (b[1] << 8) | (r[2] << 16) | (g[2] << 24);
-        w.c = b[2] | (r[3] << 8) | (g[3] << 16) | (b[3] << 24);
-        *(U3*)o = w; // global_store_dwordx3
+        typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+        const v3u32 w = {r[0] | (g[0] << 8) | (b[0] << 16) | (r[1] << 24), g[1] | (b[1] << 8) | (r[2] << 16) | (g[2] << 24),
+                         b[2] | (r[3] << 8) | (g[3] << 16) | (b[3] << 24)};
+        *(VALI_GLOBAL v3u32*)o = w; // global_store_dwordx3
       } else {
-        for (int p = 0; p < n; ++p) { o[3 * p] = (uint8_t)r[p]; o[3 * p + 1] = (uint8_t)g[p]; o[3 * p + 2] = (uint8_t)b[p]; }
+        for (int p = 0; p < n; ++p) { gstore<uint8_t>(o + 3 * p, (uint8_t)r[p]); gstore<uint8_t>(o + 3 * p + 1, (uint8_t)g[p]); gstore<uint8_t>(o + 3 * p + 2, (uint8_t)b[p]); }
       }
     }
   } else if constexpr (OUT == UD_RGB_F32_PLANAR) {
-    float* o0 = (float*)(pd0 + (size_t)y * dp0) + x0;
-    float* o1 = (float*)(pd1 + (size_t)y * dp0) + x0;
-    float* o2 = (float*)(pd2 + (size_t)y * dp0) + x0;
+    uint8_t* o0 = pd0 + (size_t)y * dp0 + (size_t)x0 * 4;
+    uint8_t* o1 = pd1 + (size_t)y * dp0 + (size_t)x0 * 4;
+    uint8_t* o2 = pd2 + (size_t)y * dp0 + (size_t)x0 * 4;
     if (n == 4 && ((((uintptr_t)o0) | ((uintptr_t)o1) | ((uintptr_t)o2)) & 15u) == 0) {
-      *(float4*)o0 = make_float4(c0[0], c0[1], c0[2], c0[3]);
-      *(float4*)o1 = make_float4(c1[0], c1[1], c1[2], c1[3]);
-      *(float4*)o2 = make_float4(c2[0], c2[1], c2[2], c2[3]);
+      store16f(o0, make_float4(c0[0], c0[1], c0[2], c0[3]));
+      store16f(o1, make_float4(c1[0], c1[1], c1[2], c1[3]));
+      store16f(o2, make_float4(c2[0], c2[1], c2[2], c2[3]));
     } else {
-      for (int p = 0; p < n; ++p) { o0[p] = c0[p]; o1[p] = c1[p]; o2[p] = c2[p]; }
+      for (int p = 0; p < n; ++p) { gstore<float>(o0 + 4 * p, c0[p]); gstore<float>(o1 + 4 * p, c1[p]); gstore<float>(o2 + 4 * p, c2[p]); }
     }
   } else { // UD_RGB_F32 packed
-    float* o = (float*)(pd0 + (size_t)y * dp0) + (size_t)x0 * 3;
+    uint8_t* o = pd0 + (size_t)y * dp0 + (size_t)x0 * 12;
     if (n == 4 && (((uintptr_t)o) & 15u) == 0) {
-      *(float4*)(o + 0) = make_float4(c0[0], c1[0], c2[0], c0[1]);
-      *(float4*)(o + 4) = make_float4(c1[1], c2[1], c0[2], c1[2]);
-      *(float4*)(o + 8) = make_float4(c2[2], c0[3], c1[3], c2[3]);
+      store16f(o + 0, make_float4(c0[0], c1[0], c2[0], c0[1]));
+      store16f(o + 16, make_float4(c1[1], c2[1], c0[2], c1[2]));
+      store16f(o + 32, make_float4(c2[2], c0[3], c1[3], c2[3]));
     } else {
-      for (int p = 0; p < n; ++p) { o[3 * p] = c0[p]; o[3 * p + 1] = c1[p]; o[3 * p + 2] = c2[p]; }
+      for (int p = 0; p < n; ++p) { gstore<float>(o + 12 * p, c0[p]); gstore<float>(o + 12 * p + 4, c1[p]); gstore<float>(o + 12 * p + 8, c2[p]); }
+    }
+  }
+}
+
+// Source spans (bytes, 16-byte granular) the 256 columns of tile `tile_x` read from a luma row
+// and from a chroma row.  Host and device evaluate the SAME float expressions, so the host's
+// choice of the staged kernel is exact.
+struct UdSpan {
+  int yb, yn, cb, cn;
+};
+template <typename T>
+__host__ __device__ inline UdSpan ud_span(int tile_x, int dw, int sw, float scale_x) {
+  constexpr int E = (int)sizeof(T);
+  const int xt0 = tile_x * 256, xt1 = (xt0 + 255 < dw - 1) ? xt0 + 255 : dw - 1;
+  const int ly0 = make_tap((float)xt0 / scale_x, sw).i0, ly1 = make_tap((float)xt1 / scale_x, sw).i1;
+  const int lc0 = make_tap((float)xt0 / (scale_x * 2.0f), sw / 2).i0,
+            lc1 = make_tap((float)xt1 / (scale_x * 2.0f), sw / 2).i1;
+  UdSpan r;
+  r.yb = (ly0 * E) & ~15;
+  r.yn = (((ly1 + 1) * E + 15) & ~15) - r.yb;
+  r.cb = (lc0 * 2 * E) & ~15;
+  r.cn = (((lc1 + 1) * 2 * E + 15) & ~15) - r.cb;
+  return r;
+}
+
+// One workgroup = 256 x 16 dst pixels: wave w walks dst rows 4w..4w+3 of the tile with the
+// SAME four column taps per lane (the two float divisions per column are paid once per 4 rows).
+// STAGED: each dst row's two luma + two chroma source rows go through the wave's LDS strip;
+// the 16-byte loads of row r+1 are issued before row r is sampled (register prefetch), so
+// HBM latency overlaps the arithmetic.  !STAGED (source span too wide for the strip, i.e.
+// downscale beyond ~4x): direct byte gather.
+template <typename T, int OUT, bool STAGED>
+__global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
+  __shared__ UdStage stage[STAGED ? kWavesPerBlock : 1];
+  u32 tile_x, tile_y;
+  if (!tile_of_block(a.map, tile_x, tile_y))
+    return;
+  const SurfRef s = load_surface(a.d_src, a.src, blockIdx.y);
+  const SurfRef d = load_surface(a.d_dst, a.dst, blockIdx.y);
+  const uint8_t* py = s.p[0];
+  const uint8_t* puv = s.p[1];
+  const int sp_y = s.pitch[0], sp_uv = s.pitch[1], sw = s.width, sh = s.height;
+  const int dw = d.width, dh = d.height;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x0 = (tile_x * 64 + lane) * 4;
+  const int y_first = tile_y * kUdTileH + wave * kUdRowsPerWave; // wave-uniform
+  if (y_first >= dh)
+    return;
+
+  // ResizeUtils.cu:135-136: scale = 1.0f * dst / src ; :36-37: coord = x / scale
+  const float scale_x = 1.0f * (float)dw / (float)sw;
+  const float scale_y = 1.0f * (float)dh / (float)sh;
+  constexpr int E = (int)sizeof(T);
+
+  // column taps of this lane's 4 pixels (clamped to the last column for tail lanes)
+  Tap tx[4], tcx[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int x = min(x0 + p, dw - 1);
+    tx[p] = make_tap((float)x / scale_x, sw);
+    tcx[p] = make_tap((float)x / (scale_x * 2.0f), sw / 2);
+  }
+  const int n = min(4, dw - x0); // valid pixels of this lane (<= 0: tail lane, staging only)
+
+  struct RowTaps {
+    Tap ty, tcy;
+  };
+  auto row_taps = [&](int y) {
+    RowTaps r;
+    r.ty = make_tap((float)y / scale_y, sh);
+    r.tcy = make_tap((float)y / (scale_y * 2.0f), sh / 2);
+    return r;
+  };
+
+  // texels -> c0/c1/c2 of the lane's 4 pixels
+  auto sample = [&](const RowTaps& rt, auto luma, auto chroma, float (&c0)[4], float (&c1)[4], float (&c2)[4]) {
+    u32 l[4][4], cu[4][4], cv[4][4]; // [pixel][00,10,01,11]
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      l[p][0] = luma(0, tx[p].i0); l[p][1] = luma(0, tx[p].i1);
+      l[p][2] = luma(1, tx[p].i0); l[p][3] = luma(1, tx[p].i1);
+      cu[p][0] = chroma(0, tcx[p].i0, 0); cu[p][1] = chroma(0, tcx[p].i1, 0);
+      cu[p][2] = chroma(1, tcx[p].i0, 0); cu[p][3] = chroma(1, tcx[p].i1, 0);
+      cv[p][0] = chroma(0, tcx[p].i0, 1); cv[p][1] = chroma(0, tcx[p].i1, 1);
+      cv[p][2] = chroma(1, tcx[p].i0, 1); cv[p][3] = chroma(1, tcx[p].i1, 1);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      // every factor fits in 24 bits (weights <= 256, texels <= 65535, row sums < 2^24):
+      // v_mul_u32_u24 / v_mad_u32_u24 are full rate, v_mul_lo_u32 is quarter rate
+      auto bil = [](u32 wy0, u32 wy1, u32 wx0, u32 wx1, const u32 (&q)[4]) {
+        const u32 top = __umul24(wx0, q[0]) + __umul24(wx1, q[1]);
+        const u32 bot = __umul24(wx0, q[2]) + __umul24(wx1, q[3]);
+        return __umul24(wy0, top) + __umul24(wy1, bot);
+      };
+      const u32 sy = bil(rt.ty.w0, rt.ty.w1, tx[p].w0, tx[p].w1, l[p]);
+      const u32 su = bil(rt.tcy.w0, rt.tcy.w1, tcx[p].w0, tcx[p].w1, cu[p]);
+      const u32 sv = bil(rt.tcy.w0, rt.tcy.w1, tcx[p].w0, tcx[p].w1, cv[p]);
+      const float ny = (float)sy * TexelTraits<T>::kInvDen;
+      const float nu = (float)su * TexelTraits<T>::kInvDen;
+      const float nv = (float)sv * TexelTraits<T>::kInvDen;
+      if constexpr (OUT == UD_YUV444) {
+        c0[p] = ny; c1[p] = nu; c2[p] = nv;
+      } else {
+        const float u = nu - 0.5f, v = nv - 0.5f;
+        c0[p] = __builtin_fmaf(1.140f, v, ny);
+        c1[p] = __builtin_fmaf(-0.581f, v, __builtin_fmaf(-0.394f, u, ny));
+        c2[p] = __builtin_fmaf(2.032f, u, ny);
+      }
+    }
+  };
+
+  if constexpr (STAGED) {
+    const UdSpan sp = ud_span<T>((int)tile_x, dw, sw, scale_x);
+    const int nyv = sp.yn / 16, ncv = sp.cn / 16, total = 2 * (nyv + ncv); // <= kUdChunks * 64
+    const bool aligned = ((((uintptr_t)py) | ((uintptr_t)puv) | (uintptr_t)sp_y | (uintptr_t)sp_uv) & 15u) == 0;
+    UdStage& st = stage[wave];
+    // chunk k of a row's staging set -> (global source address, LDS destination)
+    auto chunk = [&](const RowTaps& rt, int k, const uint8_t*& src, uint8_t*& dst) {
+      if (k < 2 * nyv) {
+        const int r = k >= nyv ? 1 : 0, v = k - r * nyv;
+        src = py + (size_t)(r ? rt.ty.i1 : rt.ty.i0) * sp_y + sp.yb + v * 16;
+        dst = &st.luma[r][v * 16];
+      } else {
+        const int kk = k - 2 * nyv, r = kk >= ncv ? 1 : 0, v = kk - r * ncv;
+        src = puv + (size_t)(r ? rt.tcy.i1 : rt.tcy.i0) * sp_uv + sp.cb + v * 16;
+        dst = &st.chroma[r][v * 16];
+      }
+    };
+    uint4 pf[kUdChunks]; // prefetch registers: the next row's chunks of this lane
+    auto issue = [&](const RowTaps& rt) {
+#pragma unroll
+      for (int i = 0; i < kUdChunks; ++i) {
+        const int k = lane + i * kWave;
+        if (k < total) {
+          const uint8_t* src; uint8_t* dst;
+          chunk(rt, k, src, dst);
+          if (aligned) pf[i] = gload16(src);
+          else { // foreign, unaligned memory: byte loads (rare, slow, still correct)
+            u32 w[4] = {0, 0, 0, 0};
+            for (int bb = 0; bb < 16; ++bb) w[bb >> 2] |= (u32)gload<uint8_t>(src + bb) << (8 * (bb & 3));
+            pf[i] = make_uint4(w[0], w[1], w[2], w[3]);
+          }
+        }
+      }
+    };
+    auto commit = [&](const RowTaps& rt) {
+#pragma unroll
+      for (int i = 0; i < kUdChunks; ++i) {
+        const int k = lane + i * kWave;
+        if (k < total) {
+          const uint8_t* src; uint8_t* dst;
+          chunk(rt, k, src, dst);
+          *reinterpret_cast<uint4*>(dst) = pf[i];
+        }
+      }
+    };
+    RowTaps cur = row_taps(y_first);
+    issue(cur);
+#pragma unroll 1
+    for (int rr = 0; rr < kUdRowsPerWave; ++rr) {
+      const int y = y_first + rr;
+      if (y >= dh)
+        break;
+      commit(cur);
+      wave_lds_sync();
+      const bool more = rr + 1 < kUdRowsPerWave && y + 1 < dh;
+      RowTaps nxt = cur;
+      if (more) {
+        nxt = row_taps(y + 1);
+        issue(nxt); // in flight while this row is sampled
+      }
+      if (n > 0) {
+        float c0[4], c1[4], c2[4];
+        sample(cur,
+               [&](int r, int i) { return (u32)((const T*)(st.luma[r] + (i * E - sp.yb)))[0]; },
+               [&](int r, int i, int c) { return (u32)((const T*)(st.chroma[r] + (i * 2 * E - sp.cb)))[c]; },
+               c0, c1, c2);
+        ud_store<T, OUT>(d, x0, y, n, c0, c1, c2);
+      }
+      wave_lds_sync(); // the strip is re-filled by the next row
+      cur = nxt;
+    }
+  } else {
+    if (n <= 0)
+      return;
+#pragma unroll 1
+    for (int rr = 0; rr < kUdRowsPerWave; ++rr) {
+      const int y = y_first + rr;
+      if (y >= dh)
+        break;
+      const RowTaps rt = row_taps(y);
+      const uint8_t* yrow0 = py + (size_t)rt.ty.i0 * sp_y;
+      const uint8_t* yrow1 = py + (size_t)rt.ty.i1 * sp_y;
+      const uint8_t* crow0 = puv + (size_t)rt.tcy.i0 * sp_uv;
+      const uint8_t* crow1 = puv + (size_t)rt.tcy.i1 * sp_uv;
+      float c0[4], c1[4], c2[4];
+      sample(rt, [&](int r, int i) { return (u32)gload<T>((r ? yrow1 : yrow0) + (size_t)i * E); },
+             [&](int r, int i, int c) { return (u32)gload<T>((r ? crow1 : crow0) + ((size_t)i * 2 + c) * E); },
+             c0, c1, c2);
+      ud_store<T, OUT>(d, x0, y, n, c0, c1, c2);
     }
   }
 }
@@ -281,16 +407,29 @@ static int ud_out_kind(int src_fmt, int dst_fmt) {
   return -1;
 }
 
-static int launch_ud(UdArgs& a, int src_fmt, int dst_w, int dst_h, int dst_fmt, int n,
+static int launch_ud(UdArgs& a, int src_fmt, int src_w, int dst_w, int dst_h, int dst_fmt, int n,
                      hipStream_t stream) {
   const int kind = ud_out_kind(src_fmt, dst_fmt);
   if (kind < 0)
     return fail(VALI_ERR_UNSUPPORTED, "ud_nv12: unsupported format pair %d -> %d", src_fmt, dst_fmt);
-  a.map = make_tile_map((dst_w + 255) / 256, (dst_h + 3) / 4);
+  a.map = make_tile_map((dst_w + 255) / 256, (dst_h + kUdTileH - 1) / kUdTileH);
   const dim3 grid(a.map.per_xcd * 8u, n), block(kBlock);
+  // staged kernel iff every tile's source spans fit the strip (same float math as the device)
+  bool staged = true;
+  {
+    const float scale_x = 1.0f * (float)dst_w / (float)src_w;
+    for (int t = 0; t < (dst_w + 255) / 256 && staged; ++t) {
+      const UdSpan sp = src_fmt == VALI_FMT_NV12 ? ud_span<uint8_t>(t, dst_w, src_w, scale_x)
+                                                 : ud_span<uint16_t>(t, dst_w, src_w, scale_x);
+      staged = 2 * (sp.yn / 16 + sp.cn / 16) <= kUdChunks * kWave && sp.yn <= kUdRowBytes && sp.cn <= kUdRowBytes;
+    }
+  }
 #define VALI_UD_CASE(T, K)                                                                  \
   case K:                                                                                   \
-    hipLaunchKernelGGL((k_ud_nv12<T, K>), grid, block, 0, stream, a);                        \
+    if (staged)                                                                             \
+      hipLaunchKernelGGL((k_ud_nv12<T, K, true>), grid, block, 0, stream, a);                \
+    else                                                                                    \
+      hipLaunchKernelGGL((k_ud_nv12<T, K, false>), grid, block, 0, stream, a);               \
     break;
   if (src_fmt == VALI_FMT_NV12) {
     switch (kind) {
@@ -330,13 +469,14 @@ int vali_ud_nv12(const vali_surface* src, const vali_surface* dst, vali_stream_t
   a.dst = *dst;
   hipStream_t s = as_stream(stream);
   DeviceScope scope(stream_device(s));
-  return launch_ud(a, src->format, dst->width, dst->height, dst->format, 1, s);
+  return launch_ud(a, src->format, src->width, dst->width, dst->height, dst->format, 1, s);
 }
 
 int vali_ud_nv12_batch(const vali_surface* d_src, const vali_surface* d_dst, int n, int src_format,
-                       int dst_width, int dst_height, int dst_format, vali_stream_t stream) {
+                       int src_width, int dst_width, int dst_height, int dst_format,
+                       vali_stream_t stream) {
   VALI_REQUIRE(d_src && d_dst, "null argument");
-  VALI_REQUIRE(dst_width > 0 && dst_height > 0, "empty geometry");
+  VALI_REQUIRE(src_width >= 2 && dst_width > 0 && dst_height > 0, "empty geometry");
   VALI_REQUIRE(n >= 0 && n <= 65535, "batch size out of range (0..65535)");
   if (n == 0)
     return VALI_OK;
@@ -345,7 +485,7 @@ int vali_ud_nv12_batch(const vali_surface* d_src, const vali_surface* d_dst, int
   a.d_dst = d_dst;
   hipStream_t s = as_stream(stream);
   DeviceScope scope(stream_device(s));
-  return launch_ud(a, src_format, dst_width, dst_height, dst_format, n, s);
+  return launch_ud(a, src_format, src_width, dst_width, dst_height, dst_format, n, s);
 }
 
 } // extern "C"

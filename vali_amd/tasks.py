@@ -409,7 +409,7 @@ class PySurfaceUD(_SurfaceTask):
         if (batch.src_format, batch.dst_format) not in _UD_SEMIPLANAR:
             return False, TaskExecInfo.NOT_SUPPORTED
         d = _status(shim.ud_nv12_batch(batch.d_src, batch.d_dst, batch.n, int(batch.src_format),
-                                       batch.dst_size[0], batch.dst_size[1],
+                                       batch.src_size[0], batch.dst_size[0], batch.dst_size[1],
                                        int(batch.dst_format), self._stream))
         return d.success, d.info
 
