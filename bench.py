@@ -127,12 +127,20 @@ def main():
     torch.cuda.set_device(dev)
 
     dist = None
+    # "nccl" is RCCL on ROCm.  VALI_BENCH_BACKEND=gloo exists only so the N>1 code path can be
+    # exercised with several ranks sharing ONE GPU (tests/test_gpu_bench.py); collectives then
+    # run on CPU tensors.
+    backend = os.environ.get("VALI_BENCH_BACKEND", "nccl")
+    coll_dev = f"cuda:{dev}" if backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", dev))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     W, H, F = args.width, args.height, args.frames
     dst_fmt = vali.PixelFormat[args.dst]
@@ -143,7 +151,7 @@ def main():
     # the one collective of the path: rank 0 resolves the colour context to a matrix,
     # everyone receives the 32-byte block over RCCL/xGMI
     cc = vali.ColorspaceConversionContext(vali.ColorSpace.BT_709, vali.ColorRange.MPEG)
-    coeffs = pipe.set_coefficients(cc if rank == 0 else None, src=0, device=f"cuda:{dev}")
+    coeffs = pipe.set_coefficients(cc if rank == 0 else None, src=0, device=coll_dev)
     stream = pipe.Stream
 
     # distinct content in the first NSEED frames (uploaded), cycled device-to-device into
@@ -186,7 +194,7 @@ def main():
         shim.event_destroy(dev, b)
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{dev}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -1,0 +1,47 @@
+"""bench.py contract on a real GPU: one JSON line with the required keys; the N>1 code path
+(sharding, coefficient broadcast, barrier, max-over-ranks) with 2 ranks sharing the one GPU."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+            "scaling", "vs_baseline", "dtype", "data", "config", "roofline"]
+
+
+def last_json(out: str):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_contract(gpu):
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1",
+                        "--frames", "16", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = last_json(r.stdout)
+    for k in REQUIRED:
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["unit"] == "frames/s" and j["dtype"] == "u8"
+    assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1
+    assert j["parity_vs_oracle"]["max_abs_diff_lsb"] == 0
+    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] >= 1
+    assert "workload" in j["config"] and "model" not in j["config"]
+
+
+def test_bench_two_ranks_share_one_gpu(gpu):
+    env = dict(os.environ, VALI_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29617", str(ROOT / "bench.py"),
+                        "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "16"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    j = last_json(r.stdout)
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 32 and j["scaling"] == "weak"
+    assert "cpu_baseline" not in j and j["value"] > 0
