@@ -5,6 +5,7 @@ names: Surface, SurfacePlane, PixelFormat, PySurfaceConverter, PyFrameUploader, 
 (reference: src/python_vali/__init__.py:14-16 re-exporting _python_vali).
 """
 from ._native import shim as _shim  # noqa: F401  (fails loudly if the HIP library is absent)
+from .codecs import PyDecoder, PyFrameConverter, PyNvEncoder, PyNvJpegEncoder
 from .enums import (ColorRange, ColorSpace, ColorspaceConversionContext, DLDeviceType,
                     PixelFormat, TaskExecDetails, TaskExecInfo, TaskExecStatus, export_values)
 from .runtime import CudaStreamEvent, GetNumGpus, HipResMgr
