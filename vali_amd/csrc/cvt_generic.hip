@@ -111,9 +111,14 @@ __device__ __forceinline__ void load_block(Block& b, const SurfRef& s, const Geo
   if constexpr (k_ispacked(SRC)) {
     const uint8_t* rb = s.p[0] + (size_t)q.row0 * s.pitch[0] + (size_t)q.wave_g0 * 48;
     const int vb = q.valid_lanes * 48;
+    // both rows' global loads are issued before either row goes through the strip
+    StripRegs regs[2];
+    strip_fetch(regs[0], q.lane, rb, vb);
+    strip_fetch(regs[1], q.lane, s.p[0] + (size_t)r1 * s.pitch[0] + (size_t)q.wave_g0 * 48, vb);
     u32 o[12];
+#pragma unroll
     for (int r = 0; r < 2; ++r) {
-      strip_load_row(strip, q.lane, o, q.lane_valid, r == 0 ? rb : s.p[0] + (size_t)r1 * s.pitch[0] + (size_t)q.wave_g0 * 48, vb);
+      strip_unpack(strip, q.lane, regs[r], o, q.lane_valid);
       if (q.lane_valid) {
         if constexpr (SRC == K_RGB) deinterleave3(o, b.c0[r], b.c1[r], b.c2[r]);
         else deinterleave3(o, b.c2[r], b.c1[r], b.c0[r]);
@@ -236,6 +241,9 @@ __device__ __forceinline__ void transform_block(Block& b, const vali_cvt_params&
         u32& cv = b.cv[j >> 1];
         if (j & 1) { cu = pack_u8<2>(ua, cu); cu = pack_u8<3>(ub, cu); cv = pack_u8<2>(va, cv); cv = pack_u8<3>(vb, cv); }
         else { cu = pack_u8<0>(ua, 0u); cu = pack_u8<1>(ub, cu); cv = pack_u8<0>(va, 0u); cv = pack_u8<1>(vb, cv); }
+        // keep the four 4-pixel groups from being interleaved: 16 live chroma floats per group
+        // times four groups is what pushed this branch to 106 VGPRs
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   } else if constexpr (SRC == K_Y && DST == K_YUV444) {
@@ -364,6 +372,7 @@ __global__ void __launch_bounds__(kBlock) k_cvt8(const CvtArgs a) {
   }
   if (!q.lane_valid)
     return;
+#pragma unroll 1 // the byte-granular path must not set the kernel's register budget
   for (int k = 0; k < 8; ++k)
     quad_slow<SRC, DST>(s, d, q.x0 / 2 + k, tile_y, a.p);
 }
@@ -400,7 +409,11 @@ __global__ void __launch_bounds__(kBlock) k_p16_to_nv12(const ElemArgs a) {
   }
 }
 
-// RGB u8 -> RGB_32F: f = v / 255 (correctly rounded division), 3W elements per row
+// RGB u8 -> RGB_32F: f = v / 255 (correctly rounded division), 3W elements per row.
+// A workgroup converts 4096 consecutive elements of a row in 4 passes of 1024: per pass a
+// lane loads one dword (4 elements) and stores one float4, so every store instruction of a
+// wave writes 1 KiB contiguous (non-temporal); the 4 loads are issued before the arithmetic.
+constexpr int kU8F32Tile = 4096;
 __global__ void __launch_bounds__(kBlock) k_rgb8_to_f32(const ElemArgs a) {
   u32 tx, ty;
   if (!tile_of_block(a.map, tx, ty))
@@ -408,17 +421,31 @@ __global__ void __launch_bounds__(kBlock) k_rgb8_to_f32(const ElemArgs a) {
   const SurfRef s = load_surface(a.d_src, a.src, blockIdx.y);
   const SurfRef d = load_surface(a.d_dst, a.dst, blockIdx.y);
   const int n = s.width * 3, y = ty;
-  const int e0 = (tx * kBlock + threadIdx.x) * 4;
-  if (e0 >= n || y >= s.height)
+  if (y >= s.height)
     return;
   const uint8_t* srow = s.p[0] + (size_t)y * s.pitch[0];
-  float* drow = (float*)(d.p[0] + (size_t)y * d.pitch[0]);
-  if (e0 + 4 <= n && ((((uintptr_t)srow) & 3u) == 0) && ((((uintptr_t)drow) & 15u) == 0)) {
-    const u32 w = *reinterpret_cast<const u32*>(srow + e0);
-    *reinterpret_cast<float4*>(drow + e0) = make_float4(ubyte_f32<0>(w) / 255.0f, ubyte_f32<1>(w) / 255.0f, ubyte_f32<2>(w) / 255.0f, ubyte_f32<3>(w) / 255.0f);
-  } else {
-    for (int k = 0; k < 4 && e0 + k < n; ++k)
-      drow[e0 + k] = (float)srow[e0 + k] / 255.0f;
+  uint8_t* drow = d.p[0] + (size_t)y * d.pitch[0];
+  const int base = tx * kU8F32Tile + threadIdx.x * 4;
+  const bool vec = ((((uintptr_t)srow) & 3u) == 0) && ((((uintptr_t)drow) & 15u) == 0);
+  u32 w[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int e0 = base + it * 1024;
+    w[it] = (vec && e0 + 4 <= n) ? gload<u32>(srow + e0) : 0u;
+  }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int e0 = base + it * 1024;
+    if (e0 >= n)
+      break;
+    if (vec && e0 + 4 <= n) {
+      const u32 q = w[it];
+      const v4f32 f = {ubyte_f32<0>(q) / 255.0f, ubyte_f32<1>(q) / 255.0f, ubyte_f32<2>(q) / 255.0f, ubyte_f32<3>(q) / 255.0f};
+      __builtin_nontemporal_store(f, (VALI_GLOBAL v4f32*)(drow + (size_t)e0 * 4));
+    } else {
+      for (int k = 0; k < 4 && e0 + k < n; ++k)
+        gstore<float>(drow + (size_t)(e0 + k) * 4, (float)gload<uint8_t>(srow + e0 + k) / 255.0f);
+    }
   }
 }
 
@@ -476,7 +503,7 @@ static int launch_convert(CvtArgs& a, ElemArgs& e, int src_fmt, int dst_fmt, int
     return VALI_OK;
   }
   if (src_fmt == VALI_FMT_RGB && dst_fmt == VALI_FMT_RGB_32F) {
-    e.map = make_tile_map((width * 3 + kBlock * 4 - 1) / (kBlock * 4), height);
+    e.map = make_tile_map((width * 3 + kU8F32Tile - 1) / kU8F32Tile, height);
     hipLaunchKernelGGL(k_rgb8_to_f32, dim3(e.map.per_xcd * 8u, n), dim3(kBlock), 0, stream, e);
     VALI_LAUNCH_CHECK();
     return VALI_OK;
@@ -496,7 +523,17 @@ static int launch_convert(CvtArgs& a, ElemArgs& e, int src_fmt, int dst_fmt, int
     block = kBlock;
   a.map = make_tile_map((groups + block - 1) / block, (height + 1) / 2);
   const dim3 grid(a.map.per_xcd * 8u, n);
-  const unsigned lds = residency_lds_bytes(block, 16, (unsigned)sizeof(PackedStrip) * kWavesPerBlock);
+  // residency cap: 16 waves/CU measured best for plane -> packed streams (profiles/r01_variants.md);
+  // VALI_WAVES_PER_CU is a tuning knob for A/B runs only
+  // Packed SOURCES (global -> LDS strip -> registers before any arithmetic) have a longer
+  // dependent chain per wave and want 24 waves/CU (RGB->RGB_PLANAR 5.79 -> 5.98, RGB->YUV444
+  // 4.78 -> 5.38, RGB->Y 4.76 -> 5.71 TB/s); everything else keeps 16.
+  static const int waves_override = [] {
+    const char* e = getenv("VALI_WAVES_PER_CU");
+    return e ? atoi(e) : 0;
+  }();
+  const int waves_per_cu = waves_override > 0 ? waves_override : (k_ispacked(sk) ? 24 : 16);
+  const unsigned lds = residency_lds_bytes(block, waves_per_cu, (unsigned)sizeof(PackedStrip) * kWavesPerBlock);
 #define VALI_PAIR(S, D)                                                                     \
   if (sk == S && dk == D) {                                                                 \
     launch_cvt8<S, D>(a, grid, block, lds, stream);                                          \

@@ -312,6 +312,38 @@ __device__ __forceinline__ void strip_load_row(PackedStrip& strip, int lane,
   wave_lds_sync();
 }
 
+// Two-phase form of strip_load_row for kernels that read SEVERAL packed rows per lane:
+// strip_fetch issues the 3 global loads of a row into registers (no LDS, no wait), so the
+// loads of all rows are in flight together; strip_unpack then runs the row through the
+// strip.  Measured on RGB -> RGB_PLANAR / YUV444 2160p (profiles/r01_converters.md).
+struct StripRegs {
+  uint4 v[3];
+};
+
+__device__ __forceinline__ void strip_fetch(StripRegs& r, int lane, const uint8_t* row_base,
+                                            int valid_bytes) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int off = (k * kWave + lane) * 16;
+    r.v[k] = off < valid_bytes ? load16(row_base + off) : make_uint4(0, 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void strip_unpack(PackedStrip& strip, int lane, const StripRegs& r,
+                                             u32 (&o)[12], bool lane_valid) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    strip.v[k * kWave + lane] = r.v[k];
+  wave_lds_sync();
+  if (lane_valid) {
+    const uint4 a = strip.v[lane * 3 + 0], b = strip.v[lane * 3 + 1], c = strip.v[lane * 3 + 2];
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
+    o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    o[8] = c.x; o[9] = c.y; o[10] = c.z; o[11] = c.w;
+  }
+  wave_lds_sync();
+}
+
 // Scatter 16 pixels (3 channels, already quantised into per-channel dwords
 // c0/c1/c2, 4 pixels per dword) into the 12 dwords of a packed row segment.
 // v_perm_b32 does an arbitrary 4-of-8 byte pick in one instruction.
