@@ -77,3 +77,32 @@ def test_surface_from_tensor(vali, gpu):
         s.__dlpack_device__()                            # PySurface.cpp:389-393
     s2 = vali.Surface.from_cai(t, vali.Y)
     assert (s2.Width, s2.Height) == (w * 3, h)
+
+
+def test_empty_surfaces_are_rejected_not_crashed(vali, gpu):
+    """Surface.Make(format) alone gives an empty surface (MemoryInterfaces.cpp:336-367); every
+    task must answer with an error code."""
+    T = vali.TaskExecInfo
+    e_nv12, e_rgb = vali.Surface.Make(vali.NV12), vali.Surface.Make(vali.RGB)
+    assert e_nv12.IsEmpty and e_nv12.HostSize == 0 and e_nv12.Width == 0
+    full = vali.Surface.Make(vali.RGB, 64, 48, gpu)
+    assert vali.PySurfaceConverter(gpu).Run(e_nv12, full) == (False, T.INVALID_INPUT)
+    assert vali.PySurfaceConverter(gpu).Run(e_nv12, e_rgb) == (False, T.INVALID_INPUT)
+    assert vali.PySurfaceResizer(vali.RGB, gpu).Run(e_rgb, full) == (False, T.INVALID_INPUT)
+    assert vali.PySurfaceRotator(gpu).Run(e_rgb, full, 90.0) == (False, T.INVALID_INPUT)
+    assert vali.PySurfaceUD(gpu).Run(e_nv12, full) == (False, T.INVALID_INPUT)
+    assert vali.PyFrameUploader(gpu).Run(np.zeros(16, np.uint8), e_rgb) == (False, T.INVALID_INPUT)
+    assert vali.PySurfaceDownloader(gpu).Run(e_rgb, np.zeros(16, np.uint8)) == (False, T.INVALID_INPUT)
+    assert e_rgb.Clone().IsEmpty
+
+
+def test_streams_and_events(vali, gpu):
+    """Tasks sharing a stream are stream-ordered; CudaStreamEvent Record/Wait synchronises."""
+    a = vali.PySurfaceConverter(gpu)
+    b = vali.PySurfaceConverter(gpu, a.Stream)
+    assert a.Stream == b.Stream and a.Stream != 0
+    assert vali.PySurfaceResizer(vali.NV12, gpu).Stream == a.Stream      # per-GPU default stream
+    ev = vali.CudaStreamEvent(a.Stream, gpu)
+    ev.Record()
+    ev.Wait()
+    assert vali.GetNumGpus() >= 1
