@@ -340,11 +340,11 @@ template <int SRC, int DST>
 __global__ void __launch_bounds__(kBlock) k_cvt8(const CvtArgs a) {
   extern __shared__ uint4 dyn_lds[];
   PackedStrip* const strips = reinterpret_cast<PackedStrip*>(dyn_lds);
-  u32 tile_x, tile_y;
-  if (!tile_of_block(a.map, tile_x, tile_y))
+  u32 tile_x, tile_y, frame;
+  if (!tile_of_block(a.map, tile_x, tile_y, frame))
     return;
-  const SurfRef s = load_surface(a.d_src, a.src, blockIdx.y);
-  const SurfRef d = load_surface(a.d_dst, a.dst, blockIdx.y);
+  const SurfRef s = load_surface(a.d_src, a.src, frame);
+  const SurfRef d = load_surface(a.d_dst, a.dst, frame);
   const int W = s.width, H = s.height;
   Geo q;
   q.lane = threadIdx.x & (kWave - 1);
@@ -387,11 +387,11 @@ struct ElemArgs {
 
 // P10/P12 (MSB-aligned u16) -> NV12: round(v / 256) saturated, on the whole W x 1.5H plane.
 __global__ void __launch_bounds__(kBlock) k_p16_to_nv12(const ElemArgs a) {
-  u32 tx, ty;
-  if (!tile_of_block(a.map, tx, ty))
+  u32 tx, ty, frame;
+  if (!tile_of_block(a.map, tx, ty, frame))
     return;
-  const SurfRef s = load_surface(a.d_src, a.src, blockIdx.y);
-  const SurfRef d = load_surface(a.d_dst, a.dst, blockIdx.y);
+  const SurfRef s = load_surface(a.d_src, a.src, frame);
+  const SurfRef d = load_surface(a.d_dst, a.dst, frame);
   const int W = s.width, rows = s.height + (s.height + 1) / 2; // luma rows + chroma rows (p[0] spans both)
   const int x0 = (tx * kBlock + threadIdx.x) * 8, y = ty;
   if (x0 >= W || y >= rows)
@@ -415,11 +415,11 @@ __global__ void __launch_bounds__(kBlock) k_p16_to_nv12(const ElemArgs a) {
 // wave writes 1 KiB contiguous (non-temporal); the 4 loads are issued before the arithmetic.
 constexpr int kU8F32Tile = 4096;
 __global__ void __launch_bounds__(kBlock) k_rgb8_to_f32(const ElemArgs a) {
-  u32 tx, ty;
-  if (!tile_of_block(a.map, tx, ty))
+  u32 tx, ty, frame;
+  if (!tile_of_block(a.map, tx, ty, frame))
     return;
-  const SurfRef s = load_surface(a.d_src, a.src, blockIdx.y);
-  const SurfRef d = load_surface(a.d_dst, a.dst, blockIdx.y);
+  const SurfRef s = load_surface(a.d_src, a.src, frame);
+  const SurfRef d = load_surface(a.d_dst, a.dst, frame);
   const int n = s.width * 3, y = ty;
   if (y >= s.height)
     return;
@@ -451,11 +451,11 @@ __global__ void __launch_bounds__(kBlock) k_rgb8_to_f32(const ElemArgs a) {
 
 // RGB_32F packed -> RGB_32F_PLANAR: lane = 4 pixels (48 B in, 3 x 16 B out)
 __global__ void __launch_bounds__(kBlock) k_f32_deinterleave(const ElemArgs a) {
-  u32 tx, ty;
-  if (!tile_of_block(a.map, tx, ty))
+  u32 tx, ty, frame;
+  if (!tile_of_block(a.map, tx, ty, frame))
     return;
-  const SurfRef s = load_surface(a.d_src, a.src, blockIdx.y);
-  const SurfRef d = load_surface(a.d_dst, a.dst, blockIdx.y);
+  const SurfRef s = load_surface(a.d_src, a.src, frame);
+  const SurfRef d = load_surface(a.d_dst, a.dst, frame);
   const int W = s.width, y = ty;
   const int x0 = (tx * kBlock + threadIdx.x) * 4;
   if (x0 >= W || y >= s.height)
@@ -497,20 +497,20 @@ static int launch_convert(CvtArgs& a, ElemArgs& e, int src_fmt, int dst_fmt, int
                           hipStream_t stream) {
   // element-type conversions first
   if ((src_fmt == VALI_FMT_P10 || src_fmt == VALI_FMT_P12) && dst_fmt == VALI_FMT_NV12) {
-    e.map = make_tile_map((width + kBlock * 8 - 1) / (kBlock * 8), height + (height + 1) / 2);
-    hipLaunchKernelGGL(k_p16_to_nv12, dim3(e.map.per_xcd * 8u, n), dim3(kBlock), 0, stream, e);
+    e.map = make_tile_map((width + kBlock * 8 - 1) / (kBlock * 8), height + (height + 1) / 2, (u32)n);
+    hipLaunchKernelGGL(k_p16_to_nv12, tile_grid(e.map), dim3(kBlock), 0, stream, e);
     VALI_LAUNCH_CHECK();
     return VALI_OK;
   }
   if (src_fmt == VALI_FMT_RGB && dst_fmt == VALI_FMT_RGB_32F) {
-    e.map = make_tile_map((width * 3 + kU8F32Tile - 1) / kU8F32Tile, height);
-    hipLaunchKernelGGL(k_rgb8_to_f32, dim3(e.map.per_xcd * 8u, n), dim3(kBlock), 0, stream, e);
+    e.map = make_tile_map((width * 3 + kU8F32Tile - 1) / kU8F32Tile, height, (u32)n);
+    hipLaunchKernelGGL(k_rgb8_to_f32, tile_grid(e.map), dim3(kBlock), 0, stream, e);
     VALI_LAUNCH_CHECK();
     return VALI_OK;
   }
   if (src_fmt == VALI_FMT_RGB_32F && dst_fmt == VALI_FMT_RGB_32F_PLANAR) {
-    e.map = make_tile_map((width + kBlock * 4 - 1) / (kBlock * 4), height);
-    hipLaunchKernelGGL(k_f32_deinterleave, dim3(e.map.per_xcd * 8u, n), dim3(kBlock), 0, stream, e);
+    e.map = make_tile_map((width + kBlock * 4 - 1) / (kBlock * 4), height, (u32)n);
+    hipLaunchKernelGGL(k_f32_deinterleave, tile_grid(e.map), dim3(kBlock), 0, stream, e);
     VALI_LAUNCH_CHECK();
     return VALI_OK;
   }
@@ -521,8 +521,8 @@ static int launch_convert(CvtArgs& a, ElemArgs& e, int src_fmt, int dst_fmt, int
   int block = ((groups + kWave - 1) / kWave) * kWave;
   if (block > kBlock)
     block = kBlock;
-  a.map = make_tile_map((groups + block - 1) / block, (height + 1) / 2);
-  const dim3 grid(a.map.per_xcd * 8u, n);
+  a.map = make_tile_map((groups + block - 1) / block, (height + 1) / 2, (u32)n);
+  const dim3 grid = tile_grid(a.map);
   // residency cap: 16 waves/CU measured best for plane -> packed streams (profiles/r01_variants.md);
   // VALI_WAVES_PER_CU is a tuning knob for A/B runs only
   // Packed SOURCES (global -> LDS strip -> registers before any arithmetic) have a longer

@@ -95,10 +95,9 @@ __global__ void __launch_bounds__(kBlock) k_nv12_rgb8(const Nv12RgbArgs a) {
   extern __shared__ uint4 dyn_lds[];
   PackedStrip* const strips = reinterpret_cast<PackedStrip*>(dyn_lds);
 
-  u32 tile_x, tile_y;
-  if (!tile_of_block(a.map, tile_x, tile_y))
+  u32 tile_x, tile_y, frame;
+  if (!tile_of_block(a.map, tile_x, tile_y, frame))
     return;
-  const u32 frame = blockIdx.y;
 
   const uint8_t* py;
   const uint8_t* puv;
@@ -240,8 +239,8 @@ static int launch_nv12_rgb(Nv12RgbArgs& a, int width, int height, int n, int dst
   int block = ((groups + kWave - 1) / kWave) * kWave;
   if (block > kBlock)
     block = kBlock;
-  a.map = make_tile_map((groups + block - 1) / block, (height + 1) / 2);
-  const dim3 grid(a.map.per_xcd * 8u, n);
+  a.map = make_tile_map((groups + block - 1) / block, (height + 1) / 2, (u32)n);
+  const dim3 grid = tile_grid(a.map);
   // tuning knobs for A/B measurements only (not part of the API)
   static const bool direct = [] {
     const char* e = getenv("VALI_NV12_DIRECT_STORE");

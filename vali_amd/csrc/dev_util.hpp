@@ -126,28 +126,62 @@ __device__ __forceinline__ float4 load16f(const void* p) {
 // a frame over the 8 private L2s.  Giving each XCD one CONTIGUOUS eighth of the frame's
 // tiles instead measured +3.5% on NV12->RGB 2160p (DRAM page locality of each L2's
 // fill/evict stream), +7% together with nt stores (profiles/r01_variants.md).
-//   launch: grid.x = 8 * per_xcd (per_xcd = ceil(total / 8)), grid.y = frames
-//   tile   = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8   (skip if >= total)
+// Over a BATCH the contiguous share is taken over the whole tile list of the launch
+// (frame-major): XCD k owns tiles [k*T/8, (k+1)*T/8), i.e. whole consecutive frames.  That
+// measured another +6% (6.20 -> 6.57 TB/s, 82% of the HBM peak; sweep 5 in
+// profiles/r01_variants.md); a single frame degenerates to the per-frame split above.
+//   launch: grid.x = 8 * per_xcd, per_xcd = ceil(total / 8), total = frames * per_frame
+//   t      = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8   (skip if >= total)
+//   frame  = t / per_frame ; tile = t % per_frame
 // ---------------------------------------------------------------------------
 struct TileMap {
-  u32 total;    // tiles per frame (= tiles_x * tiles_y)
-  u32 per_xcd;  // ceil(total / 8)
-  u32 tiles_x;  // tiles along x
+  u32 total;      // tiles of the whole launch (= frames * per_frame)
+  u32 per_xcd;    // ceil(total / 8)
+  u32 tiles_x;    // tiles along x of one frame
+  u32 per_frame;  // tiles of one frame
 };
 
-__host__ __device__ inline TileMap make_tile_map(u32 tiles_x, u32 tiles_y) {
+__host__ __device__ inline TileMap make_tile_map(u32 tiles_x, u32 tiles_y, u32 frames = 1u) {
   TileMap m;
-  m.total = tiles_x * tiles_y;
+  m.per_frame = tiles_x * tiles_y;
+  m.total = m.per_frame * frames;
   m.per_xcd = (m.total + 7u) / 8u;
   m.tiles_x = tiles_x;
   return m;
 }
 
-// returns false when this workgroup is grid padding
-__device__ __forceinline__ bool tile_of_block(const TileMap& m, u32& tx, u32& ty) {
+// same for a tile list whose length per frame is already known (plane-job kernels)
+__host__ __device__ inline TileMap make_tile_map_linear(u32 per_frame, u32 frames) {
+  TileMap m;
+  m.per_frame = per_frame;
+  m.total = per_frame * frames;
+  m.per_xcd = (m.total + 7u) / 8u;
+  m.tiles_x = 1u;
+  return m;
+}
+
+inline dim3 tile_grid(const TileMap& m) { return dim3(m.per_xcd * 8u); }
+
+// linear tile of this workgroup -> (frame, tile within the frame); false for grid padding
+__device__ __forceinline__ bool frame_tile_of_block(const TileMap& m, u32& frame, u32& tile) {
   const u32 b = blockIdx.x;
   const u32 t = (b & 7u) * m.per_xcd + (b >> 3);
   if (t >= m.total)
+    return false;
+  if (m.total == m.per_frame) {
+    frame = 0;
+    tile = t;
+  } else {
+    frame = t / m.per_frame;
+    tile = t - frame * m.per_frame;
+  }
+  return true;
+}
+
+// (frame, tile_x, tile_y) of this workgroup; false for grid padding
+__device__ __forceinline__ bool tile_of_block(const TileMap& m, u32& tx, u32& ty, u32& frame) {
+  u32 t;
+  if (!frame_tile_of_block(m, frame, t))
     return false;
   if (m.tiles_x == 1u) {
     tx = 0;
@@ -234,10 +268,9 @@ __device__ __forceinline__ PlaneView plane_view(const vali_surface* d_src, const
 // tile index of this workgroup -> (job, tile_x, tile_y) through the XCD-contiguous map;
 // false for grid padding.  Conditional copies instead of jobs[j] (no dynamic indexing).
 __device__ __forceinline__ bool plane_tile(const PlaneJob (&jobs)[3], int njobs, const TileMap& map,
-                                           PlaneJob& job, u32& tx, u32& ty) {
-  const u32 b = blockIdx.x;
-  const u32 t = (b & 7u) * map.per_xcd + (b >> 3);
-  if (t >= map.total)
+                                           PlaneJob& job, u32& tx, u32& ty, u32& frame) {
+  u32 t;
+  if (!frame_tile_of_block(map, frame, t))
     return false;
   job = jobs[0];
   if (njobs > 1 && t >= jobs[1].first_tile) job = jobs[1];

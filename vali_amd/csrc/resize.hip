@@ -146,11 +146,11 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
 template <typename T>
 __global__ void __launch_bounds__(kBlock) k_resize(const ResizeArgs a) {
   ResizeJob job;
-  u32 tx, ty;
-  if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty))
+  u32 tx, ty, frame;
+  if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
     return;
   __shared__ StageRows stage[kWavesPerBlock];
-  const PlaneView v = plane_view(a.d_src, a.d_dst, blockIdx.y, job, a.sw, a.sh, a.dw, a.dh);
+  const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
   switch (job.channels) {
   case 1: resize_tile<T, 1>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage); break;
   case 2: resize_tile<T, 2>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage); break;
@@ -195,10 +195,8 @@ static int launch_resize(ResizeArgs& a, int fmt, int dst_w, int dst_h, int n, hi
     a.job[k].tiles_x = (u32)(dw + 255) / 256;
     total += a.job[k].tiles_x * (u32)((dh + 3) / 4);
   }
-  a.map.total = total;
-  a.map.per_xcd = (total + 7u) / 8u;
-  a.map.tiles_x = 1;
-  const dim3 grid(a.map.per_xcd * 8u, n), block(kBlock);
+  a.map = make_tile_map_linear(total, (u32)n);
+  const dim3 grid = tile_grid(a.map), block(kBlock);
   if (elem == 1)
     hipLaunchKernelGGL(k_resize<uint8_t>, grid, block, 0, stream, a);
   else if (elem == 2)

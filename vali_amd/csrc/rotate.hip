@@ -47,8 +47,8 @@ struct RotArgs {
   TileMap map;
 };
 
-__device__ __forceinline__ bool rot_tile(const RotArgs& a, RotJob& job, u32& tx, u32& ty) {
-  return plane_tile(a.job, a.njobs, a.map, job, tx, ty);
+__device__ __forceinline__ bool rot_tile(const RotArgs& a, RotJob& job, u32& tx, u32& ty, u32& frame) {
+  return plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame);
 }
 
 template <typename T, int C>
@@ -106,10 +106,10 @@ __device__ __forceinline__ void affine_tile(const RotArgs& a, const RotJob& job,
 template <typename T>
 __global__ void __launch_bounds__(kBlock) k_rotate_affine(const RotArgs a) {
   RotJob job;
-  u32 tx, ty;
-  if (!rot_tile(a, job, tx, ty))
+  u32 tx, ty, frame;
+  if (!rot_tile(a, job, tx, ty, frame))
     return;
-  const PlaneView v = plane_view(a.d_src, a.d_dst, blockIdx.y, job, a.sw, a.sh, a.dw, a.dh);
+  const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
   if (job.channels == 1)
     affine_tile<T, 1>(a, job, v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty);
   else
@@ -126,10 +126,10 @@ __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
   constexpr int S = kRotTile * P + 4; // LDS row stride in bytes (dword aligned, odd dwords)
   __shared__ __attribute__((aligned(16))) uint8_t lds[kRotTile * S];
   RotJob job;
-  u32 tile_x, tile_y;
-  if (!rot_tile(a, job, tile_x, tile_y))
+  u32 tile_x, tile_y, frame;
+  if (!rot_tile(a, job, tile_x, tile_y, frame))
     return;
-  const PlaneView v = plane_view(a.d_src, a.d_dst, blockIdx.y, job, a.sw, a.sh, a.dw, a.dh);
+  const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
   const int src_w = v.sw, src_h = v.sh, dst_w = v.dw, dst_h = v.dh;
   const uint8_t* src = v.sp;
   uint8_t* dst = v.dp;
@@ -305,10 +305,8 @@ static int launch_rotate(RotArgs& a, int fmt, int sw, int sh, int dw, int dh, do
       total += j.tiles_x * (u32)((pdh + 3) / 4);
     }
   }
-  a.map.total = total;
-  a.map.per_xcd = (total + 7u) / 8u;
-  a.map.tiles_x = 1;
-  const dim3 grid(a.map.per_xcd * 8u, n), block(kBlock);
+  a.map = make_tile_map_linear(total, (u32)n);
+  const dim3 grid = tile_grid(a.map), block(kBlock);
   if (tiled) {
     const int pixel_bytes = elem * a.job[0].channels; // all jobs of a format share it
     const int rc = q90 ? launch_tile<1>(a, pixel_bytes, grid, stream) : launch_tile<3>(a, pixel_bytes, grid, stream);

@@ -213,11 +213,11 @@ __host__ __device__ inline UdSpan ud_span(int tile_x, int dw, int sw, float scal
 template <typename T, int OUT, bool STAGED>
 __global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
   __shared__ UdStage stage[STAGED ? kWavesPerBlock : 1];
-  u32 tile_x, tile_y;
-  if (!tile_of_block(a.map, tile_x, tile_y))
+  u32 tile_x, tile_y, frame;
+  if (!tile_of_block(a.map, tile_x, tile_y, frame))
     return;
-  const SurfRef s = load_surface(a.d_src, a.src, blockIdx.y);
-  const SurfRef d = load_surface(a.d_dst, a.dst, blockIdx.y);
+  const SurfRef s = load_surface(a.d_src, a.src, frame);
+  const SurfRef d = load_surface(a.d_dst, a.dst, frame);
   const uint8_t* py = s.p[0];
   const uint8_t* puv = s.p[1];
   const int sp_y = s.pitch[0], sp_uv = s.pitch[1], sw = s.width, sh = s.height;
@@ -412,8 +412,8 @@ static int launch_ud(UdArgs& a, int src_fmt, int src_w, int dst_w, int dst_h, in
   const int kind = ud_out_kind(src_fmt, dst_fmt);
   if (kind < 0)
     return fail(VALI_ERR_UNSUPPORTED, "ud_nv12: unsupported format pair %d -> %d", src_fmt, dst_fmt);
-  a.map = make_tile_map((dst_w + 255) / 256, (dst_h + kUdTileH - 1) / kUdTileH);
-  const dim3 grid(a.map.per_xcd * 8u, n), block(kBlock);
+  a.map = make_tile_map((dst_w + 255) / 256, (dst_h + kUdTileH - 1) / kUdTileH, (u32)n);
+  const dim3 grid = tile_grid(a.map), block(kBlock);
   // staged kernel iff every tile's source spans fit the strip (same float math as the device)
   bool staged = true;
   {
