@@ -21,8 +21,8 @@
 // Oracle: vali_oracle_ud_nv12 (oracle/vali_oracle.c), bit-exact.
 //
 // Work decomposition: one lane = 4 adjacent dst pixels of a row, so u8 planar output is a
-// dword, u8 packed 12 B (dwordx3), f32 16/48 B per lane; a workgroup = 256 x 16 dst pixels,
-// each wave walking 4 rows with the same column taps.  The source rows a dst row samples are
+// dword, u8 packed 12 B (dwordx3), f32 16/48 B per lane; a workgroup = 256 x 32 dst pixels,
+// each wave walking 8 rows with the same column taps.  The source rows a dst row samples are
 // staged per wave in LDS with 16-byte coalesced loads (every 128-byte line fetched once);
 // tiles walk the frame through the XCD-contiguous TileMap.  HBM traffic = touched source
 // rows + the dst surface.
@@ -85,17 +85,38 @@ template <typename T> __device__ __forceinline__ u32 trunc_sat(float v) {
   return (u32)c;                                                  // v_cvt_u32_f32 truncates
 }
 
-// per-wave staging: the two luma rows and the two chroma rows a dst row samples
-constexpr int kUdChunks = 4;                    // 16-byte prefetch registers per lane
-constexpr int kUdRowBytes = 1024;               // per staged row; 4 rows x 1 KiB = kUdChunks x 64 lanes x 16 B
-constexpr int kUdRowsPerWave = 4; // dst rows a wave walks with the same column taps
+// per-wave staging: the two luma rows and the two chroma rows a dst row samples.  Lane l owns
+// bytes [16 l, 16 l + 16) of each of the four rows: one prefetch register per row, source
+// address = wave-uniform row base (SGPRs) + a per-lane constant, no per-row address arithmetic.
+constexpr int kUdRowBytes = kWave * 16;         // 1 KiB per staged row
+constexpr int kUdRowsPerWave = 8; // dst rows a wave walks with the same column taps
 constexpr int kUdTileH = kWavesPerBlock * kUdRowsPerWave;
 struct alignas(16) UdStage {
   uint8_t luma[2][kUdRowBytes];
   uint8_t chroma[2][kUdRowBytes];
 };
 
-// store 4 pixels of one dst row (c0/c1/c2 = Y,U,V or R,G,B normalised), n = valid pixels
+// Scale folded into the normalisation constant so the output stage is a bare truncation:
+// 2^k * (float(S) * kInvDen) == float(S) * (2^k * kInvDen) and 2^k * fma(a, v, y) ==
+// fma(a, 2^k v, 2^k y) bit for bit (power-of-two scaling commutes with IEEE rounding; nothing
+// here is near the subnormal range), so the reference's "val * 256" costs no instruction.
+template <typename T, int OUT> struct UdScale {
+  static constexpr float value = OUT == UD_YUV444 ? TexelTraits<T>::kMax
+                                 : (OUT == UD_RGB_U8 || OUT == UD_RGB_U8_PLANAR) ? 256.0f : 1.0f;
+};
+
+// four pre-scaled values -> 4 truncated, saturated bytes in one dword
+// (v_trunc_f32 + v_cvt_pk_u8_f32: the convert saturates and merges the byte; its rounding is
+// a no-op on an integer-valued float) == cvt.rzi.u8.f32 + packing
+__device__ __forceinline__ u32 trunc_pack4(float a, float b, float c, float e) {
+  u32 w = pack_u8<0>(__builtin_truncf(a), 0u);
+  w = pack_u8<1>(__builtin_truncf(b), w);
+  w = pack_u8<2>(__builtin_truncf(c), w);
+  return pack_u8<3>(__builtin_truncf(e), w);
+}
+
+// store 4 pixels of one dst row; c0/c1/c2 = Y,U,V or R,G,B already multiplied by
+// UdScale<T,OUT>; n = valid pixels; y is wave-uniform
 template <typename T, int OUT>
 __device__ __forceinline__ void ud_store(const SurfRef& d, int x0, int y, int n, const float (&c0)[4],
                                          const float (&c1)[4], const float (&c2)[4]) {
@@ -104,66 +125,73 @@ __device__ __forceinline__ void ud_store(const SurfRef& d, int x0, int y, int n,
   uint8_t* pd2 = d.p[2];
   const int dp0 = d.pitch[0], dp1 = d.pitch[1], dp2 = d.pitch[2];
   if constexpr (OUT == UD_YUV444) {
-    u32 q0[4], q1[4], q2[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      q0[p] = trunc_sat<T>(c0[p] * TexelTraits<T>::kMax);
-      q1[p] = trunc_sat<T>(c1[p] * TexelTraits<T>::kMax);
-      q2[p] = trunc_sat<T>(c2[p] * TexelTraits<T>::kMax);
-    }
-    uint8_t* o0 = pd0 + (size_t)y * dp0 + (size_t)x0 * sizeof(T);
-    uint8_t* o1 = pd1 + (size_t)y * dp1 + (size_t)x0 * sizeof(T);
-    uint8_t* o2 = pd2 + (size_t)y * dp2 + (size_t)x0 * sizeof(T);
+    uint8_t* o0 = pd0 + (u32)(y * dp0) + (size_t)x0 * sizeof(T);
+    uint8_t* o1 = pd1 + (u32)(y * dp1) + (size_t)x0 * sizeof(T);
+    uint8_t* o2 = pd2 + (u32)(y * dp2) + (size_t)x0 * sizeof(T);
     constexpr u32 kA = sizeof(T) == 1 ? 3u : 7u;
-    if (n == 4 && ((((uintptr_t)o0) | ((uintptr_t)o1) | ((uintptr_t)o2)) & kA) == 0) {
-      if constexpr (sizeof(T) == 1) {
-        gstore<u32>(o0, q0[0] | (q0[1] << 8) | (q0[2] << 16) | (q0[3] << 24));
-        gstore<u32>(o1, q1[0] | (q1[1] << 8) | (q1[2] << 16) | (q1[3] << 24));
-        gstore<u32>(o2, q2[0] | (q2[1] << 8) | (q2[2] << 16) | (q2[3] << 24));
+    const bool fast = n == 4 && ((((uintptr_t)o0) | ((uintptr_t)o1) | ((uintptr_t)o2)) & kA) == 0;
+    if constexpr (sizeof(T) == 1) {
+      const u32 w0 = trunc_pack4(c0[0], c0[1], c0[2], c0[3]);
+      const u32 w1 = trunc_pack4(c1[0], c1[1], c1[2], c1[3]);
+      const u32 w2 = trunc_pack4(c2[0], c2[1], c2[2], c2[3]);
+      if (fast) {
+        gstore<u32>(o0, w0); gstore<u32>(o1, w1); gstore<u32>(o2, w2);
       } else {
+        for (int p = 0; p < n; ++p) {
+          gstore<uint8_t>(o0 + p, (uint8_t)(w0 >> (8 * p))); gstore<uint8_t>(o1 + p, (uint8_t)(w1 >> (8 * p)));
+          gstore<uint8_t>(o2 + p, (uint8_t)(w2 >> (8 * p)));
+        }
+      }
+    } else {
+      u32 q0[4], q1[4], q2[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        q0[p] = trunc_sat<T>(c0[p]); q1[p] = trunc_sat<T>(c1[p]); q2[p] = trunc_sat<T>(c2[p]);
+      }
+      if (fast) {
         store8(o0, make_uint2(q0[0] | (q0[1] << 16), q0[2] | (q0[3] << 16)));
         store8(o1, make_uint2(q1[0] | (q1[1] << 16), q1[2] | (q1[3] << 16)));
         store8(o2, make_uint2(q2[0] | (q2[1] << 16), q2[2] | (q2[3] << 16)));
+      } else {
+        for (int p = 0; p < n; ++p) {
+          gstore<T>(o0 + p * sizeof(T), (T)q0[p]); gstore<T>(o1 + p * sizeof(T), (T)q1[p]); gstore<T>(o2 + p * sizeof(T), (T)q2[p]);
+        }
       }
+    }
+  } else if constexpr (OUT == UD_RGB_U8_PLANAR) {
+    const u32 wr = trunc_pack4(c0[0], c0[1], c0[2], c0[3]);
+    const u32 wg = trunc_pack4(c1[0], c1[1], c1[2], c1[3]);
+    const u32 wb = trunc_pack4(c2[0], c2[1], c2[2], c2[3]);
+    uint8_t* o0 = pd0 + (u32)(y * dp0) + x0;
+    uint8_t* o1 = pd1 + (u32)(y * dp0) + x0;
+    uint8_t* o2 = pd2 + (u32)(y * dp0) + x0;
+    if (n == 4 && ((((uintptr_t)o0) | ((uintptr_t)o1) | ((uintptr_t)o2)) & 3u) == 0) {
+      gstore<u32>(o0, wr); gstore<u32>(o1, wg); gstore<u32>(o2, wb);
     } else {
       for (int p = 0; p < n; ++p) {
-        gstore<T>(o0 + p * sizeof(T), (T)q0[p]); gstore<T>(o1 + p * sizeof(T), (T)q1[p]); gstore<T>(o2 + p * sizeof(T), (T)q2[p]);
+        gstore<uint8_t>(o0 + p, (uint8_t)(wr >> (8 * p))); gstore<uint8_t>(o1 + p, (uint8_t)(wg >> (8 * p)));
+        gstore<uint8_t>(o2 + p, (uint8_t)(wb >> (8 * p)));
       }
     }
-  } else if constexpr (OUT == UD_RGB_U8 || OUT == UD_RGB_U8_PLANAR) {
-    u32 r[4], g[4], b[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      r[p] = trunc_sat<uint8_t>(c0[p] * 256.0f);
-      g[p] = trunc_sat<uint8_t>(c1[p] * 256.0f);
-      b[p] = trunc_sat<uint8_t>(c2[p] * 256.0f);
-    }
-    if constexpr (OUT == UD_RGB_U8_PLANAR) {
-      uint8_t* o0 = pd0 + (size_t)y * dp0 + x0;
-      uint8_t* o1 = pd1 + (size_t)y * dp0 + x0;
-      uint8_t* o2 = pd2 + (size_t)y * dp0 + x0;
-      if (n == 4 && ((((uintptr_t)o0) | ((uintptr_t)o1) | ((uintptr_t)o2)) & 3u) == 0) {
-        gstore<u32>(o0, r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24));
-        gstore<u32>(o1, g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24));
-        gstore<u32>(o2, b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24));
-      } else {
-        for (int p = 0; p < n; ++p) { gstore<uint8_t>(o0 + p, (uint8_t)r[p]); gstore<uint8_t>(o1 + p, (uint8_t)g[p]); gstore<uint8_t>(o2 + p, (uint8_t)b[p]); }
-      }
+  } else if constexpr (OUT == UD_RGB_U8) {
+    // bytes in memory order: r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3
+    const u32 w0 = trunc_pack4(c0[0], c1[0], c2[0], c0[1]);
+    const u32 w1 = trunc_pack4(c1[1], c2[1], c0[2], c1[2]);
+    const u32 w2 = trunc_pack4(c2[2], c0[3], c1[3], c2[3]);
+    uint8_t* o = pd0 + (u32)(y * dp0) + (size_t)x0 * 3;
+    if (n == 4 && (((uintptr_t)o) & 3u) == 0) {
+      typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+      const v3u32 w = {w0, w1, w2};
+      *(VALI_GLOBAL v3u32*)o = w; // global_store_dwordx3
     } else {
-      uint8_t* o = pd0 + (size_t)y * dp0 + (size_t)x0 * 3;
-      if (n == 4 && (((uintptr_t)o) & 3u) == 0) {
-        typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
-        const v3u32 w = {r[0] | (g[0] << 8) | (b[0] << 16) | (r[1] << 24), g[1] | (b[1] << 8) | (r[2] << 16) | (g[2] << 24),
-                         b[2] | (r[3] << 8) | (g[3] << 16) | (b[3] << 24)};
-        *(VALI_GLOBAL v3u32*)o = w; // global_store_dwordx3
-      } else {
-        for (int p = 0; p < n; ++p) { gstore<uint8_t>(o + 3 * p, (uint8_t)r[p]); gstore<uint8_t>(o + 3 * p + 1, (uint8_t)g[p]); gstore<uint8_t>(o + 3 * p + 2, (uint8_t)b[p]); }
-      }
+      const u32 ww[3] = {w0, w1, w2};
+      for (int k = 0; k < 3 * n; ++k)
+        gstore<uint8_t>(o + k, (uint8_t)(ww[k >> 2] >> (8 * (k & 3))));
     }
   } else if constexpr (OUT == UD_RGB_F32_PLANAR) {
-    uint8_t* o0 = pd0 + (size_t)y * dp0 + (size_t)x0 * 4;
-    uint8_t* o1 = pd1 + (size_t)y * dp0 + (size_t)x0 * 4;
-    uint8_t* o2 = pd2 + (size_t)y * dp0 + (size_t)x0 * 4;
+    uint8_t* o0 = pd0 + (u32)(y * dp0) + (size_t)x0 * 4;
+    uint8_t* o1 = pd1 + (u32)(y * dp0) + (size_t)x0 * 4;
+    uint8_t* o2 = pd2 + (u32)(y * dp0) + (size_t)x0 * 4;
     if (n == 4 && ((((uintptr_t)o0) | ((uintptr_t)o1) | ((uintptr_t)o2)) & 15u) == 0) {
       store16f(o0, make_float4(c0[0], c0[1], c0[2], c0[3]));
       store16f(o1, make_float4(c1[0], c1[1], c1[2], c1[3]));
@@ -172,7 +200,7 @@ __device__ __forceinline__ void ud_store(const SurfRef& d, int x0, int y, int n,
       for (int p = 0; p < n; ++p) { gstore<float>(o0 + 4 * p, c0[p]); gstore<float>(o1 + 4 * p, c1[p]); gstore<float>(o2 + 4 * p, c2[p]); }
     }
   } else { // UD_RGB_F32 packed
-    uint8_t* o = pd0 + (size_t)y * dp0 + (size_t)x0 * 12;
+    uint8_t* o = pd0 + (u32)(y * dp0) + (size_t)x0 * 12;
     if (n == 4 && (((uintptr_t)o) & 15u) == 0) {
       store16f(o + 0, make_float4(c0[0], c1[0], c2[0], c0[1]));
       store16f(o + 16, make_float4(c1[1], c2[1], c0[2], c1[2]));
@@ -184,18 +212,13 @@ __device__ __forceinline__ void ud_store(const SurfRef& d, int x0, int y, int n,
 }
 
 // Source spans (bytes, 16-byte granular) the 256 columns of tile `tile_x` read from a luma row
-// and from a chroma row.  Host and device evaluate the SAME float expressions, so the host's
-// choice of the staged kernel is exact.
+// and from a chroma row; the host uses it to choose the staged kernel.  The device derives the
+// same numbers from the taps of lane 0's first and lane 63's last pixel (same float
+// expressions, so the two always agree).
 struct UdSpan {
   int yb, yn, cb, cn;
 };
-template <typename T>
-__host__ __device__ inline UdSpan ud_span(int tile_x, int dw, int sw, float scale_x) {
-  constexpr int E = (int)sizeof(T);
-  const int xt0 = tile_x * 256, xt1 = (xt0 + 255 < dw - 1) ? xt0 + 255 : dw - 1;
-  const int ly0 = make_tap((float)xt0 / scale_x, sw).i0, ly1 = make_tap((float)xt1 / scale_x, sw).i1;
-  const int lc0 = make_tap((float)xt0 / (scale_x * 2.0f), sw / 2).i0,
-            lc1 = make_tap((float)xt1 / (scale_x * 2.0f), sw / 2).i1;
+__host__ __device__ inline UdSpan ud_span_of(int ly0, int ly1, int lc0, int lc1, int E) {
   UdSpan r;
   r.yb = (ly0 * E) & ~15;
   r.yn = (((ly1 + 1) * E + 15) & ~15) - r.yb;
@@ -203,13 +226,26 @@ __host__ __device__ inline UdSpan ud_span(int tile_x, int dw, int sw, float scal
   r.cn = (((lc1 + 1) * 2 * E + 15) & ~15) - r.cb;
   return r;
 }
+template <typename T>
+__host__ inline UdSpan ud_span(int tile_x, int dw, int sw, float scale_x) {
+  const int xt0 = tile_x * 256, xt1 = (xt0 + 255 < dw - 1) ? xt0 + 255 : dw - 1;
+  const float c0 = (float)xt0 / scale_x, c1 = (float)xt1 / scale_x;
+  return ud_span_of(make_tap(c0, sw).i0, make_tap(c1, sw).i1, make_tap(c0 * 0.5f, sw / 2).i0,
+                    make_tap(c1 * 0.5f, sw / 2).i1, (int)sizeof(T));
+}
 
-// One workgroup = 256 x 16 dst pixels: wave w walks dst rows 4w..4w+3 of the tile with the
-// SAME four column taps per lane (the two float divisions per column are paid once per 4 rows).
-// STAGED: each dst row's two luma + two chroma source rows go through the wave's LDS strip;
-// the 16-byte loads of row r+1 are issued before row r is sampled (register prefetch), so
-// HBM latency overlaps the arithmetic.  !STAGED (source span too wide for the strip, i.e.
-// downscale beyond ~4x): direct byte gather.
+// One workgroup = 256 x 32 dst pixels: wave w walks dst rows 8w..8w+7 of the tile with the
+// SAME four column taps per lane, so the float divisions of the coordinates (IEEE, ~12
+// instructions each) are paid once per 8 rows.  Instruction count is what bounds this kernel
+// (profiles/r01_secondary.md), hence:
+//  * the chroma coordinate x / (2 scale) is taken as 0.5f * (x / scale): identical bits
+//    (power-of-two scaling commutes with rounding), half the divisions;
+//  * the 8 row taps of a wave are evaluated lane-parallel (lane r computes row r) and read
+//    back with v_readlane, so per row they are SGPRs and every row base address is scalar;
+//  * STAGED: each dst row's two luma + two chroma source rows go through the wave's LDS strip,
+//    lane l owning the same 16 bytes of every row; the loads of row r+1 are issued before row
+//    r is sampled (register prefetch), so HBM latency overlaps the arithmetic.
+//    !STAGED (source span wider than the strip, i.e. downscale beyond ~4x): direct byte gather.
 template <typename T, int OUT, bool STAGED>
 __global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
   __shared__ UdStage stage[STAGED ? kWavesPerBlock : 1];
@@ -222,7 +258,8 @@ __global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
   const uint8_t* puv = s.p[1];
   const int sp_y = s.pitch[0], sp_uv = s.pitch[1], sw = s.width, sh = s.height;
   const int dw = d.width, dh = d.height;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int x0 = (tile_x * 64 + lane) * 4;
   const int y_first = tile_y * kUdTileH + wave * kUdRowsPerWave; // wave-uniform
   if (y_first >= dh)
@@ -238,32 +275,42 @@ __global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int x = min(x0 + p, dw - 1);
-    tx[p] = make_tap((float)x / scale_x, sw);
-    tcx[p] = make_tap((float)x / (scale_x * 2.0f), sw / 2);
+    const float cx = (float)x / scale_x;
+    tx[p] = make_tap(cx, sw);
+    tcx[p] = make_tap(cx * 0.5f, sw / 2); // == x / (scale_x * 2.0f)
   }
   const int n = min(4, dw - x0); // valid pixels of this lane (<= 0: tail lane, staging only)
 
+  // row taps: lane r evaluates row y_first + r; rows are read back as scalars
   struct RowTaps {
     Tap ty, tcy;
   };
-  auto row_taps = [&](int y) {
+  const float cyl = (float)(y_first + (lane & (kUdRowsPerWave - 1))) / scale_y;
+  const Tap vty = make_tap(cyl, sh), vtcy = make_tap(cyl * 0.5f, sh / 2);
+  auto row_taps = [&](int rr) {
     RowTaps r;
-    r.ty = make_tap((float)y / scale_y, sh);
-    r.tcy = make_tap((float)y / (scale_y * 2.0f), sh / 2);
+    r.ty.i0 = __builtin_amdgcn_readlane(vty.i0, rr);
+    r.ty.i1 = __builtin_amdgcn_readlane(vty.i1, rr);
+    r.ty.w0 = (u32)__builtin_amdgcn_readlane((int)vty.w0, rr);
+    r.ty.w1 = (u32)__builtin_amdgcn_readlane((int)vty.w1, rr);
+    r.tcy.i0 = __builtin_amdgcn_readlane(vtcy.i0, rr);
+    r.tcy.i1 = __builtin_amdgcn_readlane(vtcy.i1, rr);
+    r.tcy.w0 = (u32)__builtin_amdgcn_readlane((int)vtcy.w0, rr);
+    r.tcy.w1 = (u32)__builtin_amdgcn_readlane((int)vtcy.w1, rr);
     return r;
   };
 
-  // texels -> c0/c1/c2 of the lane's 4 pixels
+  // texels -> c0/c1/c2 (scaled by UdScale) of the lane's 4 pixels
+  constexpr float kScale = UdScale<T, OUT>::value;
+  constexpr float kNorm = TexelTraits<T>::kInvDen * kScale;
   auto sample = [&](const RowTaps& rt, auto luma, auto chroma, float (&c0)[4], float (&c1)[4], float (&c2)[4]) {
     u32 l[4][4], cu[4][4], cv[4][4]; // [pixel][00,10,01,11]
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      l[p][0] = luma(0, tx[p].i0); l[p][1] = luma(0, tx[p].i1);
-      l[p][2] = luma(1, tx[p].i0); l[p][3] = luma(1, tx[p].i1);
-      cu[p][0] = chroma(0, tcx[p].i0, 0); cu[p][1] = chroma(0, tcx[p].i1, 0);
-      cu[p][2] = chroma(1, tcx[p].i0, 0); cu[p][3] = chroma(1, tcx[p].i1, 0);
-      cv[p][0] = chroma(0, tcx[p].i0, 1); cv[p][1] = chroma(0, tcx[p].i1, 1);
-      cv[p][2] = chroma(1, tcx[p].i0, 1); cv[p][3] = chroma(1, tcx[p].i1, 1);
+      l[p][0] = luma(0, p, 0); l[p][1] = luma(0, p, 1);
+      l[p][2] = luma(1, p, 0); l[p][3] = luma(1, p, 1);
+      chroma(0, p, 0, cu[p][0], cv[p][0]); chroma(0, p, 1, cu[p][1], cv[p][1]);
+      chroma(1, p, 0, cu[p][2], cv[p][2]); chroma(1, p, 1, cu[p][3], cv[p][3]);
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -277,13 +324,13 @@ __global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
       const u32 sy = bil(rt.ty.w0, rt.ty.w1, tx[p].w0, tx[p].w1, l[p]);
       const u32 su = bil(rt.tcy.w0, rt.tcy.w1, tcx[p].w0, tcx[p].w1, cu[p]);
       const u32 sv = bil(rt.tcy.w0, rt.tcy.w1, tcx[p].w0, tcx[p].w1, cv[p]);
-      const float ny = (float)sy * TexelTraits<T>::kInvDen;
-      const float nu = (float)su * TexelTraits<T>::kInvDen;
-      const float nv = (float)sv * TexelTraits<T>::kInvDen;
+      const float ny = (float)sy * kNorm;
+      const float nu = (float)su * kNorm;
+      const float nv = (float)sv * kNorm;
       if constexpr (OUT == UD_YUV444) {
         c0[p] = ny; c1[p] = nu; c2[p] = nv;
       } else {
-        const float u = nu - 0.5f, v = nv - 0.5f;
+        const float u = nu - 0.5f * kScale, v = nv - 0.5f * kScale;
         c0[p] = __builtin_fmaf(1.140f, v, ny);
         c1[p] = __builtin_fmaf(-0.581f, v, __builtin_fmaf(-0.394f, u, ny));
         c2[p] = __builtin_fmaf(2.032f, u, ny);
@@ -292,70 +339,75 @@ __global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
   };
 
   if constexpr (STAGED) {
-    const UdSpan sp = ud_span<T>((int)tile_x, dw, sw, scale_x);
-    const int nyv = sp.yn / 16, ncv = sp.cn / 16, total = 2 * (nyv + ncv); // <= kUdChunks * 64
+    // spans of this tile: first tap of lane 0 .. last tap of lane 63 (columns are monotonic)
+    const UdSpan sp = ud_span_of(__builtin_amdgcn_readlane(tx[0].i0, 0), __builtin_amdgcn_readlane(tx[3].i1, 63),
+                                 __builtin_amdgcn_readlane(tcx[0].i0, 0), __builtin_amdgcn_readlane(tcx[3].i1, 63), E);
     const bool aligned = ((((uintptr_t)py) | ((uintptr_t)puv) | (uintptr_t)sp_y | (uintptr_t)sp_uv) & 15u) == 0;
     UdStage& st = stage[wave];
-    // chunk k of a row's staging set -> (global source address, LDS destination)
-    auto chunk = [&](const RowTaps& rt, int k, const uint8_t*& src, uint8_t*& dst) {
-      if (k < 2 * nyv) {
-        const int r = k >= nyv ? 1 : 0, v = k - r * nyv;
-        src = py + (size_t)(r ? rt.ty.i1 : rt.ty.i0) * sp_y + sp.yb + v * 16;
-        dst = &st.luma[r][v * 16];
-      } else {
-        const int kk = k - 2 * nyv, r = kk >= ncv ? 1 : 0, v = kk - r * ncv;
-        src = puv + (size_t)(r ? rt.tcy.i1 : rt.tcy.i0) * sp_uv + sp.cb + v * 16;
-        dst = &st.chroma[r][v * 16];
-      }
+    const int off = lane * 16;
+    const bool in_y = off < sp.yn, in_c = off < sp.cn;
+    uint4 pf[4]; // prefetch registers: this lane's 16 bytes of luma0, luma1, chroma0, chroma1
+    auto fetch = [&](const uint8_t* src) {
+      if (aligned)
+        return gload16(src);
+      u32 w[4] = {0, 0, 0, 0}; // foreign, unaligned memory: byte loads (rare, slow, still correct)
+      for (int bb = 0; bb < 16; ++bb) w[bb >> 2] |= (u32)gload<uint8_t>(src + bb) << (8 * (bb & 3));
+      return make_uint4(w[0], w[1], w[2], w[3]);
     };
-    uint4 pf[kUdChunks]; // prefetch registers: the next row's chunks of this lane
     auto issue = [&](const RowTaps& rt) {
-#pragma unroll
-      for (int i = 0; i < kUdChunks; ++i) {
-        const int k = lane + i * kWave;
-        if (k < total) {
-          const uint8_t* src; uint8_t* dst;
-          chunk(rt, k, src, dst);
-          if (aligned) pf[i] = gload16(src);
-          else { // foreign, unaligned memory: byte loads (rare, slow, still correct)
-            u32 w[4] = {0, 0, 0, 0};
-            for (int bb = 0; bb < 16; ++bb) w[bb >> 2] |= (u32)gload<uint8_t>(src + bb) << (8 * (bb & 3));
-            pf[i] = make_uint4(w[0], w[1], w[2], w[3]);
-          }
-        }
+      // scalar address arithmetic; a plane is < 4 GiB, so 32-bit row offsets (s_mul_i32)
+      const uint8_t* y0 = py + (u32)(rt.ty.i0 * sp_y + sp.yb);
+      const uint8_t* y1 = py + (u32)(rt.ty.i1 * sp_y + sp.yb);
+      const uint8_t* q0 = puv + (u32)(rt.tcy.i0 * sp_uv + sp.cb);
+      const uint8_t* q1 = puv + (u32)(rt.tcy.i1 * sp_uv + sp.cb);
+      if (in_y) { pf[0] = fetch(y0 + off); pf[1] = fetch(y1 + off); }
+      if (in_c) { pf[2] = fetch(q0 + off); pf[3] = fetch(q1 + off); }
+    };
+    auto commit = [&]() {
+      if (in_y) {
+        *reinterpret_cast<uint4*>(&st.luma[0][off]) = pf[0];
+        *reinterpret_cast<uint4*>(&st.luma[1][off]) = pf[1];
+      }
+      if (in_c) {
+        *reinterpret_cast<uint4*>(&st.chroma[0][off]) = pf[2];
+        *reinterpret_cast<uint4*>(&st.chroma[1][off]) = pf[3];
       }
     };
-    auto commit = [&](const RowTaps& rt) {
+    // LDS byte offsets of the column taps (row-invariant)
+    int ly[4][2], lc[4][2];
 #pragma unroll
-      for (int i = 0; i < kUdChunks; ++i) {
-        const int k = lane + i * kWave;
-        if (k < total) {
-          const uint8_t* src; uint8_t* dst;
-          chunk(rt, k, src, dst);
-          *reinterpret_cast<uint4*>(dst) = pf[i];
-        }
-      }
-    };
-    RowTaps cur = row_taps(y_first);
+    for (int p = 0; p < 4; ++p) {
+      ly[p][0] = tx[p].i0 * E - sp.yb; ly[p][1] = tx[p].i1 * E - sp.yb;
+      lc[p][0] = tcx[p].i0 * 2 * E - sp.cb; lc[p][1] = tcx[p].i1 * 2 * E - sp.cb;
+    }
+    RowTaps cur = row_taps(0);
     issue(cur);
 #pragma unroll 1
     for (int rr = 0; rr < kUdRowsPerWave; ++rr) {
       const int y = y_first + rr;
       if (y >= dh)
         break;
-      commit(cur);
+      commit();
       wave_lds_sync();
       const bool more = rr + 1 < kUdRowsPerWave && y + 1 < dh;
       RowTaps nxt = cur;
       if (more) {
-        nxt = row_taps(y + 1);
+        nxt = row_taps(rr + 1);
         issue(nxt); // in flight while this row is sampled
       }
       if (n > 0) {
         float c0[4], c1[4], c2[4];
         sample(cur,
-               [&](int r, int i) { return (u32)((const T*)(st.luma[r] + (i * E - sp.yb)))[0]; },
-               [&](int r, int i, int c) { return (u32)((const T*)(st.chroma[r] + (i * 2 * E - sp.cb)))[c]; },
+               [&](int r, int p, int t) { return (u32) * (const T*)(st.luma[r] + ly[p][t]); },
+               [&](int r, int p, int t, u32& u, u32& v) {
+                 if constexpr (E == 1) { // U and V are neighbours: one 16-bit LDS read
+                   const u32 w = *(const uint16_t*)(st.chroma[r] + lc[p][t]);
+                   u = w & 0xffu; v = w >> 8;
+                 } else {
+                   const u32 w = *(const u32*)(st.chroma[r] + lc[p][t]);
+                   u = w & 0xffffu; v = w >> 16;
+                 }
+               },
                c0, c1, c2);
         ud_store<T, OUT>(d, x0, y, n, c0, c1, c2);
       }
@@ -370,14 +422,16 @@ __global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
       const int y = y_first + rr;
       if (y >= dh)
         break;
-      const RowTaps rt = row_taps(y);
-      const uint8_t* yrow0 = py + (size_t)rt.ty.i0 * sp_y;
-      const uint8_t* yrow1 = py + (size_t)rt.ty.i1 * sp_y;
-      const uint8_t* crow0 = puv + (size_t)rt.tcy.i0 * sp_uv;
-      const uint8_t* crow1 = puv + (size_t)rt.tcy.i1 * sp_uv;
+      const RowTaps rt = row_taps(rr);
+      const uint8_t* yrow[2] = {py + (size_t)rt.ty.i0 * sp_y, py + (size_t)rt.ty.i1 * sp_y};
+      const uint8_t* crow[2] = {puv + (size_t)rt.tcy.i0 * sp_uv, puv + (size_t)rt.tcy.i1 * sp_uv};
       float c0[4], c1[4], c2[4];
-      sample(rt, [&](int r, int i) { return (u32)gload<T>((r ? yrow1 : yrow0) + (size_t)i * E); },
-             [&](int r, int i, int c) { return (u32)gload<T>((r ? crow1 : crow0) + ((size_t)i * 2 + c) * E); },
+      sample(rt,
+             [&](int r, int p, int t) { return (u32)gload<T>(yrow[r] + (size_t)(t ? tx[p].i1 : tx[p].i0) * E); },
+             [&](int r, int p, int t, u32& u, u32& v) {
+               const uint8_t* q = crow[r] + (size_t)(t ? tcx[p].i1 : tcx[p].i0) * 2 * E;
+               u = (u32)gload<T>(q); v = (u32)gload<T>(q + E);
+             },
              c0, c1, c2);
       ud_store<T, OUT>(d, x0, y, n, c0, c1, c2);
     }
@@ -421,7 +475,7 @@ static int launch_ud(UdArgs& a, int src_fmt, int src_w, int dst_w, int dst_h, in
     for (int t = 0; t < (dst_w + 255) / 256 && staged; ++t) {
       const UdSpan sp = src_fmt == VALI_FMT_NV12 ? ud_span<uint8_t>(t, dst_w, src_w, scale_x)
                                                  : ud_span<uint16_t>(t, dst_w, src_w, scale_x);
-      staged = 2 * (sp.yn / 16 + sp.cn / 16) <= kUdChunks * kWave && sp.yn <= kUdRowBytes && sp.cn <= kUdRowBytes;
+      staged = sp.yn <= kUdRowBytes && sp.cn <= kUdRowBytes;
     }
   }
 #define VALI_UD_CASE(T, K)                                                                  \
