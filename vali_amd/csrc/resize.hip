@@ -20,11 +20,12 @@
 //   i = min(i, sw-1) ; i1 = min(i+1, sw-1)            (same for y -> j, b)
 //   t0 = fma(a, T[j][i1]-T[j][i], T[j][i]) ; t1 on row j1 ; v = fma(b, t1-t0, t0)
 //   u8/u16: round-half-even + saturate ; f32: v
-// One lane = 4 adjacent dst pixels of one plane row; 64x4 lanes per workgroup; plane jobs
-// are concatenated in the XCD-contiguous TileMap.  Source texels are gathered through
-// L1/L2; HBM traffic = touched source lines + dst.
+// One lane = 4 adjacent dst pixels of one plane row; a workgroup = 256 x 16 dst pixels of one
+// plane; plane jobs are concatenated in the XCD-contiguous TileMap.  HBM traffic = touched
+// source rows + dst.
 #include "common.hpp"
 #include "dev_util.hpp"
+#include <type_traits>
 
 namespace vali {
 
@@ -66,12 +67,19 @@ __device__ __forceinline__ Lerp make_lerp(int x, float scale, int size) {
   return l;
 }
 
-// Per-wave LDS staging of the two source rows a wave's dst row needs.  A wave (= one dst
-// row x 256 px) reads the source span [byte_begin, byte_begin + nbytes) of rows i0 and i1
-// with 16-byte coalesced loads, then gathers its texels from LDS: every 128-byte line is
-// fetched ONCE instead of once per byte-gather instruction (the direct gather re-requested
-// each line ~8x from L2 and ran at 1.9 TB/s-equivalent; see profiles/r01_secondary.md).
-constexpr int kStageRowBytes = 3072 + 64; // per row slot; span 3072 B = 12x downscale for u8 C1
+// Per-wave LDS staging of the two source rows a dst row needs.  A wave walks kRsRowsPerWave
+// dst rows x 256 px with the SAME column taps (coordinates, float divisions and LDS offsets are
+// paid once per tile, not per row).  For each dst row it reads the source span
+// [byte_begin, byte_begin + nbytes) of rows i0 and i1 with 16-byte coalesced loads -- lane l
+// owns chunks l, l+64, ... of both rows -- then gathers its texels from LDS: every 128-byte
+// line is fetched ONCE instead of once per byte-gather instruction (the direct gather
+// re-requested each line ~8x from L2; profiles/r01_secondary.md).  The loads of row r+1 are
+// issued before row r is sampled.  A row whose vertical weight is exactly 0 (integer scale
+// factors: BASELINE config 3) never fetches its second source row: fma(0, t1 - t0, t0) == t0.
+constexpr int kRsRowsPerWave = 8;
+constexpr int kRsTileH = kWavesPerBlock * kRsRowsPerWave;
+constexpr int kRsChunks = 3;                             // 16-byte chunks per lane per row
+constexpr int kStageRowBytes = kRsChunks * kWave * 16;   // 3072 B = 12x downscale for u8 C1
 struct alignas(16) StageRows {
   uint8_t row[2][kStageRowBytes];
 };
@@ -80,38 +88,49 @@ template <typename T, int C>
 __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int sw, int sh,
                                             uint8_t* dp, int dpitch, int dw, int dh, u32 tx,
                                             u32 ty, StageRows* stage_all) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int x0 = (tx * 64 + lane) * 4;
-  const int y = ty * 4 + wave; // wave-uniform
-  if (y >= dh)
+  const int y_first = ty * kRsTileH + wave * kRsRowsPerWave; // wave-uniform
+  if (y_first >= dh)
     return;
   const float scale_x = (float)sw / (float)dw, scale_y = (float)sh / (float)dh;
-  const Lerp ly = make_lerp(y, scale_y, sh);
-  const uint8_t* r0 = sp + (size_t)ly.i0 * spitch;
-  const uint8_t* r1 = sp + (size_t)ly.i1 * spitch;
-
-  // wave-uniform source span of this tile row
   constexpr int PB = C * (int)sizeof(T);
-  const int xt0 = tx * 256, xt1 = min(xt0 + 255, dw - 1);
-  const int sx0 = make_lerp(xt0, scale_x, sw).i0, sx1 = make_lerp(xt1, scale_x, sw).i1;
+
+  // column taps of the lane's 4 pixels (tail lanes clamp to the last column)
+  Lerp lx[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+    lx[p] = make_lerp(min(x0 + p, dw - 1), scale_x, sw);
+  const int n = min(4, dw - x0); // valid pixels (<= 0: tail lane, staging only)
+
+  // row taps: lane r evaluates row y_first + r, read back as scalars
+  const Lerp vly = make_lerp(y_first + (lane & (kRsRowsPerWave - 1)), scale_y, sh);
+  auto row_lerp = [&](int rr) {
+    Lerp l;
+    l.i0 = __builtin_amdgcn_readlane(vly.i0, rr);
+    l.i1 = __builtin_amdgcn_readlane(vly.i1, rr);
+    l.a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vly.a), rr));
+    return l;
+  };
+
+  // wave-uniform source span of this tile: first tap of lane 0 .. last tap of lane 63
+  const int sx0 = __builtin_amdgcn_readlane(lx[0].i0, 0), sx1 = __builtin_amdgcn_readlane(lx[3].i1, 63);
   const int byte_begin = (sx0 * PB) & ~15;
   const int nbytes = (((sx1 + 1) * PB + 15) & ~15) - byte_begin;
   const bool staged = nbytes <= kStageRowBytes && ((((uintptr_t)sp) | (uintptr_t)spitch) & 15u) == 0;
+
   // The sampling code is instantiated twice (LDS rows / global rows) so each copy gets typed
   // ds_read / global_load instructions; all texels of the lane are fetched before any
   // arithmetic so the loads overlap.
-  auto sample_and_store = [&](auto fetch) {
-    if (x0 >= dw)
-      return;
-    Lerp lx[4];
+  auto sample_and_store = [&](const Lerp& ly, int y, auto fetch) {
     float t[4][4][C]; // [pixel][00,10,01,11][channel]
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      lx[p] = make_lerp(min(x0 + p, dw - 1), scale_x, sw);
 #pragma unroll
       for (int ch = 0; ch < C; ++ch) {
-        t[p][0][ch] = fetch(0, lx[p].i0, ch); t[p][1][ch] = fetch(0, lx[p].i1, ch);
-        t[p][2][ch] = fetch(1, lx[p].i0, ch); t[p][3][ch] = fetch(1, lx[p].i1, ch);
+        t[p][0][ch] = fetch(0, p, 0, ch); t[p][1][ch] = fetch(0, p, 1, ch);
+        t[p][2][ch] = fetch(1, p, 0, ch); t[p][3][ch] = fetch(1, p, 1, ch);
       }
     }
     float res[4][C];
@@ -123,23 +142,91 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
         const float t1 = __builtin_fmaf(lx[p].a, t[p][3][ch] - t[p][2][ch], t[p][2][ch]);
         res[p][ch] = __builtin_fmaf(ly.a, t1 - t0, t0);
       }
-    const int n = min(4, dw - x0);
-    store_px4<T, C>(dp + (size_t)y * dpitch + (size_t)x0 * PB, res, (1u << n) - 1u);
+    store_px4<T, C>(dp + (u32)(y * dpitch) + (size_t)x0 * PB, res, (1u << n) - 1u);
   };
+
   if (staged) {
     StageRows& st = stage_all[wave];
-    for (int k = lane; k < 2 * (nbytes / 16); k += kWave) {
-      const int r = k >= nbytes / 16 ? 1 : 0, v = k - r * (nbytes / 16);
-      *reinterpret_cast<uint4*>(&st.row[r][v * 16]) = gload16((r ? r1 : r0) + byte_begin + v * 16);
+    const int nchunks = nbytes / 16;
+    int lo[4][2]; // LDS byte offsets of the column taps (row-invariant)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      lo[p][0] = lx[p].i0 * PB - byte_begin;
+      lo[p][1] = lx[p].i1 * PB - byte_begin;
     }
-    wave_lds_sync();
-    sample_and_store([&](int r, int i, int ch) {
-      return (float)((const T*)(st.row[r] + (i * PB - byte_begin)))[ch];
-    });
+    // Register prefetch pipeline, DEPTH dst rows ahead, CPR 16-byte chunks per lane per row.
+    // HBM latency x per-CU bandwidth share needs ~46 KB in flight per CU; one row of a
+    // narrow span (768 B at 3x) is far too little, so narrow spans run 4 rows ahead
+    // (<1, 4>), wide ones 1 row ahead with 3 chunks (<3, 1>).  The row loop is fully
+    // unrolled so the ring of prefetch registers is indexed statically.
+    auto pipeline = [&](auto cpr_tag, auto depth_tag) {
+      constexpr int CPR = decltype(cpr_tag)::value, DEPTH = decltype(depth_tag)::value;
+      uint4 pf[DEPTH][2][CPR];
+      // Loads are unconditional and straight-line (the compiler then counts vmcnt instead of
+      // draining at every branch): lanes past the span re-read its last chunk, and a row with
+      // vertical weight 0 re-reads row i0 (same lines: no extra HBM traffic).
+      auto issue = [&](int rr, uint4 (&q)[2][CPR]) {
+        const Lerp ly = row_lerp(rr);
+        // (float planes always fetch both rows: 0 * inf must stay NaN)
+        const bool two = sizeof(T) == 4 || ly.a != 0.0f;
+        // scalar row addresses; a plane is < 4 GiB
+        const uint8_t* r0 = sp + (u32)(ly.i0 * spitch + byte_begin);
+        const uint8_t* r1 = sp + (u32)((two ? ly.i1 : ly.i0) * spitch + byte_begin);
+#pragma unroll
+        for (int i = 0; i < CPR; ++i) {
+          const int k = min(lane + i * kWave, nchunks - 1);
+          q[0][i] = gload16(r0 + k * 16);
+          q[1][i] = gload16(r1 + k * 16);
+        }
+      };
+      auto commit = [&](const uint4 (&q)[2][CPR]) {
+#pragma unroll
+        for (int i = 0; i < CPR; ++i) {
+          const int k = lane + i * kWave;
+          if (k < nchunks) {
+            *reinterpret_cast<uint4*>(&st.row[0][k * 16]) = q[0][i];
+            *reinterpret_cast<uint4*>(&st.row[1][k * 16]) = q[1][i];
+          }
+        }
+      };
+#pragma unroll
+      for (int k = 0; k < DEPTH; ++k)
+        if (k < kRsRowsPerWave && y_first + k < dh)
+          issue(k, pf[k]);
+#pragma unroll
+      for (int rr = 0; rr < kRsRowsPerWave; ++rr) {
+        const int y = y_first + rr;
+        if (y >= dh)
+          break;
+        commit(pf[rr % DEPTH]);
+        wave_lds_sync();
+        if (rr + DEPTH < kRsRowsPerWave && y + DEPTH < dh)
+          issue(rr + DEPTH, pf[rr % DEPTH]); // in flight while rows rr .. rr+DEPTH-1 are sampled
+        if (n > 0)
+          sample_and_store(row_lerp(rr), y, [&](int r, int p, int t, int ch) {
+            return (float)((const T*)(st.row[r] + lo[p][t]))[ch];
+          });
+        wave_lds_sync(); // the strip is re-filled by the next row
+      }
+    };
+    if (nchunks <= kWave)
+      pipeline(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{});
+    else
+      pipeline(std::integral_constant<int, kRsChunks>{}, std::integral_constant<int, 1>{});
   } else {
-    sample_and_store([&](int r, int i, int ch) {
-      return (float)gload<T>((r ? r1 : r0) + (size_t)i * PB + ch * sizeof(T));
-    });
+    if (n <= 0)
+      return;
+#pragma unroll 1
+    for (int rr = 0; rr < kRsRowsPerWave; ++rr) {
+      const int y = y_first + rr;
+      if (y >= dh)
+        break;
+      const Lerp ly = row_lerp(rr);
+      const uint8_t* rows[2] = {sp + (size_t)ly.i0 * spitch, sp + (size_t)ly.i1 * spitch};
+      sample_and_store(ly, y, [&](int r, int p, int t, int ch) {
+        return (float)gload<T>(rows[r] + (size_t)(t ? lx[p].i1 : lx[p].i0) * PB + ch * sizeof(T));
+      });
+    }
   }
 }
 
@@ -193,7 +280,7 @@ static int launch_resize(ResizeArgs& a, int fmt, int dst_w, int dst_h, int n, hi
       return fail(VALI_ERR_INVALID_ARG, "resize: destination too small for its chroma planes");
     a.job[k].first_tile = total;
     a.job[k].tiles_x = (u32)(dw + 255) / 256;
-    total += a.job[k].tiles_x * (u32)((dh + 3) / 4);
+    total += a.job[k].tiles_x * (u32)((dh + kRsTileH - 1) / kRsTileH);
   }
   a.map = make_tile_map_linear(total, (u32)n);
   const dim3 grid = tile_grid(a.map), block(kBlock);

@@ -338,30 +338,55 @@ __global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
     }
   };
 
+  // direct byte gather: source span wider than the strip, or foreign memory that is not
+  // 16-byte aligned
+  auto gather_rows = [&]() {
+    if (n <= 0)
+      return;
+#pragma unroll 1
+    for (int rr = 0; rr < kUdRowsPerWave; ++rr) {
+      const int y = y_first + rr;
+      if (y >= dh)
+        break;
+      const RowTaps rt = row_taps(rr);
+      const uint8_t* yrow[2] = {py + (size_t)rt.ty.i0 * sp_y, py + (size_t)rt.ty.i1 * sp_y};
+      const uint8_t* crow[2] = {puv + (size_t)rt.tcy.i0 * sp_uv, puv + (size_t)rt.tcy.i1 * sp_uv};
+      float c0[4], c1[4], c2[4];
+      sample(rt,
+             [&](int r, int p, int t) { return (u32)gload<T>(yrow[r] + (size_t)(t ? tx[p].i1 : tx[p].i0) * E); },
+             [&](int r, int p, int t, u32& u, u32& v) {
+               const uint8_t* q = crow[r] + (size_t)(t ? tcx[p].i1 : tcx[p].i0) * 2 * E;
+               u = (u32)gload<T>(q); v = (u32)gload<T>(q + E);
+             },
+             c0, c1, c2);
+      ud_store<T, OUT>(d, x0, y, n, c0, c1, c2);
+    }
+  };
+
   if constexpr (STAGED) {
+    const bool aligned = ((((uintptr_t)py) | ((uintptr_t)puv) | (uintptr_t)sp_y | (uintptr_t)sp_uv) & 15u) == 0;
+    if (!aligned) {
+      gather_rows();
+      return;
+    }
     // spans of this tile: first tap of lane 0 .. last tap of lane 63 (columns are monotonic)
     const UdSpan sp = ud_span_of(__builtin_amdgcn_readlane(tx[0].i0, 0), __builtin_amdgcn_readlane(tx[3].i1, 63),
                                  __builtin_amdgcn_readlane(tcx[0].i0, 0), __builtin_amdgcn_readlane(tcx[3].i1, 63), E);
-    const bool aligned = ((((uintptr_t)py) | ((uintptr_t)puv) | (uintptr_t)sp_y | (uintptr_t)sp_uv) & 15u) == 0;
     UdStage& st = stage[wave];
     const int off = lane * 16;
     const bool in_y = off < sp.yn, in_c = off < sp.cn;
+    // Loads are unconditional and straight-line (lanes past a span re-read its last 16 bytes),
+    // so the compiler counts vmcnt instead of draining at branches.
+    const int off_y = min(off, sp.yn - 16), off_c = min(off, sp.cn - 16);
     uint4 pf[4]; // prefetch registers: this lane's 16 bytes of luma0, luma1, chroma0, chroma1
-    auto fetch = [&](const uint8_t* src) {
-      if (aligned)
-        return gload16(src);
-      u32 w[4] = {0, 0, 0, 0}; // foreign, unaligned memory: byte loads (rare, slow, still correct)
-      for (int bb = 0; bb < 16; ++bb) w[bb >> 2] |= (u32)gload<uint8_t>(src + bb) << (8 * (bb & 3));
-      return make_uint4(w[0], w[1], w[2], w[3]);
-    };
     auto issue = [&](const RowTaps& rt) {
       // scalar address arithmetic; a plane is < 4 GiB, so 32-bit row offsets (s_mul_i32)
       const uint8_t* y0 = py + (u32)(rt.ty.i0 * sp_y + sp.yb);
       const uint8_t* y1 = py + (u32)(rt.ty.i1 * sp_y + sp.yb);
       const uint8_t* q0 = puv + (u32)(rt.tcy.i0 * sp_uv + sp.cb);
       const uint8_t* q1 = puv + (u32)(rt.tcy.i1 * sp_uv + sp.cb);
-      if (in_y) { pf[0] = fetch(y0 + off); pf[1] = fetch(y1 + off); }
-      if (in_c) { pf[2] = fetch(q0 + off); pf[3] = fetch(q1 + off); }
+      pf[0] = gload16(y0 + off_y); pf[1] = gload16(y1 + off_y);
+      pf[2] = gload16(q0 + off_c); pf[3] = gload16(q1 + off_c);
     };
     auto commit = [&]() {
       if (in_y) {
@@ -415,26 +440,7 @@ __global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
       cur = nxt;
     }
   } else {
-    if (n <= 0)
-      return;
-#pragma unroll 1
-    for (int rr = 0; rr < kUdRowsPerWave; ++rr) {
-      const int y = y_first + rr;
-      if (y >= dh)
-        break;
-      const RowTaps rt = row_taps(rr);
-      const uint8_t* yrow[2] = {py + (size_t)rt.ty.i0 * sp_y, py + (size_t)rt.ty.i1 * sp_y};
-      const uint8_t* crow[2] = {puv + (size_t)rt.tcy.i0 * sp_uv, puv + (size_t)rt.tcy.i1 * sp_uv};
-      float c0[4], c1[4], c2[4];
-      sample(rt,
-             [&](int r, int p, int t) { return (u32)gload<T>(yrow[r] + (size_t)(t ? tx[p].i1 : tx[p].i0) * E); },
-             [&](int r, int p, int t, u32& u, u32& v) {
-               const uint8_t* q = crow[r] + (size_t)(t ? tcx[p].i1 : tcx[p].i0) * 2 * E;
-               u = (u32)gload<T>(q); v = (u32)gload<T>(q + E);
-             },
-             c0, c1, c2);
-      ud_store<T, OUT>(d, x0, y, n, c0, c1, c2);
-    }
+    gather_rows();
   }
 }
 
