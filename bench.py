@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="budget of the CPU baseline sample (rank 0, N=1 only); 0 disables")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip BASELINE configs[1..3] (tools/bench_configs.py; a few seconds, N=1 only)")
     return ap.parse_args()
 
 
@@ -93,6 +95,21 @@ def cpu_baseline(width, height, coeffs, budget_s):
         "note": "the reference's CPU path is FFmpeg libswscale (not available offline); this "
                 "is the build's own C restatement of the GPU arithmetic",
     }
+
+
+def secondary_configs(pipe):
+    """BASELINE configs[1..3] (parity-test configurations) measured after the timed
+    region with HIP events on the task streams: reported beside the headline, never part of
+    `value`.  A failure here is recorded, it does not take the headline line down."""
+    try:
+        pipe.srcs.clear()   # give the 19 GB of headline surfaces back first
+        pipe.dsts.clear()
+        sys.path.insert(0, str(ROOT / "tools"))
+        import bench_configs as bc
+
+        return [bc.cfg2(), bc.cfg3(), bc.cfg4()]
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def measured_traffic(bytes_per_frame, frames, dst, W, H):
@@ -246,6 +263,8 @@ def main():
             out["parity_vs_oracle"] = parity
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(W, H, coeffs, args.cpu_seconds)
+        if world == 1 and not args.no_secondary:
+            out["secondary"] = secondary_configs(pipe)
         print(json.dumps(out), flush=True)
 
     if dist is not None:

@@ -86,13 +86,15 @@ def cfg3(n=64):
     batch = rs.PrepareBatch(srcs, dsts)
     ms, wall = timed(rs.Stream, lambda: rs.RunBatchAsync(batch), 50)
     b = 13824000
-    touched = 720 * 3840 * 2 // 1 // 1  # informational: see note
+    touched = 720 * 3840 + 360 * 3840 + 1382400  # one source row per dst row (weight of the 2nd is 0) + dst
     return {"config": f"cfg3 PySurfaceResizer NV12 3840x2160->1280x720 bilinear, batch={n}, one launch",
             "ms_per_batch": round(ms, 4), "us_per_frame": round(ms * 1e3 / n, 3), "frames_per_s": round(n / (ms * 1e-3), 1),
             "GBps_judge_bytes(13.824MB/frame)": round(b * n / (ms * 1e-3) / 1e9, 1),
-            "frac_of_8TBps": round(b * n / (ms * 1e-3) / 1e9 / PEAK, 4),
-            "note": "exact 3x: the NPP grid samples src[3y][3x] (weights 1,0); only every third source row/column "
-                    "is touched, so HBM fetch is below the judge figure"}
+            "frac_of_8TBps_judge_bytes": round(b * n / (ms * 1e-3) / 1e9 / PEAK, 4),
+            "GBps_touched_bytes(5.5296MB/frame)": round(touched * n / (ms * 1e-3) / 1e9, 1),
+            "frac_of_8TBps_touched_bytes": round(touched * n / (ms * 1e-3) / 1e9 / PEAK, 4),
+            "note": "exact 3x: the NPP grid samples src[3y][3x] (weights 1,0); rows with vertical weight 0 are not "
+                    "fetched, so real HBM traffic is the touched-bytes figure, below the judge's 13.824 MB"}
 
 
 def cfg4(n=64):
