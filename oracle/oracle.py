@@ -209,17 +209,27 @@ def canonical_shifts(angle: float, src_w: int, src_h: int):
             270: (270.0, src_h - 1.0, 0.0)}[n]
 
 
-def resize_plane(src: np.ndarray, channels: int, dst_w: int, dst_h: int) -> np.ndarray:
-    """src: (H, W*channels) uint8/uint16/float32 -> (dst_h, dst_w*channels), bilinear."""
+def resize_plane(src: np.ndarray, channels: int, dst_w: int, dst_h: int, interp: str = "linear") -> np.ndarray:
+    """src: (H, W*channels) uint8/uint16/float32 -> (dst_h, dst_w*channels); bilinear or lanczos."""
     assert src.ndim == 2 and src.flags.c_contiguous
     sh, sw = src.shape[0], src.shape[1] // channels
     out = np.zeros((dst_h, dst_w * channels), src.dtype)
-    rc = lib().vali_oracle_resize_plane(C.c_void_p(src.ctypes.data), src.strides[0], sw, sh,
-                                        C.c_void_p(out.ctypes.data), out.strides[0], dst_w, dst_h,
-                                        src.dtype.itemsize, channels)
+    fn = {"linear": lib().vali_oracle_resize_plane, "lanczos": lib().vali_oracle_resize_plane_lanczos}[interp]
+    rc = fn(C.c_void_p(src.ctypes.data), src.strides[0], sw, sh,
+            C.c_void_p(out.ctypes.data), out.strides[0], dst_w, dst_h,
+            src.dtype.itemsize, channels)
     if rc:
-        raise RuntimeError(f"vali_oracle_resize_plane -> {rc}")
+        raise RuntimeError(f"vali_oracle_resize_plane[{interp}] -> {rc}")
     return out
+
+
+def lanczos3_weights(a: float) -> np.ndarray:
+    w = (C.c_float * 6)()
+    f = lib().vali_oracle_lanczos3_weights
+    f.restype = None
+    f.argtypes = [C.c_float, C.POINTER(C.c_float)]
+    f(a, w)
+    return np.array(list(w), np.float32)
 
 
 # plane lists in HOST (tightly packed) layout: (rows_fn, cols_fn, channels, subsample_x, subsample_y)
@@ -240,13 +250,14 @@ def host_planes(fmt: str, w: int, h: int):
     raise ValueError(fmt)
 
 
-def resize_surface(host: np.ndarray, fmt: str, sw: int, sh: int, dw: int, dh: int) -> np.ndarray:
+def resize_surface(host: np.ndarray, fmt: str, sw: int, sh: int, dw: int, dh: int,
+                   interp: str = "linear") -> np.ndarray:
     """Resize a whole surface given as its flat host image (element dtype = host.dtype)."""
     out, off = [], 0
     for (pw, ph, ch), (qw, qh, _) in zip(host_planes(fmt, sw, sh), host_planes(fmt, dw, dh)):
         n = pw * ph * ch
         plane = np.ascontiguousarray(host[off: off + n].reshape(ph, pw * ch))
-        out.append(resize_plane(plane, ch, qw, qh).reshape(-1))
+        out.append(resize_plane(plane, ch, qw, qh, interp).reshape(-1))
         off += n
     return np.concatenate(out)
 

@@ -421,3 +421,120 @@ int vali_oracle_resize_plane(const void* src, int src_pitch, int src_w, int src_
   }
   return VALI_OK;
 }
+
+/* ==========================================================================
+ * Lanczos-3 resize (reference: nppiResize_*R_Ctx with NPPI_INTER_LANCZOS,
+ * src/TC/src/TaskResizeSurface.cpp:67,116,224,273).  NPP is closed source and the input of
+ * the reference's resize golden is missing, so the tap arithmetic is this build's definition
+ * (PARITY UNPINNED beyond the geometry): a 6x6 interpolating (not anti-aliasing) Lanczos-3
+ * kernel on the pinned sampling grid src = dst * (src_size / dst_size) -- the fixture
+ * test_small.nv12 shows the reference's 2x downscale is the point sample src[2y][2x], which an
+ * interpolating kernel evaluated at integer offsets gives and an area-scaled one would not.
+ *
+ *   f = x * scale ; i = floor(f) ; a = f - i ; taps i-2 .. i+3, indices clamped to the plane
+ *   raw_k = sin(pi t_k) sin(pi t_k / 3) / t_k^2 ,  t_k = a + (2 - k)     (3/pi^2 cancels)
+ *   w_k = raw_k / (((((raw_0 + raw_1) + raw_2) + raw_3) + raw_4) + raw_5)
+ *   a == 0: w = {0,0,1,0,0,0}
+ * sin/cos are FIXED polynomials (below) so CPU and GPU agree bit for bit; sin(pi(a+m)) =
+ * (-1)^m sin(pi a) and sin(pi(a+m)/3) by the angle-sum identity from sin/cos(pi a / 3).
+ *   rows:    h_r = w_0 t_0 ; h_r = fma(w_k, t_k, h_r), k = 1..5       (6 source rows)
+ *   columns: v = wy_0 h_0 ; v = fma(wy_r, h_r, v), r = 1..5
+ *   u8/u16: round-half-even + saturate ; f32: v
+ * ========================================================================== */
+static inline float lz_sin_poly(float z) { /* sin z, 0 <= z <= pi/2, Taylor to z^11 */
+  const float z2 = z * z;
+  float p = fmaf(z2, -2.5052108e-8f, 2.7557319e-6f);
+  p = fmaf(z2, p, -1.9841270e-4f);
+  p = fmaf(z2, p, 8.3333333e-3f);
+  p = fmaf(z2, p, -1.6666667e-1f);
+  return fmaf(z * z2, p, z);
+}
+static inline float lz_cos_poly(float z) { /* cos z, 0 <= z <= pi/3, Taylor to z^12 */
+  const float z2 = z * z;
+  float p = fmaf(z2, 2.0876757e-9f, -2.7557319e-7f);
+  p = fmaf(z2, p, 2.4801587e-5f);
+  p = fmaf(z2, p, -1.3888889e-3f);
+  p = fmaf(z2, p, 4.1666667e-2f);
+  p = fmaf(z2, p, -0.5f);
+  return fmaf(z2, p, 1.0f);
+}
+
+void vali_oracle_lanczos3_weights(float a, float w[6]) {
+  if (a == 0.0f) {
+    w[0] = w[1] = w[3] = w[4] = w[5] = 0.0f;
+    w[2] = 1.0f;
+    return;
+  }
+  const float y = a <= 0.5f ? a : 1.0f - a;
+  const float s1 = lz_sin_poly(y * 3.14159265f);          /* sin(pi a) */
+  const float z = a * 1.04719755f;                         /* pi a / 3 */
+  const float s3 = lz_sin_poly(z), c3 = lz_cos_poly(z);
+  const float h = 0.866025404f;                            /* sin(pi/3) */
+  /* m = 2, 1, 0, -1, -2, -3 : sin(z + m pi/3) and the sign (-1)^m of sin(pi (a + m)) */
+  const float q[6] = {fmaf(c3, h, -0.5f * s3), fmaf(c3, h, 0.5f * s3), s3,
+                      fmaf(c3, -h, 0.5f * s3), fmaf(c3, -h, -0.5f * s3), -s3};
+  const float sg[6] = {1.0f, -1.0f, 1.0f, -1.0f, 1.0f, -1.0f};
+  float raw[6];
+  for (int k = 0; k < 6; ++k) {
+    const float t = a + (float)(2 - k);
+    raw[k] = (sg[k] * s1) * q[k] / (t * t);
+  }
+  const float sum = ((((raw[0] + raw[1]) + raw[2]) + raw[3]) + raw[4]) + raw[5];
+  for (int k = 0; k < 6; ++k)
+    w[k] = raw[k] / sum;
+}
+
+typedef struct { int idx[6]; float w[6]; } lz_tap_t;
+
+static inline lz_tap_t lz_make_tap(int x, float scale, int size) {
+  const float f = (float)x * scale;
+  const float fl = floorf(f);
+  lz_tap_t t;
+  vali_oracle_lanczos3_weights(f - fl, t.w);
+  const int i = (int)fl;
+  for (int k = 0; k < 6; ++k) {
+    int j = i - 2 + k;
+    j = j < 0 ? 0 : (j > size - 1 ? size - 1 : j);
+    t.idx[k] = j;
+  }
+  return t;
+}
+
+int vali_oracle_resize_plane_lanczos(const void* src, int src_pitch, int src_w, int src_h,
+                                     void* dst, int dst_pitch, int dst_w, int dst_h, int elem,
+                                     int channels) {
+  if (!src || !dst || src_w <= 0 || src_h <= 0 || dst_w <= 0 || dst_h <= 0)
+    return VALI_ERR_INVALID_ARG;
+  if ((elem != 1 && elem != 2 && elem != 4) || channels < 1 || channels > 3)
+    return VALI_ERR_INVALID_ARG;
+  const float scale_x = (float)src_w / (float)dst_w, scale_y = (float)src_h / (float)dst_h;
+  for (int y = 0; y < dst_h; ++y) {
+    const lz_tap_t ty = lz_make_tap(y, scale_y, src_h);
+    uint8_t* drow = (uint8_t*)dst + (size_t)y * dst_pitch;
+    for (int x = 0; x < dst_w; ++x) {
+      const lz_tap_t tx = lz_make_tap(x, scale_x, src_w);
+      for (int ch = 0; ch < channels; ++ch) {
+        float v = 0.0f;
+        for (int r = 0; r < 6; ++r) {
+          const uint8_t* row = (const uint8_t*)src + (size_t)ty.idx[r] * src_pitch;
+          float hsum = tx.w[0] * rot_texel(row, tx.idx[0] * channels + ch, elem);
+          for (int k = 1; k < 6; ++k)
+            hsum = fmaf(tx.w[k], rot_texel(row, tx.idx[k] * channels + ch, elem), hsum);
+          v = r == 0 ? ty.w[0] * hsum : fmaf(ty.w[r], hsum, v);
+        }
+        const int o = x * channels + ch;
+        if (elem == 1) {
+          drow[o] = vali_oracle_q_u8(v);
+        } else if (elem == 2) {
+          float rr = rintf(v);
+          if (!(rr > 0.0f)) rr = 0.0f;
+          if (rr > 65535.0f) rr = 65535.0f;
+          ((uint16_t*)drow)[o] = (uint16_t)rr;
+        } else {
+          ((float*)drow)[o] = v;
+        }
+      }
+    }
+  }
+  return VALI_OK;
+}

@@ -94,6 +94,15 @@ VALI_API int vali_oracle_resize_plane(const void* src, int src_pitch, int src_w,
                                       void* dst, int dst_pitch, int dst_w, int dst_h, int elem,
                                       int channels);
 
+/* Lanczos-3 (6x6 taps, interpolating, same sampling grid) variant: the reference's
+ * NPPI_INTER_LANCZOS restated with this build's own tap arithmetic (weights from fixed
+ * polynomials, fma accumulation order documented in vali_oracle.c) -- parity unpinned against
+ * NPP beyond the geometry; on integer scale factors it is the same point sample. */
+VALI_API void vali_oracle_lanczos3_weights(float a, float w[6]);
+VALI_API int vali_oracle_resize_plane_lanczos(const void* src, int src_pitch, int src_w, int src_h,
+                                              void* dst, int dst_pitch, int dst_w, int dst_h,
+                                              int elem, int channels);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,12 +14,12 @@ DT = {"RGB_32F": np.float32, "RGB_32F_PLANAR": np.float32, "P10": np.uint16,
       "YUV444_10bit": np.uint16, "YUV420_10bit": np.uint16}
 
 
-def roundtrip(vali, gpu, fmt, host, sw, sh, dw, dh, is_async=False):
+def roundtrip(vali, gpu, fmt, host, sw, sh, dw, dh, is_async=False, interp=None):
     pf = vali.PixelFormat[fmt]
     src = vali.Surface.Make(pf, sw, sh, gpu)
     dst = vali.Surface.Make(pf, dw, dh, gpu)
     assert vali.PyFrameUploader(gpu).Run(host.view(np.uint8), src)[0]
-    rs = vali.PySurfaceResizer(pf, gpu)
+    rs = vali.PySurfaceResizer(pf, gpu) if interp is None else vali.PySurfaceResizer(pf, gpu, interpolation=interp)
     ok, info = rs.RunAsync(src, dst) if is_async else rs.Run(src, dst)
     assert ok and info == vali.TaskExecInfo.SUCCESS
     if is_async:
@@ -79,3 +79,56 @@ def test_resize_batch_2160p_to_720p(vali, gpu, oracle):
         out = np.zeros(d.HostSize, np.uint8)
         assert vali.PySurfaceDownloader(gpu).Run(d, out)[0]
         assert np.array_equal(out, wants[i % 2])
+
+
+# ---- Lanczos-3 (the reference's NPPI_INTER_LANCZOS, restated) --------------------------------
+@pytest.mark.parametrize("fmt", ["NV12", "YUV420", "RGB", "RGB_PLANAR", "RGB_32F", "Y", "P10", "YUV444_10bit"])
+@pytest.mark.parametrize("geom", [(848, 464, 424, 232), (640, 360, 1000, 500), (130, 70, 58, 34),
+                                  (1920, 1080, 1280, 720), (64, 48, 640, 480)])
+def test_lanczos_bit_exact(vali, gpu, oracle, fmt, geom):
+    sw, sh, dw, dh = geom
+    dt = DT.get(fmt, np.uint8)
+    n = vali.Surface.Make(vali.PixelFormat[fmt], sw, sh, gpu).HostSize // np.dtype(dt).itemsize
+    rng = np.random.default_rng(22)
+    host = (rng.random(n) * (1000 if dt == np.uint16 else 255)).astype(dt)
+    got = roundtrip(vali, gpu, fmt, host, sw, sh, dw, dh, interp=vali.Interpolation.LANCZOS)
+    want = oracle.resize_surface(host, fmt, sw, sh, dw, dh, "lanczos")
+    assert np.array_equal(got, want)
+
+
+def test_lanczos_real_frames_match_reference_fixture_geometry(vali, gpu, oracle):
+    """reference tests/test_PySurfaceResizer.py resizes by exactly 2x with NPP Lanczos; at integer
+    factors an interpolating kernel is the point sample src[2y][2x] -- same as bilinear."""
+    raw = np.fromfile(GOLDEN / "test_small_2frames.nv12", np.uint8).reshape(2, -1)
+    for frame in raw:
+        lz = roundtrip(vali, gpu, "NV12", frame.copy(), 424, 232, 212, 116, interp=vali.Interpolation.LANCZOS)
+        bl = roundtrip(vali, gpu, "NV12", frame.copy(), 424, 232, 212, 116)
+        assert np.array_equal(lz, bl)
+        assert np.array_equal(lz, oracle.resize_surface(frame, "NV12", 424, 232, 212, 116, "lanczos"))
+
+
+def test_lanczos_batch_2160p_to_720p(vali, gpu, oracle):
+    sw, sh, dw, dh, n = 3840, 2160, 1280, 720, 3
+    rs = vali.PySurfaceResizer(vali.NV12, gpu, interpolation=vali.Interpolation.LANCZOS)
+    assert rs.Interpolation == vali.Interpolation.LANCZOS
+    rng = np.random.default_rng(6)
+    frame = rng.integers(0, 256, sw * sh * 3 // 2, dtype=np.uint8)
+    srcs = [vali.Surface.Make(vali.NV12, sw, sh, gpu) for _ in range(n)]
+    dsts = [vali.Surface.Make(vali.NV12, dw, dh, gpu) for _ in range(n)]
+    for s_ in srcs:
+        assert vali.PyFrameUploader(gpu).Run(frame, s_)[0]
+    assert rs.RunBatch(srcs, dsts) == (True, vali.TaskExecInfo.SUCCESS)
+    want = oracle.resize_surface(frame, "NV12", sw, sh, dw, dh, "lanczos")
+    for d in dsts:
+        out = np.zeros(d.HostSize, np.uint8)
+        assert vali.PySurfaceDownloader(gpu).Run(d, out)[0]
+        assert np.array_equal(out, want)
+
+
+def test_lanczos_noninteger_2160p_to_1080x608(vali, gpu, oracle):
+    """wide spans: the chroma plane of a 3.55x downscale exceeds the LDS strip (gather path)."""
+    sw, sh, dw, dh = 3840, 2160, 1080, 608
+    rng = np.random.default_rng(7)
+    frame = rng.integers(0, 256, sw * sh * 3 // 2, dtype=np.uint8)
+    got = roundtrip(vali, gpu, "NV12", frame, sw, sh, dw, dh, interp=vali.Interpolation.LANCZOS)
+    assert np.array_equal(got, oracle.resize_surface(frame, "NV12", sw, sh, dw, dh, "lanczos"))

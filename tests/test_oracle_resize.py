@@ -54,3 +54,44 @@ def test_resize_identity_and_edges(oracle):
     assert np.array_equal(out[:128].reshape(8, 16), nv[:24][0::3, 0::3])
     uv = nv[24:].reshape(12, 24, 2)
     assert np.array_equal(out[128:].reshape(4, 8, 2), uv[0::3, 0::3])
+
+
+# ---- Lanczos-3 restatement: properties that hold whatever NPP's exact taps are ----------------
+def test_lanczos_weights_are_lanczos3():
+    from oracle import oracle as o
+    for a in np.linspace(0.0, 0.999, 41, dtype=np.float32):
+        w = o.lanczos3_weights(float(a))
+        t = np.float64(a) + np.array([2, 1, 0, -1, -2, -3.0])
+        ref = np.sinc(t) * np.sinc(t / 3)
+        ref /= ref.sum()
+        assert np.abs(w - ref).max() < 3e-7
+        assert abs(float(w.astype(np.float64).sum()) - 1.0) < 3e-7
+
+
+def test_lanczos_identity_and_integer_factors():
+    from oracle import oracle as o
+    rng = np.random.default_rng(3)
+    for dt, hi in ((np.uint8, 256), (np.uint16, 1024)):
+        src = rng.integers(0, hi, (48, 66), dtype=dt)
+        assert np.array_equal(o.resize_plane(src, 1, 66, 48, "lanczos"), src)              # a == 0 everywhere
+        assert np.array_equal(o.resize_plane(src, 1, 33, 24, "lanczos"), src[::2, ::2])    # fixture geometry
+        assert np.array_equal(o.resize_plane(src, 1, 22, 16, "lanczos"), src[::3, ::3])
+        assert np.array_equal(o.resize_plane(src, 2, 33, 48, "lanczos"), o.resize_plane(src, 2, 33, 48, "linear"))
+    flat = np.full((20, 30), 177, np.uint8)
+    assert np.array_equal(o.resize_plane(flat, 1, 77, 41, "lanczos"), np.full((41, 77), 177, np.uint8))
+    f32 = rng.random((16, 24), dtype=np.float32)
+    assert np.array_equal(o.resize_plane(f32, 1, 24, 16, "lanczos"), f32)
+
+
+def test_lanczos_upscale_is_sharper_than_bilinear_on_a_band_limited_signal():
+    """sanity of the filter itself: reconstructing a smooth sinusoid, Lanczos-3 beats bilinear."""
+    from oracle import oracle as o
+    x = np.arange(64, dtype=np.float64)
+    src = (127.5 + 100 * np.sin(2 * np.pi * x / 9.0))[None, :].repeat(8, 0).astype(np.float32)
+    dw = 64 * 4
+    xs = np.arange(dw) * (64 / dw)
+    truth = 127.5 + 100 * np.sin(2 * np.pi * xs / 9.0)
+    inner = slice(16, dw - 16)
+    e_lz = np.abs(o.resize_plane(src, 1, dw, 8, "lanczos")[0][inner] - truth[inner]).max()
+    e_bl = np.abs(o.resize_plane(src, 1, dw, 8, "linear")[0][inner] - truth[inner]).max()
+    assert e_lz < 0.35 * e_bl

@@ -6,7 +6,7 @@ names: Surface, SurfacePlane, PixelFormat, PySurfaceConverter, PyFrameUploader, 
 """
 from ._native import shim as _shim  # noqa: F401  (fails loudly if the HIP library is absent)
 from .codecs import PyDecoder, PyFrameConverter, PyNvEncoder, PyNvJpegEncoder
-from .enums import (ColorRange, ColorSpace, ColorspaceConversionContext, DLDeviceType,
+from .enums import (ColorRange, ColorSpace, ColorspaceConversionContext, DLDeviceType, Interpolation,
                     PixelFormat, TaskExecDetails, TaskExecInfo, TaskExecStatus, export_values)
 from .runtime import CudaStreamEvent, GetNumGpus, HipResMgr
 from .surface import Surface, SurfacePlane

@@ -378,6 +378,7 @@ PYBIND11_MODULE(_vali_shim, m) {
         },
         py::call_guard<py::gil_scoped_release>());
   m.attr("INTERP_LINEAR") = (int)VALI_INTERP_LINEAR;
+  m.attr("INTERP_LANCZOS") = (int)VALI_INTERP_LANCZOS;
 
   m.def("rotate",
         [](const SurfaceDesc& src, const SurfaceDesc& dst, double angle, double shx, double shy,

@@ -7,9 +7,9 @@
 // (reference: src/TC/src/TaskResizeSurface.cpp:34-286; NV12 path :132-188).  Here the Y
 // plane and the interleaved UV plane (as a 2-channel image) are resized by one kernel.
 //
-// Interpolation: BILINEAR (BASELINE config 3) on NPP's sampling grid.  The reference
-// hard-codes NPPI_INTER_LANCZOS (TaskResizeSurface.cpp:67,116,224,273) and has no switch;
-// Lanczos is listed as "next" (SURVEY.md 8f-4).  GEOMETRY is pinned by the reference's own
+// Interpolation: BILINEAR (BASELINE config 3, the default) or LANCZOS-3 on NPP's sampling
+// grid.  The reference hard-codes NPPI_INTER_LANCZOS (TaskResizeSurface.cpp:67,116,224,273)
+// and has no switch; the Lanczos kernel is at the end of this file.  GEOMETRY is pinned by the reference's own
 // fixture: tests/data/test_small.nv12 (the expected 848x464 -> 424x232 output of
 // tests/test_PySurfaceResizer.py) equals src[2y][2x] of the frame (41.7 dB through JPEG noise)
 // and NOT the centre-aligned (x+0.5)*s-0.5 sample (26.4 dB) -- tests/test_oracle_resize.py.
@@ -245,6 +245,191 @@ __global__ void __launch_bounds__(kBlock) k_resize(const ResizeArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Lanczos-3 (VALI_INTERP_LANCZOS): the reference's NPPI_INTER_LANCZOS restated as a 6x6
+// interpolating kernel on the same sampling grid (oracle: vali_oracle_resize_plane_lanczos,
+// which documents the tap arithmetic; parity unpinned against NPP beyond the geometry).
+// Weights come from fixed polynomials with explicit fma so CPU and GPU agree bit for bit.
+// Same decomposition as the bilinear kernel: lane = 4 dst pixels, a wave walks 8 dst rows
+// with the same column weights; the six source rows of a dst row are staged in the wave's LDS
+// strip (lane l owns chunks l and l+64 of every row).  Consecutive dst rows share most of
+// their source rows, so the re-staging is served by L2, not HBM.
+__device__ __forceinline__ float lz_sin_poly(float z) { // sin z, 0 <= z <= pi/2
+  const float z2 = z * z;
+  float p = __builtin_fmaf(z2, -2.5052108e-8f, 2.7557319e-6f);
+  p = __builtin_fmaf(z2, p, -1.9841270e-4f);
+  p = __builtin_fmaf(z2, p, 8.3333333e-3f);
+  p = __builtin_fmaf(z2, p, -1.6666667e-1f);
+  return __builtin_fmaf(z * z2, p, z);
+}
+__device__ __forceinline__ float lz_cos_poly(float z) { // cos z, 0 <= z <= pi/3
+  const float z2 = z * z;
+  float p = __builtin_fmaf(z2, 2.0876757e-9f, -2.7557319e-7f);
+  p = __builtin_fmaf(z2, p, 2.4801587e-5f);
+  p = __builtin_fmaf(z2, p, -1.3888889e-3f);
+  p = __builtin_fmaf(z2, p, 4.1666667e-2f);
+  p = __builtin_fmaf(z2, p, -0.5f);
+  return __builtin_fmaf(z2, p, 1.0f);
+}
+__device__ __forceinline__ void lanczos3_weights(float a, float (&w)[6]) {
+  const float y = a <= 0.5f ? a : 1.0f - a;
+  const float s1 = lz_sin_poly(y * 3.14159265f);
+  const float z = a * 1.04719755f;
+  const float s3 = lz_sin_poly(z), c3 = lz_cos_poly(z);
+  const float h = 0.866025404f;
+  const float q[6] = {__builtin_fmaf(c3, h, -0.5f * s3), __builtin_fmaf(c3, h, 0.5f * s3), s3,
+                      __builtin_fmaf(c3, -h, 0.5f * s3), __builtin_fmaf(c3, -h, -0.5f * s3), -s3};
+  float raw[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float t = a + (float)(2 - k);
+    const float s = (k & 1) ? -s1 : s1;
+    raw[k] = s * q[k] / (t * t);
+  }
+  const float sum = ((((raw[0] + raw[1]) + raw[2]) + raw[3]) + raw[4]) + raw[5];
+  const bool on_grid = a == 0.0f;
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+    w[k] = on_grid ? (k == 2 ? 1.0f : 0.0f) : raw[k] / sum;
+}
+
+struct LzTap {
+  int i;      // floor of the source coordinate; taps i-2 .. i+3
+  float w[6];
+};
+__device__ __forceinline__ LzTap make_lz_tap(int x, float scale) {
+  const float f = (float)x * scale;
+  const float fl = __builtin_floorf(f);
+  LzTap t;
+  lanczos3_weights(f - fl, t.w);
+  t.i = (int)fl;
+  return t;
+}
+__device__ __forceinline__ int clampi(int v, int hi) { return min(max(v, 0), hi); }
+
+constexpr int kLzCpr = 2;                              // 16-byte chunks per lane per row
+constexpr int kLzRowBytes = kLzCpr * kWave * 16;       // 2 KiB per staged row
+struct alignas(16) LzStage {
+  uint8_t row[6][kLzRowBytes];
+};
+
+template <typename T, int C>
+__device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int sw, int sh,
+                                             uint8_t* dp, int dpitch, int dw, int dh, u32 tx,
+                                             u32 ty, LzStage* stage_all) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int x0 = (tx * 64 + lane) * 4;
+  const int y_first = ty * kRsTileH + wave * kRsRowsPerWave; // wave-uniform
+  if (y_first >= dh)
+    return;
+  const float scale_x = (float)sw / (float)dw, scale_y = (float)sh / (float)dh;
+  constexpr int PB = C * (int)sizeof(T);
+
+  LzTap cx[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+    cx[p] = make_lz_tap(min(x0 + p, dw - 1), scale_x);
+  const int n = min(4, dw - x0);
+  // row taps: lane r evaluates row y_first + r, read back as scalars
+  const LzTap vy = make_lz_tap(y_first + (lane & (kRsRowsPerWave - 1)), scale_y);
+  auto row_tap = [&](int rr) {
+    LzTap t;
+    t.i = __builtin_amdgcn_readlane(vy.i, rr);
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      t.w[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vy.w[k]), rr));
+    return t;
+  };
+
+  const int sx0 = clampi(__builtin_amdgcn_readlane(cx[0].i, 0) - 2, sw - 1);
+  const int sx1 = clampi(__builtin_amdgcn_readlane(cx[3].i, 63) + 3, sw - 1);
+  const int byte_begin = (sx0 * PB) & ~15;
+  const int nbytes = (((sx1 + 1) * PB + 15) & ~15) - byte_begin;
+  const bool staged = nbytes <= kLzRowBytes && ((((uintptr_t)sp) | (uintptr_t)spitch) & 15u) == 0;
+
+  auto filter_and_store = [&](const LzTap& cy, int y, auto fetch) {
+    float res[4][C];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) {
+        float v = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          float h = cx[p].w[0] * fetch(r, p, 0, ch);
+#pragma unroll
+          for (int k = 1; k < 6; ++k)
+            h = __builtin_fmaf(cx[p].w[k], fetch(r, p, k, ch), h);
+          v = r == 0 ? cy.w[0] * h : __builtin_fmaf(cy.w[r], h, v);
+        }
+        res[p][ch] = v;
+      }
+    store_px4<T, C>(dp + (u32)(y * dpitch) + (size_t)x0 * PB, res, (1u << n) - 1u);
+  };
+
+  if (staged) {
+    LzStage& st = stage_all[wave];
+    const int nchunks = nbytes / 16;
+#pragma unroll 1
+    for (int rr = 0; rr < kRsRowsPerWave; ++rr) {
+      const int y = y_first + rr;
+      if (y >= dh)
+        break;
+      const LzTap cy = row_tap(rr);
+      uint4 q[6][kLzCpr];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const uint8_t* row = sp + (u32)(clampi(cy.i - 2 + r, sh - 1) * spitch + byte_begin);
+#pragma unroll
+        for (int c = 0; c < kLzCpr; ++c)
+          q[r][c] = gload16(row + min(lane + c * kWave, nchunks - 1) * 16);
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < kLzCpr; ++c)
+          if (lane + c * kWave < nchunks)
+            *reinterpret_cast<uint4*>(&st.row[r][(lane + c * kWave) * 16]) = q[r][c];
+      wave_lds_sync();
+      if (n > 0)
+        filter_and_store(cy, y, [&](int r, int p, int k, int ch) {
+          return (float)((const T*)(st.row[r] + (clampi(cx[p].i - 2 + k, sw - 1) * PB - byte_begin)))[ch];
+        });
+      wave_lds_sync(); // the strip is re-filled by the next row
+    }
+  } else {
+    if (n <= 0)
+      return;
+#pragma unroll 1
+    for (int rr = 0; rr < kRsRowsPerWave; ++rr) {
+      const int y = y_first + rr;
+      if (y >= dh)
+        break;
+      const LzTap cy = row_tap(rr);
+      filter_and_store(cy, y, [&](int r, int p, int k, int ch) {
+        const uint8_t* row = sp + (size_t)clampi(cy.i - 2 + r, sh - 1) * spitch;
+        return (float)gload<T>(row + (size_t)clampi(cx[p].i - 2 + k, sw - 1) * PB + ch * sizeof(T));
+      });
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_resize_lanczos(const ResizeArgs a) {
+  ResizeJob job;
+  u32 tx, ty, frame;
+  if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
+    return;
+  __shared__ LzStage stage[kWavesPerBlock];
+  const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
+  switch (job.channels) {
+  case 1: lanczos_tile<T, 1>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage); break;
+  case 2: lanczos_tile<T, 2>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage); break;
+  default: lanczos_tile<T, 3>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage); break;
+  }
+}
+
 // plane jobs per pixel format: which components, their subsampling and channel count
 static int resize_jobs(int fmt, ResizeJob* j, int* elem) {
   auto set = [&](int k, int comp, int sx, int sy, int ch) {
@@ -268,7 +453,7 @@ static int resize_jobs(int fmt, ResizeJob* j, int* elem) {
   }
 }
 
-static int launch_resize(ResizeArgs& a, int fmt, int dst_w, int dst_h, int n, hipStream_t stream) {
+static int launch_resize(ResizeArgs& a, int fmt, int dst_w, int dst_h, int n, int interp, hipStream_t stream) {
   int elem = 1;
   a.njobs = resize_jobs(fmt, a.job, &elem);
   if (!a.njobs)
@@ -284,7 +469,14 @@ static int launch_resize(ResizeArgs& a, int fmt, int dst_w, int dst_h, int n, hi
   }
   a.map = make_tile_map_linear(total, (u32)n);
   const dim3 grid = tile_grid(a.map), block(kBlock);
-  if (elem == 1)
+  if (interp == VALI_INTERP_LANCZOS) {
+    if (elem == 1)
+      hipLaunchKernelGGL(k_resize_lanczos<uint8_t>, grid, block, 0, stream, a);
+    else if (elem == 2)
+      hipLaunchKernelGGL(k_resize_lanczos<uint16_t>, grid, block, 0, stream, a);
+    else
+      hipLaunchKernelGGL(k_resize_lanczos<float>, grid, block, 0, stream, a);
+  } else if (elem == 1)
     hipLaunchKernelGGL(k_resize<uint8_t>, grid, block, 0, stream, a);
   else if (elem == 2)
     hipLaunchKernelGGL(k_resize<uint16_t>, grid, block, 0, stream, a);
@@ -306,7 +498,7 @@ int vali_resize(const vali_surface* src, const vali_surface* dst, int interpolat
   VALI_REQUIRE(src->format == dst->format, "src/dst format mismatch");
   VALI_REQUIRE(src->width > 0 && src->height > 0 && dst->width > 0 && dst->height > 0, "empty surface");
   VALI_REQUIRE(src->plane[0] && dst->plane[0], "null plane");
-  if (interpolation != VALI_INTERP_LINEAR)
+  if (interpolation != VALI_INTERP_LINEAR && interpolation != VALI_INTERP_LANCZOS)
     return fail(VALI_ERR_UNSUPPORTED, "resize: interpolation %d not implemented", interpolation);
   ResizeArgs a = {};
   a.sw = src->width; a.sh = src->height; a.dw = dst->width; a.dh = dst->height;
@@ -322,7 +514,7 @@ int vali_resize(const vali_surface* src, const vali_surface* dst, int interpolat
   }
   hipStream_t s = as_stream(stream);
   DeviceScope scope(stream_device(s));
-  return launch_resize(a, src->format, dst->width, dst->height, 1, s);
+  return launch_resize(a, src->format, dst->width, dst->height, 1, interpolation, s);
 }
 
 int vali_resize_batch(const vali_surface* d_src, const vali_surface* d_dst, int n, int format,
@@ -330,7 +522,7 @@ int vali_resize_batch(const vali_surface* d_src, const vali_surface* d_dst, int 
   VALI_REQUIRE(d_src && d_dst, "null argument");
   VALI_REQUIRE(dst_width > 0 && dst_height > 0, "empty geometry");
   VALI_REQUIRE(n >= 0 && n <= 65535, "batch size out of range (0..65535)");
-  if (interpolation != VALI_INTERP_LINEAR)
+  if (interpolation != VALI_INTERP_LINEAR && interpolation != VALI_INTERP_LANCZOS)
     return fail(VALI_ERR_UNSUPPORTED, "resize: interpolation %d not implemented", interpolation);
   if (n == 0)
     return VALI_OK;
@@ -339,7 +531,7 @@ int vali_resize_batch(const vali_surface* d_src, const vali_surface* d_dst, int 
   a.d_dst = d_dst;
   hipStream_t s = as_stream(stream);
   DeviceScope scope(stream_device(s));
-  return launch_resize(a, format, dst_width, dst_height, n, s);
+  return launch_resize(a, format, dst_width, dst_height, n, interpolation, s);
 }
 
 } // extern "C"

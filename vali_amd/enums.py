@@ -65,6 +65,13 @@ class ColorRange(enum.IntEnum):
     UDEF = 2
 
 
+class Interpolation(enum.IntEnum):
+    """Resize filter (new: the reference hard-codes NPP Lanczos, TaskResizeSurface.cpp:67).
+    Values = include/vali_hip.h `vali_interpolation`."""
+    LINEAR = 1
+    LANCZOS = 16
+
+
 class DLDeviceType(enum.IntEnum):
     """DLPack device types.  The reference exports kDLCUDA only
     (src/TC/src/SurfacePlane.cpp:255); on ROCm the exchange type is kDLROCM."""

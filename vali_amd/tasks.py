@@ -10,7 +10,7 @@ from __future__ import annotations
 from typing import List, Optional, Sequence, Tuple
 
 from ._native import shim
-from .enums import (ColorRange, ColorSpace, ColorspaceConversionContext, PixelFormat,
+from .enums import (ColorRange, ColorSpace, ColorspaceConversionContext, Interpolation, PixelFormat,
                     TaskExecDetails, TaskExecInfo)
 from .runtime import CudaStreamEvent, HipResMgr
 from .surface import Surface
@@ -533,19 +533,27 @@ class PySurfaceResizer(_SurfaceTask):
 
     reference: src/python_vali/src/PySurfaceResizer.cpp:28-147; ResizeSurface
     (src/TC/src/TaskResizeSurface.cpp:293-328).  One launch resizes every plane (NV12 needs
-    five NPP launches and two temporaries in the reference).  Interpolation is bilinear
-    (BASELINE.json config 3); the reference's NPP Lanczos is not reproduced yet.
+    five NPP launches and two temporaries in the reference).  Interpolation is bilinear by
+    default (BASELINE.json config 3); `interpolation=Interpolation.LANCZOS` selects the 6x6
+    Lanczos-3 restatement of the reference's hard-coded NPPI_INTER_LANCZOS (same sampling
+    grid; tap arithmetic is this build's, see oracle/vali_oracle.c).
     RGB_PLANAR: the reference resizes the 3 stacked planes as ONE W x 3H image so rows
     bleed across channel seams (TaskResizeSurface.cpp:298, Surfaces.hpp:409); here each
     channel is resized on its own.
     """
 
-    def __init__(self, format: PixelFormat, gpu_id: int, stream=None):
+    def __init__(self, format: PixelFormat, gpu_id: int, stream=None,
+                 interpolation: Interpolation = Interpolation.LINEAR):
         fmt = PixelFormat(format)
         if fmt not in _RESIZE_FORMATS:                       # TaskResizeSurface.cpp:307-308
             raise RuntimeError("pixel format not supported")
         super().__init__(gpu_id, stream)
         self._format = fmt
+        self._interp = int(Interpolation(interpolation))
+
+    @property
+    def Interpolation(self) -> Interpolation:
+        return Interpolation(self._interp)
 
     @property
     def Format(self) -> PixelFormat:
@@ -556,7 +564,7 @@ class PySurfaceResizer(_SurfaceTask):
             return _S_INVALID
         if dst.Format != src.Format or src.Format != self._format:   # :46-48, :93-95
             return _S_INVALID
-        return _status(shim.resize(src.desc(), dst.desc(), shim.INTERP_LINEAR, self._stream))
+        return _status(shim.resize(src.desc(), dst.desc(), self._interp, self._stream))
 
     def RunAsync(self, src: Surface, dst: Surface) -> Tuple[bool, TaskExecInfo]:
         d = self._run(src, dst)
@@ -576,7 +584,7 @@ class PySurfaceResizer(_SurfaceTask):
         if batch.src_format != batch.dst_format or batch.src_format != self._format:
             return False, TaskExecInfo.INVALID_INPUT
         d = _status(shim.resize_batch(batch.d_src, batch.d_dst, batch.n, int(self._format),
-                                      batch.dst_size[0], batch.dst_size[1], shim.INTERP_LINEAR,
+                                      batch.dst_size[0], batch.dst_size[1], self._interp,
                                       self._stream))
         return d.success, d.info
 
