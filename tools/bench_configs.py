@@ -121,6 +121,25 @@ def cfg4(n=64):
             "frac_of_8TBps": round((b_ud + b_rot) * n / ((ms_ud + ms_rot) * 1e-3) / 1e9 / PEAK, 4)}
 
 
+def cfg3_lanczos(n=64):
+    """cfg3 geometries with the reference's own filter (Lanczos-3) -- exact 3x and a non-integer factor"""
+    out = []
+    for (sw, sh, dw, dh) in ((3840, 2160, 1280, 720), (3840, 2160, 1920, 1088), (1920, 1080, 3840, 2160)):
+        res = {}
+        for name, interp in (("linear", vali.Interpolation.LINEAR), ("lanczos", vali.Interpolation.LANCZOS)):
+            rs = vali.PySurfaceResizer(vali.NV12, DEV, interpolation=interp)
+            m = n if sw * sh <= 3840 * 2160 and dw * dh <= 1920 * 1088 else 16
+            srcs = [vali.Surface.Make(vali.NV12, sw, sh, DEV) for _ in range(m)]
+            dsts = [vali.Surface.Make(vali.NV12, dw, dh, DEV) for _ in range(m)]
+            fill(srcs)
+            batch = rs.PrepareBatch(srcs, dsts)
+            ms, _ = timed(rs.Stream, lambda: rs.RunBatchAsync(batch), 20)
+            b = (sw * sh + dw * dh) * 3 // 2
+            res[name] = {"us_per_frame": round(ms * 1e3 / m, 3), "GBps_src_plus_dst": round(b * m / (ms * 1e-3) / 1e9, 1)}
+        out.append({"geometry": f"NV12 {sw}x{sh}->{dw}x{dh}", **res})
+    return {"config": "resize filters", "results": out}
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["cfg2", "cfg3", "cfg4"]
     for name in which:

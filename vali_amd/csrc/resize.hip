@@ -230,7 +230,9 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
   }
 }
 
-template <typename T>
+// MAXC = the largest channel count among the surface's plane jobs: the kernel is only as
+// register-heavy as the format needs (planar formats never carry the packed-RGB code).
+template <typename T, int MAXC>
 __global__ void __launch_bounds__(kBlock) k_resize(const ResizeArgs a) {
   ResizeJob job;
   u32 tx, ty, frame;
@@ -238,11 +240,12 @@ __global__ void __launch_bounds__(kBlock) k_resize(const ResizeArgs a) {
     return;
   __shared__ StageRows stage[kWavesPerBlock];
   const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
-  switch (job.channels) {
-  case 1: resize_tile<T, 1>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage); break;
-  case 2: resize_tile<T, 2>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage); break;
-  default: resize_tile<T, 3>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage); break;
-  }
+  if (MAXC >= 3 && job.channels == 3)
+    resize_tile<T, 3>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage);
+  else if (MAXC >= 2 && job.channels == 2)
+    resize_tile<T, 2>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage);
+  else
+    resize_tile<T, 1>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -308,9 +311,9 @@ __device__ __forceinline__ LzTap make_lz_tap(int x, float scale) {
 __device__ __forceinline__ int clampi(int v, int hi) { return min(max(v, 0), hi); }
 
 constexpr int kLzCpr = 2;                              // 16-byte chunks per lane per row
-constexpr int kLzRowBytes = kLzCpr * kWave * 16;       // 2 KiB per staged row
+constexpr int kLzRowBytes = kLzCpr * kWave * 16;       // 2 KiB: the staged source row
 struct alignas(16) LzStage {
-  uint8_t row[6][kLzRowBytes];
+  uint8_t row[kLzRowBytes];
 };
 
 template <typename T, int C>
@@ -348,57 +351,87 @@ __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int 
   const int nbytes = (((sx1 + 1) * PB + 15) & ~15) - byte_begin;
   const bool staged = nbytes <= kLzRowBytes && ((((uintptr_t)sp) | (uintptr_t)spitch) & 15u) == 0;
 
-  auto filter_and_store = [&](const LzTap& cy, int y, auto fetch) {
-    float res[4][C];
+  if (staged) {
+    // Sliding window: hq[r] = the horizontal 6-tap filter of source row (base + r) at this
+    // lane's 4 columns.  Moving to the next dst row shifts the window by the advance of
+    // floor(y * scale) and filters only the source rows that entered it (an upscale re-uses
+    // almost all of them; a 3x downscale half).  Each h is computed by the same expression
+    // whatever dst row asked for it, so re-use does not change a bit.  One source row at a
+    // time goes through the wave's LDS strip; the next row's loads are in flight meanwhile.
+    LzStage& st = stage_all[wave];
+    const int nchunks = nbytes / 16;
+    int lo[4][6]; // LDS byte offsets of the column taps (row-invariant)
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-      for (int ch = 0; ch < C; ++ch) {
-        float v = 0.0f;
+      for (int k = 0; k < 6; ++k)
+        lo[p][k] = clampi(cx[p].i - 2 + k, sw - 1) * PB - byte_begin;
+    float hq[6][4][C];
+    uint4 pf[kLzCpr];
+    int pf_row = -0x40000000; // logical source row held by pf
+    auto issue = [&](int logical) {
+      const uint8_t* row = sp + (u32)(clampi(logical, sh - 1) * spitch + byte_begin);
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
-          float h = cx[p].w[0] * fetch(r, p, 0, ch);
+      for (int c = 0; c < kLzCpr; ++c)
+        pf[c] = gload16(row + min(lane + c * kWave, nchunks - 1) * 16);
+      pf_row = logical;
+    };
+    auto append = [&](int logical) {
+      if (pf_row != logical) // first row of the wave, or a jump of more than 6 rows
+        issue(logical);
+#pragma unroll
+      for (int c = 0; c < kLzCpr; ++c)
+        if (lane + c * kWave < nchunks)
+          *reinterpret_cast<uint4*>(&st.row[(lane + c * kWave) * 16]) = pf[c];
+      wave_lds_sync();
+      issue(logical + 1); // in flight while this row is filtered
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+#pragma unroll
+          for (int r = 0; r < 5; ++r)
+            hq[r][p][ch] = hq[r + 1][p][ch];
+          auto texel = [&](int k) { return (float)((const T*)(st.row + lo[p][k]))[ch]; };
+          float h = cx[p].w[0] * texel(0);
 #pragma unroll
           for (int k = 1; k < 6; ++k)
-            h = __builtin_fmaf(cx[p].w[k], fetch(r, p, k, ch), h);
-          v = r == 0 ? cy.w[0] * h : __builtin_fmaf(cy.w[r], h, v);
+            h = __builtin_fmaf(cx[p].w[k], texel(k), h);
+          hq[5][p][ch] = h;
+          __builtin_amdgcn_sched_barrier(0); // one pixel-channel at a time: bounds the live registers
         }
-        res[p][ch] = v;
-      }
-    store_px4<T, C>(dp + (u32)(y * dpitch) + (size_t)x0 * PB, res, (1u << n) - 1u);
-  };
-
-  if (staged) {
-    LzStage& st = stage_all[wave];
-    const int nchunks = nbytes / 16;
+      wave_lds_sync(); // the strip is re-filled by the next row
+    };
+    int base = 0;
 #pragma unroll 1
     for (int rr = 0; rr < kRsRowsPerWave; ++rr) {
       const int y = y_first + rr;
       if (y >= dh)
         break;
       const LzTap cy = row_tap(rr);
-      uint4 q[6][kLzCpr];
+      const int want = cy.i - 2;
+      const int delta = rr == 0 ? 6 : min(want - base, 6);
+#pragma unroll 1
+      for (int s = 0; s < delta; ++s)
+        append(want + 6 - delta + s);
+      base = want;
+      if (n > 0) {
+        float res[4][C];
 #pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        const uint8_t* row = sp + (u32)(clampi(cy.i - 2 + r, sh - 1) * spitch + byte_begin);
+        for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int c = 0; c < kLzCpr; ++c)
-          q[r][c] = gload16(row + min(lane + c * kWave, nchunks - 1) * 16);
+          for (int ch = 0; ch < C; ++ch) {
+            float v = cy.w[0] * hq[0][p][ch];
+#pragma unroll
+            for (int r = 1; r < 6; ++r)
+              v = __builtin_fmaf(cy.w[r], hq[r][p][ch], v);
+            res[p][ch] = v;
+          }
+        store_px4<T, C>(dp + (u32)(y * dpitch) + (size_t)x0 * PB, res, (1u << n) - 1u);
       }
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = 0; c < kLzCpr; ++c)
-          if (lane + c * kWave < nchunks)
-            *reinterpret_cast<uint4*>(&st.row[r][(lane + c * kWave) * 16]) = q[r][c];
-      wave_lds_sync();
-      if (n > 0)
-        filter_and_store(cy, y, [&](int r, int p, int k, int ch) {
-          return (float)((const T*)(st.row[r] + (clampi(cx[p].i - 2 + k, sw - 1) * PB - byte_begin)))[ch];
-        });
-      wave_lds_sync(); // the strip is re-filled by the next row
     }
   } else {
+    // source span wider than the strip (or foreign unaligned memory): direct gather, 36 taps
     if (n <= 0)
       return;
 #pragma unroll 1
@@ -407,15 +440,32 @@ __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int 
       if (y >= dh)
         break;
       const LzTap cy = row_tap(rr);
-      filter_and_store(cy, y, [&](int r, int p, int k, int ch) {
-        const uint8_t* row = sp + (size_t)clampi(cy.i - 2 + r, sh - 1) * spitch;
-        return (float)gload<T>(row + (size_t)clampi(cx[p].i - 2 + k, sw - 1) * PB + ch * sizeof(T));
-      });
+      float res[4][C];
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+          float v = 0.0f;
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+            const uint8_t* row = sp + (size_t)clampi(cy.i - 2 + r, sh - 1) * spitch;
+            auto texel = [&](int k) {
+              return (float)gload<T>(row + (size_t)clampi(cx[p].i - 2 + k, sw - 1) * PB + ch * sizeof(T));
+            };
+            float h = cx[p].w[0] * texel(0);
+#pragma unroll
+            for (int k = 1; k < 6; ++k)
+              h = __builtin_fmaf(cx[p].w[k], texel(k), h);
+            v = r == 0 ? cy.w[0] * h : __builtin_fmaf(cy.w[r], h, v);
+          }
+          res[p][ch] = v;
+        }
+      store_px4<T, C>(dp + (u32)(y * dpitch) + (size_t)x0 * PB, res, (1u << n) - 1u);
     }
   }
 }
 
-template <typename T>
+template <typename T, int MAXC>
 __global__ void __launch_bounds__(kBlock) k_resize_lanczos(const ResizeArgs a) {
   ResizeJob job;
   u32 tx, ty, frame;
@@ -423,11 +473,12 @@ __global__ void __launch_bounds__(kBlock) k_resize_lanczos(const ResizeArgs a) {
     return;
   __shared__ LzStage stage[kWavesPerBlock];
   const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
-  switch (job.channels) {
-  case 1: lanczos_tile<T, 1>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage); break;
-  case 2: lanczos_tile<T, 2>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage); break;
-  default: lanczos_tile<T, 3>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage); break;
-  }
+  if (MAXC >= 3 && job.channels == 3)
+    lanczos_tile<T, 3>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage);
+  else if (MAXC >= 2 && job.channels == 2)
+    lanczos_tile<T, 2>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage);
+  else
+    lanczos_tile<T, 1>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage);
 }
 
 // plane jobs per pixel format: which components, their subsampling and channel count
@@ -469,19 +520,25 @@ static int launch_resize(ResizeArgs& a, int fmt, int dst_w, int dst_h, int n, in
   }
   a.map = make_tile_map_linear(total, (u32)n);
   const dim3 grid = tile_grid(a.map), block(kBlock);
+  int maxc = 1;
+  for (int k = 0; k < a.njobs; ++k)
+    maxc = a.job[k].channels > maxc ? a.job[k].channels : maxc;
+#define VALI_RS_LAUNCH(KERNEL, T)                                                          \
+  do {                                                                                     \
+    if (maxc == 1) hipLaunchKernelGGL((KERNEL<T, 1>), grid, block, 0, stream, a);           \
+    else if (maxc == 2) hipLaunchKernelGGL((KERNEL<T, 2>), grid, block, 0, stream, a);      \
+    else hipLaunchKernelGGL((KERNEL<T, 3>), grid, block, 0, stream, a);                     \
+  } while (0)
   if (interp == VALI_INTERP_LANCZOS) {
-    if (elem == 1)
-      hipLaunchKernelGGL(k_resize_lanczos<uint8_t>, grid, block, 0, stream, a);
-    else if (elem == 2)
-      hipLaunchKernelGGL(k_resize_lanczos<uint16_t>, grid, block, 0, stream, a);
-    else
-      hipLaunchKernelGGL(k_resize_lanczos<float>, grid, block, 0, stream, a);
-  } else if (elem == 1)
-    hipLaunchKernelGGL(k_resize<uint8_t>, grid, block, 0, stream, a);
-  else if (elem == 2)
-    hipLaunchKernelGGL(k_resize<uint16_t>, grid, block, 0, stream, a);
-  else
-    hipLaunchKernelGGL(k_resize<float>, grid, block, 0, stream, a);
+    if (elem == 1) VALI_RS_LAUNCH(k_resize_lanczos, uint8_t);
+    else if (elem == 2) VALI_RS_LAUNCH(k_resize_lanczos, uint16_t);
+    else VALI_RS_LAUNCH(k_resize_lanczos, float);
+  } else {
+    if (elem == 1) VALI_RS_LAUNCH(k_resize, uint8_t);
+    else if (elem == 2) VALI_RS_LAUNCH(k_resize, uint16_t);
+    else VALI_RS_LAUNCH(k_resize, float);
+  }
+#undef VALI_RS_LAUNCH
   VALI_LAUNCH_CHECK();
   return VALI_OK;
 }
