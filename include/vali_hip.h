@@ -188,6 +188,34 @@ VALI_API int vali_convert_batch(const vali_surface* d_src, const vali_surface* d
                                 int src_format, int dst_format, int width, int height,
                                 const vali_cvt_params* params, vali_stream_t stream);
 
+/* ---- fused inference pre-processing ------------------------------- */
+
+/*
+ * NV12 -> (bilinear resize to the dst size) -> RGB u8 -> float -> normalised, one launch.
+ * No reference kernel: replaces the CHAIN the reference's samples run
+ * (tests/test_TorchSegmentation.py:176-240): PySurfaceConverter NV12->RGB, RGB->RGB_32F
+ * (nppiScale_8u32f_C3R, v/255), RGB_32F->RGB_32F_PLANAR, torch.divide(x, 255.0),
+ * torchvision Normalize -- optionally behind a PySurfaceResizer.  Defined as that chain step
+ * by step and bit-identical to running it with vali_resize + vali_nv12_to_rgb + vali_convert:
+ *   q_c   = u8 RGB of vali_nv12_to_rgb(csc) on the (resized) NV12
+ *   out_c = ((q_c / 255.0f) / div - mean[c]) / std_[c]          c = R, G, B ; IEEE float32
+ * div = 1, mean = 0, std_ = 1 gives plain NV12 -> RGB_32F[_PLANAR].
+ * dst->format: VALI_FMT_RGB_32F_PLANAR or VALI_FMT_RGB_32F; all four sizes even.
+ */
+typedef struct vali_preproc_params {
+  vali_csc csc;
+  float div;
+  float mean[3];
+  float std_[3];
+  float reserved;
+} vali_preproc_params;
+
+VALI_API int vali_nv12_preproc(const vali_surface* src, const vali_surface* dst,
+                               const vali_preproc_params* params, vali_stream_t stream);
+VALI_API int vali_nv12_preproc_batch(const vali_surface* d_src, const vali_surface* d_dst, int n,
+                                     int dst_width, int dst_height, int dst_format,
+                                     const vali_preproc_params* params, vali_stream_t stream);
+
 /* ---- UD: chroma upsample + resize (+ YUV->RGB) in one pass ---------------------- */
 
 /*

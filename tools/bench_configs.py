@@ -140,6 +140,42 @@ def cfg3_lanczos(n=64):
     return {"config": "resize filters", "results": out}
 
 
+def preproc(n=64):
+    """fused NV12 -> resize -> RGB -> f32 planar normalised vs the surface part of the
+    reference-style chain (resizer + 3 converter launches; the two torch kernels of the chain are
+    NOT included in the chain time, so the real gap is larger)."""
+    out = []
+    cc = vali.ColorspaceConversionContext(vali.ColorSpace.BT_709, vali.ColorRange.MPEG)
+    for (sw, sh, dw, dh) in ((1920, 1080, 1920, 1080), (3840, 2160, 640, 640), (1920, 1080, 640, 384)):
+        srcs = [vali.Surface.Make(vali.NV12, sw, sh, DEV) for _ in range(n)]
+        fill(srcs)
+        dsts = [vali.Surface.Make(vali.RGB_32F_PLANAR, dw, dh, DEV) for _ in range(n)]
+        pp = vali.PySurfacePreprocessor(DEV, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), div=255.0)
+        b = pp.PrepareBatch(srcs, dsts)
+        ms_f, _ = timed(pp.Stream, lambda: pp.RunBatchAsync(b, cc_ctx=cc), 20)
+        # chain
+        rs = vali.PySurfaceResizer(vali.NV12, DEV, pp.Stream)
+        cv = vali.PySurfaceConverter(DEV, pp.Stream)
+        small = srcs if (sw, sh) == (dw, dh) else [vali.Surface.Make(vali.NV12, dw, dh, DEV) for _ in range(n)]
+        rgb = [vali.Surface.Make(vali.RGB, dw, dh, DEV) for _ in range(n)]
+        f32 = [vali.Surface.Make(vali.RGB_32F, dw, dh, DEV) for _ in range(n)]
+        b0 = rs.PrepareBatch(srcs, small) if small is not srcs else None
+        b1, b2, b3 = cv.PrepareBatch(small, rgb), cv.PrepareBatch(rgb, f32), cv.PrepareBatch(f32, dsts)
+
+        def chain():
+            if b0 is not None:
+                rs.RunBatchAsync(b0)
+            cv.RunBatchAsync(b1, cc_ctx=cc)
+            cv.RunBatchAsync(b2)
+            cv.RunBatchAsync(b3)
+        ms_c, _ = timed(pp.Stream, chain, 20)
+        alg = sw * sh * 3 // 2 + dw * dh * 12
+        out.append({"geometry": f"NV12 {sw}x{sh} -> RGB_32F_PLANAR {dw}x{dh} normalised, batch {n}",
+                    "fused_us_per_frame": round(ms_f * 1e3 / n, 3), "chain_us_per_frame(surface part only)": round(ms_c * 1e3 / n, 3),
+                    "speedup": round(ms_c / ms_f, 2), "fused_GBps(src+dst bytes)": round(alg * n / (ms_f * 1e-3) / 1e9, 1)})
+    return {"config": "fused pre-processing (PySurfacePreprocessor)", "results": out}
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["cfg2", "cfg3", "cfg4"]
     for name in which:

@@ -10,7 +10,7 @@ from .enums import (ColorRange, ColorSpace, ColorspaceConversionContext, DLDevic
                     PixelFormat, TaskExecDetails, TaskExecInfo, TaskExecStatus, export_values)
 from .runtime import CudaStreamEvent, GetNumGpus, HipResMgr
 from .surface import Surface, SurfacePlane
-from .tasks import (PySurfaceConverter, PySurfaceResizer, PySurfaceRotator, PySurfaceUD,
+from .tasks import (PySurfaceConverter, PySurfacePreprocessor, PySurfaceResizer, PySurfaceRotator, PySurfaceUD,
                     SurfaceBatch)
 from .pipeline import BatchedFramePipeline, broadcast_coefficients, shard_frames
 from .transfer import PyFrameUploader, PySurfaceDownloader

@@ -37,23 +37,6 @@ struct Nv12RgbArgs {
   TileMap map;               // tiles of one frame: x segments x row pairs
 };
 
-struct ChromaTerm {
-  float rv, guv, bu;
-};
-
-__device__ __forceinline__ ChromaTerm chroma_term(float u, float v, const vali_csc& k) {
-  const float uc = u - 128.0f, vc = v - 128.0f;
-  ChromaTerm t;
-  t.rv = k.crv * vc;
-  t.guv = __builtin_fmaf(k.cgu, uc, k.cgv * vc);
-  t.bu = k.cbu * uc;
-  return t;
-}
-
-__device__ __forceinline__ float luma_term(float y, const vali_csc& k) {
-  return k.cy * (y - k.y0);
-}
-
 // 4 pixels of one row: y4 = 4 luma bytes, chroma terms c01 (px 0,1) / c23 (px 2,3).
 // Packed: writes dwords o[0..2] of the 12-byte group.  Planar: r/g/b dwords.
 template <int LAYOUT>

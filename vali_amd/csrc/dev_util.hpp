@@ -65,6 +65,43 @@ __device__ __forceinline__ u32 quantize_u8(float v) {
 #endif
 }
 
+// ---- arithmetic shared by several kernels (each restated in oracle/vali_oracle*.c) -----
+// YUV -> RGB in the vali_csc form: R = cy*(Y-y0) + crv*V', G = cy*(Y-y0) + (cgu*U' + cgv*V'),
+// B = cy*(Y-y0) + cbu*U'  with U' = U-128, V' = V-128 (oracle: vali_oracle_nv12_to_rgb)
+struct ChromaTerm {
+  float rv, guv, bu;
+};
+
+__device__ __forceinline__ ChromaTerm chroma_term(float u, float v, const vali_csc& k) {
+  const float uc = u - 128.0f, vc = v - 128.0f;
+  ChromaTerm t;
+  t.rv = k.crv * vc;
+  t.guv = __builtin_fmaf(k.cgu, uc, k.cgv * vc);
+  t.bu = k.cbu * uc;
+  return t;
+}
+
+__device__ __forceinline__ float luma_term(float y, const vali_csc& k) {
+  return k.cy * (y - k.y0);
+}
+
+// bilinear tap on the resize grid f = x * scale (oracle: make_lerp in vali_oracle.c)
+struct Lerp {
+  int i0, i1;
+  float a;
+};
+
+__device__ __forceinline__ Lerp make_lerp(int x, float scale, int size) {
+  const float f = (float)x * scale;
+  const float fl = __builtin_floorf(f);
+  Lerp l;
+  l.a = f - fl;
+  const int i = (int)fl;
+  l.i0 = min(i, size - 1);
+  l.i1 = min(i + 1, size - 1);
+  return l;
+}
+
 // 16-byte global accesses.  Stores of finished output use the non-temporal form:
 // the surface kernels never re-read what they write, and streaming full 128-byte
 // lines past the L2 measured +2..3% on the 1:2 read:write mix (profiles/r01_variants.md).

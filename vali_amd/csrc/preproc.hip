@@ -1,0 +1,237 @@
+// Fused inference pre-processing: NV12 -> (bilinear resize) -> RGB -> float -> normalised,
+// planar or packed, in ONE pass.
+//
+// The reference has no such kernel; its samples and tests/test_TorchSegmentation.py:176-240
+// run the chain
+//   PySurfaceConverter NV12 -> RGB            (nppiNV12ToRGB*_8u_P2C3R)
+//   PySurfaceConverter RGB -> RGB_32F         (nppiScale_8u32f_C3R: v / 255)
+//   PySurfaceConverter RGB_32F -> RGB_32F_PLANAR
+//   torch.divide(x, 255.0) ; torchvision Normalize: (x - mean[c]) / std[c]
+// (optionally behind a PySurfaceResizer), i.e. three to four surface launches plus two torch
+// kernels and ~80 bytes of HBM traffic per pixel.  Here: 1.5 B read + 12 B written per pixel.
+//
+// DEFINITION = that chain, step by step, so the result is bit-identical to running the chain
+// with this library's own kernels (tests/test_gpu_preproc.py checks exactly that):
+//   1. sizes differ: NV12' = bilinear resize of the Y plane and of the interleaved UV plane on
+//      the grid src = dst * (src_size / dst_size), each rounded half-even to u8 (resize.hip)
+//   2. q_c = the u8 RGB of cvt_nv12_rgb.hip (vali_csc coefficients, round-half-even, saturate)
+//   3. out_c = ((q_c / 255.0f) / div - mean[c]) / std[c]            three IEEE divisions
+// Step 3 depends only on (c, q): each workgroup evaluates it ONCE for all 3 x 256 inputs into
+// an LDS table with exactly those operations and every pixel then costs one ds_read_b32 --
+// same bits, no per-pixel divisions.
+//
+// Work decomposition: lane = 4 dst px x 2 rows (one chroma sample pair per row pair), so each
+// planar store instruction is one float4 per lane = 1 KiB contiguous per wave; a workgroup
+// covers 256 x 32 dst pixels (each wave walks 4 row pairs) and the table is built once per
+// workgroup.  Same-size inputs stream (dword luma loads); resized inputs gather their taps
+// through L1/L2 (the destination of a network input is small, the traffic is the source).
+// Oracle: composition of vali_oracle_resize_plane, vali_oracle_nv12_to_rgb and float32
+// numpy arithmetic (tests/test_gpu_preproc.py, tests/test_oracle_preproc.py).
+#include "common.hpp"
+#include "dev_util.hpp"
+
+namespace vali {
+
+struct PreprocArgs {
+  const vali_surface* d_src;
+  const vali_surface* d_dst;
+  vali_surface src, dst;
+  vali_preproc_params prm;
+  int packed; // dst is RGB_32F (interleaved) instead of RGB_32F_PLANAR
+  TileMap map;
+};
+
+constexpr int kPpRowPairsPerWave = 4;
+constexpr int kPpTileH = kWavesPerBlock * kPpRowPairsPerWave * 2; // 32 dst rows
+
+__global__ void __launch_bounds__(kBlock) k_nv12_preproc(const PreprocArgs a) {
+  __shared__ float lut[3][256];
+  u32 tile_x, tile_y, frame;
+  if (!tile_of_block(a.map, tile_x, tile_y, frame))
+    return;
+  // step 3 for every (channel, u8 value)
+  for (int e = threadIdx.x; e < 3 * 256; e += kBlock) {
+    const int c = e >> 8, q = e & 255;
+    const float f = (float)q / 255.0f;
+    const float g = f / a.prm.div;
+    lut[c][q] = (g - a.prm.mean[c]) / a.prm.std_[c];
+  }
+  __syncthreads();
+
+  const SurfRef s = load_surface(a.d_src, a.src, frame);
+  const SurfRef d = load_surface(a.d_dst, a.dst, frame);
+  const uint8_t* py = s.p[0];
+  const uint8_t* puv = s.p[1];
+  const int sp_y = s.pitch[0], sp_uv = s.pitch[1], sw = s.width, sh = s.height;
+  const int dw = d.width, dh = d.height, dp = d.pitch[0];
+  const vali_csc k = a.prm.csc;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int x0 = (tile_x * 64 + lane) * 4;
+  if (x0 >= dw)
+    return;
+  const int n = min(4, dw - x0); // dw is even: n is 2 or 4
+  const bool same = sw == dw && sh == dh;
+  const bool fast_luma = same && ((((uintptr_t)py) | (uintptr_t)sp_y | ((uintptr_t)puv) | (uintptr_t)sp_uv) & 3u) == 0;
+
+  // resize geometry (resize.hip): per plane scale = src_size / dst_size
+  const float lsx = (float)sw / (float)dw, lsy = (float)sh / (float)dh;
+  const float csx = (float)(sw >> 1) / (float)(dw >> 1), csy = (float)(sh >> 1) / (float)(dh >> 1);
+  Lerp lx[4], cxl[2];
+  if (!same) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      lx[p] = make_lerp(min(x0 + p, dw - 1), lsx, sw);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      cxl[j] = make_lerp(min((x0 >> 1) + j, (dw >> 1) - 1), csx, sw >> 1);
+  }
+
+#pragma unroll 1
+  for (int it = 0; it < kPpRowPairsPerWave; ++it) {
+    const int y0 = tile_y * kPpTileH + (wave * kPpRowPairsPerWave + it) * 2; // wave-uniform
+    if (y0 >= dh)
+      break;
+    // ---- the resized NV12' texels of this lane: 2 x 4 luma, 2 chroma pairs ----
+    float yv[2][4], uu[2], vv[2];
+    if (same) {
+      const uint8_t* r0 = py + (u32)(y0 * sp_y) + x0;
+      const uint8_t* r1 = py + (u32)((y0 + 1) * sp_y) + x0;
+      const uint8_t* rc = puv + (u32)((y0 >> 1) * sp_uv) + x0;
+      u32 w0, w1, wc;
+      if (fast_luma && n == 4) {
+        w0 = gload<u32>(r0); w1 = gload<u32>(r1); wc = gload<u32>(rc);
+      } else {
+        w0 = w1 = wc = 0;
+        for (int p = 0; p < n; ++p) {
+          w0 |= (u32)gload<uint8_t>(r0 + p) << (8 * p);
+          w1 |= (u32)gload<uint8_t>(r1 + p) << (8 * p);
+          wc |= (u32)gload<uint8_t>(rc + p) << (8 * p);
+        }
+      }
+      yv[0][0] = ubyte_f32<0>(w0); yv[0][1] = ubyte_f32<1>(w0); yv[0][2] = ubyte_f32<2>(w0); yv[0][3] = ubyte_f32<3>(w0);
+      yv[1][0] = ubyte_f32<0>(w1); yv[1][1] = ubyte_f32<1>(w1); yv[1][2] = ubyte_f32<2>(w1); yv[1][3] = ubyte_f32<3>(w1);
+      uu[0] = ubyte_f32<0>(wc); vv[0] = ubyte_f32<1>(wc); uu[1] = ubyte_f32<2>(wc); vv[1] = ubyte_f32<3>(wc);
+    } else {
+      // bilinear taps, arithmetic of resize_tile (t0, t1, v; then round-half-even to u8)
+      auto bilerp = [&](const uint8_t* r0, const uint8_t* r1, int i0, int i1, float ax, float ay) {
+        const float t00 = (float)gload<uint8_t>(r0 + i0), t10 = (float)gload<uint8_t>(r0 + i1);
+        const float t01 = (float)gload<uint8_t>(r1 + i0), t11 = (float)gload<uint8_t>(r1 + i1);
+        const float t0 = __builtin_fmaf(ax, t10 - t00, t00);
+        const float t1 = __builtin_fmaf(ax, t11 - t01, t01);
+        return (float)quantize_u8(__builtin_fmaf(ay, t1 - t0, t0));
+      };
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const Lerp ly = make_lerp(min(y0 + r, dh - 1), lsy, sh);
+        const uint8_t* r0 = py + (size_t)ly.i0 * sp_y;
+        const uint8_t* r1 = py + (size_t)ly.i1 * sp_y;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          yv[r][p] = bilerp(r0, r1, lx[p].i0, lx[p].i1, lx[p].a, ly.a);
+      }
+      const Lerp cy = make_lerp(y0 >> 1, csy, sh >> 1);
+      const uint8_t* c0 = puv + (size_t)cy.i0 * sp_uv;
+      const uint8_t* c1 = puv + (size_t)cy.i1 * sp_uv;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        uu[j] = bilerp(c0, c1, cxl[j].i0 * 2, cxl[j].i1 * 2, cxl[j].a, cy.a);
+        vv[j] = bilerp(c0, c1, cxl[j].i0 * 2 + 1, cxl[j].i1 * 2 + 1, cxl[j].a, cy.a);
+      }
+    }
+    // ---- step 2 + 3 ----
+    const ChromaTerm ct[2] = {chroma_term(uu[0], vv[0], k), chroma_term(uu[1], vv[1], k)};
+    float o[2][3][4]; // [row][channel][pixel]
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float yf = luma_term(yv[r][p], k);
+        const ChromaTerm& c = ct[p >> 1];
+        o[r][0][p] = lut[0][quantize_u8(yf + c.rv)];
+        o[r][1][p] = lut[1][quantize_u8(yf + c.guv)];
+        o[r][2][p] = lut[2][quantize_u8(yf + c.bu)];
+      }
+    // ---- stores ----
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int y = y0 + r;
+      if (y >= dh)
+        break;
+      if (!a.packed) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          uint8_t* q = d.p[c] + (u32)(y * dp) + (size_t)x0 * 4;
+          if (n == 4 && (((uintptr_t)q) & 15u) == 0)
+            store16f(q, make_float4(o[r][c][0], o[r][c][1], o[r][c][2], o[r][c][3]));
+          else
+            for (int p = 0; p < n; ++p) gstore<float>(q + 4 * p, o[r][c][p]);
+        }
+      } else {
+        uint8_t* q = d.p[0] + (u32)(y * dp) + (size_t)x0 * 12;
+        if (n == 4 && (((uintptr_t)q) & 15u) == 0) {
+          store16f(q + 0, make_float4(o[r][0][0], o[r][1][0], o[r][2][0], o[r][0][1]));
+          store16f(q + 16, make_float4(o[r][1][1], o[r][2][1], o[r][0][2], o[r][1][2]));
+          store16f(q + 32, make_float4(o[r][2][2], o[r][0][3], o[r][1][3], o[r][2][3]));
+        } else {
+          for (int p = 0; p < n; ++p) {
+            gstore<float>(q + 12 * p, o[r][0][p]); gstore<float>(q + 12 * p + 4, o[r][1][p]); gstore<float>(q + 12 * p + 8, o[r][2][p]);
+          }
+        }
+      }
+    }
+  }
+}
+
+static int launch_preproc(PreprocArgs& a, int dst_w, int dst_h, int dst_fmt, int n, hipStream_t stream) {
+  if (dst_fmt != VALI_FMT_RGB_32F && dst_fmt != VALI_FMT_RGB_32F_PLANAR)
+    return fail(VALI_ERR_UNSUPPORTED, "nv12_preproc: destination must be RGB_32F or RGB_32F_PLANAR (got %d)", dst_fmt);
+  a.packed = dst_fmt == VALI_FMT_RGB_32F;
+  a.map = make_tile_map((dst_w + 255) / 256, (dst_h + kPpTileH - 1) / kPpTileH, (u32)n);
+  hipLaunchKernelGGL(k_nv12_preproc, tile_grid(a.map), dim3(kBlock), 0, stream, a);
+  VALI_LAUNCH_CHECK();
+  return VALI_OK;
+}
+
+} // namespace vali
+
+using namespace vali;
+
+extern "C" {
+
+int vali_nv12_preproc(const vali_surface* src, const vali_surface* dst, const vali_preproc_params* params,
+                      vali_stream_t stream) {
+  VALI_REQUIRE(src && dst && params, "null argument");
+  VALI_REQUIRE(src->format == VALI_FMT_NV12, "source must be NV12");
+  VALI_REQUIRE(src->width >= 2 && src->height >= 2 && dst->width >= 2 && dst->height >= 2, "empty surface");
+  VALI_REQUIRE(((src->width | src->height | dst->width | dst->height) & 1) == 0, "4:2:0 needs even sizes");
+  VALI_REQUIRE(src->plane[0] && src->plane[1] && dst->plane[0], "null plane");
+  if (dst->format == VALI_FMT_RGB_32F_PLANAR)
+    VALI_REQUIRE(dst->plane[1] && dst->plane[2], "null dst plane");
+  PreprocArgs a = {};
+  a.src = *src;
+  a.dst = *dst;
+  a.prm = *params;
+  hipStream_t s = as_stream(stream);
+  DeviceScope scope(stream_device(s));
+  return launch_preproc(a, dst->width, dst->height, dst->format, 1, s);
+}
+
+int vali_nv12_preproc_batch(const vali_surface* d_src, const vali_surface* d_dst, int n, int dst_width,
+                            int dst_height, int dst_format, const vali_preproc_params* params,
+                            vali_stream_t stream) {
+  VALI_REQUIRE(d_src && d_dst && params, "null argument");
+  VALI_REQUIRE(dst_width >= 2 && dst_height >= 2 && ((dst_width | dst_height) & 1) == 0, "bad geometry");
+  VALI_REQUIRE(n >= 0 && n <= 65535, "batch size out of range (0..65535)");
+  if (n == 0)
+    return VALI_OK;
+  PreprocArgs a = {};
+  a.d_src = d_src;
+  a.d_dst = d_dst;
+  a.prm = *params;
+  hipStream_t s = as_stream(stream);
+  DeviceScope scope(stream_device(s));
+  return launch_preproc(a, dst_width, dst_height, dst_format, n, s);
+}
+
+} // extern "C"

@@ -44,6 +44,10 @@ struct CvtParams {
   vali_cvt_params p;
 };
 
+struct PreprocParams {
+  vali_preproc_params p;
+};
+
 // ---- DLPack ------------------------------------------------------------------
 
 struct ExportCtx {
@@ -349,6 +353,32 @@ PYBIND11_MODULE(_vali_shim, m) {
            int height, const CvtParams& p, uintptr_t stream) {
           return vali_convert_batch((const vali_surface*)P(d_src), (const vali_surface*)P(d_dst), n,
                                     src_format, dst_format, width, height, &p.p, P(stream));
+        },
+        py::call_guard<py::gil_scoped_release>());
+
+  py::class_<PreprocParams>(m, "PreprocParams")
+      .def(py::init([](const Csc& csc, float div, const std::vector<float>& mean,
+                       const std::vector<float>& std_) {
+        PreprocParams p;
+        std::memset(&p.p, 0, sizeof(p.p));
+        p.p.csc = csc.k;
+        p.p.div = div;
+        for (size_t i = 0; i < 3; ++i) {
+          p.p.mean[i] = i < mean.size() ? mean[i] : 0.0f;
+          p.p.std_[i] = i < std_.size() ? std_[i] : 1.0f;
+        }
+        return p;
+      }));
+  m.def("nv12_preproc",
+        [](const SurfaceDesc& src, const SurfaceDesc& dst, const PreprocParams& p, uintptr_t stream) {
+          return vali_nv12_preproc(&src.s, &dst.s, &p.p, P(stream));
+        },
+        py::call_guard<py::gil_scoped_release>());
+  m.def("nv12_preproc_batch",
+        [](uintptr_t d_src, uintptr_t d_dst, int n, int dst_width, int dst_height, int dst_format,
+           const PreprocParams& p, uintptr_t stream) {
+          return vali_nv12_preproc_batch((const vali_surface*)P(d_src), (const vali_surface*)P(d_dst), n,
+                                         dst_width, dst_height, dst_format, &p.p, P(stream));
         },
         py::call_guard<py::gil_scoped_release>());
 

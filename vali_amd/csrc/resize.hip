@@ -51,22 +51,6 @@ template <> __device__ __forceinline__ uint16_t rs_finish<uint16_t>(float v) {
 }
 template <> __device__ __forceinline__ float rs_finish<float>(float v) { return v; }
 
-struct Lerp {
-  int i0, i1;
-  float a;
-};
-
-__device__ __forceinline__ Lerp make_lerp(int x, float scale, int size) {
-  const float f = (float)x * scale;
-  const float fl = __builtin_floorf(f);
-  Lerp l;
-  l.a = f - fl;
-  const int i = (int)fl;
-  l.i0 = min(i, size - 1);
-  l.i1 = min(i + 1, size - 1);
-  return l;
-}
-
 // Per-wave LDS staging of the two source rows a dst row needs.  A wave walks kRsRowsPerWave
 // dst rows x 256 px with the SAME column taps (coordinates, float divisions and LDS offsets are
 // paid once per tile, not per row).  For each dst row it reads the source span

@@ -422,6 +422,92 @@ class PySurfaceUD(_SurfaceTask):
         return SurfaceBatch(self._gpu_id, self._stream, srcs, dsts)
 
 
+# ---- PySurfacePreprocessor (new: fused inference pre-processing) -------------
+class PySurfacePreprocessor(_SurfaceTask):
+    """NV12 -> (bilinear resize to dst size) -> RGB -> float -> normalised, ONE launch.
+
+    The reference has no such task: its samples and tests/test_TorchSegmentation.py:176-240
+    chain PySurfaceConverter NV12->RGB, RGB->RGB_32F, RGB_32F->RGB_32F_PLANAR and then run
+    `torch.divide(x, 255.0)` + torchvision `Normalize(mean, std)` (optionally after a
+    PySurfaceResizer).  This task is DEFINED as that chain and is bit-identical to running
+    it with this library's own tasks (tests/test_gpu_preproc.py):
+
+        out[c] = ((rgb_u8[c] / 255.0) / div - mean[c]) / std[c]          float32, IEEE
+
+    `div=1, mean=0, std=1` is plain NV12 -> RGB_32F[_PLANAR].  Colour variant selection is
+    nv12_rgb's (TaskConvertSurface.cpp:117-149).  dst: RGB_32F_PLANAR or RGB_32F.
+    """
+
+    def __init__(self, gpu_id: int, stream=None, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0),
+                 div: float = 1.0):
+        super().__init__(gpu_id, stream)
+        self._norm = (float(div), tuple(float(v) for v in mean), tuple(float(v) for v in std))
+        if len(self._norm[1]) != 3 or len(self._norm[2]) != 3:
+            raise ValueError("mean / std need 3 values (R, G, B)")
+        if self._norm[0] == 0.0 or any(v == 0.0 for v in self._norm[2]):
+            raise ValueError("div / std must be non-zero")
+        self._params_cache = {}
+
+    def _params(self, cc_ctx):
+        coeffs = _nv12_variant(cc_ctx)
+        if coeffs is None:
+            return None
+        p = self._params_cache.get(coeffs)
+        if p is None:
+            div, mean, std = self._norm
+            p = self._params_cache[coeffs] = shim.PreprocParams(_csc(coeffs), div, list(mean), list(std))
+        return p
+
+    @staticmethod
+    def _check(src_fmt, dst_fmt, sw, sh, dw, dh):
+        if src_fmt != F.NV12 or dst_fmt not in (F.RGB_32F, F.RGB_32F_PLANAR):
+            return TaskExecDetails.failed(TaskExecInfo.NOT_SUPPORTED)
+        if (sw | sh | dw | dh) & 1:
+            return _S_INVALID
+        return None
+
+    def _run(self, src: Surface, dst: Surface, cc_ctx) -> TaskExecDetails:
+        if src is None or dst is None or src.IsEmpty or dst.IsEmpty:
+            return _S_INVALID
+        bad = self._check(src.Format, dst.Format, src.Width, src.Height, dst.Width, dst.Height)
+        if bad:
+            return bad
+        p = self._params(cc_ctx)
+        if p is None:
+            return _S_UNSUPP_CC
+        return _status(shim.nv12_preproc(src.desc(), dst.desc(), p, self._stream))
+
+    def RunAsync(self, src: Surface, dst: Surface, cc_ctx=None) -> Tuple[bool, TaskExecInfo]:
+        d = self._run(src, dst, cc_ctx)
+        return d.success, d.info
+
+    def Run(self, src: Surface, dst: Surface, cc_ctx=None) -> Tuple[bool, TaskExecInfo]:
+        d = self._run(src, dst, cc_ctx)
+        self._sync()
+        return d.success, d.info
+
+    def PrepareBatch(self, srcs: Sequence[Surface], dsts: Sequence[Surface]) -> "SurfaceBatch":
+        return SurfaceBatch(self._gpu_id, self._stream, srcs, dsts)
+
+    def RunBatchAsync(self, batch, dsts=None, cc_ctx=None) -> Tuple[bool, TaskExecInfo]:
+        if not isinstance(batch, SurfaceBatch):
+            batch = SurfaceBatch(self._gpu_id, self._stream, batch, dsts)
+        bad = self._check(batch.src_format, batch.dst_format, *batch.src_size, *batch.dst_size)
+        if bad:
+            return bad.success, bad.info
+        p = self._params(cc_ctx)
+        if p is None:
+            return False, TaskExecInfo.UNSUPPORTED_FMT_CONV_PARAMS
+        d = _status(shim.nv12_preproc_batch(batch.d_src, batch.d_dst, batch.n, batch.dst_size[0],
+                                            batch.dst_size[1], int(batch.dst_format), p, self._stream))
+        return d.success, d.info
+
+    def RunBatch(self, batch, dsts=None, cc_ctx=None) -> Tuple[bool, TaskExecInfo]:
+        r = self.RunBatchAsync(batch, dsts, cc_ctx)
+        self._sync()
+        return r
+
+
 # ---- PySurfaceRotator --------------------------------------------------------------------
 _ROT_FORMATS = [F.Y, F.GRAY12, F.RGB, F.BGR, F.RGB_PLANAR, F.YUV420, F.YUV422, F.YUV444, F.RGB_32F,
                 F.RGB_32F_PLANAR, F.YUV444_10bit, F.YUV420_10bit]
