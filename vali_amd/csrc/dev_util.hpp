@@ -149,6 +149,11 @@ __device__ __forceinline__ void store16f(void* p, float4 v) {
   const v4f32 w = {v.x, v.y, v.z, v.w};
   *(VALI_GLOBAL v4f32*)p = w;
 }
+// non-temporal: only where a wave instruction writes whole 128-byte lines
+__device__ __forceinline__ void store16f_nt(void* p, float4 v) {
+  const v4f32 w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, (VALI_GLOBAL v4f32*)p);
+}
 __device__ __forceinline__ float4 load16f(const void* p) {
   const v4f32 w = *(const VALI_GLOBAL v4f32*)p;
   return make_float4(w.x, w.y, w.z, w.w);

@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(kBlock) k_nv12_preproc(const PreprocArgs a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           uint8_t* q = d.p[c] + (u32)(y * dp) + (size_t)x0 * 4;
-          if (n == 4 && (((uintptr_t)q) & 15u) == 0)
+          if (n == 4 && (((uintptr_t)q) & 15u) == 0) // (non-temporal measured 5-9 % slower here)
             store16f(q, make_float4(o[r][c][0], o[r][c][1], o[r][c][2], o[r][c][3]));
           else
             for (int p = 0; p < n; ++p) gstore<float>(q + 4 * p, o[r][c][p]);
