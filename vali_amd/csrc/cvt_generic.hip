@@ -481,28 +481,76 @@ __global__ void __launch_bounds__(kBlock) k_rgb8_to_f32(const ElemArgs a) {
   }
 }
 
-// RGB_32F packed -> RGB_32F_PLANAR: lane = 4 pixels (48 B in, 3 x 16 B out)
+// RGB_32F packed -> RGB_32F_PLANAR: lane = 4 pixels (48 B in, 3 x 16 B out) x 2 rows.
+// A wave's 256 pixels of a row are 3 KiB contiguous: they are loaded as 3 x 1 KiB coalesced
+// pieces (lane l: bytes 16 l of each KiB), pass through the wave's LDS strip, and come back as
+// the lane's own 48 bytes (ds_read_b128 at a 48-byte lane stride is conflict-free) -- instead
+// of three loads that each touch 16 bytes in every 48.  Both rows' loads are issued first.
+struct alignas(16) F32Strip {
+  uint8_t b[3 * 1024];
+};
 __global__ void __launch_bounds__(kBlock) k_f32_deinterleave(const ElemArgs a) {
+  __shared__ F32Strip strips[kWavesPerBlock];
   u32 tx, ty, frame;
   if (!tile_of_block(a.map, tx, ty, frame))
     return;
   const SurfRef s = load_surface(a.d_src, a.src, frame);
   const SurfRef d = load_surface(a.d_dst, a.dst, frame);
-  const int W = s.width, y = ty;
-  const int x0 = (tx * kBlock + threadIdx.x) * 4;
-  if (x0 >= W || y >= s.height)
+  const int W = s.width, H = s.height;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int xw = (tx * kWavesPerBlock + wave) * 256; // first pixel of the wave
+  const int x0 = xw + lane * 4, y0 = ty * 2;
+  if (xw >= W || y0 >= H)
     return;
-  const float* srow = (const float*)(s.p[0] + (size_t)y * s.pitch[0]) + (size_t)x0 * 3;
-  float* o0 = (float*)(d.p[0] + (size_t)y * d.pitch[0]) + x0;
-  float* o1 = (float*)(d.p[1] + (size_t)y * d.pitch[1]) + x0;
-  float* o2 = (float*)(d.p[2] + (size_t)y * d.pitch[2]) + x0;
-  if (x0 + 4 <= W && (((uintptr_t)srow | (uintptr_t)o0 | (uintptr_t)o1 | (uintptr_t)o2) & 15u) == 0) {
-    const float4 a0 = ((const float4*)srow)[0], a1 = ((const float4*)srow)[1], a2 = ((const float4*)srow)[2];
-    *(float4*)o0 = make_float4(a0.x, a0.w, a1.z, a2.y);
-    *(float4*)o1 = make_float4(a0.y, a1.x, a1.w, a2.z);
-    *(float4*)o2 = make_float4(a0.z, a1.y, a2.x, a2.w);
-  } else {
-    for (int k = 0; k < 4 && x0 + k < W; ++k) { o0[k] = srow[3 * k]; o1[k] = srow[3 * k + 1]; o2[k] = srow[3 * k + 2]; }
+  const bool aligned = ((((uintptr_t)s.p[0]) | (uintptr_t)s.pitch[0] | ((uintptr_t)d.p[0]) | ((uintptr_t)d.p[1]) |
+                         ((uintptr_t)d.p[2]) | (uintptr_t)d.pitch[0] | (uintptr_t)d.pitch[1] | (uintptr_t)d.pitch[2]) & 15u) == 0;
+  if (aligned && xw + 256 <= W) {
+    F32Strip& st = strips[wave];
+    const int rows = min(2, H - y0);
+    uint4 v[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const uint8_t* srow = s.p[0] + (size_t)min(y0 + r, H - 1) * s.pitch[0] + (size_t)xw * 12;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        v[r][i] = load16(srow + i * 1024 + lane * 16);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (r >= rows)
+        break;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        *reinterpret_cast<uint4*>(&st.b[i * 1024 + lane * 16]) = v[r][i];
+      wave_lds_sync();
+      const float4 a0 = *reinterpret_cast<const float4*>(&st.b[lane * 48]);
+      const float4 a1 = *reinterpret_cast<const float4*>(&st.b[lane * 48 + 16]);
+      const float4 a2 = *reinterpret_cast<const float4*>(&st.b[lane * 48 + 32]);
+      wave_lds_sync();
+      const int y = y0 + r;
+      store16f(d.p[0] + (size_t)y * d.pitch[0] + (size_t)x0 * 4, make_float4(a0.x, a0.w, a1.z, a2.y));
+      store16f(d.p[1] + (size_t)y * d.pitch[1] + (size_t)x0 * 4, make_float4(a0.y, a1.x, a1.w, a2.z));
+      store16f(d.p[2] + (size_t)y * d.pitch[2] + (size_t)x0 * 4, make_float4(a0.z, a1.y, a2.x, a2.w));
+    }
+    return;
+  }
+  // ragged last chunk of a row / foreign alignment: per-lane element path
+  if (x0 >= W)
+    return;
+  for (int r = 0; r < 2 && y0 + r < H; ++r) {
+    const int y = y0 + r;
+    const float* srow = (const float*)(s.p[0] + (size_t)y * s.pitch[0]) + (size_t)x0 * 3;
+    float* o0 = (float*)(d.p[0] + (size_t)y * d.pitch[0]) + x0;
+    float* o1 = (float*)(d.p[1] + (size_t)y * d.pitch[1]) + x0;
+    float* o2 = (float*)(d.p[2] + (size_t)y * d.pitch[2]) + x0;
+    if (x0 + 4 <= W && (((uintptr_t)srow | (uintptr_t)o0 | (uintptr_t)o1 | (uintptr_t)o2) & 15u) == 0) {
+      const float4 a0 = ((const float4*)srow)[0], a1 = ((const float4*)srow)[1], a2 = ((const float4*)srow)[2];
+      *(float4*)o0 = make_float4(a0.x, a0.w, a1.z, a2.y);
+      *(float4*)o1 = make_float4(a0.y, a1.x, a1.w, a2.z);
+      *(float4*)o2 = make_float4(a0.z, a1.y, a2.x, a2.w);
+    } else {
+      for (int k = 0; k < 4 && x0 + k < W; ++k) { o0[k] = srow[3 * k]; o1[k] = srow[3 * k + 1]; o2[k] = srow[3 * k + 2]; }
+    }
   }
 }
 
@@ -541,7 +589,7 @@ static int launch_convert(CvtArgs& a, ElemArgs& e, int src_fmt, int dst_fmt, int
     return VALI_OK;
   }
   if (src_fmt == VALI_FMT_RGB_32F && dst_fmt == VALI_FMT_RGB_32F_PLANAR) {
-    e.map = make_tile_map((width + kBlock * 4 - 1) / (kBlock * 4), height, (u32)n);
+    e.map = make_tile_map((width + kBlock * 4 - 1) / (kBlock * 4), (height + 1) / 2, (u32)n);
     hipLaunchKernelGGL(k_f32_deinterleave, tile_grid(e.map), dim3(kBlock), 0, stream, e);
     VALI_LAUNCH_CHECK();
     return VALI_OK;
