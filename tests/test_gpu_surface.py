@@ -106,3 +106,28 @@ def test_streams_and_events(vali, gpu):
     ev.Record()
     ev.Wait()
     assert vali.GetNumGpus() >= 1
+
+
+def test_cuda_buffer(vali, gpu):
+    """CudaBuffer (reference VALI.cpp:349-441): Make / props / Clone / CopyFrom semantics."""
+    import torch
+
+    b = vali.CudaBuffer.Make(4, 1000, gpu)
+    assert (b.ElemSize, b.NumElems, b.RawMemSize) == (4, 1000, 4000) and b.GpuMem != 0
+    # fill through a foreign view of the same memory, then Clone / CopyFrom move the bytes
+    src = torch.arange(1000, dtype=torch.int32, device="cuda")
+    shim = __import__("vali_amd._native", fromlist=["shim"]).shim
+    shim.memcpy2d_async(gpu, b.GpuMem, 4000, src.data_ptr(), 4000, 4000, 1, 2, 0)
+    shim.stream_sync(gpu, 0)
+    c = b.Clone()
+    assert c.GpuMem != b.GpuMem and c.RawMemSize == 4000
+    d = vali.CudaBuffer.Make(1, 4000, gpu)                      # same raw size, other element size
+    d.CopyFrom(c, gpu_id=gpu)
+    out = torch.empty(1000, dtype=torch.int32, device="cuda")
+    shim.memcpy2d_async(gpu, out.data_ptr(), 4000, d.GpuMem, 4000, 4000, 1, 2, 0)
+    shim.stream_sync(gpu, 0)
+    assert torch.equal(out, src)
+    with pytest.raises(RuntimeError):                           # VALI.cpp:31-33
+        vali.CudaBuffer.Make(4, 999, gpu).CopyFrom(b, gpu_id=gpu)
+    with pytest.raises(TypeError):
+        vali.CudaBuffer()

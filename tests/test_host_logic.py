@@ -95,3 +95,33 @@ def test_product_does_not_import_oracle():
         if "import oracle" in text or "from oracle" in text or "vali_oracle.h" in text:
             offenders.append(str(p))
     assert not offenders
+
+
+def test_public_api_surface_of_the_hot_path():
+    """Every name SURVEY.md 8(b1) lists for the path is importable from `vali_amd` and from the
+    `python_vali` alias, with the reference's method names (src/python_vali/__init__.pyi)."""
+    import python_vali
+
+    api = {
+        "PySurfaceConverter": ["Run", "RunAsync", "Conversions", "Stream", "RunBatch", "RunBatchAsync"],
+        "PySurfaceResizer": ["Run", "RunAsync", "Stream", "RunBatch", "RunBatchAsync"],
+        "PySurfaceRotator": ["Run", "RunAsync", "SupportedFormats", "Stream"],
+        "PySurfaceUD": ["Run", "RunAsync", "SupportedFormats", "Stream"],
+        "PySurfacePreprocessor": ["Run", "RunAsync", "RunBatch", "RunBatchAsync", "Stream"],
+        "PyFrameUploader": ["Run"], "PySurfaceDownloader": ["Run"], "PyFrameConverter": ["Run", "Format"],
+        "Surface": ["Make", "Clone", "Width", "Height", "Pitch", "Format", "IsEmpty", "NumPlanes", "HostSize",
+                    "IsOwnMemory", "Shape", "Planes", "from_dlpack", "from_cai", "__dlpack__", "__dlpack_device__",
+                    "__cuda_array_interface__"],
+        "SurfacePlane": ["Width", "Height", "Pitch", "ElemSize", "HostFrameSize", "GpuMem", "__dlpack__",
+                         "__dlpack_device__", "__cuda_array_interface__"],
+        "CudaBuffer": ["Make", "Clone", "CopyFrom", "ElemSize", "GpuMem", "NumElems", "RawMemSize"],
+        "CudaStreamEvent": ["Record", "Wait"],
+    }
+    for mod in (vali, python_vali):
+        for cls, members in api.items():
+            c = getattr(mod, cls)
+            missing = [m for m in members if not hasattr(c, m)]
+            assert not missing, (cls, missing)
+        for name in ("ColorspaceConversionContext", "PixelFormat", "TaskExecInfo", "TaskExecDetails", "ColorSpace",
+                     "ColorRange", "DLDeviceType", "GetNumGpus", "Interpolation", "NV12", "RGB", "SUCCESS", "BT_709"):
+            assert hasattr(mod, name), name

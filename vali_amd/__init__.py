@@ -10,6 +10,7 @@ from .enums import (ColorRange, ColorSpace, ColorspaceConversionContext, DLDevic
                     PixelFormat, TaskExecDetails, TaskExecInfo, TaskExecStatus, export_values)
 from .runtime import CudaStreamEvent, GetNumGpus, HipResMgr
 from .surface import Surface, SurfacePlane
+from .buffer import CudaBuffer
 from .tasks import (PySurfaceConverter, PySurfacePreprocessor, PySurfaceResizer, PySurfaceRotator, PySurfaceUD,
                     SurfaceBatch)
 from .pipeline import BatchedFramePipeline, broadcast_coefficients, shard_frames
