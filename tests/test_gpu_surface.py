@@ -131,3 +131,41 @@ def test_cuda_buffer(vali, gpu):
         vali.CudaBuffer.Make(4, 999, gpu).CopyFrom(b, gpu_id=gpu)
     with pytest.raises(TypeError):
         vali.CudaBuffer()
+
+
+def test_two_threads_two_streams(vali, gpu, oracle):
+    """one task instance = one stream, no internal locking, distinct instances may
+    run from distinct threads concurrently (every Run releases the GIL)."""
+    import threading
+
+    from conftest import make_nv12
+
+    w, h, iters = 640, 360, 40
+    cc = vali.ColorspaceConversionContext(vali.ColorSpace.BT_709, vali.ColorRange.MPEG)
+    results, errors = {}, []
+
+    def worker(idx):
+        try:
+            nv = make_nv12(w, h, 100 + idx)
+            stream = vali._native.shim.stream_create(gpu)
+            cvt = vali.PySurfaceConverter(gpu, stream)
+            rs = vali.PySurfaceResizer(vali.NV12, gpu, stream)
+            src = vali.Surface.Make(vali.NV12, w, h, gpu)
+            half = vali.Surface.Make(vali.NV12, w // 2, h // 2, gpu)
+            dst = vali.Surface.Make(vali.RGB, w // 2, h // 2, gpu)
+            assert vali.PyFrameUploader(gpu, stream).Run(nv.reshape(-1), src)[0]
+            for _ in range(iters):
+                assert rs.RunAsync(src, half)[0] and cvt.RunAsync(half, dst, cc)[0]
+            assert cvt.Run(half, dst, cc)[0]
+            out = np.zeros(dst.HostSize, np.uint8)
+            assert vali.PySurfaceDownloader(gpu, stream).Run(dst, out)[0]
+            small = oracle.resize_surface(nv.reshape(-1), "NV12", w, h, w // 2, h // 2).reshape(h * 3 // 4, w // 2)
+            results[idx] = np.array_equal(out, oracle.nv12_to_rgb(small, w // 2, h // 2, oracle.csc(1), "RGB").reshape(-1))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+    assert results == {0: True, 1: True, 2: True, 3: True}
