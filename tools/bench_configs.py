@@ -176,6 +176,22 @@ def preproc(n=64):
     return {"config": "fused pre-processing (PySurfacePreprocessor)", "results": out}
 
 
+def ud_scales(n=32):
+    """UD per destination pixel at different scale factors (LDS bank-conflict / staging study)."""
+    out = []
+    ud = vali.PySurfaceUD(DEV)
+    for (sw, sh, dw, dh) in ((3840, 2160, 1920, 1080), (1920, 1080, 1920, 1080), (5760, 3240, 1920, 1080),
+                             (2880, 1620, 1920, 1080), (960, 540, 1920, 1080), (2560, 1440, 1920, 1080)):
+        srcs = [vali.Surface.Make(vali.NV12, sw, sh, DEV) for _ in range(n)]
+        dsts = [vali.Surface.Make(vali.RGB, dw, dh, DEV) for _ in range(n)]
+        fill(srcs)
+        b = ud.PrepareBatch(srcs, dsts)
+        ms, _ = timed(ud.Stream, lambda: ud.RunBatchAsync(b), 20)
+        out.append({"geometry": f"{sw}x{sh}->{dw}x{dh}", "scale": round(sw / dw, 3), "us_per_frame": round(ms * 1e3 / n, 3),
+                    "GBps": round((sw * sh * 1.5 + dw * dh * 3) * n / (ms * 1e-3) / 1e9, 1)})
+    return {"config": "UD NV12->RGB 1080p output at several source scales", "results": out}
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["cfg2", "cfg3", "cfg4"]
     for name in which:
