@@ -294,8 +294,8 @@ __device__ __forceinline__ LzTap make_lz_tap(int x, float scale) {
 }
 __device__ __forceinline__ int clampi(int v, int hi) { return min(max(v, 0), hi); }
 
-constexpr int kLzCpr = 2;                              // 16-byte chunks per lane per row
-constexpr int kLzRowBytes = kLzCpr * kWave * 16;       // 2 KiB: the staged source row
+constexpr int kLzCpr = 4;                              // 16-byte chunks per lane per row
+constexpr int kLzRowBytes = kLzCpr * kWave * 16;       // 4 KiB: the staged source row
 struct alignas(16) LzStage {
   uint8_t row[kLzRowBytes];
 };
