@@ -215,6 +215,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # Full-size verification on the GPU (every rank, all F frames): frame i was filled from seed
+    # frame i % nseed, so its output must equal output i % nseed byte for byte; the seed outputs
+    # themselves are what rank 0 checks against the oracle below.  The per-rank 64-bit checksum
+    # and mismatch count are summed over ranks (the optional all-reduce of SURVEY.md 8e).
+    verification = None
+    if not args.no_parity:
+        outs = [torch.from_dlpack(d) for d in pipe.dsts]
+        sums = [int(outs[i].sum(dtype=torch.int64).item()) for i in range(nseed)]
+        bad = sum(0 if torch.equal(outs[i], outs[i % nseed]) else 1 for i in range(nseed, F))
+        tot = torch.tensor([sum(sums[i % nseed] for i in range(F)), bad, F], dtype=torch.int64, device=coll_dev)
+        if dist is not None:
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        verification = {"frames_verified_on_gpu": int(tot[2]), "frames_mismatching": int(tot[1]),
+                        "checksum_of_checksums": int(tot[0])}
+        del outs
+
     parity = None
     if not args.no_parity and rank == 0:
         from oracle import oracle as o
@@ -261,6 +277,8 @@ def main():
         }
         if parity is not None:
             out["parity_vs_oracle"] = parity
+        if verification is not None:
+            out["verification"] = verification
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(W, H, coeffs, args.cpu_seconds)
         if world == 1 and not args.no_secondary:

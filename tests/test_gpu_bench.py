@@ -33,6 +33,9 @@ def test_bench_single_gpu_contract(gpu):
     assert j["parity_vs_oracle"]["max_abs_diff_lsb"] == 0
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] >= 1
     assert "workload" in j["config"] and "model" not in j["config"]
+    assert j["verification"] == {"frames_verified_on_gpu": 16, "frames_mismatching": 0,
+                                 "checksum_of_checksums": j["verification"]["checksum_of_checksums"]}
+    assert [c["config"][:4] for c in j["secondary"]] == ["cfg2", "cfg3", "cfg4"]
 
 
 def test_bench_two_ranks_share_one_gpu(gpu):
@@ -45,3 +48,4 @@ def test_bench_two_ranks_share_one_gpu(gpu):
     j = last_json(r.stdout)
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 32 and j["scaling"] == "weak"
     assert "cpu_baseline" not in j and j["value"] > 0
+    assert j["verification"]["frames_verified_on_gpu"] == 32 and j["verification"]["frames_mismatching"] == 0
