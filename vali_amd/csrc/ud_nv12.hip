@@ -303,30 +303,75 @@ __global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
   // texels -> c0/c1/c2 (scaled by UdScale) of the lane's 4 pixels
   constexpr float kScale = UdScale<T, OUT>::value;
   constexpr float kNorm = TexelTraits<T>::kInvDen * kScale;
+  // luma(r, p, t): texel of source row r (0/1), pixel p, horizontal tap t (0/1);
+  // chroma(r, p, t): the interleaved pair, U in the low T-sized field, V in the high one.
   auto sample = [&](const RowTaps& rt, auto luma, auto chroma, float (&c0)[4], float (&c1)[4], float (&c2)[4]) {
-    u32 l[4][4], cu[4][4], cv[4][4]; // [pixel][00,10,01,11]
+    u32 sy[4], su[4], sv[4]; // the integer filter sums S (see the header of this file)
+    if constexpr (E == 1) {
+      // 8-bit texels: the horizontal stage fits 16 bits exactly (w0 q0 + w1 q1 <= 256 * 255),
+      // so it runs two rows at a time in packed 16-bit lanes, and the vertical stage is one
+      // 2-element dot product:
+      //   A = {T[row0][i0], T[row1][i0]}  B = {T[row0][i1], T[row1][i1]}        (v_perm_b32)
+      //   H = A * {w0,w0} + B * {w1,w1}           (v_pk_mul_lo_u16, v_pk_mad_u16) = {top, bot}
+      //   S = H.x * wy0 + H.y * wy1                                         (v_dot2_u32_u16)
+      // 5 VALU per component instead of 6 multiplies + byte extraction; same integers.
+      typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+      auto as_v2 = [](u32 w) { return __builtin_bit_cast(v2u16, w); };
+      const v2u16 wyl = as_v2(rt.ty.w0 | (rt.ty.w1 << 16)), wyc = as_v2(rt.tcy.w0 | (rt.tcy.w1 << 16));
+      u32 l[4][2][2], c[4][2][2]; // [pixel][tap][row]: all LDS / global reads first
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      l[p][0] = luma(0, p, 0); l[p][1] = luma(0, p, 1);
-      l[p][2] = luma(1, p, 0); l[p][3] = luma(1, p, 1);
-      chroma(0, p, 0, cu[p][0], cv[p][0]); chroma(0, p, 1, cu[p][1], cv[p][1]);
-      chroma(1, p, 0, cu[p][2], cv[p][2]); chroma(1, p, 1, cu[p][3], cv[p][3]);
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          l[p][t][0] = luma(0, p, t); l[p][t][1] = luma(1, p, t);
+          c[p][t][0] = chroma(0, p, t); c[p][t][1] = chroma(1, p, t);
+        }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const v2u16 wx0 = as_v2(tx[p].w0 * 0x10001u), wx1 = as_v2(tx[p].w1 * 0x10001u);
+        const v2u16 wc0 = as_v2(tcx[p].w0 * 0x10001u), wc1 = as_v2(tcx[p].w1 * 0x10001u);
+        // byte 0 of row 0 -> lane 0, byte 0 of row 1 -> lane 1 (selector: 0x0c = constant 0)
+        const v2u16 ya = as_v2(__builtin_amdgcn_perm(l[p][0][1], l[p][0][0], 0x0c040c00u));
+        const v2u16 yb = as_v2(__builtin_amdgcn_perm(l[p][1][1], l[p][1][0], 0x0c040c00u));
+        const v2u16 ua = as_v2(__builtin_amdgcn_perm(c[p][0][1], c[p][0][0], 0x0c040c00u));
+        const v2u16 ub = as_v2(__builtin_amdgcn_perm(c[p][1][1], c[p][1][0], 0x0c040c00u));
+        const v2u16 va = as_v2(__builtin_amdgcn_perm(c[p][0][1], c[p][0][0], 0x0c050c01u));
+        const v2u16 vb = as_v2(__builtin_amdgcn_perm(c[p][1][1], c[p][1][0], 0x0c050c01u));
+        sy[p] = __builtin_amdgcn_udot2(ya * wx0 + yb * wx1, wyl, 0u, false);
+        su[p] = __builtin_amdgcn_udot2(ua * wc0 + ub * wc1, wyc, 0u, false);
+        sv[p] = __builtin_amdgcn_udot2(va * wc0 + vb * wc1, wyc, 0u, false);
+      }
+    } else {
+      u32 l[4][4], cu[4][4], cv[4][4]; // [pixel][00,10,01,11]
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        l[p][0] = luma(0, p, 0); l[p][1] = luma(0, p, 1);
+        l[p][2] = luma(1, p, 0); l[p][3] = luma(1, p, 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const u32 w = chroma(q >> 1, p, q & 1);
+          cu[p][q] = w & 0xffffu; cv[p][q] = w >> 16;
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        // every factor fits in 24 bits (weights <= 256, texels <= 65535, row sums < 2^24):
+        // v_mul_u32_u24 / v_mad_u32_u24 are full rate, v_mul_lo_u32 is quarter rate
+        auto bil = [](u32 wy0, u32 wy1, u32 wx0, u32 wx1, const u32 (&q)[4]) {
+          const u32 top = __umul24(wx0, q[0]) + __umul24(wx1, q[1]);
+          const u32 bot = __umul24(wx0, q[2]) + __umul24(wx1, q[3]);
+          return __umul24(wy0, top) + __umul24(wy1, bot);
+        };
+        sy[p] = bil(rt.ty.w0, rt.ty.w1, tx[p].w0, tx[p].w1, l[p]);
+        su[p] = bil(rt.tcy.w0, rt.tcy.w1, tcx[p].w0, tcx[p].w1, cu[p]);
+        sv[p] = bil(rt.tcy.w0, rt.tcy.w1, tcx[p].w0, tcx[p].w1, cv[p]);
+      }
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      // every factor fits in 24 bits (weights <= 256, texels <= 65535, row sums < 2^24):
-      // v_mul_u32_u24 / v_mad_u32_u24 are full rate, v_mul_lo_u32 is quarter rate
-      auto bil = [](u32 wy0, u32 wy1, u32 wx0, u32 wx1, const u32 (&q)[4]) {
-        const u32 top = __umul24(wx0, q[0]) + __umul24(wx1, q[1]);
-        const u32 bot = __umul24(wx0, q[2]) + __umul24(wx1, q[3]);
-        return __umul24(wy0, top) + __umul24(wy1, bot);
-      };
-      const u32 sy = bil(rt.ty.w0, rt.ty.w1, tx[p].w0, tx[p].w1, l[p]);
-      const u32 su = bil(rt.tcy.w0, rt.tcy.w1, tcx[p].w0, tcx[p].w1, cu[p]);
-      const u32 sv = bil(rt.tcy.w0, rt.tcy.w1, tcx[p].w0, tcx[p].w1, cv[p]);
-      const float ny = (float)sy * kNorm;
-      const float nu = (float)su * kNorm;
-      const float nv = (float)sv * kNorm;
+      const float ny = (float)sy[p] * kNorm;
+      const float nu = (float)su[p] * kNorm;
+      const float nv = (float)sv[p] * kNorm;
       if constexpr (OUT == UD_YUV444) {
         c0[p] = ny; c1[p] = nu; c2[p] = nv;
       } else {
@@ -354,9 +399,9 @@ __global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
       float c0[4], c1[4], c2[4];
       sample(rt,
              [&](int r, int p, int t) { return (u32)gload<T>(yrow[r] + (size_t)(t ? tx[p].i1 : tx[p].i0) * E); },
-             [&](int r, int p, int t, u32& u, u32& v) {
+             [&](int r, int p, int t) {
                const uint8_t* q = crow[r] + (size_t)(t ? tcx[p].i1 : tcx[p].i0) * 2 * E;
-               u = (u32)gload<T>(q); v = (u32)gload<T>(q + E);
+               return (u32)gload<T>(q) | ((u32)gload<T>(q + E) << (8 * E));
              },
              c0, c1, c2);
       ud_store<T, OUT>(d, x0, y, n, c0, c1, c2);
@@ -424,14 +469,11 @@ __global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
         float c0[4], c1[4], c2[4];
         sample(cur,
                [&](int r, int p, int t) { return (u32) * (const T*)(st.luma[r] + ly[p][t]); },
-               [&](int r, int p, int t, u32& u, u32& v) {
-                 if constexpr (E == 1) { // U and V are neighbours: one 16-bit LDS read
-                   const u32 w = *(const uint16_t*)(st.chroma[r] + lc[p][t]);
-                   u = w & 0xffu; v = w >> 8;
-                 } else {
-                   const u32 w = *(const u32*)(st.chroma[r] + lc[p][t]);
-                   u = w & 0xffffu; v = w >> 16;
-                 }
+               [&](int r, int p, int t) { // U and V are neighbours: one LDS read for the pair
+                 if constexpr (E == 1)
+                   return (u32) * (const uint16_t*)(st.chroma[r] + lc[p][t]);
+                 else
+                   return *(const u32*)(st.chroma[r] + lc[p][t]);
                },
                c0, c1, c2);
         ud_store<T, OUT>(d, x0, y, n, c0, c1, c2);
