@@ -280,6 +280,13 @@ __global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
     tcx[p] = make_tap(cx * 0.5f, sw / 2); // == x / (scale_x * 2.0f)
   }
   const int n = min(4, dw - x0); // valid pixels of this lane (<= 0: tail lane, staging only)
+  // column weights replicated into both 16-bit lanes (8-bit sources, see sample())
+  u32 pw[4][4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    pw[p][0] = tx[p].w0 * 0x10001u; pw[p][1] = tx[p].w1 * 0x10001u;
+    pw[p][2] = tcx[p].w0 * 0x10001u; pw[p][3] = tcx[p].w1 * 0x10001u;
+  }
 
   // row taps: lane r evaluates row y_first + r; rows are read back as scalars
   struct RowTaps {
@@ -328,8 +335,7 @@ __global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
         }
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        const v2u16 wx0 = as_v2(tx[p].w0 * 0x10001u), wx1 = as_v2(tx[p].w1 * 0x10001u);
-        const v2u16 wc0 = as_v2(tcx[p].w0 * 0x10001u), wc1 = as_v2(tcx[p].w1 * 0x10001u);
+        const v2u16 wx0 = as_v2(pw[p][0]), wx1 = as_v2(pw[p][1]), wc0 = as_v2(pw[p][2]), wc1 = as_v2(pw[p][3]);
         // byte 0 of row 0 -> lane 0, byte 0 of row 1 -> lane 1 (selector: 0x0c = constant 0)
         const v2u16 ya = as_v2(__builtin_amdgcn_perm(l[p][0][1], l[p][0][0], 0x0c040c00u));
         const v2u16 yb = as_v2(__builtin_amdgcn_perm(l[p][1][1], l[p][1][0], 0x0c040c00u));
