@@ -68,6 +68,8 @@ typedef void* vali_event_t;  /* hipEvent_t  */
  *   RGB_PLANAR/RGB_32F_PLANAR plane[c] = base + c*height*pitch
  *   Y              plane[0]
  * width/height are in pixels of the full-resolution (luma) grid.
+ * Every plane must be smaller than 4 GiB (the gather kernels form row offsets in 32 bits);
+ * the single-surface entry points check it (VALI_ERR_INVALID_ARG), batch callers guarantee it.
  */
 typedef struct vali_surface {
   void* plane[3];

@@ -42,6 +42,16 @@ inline hipStream_t as_stream(vali_stream_t s) { return (hipStream_t)s; }
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// The gather kernels (resize, UD, rotate, pre-processing) form row offsets in 32 bits
+// (s_mul_i32 instead of a 64-bit VALU multiply-add per row): every plane of a surface must
+// stay below 4 GiB.  3 * height rows bounds the tallest plane layout (stacked planar).
+inline bool planes_fit_32bit(const vali_surface& s) {
+  for (int c = 0; c < 3; ++c)
+    if (s.plane[c] && (s.pitch[c] < 0 || (uint64_t)s.pitch[c] * (uint64_t)s.height * 3u >= (1ull << 32)))
+      return false;
+  return true;
+}
+
 } // namespace vali
 
 #define VALI_HIP_CHECK(expr)                                                   \

@@ -206,6 +206,7 @@ int vali_nv12_preproc(const vali_surface* src, const vali_surface* dst, const va
   VALI_REQUIRE(src->width >= 2 && src->height >= 2 && dst->width >= 2 && dst->height >= 2, "empty surface");
   VALI_REQUIRE(((src->width | src->height | dst->width | dst->height) & 1) == 0, "4:2:0 needs even sizes");
   VALI_REQUIRE(src->plane[0] && src->plane[1] && dst->plane[0], "null plane");
+  VALI_REQUIRE(planes_fit_32bit(*src) && planes_fit_32bit(*dst), "plane of 4 GiB or more");
   if (dst->format == VALI_FMT_RGB_32F_PLANAR)
     VALI_REQUIRE(dst->plane[1] && dst->plane[2], "null dst plane");
   PreprocArgs a = {};

@@ -539,6 +539,7 @@ int vali_resize(const vali_surface* src, const vali_surface* dst, int interpolat
   VALI_REQUIRE(src->format == dst->format, "src/dst format mismatch");
   VALI_REQUIRE(src->width > 0 && src->height > 0 && dst->width > 0 && dst->height > 0, "empty surface");
   VALI_REQUIRE(src->plane[0] && dst->plane[0], "null plane");
+  VALI_REQUIRE(planes_fit_32bit(*src) && planes_fit_32bit(*dst), "plane of 4 GiB or more");
   if (interpolation != VALI_INTERP_LINEAR && interpolation != VALI_INTERP_LANCZOS)
     return fail(VALI_ERR_UNSUPPORTED, "resize: interpolation %d not implemented", interpolation);
   ResizeArgs a = {};

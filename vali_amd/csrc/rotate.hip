@@ -341,6 +341,7 @@ int vali_rotate(const vali_surface* src, const vali_surface* dst, double angle, 
   VALI_REQUIRE(src->format == dst->format, "src/dst format mismatch");
   VALI_REQUIRE(src->width > 0 && src->height > 0 && dst->width > 0 && dst->height > 0, "empty surface");
   VALI_REQUIRE(src->plane[0] && dst->plane[0], "null plane");
+  VALI_REQUIRE(planes_fit_32bit(*src) && planes_fit_32bit(*dst), "plane of 4 GiB or more");
   RotArgs a = {};
   a.sw = src->width; a.sh = src->height; a.dw = dst->width; a.dh = dst->height;
   int elem = 1;

@@ -570,6 +570,7 @@ int vali_ud_nv12(const vali_surface* src, const vali_surface* dst, vali_stream_t
   VALI_REQUIRE(src->width >= 2 && src->height >= 2 && dst->width > 0 && dst->height > 0,
                "empty surface");
   VALI_REQUIRE(src->plane[0] && src->plane[1] && dst->plane[0], "null plane");
+  VALI_REQUIRE(planes_fit_32bit(*src) && planes_fit_32bit(*dst), "plane of 4 GiB or more");
   if (dst->format != VALI_FMT_RGB && dst->format != VALI_FMT_RGB_32F)
     VALI_REQUIRE(dst->plane[1] && dst->plane[2], "null dst plane");
   UdArgs a = {};
