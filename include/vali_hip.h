@@ -57,6 +57,7 @@ enum vali_pixel_format {
 
 typedef void* vali_stream_t; /* hipStream_t */
 typedef void* vali_event_t;  /* hipEvent_t  */
+typedef void* vali_graph_t;  /* hipGraphExec_t */
 
 /*
  * A borrowed view of one surface: what the reference hands to NPP as
@@ -116,6 +117,19 @@ VALI_API int vali_event_destroy(int device, vali_event_t event);
 VALI_API int vali_event_record(int device, vali_event_t event, vali_stream_t stream);
 VALI_API int vali_event_sync(int device, vali_event_t event);
 VALI_API int vali_event_elapsed_ms(vali_event_t start, vali_event_t stop, float* ms);
+
+/*
+ * Stream capture (no reference counterpart: the reference issues every NPP call eagerly).
+ * Per-frame chains of small launches (BASELINE config 2: 1080p, batch 1) are bound by the
+ * ~5 us host cost of each launch, not by the GPU.  Between capture_begin and capture_end every
+ * asynchronous vali_* call on `stream` is RECORDED instead of executed (device pointers and
+ * sizes are frozen into the graph); vali_graph_launch replays the whole chain with one
+ * submission.  Capture is thread-local; do not synchronise or allocate while capturing.
+ */
+VALI_API int vali_graph_capture_begin(int device, vali_stream_t stream);
+VALI_API int vali_graph_capture_end(int device, vali_stream_t stream, vali_graph_t* graph);
+VALI_API int vali_graph_launch(int device, vali_graph_t graph, vali_stream_t stream);
+VALI_API int vali_graph_destroy(int device, vali_graph_t graph);
 
 /* cuMemAllocPitch / cuMemAlloc / cuMemFree (SurfacePlane.cpp:186-213).
  * Pitch policy: width_bytes rounded up to 256 B, so every row starts on two

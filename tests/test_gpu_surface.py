@@ -169,3 +169,38 @@ def test_two_threads_two_streams(vali, gpu, oracle):
     [t.join() for t in ts]
     assert not errors, errors
     assert results == {0: True, 1: True, 2: True, 3: True}
+
+
+def test_stream_capture_replays_a_chain(vali, gpu, oracle):
+    """StreamCapture: resize -> convert -> planar recorded once, replayed per frame; results are
+    the eager results, for every refill of the captured input surface."""
+    from conftest import make_nv12
+
+    w, h = 1280, 720
+    stream = vali._native.shim.stream_create(gpu)
+    rs, cvt = vali.PySurfaceResizer(vali.NV12, gpu, stream), vali.PySurfaceConverter(gpu, stream)
+    up, dn = vali.PyFrameUploader(gpu, stream), vali.PySurfaceDownloader(gpu, stream)
+    cc = vali.ColorspaceConversionContext(vali.ColorSpace.BT_709, vali.ColorRange.MPEG)
+    src = vali.Surface.Make(vali.NV12, w, h, gpu)
+    half = vali.Surface.Make(vali.NV12, w // 2, h // 2, gpu)
+    rgb = vali.Surface.Make(vali.RGB, w // 2, h // 2, gpu)
+    pl = vali.Surface.Make(vali.RGB_PLANAR, w // 2, h // 2, gpu)
+    # warm every kernel once outside the capture (module loading is not capturable)
+    assert rs.Run(src, half)[0] and cvt.Run(half, rgb, cc)[0] and cvt.Run(rgb, pl)[0]
+    cap = vali.StreamCapture(stream, gpu).Keep(src, half, rgb, pl)
+    with cap:
+        assert rs.RunAsync(src, half)[0]
+        assert cvt.RunAsync(half, rgb, cc)[0]
+        assert cvt.RunAsync(rgb, pl)[0]
+    for seed in (1, 2, 3):
+        nv = make_nv12(w, h, seed)
+        assert up.Run(nv.reshape(-1), src)[0]
+        vali._native.shim.memset2d_async(gpu, pl._planes[0].GpuMem, pl._planes[0].Pitch, 0, w // 2, 3 * h // 2, stream)
+        cap.Launch()
+        out = np.zeros(pl.HostSize, np.uint8)
+        assert dn.Run(pl, out)[0]
+        small = oracle.resize_surface(nv.reshape(-1), "NV12", w, h, w // 2, h // 2).reshape(h * 3 // 4, w // 2)
+        want = oracle.nv12_to_rgb(small, w // 2, h // 2, oracle.csc(1), "RGB_PLANAR").reshape(-1)
+        assert np.array_equal(out, want)
+    with pytest.raises(RuntimeError):
+        vali.StreamCapture(stream, gpu).Launch()

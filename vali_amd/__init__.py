@@ -8,7 +8,7 @@ from ._native import shim as _shim  # noqa: F401  (fails loudly if the HIP libra
 from .codecs import PyDecoder, PyFrameConverter, PyNvEncoder, PyNvJpegEncoder
 from .enums import (ColorRange, ColorSpace, ColorspaceConversionContext, DLDeviceType, Interpolation,
                     PixelFormat, TaskExecDetails, TaskExecInfo, TaskExecStatus, export_values)
-from .runtime import CudaStreamEvent, GetNumGpus, HipResMgr
+from .runtime import CudaStreamEvent, GetNumGpus, HipResMgr, StreamCapture
 from .surface import Surface, SurfacePlane
 from .buffer import CudaBuffer
 from .tasks import (PySurfaceConverter, PySurfacePreprocessor, PySurfaceResizer, PySurfaceRotator, PySurfaceUD,

@@ -252,6 +252,18 @@ PYBIND11_MODULE(_vali_shim, m) {
     return ms;
   });
 
+  m.def("graph_capture_begin",
+        [](int device, uintptr_t s) { check(vali_graph_capture_begin(device, P(s)), "vali_graph_capture_begin"); });
+  m.def("graph_capture_end", [](int device, uintptr_t s) {
+    vali_graph_t g = nullptr;
+    check(vali_graph_capture_end(device, P(s), &g), "vali_graph_capture_end");
+    return (uintptr_t)g;
+  });
+  m.def("graph_launch",
+        [](int device, uintptr_t g, uintptr_t s) { check(vali_graph_launch(device, P(g), P(s)), "vali_graph_launch"); },
+        py::call_guard<py::gil_scoped_release>());
+  m.def("graph_destroy", [](int device, uintptr_t g) { return vali_graph_destroy(device, P(g)); });
+
   m.def("mem_alloc_pitch", [](int device, size_t width_bytes, size_t height) {
     void* p = nullptr;
     size_t pitch = 0;

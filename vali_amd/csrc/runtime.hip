@@ -167,6 +167,44 @@ int vali_event_elapsed_ms(vali_event_t start, vali_event_t stop, float* ms) {
   return VALI_OK;
 }
 
+// ---- stream capture: a chain of asynchronous vali_* calls replayed as ONE hipGraph launch ----
+int vali_graph_capture_begin(int device, vali_stream_t stream) {
+  VALI_REQUIRE(stream, "capture needs an explicit (non-null) stream");
+  VALI_DEVICE(device);
+  VALI_HIP_CHECK(hipStreamBeginCapture(as_stream(stream), hipStreamCaptureModeThreadLocal));
+  return VALI_OK;
+}
+
+int vali_graph_capture_end(int device, vali_stream_t stream, vali_graph_t* graph) {
+  VALI_REQUIRE(stream && graph, "null argument");
+  VALI_DEVICE(device);
+  hipGraph_t g = nullptr;
+  VALI_HIP_CHECK(hipStreamEndCapture(as_stream(stream), &g));
+  if (!g)
+    return fail(VALI_ERR_RUNTIME, "vali_graph_capture_end: capture was invalidated");
+  hipGraphExec_t exec = nullptr;
+  const hipError_t e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess)
+    return fail(VALI_ERR_RUNTIME, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+  *graph = (vali_graph_t)exec;
+  return VALI_OK;
+}
+
+int vali_graph_launch(int device, vali_graph_t graph, vali_stream_t stream) {
+  VALI_REQUIRE(graph, "null graph");
+  VALI_DEVICE(device);
+  VALI_HIP_CHECK(hipGraphLaunch((hipGraphExec_t)graph, as_stream(stream)));
+  return VALI_OK;
+}
+
+int vali_graph_destroy(int device, vali_graph_t graph) {
+  VALI_DEVICE(device);
+  if (graph)
+    VALI_HIP_CHECK(hipGraphExecDestroy((hipGraphExec_t)graph));
+  return VALI_OK;
+}
+
 int vali_mem_alloc_pitch(int device, size_t width_bytes, size_t height, void** dptr,
                          size_t* pitch) {
   VALI_REQUIRE(dptr && pitch, "null argument");
