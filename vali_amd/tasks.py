@@ -38,8 +38,8 @@ def _csc(coeffs):
 def _status(rc: int) -> TaskExecDetails:
     """C status -> TaskExecDetails (the reference maps NppStatus the same way, e.g.
     TaskConvertSurface.cpp:151-155)."""
-    if rc == shim.OK:
-        return TaskExecDetails.ok()
+    if rc == 0:              # shim.OK; the shared immutable success object (hot path)
+        return _S_OK
     if rc == shim.ERR_INVALID_ARG:
         return TaskExecDetails.failed(TaskExecInfo.INVALID_INPUT, shim.last_error())
     if rc == shim.ERR_UNSUPPORTED:
@@ -47,6 +47,7 @@ def _status(rc: int) -> TaskExecDetails:
     raise RuntimeError("HIP failure: " + shim.last_error())
 
 
+_S_OK = TaskExecDetails.ok()
 _S_INVALID = TaskExecDetails.failed(TaskExecInfo.INVALID_INPUT, "invalid src / dst")
 _S_UNSUPP_CC = TaskExecDetails.failed(TaskExecInfo.UNSUPPORTED_FMT_CONV_PARAMS,
                                       "unsupported cc_ctx params")
@@ -65,15 +66,22 @@ def _nv12_variant(cc_ctx: Optional[ColorspaceConversionContext]):
     return None
 
 
+_MISSING = object()
+_nv12_csc_cache = {}    # (color_space, color_range) | None -> shim.Csc | None (unsupported)
+
+
 def _nv12_rgb(io, stream: int, cc_ctx, csc=None) -> TaskExecDetails:
     """nv12_rgb / nv12_bgr (TaskConvertSurface.cpp:61-156).  The reference's nv12_bgr
     falls off the end of the function (its return sits after `break`, :100-105); here
     BGR simply follows the RGB logic with the channel order reversed."""
     if csc is None:     # `csc` = a matrix handed in from outside (the multi-GPU broadcast)
-        coeffs = _nv12_variant(cc_ctx)
-        if coeffs is None:
+        key = (cc_ctx.color_space, cc_ctx.color_range) if cc_ctx is not None else None
+        csc = _nv12_csc_cache.get(key, _MISSING)
+        if csc is _MISSING:
+            coeffs = _nv12_variant(cc_ctx)
+            csc = _nv12_csc_cache[key] = _csc(coeffs) if coeffs is not None else None
+        if csc is None:
             return _S_UNSUPP_CC
-        csc = _csc(coeffs)
     return _status(io.nv12_to_rgb(stream, csc))
 
 
