@@ -229,8 +229,9 @@ typedef struct vali_preproc_params {
 VALI_API int vali_nv12_preproc(const vali_surface* src, const vali_surface* dst,
                                const vali_preproc_params* params, vali_stream_t stream);
 VALI_API int vali_nv12_preproc_batch(const vali_surface* d_src, const vali_surface* d_dst, int n,
-                                     int dst_width, int dst_height, int dst_format,
-                                     const vali_preproc_params* params, vali_stream_t stream);
+                                     int src_width, int src_height, int dst_width, int dst_height,
+                                     int dst_format, const vali_preproc_params* params,
+                                     vali_stream_t stream);
 
 /* ---- UD: chroma upsample + resize (+ YUV->RGB) in one pass ---------------------- */
 

@@ -22,8 +22,8 @@
 //
 // Work decomposition: lane = 4 dst px x 2 rows (one chroma sample pair per row pair), so each
 // planar store instruction is one float4 per lane = 1 KiB contiguous per wave; a workgroup
-// covers 256 x 32 dst pixels (each wave walks 4 row pairs) and the table is built once per
-// workgroup.  Same-size inputs stream (dword luma loads); resized inputs gather their taps
+// covers 1024 x 8 dst pixels (the 4 waves side by side, each walking 4 row pairs, so a plane
+// row leaves the workgroup as 4 KiB contiguous) and the table is built once per workgroup.  Same-size inputs stream (dword luma loads); resized inputs gather their taps
 // through L1/L2 (the destination of a network input is small, the traffic is the source).
 // Oracle: composition of vali_oracle_resize_plane, vali_oracle_nv12_to_rgb and float32
 // numpy arithmetic (tests/test_gpu_preproc.py, tests/test_oracle_preproc.py).
@@ -42,8 +42,12 @@ struct PreprocArgs {
 };
 
 constexpr int kPpRowPairsPerWave = 4;
-constexpr int kPpTileH = kWavesPerBlock * kPpRowPairsPerWave * 2; // 32 dst rows
+constexpr int kPpTileH = kPpRowPairsPerWave * 2;                 // 8 dst rows
+constexpr int kPpTileW = kWavesPerBlock * kWave * 4;             // 1024 dst px: the 4 waves sit side by side
 
+// SAME = source and destination sizes are equal (decided on the host): that instantiation
+// carries none of the resize code and fits twice as many waves per SIMD.
+template <bool SAME>
 __global__ void __launch_bounds__(kBlock) k_nv12_preproc(const PreprocArgs a) {
   __shared__ float lut[3][256];
   u32 tile_x, tile_y, frame;
@@ -67,18 +71,18 @@ __global__ void __launch_bounds__(kBlock) k_nv12_preproc(const PreprocArgs a) {
   const vali_csc k = a.prm.csc;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int x0 = (tile_x * 64 + lane) * 4;
+  const int x0 = tile_x * kPpTileW + (wave * kWave + lane) * 4;
   if (x0 >= dw)
     return;
   const int n = min(4, dw - x0); // dw is even: n is 2 or 4
-  const bool same = sw == dw && sh == dh;
+  constexpr bool same = SAME;
   const bool fast_luma = same && ((((uintptr_t)py) | (uintptr_t)sp_y | ((uintptr_t)puv) | (uintptr_t)sp_uv) & 3u) == 0;
 
   // resize geometry (resize.hip): per plane scale = src_size / dst_size
   const float lsx = (float)sw / (float)dw, lsy = (float)sh / (float)dh;
   const float csx = (float)(sw >> 1) / (float)(dw >> 1), csy = (float)(sh >> 1) / (float)(dh >> 1);
   Lerp lx[4], cxl[2];
-  if (!same) {
+  if constexpr (!same) {
 #pragma unroll
     for (int p = 0; p < 4; ++p)
       lx[p] = make_lerp(min(x0 + p, dw - 1), lsx, sw);
@@ -89,12 +93,12 @@ __global__ void __launch_bounds__(kBlock) k_nv12_preproc(const PreprocArgs a) {
 
 #pragma unroll 1
   for (int it = 0; it < kPpRowPairsPerWave; ++it) {
-    const int y0 = tile_y * kPpTileH + (wave * kPpRowPairsPerWave + it) * 2; // wave-uniform
+    const int y0 = tile_y * kPpTileH + it * 2; // wave-uniform
     if (y0 >= dh)
       break;
     // ---- the resized NV12' texels of this lane: 2 x 4 luma, 2 chroma pairs ----
     float yv[2][4], uu[2], vv[2];
-    if (same) {
+    if constexpr (same) {
       const uint8_t* r0 = py + (u32)(y0 * sp_y) + x0;
       const uint8_t* r1 = py + (u32)((y0 + 1) * sp_y) + x0;
       const uint8_t* rc = puv + (u32)((y0 >> 1) * sp_uv) + x0;
@@ -162,8 +166,10 @@ __global__ void __launch_bounds__(kBlock) k_nv12_preproc(const PreprocArgs a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           uint8_t* q = d.p[c] + (u32)(y * dp) + (size_t)x0 * 4;
-          if (n == 4 && (((uintptr_t)q) & 15u) == 0) // (non-temporal measured 5-9 % slower here)
-            store16f(q, make_float4(o[r][c][0], o[r][c][1], o[r][c][2], o[r][c][3]));
+          // a wave writes 1 KiB, the workgroup 4 KiB contiguous per plane row: non-temporal pays
+          // in this layout (5.55 -> 5.29 us at 1080p; it cost 5-9 % with 256 x 32 tiles)
+          if (n == 4 && (((uintptr_t)q) & 15u) == 0)
+            store16f_nt(q, make_float4(o[r][c][0], o[r][c][1], o[r][c][2], o[r][c][3]));
           else
             for (int p = 0; p < n; ++p) gstore<float>(q + 4 * p, o[r][c][p]);
         }
@@ -183,12 +189,16 @@ __global__ void __launch_bounds__(kBlock) k_nv12_preproc(const PreprocArgs a) {
   }
 }
 
-static int launch_preproc(PreprocArgs& a, int dst_w, int dst_h, int dst_fmt, int n, hipStream_t stream) {
+static int launch_preproc(PreprocArgs& a, int src_w, int src_h, int dst_w, int dst_h, int dst_fmt, int n,
+                          hipStream_t stream) {
   if (dst_fmt != VALI_FMT_RGB_32F && dst_fmt != VALI_FMT_RGB_32F_PLANAR)
     return fail(VALI_ERR_UNSUPPORTED, "nv12_preproc: destination must be RGB_32F or RGB_32F_PLANAR (got %d)", dst_fmt);
   a.packed = dst_fmt == VALI_FMT_RGB_32F;
-  a.map = make_tile_map((dst_w + 255) / 256, (dst_h + kPpTileH - 1) / kPpTileH, (u32)n);
-  hipLaunchKernelGGL(k_nv12_preproc, tile_grid(a.map), dim3(kBlock), 0, stream, a);
+  a.map = make_tile_map((dst_w + kPpTileW - 1) / kPpTileW, (dst_h + kPpTileH - 1) / kPpTileH, (u32)n);
+  if (src_w == dst_w && src_h == dst_h)
+    hipLaunchKernelGGL(k_nv12_preproc<true>, tile_grid(a.map), dim3(kBlock), 0, stream, a);
+  else
+    hipLaunchKernelGGL(k_nv12_preproc<false>, tile_grid(a.map), dim3(kBlock), 0, stream, a);
   VALI_LAUNCH_CHECK();
   return VALI_OK;
 }
@@ -215,14 +225,16 @@ int vali_nv12_preproc(const vali_surface* src, const vali_surface* dst, const va
   a.prm = *params;
   hipStream_t s = as_stream(stream);
   DeviceScope scope(stream_device(s));
-  return launch_preproc(a, dst->width, dst->height, dst->format, 1, s);
+  return launch_preproc(a, src->width, src->height, dst->width, dst->height, dst->format, 1, s);
 }
 
-int vali_nv12_preproc_batch(const vali_surface* d_src, const vali_surface* d_dst, int n, int dst_width,
-                            int dst_height, int dst_format, const vali_preproc_params* params,
-                            vali_stream_t stream) {
+int vali_nv12_preproc_batch(const vali_surface* d_src, const vali_surface* d_dst, int n, int src_width,
+                            int src_height, int dst_width, int dst_height, int dst_format,
+                            const vali_preproc_params* params, vali_stream_t stream) {
   VALI_REQUIRE(d_src && d_dst && params, "null argument");
-  VALI_REQUIRE(dst_width >= 2 && dst_height >= 2 && ((dst_width | dst_height) & 1) == 0, "bad geometry");
+  VALI_REQUIRE(src_width >= 2 && src_height >= 2 && dst_width >= 2 && dst_height >= 2 &&
+                   ((src_width | src_height | dst_width | dst_height) & 1) == 0,
+               "bad geometry");
   VALI_REQUIRE(n >= 0 && n <= 65535, "batch size out of range (0..65535)");
   if (n == 0)
     return VALI_OK;
@@ -232,7 +244,7 @@ int vali_nv12_preproc_batch(const vali_surface* d_src, const vali_surface* d_dst
   a.prm = *params;
   hipStream_t s = as_stream(stream);
   DeviceScope scope(stream_device(s));
-  return launch_preproc(a, dst_width, dst_height, dst_format, n, s);
+  return launch_preproc(a, src_width, src_height, dst_width, dst_height, dst_format, n, s);
 }
 
 } // extern "C"

@@ -387,10 +387,11 @@ PYBIND11_MODULE(_vali_shim, m) {
         },
         py::call_guard<py::gil_scoped_release>());
   m.def("nv12_preproc_batch",
-        [](uintptr_t d_src, uintptr_t d_dst, int n, int dst_width, int dst_height, int dst_format,
-           const PreprocParams& p, uintptr_t stream) {
+        [](uintptr_t d_src, uintptr_t d_dst, int n, int src_width, int src_height, int dst_width,
+           int dst_height, int dst_format, const PreprocParams& p, uintptr_t stream) {
           return vali_nv12_preproc_batch((const vali_surface*)P(d_src), (const vali_surface*)P(d_dst), n,
-                                         dst_width, dst_height, dst_format, &p.p, P(stream));
+                                         src_width, src_height, dst_width, dst_height, dst_format, &p.p,
+                                         P(stream));
         },
         py::call_guard<py::gil_scoped_release>());
 

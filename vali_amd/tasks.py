@@ -506,8 +506,9 @@ class PySurfacePreprocessor(_SurfaceTask):
         p = self._params(cc_ctx)
         if p is None:
             return False, TaskExecInfo.UNSUPPORTED_FMT_CONV_PARAMS
-        d = _status(shim.nv12_preproc_batch(batch.d_src, batch.d_dst, batch.n, batch.dst_size[0],
-                                            batch.dst_size[1], int(batch.dst_format), p, self._stream))
+        d = _status(shim.nv12_preproc_batch(batch.d_src, batch.d_dst, batch.n, batch.src_size[0],
+                                            batch.src_size[1], batch.dst_size[0], batch.dst_size[1],
+                                            int(batch.dst_format), p, self._stream))
         return d.success, d.info
 
     def RunBatch(self, batch, dsts=None, cc_ctx=None) -> Tuple[bool, TaskExecInfo]:
