@@ -149,7 +149,9 @@ def main():
     # run on CPU tensors.
     backend = os.environ.get("VALI_BENCH_BACKEND", "nccl")
     coll_dev = f"cuda:{dev}" if backend == "nccl" else "cpu"
-    if world > 1:
+    # VALI_BENCH_FORCE_DIST=1: initialise the process group even for one rank, so the RCCL code
+    # path (init, broadcast, all-reduce, barrier) can be exercised on a single-GPU box
+    if world > 1 or os.environ.get("VALI_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -49,3 +49,17 @@ def test_bench_two_ranks_share_one_gpu(gpu):
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 32 and j["scaling"] == "weak"
     assert "cpu_baseline" not in j and j["value"] > 0
     assert j["verification"]["frames_verified_on_gpu"] == 32 and j["verification"]["frames_mismatching"] == 0
+
+
+def test_bench_rccl_path_single_rank(gpu):
+    """backend "nccl" (= RCCL) with one rank: process-group init with a device id, the coefficient
+    broadcast, the MAX / SUM all-reduces and the barriers all run on the GPU."""
+    env = dict(os.environ, VALI_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29618",
+               RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--frames", "16", "--cpu-seconds", "0", "--no-secondary"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    j = last_json(r.stdout)
+    assert j["n_gpus"] == 1 and j["verification"]["frames_mismatching"] == 0
+    assert j["parity_vs_oracle"]["max_abs_diff_lsb"] == 0
