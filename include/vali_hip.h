@@ -250,6 +250,19 @@ VALI_API int vali_ud_nv12_batch(const vali_surface* d_src, const vali_surface* d
                                 int src_format, int src_width, int dst_width, int dst_height,
                                 int dst_format, vali_stream_t stream);
 
+/*
+ * UD with the result written rotated by `quarter_turns` x 90 degrees (1..3; 0 = vali_ud_nv12):
+ * the fused form of the chain PySurfaceUD -> PySurfaceRotator (BASELINE config 4), bit-identical
+ * to vali_ud_nv12 followed by vali_rotate with the canonical quarter-turn shifts
+ * (PySurfaceRotator.cpp:47-73), without the intermediate surface.  NV12 -> RGB only.
+ * `dst` is the ROTATED surface: for odd quarter_turns the UD output is dst->height x dst->width.
+ */
+VALI_API int vali_ud_nv12_rot(const vali_surface* src, const vali_surface* dst, int quarter_turns,
+                              vali_stream_t stream);
+VALI_API int vali_ud_nv12_rot_batch(const vali_surface* d_src, const vali_surface* d_dst, int n,
+                                    int src_format, int src_width, int dst_width, int dst_height,
+                                    int dst_format, int quarter_turns, vali_stream_t stream);
+
 /* ---- resize: replaces nppiResize_{8u,32f}_C{1,3}R_Ctx --------------------------------- */
 
 /* Values follow NppiInterpolationMode (NPPI_INTER_LINEAR = 2 is not used by the reference;

@@ -103,3 +103,52 @@ def test_planar_sources(vali, gpu, oracle, src_fmt, dst_fmt, dt):
         want.append(oracle.resize_plane(plane, 1, dw, dh).reshape(-1))
         off += pw * ph
     assert np.array_equal(got, np.concatenate(want))
+
+
+# ---- fused UD + quarter-turn rotation (BASELINE config 4 as one pass) ---------------------------
+@pytest.mark.parametrize("angle", [90.0, 180.0, 270.0, -90.0])
+@pytest.mark.parametrize("geom", [(3840, 2160, 1920, 1080), (848, 464, 640, 360), (640, 360, 1280, 720),
+                                  (424, 232, 421, 233), (64, 48, 7, 5), (130, 70, 58, 34), (1920, 1080, 250, 251)])
+def test_ud_rotated_equals_ud_then_rotator(vali, gpu, oracle, angle, geom):
+    sw, sh, uw, uh = geom                       # uw x uh = size of the un-rotated UD output
+    nv = make_nv12(sw, sh, 23)
+    src = vali.Surface.Make(vali.NV12, sw, sh, gpu)
+    assert vali.PyFrameUploader(gpu).Run(nv.reshape(-1), src)[0]
+    odd = int(round(angle / 90.0)) % 2 == 1
+    dw, dh = (uh, uw) if odd else (uw, uh)
+    ud = vali.PySurfaceUD(gpu)
+    fused = vali.Surface.Make(vali.RGB, dw, dh, gpu)
+    assert ud.RunRotated(src, fused, angle) == (True, vali.TaskExecInfo.SUCCESS)
+    # the chain it replaces, with this library's own tasks
+    mid = vali.Surface.Make(vali.RGB, uw, uh, gpu)
+    chain = vali.Surface.Make(vali.RGB, dw, dh, gpu)
+    assert ud.Run(src, mid)[0] and vali.PySurfaceRotator(gpu).Run(mid, chain, angle)[0]
+    a = np.zeros(fused.HostSize, np.uint8)
+    b = np.zeros(chain.HostSize, np.uint8)
+    assert vali.PySurfaceDownloader(gpu).Run(fused, a)[0] and vali.PySurfaceDownloader(gpu).Run(chain, b)[0]
+    assert np.array_equal(a, b)
+    # and the CPU oracle: UD, then the exact permutation of a quarter turn
+    want = oracle.ud_nv12(nv, sw, sh, "NV12", uw, uh, "RGB").reshape(uh, uw, 3)
+    k = int(round(angle / 90.0)) % 4            # rotate.hip: 90 deg = dst(x', y') = src(W-1-y', x')
+    want = np.rot90(want, k=k)                  # np.rot90 (counter-clockwise) is that permutation
+    assert np.array_equal(a.reshape(dh, dw, 3), want)
+
+
+def test_ud_rotated_batch_and_errors(vali, gpu, oracle):
+    sw, sh, uw, uh, n = 1280, 720, 640, 360, 5
+    nv = make_nv12(sw, sh, 29)
+    srcs = [vali.Surface.Make(vali.NV12, sw, sh, gpu) for _ in range(n)]
+    for s_ in srcs:
+        assert vali.PyFrameUploader(gpu).Run(nv.reshape(-1), s_)[0]
+    dsts = [vali.Surface.Make(vali.RGB, uh, uw, gpu) for _ in range(n)]
+    ud = vali.PySurfaceUD(gpu)
+    assert ud.RunRotatedBatch(srcs, dsts, angle=270.0) == (True, vali.TaskExecInfo.SUCCESS)
+    want = np.rot90(oracle.ud_nv12(nv, sw, sh, "NV12", uw, uh, "RGB").reshape(uh, uw, 3), k=3)
+    for d in dsts:
+        out = np.zeros(d.HostSize, np.uint8)
+        assert vali.PySurfaceDownloader(gpu).Run(d, out)[0]
+        assert np.array_equal(out.reshape(uw, uh, 3), want)
+    assert ud.RunRotated(srcs[0], dsts[0], 45.0) == (False, vali.TaskExecInfo.NOT_SUPPORTED)
+    assert ud.RunRotated(srcs[0], dsts[0], 0.0) == (False, vali.TaskExecInfo.NOT_SUPPORTED)
+    planar = vali.Surface.Make(vali.RGB_PLANAR, uh, uw, gpu)
+    assert ud.RunRotated(srcs[0], planar, 90.0) == (False, vali.TaskExecInfo.NOT_SUPPORTED)

@@ -134,11 +134,16 @@ def cfg4(n=64):
     rbatch = rot.PrepareBatch(mids, outs)
     ms_rot, wall_rot = timed(ud.Stream, lambda: rot.RunBatchAsync(rbatch, angle=90.0), 30)
     ms_rot1, wall_rot1 = timed(ud.Stream, lambda: rot.RunAsync(mids[0], outs[0], 90.0), 200, 20)
+    fbatch = ud.PrepareBatch(srcs, outs)
+    ms_fused, _ = timed(ud.Stream, lambda: ud.RunRotatedBatchAsync(fbatch, angle=90.0), 30)
     b_ud, b_rot = 18662400, 12441600
     return {"config": f"cfg4 PySurfaceUD NV12 2160p->RGB 1080p (batch={n}, one launch) + PySurfaceRotator 90deg (batch, one launch)",
             "ud_us_per_frame": round(ms_ud * 1e3 / n, 3), "ud_GBps": round(b_ud * n / (ms_ud * 1e-3) / 1e9, 1),
             "rot_us_per_frame": round(ms_rot * 1e3 / n, 3), "rot_GBps": round(b_rot * n / (ms_rot * 1e-3) / 1e9, 1),
             "rot_single_call_us(stream)": round(ms_rot1 * 1e3, 3), "rot_single_call_us(host)": round(wall_rot1 * 1e3, 3),
+            "fused_ud_rot90_us_per_frame(PySurfaceUD.RunRotatedBatch)": round(ms_fused * 1e3 / n, 3),
+            "fused_GBps(18.66MB moved)": round(b_ud * n / (ms_fused * 1e-3) / 1e9, 1),
+            "fused_GBps_vs_chain_bytes(31.104MB)": round((b_ud + b_rot) * n / (ms_fused * 1e-3) / 1e9, 1),
             "chain_us_per_frame": round((ms_ud + ms_rot) * 1e3 / n, 3),
             "chain_GBps(31.104MB/frame)": round((b_ud + b_rot) * n / ((ms_ud + ms_rot) * 1e-3) / 1e9, 1),
             "frac_of_8TBps": round((b_ud + b_rot) * n / ((ms_ud + ms_rot) * 1e-3) / 1e9 / PEAK, 4)}

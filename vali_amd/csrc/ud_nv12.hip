@@ -246,22 +246,47 @@ __host__ inline UdSpan ud_span(int tile_x, int dw, int sw, float scale_x) {
 //    lane l owning the same 16 bytes of every row; the loads of row r+1 are issued before row
 //    r is sampled (register prefetch), so HBM latency overlaps the arithmetic.
 //    !STAGED (source span wider than the strip, i.e. downscale beyond ~4x): direct byte gather.
-template <typename T, int OUT, bool STAGED>
+//
+// ROT != 0 (NV12 -> packed RGB only): the UD result is written rotated by ROT quarter turns,
+// exactly what PySurfaceRotator's canonical 90 / 180 / 270 degree turn of the UD output gives
+// (rotate.hip: ROT 1: dst(x', y') = ud(W-1-y', x'); 2: ud(W-1-x', H-1-y'); 3: ud(y', H-1-x')),
+// without the intermediate surface (BASELINE config 4 as one pass: 18.7 instead of 31.1 MB).
+// For odd ROT a lane keeps its 4 pixels of all 8 rows in registers (24 bytes per pixel = the
+// 8 rows are 8 neighbouring pixels of one destination row) and stores them as 3 x 8 bytes.
+template <typename T, int OUT, bool STAGED, int ROT = 0>
 __global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
+  static_assert(ROT == 0 || (sizeof(T) == 1 && OUT == UD_RGB_U8), "rotated output: NV12 -> RGB only");
   __shared__ UdStage stage[STAGED ? kWavesPerBlock : 1];
   u32 tile_x, tile_y, frame;
-  if (!tile_of_block(a.map, tile_x, tile_y, frame))
+  if constexpr ((ROT & 1) != 0) {
+    // transposed output: consecutive workgroups walk DOWN the UD image, i.e. along the
+    // destination rows, so the 96-byte pieces of a destination line meet in L2
+    u32 t;
+    if (!frame_tile_of_block(a.map, frame, t))
+      return;
+    const u32 tiles_y = a.map.per_frame / a.map.tiles_x;
+    tile_x = t / tiles_y;
+    tile_y = t - tile_x * tiles_y;
+  } else if (!tile_of_block(a.map, tile_x, tile_y, frame)) {
     return;
+  }
   const SurfRef s = load_surface(a.d_src, a.src, frame);
   const SurfRef d = load_surface(a.d_dst, a.dst, frame);
   const uint8_t* py = s.p[0];
   const uint8_t* puv = s.p[1];
   const int sp_y = s.pitch[0], sp_uv = s.pitch[1], sw = s.width, sh = s.height;
-  const int dw = d.width, dh = d.height;
+  // size of the (virtual) un-rotated UD output
+  const int dw = (ROT & 1) ? d.height : d.width, dh = (ROT & 1) ? d.width : d.height;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int x0 = (tile_x * 64 + lane) * 4;
   const int y_first = tile_y * kUdTileH + wave * kUdRowsPerWave; // wave-uniform
+  // odd ROT: the workgroup's 256 x 32 output tile is collected in LDS and written transposed
+  // one dword per pixel (r | g << 8 | b << 16); 258 dwords per tile row: the store phase's
+  // (8 columns) x (8 row groups) of a wave then hit 64 different banks (8 g + 2 j + column)
+  constexpr int kRotStride = 256 * 4 + 8;
+  __shared__ __attribute__((aligned(16))) uint8_t rot_tile[(ROT & 1) ? kUdTileH * kRotStride : 16];
+  auto body = [&]() { // (a lambda so that its early exits still reach the transposed store below)
   if (y_first >= dh)
     return;
 
@@ -389,6 +414,44 @@ __global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
     }
   };
 
+  // ---- output: plain, or rotated by quarter turns ----
+  auto emit = [&](int rr, int y, const float (&c0)[4], const float (&c1)[4], const float (&c2)[4]) {
+    if constexpr (ROT == 0) {
+      ud_store<T, OUT>(d, x0, y, n, c0, c1, c2);
+    } else if constexpr (ROT == 2) {
+      // dst(uw-1-x, uh-1-y) = ud(x, y): the lane's 4 pixels in reverse order
+      const u32 w0 = trunc_pack4(c0[3], c1[3], c2[3], c0[2]);
+      const u32 w1 = trunc_pack4(c1[2], c2[2], c0[1], c1[1]);
+      const u32 w2 = trunc_pack4(c2[1], c0[0], c1[0], c2[0]);
+      uint8_t* row = d.p[0] + (u32)((dh - 1 - y) * d.pitch[0]);
+      uint8_t* o = row + (ptrdiff_t)(dw - 4 - x0) * 3;
+      if (n == 4 && (((uintptr_t)o) & 3u) == 0) {
+        typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+        const v3u32 w = {w0, w1, w2};
+        *(VALI_GLOBAL v3u32*)o = w;
+      } else {
+        const u32 ww[3] = {w0, w1, w2};
+        for (int p = 0; p < n; ++p) // pixel p sits at bytes 3 (3 - p) .. of the reversed group
+          for (int b = 0; b < 3; ++b) {
+            const int k = 3 * (3 - p) + b;
+            gstore<uint8_t>(row + (ptrdiff_t)(dw - 1 - x0 - p) * 3 + b, (uint8_t)(ww[k >> 2] >> (8 * (k & 3))));
+          }
+      }
+    } else {
+      // row (wave, rr) of the tile, this lane's 4 pixels
+      u32 px[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        px[p] = pack_u8<0>(__builtin_truncf(c0[p]), 0u);
+        px[p] = pack_u8<1>(__builtin_truncf(c1[p]), px[p]);
+        px[p] = pack_u8<2>(__builtin_truncf(c2[p]), px[p]);
+      }
+      uint2* t = reinterpret_cast<uint2*>(rot_tile + (wave * kUdRowsPerWave + rr) * kRotStride + lane * 16);
+      t[0] = make_uint2(px[0], px[1]);
+      t[1] = make_uint2(px[2], px[3]);
+    }
+  };
+
   // direct byte gather: source span wider than the strip, or foreign memory that is not
   // 16-byte aligned
   auto gather_rows = [&]() {
@@ -410,7 +473,7 @@ __global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
                return (u32)gload<T>(q) | ((u32)gload<T>(q + E) << (8 * E));
              },
              c0, c1, c2);
-      ud_store<T, OUT>(d, x0, y, n, c0, c1, c2);
+      emit(rr, y, c0, c1, c2);
     }
   };
 
@@ -482,13 +545,63 @@ __global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
                    return *(const u32*)(st.chroma[r] + lc[p][t]);
                },
                c0, c1, c2);
-        ud_store<T, OUT>(d, x0, y, n, c0, c1, c2);
+        emit(rr, y, c0, c1, c2);
       }
       wave_lds_sync(); // the strip is re-filled by the next row
       cur = nxt;
     }
   } else {
     gather_rows();
+  }
+  }; // body
+  body();
+
+  if constexpr ((ROT & 1) != 0) {
+    // Transposed store of the 256 (x) x 32 (y) tile: destination row <-> tile column.  8 lanes x 4
+    // pixels (12 bytes each, one global_store_dwordx3) cover the 32 pixels of a destination row
+    // segment, 32 destination rows per pass.   ROT 1: dst(y, uw-1-x) = ud(x, y), pixels in rising y;
+    // ROT 3: dst(uh-1-y, x) = ud(x, y), pixels in falling y.
+    __syncthreads();
+    const int t = threadIdx.x, g = t & 7;
+    const int yb = tile_y * kUdTileH;            // first UD row of the tile
+    const int rows = min(kUdTileH, dh - yb);     // valid UD rows in the tile
+#pragma unroll 1
+    for (int pass = 0; pass < 256 / 32; ++pass) {
+      const int cx = pass * 32 + (t >> 3);       // tile column
+      const int x = tile_x * 256 + cx;           // UD column
+      if (x >= dw)
+        continue;
+      // tile rows of this lane's 4 pixels, in destination order
+      int tr[4];
+      bool ok[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        tr[j] = ROT == 1 ? 4 * g + j : kUdTileH - 1 - (4 * g + j);
+        ok[j] = tr[j] < rows;
+      }
+      u32 px[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        px[j] = ok[j] ? *reinterpret_cast<const u32*>(rot_tile + tr[j] * kRotStride + cx * 4) : 0u;
+      }
+      // destination: row, and the x' of pixel j = 0
+      const int drow = ROT == 1 ? dw - 1 - x : x;
+      const int dx0 = ROT == 1 ? yb + 4 * g : dh - 1 - yb - (kUdTileH - 1 - 4 * g);
+      uint8_t* o = d.p[0] + (u32)(drow * d.pitch[0]) + (ptrdiff_t)dx0 * 3;
+      if (ok[0] && ok[1] && ok[2] && ok[3] && (((uintptr_t)o) & 3u) == 0) {
+        typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+        const v3u32 w = {px[0] | (px[1] << 24), (px[1] >> 8) | (px[2] << 16), (px[2] >> 16) | (px[3] << 8)};
+        *(VALI_GLOBAL v3u32*)o = w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (ok[j]) {
+            gstore<uint8_t>(o + 3 * j, (uint8_t)px[j]);
+            gstore<uint8_t>(o + 3 * j + 1, (uint8_t)(px[j] >> 8));
+            gstore<uint8_t>(o + 3 * j + 2, (uint8_t)(px[j] >> 16));
+          }
+      }
+    }
   }
 }
 
@@ -515,11 +628,22 @@ static int ud_out_kind(int src_fmt, int dst_fmt) {
   return -1;
 }
 
+// dst_w / dst_h: size of the DESTINATION surface; for odd `rot` the UD output itself is
+// dst_h x dst_w and is written turned.
 static int launch_ud(UdArgs& a, int src_fmt, int src_w, int dst_w, int dst_h, int dst_fmt, int n,
-                     hipStream_t stream) {
+                     hipStream_t stream, int rot = 0) {
   const int kind = ud_out_kind(src_fmt, dst_fmt);
   if (kind < 0)
     return fail(VALI_ERR_UNSUPPORTED, "ud_nv12: unsupported format pair %d -> %d", src_fmt, dst_fmt);
+  if (rot < 0 || rot > 3)
+    return fail(VALI_ERR_INVALID_ARG, "ud_nv12: quarter_turns must be 0..3 (got %d)", rot);
+  if (rot != 0 && !(src_fmt == VALI_FMT_NV12 && kind == UD_RGB_U8))
+    return fail(VALI_ERR_UNSUPPORTED, "ud_nv12: rotated output is implemented for NV12 -> RGB only");
+  if (rot & 1) {
+    const int t = dst_w;
+    dst_w = dst_h;
+    dst_h = t;
+  }
   a.map = make_tile_map((dst_w + 255) / 256, (dst_h + kUdTileH - 1) / kUdTileH, (u32)n);
   const dim3 grid = tile_grid(a.map), block(kBlock);
   // staged kernel iff every tile's source spans fit the strip (same float math as the device)
@@ -539,7 +663,21 @@ static int launch_ud(UdArgs& a, int src_fmt, int src_w, int dst_w, int dst_h, in
     else                                                                                    \
       hipLaunchKernelGGL((k_ud_nv12<T, K, false>), grid, block, 0, stream, a);               \
     break;
-  if (src_fmt == VALI_FMT_NV12) {
+  if (rot != 0) {
+#define VALI_UD_ROT(R)                                                                      \
+  case R:                                                                                   \
+    if (staged)                                                                             \
+      hipLaunchKernelGGL((k_ud_nv12<uint8_t, UD_RGB_U8, true, R>), grid, block, 0, stream, a);  \
+    else                                                                                    \
+      hipLaunchKernelGGL((k_ud_nv12<uint8_t, UD_RGB_U8, false, R>), grid, block, 0, stream, a); \
+    break;
+    switch (rot) {
+      VALI_UD_ROT(1)
+      VALI_UD_ROT(2)
+      VALI_UD_ROT(3)
+    }
+#undef VALI_UD_ROT
+  } else if (src_fmt == VALI_FMT_NV12) {
     switch (kind) {
       VALI_UD_CASE(uint8_t, UD_YUV444)
       VALI_UD_CASE(uint8_t, UD_RGB_U8)
@@ -579,6 +717,37 @@ int vali_ud_nv12(const vali_surface* src, const vali_surface* dst, vali_stream_t
   hipStream_t s = as_stream(stream);
   DeviceScope scope(stream_device(s));
   return launch_ud(a, src->format, src->width, dst->width, dst->height, dst->format, 1, s);
+}
+
+int vali_ud_nv12_rot(const vali_surface* src, const vali_surface* dst, int quarter_turns,
+                     vali_stream_t stream) {
+  VALI_REQUIRE(src && dst, "null argument");
+  VALI_REQUIRE(src->width >= 2 && src->height >= 2 && dst->width > 0 && dst->height > 0,
+               "empty surface");
+  VALI_REQUIRE(src->plane[0] && src->plane[1] && dst->plane[0], "null plane");
+  VALI_REQUIRE(planes_fit_32bit(*src) && planes_fit_32bit(*dst), "plane of 4 GiB or more");
+  UdArgs a = {};
+  a.src = *src;
+  a.dst = *dst;
+  hipStream_t s = as_stream(stream);
+  DeviceScope scope(stream_device(s));
+  return launch_ud(a, src->format, src->width, dst->width, dst->height, dst->format, 1, s, quarter_turns);
+}
+
+int vali_ud_nv12_rot_batch(const vali_surface* d_src, const vali_surface* d_dst, int n, int src_format,
+                           int src_width, int dst_width, int dst_height, int dst_format,
+                           int quarter_turns, vali_stream_t stream) {
+  VALI_REQUIRE(d_src && d_dst, "null argument");
+  VALI_REQUIRE(src_width >= 2 && dst_width > 0 && dst_height > 0, "empty geometry");
+  VALI_REQUIRE(n >= 0 && n <= 65535, "batch size out of range (0..65535)");
+  if (n == 0)
+    return VALI_OK;
+  UdArgs a = {};
+  a.d_src = d_src;
+  a.d_dst = d_dst;
+  hipStream_t s = as_stream(stream);
+  DeviceScope scope(stream_device(s));
+  return launch_ud(a, src_format, src_width, dst_width, dst_height, dst_format, n, s, quarter_turns);
 }
 
 int vali_ud_nv12_batch(const vali_surface* d_src, const vali_surface* d_dst, int n, int src_format,

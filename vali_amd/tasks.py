@@ -411,6 +411,44 @@ class PySurfaceUD(_SurfaceTask):
         self._sync()
         return d.success, d.info
 
+    # -- fused UD + quarter-turn rotation (new; BASELINE config 4 as ONE pass) ----------------
+    @staticmethod
+    def _quarter(angle: float):
+        """90 / 180 / 270 (any sign / multiple of 360) -> 1 / 2 / 3; None otherwise."""
+        q = float(angle) / 90.0
+        return int(round(q)) % 4 if abs(q - round(q)) < 1e-9 and int(round(q)) % 4 else None
+
+    def RunRotatedAsync(self, src: Surface, dst: Surface, angle: float) -> Tuple[bool, TaskExecInfo]:
+        """UD with the result written rotated by `angle` (a non-zero multiple of 90 degrees):
+        bit-identical to `Run(src, tmp)` + `PySurfaceRotator.Run(tmp, dst, angle)` without the
+        intermediate surface.  NV12 -> RGB only; for 90 / 270 `dst` is (UD height) x (UD width)."""
+        q = self._quarter(angle)
+        if q is None or (src.Format, dst.Format) != (F.NV12, F.RGB):
+            return False, TaskExecInfo.NOT_SUPPORTED
+        d = _status(shim.ud_nv12_rot(src.desc(), dst.desc(), q, self._stream))
+        return d.success, d.info
+
+    def RunRotated(self, src: Surface, dst: Surface, angle: float) -> Tuple[bool, TaskExecInfo]:
+        r = self.RunRotatedAsync(src, dst, angle)
+        self._sync()
+        return r
+
+    def RunRotatedBatchAsync(self, batch, dsts=None, angle: float = 90.0) -> Tuple[bool, TaskExecInfo]:
+        if not isinstance(batch, SurfaceBatch):
+            batch = SurfaceBatch(self._gpu_id, self._stream, batch, dsts)
+        q = self._quarter(angle)
+        if q is None or (batch.src_format, batch.dst_format) != (F.NV12, F.RGB):
+            return False, TaskExecInfo.NOT_SUPPORTED
+        d = _status(shim.ud_nv12_rot_batch(batch.d_src, batch.d_dst, batch.n, int(batch.src_format),
+                                           batch.src_size[0], batch.dst_size[0], batch.dst_size[1],
+                                           int(batch.dst_format), q, self._stream))
+        return d.success, d.info
+
+    def RunRotatedBatch(self, batch, dsts=None, angle: float = 90.0) -> Tuple[bool, TaskExecInfo]:
+        r = self.RunRotatedBatchAsync(batch, dsts, angle)
+        self._sync()
+        return r
+
     def RunBatchAsync(self, batch, dsts=None) -> Tuple[bool, TaskExecInfo]:
         if not isinstance(batch, SurfaceBatch):
             batch = SurfaceBatch(self._gpu_id, self._stream, batch, dsts)
