@@ -121,15 +121,112 @@ __global__ void __launch_bounds__(kBlock) k_rotate_affine(const RotArgs a) {
 // QUARTER = 3: dst(x', y') = src(y', H-1-x')   [angle 270, shift_x = H-1]
 constexpr int kRotTile = 64;
 
+// 3-byte pixels are held in LDS as ONE DWORD PER PIXEL: the column walk of the transposed
+// store then costs one aligned ds_read_b32 per pixel instead of three ds_read_u8 plus the
+// shifts to reassemble them (2.4 -> see profiles/r01_secondary.md), and a row stride of 65
+// dwords makes the (16 row groups) x (4 columns) of a wave hit 64 different banks.
+constexpr int kRotTileHRgb = 64; // 128-row tiles (384-byte destination segments) measured slower: 3.0 vs 2.4 us
+template <int QUARTER>
+__device__ __forceinline__ void rotate_tile_rgb8(const PlaneView& v, u32 tile_x, u32 tile_y) {
+  constexpr int P = 3, SD = kRotTile + 1; // LDS row stride in dwords
+  constexpr int TH = kRotTileHRgb;        // tile rows
+  __shared__ u32 lds[TH * SD];
+  const int src_w = v.sw, src_h = v.sh, dst_w = v.dw, dst_h = v.dh;
+  const uint8_t* src = v.sp;
+  uint8_t* dst = v.dp;
+  const int src_pitch = v.spitch, dst_pitch = v.dpitch;
+  const int cx = tile_x * kRotTile, ry = tile_y * TH; // src tile origin (col, row)
+  const int tw = min(kRotTile, src_w - cx), th = min(TH, src_h - ry);
+  const int t = threadIdx.x;
+
+  // phase 1: 16 lanes x 4 pixels (one 12-byte load) per source row, 16 rows per pass
+  const uint8_t* sbase = src + (size_t)ry * src_pitch + (size_t)cx * P;
+  const bool vec = ((((uintptr_t)sbase) | (uintptr_t)src_pitch) & 3u) == 0;
+  {
+  const int chunk = t & 15;
+#pragma unroll
+  for (int pass = 0; pass < TH / 16; ++pass) {
+    const int r = pass * 16 + (t >> 4);
+    if (r >= th || chunk * 4 >= tw)
+      continue;
+    const uint8_t* q = sbase + (size_t)r * src_pitch + chunk * 12;
+    u32 px[4];
+    if (vec && chunk * 4 + 4 <= tw) {
+      typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+      const v3u32 w = *(const VALI_GLOBAL v3u32*)q;
+      px[0] = w.x & 0xffffffu;
+      px[1] = (w.x >> 24) | ((w.y & 0xffffu) << 8);
+      px[2] = (w.y >> 16) | ((w.z & 0xffu) << 16);
+      px[3] = w.z >> 8;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        px[k] = chunk * 4 + k < tw ? ((u32)gload<uint8_t>(q + 3 * k) | ((u32)gload<uint8_t>(q + 3 * k + 1) << 8) |
+                                      ((u32)gload<uint8_t>(q + 3 * k + 2) << 16))
+                                   : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      lds[r * SD + chunk * 4 + k] = px[k];
+  }
+  }
+  __syncthreads();
+
+  // phase 2: dst rows.  TH/4 lanes x 4 pixels cover one dst row of the tile.
+  constexpr int kLanesPerRow = TH / 4, kRowsPerPass = kBlock / kLanesPerRow;
+  const int chunk = t % kLanesPerRow;
+#pragma unroll
+  for (int pass = 0; pass < kRotTile / kRowsPerPass; ++pass) {
+    const int lc = pass * kRowsPerPass + t / kLanesPerRow; // column of the src tile feeding this dst row
+    if (lc >= tw)
+      continue;
+    int dy_, dx0;
+    if constexpr (QUARTER == 1) {
+      dy_ = src_w - 1 - (cx + lc);
+      dx0 = ry + chunk * 4;
+    } else {
+      dy_ = cx + lc;
+      dx0 = src_h - 1 - (ry + chunk * 4 + 3);
+    }
+    if (dy_ < 0 || dy_ >= dst_h)
+      continue;
+    u32 px[4];
+    bool ok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int jj = QUARTER == 1 ? chunk * 4 + q : chunk * 4 + 3 - q;
+      ok[q] = jj < th && dx0 + q >= 0 && dx0 + q < dst_w;
+      px[q] = ok[q] ? lds[jj * SD + lc] : 0u;
+    }
+    uint8_t* o = dst + (size_t)dy_ * dst_pitch + (ptrdiff_t)dx0 * P;
+    if (ok[0] && ok[1] && ok[2] && ok[3] && (((uintptr_t)o) & 3u) == 0) {
+      typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+      const v3u32 w = {px[0] | (px[1] << 24), (px[1] >> 8) | (px[2] << 16), (px[2] >> 16) | (px[3] << 8)};
+      *(VALI_GLOBAL v3u32*)o = w;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (ok[q]) {
+          gstore<uint8_t>(o + 3 * q, (uint8_t)px[q]);
+          gstore<uint8_t>(o + 3 * q + 1, (uint8_t)(px[q] >> 8));
+          gstore<uint8_t>(o + 3 * q + 2, (uint8_t)(px[q] >> 16));
+        }
+    }
+  }
+}
+
 template <int P, int QUARTER>
 __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
   constexpr int S = kRotTile * P + 4; // LDS row stride in bytes (dword aligned, odd dwords)
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kRotTile * S];
+  __shared__ __attribute__((aligned(16))) uint8_t lds[P == 3 ? 16 : kRotTile * S];
   RotJob job;
   u32 tile_x, tile_y, frame;
   if (!rot_tile(a, job, tile_x, tile_y, frame))
     return;
   const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
+  if constexpr (P == 3) {
+    rotate_tile_rgb8<QUARTER>(v, tile_x, tile_y);
+  } else {
   const int src_w = v.sw, src_h = v.sh, dst_w = v.dw, dst_h = v.dh;
   const uint8_t* src = v.sp;
   uint8_t* dst = v.dp;
@@ -206,6 +303,7 @@ __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
             o[q * P + b] = px[q * P + b];
     }
   }
+  } // P != 3
 }
 
 // plane jobs per pixel format (RotateSurface::Run switch, RotateSurface.cpp:168-208)
@@ -298,8 +396,9 @@ static int launch_rotate(RotArgs& a, int fmt, int sw, int sh, int dw, int dh, do
     }
     j.first_tile = total;
     if (tiled) {
+      const int th = elem * j.channels == 3 ? kRotTileHRgb : kRotTile;
       j.tiles_x = (u32)(psw + kRotTile - 1) / kRotTile;
-      total += j.tiles_x * (u32)((psh + kRotTile - 1) / kRotTile);
+      total += j.tiles_x * (u32)((psh + th - 1) / th);
     } else {
       j.tiles_x = (u32)(pdw + 255) / 256;
       total += j.tiles_x * (u32)((pdh + 3) / 4);
