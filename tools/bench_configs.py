@@ -144,6 +144,7 @@ def cfg4(n=64):
             "fused_ud_rot90_us_per_frame(PySurfaceUD.RunRotatedBatch)": round(ms_fused * 1e3 / n, 3),
             "fused_GBps(18.66MB moved)": round(b_ud * n / (ms_fused * 1e-3) / 1e9, 1),
             "fused_GBps_vs_chain_bytes(31.104MB)": round((b_ud + b_rot) * n / (ms_fused * 1e-3) / 1e9, 1),
+            "fused_frac_of_8TBps(chain bytes)": round((b_ud + b_rot) * n / (ms_fused * 1e-3) / 1e9 / PEAK, 4),
             "chain_us_per_frame": round((ms_ud + ms_rot) * 1e3 / n, 3),
             "chain_GBps(31.104MB/frame)": round((b_ud + b_rot) * n / ((ms_ud + ms_rot) * 1e-3) / 1e9, 1),
             "frac_of_8TBps": round((b_ud + b_rot) * n / ((ms_ud + ms_rot) * 1e-3) / 1e9 / PEAK, 4)}
