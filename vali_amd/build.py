@@ -61,12 +61,17 @@ def oracle_path() -> Path:
 def build_kernels(force=False):
     OBJ.mkdir(exist_ok=True)
     headers = list(CSRC.glob("*.hpp")) + [ROOT / "include" / "vali_hip.h"]
-    objs = []
+    objs, todo = [], []
     for src in sorted(CSRC.glob("*.hip")):
         obj = OBJ / (src.stem + ".o")
         if force or _stale(obj, [src] + headers):
-            _run([HIPCC, *HIP_FLAGS, "-c", src, "-o", obj])
+            todo.append([HIPCC, *HIP_FLAGS, "-c", src, "-o", obj])
         objs.append(obj)
+    if todo:   # the translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 1)) as pool:
+            list(pool.map(_run, todo))
     lib = lib_path()
     if force or _stale(lib, objs):
         _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", lib,
