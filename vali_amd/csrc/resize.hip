@@ -300,10 +300,23 @@ struct alignas(16) LzStage {
   uint8_t row[kLzRowBytes];
 };
 
-template <typename T, int C>
+// The window of horizontally filtered rows: six slots of [channel][lane] float4 (the lane's 4
+// pixels).  For surfaces made of 1-channel planes only (Y, YUV4xx, RGB_PLANAR) it lives in the
+// wave's LDS (a ring addressed by a scalar head: appending a row is ONE ds_write_b128, no
+// register shifting -- the shifts were 31 % of an append's instructions); formats with a 2- or
+// 3-channel plane keep it in registers (12-18 KiB more LDS per wave costs a third of the
+// resident waves: NV12 measured 6.9 vs 5.7 us).
+template <int MAXC> struct alignas(16) LzRing { // MAXC >= 2: register window
+  float4 unused;
+};
+template <> struct alignas(16) LzRing<1> {
+  float4 slot[6][1][kWave];
+};
+
+template <typename T, int C, int MAXC>
 __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int sw, int sh,
                                              uint8_t* dp, int dpitch, int dw, int dh, u32 tx,
-                                             u32 ty, LzStage* stage_all) {
+                                             u32 ty, LzStage* stage_all, LzRing<MAXC>* ring_all) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int x0 = (tx * 64 + lane) * 4;
@@ -350,7 +363,9 @@ __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int 
 #pragma unroll
       for (int k = 0; k < 6; ++k)
         lo[p][k] = clampi(cx[p].i - 2 + k, sw - 1) * PB - byte_begin;
-    float hq[6][4][C];
+    constexpr bool kLdsRing = MAXC == 1;
+    float hq[kLdsRing ? 1 : 6][4][C]; // register window (3-channel planes only)
+    int head = 0;                      // LDS ring: slot of the oldest row
     uint4 pf[kLzCpr];
     int pf_row = -0x40000000; // logical source row held by pf
     auto issue = [&](int logical) {
@@ -370,20 +385,32 @@ __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int 
       wave_lds_sync();
       issue(logical + 1); // in flight while this row is filtered
 #pragma unroll
-      for (int p = 0; p < 4; ++p)
+      for (int ch = 0; ch < C; ++ch) {
+        float hv[4];
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) {
-#pragma unroll
-          for (int r = 0; r < 5; ++r)
-            hq[r][p][ch] = hq[r + 1][p][ch];
+        for (int p = 0; p < 4; ++p) {
           auto texel = [&](int k) { return (float)((const T*)(st.row + lo[p][k]))[ch]; };
           float h = cx[p].w[0] * texel(0);
 #pragma unroll
           for (int k = 1; k < 6; ++k)
             h = __builtin_fmaf(cx[p].w[k], texel(k), h);
-          hq[5][p][ch] = h;
+          hv[p] = h;
           __builtin_amdgcn_sched_barrier(0); // one pixel-channel at a time: bounds the live registers
         }
+        if constexpr (kLdsRing) {
+          ring_all[wave].slot[head][ch][lane] = make_float4(hv[0], hv[1], hv[2], hv[3]); // replaces the oldest
+        } else {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+#pragma unroll
+            for (int r = 0; r < 5; ++r)
+              hq[r][p][ch] = hq[r + 1][p][ch];
+            hq[5][p][ch] = hv[p];
+          }
+        }
+      }
+      if constexpr (kLdsRing)
+        head = head == 5 ? 0 : head + 1;
       wave_lds_sync(); // the strip is re-filled by the next row
     };
     int base = 0;
@@ -402,15 +429,26 @@ __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int 
       if (n > 0) {
         float res[4][C];
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+        for (int ch = 0; ch < C; ++ch) {
+          float v[4];
 #pragma unroll
-          for (int ch = 0; ch < C; ++ch) {
-            float v = cy.w[0] * hq[0][p][ch];
+          for (int r = 0; r < 6; ++r) {
+            float q[4];
+            if constexpr (kLdsRing) {
+              const int sl = head + r >= 6 ? head + r - 6 : head + r; // logical row r of the window
+              const float4 f = ring_all[wave].slot[sl][ch][lane];
+              q[0] = f.x; q[1] = f.y; q[2] = f.z; q[3] = f.w;
+            } else {
 #pragma unroll
-            for (int r = 1; r < 6; ++r)
-              v = __builtin_fmaf(cy.w[r], hq[r][p][ch], v);
-            res[p][ch] = v;
+              for (int p = 0; p < 4; ++p) q[p] = hq[r][p][ch];
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+              v[p] = r == 0 ? cy.w[0] * q[p] : __builtin_fmaf(cy.w[r], q[p], v[p]);
           }
+#pragma unroll
+          for (int p = 0; p < 4; ++p) res[p][ch] = v[p];
+        }
         store_px4<T, C>(dp + (u32)(y * dpitch) + (size_t)x0 * PB, res, (1u << n) - 1u);
       }
     }
@@ -456,13 +494,14 @@ __global__ void __launch_bounds__(kBlock) k_resize_lanczos(const ResizeArgs a) {
   if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
     return;
   __shared__ LzStage stage[kWavesPerBlock];
+  __shared__ LzRing<MAXC> ring[kWavesPerBlock];
   const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
   if (MAXC >= 3 && job.channels == 3)
-    lanczos_tile<T, 3>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage);
+    lanczos_tile<T, 3, MAXC>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage, ring);
   else if (MAXC >= 2 && job.channels == 2)
-    lanczos_tile<T, 2>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage);
+    lanczos_tile<T, 2, MAXC>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage, ring);
   else
-    lanczos_tile<T, 1>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage);
+    lanczos_tile<T, 1, MAXC>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage, ring);
 }
 
 // plane jobs per pixel format: which components, their subsampling and channel count
