@@ -301,16 +301,16 @@ struct alignas(16) LzStage {
 };
 
 // The window of horizontally filtered rows: six slots of [channel][lane] float4 (the lane's 4
-// pixels).  For surfaces made of 1-channel planes only (Y, YUV4xx, RGB_PLANAR) it lives in the
-// wave's LDS (a ring addressed by a scalar head: appending a row is ONE ds_write_b128, no
-// register shifting -- the shifts were 31 % of an append's instructions); formats with a 2- or
-// 3-channel plane keep it in registers (12-18 KiB more LDS per wave costs a third of the
-// resident waves: NV12 measured 6.9 vs 5.7 us).
-template <int MAXC> struct alignas(16) LzRing { // MAXC >= 2: register window
-  float4 unused;
-};
-template <> struct alignas(16) LzRing<1> {
+// pixels).  For 1-channel planes (Y, the planes of YUV4xx / RGB_PLANAR, the luma of NV12) it
+// lives in the wave's LDS (a ring addressed by a scalar head: appending a row is ONE
+// ds_write_b128, no register shifting -- the shifts were 31 % of an append's instructions);
+// 2- and 3-channel planes keep it in registers (12-18 KiB more LDS per wave costs a third of
+// the resident waves: NV12 with both planes in LDS measured 6.9 vs 5.7 us).
+template <int MAXC> struct alignas(16) LzRing { // one channel's window: 6 KiB per wave
   float4 slot[6][1][kWave];
+};
+template <> struct alignas(16) LzRing<3> {      // packed 3-channel formats have no 1-channel plane
+  float4 unused;
 };
 
 template <typename T, int C, int MAXC>
@@ -363,7 +363,7 @@ __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int 
 #pragma unroll
       for (int k = 0; k < 6; ++k)
         lo[p][k] = clampi(cx[p].i - 2 + k, sw - 1) * PB - byte_begin;
-    constexpr bool kLdsRing = MAXC == 1;
+    constexpr bool kLdsRing = C == 1 && MAXC <= 2;
     float hq[kLdsRing ? 1 : 6][4][C]; // register window (3-channel planes only)
     int head = 0;                      // LDS ring: slot of the oldest row
     uint4 pf[kLzCpr];
