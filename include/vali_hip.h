@@ -217,6 +217,8 @@ VALI_API int vali_convert_batch(const vali_surface* d_src, const vali_surface* d
  *   out_c = ((q_c / 255.0f) / div - mean[c]) / std_[c]          c = R, G, B ; IEEE float32
  * div = 1, mean = 0, std_ = 1 gives plain NV12 -> RGB_32F[_PLANAR].
  * dst->format: VALI_FMT_RGB_32F_PLANAR or VALI_FMT_RGB_32F; all four sizes even.
+ * 8-bit destinations (VALI_FMT_RGB, VALI_FMT_BGR, VALI_FMT_RGB_PLANAR) stop after q_c: the
+ * fused form of PySurfaceResizer -> PySurfaceConverter; div / mean / std_ are ignored.
  */
 typedef struct vali_preproc_params {
   vali_csc csc;

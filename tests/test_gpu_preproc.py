@@ -118,7 +118,7 @@ def test_preproc_batch(vali, gpu, oracle):
 def test_preproc_errors(vali, gpu):
     pp = vali.PySurfacePreprocessor(gpu)
     nv12 = vali.Surface.Make(vali.NV12, 64, 48, gpu)
-    assert pp.Run(nv12, vali.Surface.Make(vali.RGB, 64, 48, gpu)) == (False, vali.TaskExecInfo.NOT_SUPPORTED)
+    assert pp.Run(nv12, vali.Surface.Make(vali.YUV444, 64, 48, gpu)) == (False, vali.TaskExecInfo.NOT_SUPPORTED)
     assert pp.Run(vali.Surface.Make(vali.YUV420, 64, 48, gpu),
                   vali.Surface.Make(vali.RGB_32F_PLANAR, 64, 48, gpu)) == (False, vali.TaskExecInfo.NOT_SUPPORTED)
     assert pp.Run(nv12, vali.Surface.Make(vali.RGB_32F_PLANAR, 31, 24, gpu)) == (False, vali.TaskExecInfo.INVALID_INPUT)
@@ -127,3 +127,32 @@ def test_preproc_errors(vali, gpu):
         (False, vali.TaskExecInfo.UNSUPPORTED_FMT_CONV_PARAMS)                # nv12_rgb's rule, :144-148
     with pytest.raises(ValueError):
         vali.PySurfacePreprocessor(gpu, std=(1.0, 0.0, 1.0))
+
+
+@pytest.mark.parametrize("dst_fmt", ["RGB", "BGR", "RGB_PLANAR"])
+@pytest.mark.parametrize("geom", [(1920, 1080, 1920, 1080), (1920, 1080, 640, 384), (848, 464, 300, 300),
+                                  (130, 70, 58, 34), (640, 360, 1000, 500), (3840, 2160, 1280, 720)])
+def test_preproc_u8_equals_resizer_plus_converter(vali, gpu, oracle, dst_fmt, geom):
+    """8-bit destinations: the fused form of PySurfaceResizer -> PySurfaceConverter."""
+    sw, sh, dw, dh = geom
+    host = make_nv12(sw, sh, seed=geom[1] + geom[2])
+    src = upload(vali, gpu, host, sw, sh)
+    cc = vali.ColorspaceConversionContext(vali.ColorSpace.BT_709, vali.ColorRange.MPEG)
+    pf = vali.PixelFormat[dst_fmt]
+    dst = vali.Surface.Make(pf, dw, dh, gpu)
+    assert vali.PySurfacePreprocessor(gpu).Run(src, dst, cc) == (True, vali.TaskExecInfo.SUCCESS)
+    got = download(vali, gpu, dst, np.uint8)
+    # the chain on the GPU
+    cur = src
+    if (sw, sh) != (dw, dh):
+        cur = vali.Surface.Make(vali.NV12, dw, dh, gpu)
+        assert vali.PySurfaceResizer(vali.NV12, gpu).Run(src, cur)[0]
+    ref = vali.Surface.Make(pf, dw, dh, gpu)
+    assert vali.PySurfaceConverter(gpu).Run(cur, ref, cc)[0]
+    assert np.array_equal(got, download(vali, gpu, ref, np.uint8))
+    # and the oracle
+    n12 = host if (sw, sh) == (dw, dh) else oracle.resize_surface(
+        np.ascontiguousarray(host).reshape(-1), "NV12", sw, sh, dw, dh).reshape(dh * 3 // 2, dw)
+    assert np.array_equal(got, oracle.nv12_to_rgb(n12, dw, dh, oracle.csc(1), dst_fmt).reshape(-1))
+    # a non-identity normalisation cannot apply to an 8-bit destination
+    assert vali.PySurfacePreprocessor(gpu, mean=MEAN, std=STD).Run(src, dst, cc) == (False, vali.TaskExecInfo.NOT_SUPPORTED)

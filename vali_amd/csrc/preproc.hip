@@ -37,7 +37,6 @@ struct PreprocArgs {
   const vali_surface* d_dst;
   vali_surface src, dst;
   vali_preproc_params prm;
-  int packed; // dst is RGB_32F (interleaved) instead of RGB_32F_PLANAR
   TileMap map;
 };
 
@@ -47,20 +46,27 @@ constexpr int kPpTileW = kWavesPerBlock * kWave * 4;             // 1024 dst px:
 
 // SAME = source and destination sizes are equal (decided on the host): that instantiation
 // carries none of the resize code and fits twice as many waves per SIMD.
-template <bool SAME>
+// OUT: destination layout.  The float layouts apply step 3 through the table; the 8-bit ones
+// stop after step 2 (resize + colour conversion only: the other two-task chain of the samples).
+enum : int { PP_F32_PLANAR = 0, PP_F32_PACKED = 1, PP_U8_RGB = 2, PP_U8_BGR = 3, PP_U8_PLANAR = 4 };
+
+template <bool SAME, int OUT>
 __global__ void __launch_bounds__(kBlock) k_nv12_preproc(const PreprocArgs a) {
-  __shared__ float lut[3][256];
+  constexpr bool kFloat = OUT == PP_F32_PLANAR || OUT == PP_F32_PACKED;
+  __shared__ float lut[kFloat ? 3 : 1][256];
   u32 tile_x, tile_y, frame;
   if (!tile_of_block(a.map, tile_x, tile_y, frame))
     return;
-  // step 3 for every (channel, u8 value)
-  for (int e = threadIdx.x; e < 3 * 256; e += kBlock) {
-    const int c = e >> 8, q = e & 255;
-    const float f = (float)q / 255.0f;
-    const float g = f / a.prm.div;
-    lut[c][q] = (g - a.prm.mean[c]) / a.prm.std_[c];
+  if constexpr (kFloat) {
+    // step 3 for every (channel, u8 value)
+    for (int e = threadIdx.x; e < 3 * 256; e += kBlock) {
+      const int c = e >> 8, q = e & 255;
+      const float f = (float)q / 255.0f;
+      const float g = f / a.prm.div;
+      lut[c][q] = (g - a.prm.mean[c]) / a.prm.std_[c];
+    }
+    __syncthreads();
   }
-  __syncthreads();
 
   const SurfRef s = load_surface(a.d_src, a.src, frame);
   const SurfRef d = load_surface(a.d_dst, a.dst, frame);
@@ -145,43 +151,90 @@ __global__ void __launch_bounds__(kBlock) k_nv12_preproc(const PreprocArgs a) {
     }
     // ---- step 2 + 3 ----
     const ChromaTerm ct[2] = {chroma_term(uu[0], vv[0], k), chroma_term(uu[1], vv[1], k)};
-    float o[2][3][4]; // [row][channel][pixel]
+    if constexpr (kFloat) {
+      float o[2][3][4]; // [row][channel][pixel]
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+      for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const float yf = luma_term(yv[r][p], k);
-        const ChromaTerm& c = ct[p >> 1];
-        o[r][0][p] = lut[0][quantize_u8(yf + c.rv)];
-        o[r][1][p] = lut[1][quantize_u8(yf + c.guv)];
-        o[r][2][p] = lut[2][quantize_u8(yf + c.bu)];
-      }
-    // ---- stores ----
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int y = y0 + r;
-      if (y >= dh)
-        break;
-      if (!a.packed) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          uint8_t* q = d.p[c] + (u32)(y * dp) + (size_t)x0 * 4;
-          // a wave writes 1 KiB, the workgroup 4 KiB contiguous per plane row: non-temporal pays
-          // in this layout (5.55 -> 5.29 us at 1080p; it cost 5-9 % with 256 x 32 tiles)
-          if (n == 4 && (((uintptr_t)q) & 15u) == 0)
-            store16f_nt(q, make_float4(o[r][c][0], o[r][c][1], o[r][c][2], o[r][c][3]));
-          else
-            for (int p = 0; p < n; ++p) gstore<float>(q + 4 * p, o[r][c][p]);
+        for (int p = 0; p < 4; ++p) {
+          const float yf = luma_term(yv[r][p], k);
+          const ChromaTerm& c = ct[p >> 1];
+          o[r][0][p] = lut[0][quantize_u8(yf + c.rv)];
+          o[r][1][p] = lut[1][quantize_u8(yf + c.guv)];
+          o[r][2][p] = lut[2][quantize_u8(yf + c.bu)];
         }
-      } else {
-        uint8_t* q = d.p[0] + (u32)(y * dp) + (size_t)x0 * 12;
-        if (n == 4 && (((uintptr_t)q) & 15u) == 0) {
-          store16f(q + 0, make_float4(o[r][0][0], o[r][1][0], o[r][2][0], o[r][0][1]));
-          store16f(q + 16, make_float4(o[r][1][1], o[r][2][1], o[r][0][2], o[r][1][2]));
-          store16f(q + 32, make_float4(o[r][2][2], o[r][0][3], o[r][1][3], o[r][2][3]));
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int y = y0 + r;
+        if (y >= dh)
+          break;
+        if constexpr (OUT == PP_F32_PLANAR) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            uint8_t* q = d.p[c] + (u32)(y * dp) + (size_t)x0 * 4;
+            // a wave writes 1 KiB, the workgroup 4 KiB contiguous per plane row: non-temporal pays
+            // in this layout (5.55 -> 5.29 us at 1080p; it cost 5-9 % with 256 x 32 tiles)
+            if (n == 4 && (((uintptr_t)q) & 15u) == 0)
+              store16f_nt(q, make_float4(o[r][c][0], o[r][c][1], o[r][c][2], o[r][c][3]));
+            else
+              for (int p = 0; p < n; ++p) gstore<float>(q + 4 * p, o[r][c][p]);
+          }
         } else {
-          for (int p = 0; p < n; ++p) {
-            gstore<float>(q + 12 * p, o[r][0][p]); gstore<float>(q + 12 * p + 4, o[r][1][p]); gstore<float>(q + 12 * p + 8, o[r][2][p]);
+          uint8_t* q = d.p[0] + (u32)(y * dp) + (size_t)x0 * 12;
+          if (n == 4 && (((uintptr_t)q) & 15u) == 0) {
+            store16f(q + 0, make_float4(o[r][0][0], o[r][1][0], o[r][2][0], o[r][0][1]));
+            store16f(q + 16, make_float4(o[r][1][1], o[r][2][1], o[r][0][2], o[r][1][2]));
+            store16f(q + 32, make_float4(o[r][2][2], o[r][0][3], o[r][1][3], o[r][2][3]));
+          } else {
+            for (int p = 0; p < n; ++p) {
+              gstore<float>(q + 12 * p, o[r][0][p]); gstore<float>(q + 12 * p + 4, o[r][1][p]); gstore<float>(q + 12 * p + 8, o[r][2][p]);
+            }
+          }
+        }
+      }
+    } else {
+      // 8-bit outputs: the quantised bytes themselves
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int y = y0 + r;
+        if (y >= dh)
+          break;
+        float cr[4], cg[4], cb[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const float yf = luma_term(yv[r][p], k);
+          const ChromaTerm& c = ct[p >> 1];
+          cr[p] = yf + c.rv; cg[p] = yf + c.guv; cb[p] = yf + c.bu;
+        }
+        if constexpr (OUT == PP_U8_PLANAR) {
+          u32 w[3] = {0u, 0u, 0u};
+          w[0] = pack_u8<0>(cr[0], w[0]); w[0] = pack_u8<1>(cr[1], w[0]); w[0] = pack_u8<2>(cr[2], w[0]); w[0] = pack_u8<3>(cr[3], w[0]);
+          w[1] = pack_u8<0>(cg[0], w[1]); w[1] = pack_u8<1>(cg[1], w[1]); w[1] = pack_u8<2>(cg[2], w[1]); w[1] = pack_u8<3>(cg[3], w[1]);
+          w[2] = pack_u8<0>(cb[0], w[2]); w[2] = pack_u8<1>(cb[1], w[2]); w[2] = pack_u8<2>(cb[2], w[2]); w[2] = pack_u8<3>(cb[3], w[2]);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            uint8_t* q = d.p[c] + (u32)(y * dp) + x0;
+            if (n == 4 && (((uintptr_t)q) & 3u) == 0)
+              gstore<u32>(q, w[c]);
+            else
+              for (int p = 0; p < n; ++p) gstore<uint8_t>(q + p, (uint8_t)(w[c] >> (8 * p)));
+          }
+        } else {
+          // memory order f g l per pixel: f = R (RGB) or B (BGR), l the other one
+          const float (&cf)[4] = OUT == PP_U8_RGB ? cr : cb;
+          const float (&cl)[4] = OUT == PP_U8_RGB ? cb : cr;
+          u32 d0 = 0u, d1 = 0u, d2 = 0u;
+          d0 = pack_u8<0>(cf[0], d0); d0 = pack_u8<1>(cg[0], d0); d0 = pack_u8<2>(cl[0], d0); d0 = pack_u8<3>(cf[1], d0);
+          d1 = pack_u8<0>(cg[1], d1); d1 = pack_u8<1>(cl[1], d1); d1 = pack_u8<2>(cf[2], d1); d1 = pack_u8<3>(cg[2], d1);
+          d2 = pack_u8<0>(cl[2], d2); d2 = pack_u8<1>(cf[3], d2); d2 = pack_u8<2>(cg[3], d2); d2 = pack_u8<3>(cl[3], d2);
+          uint8_t* q = d.p[0] + (u32)(y * dp) + (size_t)x0 * 3;
+          if (n == 4 && (((uintptr_t)q) & 3u) == 0) {
+            typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+            const v3u32 w = {d0, d1, d2};
+            *(VALI_GLOBAL v3u32*)q = w;
+          } else {
+            const u32 ww[3] = {d0, d1, d2};
+            for (int b = 0; b < 3 * n; ++b) gstore<uint8_t>(q + b, (uint8_t)(ww[b >> 2] >> (8 * (b & 3))));
           }
         }
       }
@@ -191,14 +244,35 @@ __global__ void __launch_bounds__(kBlock) k_nv12_preproc(const PreprocArgs a) {
 
 static int launch_preproc(PreprocArgs& a, int src_w, int src_h, int dst_w, int dst_h, int dst_fmt, int n,
                           hipStream_t stream) {
-  if (dst_fmt != VALI_FMT_RGB_32F && dst_fmt != VALI_FMT_RGB_32F_PLANAR)
-    return fail(VALI_ERR_UNSUPPORTED, "nv12_preproc: destination must be RGB_32F or RGB_32F_PLANAR (got %d)", dst_fmt);
-  a.packed = dst_fmt == VALI_FMT_RGB_32F;
+  int out;
+  switch (dst_fmt) {
+  case VALI_FMT_RGB_32F_PLANAR: out = PP_F32_PLANAR; break;
+  case VALI_FMT_RGB_32F: out = PP_F32_PACKED; break;
+  case VALI_FMT_RGB: out = PP_U8_RGB; break;
+  case VALI_FMT_BGR: out = PP_U8_BGR; break;
+  case VALI_FMT_RGB_PLANAR: out = PP_U8_PLANAR; break;
+  default:
+    return fail(VALI_ERR_UNSUPPORTED,
+                "nv12_preproc: destination must be RGB_32F[_PLANAR], RGB, BGR or RGB_PLANAR (got %d)", dst_fmt);
+  }
   a.map = make_tile_map((dst_w + kPpTileW - 1) / kPpTileW, (dst_h + kPpTileH - 1) / kPpTileH, (u32)n);
-  if (src_w == dst_w && src_h == dst_h)
-    hipLaunchKernelGGL(k_nv12_preproc<true>, tile_grid(a.map), dim3(kBlock), 0, stream, a);
-  else
-    hipLaunchKernelGGL(k_nv12_preproc<false>, tile_grid(a.map), dim3(kBlock), 0, stream, a);
+  const dim3 grid = tile_grid(a.map), block(kBlock);
+  const bool same = src_w == dst_w && src_h == dst_h;
+#define VALI_PP_CASE(O)                                                                      \
+  case O:                                                                                   \
+    if (same)                                                                               \
+      hipLaunchKernelGGL((k_nv12_preproc<true, O>), grid, block, 0, stream, a);              \
+    else                                                                                    \
+      hipLaunchKernelGGL((k_nv12_preproc<false, O>), grid, block, 0, stream, a);             \
+    break;
+  switch (out) {
+    VALI_PP_CASE(PP_F32_PLANAR)
+    VALI_PP_CASE(PP_F32_PACKED)
+    VALI_PP_CASE(PP_U8_RGB)
+    VALI_PP_CASE(PP_U8_BGR)
+    VALI_PP_CASE(PP_U8_PLANAR)
+  }
+#undef VALI_PP_CASE
   VALI_LAUNCH_CHECK();
   return VALI_OK;
 }
@@ -217,7 +291,7 @@ int vali_nv12_preproc(const vali_surface* src, const vali_surface* dst, const va
   VALI_REQUIRE(((src->width | src->height | dst->width | dst->height) & 1) == 0, "4:2:0 needs even sizes");
   VALI_REQUIRE(src->plane[0] && src->plane[1] && dst->plane[0], "null plane");
   VALI_REQUIRE(planes_fit_32bit(*src) && planes_fit_32bit(*dst), "plane of 4 GiB or more");
-  if (dst->format == VALI_FMT_RGB_32F_PLANAR)
+  if (dst->format == VALI_FMT_RGB_32F_PLANAR || dst->format == VALI_FMT_RGB_PLANAR)
     VALI_REQUIRE(dst->plane[1] && dst->plane[2], "null dst plane");
   PreprocArgs a = {};
   a.src = *src;

@@ -482,6 +482,9 @@ class PySurfacePreprocessor(_SurfaceTask):
 
     `div=1, mean=0, std=1` is plain NV12 -> RGB_32F[_PLANAR].  Colour variant selection is
     nv12_rgb's (TaskConvertSurface.cpp:117-149).  dst: RGB_32F_PLANAR or RGB_32F.
+    8-bit destinations (RGB, BGR, RGB_PLANAR) give the fused PySurfaceResizer ->
+    PySurfaceConverter chain (resize + colour conversion, no float stage); they require the
+    identity normalisation.
     """
 
     def __init__(self, gpu_id: int, stream=None, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0),
@@ -506,11 +509,15 @@ class PySurfacePreprocessor(_SurfaceTask):
 
     @staticmethod
     def _check(src_fmt, dst_fmt, sw, sh, dw, dh):
-        if src_fmt != F.NV12 or dst_fmt not in (F.RGB_32F, F.RGB_32F_PLANAR):
+        if src_fmt != F.NV12 or dst_fmt not in (F.RGB_32F, F.RGB_32F_PLANAR, F.RGB, F.BGR, F.RGB_PLANAR):
             return TaskExecDetails.failed(TaskExecInfo.NOT_SUPPORTED)
         if (sw | sh | dw | dh) & 1:
             return _S_INVALID
         return None
+
+    def _u8_needs_identity(self, dst_fmt) -> bool:
+        """8-bit destinations carry no float stage: a non-identity normalisation cannot apply."""
+        return dst_fmt in (F.RGB, F.BGR, F.RGB_PLANAR) and self._norm != (1.0, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
 
     def _run(self, src: Surface, dst: Surface, cc_ctx) -> TaskExecDetails:
         if src is None or dst is None or src.IsEmpty or dst.IsEmpty:
@@ -518,6 +525,8 @@ class PySurfacePreprocessor(_SurfaceTask):
         bad = self._check(src.Format, dst.Format, src.Width, src.Height, dst.Width, dst.Height)
         if bad:
             return bad
+        if self._u8_needs_identity(dst.Format):
+            return TaskExecDetails.failed(TaskExecInfo.NOT_SUPPORTED)
         p = self._params(cc_ctx)
         if p is None:
             return _S_UNSUPP_CC
@@ -541,6 +550,8 @@ class PySurfacePreprocessor(_SurfaceTask):
         bad = self._check(batch.src_format, batch.dst_format, *batch.src_size, *batch.dst_size)
         if bad:
             return bad.success, bad.info
+        if self._u8_needs_identity(batch.dst_format):
+            return False, TaskExecInfo.NOT_SUPPORTED
         p = self._params(cc_ctx)
         if p is None:
             return False, TaskExecInfo.UNSUPPORTED_FMT_CONV_PARAMS
