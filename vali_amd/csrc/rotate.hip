@@ -306,6 +306,93 @@ __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
   } // P != 3
 }
 
+// Canonical half turn: dst(x', y') = src(W-1-x', H-1-y') -- a reversal, no arithmetic, so it is
+// a streaming kernel: lane = 4 pixels x 4 rows, the pixel order reversed in registers
+// (byte j of the 4-pixel group comes from byte (3 - j / P) P + j % P).  The bilinear kernel it
+// replaces for this angle gathers four texels per pixel to reproduce the same bytes
+// (9.6 us per 1080p RGB frame).
+constexpr int kHalfRowsPerWave = 4, kHalfTileH = kWavesPerBlock * kHalfRowsPerWave;
+template <int P>
+__global__ void __launch_bounds__(kBlock) k_rotate_half(const RotArgs a) {
+  RotJob job;
+  u32 tile_x, tile_y, frame;
+  if (!rot_tile(a, job, tile_x, tile_y, frame))
+    return;
+  const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
+  const int W = v.dw, H = v.dh;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x0 = (tile_x * 64 + lane) * 4;
+  if (x0 >= W)
+    return;
+  const int n = min(4, W - x0);
+  constexpr int ND = P; // dwords of a 4-pixel group
+  const bool vec = n == 4 && ((((uintptr_t)v.sp) | ((uintptr_t)v.dp) | (uintptr_t)v.spitch | (uintptr_t)v.dpitch) & 3u) == 0 &&
+                   ((((W - 4 - x0) * P) | (x0 * P)) & 3) == 0;
+  u32 in[kHalfRowsPerWave][ND];
+  const int y_first = tile_y * kHalfTileH + wave * kHalfRowsPerWave;
+  if (vec) {
+#pragma unroll
+    for (int r = 0; r < kHalfRowsPerWave; ++r) {
+      const int y = min(y_first + r, H - 1);
+      const uint8_t* q = v.sp + (size_t)(H - 1 - y) * v.spitch + (size_t)(W - 4 - x0) * P;
+#pragma unroll
+      for (int k = 0; k < ND; ++k) in[r][k] = gload<u32>(q + 4 * k);
+    }
+#pragma unroll
+    for (int r = 0; r < kHalfRowsPerWave; ++r) {
+      const int y = y_first + r;
+      if (y >= H)
+        break;
+      u32 out[ND];
+#pragma unroll
+      for (int j = 0; j < ND; ++j) {
+        u32 w = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int ob = 4 * j + b, ib = (3 - ob / P) * P + ob % P;
+          w |= ((in[r][ib >> 2] >> (8 * (ib & 3))) & 0xffu) << (8 * b);
+        }
+        out[j] = w;
+      }
+      uint8_t* o = v.dp + (size_t)y * v.dpitch + (size_t)x0 * P;
+#pragma unroll
+      for (int k = 0; k < ND; ++k) gstore<u32>(o + 4 * k, out[k]);
+    }
+    return;
+  }
+  // ragged right edge / unaligned planes: byte copies
+  for (int r = 0; r < kHalfRowsPerWave; ++r) {
+    const int y = y_first + r;
+    if (y >= H)
+      break;
+    const uint8_t* srow = v.sp + (size_t)(H - 1 - y) * v.spitch;
+    uint8_t* drow = v.dp + (size_t)y * v.dpitch;
+    for (int k = 0; k < n; ++k)
+      for (int b = 0; b < P; ++b)
+        gstore<uint8_t>(drow + (size_t)(x0 + k) * P + b, gload<uint8_t>(srow + (size_t)(W - 1 - x0 - k) * P + b));
+  }
+}
+
+template <int DUMMY = 0> static int launch_half(const RotArgs& a, int pixel_bytes, dim3 grid, hipStream_t s) {
+  const dim3 block(kBlock);
+  switch (pixel_bytes) {
+#define VALI_ROT_CASE(P)                                                                    \
+  case P:                                                                                   \
+    hipLaunchKernelGGL((k_rotate_half<P>), grid, block, 0, s, a);                            \
+    break;
+    VALI_ROT_CASE(1)
+    VALI_ROT_CASE(2)
+    VALI_ROT_CASE(3)
+    VALI_ROT_CASE(4)
+    VALI_ROT_CASE(6)
+    VALI_ROT_CASE(12)
+#undef VALI_ROT_CASE
+  default:
+    return fail(VALI_ERR_UNSUPPORTED, "rotate: unsupported pixel size %d", pixel_bytes);
+  }
+  return VALI_OK;
+}
+
 // plane jobs per pixel format (RotateSurface::Run switch, RotateSurface.cpp:168-208)
 static int rotate_jobs(int fmt, RotJob* j, int* elem) {
   auto set = [&](int k, int comp, int sx, int sy, int ch) {
@@ -380,6 +467,10 @@ static int launch_rotate(RotArgs& a, int fmt, int sw, int sh, int dw, int dh, do
                    (q270 && shift_y == 0.0 && shift_x == (double)(sh - 1) && a.njobs == 1);
   static const bool no_tile = [] { const char* e = getenv("VALI_ROTATE_NO_TILE"); return e && e[0] == '1'; }();
   const bool tiled = canonical && (q90 || q270) && !no_tile;
+  // half turn with each plane's own (W-1, H-1) shifts: a reversal
+  const bool half = q180 && !no_tile && sw == dw && sh == dh &&
+                    (per_plane_shifts != 0 ||
+                     (a.njobs == 1 && shift_x == (double)(sw - 1) && shift_y == (double)(sh - 1)));
 
   u32 total = 0;
   for (int k = 0; k < a.njobs; ++k) {
@@ -399,6 +490,9 @@ static int launch_rotate(RotArgs& a, int fmt, int sw, int sh, int dw, int dh, do
       const int th = elem * j.channels == 3 ? kRotTileHRgb : kRotTile;
       j.tiles_x = (u32)(psw + kRotTile - 1) / kRotTile;
       total += j.tiles_x * (u32)((psh + th - 1) / th);
+    } else if (half) {
+      j.tiles_x = (u32)(pdw + 255) / 256;
+      total += j.tiles_x * (u32)((pdh + kHalfTileH - 1) / kHalfTileH);
     } else {
       j.tiles_x = (u32)(pdw + 255) / 256;
       total += j.tiles_x * (u32)((pdh + 3) / 4);
@@ -409,6 +503,10 @@ static int launch_rotate(RotArgs& a, int fmt, int sw, int sh, int dw, int dh, do
   if (tiled) {
     const int pixel_bytes = elem * a.job[0].channels; // all jobs of a format share it
     const int rc = q90 ? launch_tile<1>(a, pixel_bytes, grid, stream) : launch_tile<3>(a, pixel_bytes, grid, stream);
+    if (rc != VALI_OK)
+      return rc;
+  } else if (half) {
+    const int rc = launch_half<>(a, elem * a.job[0].channels, grid, stream);
     if (rc != VALI_OK)
       return rc;
   } else if (elem == 1) {
