@@ -152,3 +152,16 @@ def test_ud_rotated_batch_and_errors(vali, gpu, oracle):
     assert ud.RunRotated(srcs[0], dsts[0], 0.0) == (False, vali.TaskExecInfo.NOT_SUPPORTED)
     planar = vali.Surface.Make(vali.RGB_PLANAR, uh, uw, gpu)
     assert ud.RunRotated(srcs[0], planar, 90.0) == (False, vali.TaskExecInfo.NOT_SUPPORTED)
+
+
+@pytest.mark.parametrize("dst", ["YUV444_10bit", "RGB_32F", "RGB_32F_PLANAR"])
+@pytest.mark.parametrize("geom", [(1920, 1080, 960, 540), (1280, 720, 300, 170), (640, 360, 1280, 720),
+                                  (2048, 64, 1000, 30), (130, 70, 58, 34)])
+def test_p10_geometries(vali, gpu, oracle, dst, geom):
+    """16-bit sources: 2x downscale (two staging chunks per lane), > 4x (gather path), upscale, ragged."""
+    sw, sh, dw, dh = geom
+    rng = np.random.default_rng(sw + dh)
+    p10 = (rng.integers(0, 1024, (sh * 3 // 2, sw), dtype=np.uint16) << 6).astype(np.uint16)
+    got = run_ud(vali, gpu, p10, sw, sh, "P10", dw, dh, dst)
+    want = oracle.ud_nv12(p10, sw, sh, "P10", dw, dh, dst).reshape(-1)
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8))

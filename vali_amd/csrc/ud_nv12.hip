@@ -91,9 +91,11 @@ template <typename T> __device__ __forceinline__ u32 trunc_sat(float v) {
 constexpr int kUdRowBytes = kWave * 16;         // 1 KiB per staged row
 constexpr int kUdRowsPerWave = 8; // dst rows a wave walks with the same column taps
 constexpr int kUdTileH = kWavesPerBlock * kUdRowsPerWave;
-struct alignas(16) UdStage {
-  uint8_t luma[2][kUdRowBytes];
-  uint8_t chroma[2][kUdRowBytes];
+// CH = 16-byte chunks per lane per row: 1 for 8-bit sources, 2 for 16-bit ones (P10: the same
+// 2x downscale spans twice the bytes; with 1 KiB rows it fell to the gather path, 17.7 us)
+template <int CH> struct alignas(16) UdStage {
+  uint8_t luma[2][CH * kUdRowBytes];
+  uint8_t chroma[2][CH * kUdRowBytes];
 };
 
 // Scale folded into the normalisation constant so the output stage is a bare truncation:
@@ -256,7 +258,8 @@ __host__ inline UdSpan ud_span(int tile_x, int dw, int sw, float scale_x) {
 template <typename T, int OUT, bool STAGED, int ROT = 0>
 __global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
   static_assert(ROT == 0 || (sizeof(T) == 1 && OUT == UD_RGB_U8), "rotated output: NV12 -> RGB only");
-  __shared__ UdStage stage[STAGED ? kWavesPerBlock : 1];
+  constexpr int CH = (int)sizeof(T);
+  __shared__ UdStage<CH> stage[STAGED ? kWavesPerBlock : 1];
   u32 tile_x, tile_y, frame;
   if constexpr ((ROT & 1) != 0) {
     // transposed output: consecutive workgroups walk DOWN the UD image, i.e. along the
@@ -495,30 +498,41 @@ __global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
     // spans of this tile: first tap of lane 0 .. last tap of lane 63 (columns are monotonic)
     const UdSpan sp = ud_span_of(__builtin_amdgcn_readlane(tx[0].i0, 0), __builtin_amdgcn_readlane(tx[3].i1, 63),
                                  __builtin_amdgcn_readlane(tcx[0].i0, 0), __builtin_amdgcn_readlane(tcx[3].i1, 63), E);
-    UdStage& st = stage[wave];
-    const int off = lane * 16;
-    const bool in_y = off < sp.yn, in_c = off < sp.cn;
+    UdStage<CH>& st = stage[wave];
     // Loads are unconditional and straight-line (lanes past a span re-read its last 16 bytes),
     // so the compiler counts vmcnt instead of draining at branches.
-    const int off_y = min(off, sp.yn - 16), off_c = min(off, sp.cn - 16);
-    uint4 pf[4]; // prefetch registers: this lane's 16 bytes of luma0, luma1, chroma0, chroma1
+    int off[CH], off_y[CH], off_c[CH];
+    bool in_y[CH], in_c[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      off[c] = lane * 16 + c * kUdRowBytes;
+      in_y[c] = off[c] < sp.yn; in_c[c] = off[c] < sp.cn;
+      off_y[c] = min(off[c], sp.yn - 16); off_c[c] = min(off[c], sp.cn - 16);
+    }
+    uint4 pf[4][CH]; // prefetch registers: this lane's chunks of luma0, luma1, chroma0, chroma1
     auto issue = [&](const RowTaps& rt) {
       // scalar address arithmetic; a plane is < 4 GiB, so 32-bit row offsets (s_mul_i32)
       const uint8_t* y0 = py + (u32)(rt.ty.i0 * sp_y + sp.yb);
       const uint8_t* y1 = py + (u32)(rt.ty.i1 * sp_y + sp.yb);
       const uint8_t* q0 = puv + (u32)(rt.tcy.i0 * sp_uv + sp.cb);
       const uint8_t* q1 = puv + (u32)(rt.tcy.i1 * sp_uv + sp.cb);
-      pf[0] = gload16(y0 + off_y); pf[1] = gload16(y1 + off_y);
-      pf[2] = gload16(q0 + off_c); pf[3] = gload16(q1 + off_c);
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        pf[0][c] = gload16(y0 + off_y[c]); pf[1][c] = gload16(y1 + off_y[c]);
+        pf[2][c] = gload16(q0 + off_c[c]); pf[3][c] = gload16(q1 + off_c[c]);
+      }
     };
     auto commit = [&]() {
-      if (in_y) {
-        *reinterpret_cast<uint4*>(&st.luma[0][off]) = pf[0];
-        *reinterpret_cast<uint4*>(&st.luma[1][off]) = pf[1];
-      }
-      if (in_c) {
-        *reinterpret_cast<uint4*>(&st.chroma[0][off]) = pf[2];
-        *reinterpret_cast<uint4*>(&st.chroma[1][off]) = pf[3];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        if (in_y[c]) {
+          *reinterpret_cast<uint4*>(&st.luma[0][off[c]]) = pf[0][c];
+          *reinterpret_cast<uint4*>(&st.luma[1][off[c]]) = pf[1][c];
+        }
+        if (in_c[c]) {
+          *reinterpret_cast<uint4*>(&st.chroma[0][off[c]]) = pf[2][c];
+          *reinterpret_cast<uint4*>(&st.chroma[1][off[c]]) = pf[3][c];
+        }
       }
     };
     // LDS byte offsets of the column taps (row-invariant)
@@ -662,7 +676,8 @@ static int launch_ud(UdArgs& a, int src_fmt, int src_w, int dst_w, int dst_h, in
     for (int t = 0; t < (dst_w + 255) / 256 && staged; ++t) {
       const UdSpan sp = src_fmt == VALI_FMT_NV12 ? ud_span<uint8_t>(t, dst_w, src_w, scale_x)
                                                  : ud_span<uint16_t>(t, dst_w, src_w, scale_x);
-      staged = sp.yn <= kUdRowBytes && sp.cn <= kUdRowBytes;
+      const int cap = kUdRowBytes * (src_fmt == VALI_FMT_NV12 ? 1 : 2);
+      staged = sp.yn <= cap && sp.cn <= cap;
     }
   }
 #define VALI_UD_CASE(T, K)                                                                  \
