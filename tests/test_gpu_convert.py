@@ -137,3 +137,22 @@ def test_torch_segmentation_chain(vali, gpu, oracle):
     rgb = oracle.convert(nv12, "NV12", "RGB", w, h, oracle.cvt_params(csc_variant=1))
     want = (rgb.astype(np.float32) / np.float32(255)).reshape(h, w, 3).transpose(2, 0, 1)
     assert np.array_equal(t.cpu().numpy(), want)
+
+
+def _random_sizes(seed, n):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        w, h = int(rng.integers(1, 1400)) * 2, int(rng.integers(1, 300)) * 2       # even: valid for 4:2:0
+        if rng.random() < 0.35:
+            w = max(2, int(rng.integers(1, 6)) * 1024 + 2 * int(rng.integers(-3, 4)))  # around tile edges
+        out.append((w, h))
+    return out
+
+
+@pytest.mark.parametrize("pair", pairs(), ids=lambda p: f"{p[0]}-{p[1]}")
+@pytest.mark.parametrize("size", _random_sizes(77, 6), ids=lambda s: f"{s[0]}x{s[1]}")
+def test_all_pairs_random_sizes(vali, gpu, oracle, pair, size):
+    """seeded random widths / heights, a third of them a few pixels around multiples of the
+    kernels' 1024-pixel wave rows: tail lanes, partial 16-pixel groups, last-row pairs."""
+    run_pair(vali, gpu, oracle, pair[0], pair[1], size[0], size[1], seed=size[0] + size[1])
