@@ -105,3 +105,39 @@ def test_extreme_sizes_single_plane(vali, gpu, oracle, fmt, dt, ch, geom):
         assert vali.PySurfaceResizer(vali.PixelFormat[fmt], gpu, interpolation=interp).Run(src, d)[0]
         want = oracle.resize_surface(host, fmt, sw, sh, dw, dh, name)
         assert np.array_equal(download(vali, gpu, d, dt).view(np.uint8), want.view(np.uint8)), name
+
+
+def test_batches_mix_pitches_and_alignment(vali, gpu, oracle):
+    """A batch is an array of per-surface descriptors: surfaces of one batch may differ in pitch and
+    alignment (library-allocated next to foreign unaligned memory) and each keeps its own path."""
+    sw, sh, dw, dh = 320, 180, 160, 90
+    nvs = [make_nv12(sw, sh, 60 + i) for i in range(4)]
+    keep, srcs = [], []
+    for i, nv in enumerate(nvs):
+        if i % 2:
+            s, raw = foreign_nv12(vali, sw, sh, nv, pad=5 + i, skew=3)
+            keep.append(raw)
+        else:
+            s = upload(vali, gpu, vali.NV12, sw, sh, nv)
+        srcs.append(s)
+    cc = vali.ColorspaceConversionContext(vali.ColorSpace.BT_709, vali.ColorRange.MPEG)
+    rgb = [vali.Surface.Make(vali.RGB, sw, sh, gpu) for _ in nvs]
+    assert vali.PySurfaceConverter(gpu).RunBatch(srcs, rgb, cc)[0]
+    small = [vali.Surface.Make(vali.NV12, dw, dh, gpu) for _ in nvs]
+    assert vali.PySurfaceResizer(vali.NV12, gpu, interpolation=vali.Interpolation.LANCZOS).RunBatch(srcs, small)[0]
+    ud = [vali.Surface.Make(vali.RGB_PLANAR, dw, dh, gpu) for _ in nvs]
+    assert vali.PySurfaceUD(gpu).RunBatch(srcs, ud)[0]
+    turned = [vali.Surface.Make(vali.RGB, dh, dw, gpu) for _ in nvs]
+    assert vali.PySurfaceUD(gpu).RunRotatedBatch(srcs, turned, angle=90.0)[0]
+    pre = [vali.Surface.Make(vali.RGB_PLANAR, dw, dh, gpu) for _ in nvs]
+    assert vali.PySurfacePreprocessor(gpu).RunBatch(srcs, pre, cc)[0]
+    for i, nv in enumerate(nvs):
+        flat = nv.reshape(-1)
+        assert np.array_equal(download(vali, gpu, rgb[i]), oracle.nv12_to_rgb(nv, sw, sh, oracle.csc(1), "RGB").reshape(-1))
+        assert np.array_equal(download(vali, gpu, small[i]), oracle.resize_surface(flat, "NV12", sw, sh, dw, dh, "lanczos"))
+        assert np.array_equal(download(vali, gpu, ud[i]), oracle.ud_nv12(nv, sw, sh, "NV12", dw, dh, "RGB_PLANAR").reshape(-1))
+        want = np.rot90(oracle.ud_nv12(nv, sw, sh, "NV12", dw, dh, "RGB").reshape(dh, dw, 3), k=1)
+        assert np.array_equal(download(vali, gpu, turned[i]).reshape(dw, dh, 3), want)
+        n12 = oracle.resize_surface(flat, "NV12", sw, sh, dw, dh).reshape(dh * 3 // 2, dw)
+        assert np.array_equal(download(vali, gpu, pre[i]), oracle.nv12_to_rgb(n12, dw, dh, oracle.csc(1), "RGB_PLANAR").reshape(-1))
+    del keep
