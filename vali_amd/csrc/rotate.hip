@@ -12,14 +12,18 @@
 // mapping is an exact pixel permutation, which is what the reference's
 // rotation etalons pin.
 //
-// Two kernels:
+// Kernels:
 //  * k_rotate_affine<T>: any angle.  cos/sin arrive from the host as floats (snapped to
 //    exactly 0/+-1 for multiples of 90 degrees), so the device does only fma/mul/add and is
-//    bit-exact with the oracle.  One lane = 4 adjacent dst pixels (wide stores).
+//    bit-exact with the oracle.  One lane = 4 adjacent dst pixels (wide stores), a workgroup =
+//    32 x 32 dst pixels so that its source footprint is a compact square whatever the angle.
 //  * k_rotate_tile<P,Q>: the canonical 90 / 270 degree permutations as an LDS-tiled transpose:
 //    a 64x64-pixel tile is read with coalesced row segments, written with coalesced row
 //    segments of the transposed tile; LDS row stride 64*P+4 bytes keeps the column walks
-//    at most 2-way bank conflicted.  P = bytes per pixel (1,2,3,4,6,12).
+//    at most 2-way bank conflicted.  P = bytes per pixel (1,2,4,6,12); 3-byte pixels
+//    (rotate_tile_rgb8) keep ONE DWORD PER PIXEL in LDS: aligned ds_read_b32 column walks.
+//  * k_rotate_half<P>: the canonical 180 degree turn is a reversal: streaming, 4 pixels x 4 rows
+//    per lane, no LDS.
 // Arithmetic of the affine path (the specification, oracle: vali_oracle_rotate_plane):
 //   dx = x' - shift_x ; dy = y' - shift_y                      (float)
 //   xs = fma(-s, dy, c*dx) ; ys = fma(c, dy, s*dx)
