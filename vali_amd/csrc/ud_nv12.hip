@@ -253,8 +253,8 @@ __host__ inline UdSpan ud_span(int tile_x, int dw, int sw, float scale_x) {
 // exactly what PySurfaceRotator's canonical 90 / 180 / 270 degree turn of the UD output gives
 // (rotate.hip: ROT 1: dst(x', y') = ud(W-1-y', x'); 2: ud(W-1-x', H-1-y'); 3: ud(y', H-1-x')),
 // without the intermediate surface (BASELINE config 4 as one pass: 18.7 instead of 31.1 MB).
-// For odd ROT a lane keeps its 4 pixels of all 8 rows in registers (24 bytes per pixel = the
-// 8 rows are 8 neighbouring pixels of one destination row) and stores them as 3 x 8 bytes.
+// For odd ROT the workgroup collects its 256 x 32 output tile in LDS, one dword per pixel, and
+// writes it transposed after a barrier (destination row <-> tile column): see the end of the kernel.
 template <typename T, int OUT, bool STAGED, int ROT = 0>
 __global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
   static_assert(ROT == 0 || (sizeof(T) == 1 && OUT == UD_RGB_U8), "rotated output: NV12 -> RGB only");
