@@ -153,9 +153,9 @@ VALI_API int vali_memset2d_async(int device, void* dst, size_t dst_pitch, int va
 /* ---- colour conversion: replaces the NPP nppicc entry points ---------------- */
 
 /*
- * NV12 -> RGB / BGR (packed u8), RGB_PLANAR (u8), RGB_32F / RGB_32F_PLANAR
- * (f32 = value/255 of the rounded u8 result, i.e. the fused form of the
- * reference's NV12->RGB->RGB_32F(->PLANAR) chain).
+ * NV12 -> RGB / BGR (packed u8) or RGB_PLANAR (u8); any other dst->format returns
+ * VALI_ERR_UNSUPPORTED.  (Float outputs -- the fused form of the reference's
+ * NV12->RGB->RGB_32F(->PLANAR) chain -- are vali_nv12_preproc below.)
  * Replaces nppiNV12ToRGB_709HDTV_8u_P2C3R_Ctx, nppiNV12ToRGB_709CSC_8u_P2C3R_Ctx,
  * nppiNV12ToRGB_8u_P2C3R_Ctx and their BGR twins
  * (reference call sites: TaskConvertSurface.cpp:61-156; LibNpp.hpp table).
