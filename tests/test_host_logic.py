@@ -125,3 +125,22 @@ def test_public_api_surface_of_the_hot_path():
         for name in ("ColorspaceConversionContext", "PixelFormat", "TaskExecInfo", "TaskExecDetails", "ColorSpace",
                      "ColorRange", "DLDeviceType", "GetNumGpus", "Interpolation", "NV12", "RGB", "SUCCESS", "BT_709"):
             assert hasattr(mod, name), name
+
+
+def test_build_entry_points_do_not_need_the_extension_they_build():
+    """A clean checkout has no .so (git-ignored): __graft_entry__.build() must load
+    vali_amd/build.py by path, and `python -m vali_amd.build` must get past the package import."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(vali.__file__).resolve().parent.parent
+    src = (root / "__graft_entry__.py").read_text()
+    assert "spec_from_file_location" in src and "from vali_amd import build" not in src
+    build_src = (root / "vali_amd" / "build.py").read_text()
+    assert "from ." not in build_src and "import vali_amd" not in build_src      # stand-alone script
+    # the package import is skipped only for that one command line
+    code = ("import sys; sys.orig_argv = ['python', '-m', 'vali_amd.build']; import importlib, vali_amd;"
+            "assert vali_amd._BUILDING and not hasattr(vali_amd, 'Surface')")
+    assert subprocess.run([sys.executable, "-c", code], cwd=root).returncode == 0
+    assert subprocess.run([sys.executable, "-m", "vali_amd.build"], cwd=root, capture_output=True).returncode == 0
