@@ -12,8 +12,22 @@ if str(ROOT) not in sys.path:
 GOLDEN = Path(__file__).resolve().parent / "golden"
 
 
+def _build_if_missing():
+    """A clean checkout has no native parts (the .so files are git-ignored): build them once,
+    through vali_amd/build.py loaded by path (importing the package needs what is being built).
+    Only MISSING products trigger this, never stale ones: a test run does not recompile."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("_vali_amd_build", ROOT / "vali_amd" / "build.py")
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    if not (b.lib_path().exists() and b.shim_path().exists() and b.oracle_path().exists()):
+        b.build_all(force=False)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    _build_if_missing()
 
 
 def make_nv12(width: int, height: int, seed: int, full_range: bool = True) -> np.ndarray:
