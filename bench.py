@@ -134,7 +134,13 @@ def main():
 
     import torch
 
-    import vali_amd as vali
+    try:
+        import vali_amd as vali
+    except ImportError:      # clean checkout: the git-ignored .so files are not there yet
+        import __graft_entry__
+
+        __graft_entry__.build()
+        import vali_amd as vali
     from vali_amd._native import shim
 
     ngpu = vali.GetNumGpus()
