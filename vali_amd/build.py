@@ -35,8 +35,8 @@ HIP_FLAGS = [
 
 
 def _run(cmd):
-    print("  $", " ".join(str(c) for c in cmd), flush=True)
-    subprocess.run([str(c) for c in cmd], check=True)
+    print("  $", " ".join(str(c) for c in cmd), file=sys.stderr, flush=True)  # stdout stays clean (bench.py prints ONE JSON line)
+    subprocess.run([str(c) for c in cmd], check=True, stdout=sys.stderr)
 
 
 def _stale(product: Path, sources) -> bool:
