@@ -144,3 +144,35 @@ def test_build_entry_points_do_not_need_the_extension_they_build():
             "assert vali_amd._BUILDING and not hasattr(vali_amd, 'Surface')")
     assert subprocess.run([sys.executable, "-c", code], cwd=root).returncode == 0
     assert subprocess.run([sys.executable, "-m", "vali_amd.build"], cwd=root, capture_output=True).returncode == 0
+
+
+def test_keyword_names_of_the_hot_path_match_the_reference():
+    """Keyword arguments a reference user writes (src/python_vali/__init__.pyi and the py::arg
+    lists of src/python_vali/src/*.cpp) are accepted under the same names."""
+    import inspect
+
+    expect = {
+        (vali.Surface, "Make"): ["format", "width", "height", "gpu_id"],
+        (vali.Surface, "from_dlpack"): ["capsule", "format"],
+        (vali.Surface, "from_cai"): ["dict", "format"],
+        (vali.PySurfaceConverter, "__init__"): ["gpu_id", "stream"],
+        (vali.PySurfaceConverter, "Run"): ["src", "dst", "cc_ctx"],
+        (vali.PySurfaceConverter, "RunAsync"): ["src", "dst", "cc_ctx"],
+        (vali.PySurfaceResizer, "__init__"): ["format", "gpu_id", "stream"],
+        (vali.PySurfaceResizer, "Run"): ["src", "dst"],
+        (vali.PySurfaceRotator, "__init__"): ["gpu_id", "stream"],
+        (vali.PySurfaceRotator, "Run"): ["src", "dst", "angle", "shift_x", "shift_y"],
+        (vali.PySurfaceUD, "__init__"): ["gpu_id", "stream"],
+        (vali.PySurfaceUD, "Run"): ["src", "dst"],
+        (vali.PyFrameUploader, "__init__"): ["gpu_id", "stream"],
+        (vali.PyFrameUploader, "Run"): ["src", "dst"],
+        (vali.PySurfaceDownloader, "Run"): ["src", "dst"],
+        (vali.PyFrameConverter, "__init__"): ["width", "height", "src_format", "dst_format"],
+        (vali.PyFrameConverter, "Run"): ["src", "dst", "cc_ctx"],
+        (vali.CudaStreamEvent, "__init__"): ["stream", "gpu_id"],
+        (vali.CudaBuffer, "Make"): ["elem_size", "num_elems", "gpu_id"],
+        (vali.ColorspaceConversionContext, "__init__"): ["color_space", "color_range"],
+    }
+    for (cls, name), names in expect.items():
+        params = [p for p in inspect.signature(getattr(cls, name)).parameters if p != "self"]
+        assert params[:len(names)] == names, (cls.__name__, name, params)

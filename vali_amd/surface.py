@@ -439,9 +439,11 @@ class Surface:
         return surf
 
     @staticmethod
-    def from_cai(obj, format=PixelFormat.RGB) -> "Surface":
+    def from_cai(dict, format=PixelFormat.RGB) -> "Surface":  # noqa: A002 -- the reference's keyword
         """Borrow memory described by __cuda_array_interface__ (v3)
-        (PySurface.cpp:476-535, SurfacePlane.cpp:123-169)."""
+        (PySurface.cpp:468-535, SurfacePlane.cpp:123-169).  The first parameter is an OBJECT
+        exposing the attribute; its name `dict` is the reference's (py::arg("dict"), :529)."""
+        obj = dict
         if not hasattr(obj, "__cuda_array_interface__"):
             raise RuntimeError("'__cuda_array_interface__' not found")
         cai = obj.__cuda_array_interface__
