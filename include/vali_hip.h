@@ -287,8 +287,8 @@ enum vali_interpolation {
 VALI_API int vali_resize(const vali_surface* src, const vali_surface* dst, int interpolation,
                          vali_stream_t stream);
 VALI_API int vali_resize_batch(const vali_surface* d_src, const vali_surface* d_dst, int n,
-                               int format, int dst_width, int dst_height, int interpolation,
-                               vali_stream_t stream);
+                               int format, int src_width, int src_height, int dst_width,
+                               int dst_height, int interpolation, vali_stream_t stream);
 
 /* ---- rotation: replaces nppiRotate_{8u,16u,32f}_{C1,C3}R_Ctx ------------------------ */
 

@@ -428,10 +428,10 @@ PYBIND11_MODULE(_vali_shim, m) {
         },
         py::call_guard<py::gil_scoped_release>());
   m.def("resize_batch",
-        [](uintptr_t d_src, uintptr_t d_dst, int n, int format, int dst_w, int dst_h, int interp,
-           uintptr_t stream) {
+        [](uintptr_t d_src, uintptr_t d_dst, int n, int format, int src_w, int src_h, int dst_w,
+           int dst_h, int interp, uintptr_t stream) {
           return vali_resize_batch((const vali_surface*)P(d_src), (const vali_surface*)P(d_dst), n,
-                                   format, dst_w, dst_h, interp, P(stream));
+                                   format, src_w, src_h, dst_w, dst_h, interp, P(stream));
         },
         py::call_guard<py::gil_scoped_release>());
   m.attr("INTERP_LINEAR") = (int)VALI_INTERP_LINEAR;

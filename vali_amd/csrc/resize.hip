@@ -527,16 +527,26 @@ static int resize_jobs(int fmt, ResizeJob* j, int* elem) {
   }
 }
 
-static int launch_resize(ResizeArgs& a, int fmt, int dst_w, int dst_h, int n, int interp, hipStream_t stream) {
+static int launch_resize(ResizeArgs& a, int fmt, int src_w, int src_h, int dst_w, int dst_h, int n, int interp,
+                         hipStream_t stream) {
   int elem = 1;
   a.njobs = resize_jobs(fmt, a.job, &elem);
   if (!a.njobs)
     return fail(VALI_ERR_UNSUPPORTED, "resize: unsupported pixel format %d", fmt);
   u32 total = 0;
+  // Integer scale factors on every plane: f = x * scale is an exact integer, every fractional
+  // weight is 0 and BOTH filters reduce to the same point sample src[k y][k x] (bit for bit:
+  // fma(0, d, t) == t and {0,0,1,0,0,0} . taps == the centre tap).  Lanczos then runs on the
+  // bilinear kernel, which does not even fetch the zero-weight rows (5.7 -> 1.3 us at the
+  // reference's own 2160p -> 720p case).
+  bool integer_scale = true;
   for (int k = 0; k < a.njobs; ++k) {
     const int dw = dst_w >> a.job[k].sub_x, dh = dst_h >> a.job[k].sub_y;
     if (dw <= 0 || dh <= 0)
       return fail(VALI_ERR_INVALID_ARG, "resize: destination too small for its chroma planes");
+    const int sw = src_w >> a.job[k].sub_x, sh = src_h >> a.job[k].sub_y;
+    integer_scale = integer_scale && sw > 0 && sh > 0 && sw % dw == 0 && sh % dh == 0 && sw < (1 << 23) &&
+                    sh < (1 << 23);
     a.job[k].first_tile = total;
     a.job[k].tiles_x = (u32)(dw + 255) / 256;
     total += a.job[k].tiles_x * (u32)((dh + kRsTileH - 1) / kRsTileH);
@@ -552,7 +562,7 @@ static int launch_resize(ResizeArgs& a, int fmt, int dst_w, int dst_h, int n, in
     else if (maxc == 2) hipLaunchKernelGGL((KERNEL<T, 2>), grid, block, 0, stream, a);      \
     else hipLaunchKernelGGL((KERNEL<T, 3>), grid, block, 0, stream, a);                     \
   } while (0)
-  if (interp == VALI_INTERP_LANCZOS) {
+  if (interp == VALI_INTERP_LANCZOS && !(integer_scale && elem != 4)) {
     if (elem == 1) VALI_RS_LAUNCH(k_resize_lanczos, uint8_t);
     else if (elem == 2) VALI_RS_LAUNCH(k_resize_lanczos, uint16_t);
     else VALI_RS_LAUNCH(k_resize_lanczos, float);
@@ -595,13 +605,14 @@ int vali_resize(const vali_surface* src, const vali_surface* dst, int interpolat
   }
   hipStream_t s = as_stream(stream);
   DeviceScope scope(stream_device(s));
-  return launch_resize(a, src->format, dst->width, dst->height, 1, interpolation, s);
+  return launch_resize(a, src->format, src->width, src->height, dst->width, dst->height, 1, interpolation, s);
 }
 
 int vali_resize_batch(const vali_surface* d_src, const vali_surface* d_dst, int n, int format,
-                      int dst_width, int dst_height, int interpolation, vali_stream_t stream) {
+                      int src_width, int src_height, int dst_width, int dst_height, int interpolation,
+                      vali_stream_t stream) {
   VALI_REQUIRE(d_src && d_dst, "null argument");
-  VALI_REQUIRE(dst_width > 0 && dst_height > 0, "empty geometry");
+  VALI_REQUIRE(src_width > 0 && src_height > 0 && dst_width > 0 && dst_height > 0, "empty geometry");
   VALI_REQUIRE(n >= 0 && n <= 65535, "batch size out of range (0..65535)");
   if (interpolation != VALI_INTERP_LINEAR && interpolation != VALI_INTERP_LANCZOS)
     return fail(VALI_ERR_UNSUPPORTED, "resize: interpolation %d not implemented", interpolation);
@@ -612,7 +623,7 @@ int vali_resize_batch(const vali_surface* d_src, const vali_surface* d_dst, int 
   a.d_dst = d_dst;
   hipStream_t s = as_stream(stream);
   DeviceScope scope(stream_device(s));
-  return launch_resize(a, format, dst_width, dst_height, n, interpolation, s);
+  return launch_resize(a, format, src_width, src_height, dst_width, dst_height, n, interpolation, s);
 }
 
 } // extern "C"

@@ -728,6 +728,7 @@ class PySurfaceResizer(_SurfaceTask):
         if batch.src_format != batch.dst_format or batch.src_format != self._format:
             return False, TaskExecInfo.INVALID_INPUT
         d = _status(shim.resize_batch(batch.d_src, batch.d_dst, batch.n, int(self._format),
+                                      batch.src_size[0], batch.src_size[1],
                                       batch.dst_size[0], batch.dst_size[1], self._interp,
                                       self._stream))
         return d.success, d.info
