@@ -34,7 +34,7 @@ per = {}
 for cname, pat in (("FETCH_SIZE", "pmc_fetch/**/*counter_collection.csv"),
                    ("WRITE_SIZE", "pmc_write/**/*counter_collection.csv")):
     vals = [float(r["Counter_Value"]) for r in rows(pat)
-            if r["Counter_Name"] == cname and "nv12" in r["Kernel_Name"]]
+            if r["Counter_Name"] == cname and "k_nv12_rgb8" in r["Kernel_Name"]]
     if vals:
         per[cname] = sum(vals) / len(vals)
 if per:
