@@ -38,6 +38,16 @@ int stream_device(hipStream_t stream);
 // +4% HBM throughput for the streaming converters (profiles/r01_variants.md).
 unsigned residency_lds_bytes(int block_threads, int waves_per_cu, unsigned min_bytes);
 
+// Residency of the streaming converters, in waves per CU.  16 waves of FULL lanes measured best
+// for plane -> packed streams (profiles/r01_variants.md); when the row width leaves lanes idle
+// (1280 px = 80 of 128 lanes, 2560 px = 160 of 192) the same bytes in flight need more waves:
+// 720p 5.29 -> 5.85 TB/s, 1440p 5.18 -> 5.85 TB/s with 24-28 (sweep in profiles/r01_variants.md).
+inline int streaming_waves_per_cu(int groups, int block, int full_lane_waves) {
+  const int lanes = ((groups + block - 1) / block) * block; // lanes launched per row pair
+  const int util_pct = groups * 100 / lanes;
+  return util_pct >= 90 ? full_lane_waves : util_pct >= 70 ? full_lane_waves * 3 / 2 : full_lane_waves * 7 / 4;
+}
+
 inline hipStream_t as_stream(vali_stream_t s) { return (hipStream_t)s; }
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }

@@ -612,7 +612,7 @@ static int launch_convert(CvtArgs& a, ElemArgs& e, int src_fmt, int dst_fmt, int
     const char* e = getenv("VALI_WAVES_PER_CU");
     return e ? atoi(e) : 0;
   }();
-  const int waves_per_cu = waves_override > 0 ? waves_override : (k_ispacked(sk) ? 24 : 16);
+  const int waves_per_cu = waves_override > 0 ? waves_override : streaming_waves_per_cu(groups, block, k_ispacked(sk) ? 24 : 16);
   const unsigned lds = residency_lds_bytes(block, waves_per_cu, (unsigned)sizeof(PackedStrip) * kWavesPerBlock);
 #define VALI_PAIR(S, D)                                                                     \
   if (sk == S && dk == D) {                                                                 \

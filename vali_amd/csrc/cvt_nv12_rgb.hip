@@ -229,11 +229,11 @@ static int launch_nv12_rgb(Nv12RgbArgs& a, int width, int height, int n, int dst
     const char* e = getenv("VALI_NV12_DIRECT_STORE");
     return e && e[0] == '1';
   }();
-  static const int waves_per_cu = [] {
+  static const int waves_override = [] {
     const char* e = getenv("VALI_WAVES_PER_CU");
-    const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : 16;
+    return e ? atoi(e) : 0;
   }();
+  const int waves_per_cu = waves_override > 0 ? waves_override : streaming_waves_per_cu(groups, block, 16);
   const unsigned lds =
       residency_lds_bytes(block, waves_per_cu, (unsigned)sizeof(PackedStrip) * kWavesPerBlock);
   switch (dst_format) {
