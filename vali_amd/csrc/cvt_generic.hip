@@ -256,6 +256,60 @@ __device__ __forceinline__ void transform_block(Block& b, const vali_cvt_params&
   // relabelling of the loaded channels: load_block / store_block do the permutation.
 }
 
+// Packed RGB / BGR -> 4:2:0 (YUV420 / NV12): load + transform fused and ROW-SEQUENTIAL.  Both
+// rows' global loads are issued first; then row 0 is unpacked, turned into luma bytes and
+// chroma PAIR SUMS, and only then row 1 is unpacked and finishes the 2x2 means.  The generic
+// load_block + transform_block keeps both unpacked rows and 32 chroma floats live (106 VGPRs,
+// 4 waves per SIMD); this order needs about half of that.  Same operations in the same
+// order: ((c00 + c01) + (c10 + c11)) * 0.25.
+template <int SRC, int DST>
+__device__ __forceinline__ void load_transform_packed_420(Block& b, const SurfRef& s, const Geo& q,
+                                                          PackedStrip& strip, const vali_cvt_params& p) {
+  static_assert(k_ispacked(SRC) && k_is420(DST), "packed RGB/BGR -> 4:2:0 only");
+  const int r1 = q.row0 + (q.has_row1 ? 1 : 0);
+  const int vb = q.valid_lanes * 48;
+  StripRegs regs[2];
+  strip_fetch(regs[0], q.lane, s.p[0] + (size_t)q.row0 * s.pitch[0] + (size_t)q.wave_g0 * 48, vb);
+  strip_fetch(regs[1], q.lane, s.p[0] + (size_t)r1 * s.pitch[0] + (size_t)q.wave_g0 * 48, vb);
+  float su[8], sv[8]; // row-0 pair sums of the 8 chroma samples
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    u32 o[12], R[4], G[4], B[4];
+    strip_unpack(strip, q.lane, regs[r], o, q.lane_valid);
+    if (!q.lane_valid)
+      continue;
+    if constexpr (SRC == K_RGB) deinterleave3(o, R, G, B);
+    else deinterleave3(o, B, G, R);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      u32 y = 0;
+      float fu[4], fv[4];
+#define VALI_PX(I)                                                                          \
+  {                                                                                         \
+    const float fr = ubyte_f32<I>(R[j]), fg = ubyte_f32<I>(G[j]), fb = ubyte_f32<I>(B[j]);   \
+    y = pack_u8<I>(dot_rgb(p.rgb2yuv[0], fr, fg, fb), y);                                    \
+    fu[I] = dot_rgb(p.rgb2yuv[1], fr, fg, fb);                                              \
+    fv[I] = dot_rgb(p.rgb2yuv[2], fr, fg, fb);                                              \
+  }
+      VALI_PX(0) VALI_PX(1) VALI_PX(2) VALI_PX(3)
+#undef VALI_PX
+      b.c0[r][j] = y;
+      const float ua = fu[0] + fu[1], ub = fu[2] + fu[3], va = fv[0] + fv[1], vb2 = fv[2] + fv[3];
+      if (r == 0) {
+        su[2 * j] = ua; su[2 * j + 1] = ub; sv[2 * j] = va; sv[2 * j + 1] = vb2;
+      } else {
+        const float mu0 = (su[2 * j] + ua) * 0.25f, mu1 = (su[2 * j + 1] + ub) * 0.25f;
+        const float mv0 = (sv[2 * j] + va) * 0.25f, mv1 = (sv[2 * j + 1] + vb2) * 0.25f;
+        u32& cu = b.cu[j >> 1];
+        u32& cv = b.cv[j >> 1];
+        if (j & 1) { cu = pack_u8<2>(mu0, cu); cu = pack_u8<3>(mu1, cu); cv = pack_u8<2>(mv0, cv); cv = pack_u8<3>(mv1, cv); }
+        else { cu = pack_u8<0>(mu0, 0u); cu = pack_u8<1>(mu1, cu); cv = pack_u8<0>(mv0, 0u); cv = pack_u8<1>(mv1, cv); }
+      }
+      __builtin_amdgcn_sched_barrier(0); // one 4-pixel group at a time
+    }
+  }
+}
+
 // ---- byte-granular path: any width / alignment, one 2x2 quad at a time ---------------------
 template <int K> __device__ __forceinline__ void px_read(const SurfRef& s, int x, int y, float (&c)[3]) {
   if constexpr (K == K_RGB || K == K_BGR) {
@@ -364,9 +418,13 @@ __global__ void __launch_bounds__(kBlock) k_cvt8(const CvtArgs a) {
   const bool fast = ((W & (kLanePx - 1)) == 0) && (((align_bits_of<SRC>(s) | align_bits_of<DST>(d)) & 15u) == 0);
   if (fast) {
     Block b;
-    load_block<SRC>(b, s, q, strips[q.wave]);
-    if (q.lane_valid)
-      transform_block<SRC, DST>(b, a.p);
+    if constexpr (k_ispacked(SRC) && k_is420(DST)) {
+      load_transform_packed_420<SRC, DST>(b, s, q, strips[q.wave], a.p);
+    } else {
+      load_block<SRC>(b, s, q, strips[q.wave]);
+      if (q.lane_valid)
+        transform_block<SRC, DST>(b, a.p);
+    }
     store_block<DST>(b, d, q, strips[q.wave]);
     return;
   }
