@@ -38,8 +38,8 @@ HBM_COPY_CEILING_GBPS = 6290.0  # measured float4 copy ceiling (same guide)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)   # 5 warm-up + >= 50 timed batches
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=512, help="frames per GPU per step")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
@@ -281,6 +281,7 @@ def main():
                          "traffic": traffic, "traffic_unit": "B per launch",
                          "traffic_source": traffic_src, "kernel": "k_nv12_rgb8",
                          "avg_kernel_ms": round(avg_kernel_ms, 4),
+                         "median_kernel_ms": round(float(np.median(kernel_ms)), 4),
                          "min_kernel_ms": round(float(np.min(kernel_ms)), 4)},
         }
         if parity is not None:
