@@ -87,11 +87,23 @@ def cpu_baseline(width, height, coeffs, budget_s):
         if time.perf_counter() - t0 >= budget_s:
             break
     t_all = time.perf_counter() - t0
+    # BASELINE config 1 stand-in: ONE 1080p frame on ONE thread, like the reference's
+    # PyFrameConverter (sws_scale on a single frame); best of 5
+    hd = synth_nv12(1920, 1080, 1)
+    hd_out = [np.zeros((1080, 3 * 1920), np.uint8)]
+    t_hd = []
+    for _ in range(6):
+        t1 = time.perf_counter()
+        o.nv12_to_rgb_mt([hd], 1920, 1080, k, 1, hd_out)
+        t_hd.append(time.perf_counter() - t1)
+    t_hd = min(t_hd[1:])
     return {
         "value": round(done / t_all, 3), "unit": "frames/s", "cores": cores, "kind": "port",
         "sample": f"{done} frames {width}x{height} NV12->RGB by oracle/vali_oracle.c, "
                   f"{cores} OpenMP threads over independent frames, {t_all:.1f} s",
         "single_thread_fps": round(1.0 / t_single, 3),
+        "config1_1080p_single_thread": {"ms_per_frame": round(t_hd * 1e3, 3), "frames_per_s": round(1.0 / t_hd, 2),
+                                        "GBps(9331200 B/frame)": round(9331200 / t_hd / 1e9, 3), "cores": 1},
         "note": "the reference's CPU path is FFmpeg libswscale (not available offline); this "
                 "is the build's own C restatement of the GPU arithmetic",
     }
