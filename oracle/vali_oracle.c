@@ -22,14 +22,15 @@
  * (NPP's rounding mode is not documented for these conversions -- SURVEY.md
  * A.3 -- nearest-even is this build's definition.)
  * -------------------------------------------------------------------------- */
-uint8_t vali_oracle_q_u8(float v) {
-  float r = rintf(v); /* default rounding mode = nearest even */
+static inline uint8_t q_u8(float v) {
+  float r = __builtin_rintf(v); /* default rounding mode = nearest even */
   if (!(r > 0.0f))
     r = 0.0f; /* also maps NaN to 0 like fmaxf(NaN,0) */
   if (r > 255.0f)
     r = 255.0f;
   return (uint8_t)r;
 }
+uint8_t vali_oracle_q_u8(float v) { return q_u8(v); }
 
 int vali_oracle_csc(int variant, vali_csc* out) {
   if (!out)
@@ -95,24 +96,26 @@ int vali_oracle_nv12_to_rgb(const vali_surface* src, const vali_surface* dst,
   const int W = src->width, H = src->height;
   const uint8_t* py = (const uint8_t*)src->plane[0];
   const uint8_t* puv = (const uint8_t*)src->plane[1];
+  /* the same per-pixel arithmetic for every layout; the layout switch sits outside the pixel
+   * loop so that the CPU baseline bench.py times is not dominated by branches and calls */
+  const int planar = dst->format == VALI_FMT_RGB_PLANAR, rgb = dst->format == VALI_FMT_RGB;
   for (int y = 0; y < H; ++y) {
     const uint8_t* yrow = py + (size_t)y * src->pitch[0];
     const uint8_t* crow = puv + (size_t)(y / 2) * src->pitch[1];
+    uint8_t* o0 = (uint8_t*)dst->plane[0] + (size_t)y * dst->pitch[0];
+    uint8_t* o1 = planar ? (uint8_t*)dst->plane[1] + (size_t)y * dst->pitch[0] : 0;
+    uint8_t* o2 = planar ? (uint8_t*)dst->plane[2] + (size_t)y * dst->pitch[0] : 0;
     for (int x = 0; x < W; ++x) {
       const uint8_t* c = crow + (x & ~1);
       const chroma_term t = chroma((float)c[0], (float)c[1], csc);
       const float yf = luma((float)yrow[x], csc);
-      const uint8_t R = vali_oracle_q_u8(yf + t.rv), G = vali_oracle_q_u8(yf + t.guv),
-                    B = vali_oracle_q_u8(yf + t.bu);
-      if (dst->format == VALI_FMT_RGB_PLANAR) {
-        ((uint8_t*)dst->plane[0])[(size_t)y * dst->pitch[0] + x] = R;
-        ((uint8_t*)dst->plane[1])[(size_t)y * dst->pitch[0] + x] = G;
-        ((uint8_t*)dst->plane[2])[(size_t)y * dst->pitch[0] + x] = B;
+      const uint8_t R = q_u8(yf + t.rv), G = q_u8(yf + t.guv), B = q_u8(yf + t.bu);
+      if (planar) {
+        o0[x] = R; o1[x] = G; o2[x] = B;
+      } else if (rgb) {
+        o0[3 * x] = R; o0[3 * x + 1] = G; o0[3 * x + 2] = B;
       } else {
-        uint8_t* q = (uint8_t*)dst->plane[0] + (size_t)y * dst->pitch[0] + (size_t)x * 3;
-        q[0] = dst->format == VALI_FMT_RGB ? R : B;
-        q[1] = G;
-        q[2] = dst->format == VALI_FMT_RGB ? B : R;
+        o0[3 * x] = B; o0[3 * x + 1] = G; o0[3 * x + 2] = R;
       }
     }
   }
