@@ -127,13 +127,15 @@ def nv12_to_rgb(nv12: np.ndarray, width: int, height: int, k: Csc, dst_fmt: str 
     return out
 
 
-def nv12_to_rgb_mt(frames, width, height, k: Csc, threads: int, outs=None):
-    """frames: list of NV12 arrays; converts all with `threads` OpenMP threads (baseline)."""
+def nv12_to_rgb_mt(frames, width, height, k: Csc, threads: int, outs=None, simd: bool = False):
+    """frames: list of NV12 arrays; converts all with `threads` OpenMP threads (baseline).
+    simd=True: the AVX2 form (vali_oracle_simd.c), bit-identical output."""
     n = len(frames)
     outs = outs if outs is not None else [np.zeros((height, 3 * width), np.uint8) for _ in range(n)]
     S = (Surface * n)(*[surf_nv12(f, width, height) for f in frames])
     D = (Surface * n)(*[surf_packed3(o, width, height, "RGB") for o in outs])
-    rc = lib().vali_oracle_nv12_to_rgb_mt(S, D, n, C.byref(k), int(threads))
+    fn = lib().vali_oracle_nv12_to_rgb_simd_mt if simd else lib().vali_oracle_nv12_to_rgb_mt
+    rc = fn(S, D, n, C.byref(k), int(threads))
     if rc:
         raise RuntimeError(f"vali_oracle_nv12_to_rgb_mt -> {rc}")
     return outs

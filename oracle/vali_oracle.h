@@ -94,6 +94,14 @@ VALI_API int vali_oracle_resize_plane(const void* src, int src_pitch, int src_w,
                                       void* dst, int dst_pitch, int dst_w, int dst_h, int elem,
                                       int channels);
 
+/* AVX2 form of vali_oracle_nv12_to_rgb for packed RGB / BGR (vali_oracle_simd.c): the same
+ * operations eight pixels at a time, bit-identical output; exists only so that bench.py's
+ * cpu_baseline measures SIMD host code, as the reference's libswscale path is. */
+VALI_API int vali_oracle_nv12_to_rgb_simd(const vali_surface* src, const vali_surface* dst,
+                                          const vali_csc* csc);
+VALI_API int vali_oracle_nv12_to_rgb_simd_mt(const vali_surface* src, const vali_surface* dst, int n,
+                                             const vali_csc* csc, int threads);
+
 /* Lanczos-3 (6x6 taps, interpolating, same sampling grid) variant: the reference's
  * NPPI_INTER_LANCZOS restated with this build's own tap arithmetic (weights from fixed
  * polynomials, fma accumulation order documented in vali_oracle.c) -- parity unpinned against

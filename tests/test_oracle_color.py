@@ -48,3 +48,19 @@ def test_bt709_limited_matrix_matches_reference_frame(oracle):
     assert score["709csc"] > score["ycbcr_601"] + 1.5            # matrix family
     assert score["709csc"] > score["709hdtv"] + 9.0              # limited vs full range
     assert score["709csc"] > score["yuv_601_full"] + 9.0
+
+
+def test_simd_baseline_is_bit_identical_to_the_scalar_restatement():
+    """oracle/vali_oracle_simd.c (the CPU baseline bench.py times) == vali_oracle_nv12_to_rgb, on
+    noise, on the full-excursion gradient, for all four colour variants and ragged widths."""
+    from oracle import oracle as o
+    from conftest import make_nv12
+
+    for w, h in ((64, 48), (1920, 1080), (70, 34), (10, 6), (8, 2)):
+        for seed in (-1, 3):
+            nv = make_nv12(w, h, seed)
+            for variant in range(4):
+                k = o.csc(variant)
+                scalar = o.nv12_to_rgb_mt([nv], w, h, k, 1)[0]
+                simd = o.nv12_to_rgb_mt([nv], w, h, k, 2, simd=True)[0]
+                assert np.array_equal(scalar, simd), (w, h, seed, variant)
