@@ -29,6 +29,8 @@
 #include "common.hpp"
 #include "dev_util.hpp"
 
+#include <stdlib.h>
+
 namespace vali {
 
 enum : int {
@@ -255,8 +257,11 @@ __host__ inline UdSpan ud_span(int tile_x, int dw, int sw, float scale_x) {
 // without the intermediate surface (BASELINE config 4 as one pass: 18.7 instead of 31.1 MB).
 // For odd ROT the workgroup collects its 256 x 32 output tile in LDS, one dword per pixel, and
 // writes it transposed after a barrier (destination row <-> tile column): see the end of the kernel.
-template <typename T, int OUT, bool STAGED, int ROT = 0>
-__global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
+template <typename T, int OUT, bool STAGED, int ROT = 0, int MINW = 1>
+// (kBlock, 5) on the packed-RGB instantiation: with the two-pixel halves of sample() it fits 96
+// VGPRs (5 waves per SIMD instead of 4) at the price of 3 spilled dwords: 4.65 -> 4.40 us (cfg4a).
+// The other outputs need more registers and would spill for real, so they keep the default.
+__global__ void __launch_bounds__(kBlock, MINW) k_ud_nv12(const UdArgs a) {
   static_assert(ROT == 0 || (sizeof(T) == 1 && OUT == UD_RGB_U8), "rotated output: NV12 -> RGB only");
   constexpr int CH = (int)sizeof(T);
   __shared__ UdStage<CH> stage[STAGED ? kWavesPerBlock : 1];
@@ -364,27 +369,32 @@ __global__ void __launch_bounds__(kBlock) k_ud_nv12(const UdArgs a) {
       typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
       auto as_v2 = [](u32 w) { return __builtin_bit_cast(v2u16, w); };
       const v2u16 wyl = as_v2(rt.ty.w0 | (rt.ty.w1 << 16)), wyc = as_v2(rt.tcy.w0 | (rt.tcy.w1 << 16));
-      u32 l[4][2][2], c[4][2][2]; // [pixel][tap][row]: all LDS / global reads first
+      // two pixels at a time (reads first, then arithmetic): half the live texel registers
 #pragma unroll
-      for (int p = 0; p < 4; ++p)
+      for (int h = 0; h < 2; ++h) {
+        u32 l[2][2][2], c[2][2][2]; // [pixel][tap][row]
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          l[p][t][0] = luma(0, p, t); l[p][t][1] = luma(1, p, t);
-          c[p][t][0] = chroma(0, p, t); c[p][t][1] = chroma(1, p, t);
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            l[pp][t][0] = luma(0, 2 * h + pp, t); l[pp][t][1] = luma(1, 2 * h + pp, t);
+            c[pp][t][0] = chroma(0, 2 * h + pp, t); c[pp][t][1] = chroma(1, 2 * h + pp, t);
+          }
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+          const int p = 2 * h + pp;
+          const v2u16 wx0 = as_v2(pw[p][0]), wx1 = as_v2(pw[p][1]), wc0 = as_v2(pw[p][2]), wc1 = as_v2(pw[p][3]);
+          const v2u16 ya = as_v2(__builtin_amdgcn_perm(l[pp][0][1], l[pp][0][0], 0x0c040c00u));
+          const v2u16 yb = as_v2(__builtin_amdgcn_perm(l[pp][1][1], l[pp][1][0], 0x0c040c00u));
+          const v2u16 ua = as_v2(__builtin_amdgcn_perm(c[pp][0][1], c[pp][0][0], 0x0c040c00u));
+          const v2u16 ub = as_v2(__builtin_amdgcn_perm(c[pp][1][1], c[pp][1][0], 0x0c040c00u));
+          const v2u16 va = as_v2(__builtin_amdgcn_perm(c[pp][0][1], c[pp][0][0], 0x0c050c01u));
+          const v2u16 vb = as_v2(__builtin_amdgcn_perm(c[pp][1][1], c[pp][1][0], 0x0c050c01u));
+          sy[p] = __builtin_amdgcn_udot2(ya * wx0 + yb * wx1, wyl, 0u, false);
+          su[p] = __builtin_amdgcn_udot2(ua * wc0 + ub * wc1, wyc, 0u, false);
+          sv[p] = __builtin_amdgcn_udot2(va * wc0 + vb * wc1, wyc, 0u, false);
         }
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const v2u16 wx0 = as_v2(pw[p][0]), wx1 = as_v2(pw[p][1]), wc0 = as_v2(pw[p][2]), wc1 = as_v2(pw[p][3]);
-        // byte 0 of row 0 -> lane 0, byte 0 of row 1 -> lane 1 (selector: 0x0c = constant 0)
-        const v2u16 ya = as_v2(__builtin_amdgcn_perm(l[p][0][1], l[p][0][0], 0x0c040c00u));
-        const v2u16 yb = as_v2(__builtin_amdgcn_perm(l[p][1][1], l[p][1][0], 0x0c040c00u));
-        const v2u16 ua = as_v2(__builtin_amdgcn_perm(c[p][0][1], c[p][0][0], 0x0c040c00u));
-        const v2u16 ub = as_v2(__builtin_amdgcn_perm(c[p][1][1], c[p][1][0], 0x0c040c00u));
-        const v2u16 va = as_v2(__builtin_amdgcn_perm(c[p][0][1], c[p][0][0], 0x0c050c01u));
-        const v2u16 vb = as_v2(__builtin_amdgcn_perm(c[p][1][1], c[p][1][0], 0x0c050c01u));
-        sy[p] = __builtin_amdgcn_udot2(ya * wx0 + yb * wx1, wyl, 0u, false);
-        su[p] = __builtin_amdgcn_udot2(ua * wc0 + ub * wc1, wyc, 0u, false);
-        sv[p] = __builtin_amdgcn_udot2(va * wc0 + vb * wc1, wyc, 0u, false);
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else {
       u32 l[4][4], cu[4][4], cv[4][4]; // [pixel][00,10,01,11]
@@ -680,9 +690,12 @@ static int launch_ud(UdArgs& a, int src_fmt, int src_w, int dst_w, int dst_h, in
       staged = sp.yn <= cap && sp.cn <= cap;
     }
   }
+  static const bool occ5 = [] { const char* e = getenv("VALI_UD_OCC5"); return !(e && e[0] == '0'); }();
 #define VALI_UD_CASE(T, K)                                                                  \
   case K:                                                                                   \
-    if (staged)                                                                             \
+    if (staged && K == UD_RGB_U8 && sizeof(T) == 1 && occ5)                                 \
+      hipLaunchKernelGGL((k_ud_nv12<uint8_t, UD_RGB_U8, true, 0, 5>), grid, block, 0, stream, a); \
+    else if (staged)                                                                        \
       hipLaunchKernelGGL((k_ud_nv12<T, K, true>), grid, block, 0, stream, a);                \
     else                                                                                    \
       hipLaunchKernelGGL((k_ud_nv12<T, K, false>), grid, block, 0, stream, a);               \
