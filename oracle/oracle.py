@@ -6,7 +6,6 @@ cpu_baseline leg of bench.py, never by vali_amd.  Every function operates on HOS
 from __future__ import annotations
 
 import ctypes as C
-import os
 import subprocess
 from pathlib import Path
 

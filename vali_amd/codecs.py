@@ -22,7 +22,6 @@ from typing import Optional, Tuple
 
 import numpy as np
 
-from ._native import shim
 from .enums import ColorRange, ColorSpace, PixelFormat, TaskExecInfo
 from .runtime import HipResMgr
 from .surface import FORMATS, Surface
