@@ -285,30 +285,56 @@ __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
     }
     if (dy_ < 0 || dy_ >= dst_h)
       continue;
-    uint8_t px[4 * P];
     bool ok[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int jj = QUARTER == 1 ? chunk * 4 + q : chunk * 4 + 3 - q;
-      ok[q] = jj < th && dx0 + q >= 0 && dx0 + q < dst_w;
-#pragma unroll
-      for (int b = 0; b < P; ++b)
-        px[q * P + b] = ok[q] ? lds[jj * S + lc * P + b] : (uint8_t)0;
-    }
     uint8_t* o = dst + (size_t)dy_ * dst_pitch + (size_t)dx0 * P;
-    if (ok[0] && ok[1] && ok[2] && ok[3] && (((uintptr_t)o) & 3u) == 0) {
-      u32 w[P];
-      __builtin_memcpy(w, px, 4 * P);
+    if constexpr (P % 4 == 0) {
+      // whole-dword pixels (f32 / f32x3): dword LDS reads, no byte reassembly
+      constexpr int D = P / 4;
+      u32 w[4 * D];
 #pragma unroll
-      for (int k = 0; k < P; ++k)
-        ((u32*)o)[k] = w[k];
+      for (int q = 0; q < 4; ++q) {
+        const int jj = QUARTER == 1 ? chunk * 4 + q : chunk * 4 + 3 - q;
+        ok[q] = jj < th && dx0 + q >= 0 && dx0 + q < dst_w;
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+          w[q * D + k] = ok[q] ? *reinterpret_cast<const u32*>(lds + jj * S + lc * P + 4 * k) : 0u;
+      }
+      if (ok[0] && ok[1] && ok[2] && ok[3] && (((uintptr_t)o) & 3u) == 0) {
+#pragma unroll
+        for (int k = 0; k < 4 * D; ++k)
+          gstore<u32>(o + 4 * k, w[k]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (ok[q])
+#pragma unroll
+            for (int k = 0; k < D; ++k)
+              for (int b = 0; b < 4; ++b) gstore<uint8_t>(o + q * P + 4 * k + b, (uint8_t)(w[q * D + k] >> (8 * b)));
+      }
     } else {
+      uint8_t px[4 * P];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (ok[q])
+      for (int q = 0; q < 4; ++q) {
+        const int jj = QUARTER == 1 ? chunk * 4 + q : chunk * 4 + 3 - q;
+        ok[q] = jj < th && dx0 + q >= 0 && dx0 + q < dst_w;
 #pragma unroll
-          for (int b = 0; b < P; ++b)
-            o[q * P + b] = px[q * P + b];
+        for (int b = 0; b < P; ++b)
+          px[q * P + b] = ok[q] ? lds[jj * S + lc * P + b] : (uint8_t)0;
+      }
+      if (ok[0] && ok[1] && ok[2] && ok[3] && (((uintptr_t)o) & 3u) == 0) {
+        u32 w[P];
+        __builtin_memcpy(w, px, 4 * P);
+#pragma unroll
+        for (int k = 0; k < P; ++k)
+          ((u32*)o)[k] = w[k];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (ok[q])
+#pragma unroll
+            for (int b = 0; b < P; ++b)
+              o[q * P + b] = px[q * P + b];
+      }
     }
   }
   } // P != 3
