@@ -268,11 +268,13 @@ VALI_API int vali_ud_nv12_rot_batch(const vali_surface* d_src, const vali_surfac
 /* ---- resize: replaces nppiResize_{8u,32f}_C{1,3}R_Ctx --------------------------------- */
 
 /* Values follow NppiInterpolationMode (NPPI_INTER_LINEAR = 2 is not used by the reference;
- * NPPI_INTER_LANCZOS = 16 is what every nppiResize call site passes).  Both modes sample on the
- * grid src = dst * (src_size / dst_size), no half-pixel shift -- pinned by the reference fixture
+ * NPPI_INTER_LANCZOS = 16 is what every nppiResize call site passes; NPPI_INTER_CUBIC = 4 is the
+ * "bicubic" BASELINE.json's north_star names).  All modes sample on the grid
+ * src = dst * (src_size / dst_size), no half-pixel shift -- pinned by the reference fixture
  * test_small.nv12 (tests/test_oracle_resize.py). */
 enum vali_interpolation {
   VALI_INTERP_LINEAR = 1,   /* bilinear: BASELINE.json config 3 */
+  VALI_INTERP_CUBIC = 4,    /* 4x4 Keys / Catmull-Rom cubic convolution (a = -1/2) */
   VALI_INTERP_LANCZOS = 16  /* 6x6 interpolating Lanczos-3 (TaskResizeSurface.cpp:67,116,224,273) */
 };
 

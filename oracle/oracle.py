@@ -211,11 +211,12 @@ def canonical_shifts(angle: float, src_w: int, src_h: int):
 
 
 def resize_plane(src: np.ndarray, channels: int, dst_w: int, dst_h: int, interp: str = "linear") -> np.ndarray:
-    """src: (H, W*channels) uint8/uint16/float32 -> (dst_h, dst_w*channels); bilinear or lanczos."""
+    """src: (H, W*channels) uint8/uint16/float32 -> (dst_h, dst_w*channels); linear | cubic | lanczos."""
     assert src.ndim == 2 and src.flags.c_contiguous
     sh, sw = src.shape[0], src.shape[1] // channels
     out = np.zeros((dst_h, dst_w * channels), src.dtype)
-    fn = {"linear": lib().vali_oracle_resize_plane, "lanczos": lib().vali_oracle_resize_plane_lanczos}[interp]
+    fn = {"linear": lib().vali_oracle_resize_plane, "lanczos": lib().vali_oracle_resize_plane_lanczos,
+          "cubic": lib().vali_oracle_resize_plane_cubic}[interp]
     rc = fn(C.c_void_p(src.ctypes.data), src.strides[0], sw, sh,
             C.c_void_p(out.ctypes.data), out.strides[0], dst_w, dst_h,
             src.dtype.itemsize, channels)
@@ -227,6 +228,15 @@ def resize_plane(src: np.ndarray, channels: int, dst_w: int, dst_h: int, interp:
 def lanczos3_weights(a: float) -> np.ndarray:
     w = (C.c_float * 6)()
     f = lib().vali_oracle_lanczos3_weights
+    f.restype = None
+    f.argtypes = [C.c_float, C.POINTER(C.c_float)]
+    f(a, w)
+    return np.array(list(w), np.float32)
+
+
+def cubic_weights(a: float) -> np.ndarray:
+    w = (C.c_float * 4)()
+    f = lib().vali_oracle_cubic_weights
     f.restype = None
     f.argtypes = [C.c_float, C.POINTER(C.c_float)]
     f(a, w)

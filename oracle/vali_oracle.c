@@ -487,41 +487,62 @@ void vali_oracle_lanczos3_weights(float a, float w[6]) {
     w[k] = raw[k] / sum;
 }
 
+/*
+ * Bicubic (NPPI_INTER_CUBIC = 4; BASELINE.json's north_star names a "bilinear/bicubic resizer",
+ * the reference itself never passes it): the Keys / Catmull-Rom cubic convolution kernel
+ * (a = -1/2) on the same sampling grid, taps i-1 .. i+2:
+ *   w0 = ((-a/2 + 1) a - 1/2) a      w1 = (3a/2 - 5/2) a^2 + 1
+ *   w2 = ((-3a/2 + 2) a + 1/2) a     w3 = (a/2 - 1/2) a^2
+ * in Horner form with explicit fma, not renormalised (the four sum to 1 analytically); a == 0
+ * gives {0,1,0,0} by the formulas.  PARITY UNPINNED: which cubic NPP implements is not published.
+ * Rows/columns accumulate exactly like the Lanczos filter above (4 taps instead of 6).
+ */
+void vali_oracle_cubic_weights(float a, float w[4]) {
+  const float a2 = a * a;
+  w[0] = a * fmaf(a, fmaf(a, -0.5f, 1.0f), -0.5f);
+  w[1] = fmaf(a2, fmaf(a, 1.5f, -2.5f), 1.0f);
+  w[2] = a * fmaf(a, fmaf(a, -1.5f, 2.0f), 0.5f);
+  w[3] = a2 * fmaf(a, 0.5f, -0.5f);
+}
+
 typedef struct { int idx[6]; float w[6]; } lz_tap_t;
 
-static inline lz_tap_t lz_make_tap(int x, float scale, int size) {
+/* taps = 6: Lanczos-3 (i-2 .. i+3) ; taps = 4: cubic (i-1 .. i+2) */
+static inline lz_tap_t lz_make_tap(int x, float scale, int size, int taps) {
   const float f = (float)x * scale;
   const float fl = floorf(f);
   lz_tap_t t;
-  vali_oracle_lanczos3_weights(f - fl, t.w);
+  if (taps == 6)
+    vali_oracle_lanczos3_weights(f - fl, t.w);
+  else
+    vali_oracle_cubic_weights(f - fl, t.w);
   const int i = (int)fl;
-  for (int k = 0; k < 6; ++k) {
-    int j = i - 2 + k;
+  for (int k = 0; k < taps; ++k) {
+    int j = i - (taps / 2 - 1) + k;
     j = j < 0 ? 0 : (j > size - 1 ? size - 1 : j);
     t.idx[k] = j;
   }
   return t;
 }
 
-int vali_oracle_resize_plane_lanczos(const void* src, int src_pitch, int src_w, int src_h,
-                                     void* dst, int dst_pitch, int dst_w, int dst_h, int elem,
-                                     int channels) {
+static int resize_plane_taps(const void* src, int src_pitch, int src_w, int src_h, void* dst,
+                             int dst_pitch, int dst_w, int dst_h, int elem, int channels, int taps) {
   if (!src || !dst || src_w <= 0 || src_h <= 0 || dst_w <= 0 || dst_h <= 0)
     return VALI_ERR_INVALID_ARG;
   if ((elem != 1 && elem != 2 && elem != 4) || channels < 1 || channels > 3)
     return VALI_ERR_INVALID_ARG;
   const float scale_x = (float)src_w / (float)dst_w, scale_y = (float)src_h / (float)dst_h;
   for (int y = 0; y < dst_h; ++y) {
-    const lz_tap_t ty = lz_make_tap(y, scale_y, src_h);
+    const lz_tap_t ty = lz_make_tap(y, scale_y, src_h, taps);
     uint8_t* drow = (uint8_t*)dst + (size_t)y * dst_pitch;
     for (int x = 0; x < dst_w; ++x) {
-      const lz_tap_t tx = lz_make_tap(x, scale_x, src_w);
+      const lz_tap_t tx = lz_make_tap(x, scale_x, src_w, taps);
       for (int ch = 0; ch < channels; ++ch) {
         float v = 0.0f;
-        for (int r = 0; r < 6; ++r) {
+        for (int r = 0; r < taps; ++r) {
           const uint8_t* row = (const uint8_t*)src + (size_t)ty.idx[r] * src_pitch;
           float hsum = tx.w[0] * rot_texel(row, tx.idx[0] * channels + ch, elem);
-          for (int k = 1; k < 6; ++k)
+          for (int k = 1; k < taps; ++k)
             hsum = fmaf(tx.w[k], rot_texel(row, tx.idx[k] * channels + ch, elem), hsum);
           v = r == 0 ? ty.w[0] * hsum : fmaf(ty.w[r], hsum, v);
         }
@@ -540,4 +561,15 @@ int vali_oracle_resize_plane_lanczos(const void* src, int src_pitch, int src_w, 
     }
   }
   return VALI_OK;
+}
+
+int vali_oracle_resize_plane_lanczos(const void* src, int src_pitch, int src_w, int src_h,
+                                     void* dst, int dst_pitch, int dst_w, int dst_h, int elem,
+                                     int channels) {
+  return resize_plane_taps(src, src_pitch, src_w, src_h, dst, dst_pitch, dst_w, dst_h, elem, channels, 6);
+}
+
+int vali_oracle_resize_plane_cubic(const void* src, int src_pitch, int src_w, int src_h, void* dst,
+                                   int dst_pitch, int dst_w, int dst_h, int elem, int channels) {
+  return resize_plane_taps(src, src_pitch, src_w, src_h, dst, dst_pitch, dst_w, dst_h, elem, channels, 4);
 }

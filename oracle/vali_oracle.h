@@ -111,6 +111,13 @@ VALI_API int vali_oracle_resize_plane_lanczos(const void* src, int src_pitch, in
                                               void* dst, int dst_pitch, int dst_w, int dst_h,
                                               int elem, int channels);
 
+/* Bicubic (Keys / Catmull-Rom, a = -1/2; taps i-1 .. i+2) on the same grid: the mode
+ * BASELINE.json's north_star names next to bilinear (NPPI_INTER_CUBIC); parity unpinned. */
+VALI_API void vali_oracle_cubic_weights(float a, float w[4]);
+VALI_API int vali_oracle_resize_plane_cubic(const void* src, int src_pitch, int src_w, int src_h,
+                                            void* dst, int dst_pitch, int dst_w, int dst_h,
+                                            int elem, int channels);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,7 +48,8 @@ def test_foreign_unaligned_rows_all_gather_kernels(vali, gpu, oracle, pad, skew)
     assert vali.PySurfaceUD(gpu).Run(src, dst)[0]
     assert np.array_equal(download(vali, gpu, dst), oracle.ud_nv12(nv, sw, sh, "NV12", dw, dh, "RGB").reshape(-1))
     # resize, both filters
-    for interp, name in ((vali.Interpolation.LINEAR, "linear"), (vali.Interpolation.LANCZOS, "lanczos")):
+    for interp, name in ((vali.Interpolation.LINEAR, "linear"), (vali.Interpolation.CUBIC, "cubic"),
+                         (vali.Interpolation.LANCZOS, "lanczos")):
         small = vali.Surface.Make(vali.NV12, dw, dh, gpu)
         assert vali.PySurfaceResizer(vali.NV12, gpu, interpolation=interp).Run(src, small)[0]
         assert np.array_equal(download(vali, gpu, small), oracle.resize_surface(flat, "NV12", sw, sh, dw, dh, name))
@@ -73,7 +74,8 @@ def test_extreme_sizes_nv12(vali, gpu, oracle, geom):
     nv = make_nv12(sw, sh, 17)
     src = upload(vali, gpu, vali.NV12, sw, sh, nv)
     flat = nv.reshape(-1)
-    for interp, name in ((vali.Interpolation.LINEAR, "linear"), (vali.Interpolation.LANCZOS, "lanczos")):
+    for interp, name in ((vali.Interpolation.LINEAR, "linear"), (vali.Interpolation.CUBIC, "cubic"),
+                         (vali.Interpolation.LANCZOS, "lanczos")):
         small = vali.Surface.Make(vali.NV12, dw, dh, gpu)
         assert vali.PySurfaceResizer(vali.NV12, gpu, interpolation=interp).Run(src, small)[0]
         assert np.array_equal(download(vali, gpu, small), oracle.resize_surface(flat, "NV12", sw, sh, dw, dh, name)), name
@@ -100,7 +102,8 @@ def test_extreme_sizes_single_plane(vali, gpu, oracle, fmt, dt, ch, geom):
     rng = np.random.default_rng(sw * 7 + dh)
     host = (rng.random(sw * sh * ch) * 255).astype(dt)
     src = upload(vali, gpu, vali.PixelFormat[fmt], sw, sh, host)
-    for interp, name in ((vali.Interpolation.LINEAR, "linear"), (vali.Interpolation.LANCZOS, "lanczos")):
+    for interp, name in ((vali.Interpolation.LINEAR, "linear"), (vali.Interpolation.CUBIC, "cubic"),
+                         (vali.Interpolation.LANCZOS, "lanczos")):
         d = vali.Surface.Make(vali.PixelFormat[fmt], dw, dh, gpu)
         assert vali.PySurfaceResizer(vali.PixelFormat[fmt], gpu, interpolation=interp).Run(src, d)[0]
         want = oracle.resize_surface(host, fmt, sw, sh, dw, dh, name)

@@ -43,7 +43,8 @@ def test_random_nv12_resize_ud_preproc(vali, gpu, oracle, geom):
     nv = make_nv12(sw, sh, sw * 31 + dh)
     src = _up(vali, gpu, vali.NV12, sw, sh, nv)
     flat = nv.reshape(-1)
-    for interp, name in ((vali.Interpolation.LINEAR, "linear"), (vali.Interpolation.LANCZOS, "lanczos")):
+    for interp, name in ((vali.Interpolation.LINEAR, "linear"), (vali.Interpolation.CUBIC, "cubic"),
+                         (vali.Interpolation.LANCZOS, "lanczos")):
         d = vali.Surface.Make(vali.NV12, dw, dh, gpu)
         assert vali.PySurfaceResizer(vali.NV12, gpu, interpolation=interp).Run(src, d)[0]
         assert np.array_equal(_down(vali, gpu, d), oracle.resize_surface(flat, "NV12", sw, sh, dw, dh, name)), name
@@ -77,7 +78,8 @@ def test_random_single_plane_resize_rotate(vali, gpu, oracle, geom, fmt, dt, ch)
     host = (rng.random(sw * sh * ch) * 255).astype(dt)
     pf = vali.PixelFormat[fmt]
     src = _up(vali, gpu, pf, sw, sh, host)
-    for interp, name in ((vali.Interpolation.LINEAR, "linear"), (vali.Interpolation.LANCZOS, "lanczos")):
+    for interp, name in ((vali.Interpolation.LINEAR, "linear"), (vali.Interpolation.CUBIC, "cubic"),
+                         (vali.Interpolation.LANCZOS, "lanczos")):
         d = vali.Surface.Make(pf, dw, dh, gpu)
         assert vali.PySurfaceResizer(pf, gpu, interpolation=interp).Run(src, d)[0]
         want = oracle.resize_surface(host, fmt, sw, sh, dw, dh, name)

@@ -96,6 +96,31 @@ def test_lanczos_bit_exact(vali, gpu, oracle, fmt, geom):
     assert np.array_equal(got, want)
 
 
+# ---- bicubic (NPPI_INTER_CUBIC; the filter BASELINE.json's north_star names next to bilinear) ---
+@pytest.mark.parametrize("fmt", ["NV12", "YUV420", "RGB", "RGB_PLANAR", "RGB_32F", "Y", "P10", "YUV444_10bit"])
+@pytest.mark.parametrize("geom", [(848, 464, 424, 232), (640, 360, 1000, 500), (130, 70, 58, 34),
+                                  (1920, 1080, 1280, 720), (64, 48, 640, 480)])
+def test_cubic_bit_exact(vali, gpu, oracle, fmt, geom):
+    sw, sh, dw, dh = geom
+    dt = DT.get(fmt, np.uint8)
+    n = vali.Surface.Make(vali.PixelFormat[fmt], sw, sh, gpu).HostSize // np.dtype(dt).itemsize
+    rng = np.random.default_rng(23)
+    host = (rng.random(n) * (1000 if dt == np.uint16 else 255)).astype(dt)
+    got = roundtrip(vali, gpu, fmt, host, sw, sh, dw, dh, interp=vali.Interpolation.CUBIC)
+    want = oracle.resize_surface(host, fmt, sw, sh, dw, dh, "cubic")
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+
+
+def test_cubic_2160p_noninteger_and_wide_span(vali, gpu, oracle):
+    """1080x608 from 2160p: the luma span fits the LDS strip, a 3.55x chroma span does not (gather)."""
+    sw, sh = 3840, 2160
+    rng = np.random.default_rng(8)
+    frame = rng.integers(0, 256, sw * sh * 3 // 2, dtype=np.uint8)
+    for dw, dh in ((1080, 608), (2000, 1126)):
+        got = roundtrip(vali, gpu, "NV12", frame, sw, sh, dw, dh, interp=vali.Interpolation.CUBIC)
+        assert np.array_equal(got, oracle.resize_surface(frame, "NV12", sw, sh, dw, dh, "cubic"))
+
+
 def test_lanczos_real_frames_match_reference_fixture_geometry(vali, gpu, oracle):
     """reference tests/test_PySurfaceResizer.py resizes by exactly 2x with NPP Lanczos; at integer
     factors an interpolating kernel is the point sample src[2y][2x] -- same as bilinear."""
@@ -134,7 +159,7 @@ def test_lanczos_noninteger_2160p_to_1080x608(vali, gpu, oracle):
     assert np.array_equal(got, oracle.resize_surface(frame, "NV12", sw, sh, dw, dh, "lanczos"))
 
 
-@pytest.mark.parametrize("interp", ["linear", "lanczos"])
+@pytest.mark.parametrize("interp", ["linear", "cubic", "lanczos"])
 def test_float_planes_keep_denormals_and_signed_zero(vali, gpu, oracle, interp):
     """f32 planes: subnormal inputs, negative values and -0.0 go through the same IEEE arithmetic as
     on the CPU (no flush-to-zero in the kernels): bit-exact, not merely close."""
@@ -145,7 +170,7 @@ def test_float_planes_keep_denormals_and_signed_zero(vali, gpu, oracle, interp):
     host[::11] *= np.float32(-1.0)
     host[::13] = np.float32(-0.0)
     host[::17] = np.float32(3.0e38)                # near FLT_MAX: products overflow to inf identically
-    it = vali.Interpolation.LINEAR if interp == "linear" else vali.Interpolation.LANCZOS
+    it = vali.Interpolation[interp.upper()]
     got = roundtrip(vali, gpu, "RGB_32F", host, sw, sh, dw, dh, interp=it)
     want = oracle.resize_surface(host, "RGB_32F", sw, sh, dw, dh, interp)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))

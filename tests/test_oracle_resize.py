@@ -95,3 +95,60 @@ def test_lanczos_upscale_is_sharper_than_bilinear_on_a_band_limited_signal():
     e_lz = np.abs(o.resize_plane(src, 1, dw, 8, "lanczos")[0][inner] - truth[inner]).max()
     e_bl = np.abs(o.resize_plane(src, 1, dw, 8, "linear")[0][inner] - truth[inner]).max()
     assert e_lz < 0.35 * e_bl
+
+
+# ---- bicubic restatement (Keys a = -1/2): pinned against an independent float64 evaluation ----
+def _keys(t, a=-0.5):
+    t = np.abs(t)
+    return np.where(t <= 1, (a + 2) * t ** 3 - (a + 3) * t ** 2 + 1,
+                    np.where(t < 2, a * t ** 3 - 5 * a * t ** 2 + 8 * a * t - 4 * a, 0.0))
+
+
+def test_cubic_weights_are_the_keys_kernel():
+    from oracle import oracle as o
+    for a in np.linspace(0.0, 0.999, 41, dtype=np.float32):
+        w = o.cubic_weights(float(a))
+        ref = _keys(np.float64(a) + np.array([1, 0, -1, -2.0]))
+        assert np.abs(w - ref).max() < 2e-7
+        assert abs(float(w.astype(np.float64).sum()) - 1.0) < 3e-7
+    assert np.array_equal(o.cubic_weights(0.0), np.array([0, 1, 0, 0], np.float32))
+
+
+def test_cubic_identity_integer_factors_and_float64_model():
+    from oracle import oracle as o
+    rng = np.random.default_rng(4)
+    for dt, hi in ((np.uint8, 256), (np.uint16, 1024)):
+        src = rng.integers(0, hi, (48, 66), dtype=dt)
+        assert np.array_equal(o.resize_plane(src, 1, 66, 48, "cubic"), src)
+        assert np.array_equal(o.resize_plane(src, 1, 33, 24, "cubic"), src[::2, ::2])
+        assert np.array_equal(o.resize_plane(src, 2, 33, 48, "cubic"), o.resize_plane(src, 2, 33, 48, "linear"))
+    flat = np.full((20, 30), 177, np.uint8)
+    assert np.array_equal(o.resize_plane(flat, 1, 77, 41, "cubic"), np.full((41, 77), 177, np.uint8))
+    # separable float64 model on the same grid with clamped indices
+    src = rng.random((23, 31), dtype=np.float32)
+    dw, dh = 50, 37
+
+    def taps(n_dst, n_src):
+        f = np.arange(n_dst, dtype=np.float32) * (np.float32(n_src) / np.float32(n_dst))
+        i = np.floor(f).astype(int)
+        a = (f - np.floor(f)).astype(np.float64)
+        idx = np.clip(i[:, None] + np.arange(-1, 3)[None, :], 0, n_src - 1)
+        return idx, _keys(a[:, None] - np.arange(-1, 3)[None, :])
+
+    ix, wx = taps(dw, 31)
+    iy, wy = taps(dh, 23)
+    hor = (src.astype(np.float64)[:, ix] * wx[None]).sum(-1)          # (23, dw)
+    model = (hor[iy] * wy[:, :, None]).sum(1)                          # (dh, dw)
+    assert np.abs(o.resize_plane(src, 1, dw, dh, "cubic") - model).max() < 2e-6
+
+
+def test_cubic_sits_between_bilinear_and_lanczos_on_a_band_limited_signal():
+    from oracle import oracle as o
+    x = np.arange(64, dtype=np.float64)
+    src = (127.5 + 100 * np.sin(2 * np.pi * x / 9.0))[None, :].repeat(8, 0).astype(np.float32)
+    dw = 64 * 4
+    xs = np.arange(dw) * (64 / dw)
+    truth = 127.5 + 100 * np.sin(2 * np.pi * xs / 9.0)
+    inner = slice(16, dw - 16)
+    err = {k: np.abs(o.resize_plane(src, 1, dw, 8, k)[0][inner] - truth[inner]).max() for k in ("linear", "cubic", "lanczos")}
+    assert err["lanczos"] < err["cubic"] < err["linear"]

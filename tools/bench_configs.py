@@ -155,7 +155,8 @@ def cfg3_lanczos(n=64):
     out = []
     for (sw, sh, dw, dh) in ((3840, 2160, 1280, 720), (3840, 2160, 1920, 1088), (1920, 1080, 3840, 2160)):
         res = {}
-        for name, interp in (("linear", vali.Interpolation.LINEAR), ("lanczos", vali.Interpolation.LANCZOS)):
+        for name, interp in (("linear", vali.Interpolation.LINEAR), ("cubic", vali.Interpolation.CUBIC),
+                             ("lanczos", vali.Interpolation.LANCZOS)):
             rs = vali.PySurfaceResizer(vali.NV12, DEV, interpolation=interp)
             m = n if sw * sh <= 3840 * 2160 and dw * dh <= 1920 * 1088 else 16
             srcs = [vali.Surface.Make(vali.NV12, sw, sh, DEV) for _ in range(m)]

@@ -435,6 +435,7 @@ PYBIND11_MODULE(_vali_shim, m) {
         },
         py::call_guard<py::gil_scoped_release>());
   m.attr("INTERP_LINEAR") = (int)VALI_INTERP_LINEAR;
+  m.attr("INTERP_CUBIC") = (int)VALI_INTERP_CUBIC;
   m.attr("INTERP_LANCZOS") = (int)VALI_INTERP_LANCZOS;
 
   m.def("rotate",

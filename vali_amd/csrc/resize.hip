@@ -280,15 +280,30 @@ __device__ __forceinline__ void lanczos3_weights(float a, float (&w)[6]) {
     w[k] = on_grid ? (k == 2 ? 1.0f : 0.0f) : raw[k] / sum;
 }
 
-struct LzTap {
-  int i;      // floor of the source coordinate; taps i-2 .. i+3
-  float w[6];
+// Bicubic (VALI_INTERP_CUBIC): Keys / Catmull-Rom cubic convolution (a = -1/2), taps i-1 .. i+2;
+// same Horner forms as the oracle (vali_oracle_cubic_weights), not renormalised.
+__device__ __forceinline__ void cubic_weights(float a, float (&w)[4]) {
+  const float a2 = a * a;
+  w[0] = a * __builtin_fmaf(a, __builtin_fmaf(a, -0.5f, 1.0f), -0.5f);
+  w[1] = __builtin_fmaf(a2, __builtin_fmaf(a, 1.5f, -2.5f), 1.0f);
+  w[2] = a * __builtin_fmaf(a, __builtin_fmaf(a, -1.5f, 2.0f), 0.5f);
+  w[3] = a2 * __builtin_fmaf(a, 0.5f, -0.5f);
+}
+
+// TAPS = 6: Lanczos-3, TAPS = 4: cubic; the taps are i - kBefore .. i + TAPS - 1 - kBefore
+template <int TAPS> struct LzTap {
+  static constexpr int kBefore = TAPS / 2 - 1;
+  int i;      // floor of the source coordinate
+  float w[TAPS];
 };
-__device__ __forceinline__ LzTap make_lz_tap(int x, float scale) {
+template <int TAPS> __device__ __forceinline__ LzTap<TAPS> make_lz_tap(int x, float scale) {
   const float f = (float)x * scale;
   const float fl = __builtin_floorf(f);
-  LzTap t;
-  lanczos3_weights(f - fl, t.w);
+  LzTap<TAPS> t;
+  if constexpr (TAPS == 6)
+    lanczos3_weights(f - fl, t.w);
+  else
+    cubic_weights(f - fl, t.w);
   t.i = (int)fl;
   return t;
 }
@@ -306,17 +321,18 @@ struct alignas(16) LzStage {
 // ds_write_b128, no register shifting -- the shifts were 31 % of an append's instructions);
 // 2- and 3-channel planes keep it in registers (12-18 KiB more LDS per wave costs a third of
 // the resident waves: NV12 with both planes in LDS measured 6.9 vs 5.7 us).
-template <int MAXC> struct alignas(16) LzRing { // one channel's window: 6 KiB per wave
-  float4 slot[6][1][kWave];
+template <int MAXC, int TAPS> struct alignas(16) LzRing { // one channel's window: TAPS KiB per wave
+  float4 slot[TAPS][1][kWave];
 };
-template <> struct alignas(16) LzRing<3> {      // packed 3-channel formats have no 1-channel plane
+template <int TAPS> struct alignas(16) LzRing<3, TAPS> { // packed 3-channel formats have no 1-channel plane
   float4 unused;
 };
 
-template <typename T, int C, int MAXC>
+template <typename T, int C, int MAXC, int TAPS>
 __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int sw, int sh,
                                              uint8_t* dp, int dpitch, int dw, int dh, u32 tx,
-                                             u32 ty, LzStage* stage_all, LzRing<MAXC>* ring_all) {
+                                             u32 ty, LzStage* stage_all, LzRing<MAXC, TAPS>* ring_all) {
+  constexpr int kBefore = LzTap<TAPS>::kBefore;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int x0 = (tx * 64 + lane) * 4;
@@ -326,24 +342,24 @@ __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int 
   const float scale_x = (float)sw / (float)dw, scale_y = (float)sh / (float)dh;
   constexpr int PB = C * (int)sizeof(T);
 
-  LzTap cx[4];
+  LzTap<TAPS> cx[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p)
-    cx[p] = make_lz_tap(min(x0 + p, dw - 1), scale_x);
+    cx[p] = make_lz_tap<TAPS>(min(x0 + p, dw - 1), scale_x);
   const int n = min(4, dw - x0);
   // row taps: lane r evaluates row y_first + r, read back as scalars
-  const LzTap vy = make_lz_tap(y_first + (lane & (kRsRowsPerWave - 1)), scale_y);
+  const LzTap<TAPS> vy = make_lz_tap<TAPS>(y_first + (lane & (kRsRowsPerWave - 1)), scale_y);
   auto row_tap = [&](int rr) {
-    LzTap t;
+    LzTap<TAPS> t;
     t.i = __builtin_amdgcn_readlane(vy.i, rr);
 #pragma unroll
-    for (int k = 0; k < 6; ++k)
+    for (int k = 0; k < TAPS; ++k)
       t.w[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vy.w[k]), rr));
     return t;
   };
 
-  const int sx0 = clampi(__builtin_amdgcn_readlane(cx[0].i, 0) - 2, sw - 1);
-  const int sx1 = clampi(__builtin_amdgcn_readlane(cx[3].i, 63) + 3, sw - 1);
+  const int sx0 = clampi(__builtin_amdgcn_readlane(cx[0].i, 0) - kBefore, sw - 1);
+  const int sx1 = clampi(__builtin_amdgcn_readlane(cx[3].i, 63) + TAPS - 1 - kBefore, sw - 1);
   const int byte_begin = (sx0 * PB) & ~15;
   const int nbytes = (((sx1 + 1) * PB + 15) & ~15) - byte_begin;
   const bool staged = nbytes <= kLzRowBytes && ((((uintptr_t)sp) | (uintptr_t)spitch) & 15u) == 0;
@@ -357,14 +373,14 @@ __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int 
     // time goes through the wave's LDS strip; the next row's loads are in flight meanwhile.
     LzStage& st = stage_all[wave];
     const int nchunks = nbytes / 16;
-    int lo[4][6]; // LDS byte offsets of the column taps (row-invariant)
+    int lo[4][TAPS]; // LDS byte offsets of the column taps (row-invariant)
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-      for (int k = 0; k < 6; ++k)
-        lo[p][k] = clampi(cx[p].i - 2 + k, sw - 1) * PB - byte_begin;
+      for (int k = 0; k < TAPS; ++k)
+        lo[p][k] = clampi(cx[p].i - kBefore + k, sw - 1) * PB - byte_begin;
     constexpr bool kLdsRing = C == 1 && MAXC <= 2;
-    float hq[kLdsRing ? 1 : 6][4][C]; // register window (3-channel planes only)
+    float hq[kLdsRing ? 1 : TAPS][4][C]; // register window (3-channel planes only)
     int head = 0;                      // LDS ring: slot of the oldest row
     uint4 pf[kLzCpr];
     int pf_row = -0x40000000; // logical source row held by pf
@@ -376,7 +392,7 @@ __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int 
       pf_row = logical;
     };
     auto append = [&](int logical) {
-      if (pf_row != logical) // first row of the wave, or a jump of more than 6 rows
+      if (pf_row != logical) // first row of the wave, or a jump of more than TAPS rows
         issue(logical);
 #pragma unroll
       for (int c = 0; c < kLzCpr; ++c)
@@ -392,7 +408,7 @@ __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int 
           auto texel = [&](int k) { return (float)((const T*)(st.row + lo[p][k]))[ch]; };
           float h = cx[p].w[0] * texel(0);
 #pragma unroll
-          for (int k = 1; k < 6; ++k)
+          for (int k = 1; k < TAPS; ++k)
             h = __builtin_fmaf(cx[p].w[k], texel(k), h);
           hv[p] = h;
           __builtin_amdgcn_sched_barrier(0); // one pixel-channel at a time: bounds the live registers
@@ -403,14 +419,14 @@ __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int 
 #pragma unroll
           for (int p = 0; p < 4; ++p) {
 #pragma unroll
-            for (int r = 0; r < 5; ++r)
+            for (int r = 0; r < TAPS - 1; ++r)
               hq[r][p][ch] = hq[r + 1][p][ch];
-            hq[5][p][ch] = hv[p];
+            hq[TAPS - 1][p][ch] = hv[p];
           }
         }
       }
       if constexpr (kLdsRing)
-        head = head == 5 ? 0 : head + 1;
+        head = head == TAPS - 1 ? 0 : head + 1;
       wave_lds_sync(); // the strip is re-filled by the next row
     };
     int base = 0;
@@ -419,12 +435,12 @@ __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int 
       const int y = y_first + rr;
       if (y >= dh)
         break;
-      const LzTap cy = row_tap(rr);
-      const int want = cy.i - 2;
-      const int delta = rr == 0 ? 6 : min(want - base, 6);
+      const LzTap<TAPS> cy = row_tap(rr);
+      const int want = cy.i - kBefore;
+      const int delta = rr == 0 ? TAPS : min(want - base, TAPS);
 #pragma unroll 1
       for (int s = 0; s < delta; ++s)
-        append(want + 6 - delta + s);
+        append(want + TAPS - delta + s);
       base = want;
       if (n > 0) {
         float res[4][C];
@@ -432,10 +448,10 @@ __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int 
         for (int ch = 0; ch < C; ++ch) {
           float v[4];
 #pragma unroll
-          for (int r = 0; r < 6; ++r) {
+          for (int r = 0; r < TAPS; ++r) {
             float q[4];
             if constexpr (kLdsRing) {
-              const int sl = head + r >= 6 ? head + r - 6 : head + r; // logical row r of the window
+              const int sl = head + r >= TAPS ? head + r - TAPS : head + r; // logical row r of the window
               const float4 f = ring_all[wave].slot[sl][ch][lane];
               q[0] = f.x; q[1] = f.y; q[2] = f.z; q[3] = f.w;
             } else {
@@ -453,7 +469,7 @@ __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int 
       }
     }
   } else {
-    // source span wider than the strip (or foreign unaligned memory): direct gather, 36 taps
+    // source span wider than the strip (or foreign unaligned memory): direct gather, TAPS^2 taps
     if (n <= 0)
       return;
 #pragma unroll 1
@@ -461,7 +477,7 @@ __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int 
       const int y = y_first + rr;
       if (y >= dh)
         break;
-      const LzTap cy = row_tap(rr);
+      const LzTap<TAPS> cy = row_tap(rr);
       float res[4][C];
 #pragma unroll
       for (int p = 0; p < 4; ++p)
@@ -469,14 +485,14 @@ __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int 
         for (int ch = 0; ch < C; ++ch) {
           float v = 0.0f;
 #pragma unroll
-          for (int r = 0; r < 6; ++r) {
-            const uint8_t* row = sp + (size_t)clampi(cy.i - 2 + r, sh - 1) * spitch;
+          for (int r = 0; r < TAPS; ++r) {
+            const uint8_t* row = sp + (size_t)clampi(cy.i - kBefore + r, sh - 1) * spitch;
             auto texel = [&](int k) {
-              return (float)gload<T>(row + (size_t)clampi(cx[p].i - 2 + k, sw - 1) * PB + ch * sizeof(T));
+              return (float)gload<T>(row + (size_t)clampi(cx[p].i - kBefore + k, sw - 1) * PB + ch * sizeof(T));
             };
             float h = cx[p].w[0] * texel(0);
 #pragma unroll
-            for (int k = 1; k < 6; ++k)
+            for (int k = 1; k < TAPS; ++k)
               h = __builtin_fmaf(cx[p].w[k], texel(k), h);
             v = r == 0 ? cy.w[0] * h : __builtin_fmaf(cy.w[r], h, v);
           }
@@ -487,22 +503,25 @@ __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int 
   }
 }
 
-template <typename T, int MAXC>
-__global__ void __launch_bounds__(kBlock) k_resize_lanczos(const ResizeArgs a) {
+template <typename T, int MAXC, int TAPS>
+__global__ void __launch_bounds__(kBlock) k_resize_taps(const ResizeArgs a) {
   ResizeJob job;
   u32 tx, ty, frame;
   if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
     return;
   __shared__ LzStage stage[kWavesPerBlock];
-  __shared__ LzRing<MAXC> ring[kWavesPerBlock];
+  __shared__ LzRing<MAXC, TAPS> ring[kWavesPerBlock];
   const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
   if (MAXC >= 3 && job.channels == 3)
-    lanczos_tile<T, 3, MAXC>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage, ring);
+    lanczos_tile<T, 3, MAXC, TAPS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage, ring);
   else if (MAXC >= 2 && job.channels == 2)
-    lanczos_tile<T, 2, MAXC>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage, ring);
+    lanczos_tile<T, 2, MAXC, TAPS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage, ring);
   else
-    lanczos_tile<T, 1, MAXC>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage, ring);
+    lanczos_tile<T, 1, MAXC, TAPS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage, ring);
 }
+
+template <typename T, int MAXC> constexpr auto k_resize_lanczos = k_resize_taps<T, MAXC, 6>;
+template <typename T, int MAXC> constexpr auto k_resize_cubic = k_resize_taps<T, MAXC, 4>;
 
 // plane jobs per pixel format: which components, their subsampling and channel count
 static int resize_jobs(int fmt, ResizeJob* j, int* elem) {
@@ -535,10 +554,10 @@ static int launch_resize(ResizeArgs& a, int fmt, int src_w, int src_h, int dst_w
     return fail(VALI_ERR_UNSUPPORTED, "resize: unsupported pixel format %d", fmt);
   u32 total = 0;
   // Integer scale factors on every plane: f = x * scale is an exact integer, every fractional
-  // weight is 0 and BOTH filters reduce to the same point sample src[k y][k x] (bit for bit:
-  // fma(0, d, t) == t and {0,0,1,0,0,0} . taps == the centre tap).  Lanczos then runs on the
-  // bilinear kernel, which does not even fetch the zero-weight rows (5.7 -> 1.3 us at the
-  // reference's own 2160p -> 720p case).
+  // weight is 0 and ALL filters reduce to the same point sample src[k y][k x] (bit for bit:
+  // fma(0, d, t) == t, {0,0,1,0,0,0} . taps and {-0,1,0,-0} . taps == the centre tap).  Lanczos
+  // and cubic then run on the bilinear kernel, which does not even fetch the zero-weight rows
+  // (5.7 -> 1.3 us at the reference's own 2160p -> 720p case).
   bool integer_scale = true;
   for (int k = 0; k < a.njobs; ++k) {
     const int dw = dst_w >> a.job[k].sub_x, dh = dst_h >> a.job[k].sub_y;
@@ -562,10 +581,15 @@ static int launch_resize(ResizeArgs& a, int fmt, int src_w, int src_h, int dst_w
     else if (maxc == 2) hipLaunchKernelGGL((KERNEL<T, 2>), grid, block, 0, stream, a);      \
     else hipLaunchKernelGGL((KERNEL<T, 3>), grid, block, 0, stream, a);                     \
   } while (0)
-  if (interp == VALI_INTERP_LANCZOS && !(integer_scale && elem != 4)) {
+  const bool filtered = interp != VALI_INTERP_LINEAR && !(integer_scale && elem != 4);
+  if (filtered && interp == VALI_INTERP_LANCZOS) {
     if (elem == 1) VALI_RS_LAUNCH(k_resize_lanczos, uint8_t);
     else if (elem == 2) VALI_RS_LAUNCH(k_resize_lanczos, uint16_t);
     else VALI_RS_LAUNCH(k_resize_lanczos, float);
+  } else if (filtered) {
+    if (elem == 1) VALI_RS_LAUNCH(k_resize_cubic, uint8_t);
+    else if (elem == 2) VALI_RS_LAUNCH(k_resize_cubic, uint16_t);
+    else VALI_RS_LAUNCH(k_resize_cubic, float);
   } else {
     if (elem == 1) VALI_RS_LAUNCH(k_resize, uint8_t);
     else if (elem == 2) VALI_RS_LAUNCH(k_resize, uint16_t);
@@ -589,7 +613,8 @@ int vali_resize(const vali_surface* src, const vali_surface* dst, int interpolat
   VALI_REQUIRE(src->width > 0 && src->height > 0 && dst->width > 0 && dst->height > 0, "empty surface");
   VALI_REQUIRE(src->plane[0] && dst->plane[0], "null plane");
   VALI_REQUIRE(planes_fit_32bit(*src) && planes_fit_32bit(*dst), "plane of 4 GiB or more");
-  if (interpolation != VALI_INTERP_LINEAR && interpolation != VALI_INTERP_LANCZOS)
+  if (interpolation != VALI_INTERP_LINEAR && interpolation != VALI_INTERP_LANCZOS &&
+      interpolation != VALI_INTERP_CUBIC)
     return fail(VALI_ERR_UNSUPPORTED, "resize: interpolation %d not implemented", interpolation);
   ResizeArgs a = {};
   a.sw = src->width; a.sh = src->height; a.dw = dst->width; a.dh = dst->height;
@@ -614,7 +639,8 @@ int vali_resize_batch(const vali_surface* d_src, const vali_surface* d_dst, int 
   VALI_REQUIRE(d_src && d_dst, "null argument");
   VALI_REQUIRE(src_width > 0 && src_height > 0 && dst_width > 0 && dst_height > 0, "empty geometry");
   VALI_REQUIRE(n >= 0 && n <= 65535, "batch size out of range (0..65535)");
-  if (interpolation != VALI_INTERP_LINEAR && interpolation != VALI_INTERP_LANCZOS)
+  if (interpolation != VALI_INTERP_LINEAR && interpolation != VALI_INTERP_LANCZOS &&
+      interpolation != VALI_INTERP_CUBIC)
     return fail(VALI_ERR_UNSUPPORTED, "resize: interpolation %d not implemented", interpolation);
   if (n == 0)
     return VALI_OK;

@@ -67,8 +67,9 @@ class ColorRange(enum.IntEnum):
 
 class Interpolation(enum.IntEnum):
     """Resize filter (new: the reference hard-codes NPP Lanczos, TaskResizeSurface.cpp:67).
-    Values = include/vali_hip.h `vali_interpolation`."""
+    Values = include/vali_hip.h `vali_interpolation` (NppiInterpolationMode numbering)."""
     LINEAR = 1
+    CUBIC = 4
     LANCZOS = 16
 
 

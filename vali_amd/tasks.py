@@ -680,7 +680,8 @@ class PySurfaceResizer(_SurfaceTask):
     five NPP launches and two temporaries in the reference).  Interpolation is bilinear by
     default (BASELINE.json config 3); `interpolation=Interpolation.LANCZOS` selects the 6x6
     Lanczos-3 restatement of the reference's hard-coded NPPI_INTER_LANCZOS (same sampling
-    grid; tap arithmetic is this build's, see oracle/vali_oracle.c).
+    grid; tap arithmetic is this build's, see oracle/vali_oracle.c), `Interpolation.CUBIC`
+    the 4x4 Catmull-Rom bicubic.
     RGB_PLANAR: the reference resizes the 3 stacked planes as ONE W x 3H image so rows
     bleed across channel seams (TaskResizeSurface.cpp:298, Surfaces.hpp:409); here each
     channel is resized on its own.
