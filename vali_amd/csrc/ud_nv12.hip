@@ -30,6 +30,7 @@
 #include "dev_util.hpp"
 
 #include <stdlib.h>
+#include <type_traits>
 
 namespace vali {
 
@@ -238,6 +239,111 @@ __host__ inline UdSpan ud_span(int tile_x, int dw, int sw, float scale_x) {
                     make_tap(c1 * 0.5f, sw / 2).i1, (int)sizeof(T));
 }
 
+// ---- output of one dst row: plain, or rotated by quarter turns (NV12 -> packed RGB only) ----
+// odd ROT: the workgroup's 256 x 32 output tile is collected in LDS, one dword per pixel
+// (r | g << 8 | b << 16), and written transposed after a barrier (ud_rot_store).  258 dwords per
+// tile row: the store phase's (8 columns) x (8 row groups) of a wave then hit 64 different banks
+// (8 g + 2 j + column).
+constexpr int kRotStride = 256 * 4 + 8;
+constexpr int kRotTileBytes = kUdTileH * kRotStride;
+
+// c0/c1/c2 as for ud_store; (wave, rr) = the row's place in the workgroup tile; dw x dh = size of
+// the (virtual) un-rotated UD output.  STRIDED: the lane's pixel p is column lane + 64 p of the
+// wave's 256 (else 4 lane + p).
+template <typename T, int OUT, int ROT, bool STRIDED>
+__device__ __forceinline__ void ud_emit(const SurfRef& d, uint8_t* rot_tile, int wave, int lane, int rr,
+                                        int x0, int y, int n, int dw, int dh, const float (&c0)[4],
+                                        const float (&c1)[4], const float (&c2)[4]) {
+  if constexpr (ROT == 0) {
+    ud_store<T, OUT>(d, x0, y, n, c0, c1, c2);
+  } else if constexpr (ROT == 2) {
+    // dst(uw-1-x, uh-1-y) = ud(x, y): the lane's 4 pixels in reverse order
+    const u32 w0 = trunc_pack4(c0[3], c1[3], c2[3], c0[2]);
+    const u32 w1 = trunc_pack4(c1[2], c2[2], c0[1], c1[1]);
+    const u32 w2 = trunc_pack4(c2[1], c0[0], c1[0], c2[0]);
+    uint8_t* row = d.p[0] + (u32)((dh - 1 - y) * d.pitch[0]);
+    uint8_t* o = row + (ptrdiff_t)(dw - 4 - x0) * 3;
+    if (n == 4 && (((uintptr_t)o) & 3u) == 0) {
+      typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+      const v3u32 w = {w0, w1, w2};
+      *(VALI_GLOBAL v3u32*)o = w;
+    } else {
+      const u32 ww[3] = {w0, w1, w2};
+      for (int p = 0; p < n; ++p) // pixel p sits at bytes 3 (3 - p) .. of the reversed group
+        for (int b = 0; b < 3; ++b) {
+          const int k = 3 * (3 - p) + b;
+          gstore<uint8_t>(row + (ptrdiff_t)(dw - 1 - x0 - p) * 3 + b, (uint8_t)(ww[k >> 2] >> (8 * (k & 3))));
+        }
+    }
+  } else {
+    // row (wave, rr) of the workgroup tile, one dword per pixel; written transposed after the barrier
+    u32* t = reinterpret_cast<u32*>(rot_tile + (wave * kUdRowsPerWave + rr) * kRotStride);
+    u32 px[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      px[p] = pack_u8<0>(__builtin_truncf(c0[p]), 0u);
+      px[p] = pack_u8<1>(__builtin_truncf(c1[p]), px[p]);
+      px[p] = pack_u8<2>(__builtin_truncf(c2[p]), px[p]);
+    }
+    if constexpr (STRIDED) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        t[lane + kWave * p] = px[p];
+    } else {
+      *reinterpret_cast<uint4*>(t + 4 * lane) = make_uint4(px[0], px[1], px[2], px[3]); // rows are 8-byte aligned
+    }
+  }
+}
+
+// Transposed store of the 256 (x) x 32 (y) tile: destination row <-> tile column.  8 lanes x 4
+// pixels (12 bytes each, one global_store_dwordx3) cover the 32 pixels of a destination row
+// segment, 32 destination rows per pass.   ROT 1: dst(y, uw-1-x) = ud(x, y), pixels in rising y;
+// ROT 3: dst(uh-1-y, x) = ud(x, y), pixels in falling y.  Call after __syncthreads().
+template <int ROT>
+__device__ __forceinline__ void ud_rot_store(const SurfRef& d, const uint8_t* rot_tile, u32 tile_x,
+                                             u32 tile_y, int dw, int dh) {
+  const int t = threadIdx.x, g = t & 7;
+  const int yb = tile_y * kUdTileH;            // first UD row of the tile
+  const int rows = min(kUdTileH, dh - yb);     // valid UD rows in the tile
+#pragma unroll 1
+  for (int pass = 0; pass < 256 / 32; ++pass) {
+    const int cx = pass * 32 + (t >> 3);       // tile column
+    const int x = tile_x * 256 + cx;           // UD column
+    if (x >= dw)
+      continue;
+    // tile rows of this lane's 4 pixels, in destination order
+    int tr[4];
+    bool ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      tr[j] = ROT == 1 ? 4 * g + j : kUdTileH - 1 - (4 * g + j);
+      ok[j] = tr[j] < rows;
+    }
+    u32 px[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      px[j] = ok[j] ? *reinterpret_cast<const u32*>(rot_tile + tr[j] * kRotStride + cx * 4) : 0u;
+    }
+    // destination: row, and the x' of pixel j = 0
+    const int drow = ROT == 1 ? dw - 1 - x : x;
+    const int dx0 = ROT == 1 ? yb + 4 * g : dh - 1 - yb - (kUdTileH - 1 - 4 * g);
+    uint8_t* o = d.p[0] + (u32)(drow * d.pitch[0]) + (ptrdiff_t)dx0 * 3;
+    if (ok[0] && ok[1] && ok[2] && ok[3] && (((uintptr_t)o) & 3u) == 0) {
+      typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+      const v3u32 w = {px[0] | (px[1] << 24), (px[1] >> 8) | (px[2] << 16), (px[2] >> 16) | (px[3] << 8)};
+      *(VALI_GLOBAL v3u32*)o = w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (ok[j]) {
+          gstore<uint8_t>(o + 3 * j, (uint8_t)px[j]);
+          gstore<uint8_t>(o + 3 * j + 1, (uint8_t)(px[j] >> 8));
+          gstore<uint8_t>(o + 3 * j + 2, (uint8_t)(px[j] >> 16));
+        }
+    }
+  }
+}
+
 // One workgroup = 256 x 32 dst pixels: wave w walks dst rows 8w..8w+7 of the tile with the
 // SAME four column taps per lane, so the float divisions of the coordinates (IEEE, ~12
 // instructions each) are paid once per 8 rows.  Instruction count is what bounds this kernel
@@ -289,11 +395,8 @@ __global__ void __launch_bounds__(kBlock, MINW) k_ud_nv12(const UdArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int x0 = (tile_x * 64 + lane) * 4;
   const int y_first = tile_y * kUdTileH + wave * kUdRowsPerWave; // wave-uniform
-  // odd ROT: the workgroup's 256 x 32 output tile is collected in LDS and written transposed
-  // one dword per pixel (r | g << 8 | b << 16); 258 dwords per tile row: the store phase's
-  // (8 columns) x (8 row groups) of a wave then hit 64 different banks (8 g + 2 j + column)
-  constexpr int kRotStride = 256 * 4 + 8;
-  __shared__ __attribute__((aligned(16))) uint8_t rot_tile[(ROT & 1) ? kUdTileH * kRotStride : 16];
+  // odd ROT: the workgroup's output tile is collected in LDS and written transposed (ud_emit)
+  __shared__ __attribute__((aligned(16))) uint8_t rot_tile[(ROT & 1) ? kRotTileBytes : 16];
   auto body = [&]() { // (a lambda so that its early exits still reach the transposed store below)
   if (y_first >= dh)
     return;
@@ -440,38 +543,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_ud_nv12(const UdArgs a) {
 
   // ---- output: plain, or rotated by quarter turns ----
   auto emit = [&](int rr, int y, const float (&c0)[4], const float (&c1)[4], const float (&c2)[4]) {
-    if constexpr (ROT == 0) {
-      ud_store<T, OUT>(d, x0, y, n, c0, c1, c2);
-    } else if constexpr (ROT == 2) {
-      // dst(uw-1-x, uh-1-y) = ud(x, y): the lane's 4 pixels in reverse order
-      const u32 w0 = trunc_pack4(c0[3], c1[3], c2[3], c0[2]);
-      const u32 w1 = trunc_pack4(c1[2], c2[2], c0[1], c1[1]);
-      const u32 w2 = trunc_pack4(c2[1], c0[0], c1[0], c2[0]);
-      uint8_t* row = d.p[0] + (u32)((dh - 1 - y) * d.pitch[0]);
-      uint8_t* o = row + (ptrdiff_t)(dw - 4 - x0) * 3;
-      if (n == 4 && (((uintptr_t)o) & 3u) == 0) {
-        typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
-        const v3u32 w = {w0, w1, w2};
-        *(VALI_GLOBAL v3u32*)o = w;
-      } else {
-        const u32 ww[3] = {w0, w1, w2};
-        for (int p = 0; p < n; ++p) // pixel p sits at bytes 3 (3 - p) .. of the reversed group
-          for (int b = 0; b < 3; ++b) {
-            const int k = 3 * (3 - p) + b;
-            gstore<uint8_t>(row + (ptrdiff_t)(dw - 1 - x0 - p) * 3 + b, (uint8_t)(ww[k >> 2] >> (8 * (k & 3))));
-          }
-      }
-    } else {
-      // row (wave, rr) of the workgroup tile, one dword per pixel; written transposed after the barrier
-      u32* t = reinterpret_cast<u32*>(rot_tile + (wave * kUdRowsPerWave + rr) * kRotStride);
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        u32 px = pack_u8<0>(__builtin_truncf(c0[p]), 0u);
-        px = pack_u8<1>(__builtin_truncf(c1[p]), px);
-        px = pack_u8<2>(__builtin_truncf(c2[p]), px);
-        t[lane + kWave * p] = px;
-      }
-    }
+    ud_emit<T, OUT, ROT, kStrided>(d, rot_tile, wave, lane, rr, x0, y, n, dw, dh, c0, c1, c2);
   };
 
   // direct byte gather: source span wider than the strip, or foreign memory that is not
@@ -590,51 +662,358 @@ __global__ void __launch_bounds__(kBlock, MINW) k_ud_nv12(const UdArgs a) {
   body();
 
   if constexpr ((ROT & 1) != 0) {
-    // Transposed store of the 256 (x) x 32 (y) tile: destination row <-> tile column.  8 lanes x 4
-    // pixels (12 bytes each, one global_store_dwordx3) cover the 32 pixels of a destination row
-    // segment, 32 destination rows per pass.   ROT 1: dst(y, uw-1-x) = ud(x, y), pixels in rising y;
-    // ROT 3: dst(uh-1-y, x) = ud(x, y), pixels in falling y.
     __syncthreads();
-    const int t = threadIdx.x, g = t & 7;
-    const int yb = tile_y * kUdTileH;            // first UD row of the tile
-    const int rows = min(kUdTileH, dh - yb);     // valid UD rows in the tile
-#pragma unroll 1
-    for (int pass = 0; pass < 256 / 32; ++pass) {
-      const int cx = pass * 32 + (t >> 3);       // tile column
-      const int x = tile_x * 256 + cx;           // UD column
-      if (x >= dw)
-        continue;
-      // tile rows of this lane's 4 pixels, in destination order
-      int tr[4];
-      bool ok[4];
+    ud_rot_store<ROT>(d, rot_tile, tile_x, tile_y, dw, dh);
+  }
+}
+
+// ---- exact 2x horizontal downscale of NV12 (src width == 2 x UD width): BASELINE config 4 ----
+// scale_x = 0.5 exactly, so every column coordinate is X = 2x: xB = 2x - 0.5, i = 2x - 1,
+// frac = 0.5 -> both horizontal weights are 128/256, for luma (columns 2x-1, 2x) and for chroma
+// (coordinate x, pairs x-1, x); index -1 clamps to 0.  The filter sum of the general kernel,
+//   S = sum_r wy_r (128 T[r][c0] + 128 T[r][c1]) = 128 (wy_0 h_0 + wy_1 h_1),  h_r = T[r][c0] + T[r][c1],
+// is the same integer, and float(S) * kNorm == float(S / 128) * (128 kNorm) bit for bit, so the
+// output is identical to k_ud_nv12's (and the oracle's).  The vertical taps stay general (any
+// height).  What changes is the cost.  The general kernel is bound by the vector-memory front end
+// (profiles/r01_ud_down2.md: the texture addresser takes ~16 cycles per wave instruction whatever
+// its width, and 256 pixels cost it 4 loads + LDS traffic), so this one is built around the
+// fewest, widest memory instructions: a lane owns 8 pixels = 16 consecutive luma bytes and 8
+// chroma pairs per source row -- ONE dwordx4 per row -- the byte before them comes from the
+// neighbouring lane (DPP wave shift), and a wave's only extra load is the dword before its first
+// column (one instruction for all four rows).  No LDS, no divisions per column; the pair sums are
+// v_dot4_u32_u8 against 0/1 byte masks.  A wave = 512 x 8 output pixels.
+constexpr int kD2LanePx = 8;
+constexpr int kD2WaveW = kWave * kD2LanePx;
+
+__device__ __forceinline__ u32 wave_shr1(u32 v) { // lane l gets lane l-1's value (lane 0 keeps its own)
+  return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
+template <int OUT, int ROT>
+__global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
+  using T = uint8_t;
+  static_assert(ROT == 0 || ROT == 2, "the transposed outputs stay on k_ud_nv12");
+  static_assert(ROT == 0 || OUT == UD_RGB_U8, "rotated output: NV12 -> RGB only");
+  u32 tile_x, tile_y, frame;
+  if (!tile_of_block(a.map, tile_x, tile_y, frame))
+    return;
+  const SurfRef s = load_surface(a.d_src, a.src, frame);
+  const SurfRef d = load_surface(a.d_dst, a.dst, frame);
+  const uint8_t* py = s.p[0];
+  const uint8_t* puv = s.p[1];
+  const int sp_y = s.pitch[0], sp_uv = s.pitch[1], sw = s.width, sh = s.height;
+  const int dw = d.width, dh = d.height;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int xw = tile_x * kD2WaveW;          // first column of the wave
+  const int x0 = xw + lane * kD2LanePx;      // first column of the lane
+  const int y_first = tile_y * kUdTileH + wave * kUdRowsPerWave; // wave-uniform
+  if (y_first >= dh)
+    return;
+  const int n = min(kD2LanePx, dw - x0);
+  if (__builtin_amdgcn_readfirstlane(n) <= 0) // (n falls with the lane index)
+    return;
+  const float scale_y = 1.0f * (float)dh / (float)sh; // ResizeUtils.cu:136
+  // row taps, lane-parallel, read back as scalars (as in k_ud_nv12)
+  const float cyl = (float)(y_first + (lane & (kUdRowsPerWave - 1))) / scale_y;
+  const Tap vty = make_tap(cyl, sh), vtcy = make_tap(cyl * 0.5f, sh / 2);
+  struct RowTaps {
+    Tap ty, tcy;
+  };
+  auto row_taps = [&](int rr) {
+    RowTaps r;
+    r.ty.i0 = __builtin_amdgcn_readlane(vty.i0, rr);
+    r.ty.i1 = __builtin_amdgcn_readlane(vty.i1, rr);
+    r.ty.w0 = (u32)__builtin_amdgcn_readlane((int)vty.w0, rr);
+    r.ty.w1 = (u32)__builtin_amdgcn_readlane((int)vty.w1, rr);
+    r.tcy.i0 = __builtin_amdgcn_readlane(vtcy.i0, rr);
+    r.tcy.i1 = __builtin_amdgcn_readlane(vtcy.i1, rr);
+    r.tcy.w0 = (u32)__builtin_amdgcn_readlane((int)vtcy.w0, rr);
+    r.tcy.w1 = (u32)__builtin_amdgcn_readlane((int)vtcy.w1, rr);
+    return r;
+  };
+  // Four pixels from three dwords per source row: P = the 4 bytes before A, then A, B
+  // (rows 0,1 = luma i0,i1 ; rows 2,3 = chroma i0,i1).  xh = first of the 4 columns.
+  struct Quad {
+    u32 p[4], a[4], b[4];
+  };
+  // byte gather with the texture clamp: tail lanes (their dwordx4 could pass the end of the
+  // row) and foreign memory that is not 16-byte aligned
+  auto gather = [&](const RowTaps& rt, int xh) {
+    Quad r;
+    const int boff = 2 * xh;
+    const uint8_t* yr[2] = {py + (u32)(rt.ty.i0 * sp_y), py + (u32)(rt.ty.i1 * sp_y)};
+    const uint8_t* cr[2] = {puv + (u32)(rt.tcy.i0 * sp_uv), puv + (u32)(rt.tcy.i1 * sp_uv)};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        tr[j] = ROT == 1 ? 4 * g + j : kUdTileH - 1 - (4 * g + j);
-        ok[j] = tr[j] < rows;
+    for (int k = 0; k < 2; ++k) {
+      auto lb = [&](int c) { return (u32)gload<uint8_t>(yr[k] + min(max(c, 0), sw - 1)); };
+      auto cb = [&](int q, int e) { return (u32)gload<uint8_t>(cr[k] + 2 * min(max(q, 0), sw / 2 - 1) + e); };
+      r.p[k] = lb(boff - 1) << 24;
+      r.a[k] = lb(boff) | (lb(boff + 1) << 8) | (lb(boff + 2) << 16) | (lb(boff + 3) << 24);
+      r.b[k] = lb(boff + 4) | (lb(boff + 5) << 8) | (lb(boff + 6) << 16) | (lb(boff + 7) << 24);
+      r.p[2 + k] = (cb(xh - 1, 0) << 16) | (cb(xh - 1, 1) << 24);
+      r.a[2 + k] = cb(xh, 0) | (cb(xh, 1) << 8) | (cb(xh + 1, 0) << 16) | (cb(xh + 1, 1) << 24);
+      r.b[2 + k] = cb(xh + 2, 0) | (cb(xh + 2, 1) << 8) | (cb(xh + 3, 0) << 16) | (cb(xh + 3, 1) << 24);
+    }
+    return r;
+  };
+  // P A B of four rows -> 4 pixels at columns xh .. xh + 3 of row y (nh of them valid)
+  constexpr float kScale = UdScale<T, OUT>::value;
+  constexpr float kNorm = TexelTraits<T>::kInvDen * kScale * 128.0f;
+  // kEven: both vertical weights are 128 (luma and chroma; every row of an exact 2x vertical
+  // downscale): wy_0 h_0 + wy_1 h_1 = 128 (h_0 + h_1), the second row's dot product accumulates onto
+  // the first and the 128 moves into the normalisation constant (a power of two: same bits)
+  auto compute = [&](auto even, const RowTaps& rt, const Quad& r, float* c0, float* c1, float* c2) {
+    constexpr bool kEven = decltype(even)::value;
+    u32 sy[4], su[4], sv[4];
+    if constexpr (kEven) {
+      u32 q[4], w[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        q[k] = __builtin_amdgcn_alignbyte(r.a[k], r.p[k], k < 2 ? 3 : 2);
+        w[k] = __builtin_amdgcn_alignbyte(r.b[k], r.a[k], k < 2 ? 3 : 2);
       }
-      u32 px[4];
+      auto two = [](u32 v0, u32 v1, u32 m) { return __builtin_amdgcn_udot4(v1, m, __builtin_amdgcn_udot4(v0, m, 0u, false), false); };
+      sy[0] = two(q[0], q[1], 0x00000101u); sy[1] = two(q[0], q[1], 0x01010000u);
+      sy[2] = two(w[0], w[1], 0x00000101u); sy[3] = two(w[0], w[1], 0x01010000u);
+      const u32 v0[4] = {q[2], r.a[2], w[2], r.b[2]}, v1[4] = {q[3], r.a[3], w[3], r.b[3]};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        px[j] = ok[j] ? *reinterpret_cast<const u32*>(rot_tile + tr[j] * kRotStride + cx * 4) : 0u;
+      for (int p = 0; p < 4; ++p) {
+        su[p] = two(v0[p], v1[p], 0x00010001u);
+        sv[p] = two(v0[p], v1[p], 0x01000100u);
       }
-      // destination: row, and the x' of pixel j = 0
-      const int drow = ROT == 1 ? dw - 1 - x : x;
-      const int dx0 = ROT == 1 ? yb + 4 * g : dh - 1 - yb - (kUdTileH - 1 - 4 * g);
-      uint8_t* o = d.p[0] + (u32)(drow * d.pitch[0]) + (ptrdiff_t)dx0 * 3;
-      if (ok[0] && ok[1] && ok[2] && ok[3] && (((uintptr_t)o) & 3u) == 0) {
-        typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
-        const v3u32 w = {px[0] | (px[1] << 24), (px[1] >> 8) | (px[2] << 16), (px[2] >> 16) | (px[3] << 8)};
-        *(VALI_GLOBAL v3u32*)o = w;
-      } else {
+    } else {
+    {
+      u32 h[2][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (ok[j]) {
-            gstore<uint8_t>(o + 3 * j, (uint8_t)px[j]);
-            gstore<uint8_t>(o + 3 * j + 1, (uint8_t)(px[j] >> 8));
-            gstore<uint8_t>(o + 3 * j + 2, (uint8_t)(px[j] >> 16));
-          }
+      for (int k = 0; k < 2; ++k) {
+        const u32 q = __builtin_amdgcn_alignbyte(r.a[k], r.p[k], 3); // cols 2xh-1 .. 2xh+2
+        const u32 w = __builtin_amdgcn_alignbyte(r.b[k], r.a[k], 3); // cols 2xh+3 .. 2xh+6
+        h[k][0] = __builtin_amdgcn_udot4(q, 0x00000101u, 0u, false);
+        h[k][1] = __builtin_amdgcn_udot4(q, 0x01010000u, 0u, false);
+        h[k][2] = __builtin_amdgcn_udot4(w, 0x00000101u, 0u, false);
+        h[k][3] = __builtin_amdgcn_udot4(w, 0x01010000u, 0u, false);
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        sy[p] = __umul24(rt.ty.w0, h[0][p]) + __umul24(rt.ty.w1, h[1][p]);
+    }
+    {
+      u32 hu[2][4], hv[2][4];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const u32 q = __builtin_amdgcn_alignbyte(r.a[2 + k], r.p[2 + k], 2); // pairs xh-1, xh
+        const u32 w = __builtin_amdgcn_alignbyte(r.b[2 + k], r.a[2 + k], 2); // pairs xh+1, xh+2
+        const u32 v[4] = {q, r.a[2 + k], w, r.b[2 + k]};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          hu[k][p] = __builtin_amdgcn_udot4(v[p], 0x00010001u, 0u, false);
+          hv[k][p] = __builtin_amdgcn_udot4(v[p], 0x01000100u, 0u, false);
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        su[p] = __umul24(rt.tcy.w0, hu[0][p]) + __umul24(rt.tcy.w1, hu[1][p]);
+        sv[p] = __umul24(rt.tcy.w0, hv[0][p]) + __umul24(rt.tcy.w1, hv[1][p]);
       }
     }
+    }
+    constexpr float kN = kEven ? kNorm * 128.0f : kNorm;
+    // two pixels per instruction (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: IEEE, same bits as
+    // the scalar forms of k_ud_nv12)
+    typedef float v2f __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int p = 0; p < 4; p += 2) {
+      const v2f kn = {kN, kN};
+      const v2f ny = (v2f){(float)sy[p], (float)sy[p + 1]} * kn;
+      const v2f nu = (v2f){(float)su[p], (float)su[p + 1]} * kn;
+      const v2f nv = (v2f){(float)sv[p], (float)sv[p + 1]} * kn;
+      if constexpr (OUT == UD_YUV444) {
+        c0[p] = ny.x; c0[p + 1] = ny.y; c1[p] = nu.x; c1[p + 1] = nu.y; c2[p] = nv.x; c2[p + 1] = nv.y;
+      } else {
+        const v2f half = {0.5f * kScale, 0.5f * kScale};
+        const v2f u = nu - half, v = nv - half;
+        const v2f r = __builtin_elementwise_fma((v2f){1.140f, 1.140f}, v, ny);
+        const v2f g = __builtin_elementwise_fma((v2f){-0.581f, -0.581f}, v,
+                                                __builtin_elementwise_fma((v2f){-0.394f, -0.394f}, u, ny));
+        const v2f bl = __builtin_elementwise_fma((v2f){2.032f, 2.032f}, u, ny);
+        c0[p] = r.x; c0[p + 1] = r.y; c1[p] = g.x; c1[p + 1] = g.y; c2[p] = bl.x; c2[p + 1] = bl.y;
+      }
+    }
+  };
+  // slow path: 4 pixels at a time through the general store (any n, any alignment)
+  auto finish = [&](const RowTaps& rt, const Quad& r, int xh, int nh, int y) {
+    float c0[4], c1[4], c2[4];
+    compute(std::false_type{}, rt, r, c0, c1, c2);
+    ud_emit<T, OUT, ROT, false>(d, nullptr, wave, lane, 0, xh, y, nh, dw, dh, c0, c1, c2);
+  };
+  // fast path: the lane's 8 pixels of row y.  Planar outputs: one dwordx2 per plane.  Packed RGB:
+  // the wave's 1536 bytes go through its LDS strip so that each store instruction writes 16
+  // consecutive bytes per lane (24-byte lane groups would fill half of every instruction).
+  constexpr bool kPacked = OUT == UD_RGB_U8;
+  __shared__ __attribute__((aligned(16))) uint8_t strip[kPacked ? kWavesPerBlock : 1][kPacked ? kD2WaveW * 3 : 16];
+  auto emit_planar = [&](int y, const float (&c0)[8], const float (&c1)[8], const float (&c2)[8]) {
+    const int pp[3] = {d.pitch[0], OUT == UD_YUV444 ? d.pitch[1] : d.pitch[0], OUT == UD_YUV444 ? d.pitch[2] : d.pitch[0]};
+    const float* cc[3] = {c0, c1, c2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      uint8_t* o = d.p[k] + (u32)(y * pp[k]) + x0;
+      const u32 lo = trunc_pack4(cc[k][0], cc[k][1], cc[k][2], cc[k][3]);
+      const u32 hi = trunc_pack4(cc[k][4], cc[k][5], cc[k][6], cc[k][7]);
+      if ((((uintptr_t)o) & 7u) == 0) {
+        store8(o, make_uint2(lo, hi));
+      } else if ((((uintptr_t)o) & 3u) == 0) {
+        gstore<u32>(o, lo);
+        gstore<u32>(o + 4, hi);
+      } else {
+        for (int b = 0; b < 4; ++b) {
+          gstore<uint8_t>(o + b, (uint8_t)(lo >> (8 * b)));
+          gstore<uint8_t>(o + 4 + b, (uint8_t)(hi >> (8 * b)));
+        }
+      }
+    }
+  };
+  // packed RGB, step 1 (lanes with 8 valid pixels): the lane's 24 bytes into the wave's strip, in
+  // memory order: pixels 0..7 (ROT 0) or 7..0 from the far end (ROT 2: the row reversed)
+  auto strip_put = [&](const float (&c0)[8], const float (&c1)[8], const float (&c2)[8]) {
+    auto px = [&](int j) { return ROT == 2 ? 7 - j : j; };
+    u32 w[6];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int a0 = px(4 * g), a1 = px(4 * g + 1), a2 = px(4 * g + 2), a3 = px(4 * g + 3);
+      w[3 * g + 0] = trunc_pack4(c0[a0], c1[a0], c2[a0], c0[a1]);
+      w[3 * g + 1] = trunc_pack4(c1[a1], c2[a1], c0[a2], c1[a2]);
+      w[3 * g + 2] = trunc_pack4(c2[a2], c0[a3], c1[a3], c2[a3]);
+    }
+    uint8_t* st = strip[kPacked ? wave : 0];
+    const int so = ROT == 2 ? (kD2WaveW - kD2LanePx) * 3 - 24 * lane : 24 * lane;
+    *reinterpret_cast<uint2*>(st + so) = make_uint2(w[0], w[1]);
+    *reinterpret_cast<uint2*>(st + so + 8) = make_uint2(w[2], w[3]);
+    *reinterpret_cast<uint2*>(st + so + 16) = make_uint2(w[4], w[5]);
+  };
+  // step 2 (every lane): strip byte b -> destination byte orow + b, 16 bytes per lane; the strip
+  // holds the pixels of the wave's full lanes only: the first 3 nwf bytes (ROT 0) or the last (ROT 2)
+  const int nwf = (min(kD2WaveW, dw - xw) / kD2LanePx) * kD2LanePx;
+  auto strip_flush = [&](uint8_t* orow) {
+    const uint8_t* st = strip[kPacked ? wave : 0];
+    const int vb0 = ROT == 2 ? (kD2WaveW - nwf) * 3 : 0, vb1 = ROT == 2 ? kD2WaveW * 3 : nwf * 3;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int b = (lane + kWave * h) * 16;
+      if (b < kD2WaveW * 3 && b + 16 > vb0 && b < vb1) {
+        const uint4 v = *reinterpret_cast<const uint4*>(st + b);
+        if (b >= vb0 && b + 16 <= vb1) {
+          store16(orow + b, v);
+        } else {
+          const u32 vv[4] = {v.x, v.y, v.z, v.w};
+          for (int k = 0; k < 16; ++k)
+            if (b + k >= vb0 && b + k < vb1)
+              gstore<uint8_t>(orow + b + k, (uint8_t)(vv[k >> 2] >> (8 * (k & 3))));
+        }
+      }
+    }
+  };
+
+  const bool aligned = ((((uintptr_t)py) | ((uintptr_t)puv) | (uintptr_t)sp_y | (uintptr_t)sp_uv) & 15u) == 0 && sw >= 16;
+  if (!aligned) {
+#pragma unroll 1
+    for (int rr = 0; rr < kUdRowsPerWave; ++rr) {
+      const int y = y_first + rr;
+      if (y >= dh)
+        break;
+      const RowTaps rt = row_taps(rr);
+#pragma unroll 1
+      for (int h = 0; h < 2; ++h)
+        if (n > 4 * h)
+          finish(rt, gather(rt, x0 + 4 * h), x0 + 4 * h, min(4, n - 4 * h), y);
+    }
+    return;
+  }
+  // vector path: unconditional, clamped loads (lanes past the row re-read its last 16 bytes), the
+  // next row's loads in flight while this row is computed
+  struct Rows {
+    uint4 v[4]; // the lane's 16 bytes of luma i0, luma i1, chroma i0, chroma i1
+    u32 before; // lane k < 4: the dword before the WAVE's first byte in row k
+  };
+  const int off16 = min(2 * x0, (sw - 16) & ~15);
+  const int offw = max(2 * xw - 4, 0);
+  auto issue = [&](const RowTaps& rt) {
+    Rows r;
+    const uint8_t* row[4] = {py + (u32)(rt.ty.i0 * sp_y), py + (u32)(rt.ty.i1 * sp_y),
+                             puv + (u32)(rt.tcy.i0 * sp_uv), puv + (u32)(rt.tcy.i1 * sp_uv)};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      r.v[k] = gload16(row[k] + (u32)off16);
+    const uint8_t* rb = lane == 0 ? row[0] : lane == 1 ? row[1] : lane == 2 ? row[2] : row[3];
+    r.before = gload<u32>(rb + (u32)offw);
+    return r;
+  };
+  const int last = min(kUdRowsPerWave - 1, dh - 1 - y_first); // last valid row of the wave
+  // one row: `rows` (loaded an iteration ago) -> pixels -> stores
+  auto step = [&](int rr, const RowTaps& cur, const Rows& rows) {
+    const int y = y_first + rr;
+    // packed RGB: where row y of the wave starts in the destination, less the strip offset
+    uint8_t* orow = nullptr;
+    bool vec = true;
+    if constexpr (kPacked) {
+      orow = ROT == 2 ? d.p[0] + (u32)((dh - 1 - y) * d.pitch[0]) + (ptrdiff_t)(dw - xw - kD2WaveW) * 3
+                      : d.p[0] + (u32)(y * d.pitch[0]) + (size_t)xw * 3;
+      vec = (((uintptr_t)orow) & 15u) == 0; // wave-uniform; else every lane takes the general store
+    }
+    if (n == kD2LanePx && vec) {
+      // the 4 bytes before the lane's 16: the previous lane's last dword; lane 0 takes the
+      // wave's extra load, or the clamp (column -1 = column 0) at the left edge of the image
+      u32 prev[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const u32 edge = k < 2 ? rows.v[k].x << 24 : rows.v[k].x << 16;
+        const u32 first = xw == 0 ? edge : (u32)__builtin_amdgcn_readlane((int)rows.before, k);
+        const u32 sh1 = wave_shr1(rows.v[k].w);
+        prev[k] = lane == 0 ? first : sh1;
+      }
+      Quad q0, q1;
+      float c0[8], c1[8], c2[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        q0.p[k] = prev[k]; q0.a[k] = rows.v[k].x; q0.b[k] = rows.v[k].y;
+        q1.p[k] = rows.v[k].y; q1.a[k] = rows.v[k].z; q1.b[k] = rows.v[k].w;
+      }
+      if (cur.ty.w0 == 128u && cur.tcy.w0 == 128u) { // (w1 = 256 - w0) wave-uniform
+        compute(std::true_type{}, cur, q0, c0, c1, c2);
+        compute(std::true_type{}, cur, q1, c0 + 4, c1 + 4, c2 + 4);
+      } else {
+        compute(std::false_type{}, cur, q0, c0, c1, c2);
+        compute(std::false_type{}, cur, q1, c0 + 4, c1 + 4, c2 + 4);
+      }
+      if constexpr (kPacked)
+        strip_put(c0, c1, c2);
+      else
+        emit_planar(y, c0, c1, c2);
+    } else if (n > 0) { // the one tail lane of a ragged row (or a destination row that is not 16-byte aligned)
+#pragma unroll 1
+      for (int h = 0; h < 2; ++h)
+        if (n > 4 * h)
+          finish(cur, gather(cur, x0 + 4 * h), x0 + 4 * h, min(4, n - 4 * h), y);
+    }
+    if constexpr (kPacked) {
+      if (vec) {
+        wave_lds_sync();
+        strip_flush(orow);
+        wave_lds_sync(); // the strip is re-used by the next row
+      }
+    }
+  };
+  // the next row's loads are in flight while a row is computed (measured: keeping two register
+  // sets alive to avoid the copies costs 27 VGPRs and gains nothing)
+  RowTaps ta = row_taps(0);
+  Rows ra = issue(ta);
+#pragma unroll 1
+  for (int rr = 0; rr <= last; ++rr) {
+    const RowTaps tb = row_taps(min(rr + 1, last));
+    const Rows rb = issue(tb);
+    step(rr, ta, ra);
+    ta = tb;
+    ra = rb;
   }
 }
 
@@ -689,6 +1068,22 @@ static int launch_ud(UdArgs& a, int src_fmt, int src_w, int dst_w, int dst_h, in
       const int cap = kUdRowBytes * (src_fmt == VALI_FMT_NV12 ? 1 : 2);
       staged = sp.yn <= cap && sp.cn <= cap;
     }
+  }
+  // exact 2x horizontal downscale of NV12: the division-free, LDS-free kernel (VALI_UD_DOWN2=0
+  // keeps the general one, for A/B measurements)
+  static const bool down2_on = [] { const char* e = getenv("VALI_UD_DOWN2"); return !(e && e[0] == '0'); }();
+  if (down2_on && src_fmt == VALI_FMT_NV12 && src_w == 2 * dst_w && !(rot & 1) && kind != UD_RGB_F32 &&
+      kind != UD_RGB_F32_PLANAR) { // (float outputs are store-bound: 4 pixels per lane fill their stores better)
+    a.map = make_tile_map((dst_w + kD2WaveW - 1) / kD2WaveW, (dst_h + kUdTileH - 1) / kUdTileH, (u32)n);
+    const dim3 g2 = tile_grid(a.map);
+#define VALI_UD_D2(K, R) hipLaunchKernelGGL((k_ud_down2<K, R>), g2, block, 0, stream, a)
+    if (rot == 2) VALI_UD_D2(UD_RGB_U8, 2);
+    else if (kind == UD_YUV444) VALI_UD_D2(UD_YUV444, 0);
+    else if (kind == UD_RGB_U8) VALI_UD_D2(UD_RGB_U8, 0);
+    else VALI_UD_D2(UD_RGB_U8_PLANAR, 0);
+#undef VALI_UD_D2
+    VALI_LAUNCH_CHECK();
+    return VALI_OK;
   }
   static const bool occ5 = [] { const char* e = getenv("VALI_UD_OCC5"); return !(e && e[0] == '0'); }();
 #define VALI_UD_CASE(T, K)                                                                  \
