@@ -249,11 +249,11 @@ constexpr int kRotTileBytes = kUdTileH * kRotStride;
 
 // c0/c1/c2 as for ud_store; (wave, rr) = the row's place in the workgroup tile; dw x dh = size of
 // the (virtual) un-rotated UD output.  STRIDED: the lane's pixel p is column lane + 64 p of the
-// wave's 256 (else 4 lane + p).
+// wave's 256 (else tile column tcol + p).
 template <typename T, int OUT, int ROT, bool STRIDED>
 __device__ __forceinline__ void ud_emit(const SurfRef& d, uint8_t* rot_tile, int wave, int lane, int rr,
                                         int x0, int y, int n, int dw, int dh, const float (&c0)[4],
-                                        const float (&c1)[4], const float (&c2)[4]) {
+                                        const float (&c1)[4], const float (&c2)[4], int tcol = 0) {
   if constexpr (ROT == 0) {
     ud_store<T, OUT>(d, x0, y, n, c0, c1, c2);
   } else if constexpr (ROT == 2) {
@@ -289,8 +289,10 @@ __device__ __forceinline__ void ud_emit(const SurfRef& d, uint8_t* rot_tile, int
 #pragma unroll
       for (int p = 0; p < 4; ++p)
         t[lane + kWave * p] = px[p];
-    } else {
-      *reinterpret_cast<uint4*>(t + 4 * lane) = make_uint4(px[0], px[1], px[2], px[3]); // rows are 8-byte aligned
+    } else { // tcol = the tile column of pixel 0
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        t[tcol + p] = px[p];
     }
   }
 }
@@ -689,6 +691,130 @@ __device__ __forceinline__ u32 wave_shr1(u32 v) { // lane l gets lane l-1's valu
   return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
 
+// Row taps of one output row (wave-uniform in k_ud_down2, per half-wave in k_ud_down2_t)
+struct D2Taps {
+  Tap ty, tcy;
+};
+// Four pixels from three dwords per source row: P = the 4 bytes before A, then A, B
+// (rows 0,1 = luma i0,i1 ; rows 2,3 = chroma i0,i1).
+struct D2Quad {
+  u32 p[4], a[4], b[4];
+};
+struct D2Src {
+  const uint8_t* py;
+  const uint8_t* puv;
+  int sp_y, sp_uv, sw;
+};
+// byte gather with the texture clamp: tail lanes (their dwordx4 could pass the end of the
+// row) and foreign memory that is not 16-byte aligned
+__device__ __forceinline__ D2Quad d2_gather(const D2Src& s, const D2Taps& rt, int xh) {
+  const uint8_t* py = s.py;
+  const uint8_t* puv = s.puv;
+  const int sp_y = s.sp_y, sp_uv = s.sp_uv, sw = s.sw;
+  D2Quad r;
+  const int boff = 2 * xh;
+  const uint8_t* yr[2] = {py + (u32)(rt.ty.i0 * sp_y), py + (u32)(rt.ty.i1 * sp_y)};
+  const uint8_t* cr[2] = {puv + (u32)(rt.tcy.i0 * sp_uv), puv + (u32)(rt.tcy.i1 * sp_uv)};
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    auto lb = [&](int c) { return (u32)gload<uint8_t>(yr[k] + min(max(c, 0), sw - 1)); };
+    auto cb = [&](int q, int e) { return (u32)gload<uint8_t>(cr[k] + 2 * min(max(q, 0), sw / 2 - 1) + e); };
+    r.p[k] = lb(boff - 1) << 24;
+    r.a[k] = lb(boff) | (lb(boff + 1) << 8) | (lb(boff + 2) << 16) | (lb(boff + 3) << 24);
+    r.b[k] = lb(boff + 4) | (lb(boff + 5) << 8) | (lb(boff + 6) << 16) | (lb(boff + 7) << 24);
+    r.p[2 + k] = (cb(xh - 1, 0) << 16) | (cb(xh - 1, 1) << 24);
+    r.a[2 + k] = cb(xh, 0) | (cb(xh, 1) << 8) | (cb(xh + 1, 0) << 16) | (cb(xh + 1, 1) << 24);
+    r.b[2 + k] = cb(xh + 2, 0) | (cb(xh + 2, 1) << 8) | (cb(xh + 3, 0) << 16) | (cb(xh + 3, 1) << 24);
+  }
+  return r;
+}
+
+// P A B of four rows -> the three components (scaled by UdScale) of 4 pixels
+// kEven: both vertical weights are 128 (luma and chroma; every row of an exact 2x vertical
+// downscale): wy_0 h_0 + wy_1 h_1 = 128 (h_0 + h_1), the second row's dot product accumulates onto
+// the first and the 128 moves into the normalisation constant (a power of two: same bits)
+template <int OUT, bool kEven>
+__device__ __forceinline__ void d2_compute(const D2Taps& rt, const D2Quad& r, float* c0, float* c1, float* c2) {
+  using T = uint8_t;
+  constexpr float kScale = UdScale<T, OUT>::value;
+  constexpr float kNorm = TexelTraits<T>::kInvDen * kScale * 128.0f;
+  u32 sy[4], su[4], sv[4];
+  if constexpr (kEven) {
+    u32 q[4], w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      q[k] = __builtin_amdgcn_alignbyte(r.a[k], r.p[k], k < 2 ? 3 : 2);
+      w[k] = __builtin_amdgcn_alignbyte(r.b[k], r.a[k], k < 2 ? 3 : 2);
+    }
+    auto two = [](u32 v0, u32 v1, u32 m) { return __builtin_amdgcn_udot4(v1, m, __builtin_amdgcn_udot4(v0, m, 0u, false), false); };
+    sy[0] = two(q[0], q[1], 0x00000101u); sy[1] = two(q[0], q[1], 0x01010000u);
+    sy[2] = two(w[0], w[1], 0x00000101u); sy[3] = two(w[0], w[1], 0x01010000u);
+    const u32 v0[4] = {q[2], r.a[2], w[2], r.b[2]}, v1[4] = {q[3], r.a[3], w[3], r.b[3]};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      su[p] = two(v0[p], v1[p], 0x00010001u);
+      sv[p] = two(v0[p], v1[p], 0x01000100u);
+    }
+  } else {
+  {
+    u32 h[2][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const u32 q = __builtin_amdgcn_alignbyte(r.a[k], r.p[k], 3); // cols 2xh-1 .. 2xh+2
+      const u32 w = __builtin_amdgcn_alignbyte(r.b[k], r.a[k], 3); // cols 2xh+3 .. 2xh+6
+      h[k][0] = __builtin_amdgcn_udot4(q, 0x00000101u, 0u, false);
+      h[k][1] = __builtin_amdgcn_udot4(q, 0x01010000u, 0u, false);
+      h[k][2] = __builtin_amdgcn_udot4(w, 0x00000101u, 0u, false);
+      h[k][3] = __builtin_amdgcn_udot4(w, 0x01010000u, 0u, false);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      sy[p] = __umul24(rt.ty.w0, h[0][p]) + __umul24(rt.ty.w1, h[1][p]);
+  }
+  {
+    u32 hu[2][4], hv[2][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const u32 q = __builtin_amdgcn_alignbyte(r.a[2 + k], r.p[2 + k], 2); // pairs xh-1, xh
+      const u32 w = __builtin_amdgcn_alignbyte(r.b[2 + k], r.a[2 + k], 2); // pairs xh+1, xh+2
+      const u32 v[4] = {q, r.a[2 + k], w, r.b[2 + k]};
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        hu[k][p] = __builtin_amdgcn_udot4(v[p], 0x00010001u, 0u, false);
+        hv[k][p] = __builtin_amdgcn_udot4(v[p], 0x01000100u, 0u, false);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      su[p] = __umul24(rt.tcy.w0, hu[0][p]) + __umul24(rt.tcy.w1, hu[1][p]);
+      sv[p] = __umul24(rt.tcy.w0, hv[0][p]) + __umul24(rt.tcy.w1, hv[1][p]);
+    }
+  }
+  }
+  constexpr float kN = kEven ? kNorm * 128.0f : kNorm;
+  // two pixels per instruction (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: IEEE, same bits as
+  // the scalar forms of k_ud_nv12)
+  typedef float v2f __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int p = 0; p < 4; p += 2) {
+    const v2f kn = {kN, kN};
+    const v2f ny = (v2f){(float)sy[p], (float)sy[p + 1]} * kn;
+    const v2f nu = (v2f){(float)su[p], (float)su[p + 1]} * kn;
+    const v2f nv = (v2f){(float)sv[p], (float)sv[p + 1]} * kn;
+    if constexpr (OUT == UD_YUV444) {
+      c0[p] = ny.x; c0[p + 1] = ny.y; c1[p] = nu.x; c1[p + 1] = nu.y; c2[p] = nv.x; c2[p + 1] = nv.y;
+    } else {
+      const v2f half = {0.5f * kScale, 0.5f * kScale};
+      const v2f u = nu - half, v = nv - half;
+      const v2f r = __builtin_elementwise_fma((v2f){1.140f, 1.140f}, v, ny);
+      const v2f g = __builtin_elementwise_fma((v2f){-0.581f, -0.581f}, v,
+                                              __builtin_elementwise_fma((v2f){-0.394f, -0.394f}, u, ny));
+      const v2f bl = __builtin_elementwise_fma((v2f){2.032f, 2.032f}, u, ny);
+      c0[p] = r.x; c0[p + 1] = r.y; c1[p] = g.x; c1[p + 1] = g.y; c2[p] = bl.x; c2[p + 1] = bl.y;
+    }
+  }
+}
+
 template <int OUT, int ROT>
 __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
   using T = uint8_t;
@@ -717,9 +843,7 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
   // row taps, lane-parallel, read back as scalars (as in k_ud_nv12)
   const float cyl = (float)(y_first + (lane & (kUdRowsPerWave - 1))) / scale_y;
   const Tap vty = make_tap(cyl, sh), vtcy = make_tap(cyl * 0.5f, sh / 2);
-  struct RowTaps {
-    Tap ty, tcy;
-  };
+  using RowTaps = D2Taps;
   auto row_taps = [&](int rr) {
     RowTaps r;
     r.ty.i0 = __builtin_amdgcn_readlane(vty.i0, rr);
@@ -732,114 +856,11 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
     r.tcy.w1 = (u32)__builtin_amdgcn_readlane((int)vtcy.w1, rr);
     return r;
   };
-  // Four pixels from three dwords per source row: P = the 4 bytes before A, then A, B
-  // (rows 0,1 = luma i0,i1 ; rows 2,3 = chroma i0,i1).  xh = first of the 4 columns.
-  struct Quad {
-    u32 p[4], a[4], b[4];
-  };
-  // byte gather with the texture clamp: tail lanes (their dwordx4 could pass the end of the
-  // row) and foreign memory that is not 16-byte aligned
-  auto gather = [&](const RowTaps& rt, int xh) {
-    Quad r;
-    const int boff = 2 * xh;
-    const uint8_t* yr[2] = {py + (u32)(rt.ty.i0 * sp_y), py + (u32)(rt.ty.i1 * sp_y)};
-    const uint8_t* cr[2] = {puv + (u32)(rt.tcy.i0 * sp_uv), puv + (u32)(rt.tcy.i1 * sp_uv)};
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      auto lb = [&](int c) { return (u32)gload<uint8_t>(yr[k] + min(max(c, 0), sw - 1)); };
-      auto cb = [&](int q, int e) { return (u32)gload<uint8_t>(cr[k] + 2 * min(max(q, 0), sw / 2 - 1) + e); };
-      r.p[k] = lb(boff - 1) << 24;
-      r.a[k] = lb(boff) | (lb(boff + 1) << 8) | (lb(boff + 2) << 16) | (lb(boff + 3) << 24);
-      r.b[k] = lb(boff + 4) | (lb(boff + 5) << 8) | (lb(boff + 6) << 16) | (lb(boff + 7) << 24);
-      r.p[2 + k] = (cb(xh - 1, 0) << 16) | (cb(xh - 1, 1) << 24);
-      r.a[2 + k] = cb(xh, 0) | (cb(xh, 1) << 8) | (cb(xh + 1, 0) << 16) | (cb(xh + 1, 1) << 24);
-      r.b[2 + k] = cb(xh + 2, 0) | (cb(xh + 2, 1) << 8) | (cb(xh + 3, 0) << 16) | (cb(xh + 3, 1) << 24);
-    }
-    return r;
-  };
-  // P A B of four rows -> 4 pixels at columns xh .. xh + 3 of row y (nh of them valid)
-  constexpr float kScale = UdScale<T, OUT>::value;
-  constexpr float kNorm = TexelTraits<T>::kInvDen * kScale * 128.0f;
-  // kEven: both vertical weights are 128 (luma and chroma; every row of an exact 2x vertical
-  // downscale): wy_0 h_0 + wy_1 h_1 = 128 (h_0 + h_1), the second row's dot product accumulates onto
-  // the first and the 128 moves into the normalisation constant (a power of two: same bits)
+  using Quad = D2Quad;
+  const D2Src srcv = {py, puv, sp_y, sp_uv, sw};
+  auto gather = [&](const RowTaps& rt, int xh) { return d2_gather(srcv, rt, xh); };
   auto compute = [&](auto even, const RowTaps& rt, const Quad& r, float* c0, float* c1, float* c2) {
-    constexpr bool kEven = decltype(even)::value;
-    u32 sy[4], su[4], sv[4];
-    if constexpr (kEven) {
-      u32 q[4], w[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        q[k] = __builtin_amdgcn_alignbyte(r.a[k], r.p[k], k < 2 ? 3 : 2);
-        w[k] = __builtin_amdgcn_alignbyte(r.b[k], r.a[k], k < 2 ? 3 : 2);
-      }
-      auto two = [](u32 v0, u32 v1, u32 m) { return __builtin_amdgcn_udot4(v1, m, __builtin_amdgcn_udot4(v0, m, 0u, false), false); };
-      sy[0] = two(q[0], q[1], 0x00000101u); sy[1] = two(q[0], q[1], 0x01010000u);
-      sy[2] = two(w[0], w[1], 0x00000101u); sy[3] = two(w[0], w[1], 0x01010000u);
-      const u32 v0[4] = {q[2], r.a[2], w[2], r.b[2]}, v1[4] = {q[3], r.a[3], w[3], r.b[3]};
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        su[p] = two(v0[p], v1[p], 0x00010001u);
-        sv[p] = two(v0[p], v1[p], 0x01000100u);
-      }
-    } else {
-    {
-      u32 h[2][4];
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const u32 q = __builtin_amdgcn_alignbyte(r.a[k], r.p[k], 3); // cols 2xh-1 .. 2xh+2
-        const u32 w = __builtin_amdgcn_alignbyte(r.b[k], r.a[k], 3); // cols 2xh+3 .. 2xh+6
-        h[k][0] = __builtin_amdgcn_udot4(q, 0x00000101u, 0u, false);
-        h[k][1] = __builtin_amdgcn_udot4(q, 0x01010000u, 0u, false);
-        h[k][2] = __builtin_amdgcn_udot4(w, 0x00000101u, 0u, false);
-        h[k][3] = __builtin_amdgcn_udot4(w, 0x01010000u, 0u, false);
-      }
-#pragma unroll
-      for (int p = 0; p < 4; ++p)
-        sy[p] = __umul24(rt.ty.w0, h[0][p]) + __umul24(rt.ty.w1, h[1][p]);
-    }
-    {
-      u32 hu[2][4], hv[2][4];
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const u32 q = __builtin_amdgcn_alignbyte(r.a[2 + k], r.p[2 + k], 2); // pairs xh-1, xh
-        const u32 w = __builtin_amdgcn_alignbyte(r.b[2 + k], r.a[2 + k], 2); // pairs xh+1, xh+2
-        const u32 v[4] = {q, r.a[2 + k], w, r.b[2 + k]};
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          hu[k][p] = __builtin_amdgcn_udot4(v[p], 0x00010001u, 0u, false);
-          hv[k][p] = __builtin_amdgcn_udot4(v[p], 0x01000100u, 0u, false);
-        }
-      }
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        su[p] = __umul24(rt.tcy.w0, hu[0][p]) + __umul24(rt.tcy.w1, hu[1][p]);
-        sv[p] = __umul24(rt.tcy.w0, hv[0][p]) + __umul24(rt.tcy.w1, hv[1][p]);
-      }
-    }
-    }
-    constexpr float kN = kEven ? kNorm * 128.0f : kNorm;
-    // two pixels per instruction (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: IEEE, same bits as
-    // the scalar forms of k_ud_nv12)
-    typedef float v2f __attribute__((ext_vector_type(2)));
-#pragma unroll
-    for (int p = 0; p < 4; p += 2) {
-      const v2f kn = {kN, kN};
-      const v2f ny = (v2f){(float)sy[p], (float)sy[p + 1]} * kn;
-      const v2f nu = (v2f){(float)su[p], (float)su[p + 1]} * kn;
-      const v2f nv = (v2f){(float)sv[p], (float)sv[p + 1]} * kn;
-      if constexpr (OUT == UD_YUV444) {
-        c0[p] = ny.x; c0[p + 1] = ny.y; c1[p] = nu.x; c1[p + 1] = nu.y; c2[p] = nv.x; c2[p + 1] = nv.y;
-      } else {
-        const v2f half = {0.5f * kScale, 0.5f * kScale};
-        const v2f u = nu - half, v = nv - half;
-        const v2f r = __builtin_elementwise_fma((v2f){1.140f, 1.140f}, v, ny);
-        const v2f g = __builtin_elementwise_fma((v2f){-0.581f, -0.581f}, v,
-                                                __builtin_elementwise_fma((v2f){-0.394f, -0.394f}, u, ny));
-        const v2f bl = __builtin_elementwise_fma((v2f){2.032f, 2.032f}, u, ny);
-        c0[p] = r.x; c0[p + 1] = r.y; c1[p] = g.x; c1[p + 1] = g.y; c2[p] = bl.x; c2[p + 1] = bl.y;
-      }
-    }
+    d2_compute<OUT, decltype(even)::value>(rt, r, c0, c1, c2);
   };
   // slow path: 4 pixels at a time through the general store (any n, any alignment)
   auto finish = [&](const RowTaps& rt, const Quad& r, int xh, int nh, int y) {
@@ -1017,6 +1038,170 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
   }
 }
 
+// The same arithmetic with the output written turned by 90 / 270 degrees (ROT 1 / 3; NV12 -> packed
+// RGB): BASELINE config 4 as one pass.  The transposed store needs the 256 x 32 workgroup tile of
+// k_ud_nv12 (one dword per pixel in LDS, ud_rot_store), so a wave covers 256 columns and fetches TWO
+// output rows per instruction: lanes 0-31 row 2i, lanes 32-63 row 2i+1 of its 8 (8 pixels = one
+// dwordx4 per lane per source row, as above).  Row taps and row addresses are therefore per
+// half-wave (vector registers); lanes 0 and 32 take the dword before their row from the wave's
+// extra load.
+template <int ROT>
+__global__ void __launch_bounds__(kBlock) k_ud_down2_t(const UdArgs a) {
+  using T = uint8_t;
+  constexpr int OUT = UD_RGB_U8;
+  static_assert(ROT == 1 || ROT == 3, "quarter turns only");
+  u32 tile_x, tile_y, frame;
+  {
+    u32 t;
+    if (!frame_tile_of_block(a.map, frame, t))
+      return;
+    const u32 tiles_y = a.map.per_frame / a.map.tiles_x; // consecutive workgroups walk DOWN the UD image
+    tile_x = t / tiles_y;
+    tile_y = t - tile_x * tiles_y;
+  }
+  const SurfRef s = load_surface(a.d_src, a.src, frame);
+  const SurfRef d = load_surface(a.d_dst, a.dst, frame);
+  const uint8_t* py = s.p[0];
+  const uint8_t* puv = s.p[1];
+  const int sp_y = s.pitch[0], sp_uv = s.pitch[1], sw = s.width, sh = s.height;
+  const int dw = d.height, dh = d.width; // size of the (virtual) un-rotated UD output
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int half = lane >> 5, li = lane & 31;
+  const int xw = tile_x * 256;
+  const int x0 = xw + li * kD2LanePx;
+  const int y_first = tile_y * kUdTileH + wave * kUdRowsPerWave; // wave-uniform
+  __shared__ __attribute__((aligned(16))) uint8_t rot_tile[kRotTileBytes];
+  auto body = [&]() { // (a lambda so that its early exits still reach the transposed store below)
+    if (y_first >= dh)
+      return;
+    const int n = min(kD2LanePx, dw - x0);
+    const float scale_y = 1.0f * (float)dh / (float)sh;
+    const float cyl = (float)(y_first + (lane & (kUdRowsPerWave - 1))) / scale_y;
+    const Tap vty = make_tap(cyl, sh), vtcy = make_tap(cyl * 0.5f, sh / 2);
+    const int last = min(kUdRowsPerWave - 1, dh - 1 - y_first); // last valid row of the wave
+    // taps of row pair `it`: lanes 0-31 get row 2 it, lanes 32-63 row 2 it + 1 (clamped to `last`);
+    // `even` = all four vertical weights of both rows are 128 (wave-uniform)
+    auto pair_taps = [&](int it, bool& even) {
+      const int ra = min(2 * it, last), rb = min(2 * it + 1, last);
+      auto pick = [&](int v) {
+        const int sa = __builtin_amdgcn_readlane(v, ra), sb = __builtin_amdgcn_readlane(v, rb);
+        return half ? sb : sa;
+      };
+      D2Taps r;
+      r.ty.i0 = pick(vty.i0); r.ty.i1 = pick(vty.i1);
+      r.ty.w0 = (u32)pick((int)vty.w0); r.ty.w1 = (u32)pick((int)vty.w1);
+      r.tcy.i0 = pick(vtcy.i0); r.tcy.i1 = pick(vtcy.i1);
+      r.tcy.w0 = (u32)pick((int)vtcy.w0); r.tcy.w1 = (u32)pick((int)vtcy.w1);
+      even = __builtin_amdgcn_readlane((int)vty.w0, ra) == 128 && __builtin_amdgcn_readlane((int)vty.w0, rb) == 128 &&
+             __builtin_amdgcn_readlane((int)vtcy.w0, ra) == 128 && __builtin_amdgcn_readlane((int)vtcy.w0, rb) == 128;
+      return r;
+    };
+    const D2Src srcv = {py, puv, sp_y, sp_uv, sw};
+    // LDS tile row of output row rr of the wave
+    auto tile_row = [&](int rr) { return reinterpret_cast<u32*>(rot_tile + (wave * kUdRowsPerWave + rr) * kRotStride); };
+    auto slow = [&](const D2Taps& rt, int rr) { // 4 pixels at a time through the byte gather
+#pragma unroll 1
+      for (int h = 0; h < 2; ++h)
+        if (n > 4 * h) {
+          float c0[4], c1[4], c2[4];
+          d2_compute<OUT, false>(rt, d2_gather(srcv, rt, x0 + 4 * h), c0, c1, c2);
+          ud_emit<T, OUT, ROT, false>(d, rot_tile, wave, lane, rr, x0 + 4 * h, y_first + rr, min(4, n - 4 * h), dw, dh,
+                                      c0, c1, c2, li * kD2LanePx + 4 * h);
+        }
+    };
+    const bool aligned = ((((uintptr_t)py) | ((uintptr_t)puv) | (uintptr_t)sp_y | (uintptr_t)sp_uv) & 15u) == 0 && sw >= 16;
+    if (!aligned) {
+#pragma unroll 1
+      for (int it = 0; 2 * it <= last; ++it) {
+        bool even;
+        const D2Taps rt = pair_taps(it, even);
+        const int rr = 2 * it + half;
+        if (rr <= last && n > 0)
+          slow(rt, rr);
+      }
+      return;
+    }
+    struct Rows {
+      uint4 v[4]; // the lane's 16 bytes of luma i0, luma i1, chroma i0, chroma i1 of ITS row
+      u32 before; // lanes 0-3 / 32-35: the dword before the wave's first byte in row k of their half
+    };
+    const int off16 = min(2 * x0, (sw - 16) & ~15);
+    const int offw = max(2 * xw - 4, 0);
+    auto issue = [&](const D2Taps& rt) {
+      Rows r;
+      const uint8_t* row[4] = {py + (u32)(rt.ty.i0 * sp_y), py + (u32)(rt.ty.i1 * sp_y),
+                               puv + (u32)(rt.tcy.i0 * sp_uv), puv + (u32)(rt.tcy.i1 * sp_uv)};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        r.v[k] = gload16(row[k] + (u32)off16);
+      const uint8_t* rb = li == 0 ? row[0] : li == 1 ? row[1] : li == 2 ? row[2] : row[3];
+      r.before = gload<u32>(rb + (u32)offw);
+      return r;
+    };
+    auto step = [&](int it, const D2Taps& cur, bool even, const Rows& rows) {
+      const int rr = 2 * it + half;
+      if (rr > last)
+        return;
+      if (n == kD2LanePx) {
+        u32 prev[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const u32 edge = k < 2 ? rows.v[k].x << 24 : rows.v[k].x << 16;
+          const u32 f0 = (u32)__builtin_amdgcn_readlane((int)rows.before, k);
+          const u32 f1 = (u32)__builtin_amdgcn_readlane((int)rows.before, 32 + k);
+          const u32 first = xw == 0 ? edge : (half ? f1 : f0);
+          const u32 sh1 = wave_shr1(rows.v[k].w);
+          prev[k] = li == 0 ? first : sh1;
+        }
+        D2Quad q0, q1;
+        float c0[8], c1[8], c2[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          q0.p[k] = prev[k]; q0.a[k] = rows.v[k].x; q0.b[k] = rows.v[k].y;
+          q1.p[k] = rows.v[k].y; q1.a[k] = rows.v[k].z; q1.b[k] = rows.v[k].w;
+        }
+        if (even) {
+          d2_compute<OUT, true>(cur, q0, c0, c1, c2);
+          d2_compute<OUT, true>(cur, q1, c0 + 4, c1 + 4, c2 + 4);
+        } else {
+          d2_compute<OUT, false>(cur, q0, c0, c1, c2);
+          d2_compute<OUT, false>(cur, q1, c0 + 4, c1 + 4, c2 + 4);
+        }
+        u32 px[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          px[p] = pack_u8<0>(__builtin_truncf(c0[p]), 0u);
+          px[p] = pack_u8<1>(__builtin_truncf(c1[p]), px[p]);
+          px[p] = pack_u8<2>(__builtin_truncf(c2[p]), px[p]);
+        }
+        u32* t = tile_row(rr) + li * kD2LanePx; // 8-byte aligned (tile rows are 1032 bytes apart)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<uint2*>(t + 2 * g) = make_uint2(px[2 * g], px[2 * g + 1]);
+      } else if (n > 0) {
+        slow(cur, rr);
+      }
+    };
+    bool ea;
+    D2Taps ta = pair_taps(0, ea);
+    Rows ra = issue(ta);
+#pragma unroll 1
+    for (int it = 0; 2 * it <= last; ++it) {
+      bool eb;
+      const D2Taps tb = pair_taps(it + 1, eb); // (clamped to the last row: a harmless re-read at the end)
+      const Rows rb = issue(tb);
+      step(it, ta, ea, ra);
+      ta = tb;
+      ea = eb;
+      ra = rb;
+    }
+  };
+  body();
+  __syncthreads();
+  ud_rot_store<ROT>(d, rot_tile, tile_x, tile_y, dw, dh);
+}
+
 static int ud_out_kind(int src_fmt, int dst_fmt) {
   // SupportedConversions(), src/TC/src/UDSurface.cpp:117-133 (semi-planar sources)
   if (src_fmt == VALI_FMT_NV12) {
@@ -1082,6 +1267,12 @@ static int launch_ud(UdArgs& a, int src_fmt, int src_w, int dst_w, int dst_h, in
     else if (kind == UD_RGB_U8) VALI_UD_D2(UD_RGB_U8, 0);
     else VALI_UD_D2(UD_RGB_U8_PLANAR, 0);
 #undef VALI_UD_D2
+    VALI_LAUNCH_CHECK();
+    return VALI_OK;
+  }
+  if (down2_on && src_fmt == VALI_FMT_NV12 && src_w == 2 * dst_w && (rot & 1)) {
+    if (rot == 1) hipLaunchKernelGGL((k_ud_down2_t<1>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_ud_down2_t<3>), grid, block, 0, stream, a);
     VALI_LAUNCH_CHECK();
     return VALI_OK;
   }
