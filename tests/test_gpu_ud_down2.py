@@ -1,6 +1,6 @@
 """UD with an exact 2x horizontal downscale (source width == 2 x output width) and an 8-bit output
-runs on its own kernel (k_ud_down2: 16-byte loads, no coordinate divisions; BASELINE config 4's
-"2x downsample"; float outputs and the transposed 90/270 degree outputs stay on the general
+runs on its own kernels (k_ud_down2, and k_ud_down2_t for the 90/270 degree outputs: 16-byte loads,
+no coordinate divisions; BASELINE config 4's "2x downsample"; float outputs stay on the general
 kernel).  It must be bit-identical to the oracle -- which restates the general texture-filter
 arithmetic -- and to the general kernel, for every output format, any height, ragged widths, the
 clamped first column, foreign unaligned memory, batches and the rotated outputs."""

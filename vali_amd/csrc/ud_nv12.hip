@@ -818,7 +818,7 @@ __device__ __forceinline__ void d2_compute(const D2Taps& rt, const D2Quad& r, fl
 template <int OUT, int ROT>
 __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
   using T = uint8_t;
-  static_assert(ROT == 0 || ROT == 2, "the transposed outputs stay on k_ud_nv12");
+  static_assert(ROT == 0 || ROT == 2, "the transposed outputs: k_ud_down2_t");
   static_assert(ROT == 0 || OUT == UD_RGB_U8, "rotated output: NV12 -> RGB only");
   u32 tile_x, tile_y, frame;
   if (!tile_of_block(a.map, tile_x, tile_y, frame))
