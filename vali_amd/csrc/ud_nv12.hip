@@ -26,6 +26,15 @@
 // staged per wave in LDS with 16-byte coalesced loads (every 128-byte line fetched once);
 // tiles walk the frame through the XCD-contiguous TileMap.  HBM traffic = touched source
 // rows + the dst surface.
+//
+// Kernels in this file:
+//   k_ud_nv12<T,OUT,STAGED,ROT>  any scale factor, NV12 / P10, every output; VALU-bound (4.8 us per
+//                                2160p -> 1080p frame)
+//   k_ud_down2<OUT,ROT>          source exactly twice as wide as the output, NV12, 8-bit outputs,
+//                                0 / 180 degree output: 16-byte loads, no LDS staging (3.8 us)
+//   k_ud_down2_t<ROT>            the same for the 90 / 270 degree outputs (4.35 us, config 4 in one pass)
+// all three produce the same bits (tests/test_gpu_ud_down2.py); profiles/r01_ud_down2.md has the
+// counters that led from the first to the other two.
 #include "common.hpp"
 #include "dev_util.hpp"
 
