@@ -174,3 +174,41 @@ def test_float_planes_keep_denormals_and_signed_zero(vali, gpu, oracle, interp):
     got = roundtrip(vali, gpu, "RGB_32F", host, sw, sh, dw, dh, interp=it)
     want = oracle.resize_surface(host, "RGB_32F", sw, sh, dw, dh, interp)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+# ---- integer scale factors: the point-sample form of the kernel (BASELINE config 3 is an exact 3x) ----
+@pytest.mark.parametrize("fmt", ["NV12", "YUV420", "YUV444", "RGB", "RGB_PLANAR", "Y", "P10", "YUV422",
+                                 "YUV444_10bit", "RGB_32F"])
+@pytest.mark.parametrize("geom", [(3840, 2160, 1280, 720), (1920, 1080, 960, 540), (1200, 64, 100, 16),   # 3x, 2x, 12x4
+                                  (640, 360, 640, 360), (1002, 36, 334, 18), (4096, 32, 256, 8),           # 1x, ragged 3x2, 16x4
+                                  (1280, 720, 1280, 360), (84, 40, 42, 40)])                               # one axis only
+def test_integer_scale_is_the_point_sample(vali, gpu, oracle, fmt, geom):
+    sw, sh, dw, dh = geom
+    dt = DT.get(fmt, np.uint8)
+    n = vali.Surface.Make(vali.PixelFormat[fmt], sw, sh, gpu).HostSize // np.dtype(dt).itemsize
+    rng = np.random.default_rng(31)
+    host = (rng.random(n) * (1023 if dt == np.uint16 else 255)).astype(dt)
+    want = oracle.resize_surface(host, fmt, sw, sh, dw, dh, "linear")
+    for interp in (vali.Interpolation.LINEAR, vali.Interpolation.CUBIC, vali.Interpolation.LANCZOS):
+        if dt == np.float32 and interp != vali.Interpolation.LINEAR:
+            continue  # float planes keep each filter's own arithmetic
+        got = roundtrip(vali, gpu, fmt, host, sw, sh, dw, dh, interp=interp)
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), interp
+    # and it IS the decimated source, plane by plane
+    if fmt == "Y":
+        src = host.reshape(sh, sw)
+        assert np.array_equal(want.reshape(dh, dw), src[:: sh // dh, :: sw // dw])
+
+
+def test_integer_scale_foreign_unaligned_source(vali, gpu, oracle):
+    """unaligned rows leave the LDS-staged path: the point-sample kernel falls back to its gather"""
+    from test_gpu_edge_geometry import download, foreign_nv12
+    from conftest import make_nv12
+    sw, sh, dw, dh = 636, 180, 212, 60
+    nv = make_nv12(sw, sh, 11)
+    for pad, skew in ((3, 0), (16, 5)):
+        src, keep = foreign_nv12(vali, sw, sh, nv, pad, skew)
+        small = vali.Surface.Make(vali.NV12, dw, dh, gpu)
+        assert vali.PySurfaceResizer(vali.NV12, gpu).Run(src, small)[0]
+        assert np.array_equal(download(vali, gpu, small), oracle.resize_surface(nv.reshape(-1), "NV12", sw, sh, dw, dh, "linear"))
+        del keep

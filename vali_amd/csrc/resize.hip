@@ -25,6 +25,7 @@
 // source rows + dst.
 #include "common.hpp"
 #include "dev_util.hpp"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace vali {
@@ -68,10 +69,57 @@ struct alignas(16) StageRows {
   uint8_t row[2][kStageRowBytes];
 };
 
+// 4 pixels of raw elements (no arithmetic: the point-sample path) -> memory, like store_px4
 template <typename T, int C>
+__device__ __forceinline__ void store_px4_raw(uint8_t* dst, const u32 (&e)[4][C], u32 mask) {
+  constexpr int E = (int)sizeof(T), N = 4 * C, NB = N * E, PER = 4 / E;
+  u32 w[NB / 4];
+#pragma unroll
+  for (int k = 0; k < NB / 4; ++k)
+    w[k] = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+    w[k / PER] |= e[k / C][k % C] << (8 * E * (k % PER));
+  constexpr u32 kAlign = NB % 16 == 0 ? 15u : (NB % 8 == 0 ? 7u : 3u);
+  if (mask == 0xfu && (((uintptr_t)dst) & kAlign) == 0) {
+    if constexpr (NB % 16 == 0) {
+#pragma unroll
+      for (int k = 0; k < NB / 16; ++k) {
+        const v4u32 q = {w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]};
+        ((VALI_GLOBAL v4u32*)dst)[k] = q;
+      }
+    } else if constexpr (NB % 8 == 0) {
+#pragma unroll
+      for (int k = 0; k < NB / 8; ++k) {
+        const v2u32 q = {w[2 * k], w[2 * k + 1]};
+        ((VALI_GLOBAL v2u32*)dst)[k] = q;
+      }
+    } else if constexpr (NB == 12) {
+      typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+      const v3u32 q = {w[0], w[1], w[2]};
+      *(VALI_GLOBAL v3u32*)dst = q;
+    } else {
+#pragma unroll
+      for (int k = 0; k < NB / 4; ++k)
+        ((VALI_GLOBAL u32*)dst)[k] = w[k];
+    }
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+    if (mask & (1u << (k / C)))
+      ((VALI_GLOBAL T*)dst)[k] = (T)e[k / C][k % C];
+}
+
+// POINT (integer element types, integer scale factors on both axes -- BASELINE config 3's exact 3x):
+// f = x * k is an exact integer, every weight is 0 and the result is src[ky y][kx x] whatever the
+// filter; the tile then skips the coordinate divisions, the second source row, the float
+// conversions and the lerps -- the same bytes as the arithmetic path (tests/test_gpu_resize.py).
+template <typename T, int C, bool POINT = false>
 __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int sw, int sh,
                                             uint8_t* dp, int dpitch, int dw, int dh, u32 tx,
                                             u32 ty, StageRows* stage_all) {
+  static_assert(!POINT || sizeof(T) < 4, "float planes keep the arithmetic (0 * inf must stay NaN)");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int x0 = (tx * 64 + lane) * 4;
@@ -84,12 +132,24 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
   // column taps of the lane's 4 pixels (tail lanes clamp to the last column)
   Lerp lx[4];
 #pragma unroll
-  for (int p = 0; p < 4; ++p)
-    lx[p] = make_lerp(min(x0 + p, dw - 1), scale_x, sw);
+  for (int p = 0; p < 4; ++p) {
+    if constexpr (POINT) {
+      lx[p].i0 = lx[p].i1 = min(x0 + p, dw - 1) * (sw / dw);
+      lx[p].a = 0.0f;
+    } else {
+      lx[p] = make_lerp(min(x0 + p, dw - 1), scale_x, sw);
+    }
+  }
   const int n = min(4, dw - x0); // valid pixels (<= 0: tail lane, staging only)
 
   // row taps: lane r evaluates row y_first + r, read back as scalars
-  const Lerp vly = make_lerp(y_first + (lane & (kRsRowsPerWave - 1)), scale_y, sh);
+  Lerp vly;
+  if constexpr (POINT) {
+    vly.i0 = vly.i1 = min(y_first + (lane & (kRsRowsPerWave - 1)), dh - 1) * (sh / dh);
+    vly.a = 0.0f;
+  } else {
+    vly = make_lerp(y_first + (lane & (kRsRowsPerWave - 1)), scale_y, sh);
+  }
   auto row_lerp = [&](int rr) {
     Lerp l;
     l.i0 = __builtin_amdgcn_readlane(vly.i0, rr);
@@ -160,7 +220,8 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
         for (int i = 0; i < CPR; ++i) {
           const int k = min(lane + i * kWave, nchunks - 1);
           q[0][i] = gload16(r0 + k * 16);
-          q[1][i] = gload16(r1 + k * 16);
+          if constexpr (!POINT)
+            q[1][i] = gload16(r1 + k * 16);
         }
       };
       auto commit = [&](const uint4 (&q)[2][CPR]) {
@@ -169,7 +230,8 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
           const int k = lane + i * kWave;
           if (k < nchunks) {
             *reinterpret_cast<uint4*>(&st.row[0][k * 16]) = q[0][i];
-            *reinterpret_cast<uint4*>(&st.row[1][k * 16]) = q[1][i];
+            if constexpr (!POINT)
+              *reinterpret_cast<uint4*>(&st.row[1][k * 16]) = q[1][i];
           }
         }
       };
@@ -186,10 +248,27 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
         wave_lds_sync();
         if (rr + DEPTH < kRsRowsPerWave && y + DEPTH < dh)
           issue(rr + DEPTH, pf[rr % DEPTH]); // in flight while rows rr .. rr+DEPTH-1 are sampled
-        if (n > 0)
+        if constexpr (POINT) {
+          if (n > 0) {
+            u32 e[4][C];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+              if constexpr (C == 2 && sizeof(T) == 1) { // the interleaved pair in one LDS read
+                const u32 uv = *(const uint16_t*)(st.row[0] + lo[p][0]);
+                e[p][0] = uv & 0xffu; e[p][1] = uv >> 8;
+              } else {
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch)
+                  e[p][ch] = ((const T*)(st.row[0] + lo[p][0]))[ch];
+              }
+            }
+            store_px4_raw<T, C>(dp + (u32)(y * dpitch) + (size_t)x0 * PB, e, (1u << n) - 1u);
+          }
+        } else if (n > 0) {
           sample_and_store(row_lerp(rr), y, [&](int r, int p, int t, int ch) {
             return (float)((const T*)(st.row[r] + lo[p][t]))[ch];
           });
+        }
         wave_lds_sync(); // the strip is re-filled by the next row
       }
     };
@@ -216,7 +295,7 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
 
 // MAXC = the largest channel count among the surface's plane jobs: the kernel is only as
 // register-heavy as the format needs (planar formats never carry the packed-RGB code).
-template <typename T, int MAXC>
+template <typename T, int MAXC, bool POINT = false>
 __global__ void __launch_bounds__(kBlock) k_resize(const ResizeArgs a) {
   ResizeJob job;
   u32 tx, ty, frame;
@@ -225,11 +304,11 @@ __global__ void __launch_bounds__(kBlock) k_resize(const ResizeArgs a) {
   __shared__ StageRows stage[kWavesPerBlock];
   const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
   if (MAXC >= 3 && job.channels == 3)
-    resize_tile<T, 3>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage);
+    resize_tile<T, 3, POINT>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage);
   else if (MAXC >= 2 && job.channels == 2)
-    resize_tile<T, 2>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage);
+    resize_tile<T, 2, POINT>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage);
   else
-    resize_tile<T, 1>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage);
+    resize_tile<T, 1, POINT>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -520,6 +599,7 @@ __global__ void __launch_bounds__(kBlock) k_resize_taps(const ResizeArgs a) {
     lanczos_tile<T, 1, MAXC, TAPS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage, ring);
 }
 
+template <typename T, int MAXC> constexpr auto k_resize_point = k_resize<T, MAXC, true>;
 template <typename T, int MAXC> constexpr auto k_resize_lanczos = k_resize_taps<T, MAXC, 6>;
 template <typename T, int MAXC> constexpr auto k_resize_cubic = k_resize_taps<T, MAXC, 4>;
 
@@ -557,7 +637,8 @@ static int launch_resize(ResizeArgs& a, int fmt, int src_w, int src_h, int dst_w
   // weight is 0 and ALL filters reduce to the same point sample src[k y][k x] (bit for bit:
   // fma(0, d, t) == t, {0,0,1,0,0,0} . taps and {-0,1,0,-0} . taps == the centre tap).  Lanczos
   // and cubic then run on the bilinear kernel, which does not even fetch the zero-weight rows
-  // (5.7 -> 1.3 us at the reference's own 2160p -> 720p case).
+  // (5.7 -> 1.3 us at the reference's own 2160p -> 720p case), and integer element types take its
+  // POINT form: no coordinate arithmetic, one source row, no float math.
   bool integer_scale = true;
   for (int k = 0; k < a.njobs; ++k) {
     const int dw = dst_w >> a.job[k].sub_x, dh = dst_h >> a.job[k].sub_y;
@@ -582,7 +663,11 @@ static int launch_resize(ResizeArgs& a, int fmt, int src_w, int src_h, int dst_w
     else hipLaunchKernelGGL((KERNEL<T, 3>), grid, block, 0, stream, a);                     \
   } while (0)
   const bool filtered = interp != VALI_INTERP_LINEAR && !(integer_scale && elem != 4);
-  if (filtered && interp == VALI_INTERP_LANCZOS) {
+  static const bool point_on = [] { const char* e = getenv("VALI_RESIZE_POINT"); return !(e && e[0] == '0'); }();
+  if (integer_scale && elem != 4 && point_on) { // every filter is the point sample (see resize_tile)
+    if (elem == 1) VALI_RS_LAUNCH(k_resize_point, uint8_t);
+    else VALI_RS_LAUNCH(k_resize_point, uint16_t);
+  } else if (filtered && interp == VALI_INTERP_LANCZOS) {
     if (elem == 1) VALI_RS_LAUNCH(k_resize_lanczos, uint8_t);
     else if (elem == 2) VALI_RS_LAUNCH(k_resize_lanczos, uint16_t);
     else VALI_RS_LAUNCH(k_resize_lanczos, float);
