@@ -273,7 +273,7 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
       }
     };
     if (nchunks <= kWave)
-      pipeline(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{});
+      pipeline(std::integral_constant<int, 1>{}, std::integral_constant<int, POINT ? kRsRowsPerWave : 4>{});
     else
       pipeline(std::integral_constant<int, kRsChunks>{}, std::integral_constant<int, 1>{});
   } else {
