@@ -164,3 +164,30 @@ def test_down2_foreign_destination(vali, gpu, oracle, angle, pad, skew):
     full = raw.cpu().numpy()
     pad_bytes = full[skew: skew + dh * pitch].reshape(dh, pitch)[:, dw * 3:]
     assert (pad_bytes == 7).all() and (full[:skew] == 7).all() and (full[skew + dh * pitch:] == 7).all()
+
+
+def test_down2_random_geometries(vali, gpu, oracle):
+    """60 random (width, height, output height, output, quarter turn) cases around the tile and
+    wave boundaries of both kernels (512-column waves of k_ud_down2, 256 x 32 tiles of k_ud_down2_t)."""
+    rng = np.random.default_rng(2024)
+    ud = vali.PySurfaceUD(gpu)
+    for case in range(60):
+        dw = int(rng.choice([rng.integers(1, 40), rng.integers(250, 262), rng.integers(505, 520),
+                             rng.integers(760, 775), rng.integers(1020, 1030), rng.integers(1, 1100)]))
+        sw = 2 * dw
+        sh = 2 * int(rng.integers(1, 70))
+        dh = int(rng.choice([sh // 2, rng.integers(1, 80), rng.integers(30, 36)]))
+        k = int(rng.integers(0, 4))
+        dst = "RGB" if k else str(rng.choice(["RGB", "RGB_PLANAR", "YUV444"]))
+        nv = rng.integers(0, 256, (sh * 3 // 2, sw), dtype=np.uint8)
+        src = vali.Surface.Make(vali.NV12, sw, sh, gpu)
+        assert vali.PyFrameUploader(gpu).Run(nv.reshape(-1), src)[0]
+        ow, oh = (dh, dw) if k & 1 else (dw, dh)
+        out = vali.Surface.Make(vali.PixelFormat[dst], ow, oh, gpu)
+        ok = ud.RunRotated(src, out, 90.0 * k) if k else ud.Run(src, out)
+        assert ok == (True, vali.TaskExecInfo.SUCCESS), (case, sw, sh, dw, dh, dst, k)
+        want = oracle.ud_nv12(nv, sw, sh, "NV12", dw, dh, dst)
+        if k:
+            want = np.rot90(want.reshape(dh, dw, 3), k=k)
+        got = download(vali, gpu, out)
+        assert np.array_equal(got, np.ascontiguousarray(want).reshape(-1)), (case, sw, sh, dw, dh, dst, k)
