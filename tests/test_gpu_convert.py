@@ -156,3 +156,53 @@ def test_all_pairs_random_sizes(vali, gpu, oracle, pair, size):
     """seeded random widths / heights, a third of them a few pixels around multiples of the
     kernels' 1024-pixel wave rows: tail lanes, partial 16-pixel groups, last-row pairs."""
     run_pair(vali, gpu, oracle, pair[0], pair[1], size[0], size[1], seed=size[0] + size[1])
+
+
+def test_run_async_memo_follows_surfaces_contexts_and_repointing(vali, gpu, oracle):
+    """PySurfaceConverter.RunAsync keeps a one-entry memo of the last (src, dst, cc_ctx) call: alternating
+    pairs, a changed colour context, a different destination format and a re-pointed (DLPack) surface must
+    all produce what the un-memoised dispatch produces."""
+    import torch
+    from conftest import make_nv12
+    w, h = 320, 180
+    frames = [make_nv12(w, h, 60 + i) for i in range(3)]
+    srcs = []
+    for f in frames:
+        s_ = vali.Surface.Make(vali.NV12, w, h, gpu)
+        assert vali.PyFrameUploader(gpu).Run(f.reshape(-1), s_)[0]
+        srcs.append(s_)
+    cv = vali.PySurfaceConverter(gpu)
+    dsts = [vali.Surface.Make(vali.RGB, w, h, gpu) for _ in range(2)]
+    planar = vali.Surface.Make(vali.RGB_PLANAR, w, h, gpu)
+    cc709 = vali.ColorspaceConversionContext(vali.ColorSpace.BT_709, vali.ColorRange.MPEG)
+    cc601 = vali.ColorspaceConversionContext(vali.ColorSpace.BT_601, vali.ColorRange.JPEG)
+
+    def get(surf):
+        out = np.zeros(surf.HostSize, np.uint8)
+        assert vali.PySurfaceDownloader(gpu).Run(surf, out)[0]
+        return out
+
+    def want(i, cc, fmt="RGB"):
+        fresh = vali.Surface.Make(vali.PixelFormat[fmt], w, h, gpu)
+        assert vali.PySurfaceConverter(gpu).Run(srcs[i], fresh, cc)[0]   # a new converter: no memo
+        return get(fresh)
+
+    for rep in range(3):                                     # same pair repeatedly, then alternate
+        assert cv.RunAsync(srcs[0], dsts[0], cc709) == (True, vali.TaskExecInfo.SUCCESS)
+    assert np.array_equal(get(dsts[0]), want(0, cc709))
+    for i, d in ((1, 1), (0, 0), (2, 1), (2, 0)):
+        assert cv.RunAsync(srcs[i], dsts[d], cc709)[0]
+        assert np.array_equal(get(dsts[d]), want(i, cc709))
+    assert cv.RunAsync(srcs[2], dsts[0], cc601)[0]           # same surfaces, other matrix
+    assert np.array_equal(get(dsts[0]), want(2, cc601))
+    assert cv.RunAsync(srcs[2], dsts[0])[0]                  # default context
+    assert np.array_equal(get(dsts[0]), want(2, None))
+    assert cv.RunAsync(srcs[2], planar)[0] and cv.RunAsync(srcs[2], planar)[0]
+    assert np.array_equal(get(planar), want(2, None, "RGB_PLANAR"))
+    # size mismatch after a memoised success still fails
+    small = vali.Surface.Make(vali.RGB, w // 2, h // 2, gpu)
+    assert cv.RunAsync(srcs[2], small) == (False, vali.TaskExecInfo.INVALID_INPUT)
+    with pytest.raises(ValueError):
+        cv.RunAsync(dsts[0], srcs[0])                        # RGB -> NV12 is not a reference pair
+    with pytest.raises(AttributeError):
+        cv.RunAsync(None, dsts[0])

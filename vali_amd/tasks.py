@@ -48,6 +48,7 @@ def _status(rc: int) -> TaskExecDetails:
 
 
 _S_OK = TaskExecDetails.ok()
+_OK_PAIR = (True, TaskExecInfo.SUCCESS)
 _S_INVALID = TaskExecDetails.failed(TaskExecInfo.INVALID_INPUT, "invalid src / dst")
 _S_UNSUPP_CC = TaskExecDetails.failed(TaskExecInfo.UNSUPPORTED_FMT_CONV_PARAMS,
                                       "unsupported cc_ctx params")
@@ -117,11 +118,14 @@ class _Single:
 
     def __init__(self, src, dst):
         self.src, self.dst = src, dst
+        self.last = None    # (C-ABI entry, its parameter block) of the call made: the converter's memo
 
     def convert(self, stream, params):
+        self.last = (shim.convert, params)
         return shim.convert(self.src.desc(), self.dst.desc(), params, stream)
 
     def nv12_to_rgb(self, stream, csc):
+        self.last = (shim.nv12_to_rgb, csc)
         return shim.nv12_to_rgb(self.src.desc(), self.dst.desc(), csc, stream)
 
 
@@ -269,6 +273,14 @@ class PySurfaceConverter(_SurfaceTask):
     def __init__(self, gpu_id: int, stream=None):
         super().__init__(gpu_id, stream)
         self._batch_cache = {}
+        # memo of the last successful single-surface call: (cc_ctx, src descriptor, dst descriptor,
+        # C-ABI entry, parameter block).  A repeated RunAsync on the same pair (the per-frame loop of
+        # every sample pipeline; BASELINE config 2) then costs one C call instead of the dispatch
+        # below: 4.95 -> 4.0 us per call, which is the GPU's own rate for back-to-back 1080p
+        # kernels.  The memo keeps the (pointer-only) descriptors alive, not the surfaces; a Surface
+        # gets a NEW descriptor object when it is re-pointed (Surface._update), and a new Surface
+        # has its own, so a stale entry can never match.
+        self._memo = None
 
     @staticmethod
     def Conversions() -> List[Tuple[PixelFormat, PixelFormat]]:
@@ -281,10 +293,22 @@ class PySurfaceConverter(_SurfaceTask):
         if impl is None:                                          # :1085-1089
             raise ValueError(f"Unsupported pixel format conversion: {src.Format.name} -> "
                              f"{dst.Format.name}")
-        return impl(_Single(src, dst), self._stream, cc_ctx)
+        io = _Single(src, dst)
+        d = impl(io, self._stream, cc_ctx)
+        if d is _S_OK and io.last is not None:
+            self._memo = (cc_ctx, src.desc(), dst.desc(), io.last[0], io.last[1])
+        return d
 
     def RunAsync(self, src: Surface, dst: Surface,
                  cc_ctx: Optional[ColorspaceConversionContext] = None) -> Tuple[bool, TaskExecInfo]:
+        m = self._memo
+        if m is not None and m[0] is cc_ctx:
+            try:
+                hit = src._desc is m[1] and dst._desc is m[2]
+            except AttributeError:      # not Surfaces: let the dispatch below complain
+                hit = False
+            if hit and m[3](m[1], m[2], m[4], self._stream) == 0:
+                return _OK_PAIR
         d = self._run(src, dst, cc_ctx)
         return d.success, d.info
 
