@@ -61,7 +61,10 @@ def chain_oracle(oracle, host, sw, sh, dw, dh, coeffs, div, mean, std):
 
 
 GEOMS = [(640, 360, 640, 360), (1920, 1080, 1920, 1080), (1920, 1080, 640, 384), (848, 464, 300, 300),
-         (130, 70, 58, 34), (640, 360, 1000, 500), (3840, 2160, 1280, 720), (66, 34, 66, 34)]
+         (130, 70, 58, 34), (640, 360, 1000, 500), (3840, 2160, 1280, 720), (66, 34, 66, 34),
+         # the resized path fetches both horizontal taps with one load: narrow sources, the clamped last
+         # column under strong upscaling, odd tap positions
+         (2, 2, 8, 6), (4, 4, 6, 10), (6, 2, 2, 2), (8, 4, 258, 130), (34, 18, 1030, 70), (3840, 2160, 640, 640)]
 
 
 @pytest.mark.parametrize("geom", GEOMS)

@@ -124,9 +124,15 @@ __global__ void __launch_bounds__(kBlock) k_nv12_preproc(const PreprocArgs a) {
       uu[0] = ubyte_f32<0>(wc); vv[0] = ubyte_f32<1>(wc); uu[1] = ubyte_f32<2>(wc); vv[1] = ubyte_f32<3>(wc);
     } else {
       // bilinear taps, arithmetic of resize_tile (t0, t1, v; then round-half-even to u8)
-      auto bilerp = [&](const uint8_t* r0, const uint8_t* r1, int i0, int i1, float ax, float ay) {
-        const float t00 = (float)gload<uint8_t>(r0 + i0), t10 = (float)gload<uint8_t>(r0 + i1);
-        const float t01 = (float)gload<uint8_t>(r1 + i0), t11 = (float)gload<uint8_t>(r1 + i1);
+      // The two horizontal taps are neighbours (i1 = min(i0 + 1, last)), so a row's pair comes from
+      // ONE (unaligned) load -- 2 bytes of luma, 4 bytes = two UV pairs of chroma: 20 vector-memory
+      // instructions per lane and row pair instead of 48; the texture addresser was this path's
+      // bound (profiles/r01_ud_down2.md: ~16 cycles per wave instruction whatever its width).
+      // At the right edge (i0 = last) the load starts one texel earlier and both taps take its
+      // second half.
+      typedef uint16_t u16_unaligned __attribute__((aligned(1)));
+      typedef u32 u32_unaligned __attribute__((aligned(1)));
+      auto lerp3 = [](float t00, float t10, float t01, float t11, float ax, float ay) {
         const float t0 = __builtin_fmaf(ax, t10 - t00, t00);
         const float t1 = __builtin_fmaf(ax, t11 - t01, t01);
         return (float)quantize_u8(__builtin_fmaf(ay, t1 - t0, t0));
@@ -137,16 +143,37 @@ __global__ void __launch_bounds__(kBlock) k_nv12_preproc(const PreprocArgs a) {
         const uint8_t* r0 = py + (size_t)ly.i0 * sp_y;
         const uint8_t* r1 = py + (size_t)ly.i1 * sp_y;
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-          yv[r][p] = bilerp(r0, r1, lx[p].i0, lx[p].i1, lx[p].a, ly.a);
+        for (int p = 0; p < 4; ++p) {
+          const int base = min(lx[p].i0, sw - 2);
+          const bool edge = lx[p].i0 != base;
+          const u32 w0 = *(const VALI_GLOBAL u16_unaligned*)(r0 + base);
+          const u32 w1 = *(const VALI_GLOBAL u16_unaligned*)(r1 + base);
+          const float t10 = (float)(w0 >> 8), t11 = (float)(w1 >> 8);
+          const float t00 = edge ? t10 : (float)(w0 & 0xffu), t01 = edge ? t11 : (float)(w1 & 0xffu);
+          yv[r][p] = lerp3(t00, t10, t01, t11, lx[p].a, ly.a);
+        }
       }
       const Lerp cy = make_lerp(y0 >> 1, csy, sh >> 1);
       const uint8_t* c0 = puv + (size_t)cy.i0 * sp_uv;
       const uint8_t* c1 = puv + (size_t)cy.i1 * sp_uv;
+      if (sw >= 4) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        uu[j] = bilerp(c0, c1, cxl[j].i0 * 2, cxl[j].i1 * 2, cxl[j].a, cy.a);
-        vv[j] = bilerp(c0, c1, cxl[j].i0 * 2 + 1, cxl[j].i1 * 2 + 1, cxl[j].a, cy.a);
+        for (int j = 0; j < 2; ++j) {
+          const int base = min(cxl[j].i0, (sw >> 1) - 2);
+          const bool edge = cxl[j].i0 != base;
+          const u32 w0 = *(const VALI_GLOBAL u32_unaligned*)(c0 + 2 * base); // U V U' V'
+          const u32 w1 = *(const VALI_GLOBAL u32_unaligned*)(c1 + 2 * base);
+          const float u10 = ubyte_f32<2>(w0), v10 = ubyte_f32<3>(w0), u11 = ubyte_f32<2>(w1), v11 = ubyte_f32<3>(w1);
+          const float u00 = edge ? u10 : ubyte_f32<0>(w0), v00 = edge ? v10 : ubyte_f32<1>(w0);
+          const float u01 = edge ? u11 : ubyte_f32<0>(w1), v01 = edge ? v11 : ubyte_f32<1>(w1);
+          uu[j] = lerp3(u00, u10, u01, u11, cxl[j].a, cy.a);
+          vv[j] = lerp3(v00, v10, v01, v11, cxl[j].a, cy.a);
+        }
+      } else { // a 2-pixel-wide source has ONE chroma pair per row: no neighbour to fetch with it
+        const float u0 = (float)gload<uint8_t>(c0), v0 = (float)gload<uint8_t>(c0 + 1);
+        const float u1 = (float)gload<uint8_t>(c1), v1 = (float)gload<uint8_t>(c1 + 1);
+        uu[0] = uu[1] = lerp3(u0, u0, u1, u1, 0.0f, cy.a);
+        vv[0] = vv[1] = lerp3(v0, v0, v1, v1, 0.0f, cy.a);
       }
     }
     // ---- step 2 + 3 ----
