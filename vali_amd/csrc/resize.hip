@@ -558,6 +558,52 @@ __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int 
         break;
       const LzTap<TAPS> cy = row_tap(rr);
       float res[4][C];
+      bool wide = false;
+      if constexpr (sizeof(T) == 4 && C == 3) {
+        // packed float RGB at >= 2x is the one format whose span exceeds the strip.  The TAPS
+        // pixels of a row are 12 TAPS contiguous bytes: in a wave whose taps all lie inside the
+        // image (every tile but the first and last of a row) they come as dwordx4 loads, 5 or 3
+        // instructions per row instead of 18 or 12 (the texture addresser charges per
+        // instruction).  Same taps, same accumulation order: the same bits.
+        bool inside = ((((uintptr_t)sp) | (uintptr_t)spitch) & 3u) == 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          inside = inside && cx[p].i - kBefore >= 0 && cx[p].i - kBefore + TAPS - 1 <= sw - 1;
+        wide = __builtin_amdgcn_ballot_w64(!inside) == 0; // wave-uniform: no per-lane merge of the two forms
+        if (wide) {
+          typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
+          typedef float v2f_a4 __attribute__((ext_vector_type(2), aligned(4)));
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            float v[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int r = 0; r < TAPS; ++r) {
+              const uint8_t* q = sp + (size_t)clampi(cy.i - kBefore + r, sh - 1) * spitch + (size_t)(cx[p].i - kBefore) * 12;
+              float tv[TAPS * 3];
+#pragma unroll
+              for (int k = 0; k < TAPS * 3 / 4; ++k) {
+                const v4f_a4 w4 = *(const VALI_GLOBAL v4f_a4*)(q + 16 * k);
+                tv[4 * k] = w4.x; tv[4 * k + 1] = w4.y; tv[4 * k + 2] = w4.z; tv[4 * k + 3] = w4.w;
+              }
+              if constexpr ((TAPS * 3) % 4 == 2) {
+                const v2f_a4 w2 = *(const VALI_GLOBAL v2f_a4*)(q + 16 * (TAPS * 3 / 4));
+                tv[TAPS * 3 - 2] = w2.x; tv[TAPS * 3 - 1] = w2.y;
+              }
+#pragma unroll
+              for (int ch = 0; ch < 3; ++ch) {
+                float h = cx[p].w[0] * tv[ch];
+#pragma unroll
+                for (int k = 1; k < TAPS; ++k)
+                  h = __builtin_fmaf(cx[p].w[k], tv[3 * k + ch], h);
+                v[ch] = r == 0 ? cy.w[0] * h : __builtin_fmaf(cy.w[r], h, v[ch]);
+              }
+              __builtin_amdgcn_sched_barrier(0); // one source row at a time: bounds the live registers
+            }
+            res[p][0] = v[0]; res[p][1] = v[1]; res[p][2] = v[2];
+          }
+        }
+      }
+      if (!wide)
 #pragma unroll
       for (int p = 0; p < 4; ++p)
 #pragma unroll
