@@ -122,3 +122,25 @@ def test_memo_is_bounded_and_does_not_keep_surfaces_alive(vali, gpu):
     gc.collect()
     assert len(cv._memo) <= 16
     assert all(r() is None for r in refs)
+
+
+def test_memo_sees_a_mutated_colour_context(vali, gpu):
+    """ColorspaceConversionContext is a mutable struct (as in the reference): the memo keys on its values"""
+    w, h = 128, 64
+    src = put(vali, gpu, vali.NV12, w, h, make_nv12(w, h, 3))
+    dst = vali.Surface.Make(vali.RGB, w, h, gpu)
+    cv = vali.PySurfaceConverter(gpu)
+    cc = vali.ColorspaceConversionContext(vali.ColorSpace.BT_709, vali.ColorRange.MPEG)
+    outs = []
+    for space, rng_ in ((vali.ColorSpace.BT_709, vali.ColorRange.MPEG), (vali.ColorSpace.BT_601, vali.ColorRange.JPEG),
+                        (vali.ColorSpace.BT_709, vali.ColorRange.JPEG), (vali.ColorSpace.BT_709, vali.ColorRange.MPEG)):
+        cc.color_space, cc.color_range = space, rng_
+        for _ in range(2):
+            assert cv.RunAsync(src, dst, cc)[0]
+        sync(vali, gpu, cv)
+        got = get(vali, gpu, dst)
+        fresh = vali.Surface.Make(vali.RGB, w, h, gpu)
+        assert vali.PySurfaceConverter(gpu).Run(src, fresh, vali.ColorspaceConversionContext(space, rng_))[0]
+        assert np.array_equal(got, get(vali, gpu, fresh)), (space, rng_)
+        outs.append(got)
+    assert not np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[3])
