@@ -1,0 +1,23 @@
+"""The resize / UD kernels have a direct-gather form that normally serves only very large downscale
+factors and foreign unaligned memory.  VALI_RESIZE_FORCE_GATHER=1 / VALI_UD_FORCE_GATHER=1 (read once
+per process) make every geometry take it, so the ordinary parity suites can be replayed through that
+code in a child process.  (This replay found a real bug: lanes without pixels left the kernel before
+v_readlane broadcast the row taps of a ragged last tile from them.)"""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_parity_suites_through_the_gather_forms():
+    env = dict(os.environ, VALI_RESIZE_FORCE_GATHER="1", VALI_UD_FORCE_GATHER="1")
+    files = ["tests/test_gpu_resize.py", "tests/test_gpu_ud.py", "tests/test_gpu_edge_geometry.py",
+             "tests/test_gpu_random_geometry.py"]
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", *files],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]

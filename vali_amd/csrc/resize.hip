@@ -39,6 +39,7 @@ struct ResizeArgs {
   ResizeJob job[3];
   int njobs;
   TileMap map;
+  int force_gather; // VALI_RESIZE_FORCE_GATHER=1: no LDS staging (tests reach the gather forms with ordinary sizes)
 };
 
 template <typename T> __device__ __forceinline__ float rs_load(const uint8_t* row, int idx) {
@@ -162,7 +163,7 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
   const int sx0 = __builtin_amdgcn_readlane(lx[0].i0, 0), sx1 = __builtin_amdgcn_readlane(lx[3].i1, 63);
   const int byte_begin = (sx0 * PB) & ~15;
   const int nbytes = (((sx1 + 1) * PB + 15) & ~15) - byte_begin;
-  const bool staged = nbytes <= kStageRowBytes && ((((uintptr_t)sp) | (uintptr_t)spitch) & 15u) == 0;
+  const bool staged = stage_all != nullptr && nbytes <= kStageRowBytes && ((((uintptr_t)sp) | (uintptr_t)spitch) & 15u) == 0;
 
   // The sampling code is instantiated twice (LDS rows / global rows) so each copy gets typed
   // ds_read / global_load instructions; all texels of the lane are fetched before any
@@ -277,18 +278,21 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
     else
       pipeline(std::integral_constant<int, kRsChunks>{}, std::integral_constant<int, 1>{});
   } else {
-    if (n <= 0)
-      return;
+    // (No early exit for lanes without pixels: row_lerp() reads lanes 0..7 with v_readlane, and a
+    // lane that has left the kernel holds whatever the compiler computed for it AFTER the exit --
+    // a ragged last tile of < 32 pixels would take its row taps from such lanes.)
 #pragma unroll 1
     for (int rr = 0; rr < kRsRowsPerWave; ++rr) {
       const int y = y_first + rr;
       if (y >= dh)
         break;
       const Lerp ly = row_lerp(rr);
-      const uint8_t* rows[2] = {sp + (size_t)ly.i0 * spitch, sp + (size_t)ly.i1 * spitch};
-      sample_and_store(ly, y, [&](int r, int p, int t, int ch) {
-        return (float)gload<T>(rows[r] + (size_t)(t ? lx[p].i1 : lx[p].i0) * PB + ch * sizeof(T));
-      });
+      if (n > 0) {
+        const uint8_t* rows[2] = {sp + (size_t)ly.i0 * spitch, sp + (size_t)ly.i1 * spitch};
+        sample_and_store(ly, y, [&](int r, int p, int t, int ch) {
+          return (float)gload<T>(rows[r] + (size_t)(t ? lx[p].i1 : lx[p].i0) * PB + ch * sizeof(T));
+        });
+      }
     }
   }
 }
@@ -304,11 +308,11 @@ __global__ void __launch_bounds__(kBlock) k_resize(const ResizeArgs a) {
   __shared__ StageRows stage[kWavesPerBlock];
   const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
   if (MAXC >= 3 && job.channels == 3)
-    resize_tile<T, 3, POINT>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage);
+    resize_tile<T, 3, POINT>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.force_gather ? nullptr : stage);
   else if (MAXC >= 2 && job.channels == 2)
-    resize_tile<T, 2, POINT>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage);
+    resize_tile<T, 2, POINT>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.force_gather ? nullptr : stage);
   else
-    resize_tile<T, 1, POINT>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage);
+    resize_tile<T, 1, POINT>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.force_gather ? nullptr : stage);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -441,7 +445,7 @@ __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int 
   const int sx1 = clampi(__builtin_amdgcn_readlane(cx[3].i, 63) + TAPS - 1 - kBefore, sw - 1);
   const int byte_begin = (sx0 * PB) & ~15;
   const int nbytes = (((sx1 + 1) * PB + 15) & ~15) - byte_begin;
-  const bool staged = nbytes <= kLzRowBytes && ((((uintptr_t)sp) | (uintptr_t)spitch) & 15u) == 0;
+  const bool staged = stage_all != nullptr && nbytes <= kLzRowBytes && ((((uintptr_t)sp) | (uintptr_t)spitch) & 15u) == 0;
 
   if (staged) {
     // Sliding window: hq[r] = the horizontal 6-tap filter of source row (base + r) at this
@@ -548,15 +552,16 @@ __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int 
       }
     }
   } else {
-    // source span wider than the strip (or foreign unaligned memory): direct gather, TAPS^2 taps
-    if (n <= 0)
-      return;
+    // source span wider than the strip (or foreign unaligned memory): direct gather, TAPS^2 taps.
+    // (No early exit for lanes without pixels: row_tap() reads lanes 0..7, see resize_tile.)
 #pragma unroll 1
     for (int rr = 0; rr < kRsRowsPerWave; ++rr) {
       const int y = y_first + rr;
       if (y >= dh)
         break;
       const LzTap<TAPS> cy = row_tap(rr);
+      if (n <= 0)
+        continue;
       float res[4][C];
       bool wide = false;
       if constexpr (sizeof(T) == 4 && C == 3) {
@@ -638,11 +643,11 @@ __global__ void __launch_bounds__(kBlock) k_resize_taps(const ResizeArgs a) {
   __shared__ LzRing<MAXC, TAPS> ring[kWavesPerBlock];
   const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
   if (MAXC >= 3 && job.channels == 3)
-    lanczos_tile<T, 3, MAXC, TAPS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage, ring);
+    lanczos_tile<T, 3, MAXC, TAPS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.force_gather ? nullptr : stage, ring);
   else if (MAXC >= 2 && job.channels == 2)
-    lanczos_tile<T, 2, MAXC, TAPS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage, ring);
+    lanczos_tile<T, 2, MAXC, TAPS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.force_gather ? nullptr : stage, ring);
   else
-    lanczos_tile<T, 1, MAXC, TAPS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, stage, ring);
+    lanczos_tile<T, 1, MAXC, TAPS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.force_gather ? nullptr : stage, ring);
 }
 
 template <typename T, int MAXC> constexpr auto k_resize_point = k_resize<T, MAXC, true>;
@@ -709,6 +714,8 @@ static int launch_resize(ResizeArgs& a, int fmt, int src_w, int src_h, int dst_w
     else hipLaunchKernelGGL((KERNEL<T, 3>), grid, block, 0, stream, a);                     \
   } while (0)
   const bool filtered = interp != VALI_INTERP_LINEAR && !(integer_scale && elem != 4);
+  static const bool gather_only = [] { const char* e = getenv("VALI_RESIZE_FORCE_GATHER"); return e && e[0] == '1'; }();
+  a.force_gather = gather_only ? 1 : 0;
   static const bool point_on = [] { const char* e = getenv("VALI_RESIZE_POINT"); return !(e && e[0] == '0'); }();
   if (integer_scale && elem != 4 && point_on) { // every filter is the point sample (see resize_tile)
     if (elem == 1) VALI_RS_LAUNCH(k_resize_point, uint8_t);

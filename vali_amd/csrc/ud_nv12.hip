@@ -560,14 +560,16 @@ __global__ void __launch_bounds__(kBlock, MINW) k_ud_nv12(const UdArgs a) {
   // direct byte gather: source span wider than the strip, or foreign memory that is not
   // 16-byte aligned
   auto gather_rows = [&]() {
-    if (n <= 0)
-      return;
+    // (no early exit for lanes without pixels: row_taps() reads lanes 0..7 with v_readlane, and a
+    // lane that has left holds whatever the compiler computed for it after the exit)
 #pragma unroll 1
     for (int rr = 0; rr < kUdRowsPerWave; ++rr) {
       const int y = y_first + rr;
       if (y >= dh)
         break;
       const RowTaps rt = row_taps(rr);
+      if (n <= 0)
+        continue;
       const uint8_t* yrow[2] = {py + (size_t)rt.ty.i0 * sp_y, py + (size_t)rt.ty.i1 * sp_y};
       const uint8_t* crow[2] = {puv + (size_t)rt.tcy.i0 * sp_uv, puv + (size_t)rt.tcy.i1 * sp_uv};
       float c0[4], c1[4], c2[4];
@@ -1263,10 +1265,15 @@ static int launch_ud(UdArgs& a, int src_fmt, int src_w, int dst_w, int dst_h, in
       staged = sp.yn <= cap && sp.cn <= cap;
     }
   }
+  // VALI_UD_FORCE_GATHER=1: the direct-gather form for every geometry, and no exact-2x kernels (tests
+  // reach the gather code with ordinary sizes; it normally serves > 4x downscales only)
+  static const bool force_gather = [] { const char* e = getenv("VALI_UD_FORCE_GATHER"); return e && e[0] == '1'; }();
+  if (force_gather)
+    staged = false;
   // exact 2x horizontal downscale of NV12: the division-free, LDS-free kernel (VALI_UD_DOWN2=0
   // keeps the general one, for A/B measurements)
   static const bool down2_on = [] { const char* e = getenv("VALI_UD_DOWN2"); return !(e && e[0] == '0'); }();
-  if (down2_on && src_fmt == VALI_FMT_NV12 && src_w == 2 * dst_w && !(rot & 1) && kind != UD_RGB_F32 &&
+  if (down2_on && !force_gather && src_fmt == VALI_FMT_NV12 && src_w == 2 * dst_w && !(rot & 1) && kind != UD_RGB_F32 &&
       kind != UD_RGB_F32_PLANAR) { // (float outputs are store-bound: 4 pixels per lane fill their stores better)
     a.map = make_tile_map((dst_w + kD2WaveW - 1) / kD2WaveW, (dst_h + kUdTileH - 1) / kUdTileH, (u32)n);
     const dim3 g2 = tile_grid(a.map);
@@ -1279,7 +1286,7 @@ static int launch_ud(UdArgs& a, int src_fmt, int src_w, int dst_w, int dst_h, in
     VALI_LAUNCH_CHECK();
     return VALI_OK;
   }
-  if (down2_on && src_fmt == VALI_FMT_NV12 && src_w == 2 * dst_w && (rot & 1)) {
+  if (down2_on && !force_gather && src_fmt == VALI_FMT_NV12 && src_w == 2 * dst_w && (rot & 1)) {
     if (rot == 1) hipLaunchKernelGGL((k_ud_down2_t<1>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((k_ud_down2_t<3>), grid, block, 0, stream, a);
     VALI_LAUNCH_CHECK();
