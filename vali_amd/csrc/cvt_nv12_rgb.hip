@@ -35,6 +35,7 @@ struct Nv12RgbArgs {
   vali_surface dst;
   vali_csc csc;
   TileMap map;               // tiles of one frame: x segments x row pairs
+  int rp;                    // row pairs stacked in one workgroup (narrow frames)
 };
 
 // 4 pixels of one row: y4 = 4 luma bytes, chroma terms c01 (px 0,1) / c23 (px 2,3).
@@ -104,14 +105,19 @@ __global__ void __launch_bounds__(kBlock) k_nv12_rgb8(const Nv12RgbArgs a) {
   const vali_csc k = a.csc;
 
   const int lane = threadIdx.x & (kWave - 1);
-  const int wave = threadIdx.x / kWave;
-  const int wave_g0 = tile_x * blockDim.x + wave * kWave; // first group of this wave
+  const int wave_all = threadIdx.x / kWave;
+  const int wpr = (int)(blockDim.x / kWave) / a.rp;        // waves side by side on one row pair
+  const int wave = wave_all;                                // (LDS strip index)
+  const int wave_g0 = (tile_x * wpr + wave_all % wpr) * kWave; // first group of this wave
   const int groups = (W + kLanePx - 1) / kLanePx;
   if (wave_g0 >= groups)
     return; // whole wave out of the row: nothing to cooperate on
   const int g = wave_g0 + lane;
   const int x0 = g * kLanePx;
-  const int row0 = tile_y * 2;
+  const int crow = tile_y * a.rp + wave_all / wpr;          // chroma row = row pair index
+  if (crow * 2 >= H)
+    return;
+  const int row0 = crow * 2;
   const bool has_row1 = row0 + 1 < H;
 
   // Uniform (per frame) fast-path test: full 16-px groups and 16-B aligned rows.
@@ -129,7 +135,7 @@ __global__ void __launch_bounds__(kBlock) k_nv12_rgb8(const Nv12RgbArgs a) {
       // odd height: the last pair re-reads row0 (always a valid address)
       const uint4 yb =
           load16(py + (size_t)(row0 + (has_row1 ? 1 : 0)) * sp_y + x0);
-      const uint4 uv = load16(puv + (size_t)tile_y * sp_uv + x0);
+      const uint4 uv = load16(puv + (size_t)crow * sp_uv + x0);
       const u32 yw0[4] = {ya.x, ya.y, ya.z, ya.w};
       const u32 yw1[4] = {yb.x, yb.y, yb.z, yb.w};
       const u32 uvw[4] = {uv.x, uv.y, uv.z, uv.w};
@@ -196,7 +202,7 @@ __global__ void __launch_bounds__(kBlock) k_nv12_rgb8(const Nv12RgbArgs a) {
       if (x >= W)
         break;
       const float yv = (float)py[(size_t)y * sp_y + x];
-      const uint8_t* c = puv + (size_t)tile_y * sp_uv + (x & ~1);
+      const uint8_t* c = puv + (size_t)crow * sp_uv + (x & ~1);
       const ChromaTerm t = chroma_term((float)c[0], (float)c[1], k);
       const float yf = luma_term(yv, k);
       const uint8_t R = (uint8_t)quantize_u8(yf + t.rv), G = (uint8_t)quantize_u8(yf + t.guv),
@@ -222,7 +228,17 @@ static int launch_nv12_rgb(Nv12RgbArgs& a, int width, int height, int n, int dst
   int block = ((groups + kWave - 1) / kWave) * kWave;
   if (block > kBlock)
     block = kBlock;
-  a.map = make_tile_map((groups + block - 1) / block, (height + 1) / 2, (u32)n);
+  // Narrow frames (a row pair needs <= 128 lanes: up to 2048 px) stack 2 or 4 row pairs in one
+  // 256-thread workgroup -- adjacent rows, the same residency in fewer, fuller workgroups:
+  // 1080p 5.72 -> 6.03-6.19 TB/s, 720p 5.02 -> 5.11 (profiles/r01_variants.md sweep 8).
+  // VALI_NV12_ROWPAIRS=1 restores one row pair per workgroup (A/B only).
+  static const int rp_env = [] { const char* e = getenv("VALI_NV12_ROWPAIRS"); return e ? atoi(e) : 0; }();
+  const int row_block = block;
+  a.rp = rp_env > 0 ? rp_env : kBlock / row_block;
+  if (a.rp < 1 || row_block * a.rp > kBlock)
+    a.rp = 1;
+  a.map = make_tile_map((groups + row_block - 1) / row_block, ((height + 1) / 2 + a.rp - 1) / a.rp, (u32)n);
+  block = row_block * a.rp;
   const dim3 grid = tile_grid(a.map);
   // tuning knobs for A/B measurements only (not part of the API)
   static const bool direct = [] {
@@ -233,9 +249,9 @@ static int launch_nv12_rgb(Nv12RgbArgs& a, int width, int height, int n, int dst
     const char* e = getenv("VALI_WAVES_PER_CU");
     return e ? atoi(e) : 0;
   }();
-  const int waves_per_cu = waves_override > 0 ? waves_override : streaming_waves_per_cu(groups, block, 16);
+  const int waves_per_cu = waves_override > 0 ? waves_override : streaming_waves_per_cu(groups, row_block, 16);
   const unsigned lds =
-      residency_lds_bytes(block, waves_per_cu, (unsigned)sizeof(PackedStrip) * kWavesPerBlock);
+      residency_lds_bytes(block, waves_per_cu, (unsigned)sizeof(PackedStrip) * (unsigned)((block + kWave - 1) / kWave));
   switch (dst_format) {
   case VALI_FMT_RGB:
     if (direct)
