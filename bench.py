@@ -119,7 +119,7 @@ def secondary_configs(pipe):
         sys.path.insert(0, str(ROOT / "tools"))
         import bench_configs as bc
 
-        return [bc.cfg2(), bc.cfg3(), bc.cfg4()]
+        return [bc.hl1080(), bc.cfg2(), bc.cfg3(), bc.cfg4()]
     except Exception as e:  # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"}
 

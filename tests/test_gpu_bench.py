@@ -35,7 +35,8 @@ def test_bench_single_gpu_contract(gpu):
     assert "workload" in j["config"] and "model" not in j["config"]
     assert j["verification"] == {"frames_verified_on_gpu": 16, "frames_mismatching": 0,
                                  "checksum_of_checksums": j["verification"]["checksum_of_checksums"]}
-    assert [c["config"][:4] for c in j["secondary"]] == ["cfg2", "cfg3", "cfg4"]
+    assert [c["config"][:4] for c in j["secondary"]] == ["NV12", "cfg2", "cfg3", "cfg4"]
+    assert 0.3 < j["secondary"][0]["frac_of_8TBps"] < 1.0
 
 
 def test_bench_two_ranks_share_one_gpu(gpu):

@@ -54,6 +54,23 @@ def fill(surfs, seed=0):
     shim.stream_sync(DEV, 0)
 
 
+def hl1080(n=1024):
+    """the headline conversion on 1080p surfaces (north_star asks for 1080p next to 2160p): NV12 -> RGB,
+    one launch over n frames resident in HBM"""
+    w, h = 1920, 1080
+    srcs = [vali.Surface.Make(vali.NV12, w, h, DEV) for _ in range(n)]
+    dsts = [vali.Surface.Make(vali.RGB, w, h, DEV) for _ in range(n)]
+    fill(srcs)
+    cvt = vali.PySurfaceConverter(DEV)
+    cc = vali.ColorspaceConversionContext(vali.ColorSpace.BT_709, vali.ColorRange.MPEG)
+    batch = cvt.PrepareBatch(srcs, dsts)
+    ms, _ = timed(cvt.Stream, lambda: cvt.RunBatchAsync(batch, cc_ctx=cc), 20)
+    gbps = w * h * 4.5 * n / (ms * 1e-3) / 1e9
+    return {"config": f"NV12->RGB 1920x1080, batch={n}, one launch (the headline kernel at 1080p)",
+            "frames_per_s": round(n / (ms * 1e-3), 1), "us_per_frame": round(ms * 1e3 / n, 3),
+            "GBps_algorithmic": round(gbps, 1), "frac_of_8TBps": round(gbps / PEAK, 4)}
+
+
 def cfg2():
     w, h = 1920, 1080
     cvt = vali.PySurfaceConverter(DEV)
@@ -223,6 +240,6 @@ def ud_scales(n=32):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cfg2", "cfg3", "cfg4"]
+    which = sys.argv[1:] or ["hl1080", "cfg2", "cfg3", "cfg4"]
     for name in which:
         print(json.dumps(globals()[name]()), flush=True)
