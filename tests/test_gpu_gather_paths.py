@@ -21,3 +21,22 @@ def test_parity_suites_through_the_gather_forms():
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", *files],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+@pytest.mark.parametrize("switch,files", [
+    ("VALI_ROTATE_NO_TILE=1", ["tests/test_gpu_rotate.py"]),
+    ("VALI_NV12_DIRECT_STORE=1", ["tests/test_gpu_nv12_rgb.py"]),
+    ("VALI_NV12_ROWPAIRS=1", ["tests/test_gpu_nv12_rgb.py"]),
+    ("VALI_WAVES_PER_CU=8", ["tests/test_gpu_nv12_rgb.py", "tests/test_gpu_convert.py"]),
+    ("VALI_UD_OCC5=0", ["tests/test_gpu_ud.py"]),
+    ("VALI_UD_DOWN2=0", ["tests/test_gpu_ud.py", "tests/test_gpu_ud_down2.py"]),
+    ("VALI_RESIZE_POINT=0", ["tests/test_gpu_resize.py"]),
+])
+def test_parity_suites_under_each_ab_switch(switch, files):
+    """the alternative kernel forms kept behind environment switches (tools/README.md) stay bit-exact"""
+    k, v = switch.split("=")
+    env = dict(os.environ, **{k: v})
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        "--deselect", "tests/test_gpu_ud_down2.py::test_down2_equals_the_general_kernel", *files],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
