@@ -191,3 +191,48 @@ def test_down2_random_geometries(vali, gpu, oracle):
             want = np.rot90(want.reshape(dh, dw, 3), k=k)
         got = download(vali, gpu, out)
         assert np.array_equal(got, np.ascontiguousarray(want).reshape(-1)), (case, sw, sh, dw, dh, dst, k)
+
+
+# ---- the same kernel at a 1:1 width ratio (colour conversion with chroma interpolation) -------------
+SAME_GEOMS = [(1920, 1080, 1080), (1280, 720, 720), (848, 464, 232), (848, 464, 1000), (1002, 500, 333),
+              (518, 64, 77), (8, 4, 4), (6, 4, 2), (2, 2, 2), (10, 6, 3), (1024, 16, 5), (520, 20, 20), (1030, 24, 12)]
+
+
+@pytest.mark.parametrize("dst", ["YUV444", "RGB", "RGB_PLANAR", "RGB_32F_PLANAR"])
+@pytest.mark.parametrize("geom", SAME_GEOMS)
+def test_same_width_bit_exact(vali, gpu, oracle, dst, geom):
+    sw, sh, dh = geom
+    nv = make_nv12(sw, sh, 37)
+    src = vali.Surface.Make(vali.NV12, sw, sh, gpu)
+    assert vali.PyFrameUploader(gpu).Run(nv.reshape(-1), src)[0]
+    out = vali.Surface.Make(vali.PixelFormat[dst], sw, dh, gpu)
+    assert vali.PySurfaceUD(gpu).Run(src, out) == (True, vali.TaskExecInfo.SUCCESS)
+    dt = np.float32 if "32F" in dst else np.uint8
+    want = oracle.ud_nv12(nv, sw, sh, "NV12", sw, dh, dst).reshape(-1)
+    assert np.array_equal(download(vali, gpu, out, dt).view(np.uint8), want.view(np.uint8))
+
+
+def test_same_width_random_geometries_rotation_and_foreign_memory(vali, gpu, oracle):
+    rng = np.random.default_rng(4048)
+    ud = vali.PySurfaceUD(gpu)
+    for case in range(40):
+        sw = 2 * int(rng.choice([rng.integers(1, 20), rng.integers(126, 132), rng.integers(254, 262),
+                                 rng.integers(510, 518), rng.integers(1, 600)]))
+        sh = 2 * int(rng.integers(1, 50))
+        dh = int(rng.choice([sh, rng.integers(1, 60)]))
+        k = int(rng.choice([0, 0, 2]))
+        dst = "RGB" if k else str(rng.choice(["RGB", "RGB_PLANAR", "YUV444"]))
+        nv = rng.integers(0, 256, (sh * 3 // 2, sw), dtype=np.uint8)
+        if case % 5 == 4:
+            src, keep = foreign_nv12(vali, sw, sh, nv, pad=int(rng.choice([3, 8, 13, 16])), skew=int(rng.choice([0, 5, 8])))
+        else:
+            src, keep = vali.Surface.Make(vali.NV12, sw, sh, gpu), None
+            assert vali.PyFrameUploader(gpu).Run(nv.reshape(-1), src)[0]
+        out = vali.Surface.Make(vali.PixelFormat[dst], sw, dh, gpu)
+        ok = ud.RunRotated(src, out, 180.0) if k else ud.Run(src, out)
+        assert ok == (True, vali.TaskExecInfo.SUCCESS), (case, sw, sh, dh, dst, k)
+        want = oracle.ud_nv12(nv, sw, sh, "NV12", sw, dh, dst)
+        if k:
+            want = np.rot90(want.reshape(dh, sw, 3), k=2)
+        assert np.array_equal(download(vali, gpu, out), np.ascontiguousarray(want).reshape(-1)), (case, sw, sh, dh, dst, k)
+        del keep

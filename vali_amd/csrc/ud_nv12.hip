@@ -30,8 +30,8 @@
 // Kernels in this file:
 //   k_ud_nv12<T,OUT,STAGED,ROT>  any scale factor, NV12 / P10, every output; VALU-bound (4.8 us per
 //                                2160p -> 1080p frame)
-//   k_ud_down2<OUT,ROT>          source exactly twice as wide as the output, NV12, 8-bit outputs,
-//                                0 / 180 degree output: 16-byte loads, no LDS staging (3.8 us)
+//   k_ud_down2<OUT,ROT,RATIO>    source exactly twice as wide as the output (RATIO 2) or as wide (1), NV12,
+//                                8-bit outputs, 0 / 180 degree output: wide loads, no LDS staging (3.8 us)
 //   k_ud_down2_t<ROT>            the same for the 90 / 270 degree outputs (4.35 us, config 4 in one pass)
 // all three produce the same bits (tests/test_gpu_ud_down2.py); profiles/r01_ud_down2.md has the
 // counters that led from the first to the other two.
@@ -826,9 +826,95 @@ __device__ __forceinline__ void d2_compute(const D2Taps& rt, const D2Quad& r, fl
   }
 }
 
-template <int OUT, int ROT>
+// ---- the same scheme at a 1:1 width ratio (src width == UD width: colour conversion with chroma
+// interpolation, any height).  X = x: luma taps (x-1, x) with weights 128/128; chroma coordinate
+// x/2: even x -> pairs (x/2-1, x/2) 128/128, odd x -> the single pair (x-1)/2 with weight 256
+// (fraction 0) = 128 (T + T).  A lane's 8 pixels need 8 + 1 luma bytes and 4 + 1 chroma pairs per
+// source row: one dwordx2 each plus the dword before it (p/a/b as in D2Quad, but a, b are the
+// lane's own 8 bytes and the result is 8 pixels).
+struct D1Oct {
+  u32 p[4], a[4], b[4];
+};
+__device__ __forceinline__ D1Oct d1_gather(const D2Src& s, const D2Taps& rt, int x0) {
+  D1Oct r;
+  const int cw = s.sw / 2, c0 = x0 / 2;
+  const uint8_t* yr[2] = {s.py + (u32)(rt.ty.i0 * s.sp_y), s.py + (u32)(rt.ty.i1 * s.sp_y)};
+  const uint8_t* cr[2] = {s.puv + (u32)(rt.tcy.i0 * s.sp_uv), s.puv + (u32)(rt.tcy.i1 * s.sp_uv)};
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    auto lb = [&](int c) { return (u32)gload<uint8_t>(yr[k] + min(max(c, 0), s.sw - 1)); };
+    auto cp = [&](int q) { // one UV pair as 16 bits
+      const uint8_t* t = cr[k] + 2 * min(max(q, 0), cw - 1);
+      return (u32)gload<uint8_t>(t) | ((u32)gload<uint8_t>(t + 1) << 8);
+    };
+    r.p[k] = lb(x0 - 1) << 24;
+    r.a[k] = lb(x0) | (lb(x0 + 1) << 8) | (lb(x0 + 2) << 16) | (lb(x0 + 3) << 24);
+    r.b[k] = lb(x0 + 4) | (lb(x0 + 5) << 8) | (lb(x0 + 6) << 16) | (lb(x0 + 7) << 24);
+    r.p[2 + k] = cp(c0 - 1) << 16;
+    r.a[2 + k] = cp(c0) | (cp(c0 + 1) << 16);
+    r.b[2 + k] = cp(c0 + 2) | (cp(c0 + 3) << 16);
+  }
+  return r;
+}
+
+// P A B of four rows -> the three components (scaled by UdScale) of the lane's 8 pixels
+template <int OUT, bool kEven>
+__device__ __forceinline__ void d1_compute(const D2Taps& rt, const D1Oct& r, float* c0, float* c1, float* c2) {
+  using T = uint8_t;
+  constexpr float kScale = UdScale<T, OUT>::value;
+  constexpr float kNorm = TexelTraits<T>::kInvDen * kScale * 128.0f;
+  // operand (0: q = P|A shifted, 1: A, 2: w = A|B shifted, 3: B) and byte mask of pixel j's pair sum
+  constexpr int kLumaOp[8] = {0, 0, 0, 1, 2, 2, 2, 3};
+  constexpr u32 kLumaMask[8] = {0x00000101u, 0x00010100u, 0x01010000u, 0x01010000u,
+                                0x00000101u, 0x00010100u, 0x01010000u, 0x01010000u};
+  constexpr int kChromaOp[8] = {0, 1, 1, 1, 2, 3, 3, 3};
+  constexpr u32 kChromaMaskU[8] = {0x00010001u, 0x00000002u, 0x00010001u, 0x00020000u,
+                                   0x00010001u, 0x00000002u, 0x00010001u, 0x00020000u};
+  u32 op[4][4]; // [row][operand]
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int sh = k < 2 ? 3 : 2;
+    op[k][0] = __builtin_amdgcn_alignbyte(r.a[k], r.p[k], sh);
+    op[k][1] = r.a[k];
+    op[k][2] = __builtin_amdgcn_alignbyte(r.b[k], r.a[k], sh);
+    op[k][3] = r.b[k];
+  }
+  u32 sy[8], su[8], sv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if constexpr (kEven) {
+      auto two = [](u32 v0, u32 v1, u32 m) { return __builtin_amdgcn_udot4(v1, m, __builtin_amdgcn_udot4(v0, m, 0u, false), false); };
+      sy[j] = two(op[0][kLumaOp[j]], op[1][kLumaOp[j]], kLumaMask[j]);
+      su[j] = two(op[2][kChromaOp[j]], op[3][kChromaOp[j]], kChromaMaskU[j]);
+      sv[j] = two(op[2][kChromaOp[j]], op[3][kChromaOp[j]], kChromaMaskU[j] << 8);
+    } else {
+      auto one = [](u32 v, u32 m) { return __builtin_amdgcn_udot4(v, m, 0u, false); };
+      sy[j] = __umul24(rt.ty.w0, one(op[0][kLumaOp[j]], kLumaMask[j])) + __umul24(rt.ty.w1, one(op[1][kLumaOp[j]], kLumaMask[j]));
+      su[j] = __umul24(rt.tcy.w0, one(op[2][kChromaOp[j]], kChromaMaskU[j])) +
+              __umul24(rt.tcy.w1, one(op[3][kChromaOp[j]], kChromaMaskU[j]));
+      sv[j] = __umul24(rt.tcy.w0, one(op[2][kChromaOp[j]], kChromaMaskU[j] << 8)) +
+              __umul24(rt.tcy.w1, one(op[3][kChromaOp[j]], kChromaMaskU[j] << 8));
+    }
+  }
+  constexpr float kN = kEven ? kNorm * 128.0f : kNorm;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float ny = (float)sy[j] * kN, nu = (float)su[j] * kN, nv = (float)sv[j] * kN;
+    if constexpr (OUT == UD_YUV444) {
+      c0[j] = ny; c1[j] = nu; c2[j] = nv;
+    } else {
+      const float u = nu - 0.5f * kScale, v = nv - 0.5f * kScale;
+      c0[j] = __builtin_fmaf(1.140f, v, ny);
+      c1[j] = __builtin_fmaf(-0.581f, v, __builtin_fmaf(-0.394f, u, ny));
+      c2[j] = __builtin_fmaf(2.032f, u, ny);
+    }
+  }
+}
+
+template <int OUT, int ROT, int RATIO = 2>
 __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
   using T = uint8_t;
+  static_assert(RATIO == 1 || RATIO == 2, "source width = RATIO x UD width");
   static_assert(ROT == 0 || ROT == 2, "the transposed outputs: k_ud_down2_t");
   static_assert(ROT == 0 || OUT == UD_RGB_U8, "rotated output: NV12 -> RGB only");
   u32 tile_x, tile_y, frame;
@@ -946,7 +1032,29 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
     }
   };
 
-  const bool aligned = ((((uintptr_t)py) | ((uintptr_t)puv) | (uintptr_t)sp_y | (uintptr_t)sp_uv) & 15u) == 0 && sw >= 16;
+  // the lane's pixels of row y through byte gathers and the general store
+  auto slow_lane = [&](const RowTaps& rt, int y) {
+    if constexpr (RATIO == 2) {
+#pragma unroll 1
+      for (int h = 0; h < 2; ++h)
+        if (n > 4 * h)
+          finish(rt, gather(rt, x0 + 4 * h), x0 + 4 * h, min(4, n - 4 * h), y);
+    } else {
+      float c0[8], c1[8], c2[8];
+      d1_compute<OUT, false>(rt, d1_gather(srcv, rt, x0), c0, c1, c2);
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        if (n > 4 * h) {
+          const float (&h0)[4] = *reinterpret_cast<const float (*)[4]>(c0 + 4 * h);
+          const float (&h1)[4] = *reinterpret_cast<const float (*)[4]>(c1 + 4 * h);
+          const float (&h2)[4] = *reinterpret_cast<const float (*)[4]>(c2 + 4 * h);
+          ud_emit<T, OUT, ROT, false>(d, nullptr, wave, lane, 0, x0 + 4 * h, y, min(4, n - 4 * h), dw, dh, h0, h1, h2);
+        }
+    }
+  };
+  constexpr int kLaneBytes = 8 * RATIO; // the lane's own bytes of a luma row and of a chroma row
+  const bool aligned = ((((uintptr_t)py) | ((uintptr_t)puv) | (uintptr_t)sp_y | (uintptr_t)sp_uv) & (kLaneBytes - 1)) == 0 &&
+                       sw >= kLaneBytes;
   if (!aligned) {
 #pragma unroll 1
     for (int rr = 0; rr < kUdRowsPerWave; ++rr) {
@@ -954,10 +1062,8 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
       if (y >= dh)
         break;
       const RowTaps rt = row_taps(rr);
-#pragma unroll 1
-      for (int h = 0; h < 2; ++h)
-        if (n > 4 * h)
-          finish(rt, gather(rt, x0 + 4 * h), x0 + 4 * h, min(4, n - 4 * h), y);
+      if (n > 0)
+        slow_lane(rt, y);
     }
     return;
   }
@@ -967,15 +1073,21 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
     uint4 v[4]; // the lane's 16 bytes of luma i0, luma i1, chroma i0, chroma i1
     u32 before; // lane k < 4: the dword before the WAVE's first byte in row k
   };
-  const int off16 = min(2 * x0, (sw - 16) & ~15);
-  const int offw = max(2 * xw - 4, 0);
+  const int off16 = min(RATIO * x0, (sw - kLaneBytes) & ~(kLaneBytes - 1));
+  const int offw = max(RATIO * xw - 4, 0);
   auto issue = [&](const RowTaps& rt) {
     Rows r;
     const uint8_t* row[4] = {py + (u32)(rt.ty.i0 * sp_y), py + (u32)(rt.ty.i1 * sp_y),
                              puv + (u32)(rt.tcy.i0 * sp_uv), puv + (u32)(rt.tcy.i1 * sp_uv)};
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      r.v[k] = gload16(row[k] + (u32)off16);
+    for (int k = 0; k < 4; ++k) {
+      if constexpr (RATIO == 2) {
+        r.v[k] = gload16(row[k] + (u32)off16);
+      } else {
+        const uint2 w = load8(row[k] + (u32)off16);
+        r.v[k] = make_uint4(w.x, w.y, 0u, 0u);
+      }
+    }
     const uint8_t* rb = lane == 0 ? row[0] : lane == 1 ? row[1] : lane == 2 ? row[2] : row[3];
     r.before = gload<u32>(rb + (u32)offw);
     return r;
@@ -992,40 +1104,55 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
                       : d.p[0] + (u32)(y * d.pitch[0]) + (size_t)xw * 3;
       vec = (((uintptr_t)orow) & 15u) == 0; // wave-uniform; else every lane takes the general store
     }
+    // (broadcast BEFORE the divergent branch below: inside it only the lanes with 8 pixels run, and
+    // a load whose only reader sits there may be sunk into it -- lanes 1..3 of a wave whose lane 0
+    // alone is full would then never fetch their dword)
+    u32 before[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      before[k] = (u32)__builtin_amdgcn_readlane((int)rows.before, k);
     if (n == kD2LanePx && vec) {
-      // the 4 bytes before the lane's 16: the previous lane's last dword; lane 0 takes the
+      // the 4 bytes before the lane's own: the previous lane's last dword; lane 0 takes the
       // wave's extra load, or the clamp (column -1 = column 0) at the left edge of the image
       u32 prev[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const u32 edge = k < 2 ? rows.v[k].x << 24 : rows.v[k].x << 16;
-        const u32 first = xw == 0 ? edge : (u32)__builtin_amdgcn_readlane((int)rows.before, k);
-        const u32 sh1 = wave_shr1(rows.v[k].w);
+        const u32 first = xw == 0 ? edge : before[k];
+        const u32 sh1 = wave_shr1(RATIO == 2 ? rows.v[k].w : rows.v[k].y);
         prev[k] = lane == 0 ? first : sh1;
       }
-      Quad q0, q1;
       float c0[8], c1[8], c2[8];
+      const bool even = cur.ty.w0 == 128u && cur.tcy.w0 == 128u; // (w1 = 256 - w0) wave-uniform
+      if constexpr (RATIO == 2) {
+        Quad q0, q1;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        q0.p[k] = prev[k]; q0.a[k] = rows.v[k].x; q0.b[k] = rows.v[k].y;
-        q1.p[k] = rows.v[k].y; q1.a[k] = rows.v[k].z; q1.b[k] = rows.v[k].w;
-      }
-      if (cur.ty.w0 == 128u && cur.tcy.w0 == 128u) { // (w1 = 256 - w0) wave-uniform
-        compute(std::true_type{}, cur, q0, c0, c1, c2);
-        compute(std::true_type{}, cur, q1, c0 + 4, c1 + 4, c2 + 4);
+        for (int k = 0; k < 4; ++k) {
+          q0.p[k] = prev[k]; q0.a[k] = rows.v[k].x; q0.b[k] = rows.v[k].y;
+          q1.p[k] = rows.v[k].y; q1.a[k] = rows.v[k].z; q1.b[k] = rows.v[k].w;
+        }
+        if (even) {
+          compute(std::true_type{}, cur, q0, c0, c1, c2);
+          compute(std::true_type{}, cur, q1, c0 + 4, c1 + 4, c2 + 4);
+        } else {
+          compute(std::false_type{}, cur, q0, c0, c1, c2);
+          compute(std::false_type{}, cur, q1, c0 + 4, c1 + 4, c2 + 4);
+        }
       } else {
-        compute(std::false_type{}, cur, q0, c0, c1, c2);
-        compute(std::false_type{}, cur, q1, c0 + 4, c1 + 4, c2 + 4);
+        D1Oct o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o.p[k] = prev[k]; o.a[k] = rows.v[k].x; o.b[k] = rows.v[k].y; }
+        if (even)
+          d1_compute<OUT, true>(cur, o, c0, c1, c2);
+        else
+          d1_compute<OUT, false>(cur, o, c0, c1, c2);
       }
       if constexpr (kPacked)
         strip_put(c0, c1, c2);
       else
         emit_planar(y, c0, c1, c2);
     } else if (n > 0) { // the one tail lane of a ragged row (or a destination row that is not 16-byte aligned)
-#pragma unroll 1
-      for (int h = 0; h < 2; ++h)
-        if (n > 4 * h)
-          finish(cur, gather(cur, x0 + 4 * h), x0 + 4 * h, min(4, n - 4 * h), y);
+      slow_lane(cur, y);
     }
     if constexpr (kPacked) {
       if (vec) {
@@ -1152,6 +1279,13 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2_t(const UdArgs a) {
     };
     auto step = [&](int it, const D2Taps& cur, bool even, const Rows& rows) {
       const int rr = 2 * it + half;
+      u32 before[4]; // broadcast before any divergence (see k_ud_down2)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const u32 f0 = (u32)__builtin_amdgcn_readlane((int)rows.before, k);
+        const u32 f1 = (u32)__builtin_amdgcn_readlane((int)rows.before, 32 + k);
+        before[k] = half ? f1 : f0;
+      }
       if (rr > last)
         return;
       if (n == kD2LanePx) {
@@ -1159,9 +1293,7 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2_t(const UdArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const u32 edge = k < 2 ? rows.v[k].x << 24 : rows.v[k].x << 16;
-          const u32 f0 = (u32)__builtin_amdgcn_readlane((int)rows.before, k);
-          const u32 f1 = (u32)__builtin_amdgcn_readlane((int)rows.before, 32 + k);
-          const u32 first = xw == 0 ? edge : (half ? f1 : f0);
+          const u32 first = xw == 0 ? edge : before[k];
           const u32 sh1 = wave_shr1(rows.v[k].w);
           prev[k] = li == 0 ? first : sh1;
         }
@@ -1273,6 +1405,17 @@ static int launch_ud(UdArgs& a, int src_fmt, int src_w, int dst_w, int dst_h, in
   // exact 2x horizontal downscale of NV12: the division-free, LDS-free kernel (VALI_UD_DOWN2=0
   // keeps the general one, for A/B measurements)
   static const bool down2_on = [] { const char* e = getenv("VALI_UD_DOWN2"); return !(e && e[0] == '0'); }();
+  if (down2_on && !force_gather && src_fmt == VALI_FMT_NV12 && src_w == dst_w && !(rot & 1) && kind != UD_RGB_F32 &&
+      kind != UD_RGB_F32_PLANAR) { // 1:1 width: colour conversion with chroma interpolation
+    a.map = make_tile_map((dst_w + kD2WaveW - 1) / kD2WaveW, (dst_h + kUdTileH - 1) / kUdTileH, (u32)n);
+    const dim3 g1 = tile_grid(a.map);
+    if (rot == 2) hipLaunchKernelGGL((k_ud_down2<UD_RGB_U8, 2, 1>), g1, block, 0, stream, a);
+    else if (kind == UD_YUV444) hipLaunchKernelGGL((k_ud_down2<UD_YUV444, 0, 1>), g1, block, 0, stream, a);
+    else if (kind == UD_RGB_U8) hipLaunchKernelGGL((k_ud_down2<UD_RGB_U8, 0, 1>), g1, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_ud_down2<UD_RGB_U8_PLANAR, 0, 1>), g1, block, 0, stream, a);
+    VALI_LAUNCH_CHECK();
+    return VALI_OK;
+  }
   if (down2_on && !force_gather && src_fmt == VALI_FMT_NV12 && src_w == 2 * dst_w && !(rot & 1) && kind != UD_RGB_F32 &&
       kind != UD_RGB_F32_PLANAR) { // (float outputs are store-bound: 4 pixels per lane fill their stores better)
     a.map = make_tile_map((dst_w + kD2WaveW - 1) / kD2WaveW, (dst_h + kUdTileH - 1) / kUdTileH, (u32)n);
