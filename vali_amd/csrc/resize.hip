@@ -289,9 +289,21 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
       const Lerp ly = row_lerp(rr);
       if (n > 0) {
         const uint8_t* rows[2] = {sp + (size_t)ly.i0 * spitch, sp + (size_t)ly.i1 * spitch};
-        sample_and_store(ly, y, [&](int r, int p, int t, int ch) {
-          return (float)gload<T>(rows[r] + (size_t)(t ? lx[p].i1 : lx[p].i0) * PB + ch * sizeof(T));
-        });
+        if (PairLoad<T, C>::kMerged && sw >= 3) { // both horizontal taps of a row from one unaligned load
+          if constexpr (PairLoad<T, C>::kMerged) {
+            float pre[2][4][2][C];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+              for (int p = 0; p < 4; ++p)
+                load_tap_pair<T, C>(rows[r], lx[p].i0, sw, pre[r][p][0], pre[r][p][1]);
+            sample_and_store(ly, y, [&](int r, int p, int t, int ch) { return pre[r][p][t][ch]; });
+          }
+        } else {
+          sample_and_store(ly, y, [&](int r, int p, int t, int ch) {
+            return (float)gload<T>(rows[r] + (size_t)(t ? lx[p].i1 : lx[p].i0) * PB + ch * sizeof(T));
+          });
+        }
       }
     }
   }

@@ -55,43 +55,6 @@ __device__ __forceinline__ bool rot_tile(const RotArgs& a, RotJob& job, u32& tx,
   return plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame);
 }
 
-// The two horizontal taps of a bilinear sample are neighbours (i and min(i + 1, sw - 1)), so a
-// row's pair comes from ONE unaligned load instead of 2 C byte loads: u8 x 1 -> 2 bytes, u8 x 3 ->
-// 8 bytes (the 6 of two packed pixels), u16 x 1 -> 4 bytes.  The texture addresser takes ~16
-// cycles per wave instruction whatever its width (profiles/r01_ud_down2.md), and packed RGB paid
-// it 12 times per pixel.  At the last column (i = sw - 1, only when the coordinate is exactly on
-// it) the window starts one pixel earlier and both taps take its second pixel; the 8-byte window
-// of packed RGB also slides left at the end of the row and is shifted back in registers.
-// Needs sw >= 3 (checked by the caller); float and the other layouts keep the element loads.
-template <typename T, int C> struct PairLoad {
-  static constexpr bool kMerged = (sizeof(T) == 1 && (C == 1 || C == 3)) || (sizeof(T) == 2 && C == 1);
-};
-template <typename T, int C>
-__device__ __forceinline__ void load_tap_pair(const uint8_t* row, int i, int sw, float (&t0)[C], float (&t1)[C]) {
-  typedef uint16_t u16_unaligned __attribute__((aligned(1)));
-  typedef u32 u32_unaligned __attribute__((aligned(1)));
-  typedef unsigned long long u64_unaligned __attribute__((aligned(1)));
-  const int base = min(i, sw - 2);
-  const bool edge = i != base;
-  if constexpr (sizeof(T) == 1 && C == 1) {
-    const u32 w = *(const VALI_GLOBAL u16_unaligned*)(row + base);
-    t1[0] = (float)(w >> 8);
-    t0[0] = edge ? t1[0] : (float)(w & 0xffu);
-  } else if constexpr (sizeof(T) == 2 && C == 1) {
-    const u32 w = *(const VALI_GLOBAL u32_unaligned*)(row + 2 * base);
-    t1[0] = (float)(w >> 16);
-    t0[0] = edge ? t1[0] : (float)(w & 0xffffu);
-  } else {
-    const int want = 3 * base, start = min(want, 3 * sw - 8);
-    const unsigned long long q = *(const VALI_GLOBAL u64_unaligned*)(row + start) >> (8 * (want - start));
-    const u32 lo = (u32)q, hi = (u32)(q >> 32);
-    t1[0] = ubyte_f32<3>(lo); t1[1] = ubyte_f32<0>(hi); t1[2] = ubyte_f32<1>(hi);
-    t0[0] = edge ? t1[0] : ubyte_f32<0>(lo);
-    t0[1] = edge ? t1[1] : ubyte_f32<1>(lo);
-    t0[2] = edge ? t1[2] : ubyte_f32<2>(lo);
-  }
-}
-
 constexpr int kAffineTile = 32;
 template <typename T, int C>
 __device__ __forceinline__ void affine_tile(const RotArgs& a, const RotJob& job, const uint8_t* sp,
