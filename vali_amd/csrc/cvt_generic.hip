@@ -48,6 +48,7 @@ struct CvtArgs {
   vali_surface src, dst;
   vali_cvt_params p;
   TileMap map;
+  int rp; // row pairs stacked in one workgroup (narrow frames, as in cvt_nv12_rgb.hip)
 };
 
 // ---- per-pixel arithmetic ---------------------------------------------------------------
@@ -402,15 +403,17 @@ __global__ void __launch_bounds__(kBlock) k_cvt8(const CvtArgs a) {
   const int W = s.width, H = s.height;
   Geo q;
   q.lane = threadIdx.x & (kWave - 1);
-  q.wave = threadIdx.x / kWave;
-  q.wave_g0 = tile_x * blockDim.x + q.wave * kWave;
+  q.wave = threadIdx.x / kWave;                               // (also the LDS strip index)
+  const int wpr = (int)(blockDim.x / kWave) / a.rp;           // waves side by side on one row pair
+  q.wave_g0 = (tile_x * wpr + q.wave % wpr) * kWave;
   q.groups = (W + kLanePx - 1) / kLanePx;
-  if (q.wave_g0 >= q.groups)
+  const int crow = tile_y * a.rp + q.wave / wpr;              // row pair of this wave
+  if (q.wave_g0 >= q.groups || crow * 2 >= H)
     return;
   q.g = q.wave_g0 + q.lane;
   q.x0 = q.g * kLanePx;
-  q.row0 = tile_y * 2;
-  q.tile_y = tile_y;
+  q.row0 = crow * 2;
+  q.tile_y = crow;
   q.has_row1 = q.row0 + 1 < H;
   q.lane_valid = q.g < q.groups;
   q.valid_lanes = min(kWave, q.groups - q.wave_g0);
@@ -432,7 +435,7 @@ __global__ void __launch_bounds__(kBlock) k_cvt8(const CvtArgs a) {
     return;
 #pragma unroll 1 // the byte-granular path must not set the kernel's register budget
   for (int k = 0; k < 8; ++k)
-    quad_slow<SRC, DST>(s, d, q.x0 / 2 + k, tile_y, a.p);
+    quad_slow<SRC, DST>(s, d, q.x0 / 2 + k, crow, a.p);
 }
 
 // ---- element-type kernels ------------------------------------------------------------------
@@ -659,7 +662,14 @@ static int launch_convert(CvtArgs& a, ElemArgs& e, int src_fmt, int dst_fmt, int
   int block = ((groups + kWave - 1) / kWave) * kWave;
   if (block > kBlock)
     block = kBlock;
-  a.map = make_tile_map((groups + block - 1) / block, (height + 1) / 2, (u32)n);
+  // narrow frames stack row pairs into a 256-thread workgroup (profiles/r01_variants.md sweep 8)
+  static const int rp_env = [] { const char* e = getenv("VALI_NV12_ROWPAIRS"); return e ? atoi(e) : 0; }();
+  const int row_block = block;
+  a.rp = rp_env > 0 ? rp_env : kBlock / row_block;
+  if (a.rp < 1 || row_block * a.rp > kBlock)
+    a.rp = 1;
+  a.map = make_tile_map((groups + row_block - 1) / row_block, ((height + 1) / 2 + a.rp - 1) / a.rp, (u32)n);
+  block = row_block * a.rp;
   const dim3 grid = tile_grid(a.map);
   // residency cap: 16 waves/CU measured best for plane -> packed streams (profiles/r01_variants.md);
   // VALI_WAVES_PER_CU is a tuning knob for A/B runs only
@@ -670,7 +680,7 @@ static int launch_convert(CvtArgs& a, ElemArgs& e, int src_fmt, int dst_fmt, int
     const char* e = getenv("VALI_WAVES_PER_CU");
     return e ? atoi(e) : 0;
   }();
-  const int waves_per_cu = waves_override > 0 ? waves_override : streaming_waves_per_cu(groups, block, k_ispacked(sk) ? 24 : 16);
+  const int waves_per_cu = waves_override > 0 ? waves_override : streaming_waves_per_cu(groups, row_block, k_ispacked(sk) ? 24 : 16);
   const unsigned lds = residency_lds_bytes(block, waves_per_cu, (unsigned)sizeof(PackedStrip) * kWavesPerBlock);
 #define VALI_PAIR(S, D)                                                                     \
   if (sk == S && dk == D) {                                                                 \
