@@ -10,8 +10,9 @@ region.  One process per GPU; frames are sharded, never exchanged: the only
 collective is the RCCL broadcast of the 32-byte colour-coefficient block.
 
   python bench.py                      # 1 GPU
+  python bench.py --gpus N             # spawns N ranks itself (one per GPU, RCCL), rank 0 prints the line
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-      --master-port P bench.py --gpus N --steps K --warmup W
+      --master-port P bench.py --gpus N --steps K --warmup W     # the same under torchrun
 
 Prints ONE JSON line on rank 0 (contract in the task brief): value = whole-job frames/s,
 `roofline` = algorithmic bytes / HIP-event kernel time vs the 8 TB/s HBM peak,
@@ -138,8 +139,50 @@ def measured_traffic(bytes_per_frame, frames, dst, W, H):
     return None, None
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N copies of this command, one rank per
+    GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the env exactly as torchrun would set them),
+    wait for all of them and return the worst exit code.  Rank 0 inherits stdout, so the ONE JSON
+    line is its line; the other ranks' stdout goes to stderr."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:       # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VALI_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        pending = dict(enumerate(procs))
+        while pending:
+            for r, p in list(pending.items()):
+                code = p.poll()
+                if code is None:
+                    continue
+                del pending[r]
+                if code != 0:
+                    rc = rc or code
+                    for q in pending.values():     # one rank failed: the others would wait in a
+                        q.terminate()              # collective forever (exact PIDs we started)
+            time.sleep(0.05)
+    except BaseException:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        raise
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -169,6 +212,9 @@ def main():
     coll_dev = f"cuda:{dev}" if backend == "nccl" else "cpu"
     # VALI_BENCH_FORCE_DIST=1: initialise the process group even for one rank, so the RCCL code
     # path (init, broadcast, all-reduce, barrier) can be exercised on a single-GPU box
+    if backend == "nccl" and world > ngpu:
+        raise SystemExit(f"bench.py: {world} ranks but only {ngpu} GPU(s) visible -- RCCL needs one GPU per rank "
+                         "(VALI_BENCH_BACKEND=gloo lets several ranks share a GPU for functional tests)")
     if world > 1 or os.environ.get("VALI_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
 
@@ -230,10 +276,22 @@ def main():
         shim.event_destroy(dev, a)
         shim.event_destroy(dev, b)
 
+    per_rank_kernel_ms, ranks_seen = [float(np.mean(kernel_ms))], 1
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank's own average kernel time (+ its device index), gathered for the report
+        mine = torch.tensor([float(np.mean(kernel_ms)), float(dev)], dtype=torch.float64, device=coll_dev)
+        got = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        per_rank_kernel_ms = [round(float(g[0]), 4) for g in got]
+        rank_devices = [int(g[1]) for g in got]
+        one = torch.ones(1, dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)      # ranks that really took part in the collective
+        ranks_seen = int(one.item())
+    else:
+        rank_devices = [dev]
 
     # Full-size verification on the GPU (every rank, all F frames): frame i was filled from seed
     # frame i % nseed, so its output must equal output i % nseed byte for byte; the seed outputs
@@ -286,6 +344,10 @@ def main():
                        "frames_per_gpu": F, "global_batch": F * world,
                        "bytes_per_frame": bytes_per_frame,
                        "parallelism": f"frame-sharded x{world}, RCCL broadcast of coefficients"},
+            "ranks_seen": ranks_seen, "collective_backend": (backend if dist is not None else None),
+            "launcher": ("self-spawned" if os.environ.get("VALI_BENCH_SPAWNED") == "1"
+                         else "torchrun/env" if "WORLD_SIZE" in os.environ else "single process"),
+            "per_rank_kernel_ms": per_rank_kernel_ms, "rank_devices": rank_devices,
             "achieved_hbm_GBps_whole_job": round(bytes_per_frame * fps / 1e9, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),

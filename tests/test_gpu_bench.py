@@ -29,6 +29,7 @@ def test_bench_single_gpu_contract(gpu):
     for k in REQUIRED:
         assert k in j, k
     assert j["n_gpus"] == 1 and j["steps"] == 3 and j["unit"] == "frames/s" and j["dtype"] == "u8"
+    assert j["ranks_seen"] == 1 and j["launcher"] == "single process"
     assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1
     assert j["parity_vs_oracle"]["max_abs_diff_lsb"] == 0
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] >= 1
@@ -50,6 +51,30 @@ def test_bench_two_ranks_share_one_gpu(gpu):
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 32 and j["scaling"] == "weak"
     assert "cpu_baseline" not in j and j["value"] > 0
     assert j["verification"]["frames_verified_on_gpu"] == 32 and j["verification"]["frames_mismatching"] == 0
+
+
+def test_bench_gpus_flag_spawns_the_ranks_itself(gpu):
+    """`python bench.py --gpus 2` with no launcher (the form the driver uses): bench.py starts the two
+    ranks itself; on this one-GPU box they share the device and the collectives run over gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["VALI_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--frames", "16"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    j = last_json(r.stdout)
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["launcher"] == "self-spawned"
+    assert len(j["per_rank_kernel_ms"]) == 2 and all(v > 0 for v in j["per_rank_kernel_ms"])
+    assert j["config"]["global_batch"] == 32 and j["verification"]["frames_verified_on_gpu"] == 32
+    assert j["verification"]["frames_mismatching"] == 0 and "cpu_baseline" not in j
+
+
+def test_bench_gpus_flag_refuses_more_rccl_ranks_than_gpus(gpu, vali):
+    if vali.GetNumGpus() >= 2:
+        pytest.skip("box has several GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "VALI_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--frames", "2"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and "one GPU per rank" in r.stderr
 
 
 def test_bench_rccl_path_single_rank(gpu):
