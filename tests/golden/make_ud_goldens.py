@@ -31,6 +31,12 @@ p10 = {
     "rgb_32f_planar": load("P10_PixelFormat.RGB_32F_PLANAR", np.float32).reshape(3, H, W)[:, :ROWS],
     "yuv444_10bit": load("P10_PixelFormat.YUV444_10bit", np.uint16).reshape(3, H, W)[:, :ROWS],
 }
+# UDPlanar golden (reference tests/test_PySurfaceUD.py on the CPU-decoded YUV420 frame: every plane through
+# nppiResize NPPI_INTER_LANCZOS, UDSurface.cpp:33-93): the only fixture that holds NPP Lanczos output at a
+# NON-integer ratio (848x464 -> 640x360 luma, 424x232 -> 640x360 chroma).  tests/test_oracle_lanczos_pin.py
+planar = {"yuv444": load("YUV420_PixelFormat.YUV444", np.uint8).reshape(3, H, W)[:, :ROWS]}
+np.savez_compressed(OUT / "ud_640x360_yuv420_rows120.npz", **planar)
+print("ud_640x360_yuv420_rows120.npz", (OUT / "ud_640x360_yuv420_rows120.npz").stat().st_size)
 # whole-file identities, checked here once on the full files (recorded in DESIGN.md)
 full_rgb = load("NV12_PixelFormat.RGB", np.uint8)
 full_f = load("NV12_PixelFormat.RGB_32F", np.float32)
