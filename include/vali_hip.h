@@ -316,6 +316,41 @@ VALI_API int vali_rotate_batch(const vali_surface* d_src, const vali_surface* d_
 /* cos/sin of the angle as the kernels use them (exact 0/+-1 for multiples of 90 degrees) */
 VALI_API int vali_rotate_coeffs(double angle_deg, float* c, float* s);
 
+/* ---- tuning switches and tracing -------------------------------------------------------------
+ *
+ * Every alternative kernel form the library keeps for A/B measurements and for path-coverage tests is
+ * selected through this ONE table (no getenv anywhere else in the library).  A switch never changes a
+ * result -- every form is bit-identical (tests/test_gpu_tuning.py runs each operator under every value) --
+ * only which kernel produces it.  Values are process-wide and may be changed at any time between calls.
+ * Initial values: the default below, or the environment variable of the same name (VALI_<KEY>) read once,
+ * when the library is first used.
+ */
+enum vali_tuning_key {
+  VALI_TUNE_NV12_ROWPAIRS = 0,        /* row pairs stacked in one workgroup of the streaming converters; 0 = auto */
+  VALI_TUNE_WAVES_PER_CU = 1,         /* residency cap of the streaming converters; 0 = auto                      */
+  VALI_TUNE_NV12_DIRECT_STORE = 2,    /* 1: NV12->RGB stores 48 B per lane instead of going through the LDS strip */
+  VALI_TUNE_RESIZE_FORCE_GATHER = 3,  /* 1: every resize geometry through the direct-gather form                  */
+  VALI_TUNE_RESIZE_POINT = 4,         /* 0: keep the arithmetic form at integer scale factors (default 1)         */
+  VALI_TUNE_UD_FORCE_GATHER = 5,      /* 1: every UD geometry through the direct-gather form, no exact-ratio kernels */
+  VALI_TUNE_UD_DOWN2 = 6,             /* 0: general UD kernel also at the exact 2:1 / 1:1 width ratios (default 1) */
+  VALI_TUNE_UD_OCC5 = 7,              /* 0: default-occupancy instantiation of the staged UD kernel (default 1)    */
+  VALI_TUNE_ROTATE_NO_TILE = 8,       /* 1: quarter / half turns through the bilinear kernel                       */
+  VALI_TUNE_ROCTX = 9,                /* 1: a roctx range around every operator entry point (see below)            */
+  VALI_TUNE_RESIZE_NO_SEPARABLE = 10, /* 1: Lanczos / bicubic through the sliding-window kernel only               */
+  VALI_TUNE_COUNT = 11
+};
+VALI_API int vali_tuning_set(int key, int value);
+VALI_API int vali_tuning_get(int key, int* value);
+
+/*
+ * Tracing: with VALI_TUNE_ROCTX = 1 (or VALI_ROCTX=1 in the environment) every operator entry point of this
+ * header pushes a roctx range named after itself for the duration of the call -- the equivalent of the
+ * reference's NvtxMark around every converter / resizer (src/TC/inc/Tasks.hpp:32-59, e.g.
+ * TaskConvertSurface.cpp:112).  `rocprofv3 --marker-trace --kernel-trace` then shows which launch belongs to
+ * which call.  The roctx library (librocprofiler-sdk-roctx / libroctx64) is dlopen'ed on first use; if it is
+ * absent tracing stays off and vali_tuning_set(VALI_TUNE_ROCTX, 1) returns VALI_ERR_UNSUPPORTED.
+ */
+
 /* ---- diagnostics (used by tests only) --------------------------------------- */
 
 /* out[i] = float->u8 quantiser of the colour kernels applied to in[i]. */

@@ -49,3 +49,27 @@ def test_shim_struct_size_matches_header():
 
     # 3 pointers + 3 pitches + width + height + format, padded to 8
     assert shim.SURFACE_DESC_SIZE == 48
+
+
+def test_tuning_table_round_trip_without_a_gpu():
+    """vali_tuning_set / vali_tuning_get work without a device; unknown keys are refused; defaults as documented."""
+    from vali_amd._native import shim
+
+    assert shim.TUNE_COUNT == 11
+    defaults = {shim.TUNE_RESIZE_POINT: 1, shim.TUNE_UD_DOWN2: 1, shim.TUNE_UD_OCC5: 1}
+    import os
+    if not any(k.startswith("VALI_") and k not in ("VALI_BENCH_BACKEND", "VALI_NO_TORCH") for k in os.environ):
+        for k in range(shim.TUNE_COUNT):
+            assert shim.tuning_get(k) == defaults.get(k, 0), k
+    old = shim.tuning_get(shim.TUNE_WAVES_PER_CU)
+    assert shim.tuning_set(shim.TUNE_WAVES_PER_CU, 24) == 0 and shim.tuning_get(shim.TUNE_WAVES_PER_CU) == 24
+    assert shim.tuning_set(shim.TUNE_WAVES_PER_CU, old) == 0
+    assert shim.tuning_set(shim.TUNE_COUNT, 1) == shim.ERR_INVALID_ARG
+    assert shim.tuning_set(-1, 1) == shim.ERR_INVALID_ARG
+    import vali_amd
+    with vali_amd.tuning.Override(UD_DOWN2=0):
+        assert vali_amd.tuning.Get("ud_down2") == 0
+    assert vali_amd.tuning.Get("UD_DOWN2") == 1
+    import pytest
+    with pytest.raises(KeyError):
+        vali_amd.tuning.Get("NO_SUCH_SWITCH")

@@ -1,0 +1,104 @@
+"""The tuning table (include/vali_hip.h: vali_tuning_key) cannot change results: every operator is run
+in-process under every value of the switches that select its kernel form and must reproduce the default
+output byte for byte.  Also: tracing on (a roctx range per entry point) leaves results alone."""
+import numpy as np
+import pytest
+
+from conftest import make_nv12
+
+pytestmark = pytest.mark.gpu
+
+
+def upload(vali, gpu, fmt, w, h, host):
+    s = vali.Surface.Make(fmt, w, h, gpu)
+    assert vali.PyFrameUploader(gpu).Run(np.ascontiguousarray(host).reshape(-1), s)[0]
+    return s
+
+
+def download(vali, gpu, surf):
+    out = np.zeros(surf.HostSize, np.uint8)
+    assert vali.PySurfaceDownloader(gpu).Run(surf, out)[0]
+    return out
+
+
+def nv12_rgb(vali, gpu, w, h, dst):
+    src = upload(vali, gpu, vali.NV12, w, h, make_nv12(w, h, 1))
+    d = vali.Surface.Make(dst, w, h, gpu)
+    cc = vali.ColorspaceConversionContext(vali.ColorSpace.BT_709, vali.ColorRange.MPEG)
+    assert vali.PySurfaceConverter(gpu).Run(src, d, cc)[0]
+    return download(vali, gpu, d)
+
+
+def resize(vali, gpu, sw, sh, dw, dh, interp):
+    src = upload(vali, gpu, vali.NV12, sw, sh, make_nv12(sw, sh, 2))
+    d = vali.Surface.Make(vali.NV12, dw, dh, gpu)
+    assert vali.PySurfaceResizer(vali.NV12, gpu, interpolation=interp).Run(src, d)[0]
+    return download(vali, gpu, d)
+
+
+def ud(vali, gpu, sw, sh, dw, dh, dst):
+    src = upload(vali, gpu, vali.NV12, sw, sh, make_nv12(sw, sh, 3))
+    d = vali.Surface.Make(dst, dw, dh, gpu)
+    assert vali.PySurfaceUD(gpu).Run(src, d)[0]
+    return download(vali, gpu, d)
+
+
+def rotate(vali, gpu, w, h, angle):
+    rng = np.random.default_rng(4)
+    src = upload(vali, gpu, vali.RGB, w, h, rng.integers(0, 256, w * h * 3, dtype=np.uint8))
+    q = int(angle) % 180 != 0
+    d = vali.Surface.Make(vali.RGB, h if q else w, w if q else h, gpu)
+    assert vali.PySurfaceRotator(gpu).Run(src, d, angle)[0]
+    return download(vali, gpu, d)
+
+
+CASES = [
+    ("NV12_ROWPAIRS", (1, 2, 4), lambda v, g: nv12_rgb(v, g, 640, 360, v.RGB)),
+    ("NV12_ROWPAIRS", (1, 2), lambda v, g: nv12_rgb(v, g, 1920, 1080, v.RGB_PLANAR)),
+    ("WAVES_PER_CU", (4, 8, 24, 32), lambda v, g: nv12_rgb(v, g, 1920, 1080, v.RGB)),
+    ("NV12_DIRECT_STORE", (1,), lambda v, g: nv12_rgb(v, g, 1920, 1080, v.BGR)),
+    ("NV12_DIRECT_STORE", (1,), lambda v, g: nv12_rgb(v, g, 854, 480, v.RGB)),
+    ("RESIZE_POINT", (0,), lambda v, g: resize(v, g, 1920, 1080, 640, 360, v.Interpolation.LINEAR)),
+    ("RESIZE_POINT", (0,), lambda v, g: resize(v, g, 1920, 1080, 960, 540, v.Interpolation.LANCZOS)),
+    ("RESIZE_FORCE_GATHER", (1,), lambda v, g: resize(v, g, 1280, 720, 854, 480, v.Interpolation.LINEAR)),
+    ("RESIZE_FORCE_GATHER", (1,), lambda v, g: resize(v, g, 1280, 720, 854, 480, v.Interpolation.LANCZOS)),
+    ("RESIZE_FORCE_GATHER", (1,), lambda v, g: resize(v, g, 640, 360, 1280, 720, v.Interpolation.CUBIC)),
+    ("RESIZE_NO_SEPARABLE", (1,), lambda v, g: resize(v, g, 1280, 720, 854, 480, v.Interpolation.LANCZOS)),
+    ("RESIZE_NO_SEPARABLE", (1,), lambda v, g: resize(v, g, 640, 360, 1280, 720, v.Interpolation.CUBIC)),
+    ("UD_DOWN2", (0,), lambda v, g: ud(v, g, 1280, 720, 640, 360, v.RGB)),
+    ("UD_DOWN2", (0,), lambda v, g: ud(v, g, 1280, 720, 1280, 720, v.RGB_PLANAR)),
+    ("UD_OCC5", (0,), lambda v, g: ud(v, g, 1280, 720, 854, 480, v.RGB)),
+    ("UD_FORCE_GATHER", (1,), lambda v, g: ud(v, g, 1280, 720, 854, 480, v.RGB)),
+    ("UD_FORCE_GATHER", (1,), lambda v, g: ud(v, g, 1280, 720, 640, 360, v.YUV444)),
+    ("ROTATE_NO_TILE", (1,), lambda v, g: rotate(v, g, 640, 360, 90.0)),
+    ("ROTATE_NO_TILE", (1,), lambda v, g: rotate(v, g, 640, 360, 180.0)),
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)), ids=lambda i: f"{CASES[i][0]}-{i}")
+def test_switch_cannot_change_the_result(vali, gpu, case):
+    name, values, fn = CASES[case]
+    default = vali.tuning.Get(name)
+    want = fn(vali, gpu)
+    for v in values:
+        with vali.tuning.Override(**{name: v}):
+            assert vali.tuning.Get(name) == v
+            got = fn(vali, gpu)
+        assert np.array_equal(got, want), (name, v)
+    assert vali.tuning.Get(name) == default
+
+
+def test_tracing_on_leaves_results_alone(vali, gpu):
+    want = nv12_rgb(vali, gpu, 640, 360, vali.RGB)
+    with vali.tuning.Override(ROCTX=1):
+        assert vali.tuning.Get("ROCTX") == 1
+        assert np.array_equal(nv12_rgb(vali, gpu, 640, 360, vali.RGB), want)
+        assert np.array_equal(ud(vali, gpu, 640, 360, 320, 180, vali.RGB), ud(vali, gpu, 640, 360, 320, 180, vali.RGB))
+    assert vali.tuning.Get("ROCTX") == 0
+
+
+def test_null_stream_means_the_gpus_own_stream(vali, gpu):
+    """PySurfaceConverter(gpu_id, stream=0): a null stream carries no device, the task uses the resource
+    manager's stream of ITS gpu_id instead."""
+    cvt = vali.PySurfaceConverter(gpu, 0)
+    assert cvt.Stream != 0 and cvt.Stream == vali.HipResMgr.Instance().GetStream(gpu)

@@ -21,6 +21,7 @@ if not _BUILDING:
                         SurfaceBatch)
     from .pipeline import BatchedFramePipeline, broadcast_coefficients, shard_frames
     from .transfer import PyFrameUploader, PySurfaceDownloader
+    from . import tuning
 
     export_values(globals())
 

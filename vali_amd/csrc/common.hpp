@@ -48,6 +48,20 @@ inline int streaming_waves_per_cu(int groups, int block, int full_lane_waves) {
   return util_pct >= 90 ? full_lane_waves : util_pct >= 70 ? full_lane_waves * 3 / 2 : full_lane_waves * 7 / 4;
 }
 
+// Current value of a vali_tuning_key (include/vali_hip.h): one relaxed atomic load.
+int tuning(int key);
+
+// roctx range for the lifetime of the object when VALI_TUNE_ROCTX is on (the reference's NvtxMark,
+// src/TC/inc/Tasks.hpp:32-59); otherwise one relaxed load.
+class TraceRange {
+public:
+  explicit TraceRange(const char* name);
+  ~TraceRange();
+
+private:
+  bool m_pushed = false;
+};
+
 inline hipStream_t as_stream(vali_stream_t s) { return (hipStream_t)s; }
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
@@ -63,6 +77,18 @@ inline bool planes_fit_32bit(const vali_surface& s) {
 }
 
 } // namespace vali
+
+// First lines of every operator entry point: trace range, then the device of the stream (the current device
+// for the null stream) is made current for the call.  No usable device -> VALI_ERR_NO_DEVICE, never a silent
+// launch on whatever happens to be current.
+#define VALI_ENTRY(stream)                                                                   \
+  ::vali::TraceRange _trace(__func__);                                                        \
+  const int _dev = ::vali::stream_device(stream);                                             \
+  if (_dev < 0)                                                                               \
+    return ::vali::fail(VALI_ERR_NO_DEVICE, "%s: no usable HIP device", __func__);            \
+  ::vali::DeviceScope scope(_dev);                                                            \
+  if (!scope.ok())                                                                            \
+    return ::vali::fail(VALI_ERR_NO_DEVICE, "%s: cannot select device %d", __func__, _dev)
 
 #define VALI_HIP_CHECK(expr)                                                   \
   do {                                                                         \

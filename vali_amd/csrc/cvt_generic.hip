@@ -31,8 +31,6 @@
 #include "common.hpp"
 #include "dev_util.hpp"
 
-#include <stdlib.h>
-
 namespace vali {
 
 enum : int { K_NV12 = 0, K_YUV420 = 1, K_YUV444 = 2, K_RGB = 3, K_BGR = 4, K_RGBP = 5, K_Y = 6, K_NONE = -1 };
@@ -104,22 +102,80 @@ struct Geo {
   int lane, wave, wave_g0, g, x0, row0, groups, valid_lanes;
   bool lane_valid, has_row1;
   u32 tile_y;
+  // ragged path (any width / alignment): the group the right edge cuts slides left to END with the row (16 whole
+  // pixels again; the overlap with its neighbour is computed and stored twice with identical bytes)
+  int xs;          // first pixel of the lane's window: x0, or W - 16 for the cut group
+  bool cut;        // this lane holds the cut group: off the strip's 48-byte lane grid, packed pixels go direct
+  int n_px;        // 16; fewer only for frames narrower than one group (uniform)
+  int full_lanes;  // whole groups of this wave = lanes that use the strip
 };
 
-template <int SRC>
+// ANY = the ragged path (any width, base pointer and pitch): the misaligned forms of the same accesses
+// (dev_util.hpp load16_n, strip_fetch_u, ...); !ANY = full 16-pixel groups on 16-byte aligned rows.
+template <bool ANY> __device__ __forceinline__ uint4 ld16(const uint8_t* p, int n) {
+  if constexpr (ANY) return load16_n(p, n);
+  else return load16(p);
+}
+template <bool ANY> __device__ __forceinline__ void st16(uint8_t* p, uint4 v, int n) {
+  if constexpr (ANY) store16_n(p, v, n);
+  else store16_nt(p, v);
+}
+typedef v2u32 v2u32_u __attribute__((aligned(1)));
+template <bool ANY> __device__ __forceinline__ uint2 ld8(const uint8_t* p, int n) {
+  if constexpr (ANY) {
+    if (n >= 8) {
+      const v2u32 w = *(const v2u32_u*)p;
+      return make_uint2(w.x, w.y);
+    }
+    const uint4 v = load_bytes16(p, n);
+    return make_uint2(v.x, v.y);
+  } else {
+    return *reinterpret_cast<const uint2*>(p);
+  }
+}
+template <bool ANY> __device__ __forceinline__ void st8(uint8_t* p, uint2 v, int n) {
+  if constexpr (ANY) {
+    if (n >= 8) {
+      const v2u32 w = {v.x, v.y};
+      *(v2u32_u*)p = w;
+    } else {
+      store_bytes16(p, make_uint4(v.x, v.y, 0u, 0u), n);
+    }
+  } else {
+    *reinterpret_cast<uint2*>(p) = v;
+  }
+}
+
+template <int SRC, bool ANY>
 __device__ __forceinline__ void load_block(Block& b, const SurfRef& s, const Geo& q, PackedStrip& strip) {
   const int r1 = q.row0 + (q.has_row1 ? 1 : 0);
   if constexpr (k_ispacked(SRC)) {
     const uint8_t* rb = s.p[0] + (size_t)q.row0 * s.pitch[0] + (size_t)q.wave_g0 * 48;
-    const int vb = q.valid_lanes * 48;
+    const int vb = ANY ? q.full_lanes * 48 : q.valid_lanes * 48;
     // both rows' global loads are issued before either row goes through the strip
     StripRegs regs[2];
-    strip_fetch(regs[0], q.lane, rb, vb);
-    strip_fetch(regs[1], q.lane, s.p[0] + (size_t)r1 * s.pitch[0] + (size_t)q.wave_g0 * 48, vb);
+    u32 oc[2][12];      // ragged path: the cut group's own 48 bytes per row
+    if constexpr (ANY) {
+      strip_fetch_u(regs[0], q.lane, rb, vb);
+      strip_fetch_u(regs[1], q.lane, s.p[0] + (size_t)r1 * s.pitch[0] + (size_t)q.wave_g0 * 48, vb);
+      if (q.cut) {
+        packed_group_load(s.p[0] + (size_t)q.row0 * s.pitch[0] + (size_t)q.xs * 3, q.n_px, oc[0]);
+        packed_group_load(s.p[0] + (size_t)r1 * s.pitch[0] + (size_t)q.xs * 3, q.n_px, oc[1]);
+      }
+    } else {
+      strip_fetch(regs[0], q.lane, rb, vb);
+      strip_fetch(regs[1], q.lane, s.p[0] + (size_t)r1 * s.pitch[0] + (size_t)q.wave_g0 * 48, vb);
+    }
     u32 o[12];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      strip_unpack(strip, q.lane, regs[r], o, q.lane_valid);
+      strip_unpack(strip, q.lane, regs[r], o, q.lane_valid && !(ANY && q.cut));
+      if constexpr (ANY) {
+        if (q.cut) {
+#pragma unroll
+          for (int i = 0; i < 12; ++i) o[i] = oc[r][i];
+        }
+      }
       if (q.lane_valid) {
         if constexpr (SRC == K_RGB) deinterleave3(o, b.c0[r], b.c1[r], b.c2[r]);
         else deinterleave3(o, b.c2[r], b.c1[r], b.c0[r]);
@@ -130,7 +186,7 @@ __device__ __forceinline__ void load_block(Block& b, const SurfRef& s, const Geo
   if (!q.lane_valid)
     return;
   auto ld = [&](const uint8_t* plane, int pitch, int row, u32 (&dst)[4]) {
-    const uint4 v = load16(plane + (size_t)row * pitch + q.x0);
+    const uint4 v = ld16<ANY>(plane + (size_t)row * pitch + (ANY ? q.xs : q.x0), q.n_px);
     dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
   };
   ld(s.p[0], s.pitch[0], q.row0, b.c0[0]);
@@ -139,35 +195,41 @@ __device__ __forceinline__ void load_block(Block& b, const SurfRef& s, const Geo
     ld(s.p[1], s.pitch[1], q.row0, b.c1[0]); ld(s.p[1], s.pitch[1], r1, b.c1[1]);
     ld(s.p[2], s.pitch[2], q.row0, b.c2[0]); ld(s.p[2], s.pitch[2], r1, b.c2[1]);
   } else if constexpr (SRC == K_NV12) {
-    const uint4 uv = load16(s.p[1] + (size_t)q.tile_y * s.pitch[1] + q.x0);
+    const uint4 uv = ld16<ANY>(s.p[1] + (size_t)q.tile_y * s.pitch[1] + (ANY ? q.xs : q.x0), q.n_px);
     b.cu[0] = __builtin_amdgcn_perm(uv.y, uv.x, 0x06040200u); b.cv[0] = __builtin_amdgcn_perm(uv.y, uv.x, 0x07050301u);
     b.cu[1] = __builtin_amdgcn_perm(uv.w, uv.z, 0x06040200u); b.cv[1] = __builtin_amdgcn_perm(uv.w, uv.z, 0x07050301u);
   } else if constexpr (SRC == K_YUV420) {
-    const uint2 u = *reinterpret_cast<const uint2*>(s.p[1] + (size_t)q.tile_y * s.pitch[1] + q.x0 / 2);
-    const uint2 v = *reinterpret_cast<const uint2*>(s.p[2] + (size_t)q.tile_y * s.pitch[2] + q.x0 / 2);
+    const uint2 u = ld8<ANY>(s.p[1] + (size_t)q.tile_y * s.pitch[1] + (ANY ? q.xs : q.x0) / 2, q.n_px / 2);
+    const uint2 v = ld8<ANY>(s.p[2] + (size_t)q.tile_y * s.pitch[2] + (ANY ? q.xs : q.x0) / 2, q.n_px / 2);
     b.cu[0] = u.x; b.cu[1] = u.y; b.cv[0] = v.x; b.cv[1] = v.y;
   }
 }
 
-template <int DST>
+template <int DST, bool ANY>
 __device__ __forceinline__ void store_block(const Block& b, const SurfRef& d, const Geo& q, PackedStrip& strip) {
   if constexpr (k_ispacked(DST)) {
     uint8_t* rb = d.p[0] + (size_t)q.row0 * d.pitch[0] + (size_t)q.wave_g0 * 48;
-    const int vb = q.valid_lanes * 48;
+    const int vb = ANY ? q.full_lanes * 48 : q.valid_lanes * 48;
     u32 o[12];
     for (int r = 0; r < (q.has_row1 ? 2 : 1); ++r) {
       if (q.lane_valid) {
         if constexpr (DST == K_RGB) interleave3(b.c0[r], b.c1[r], b.c2[r], o);
         else interleave3(b.c2[r], b.c1[r], b.c0[r], o);
       }
-      strip_store_row(strip, q.lane, o, q.lane_valid, rb + (size_t)r * d.pitch[0], vb);
+      if constexpr (ANY) {
+        strip_store_row_u(strip, q.lane, o, q.lane_valid && !q.cut, rb + (size_t)r * d.pitch[0], vb);
+        if (q.cut)
+          packed_group_store(d.p[0] + (size_t)(q.row0 + r) * d.pitch[0] + (size_t)q.xs * 3, q.n_px, o);
+      } else {
+        strip_store_row(strip, q.lane, o, q.lane_valid, rb + (size_t)r * d.pitch[0], vb);
+      }
     }
     return;
   }
   if (!q.lane_valid)
     return;
   auto st = [&](uint8_t* plane, int pitch, int row, const u32 (&src)[4]) {
-    store16_nt(plane + (size_t)row * pitch + q.x0, make_uint4(src[0], src[1], src[2], src[3]));
+    st16<ANY>(plane + (size_t)row * pitch + (ANY ? q.xs : q.x0), make_uint4(src[0], src[1], src[2], src[3]), q.n_px);
   };
   st(d.p[0], d.pitch[0], q.row0, b.c0[0]);
   if (q.has_row1) st(d.p[0], d.pitch[0], q.row0 + 1, b.c0[1]);
@@ -177,10 +239,10 @@ __device__ __forceinline__ void store_block(const Block& b, const SurfRef& d, co
   } else if constexpr (DST == K_NV12) {
     const uint4 uv = make_uint4(__builtin_amdgcn_perm(b.cv[0], b.cu[0], 0x05010400u), __builtin_amdgcn_perm(b.cv[0], b.cu[0], 0x07030602u),
                                 __builtin_amdgcn_perm(b.cv[1], b.cu[1], 0x05010400u), __builtin_amdgcn_perm(b.cv[1], b.cu[1], 0x07030602u));
-    store16_nt(d.p[1] + (size_t)q.tile_y * d.pitch[1] + q.x0, uv);
+    st16<ANY>(d.p[1] + (size_t)q.tile_y * d.pitch[1] + (ANY ? q.xs : q.x0), uv, q.n_px);
   } else if constexpr (DST == K_YUV420) {
-    *reinterpret_cast<uint2*>(d.p[1] + (size_t)q.tile_y * d.pitch[1] + q.x0 / 2) = make_uint2(b.cu[0], b.cu[1]);
-    *reinterpret_cast<uint2*>(d.p[2] + (size_t)q.tile_y * d.pitch[2] + q.x0 / 2) = make_uint2(b.cv[0], b.cv[1]);
+    st8<ANY>(d.p[1] + (size_t)q.tile_y * d.pitch[1] + (ANY ? q.xs : q.x0) / 2, make_uint2(b.cu[0], b.cu[1]), q.n_px / 2);
+    st8<ANY>(d.p[2] + (size_t)q.tile_y * d.pitch[2] + (ANY ? q.xs : q.x0) / 2, make_uint2(b.cv[0], b.cv[1]), q.n_px / 2);
   }
 }
 
@@ -263,20 +325,36 @@ __device__ __forceinline__ void transform_block(Block& b, const vali_cvt_params&
 // load_block + transform_block keeps both unpacked rows and 32 chroma floats live (106 VGPRs,
 // 4 waves per SIMD); this order needs about half of that.  Same operations in the same
 // order: ((c00 + c01) + (c10 + c11)) * 0.25.
-template <int SRC, int DST>
+template <int SRC, int DST, bool ANY>
 __device__ __forceinline__ void load_transform_packed_420(Block& b, const SurfRef& s, const Geo& q,
                                                           PackedStrip& strip, const vali_cvt_params& p) {
   static_assert(k_ispacked(SRC) && k_is420(DST), "packed RGB/BGR -> 4:2:0 only");
   const int r1 = q.row0 + (q.has_row1 ? 1 : 0);
-  const int vb = q.valid_lanes * 48;
+  const int vb = ANY ? q.full_lanes * 48 : q.valid_lanes * 48;
   StripRegs regs[2];
-  strip_fetch(regs[0], q.lane, s.p[0] + (size_t)q.row0 * s.pitch[0] + (size_t)q.wave_g0 * 48, vb);
-  strip_fetch(regs[1], q.lane, s.p[0] + (size_t)r1 * s.pitch[0] + (size_t)q.wave_g0 * 48, vb);
+  u32 oc[2][12];
+  if constexpr (ANY) {
+    strip_fetch_u(regs[0], q.lane, s.p[0] + (size_t)q.row0 * s.pitch[0] + (size_t)q.wave_g0 * 48, vb);
+    strip_fetch_u(regs[1], q.lane, s.p[0] + (size_t)r1 * s.pitch[0] + (size_t)q.wave_g0 * 48, vb);
+    if (q.cut) {
+      packed_group_load(s.p[0] + (size_t)q.row0 * s.pitch[0] + (size_t)q.xs * 3, q.n_px, oc[0]);
+      packed_group_load(s.p[0] + (size_t)r1 * s.pitch[0] + (size_t)q.xs * 3, q.n_px, oc[1]);
+    }
+  } else {
+    strip_fetch(regs[0], q.lane, s.p[0] + (size_t)q.row0 * s.pitch[0] + (size_t)q.wave_g0 * 48, vb);
+    strip_fetch(regs[1], q.lane, s.p[0] + (size_t)r1 * s.pitch[0] + (size_t)q.wave_g0 * 48, vb);
+  }
   float su[8], sv[8]; // row-0 pair sums of the 8 chroma samples
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     u32 o[12], R[4], G[4], B[4];
-    strip_unpack(strip, q.lane, regs[r], o, q.lane_valid);
+    strip_unpack(strip, q.lane, regs[r], o, q.lane_valid && !(ANY && q.cut));
+    if constexpr (ANY) {
+      if (q.cut) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) o[i] = oc[r][i];
+      }
+    }
     if (!q.lane_valid)
       continue;
     if constexpr (SRC == K_RGB) deinterleave3(o, R, G, B);
@@ -307,78 +385,6 @@ __device__ __forceinline__ void load_transform_packed_420(Block& b, const SurfRe
         else { cu = pack_u8<0>(mu0, 0u); cu = pack_u8<1>(mu1, cu); cv = pack_u8<0>(mv0, 0u); cv = pack_u8<1>(mv1, cv); }
       }
       __builtin_amdgcn_sched_barrier(0); // one 4-pixel group at a time
-    }
-  }
-}
-
-// ---- byte-granular path: any width / alignment, one 2x2 quad at a time ---------------------
-template <int K> __device__ __forceinline__ void px_read(const SurfRef& s, int x, int y, float (&c)[3]) {
-  if constexpr (K == K_RGB || K == K_BGR) {
-    const uint8_t* q = s.p[0] + (size_t)y * s.pitch[0] + (size_t)x * 3;
-    c[0] = (float)q[K == K_RGB ? 0 : 2]; c[1] = (float)q[1]; c[2] = (float)q[K == K_RGB ? 2 : 0];
-  } else if constexpr (K == K_RGBP || K == K_YUV444) {
-    for (int k = 0; k < 3; ++k) c[k] = (float)s.p[k][(size_t)y * s.pitch[k] + x];
-  } else if constexpr (K == K_NV12) {
-    c[0] = (float)s.p[0][(size_t)y * s.pitch[0] + x];
-    const uint8_t* q = s.p[1] + (size_t)(y >> 1) * s.pitch[1] + (x & ~1);
-    c[1] = (float)q[0]; c[2] = (float)q[1];
-  } else if constexpr (K == K_YUV420) {
-    c[0] = (float)s.p[0][(size_t)y * s.pitch[0] + x];
-    c[1] = (float)s.p[1][(size_t)(y >> 1) * s.pitch[1] + (x >> 1)];
-    c[2] = (float)s.p[2][(size_t)(y >> 1) * s.pitch[2] + (x >> 1)];
-  } else {
-    c[0] = (float)s.p[0][(size_t)y * s.pitch[0] + x]; c[1] = c[2] = 128.0f;
-  }
-}
-
-template <int SRC, int DST>
-__device__ void quad_slow(const SurfRef& s, const SurfRef& d, int qx, int qy, const vali_cvt_params& p) {
-  float acc_u[4], acc_v[4];
-  for (int dy = 0; dy < 2; ++dy)
-    for (int dx = 0; dx < 2; ++dx) {
-      const int x = qx * 2 + dx, y = qy * 2 + dy;
-      const bool in = x < s.width && y < s.height;
-      float c[3] = {0.f, 128.f, 128.f}, o[3];
-      if (in) px_read<SRC>(s, x, y, c);
-      if constexpr (k_isyuv(SRC) && k_isrgb(DST)) {
-        const Chroma t = chroma_of(c[1], c[2], p.yuv2rgb);
-        const float yf = luma_of(c[0], p.yuv2rgb);
-        o[0] = yf + t.rv; o[1] = yf + t.guv; o[2] = yf + t.bu;
-      } else if constexpr (k_isrgb(SRC) && (k_isyuv(DST) || DST == K_Y)) {
-        o[0] = dot_rgb(p.rgb2yuv[0], c[0], c[1], c[2]);
-        o[1] = dot_rgb(p.rgb2yuv[1], c[0], c[1], c[2]);
-        o[2] = dot_rgb(p.rgb2yuv[2], c[0], c[1], c[2]);
-      } else {
-        o[0] = c[0]; o[1] = c[1]; o[2] = c[2];
-      }
-      acc_u[dy * 2 + dx] = o[1]; acc_v[dy * 2 + dx] = o[2];
-      if (!in) continue;
-      const uint8_t q0 = (uint8_t)quantize_u8(o[0]), q1 = (uint8_t)quantize_u8(o[1]), q2 = (uint8_t)quantize_u8(o[2]);
-      if constexpr (DST == K_RGB || DST == K_BGR) {
-        uint8_t* w = d.p[0] + (size_t)y * d.pitch[0] + (size_t)x * 3;
-        w[DST == K_RGB ? 0 : 2] = q0; w[1] = q1; w[DST == K_RGB ? 2 : 0] = q2;
-      } else if constexpr (DST == K_RGBP || DST == K_YUV444) {
-        d.p[0][(size_t)y * d.pitch[0] + x] = q0; d.p[1][(size_t)y * d.pitch[1] + x] = q1; d.p[2][(size_t)y * d.pitch[2] + x] = q2;
-      } else {
-        d.p[0][(size_t)y * d.pitch[0] + x] = q0; // luma of NV12 / YUV420 / Y
-      }
-    }
-  if constexpr (k_is420(DST)) {
-    const int x = qx * 2, y = qy * 2;
-    if (x < s.width && y < s.height) {
-      float fu, fv;
-      if constexpr (k_is420(SRC)) { fu = acc_u[0]; fv = acc_v[0]; }      // repack: the shared sample
-      else {
-        fu = ((acc_u[0] + acc_u[1]) + (acc_u[2] + acc_u[3])) * 0.25f;
-        fv = ((acc_v[0] + acc_v[1]) + (acc_v[2] + acc_v[3])) * 0.25f;
-      }
-      const uint8_t qu = (uint8_t)quantize_u8(fu), qv = (uint8_t)quantize_u8(fv);
-      if constexpr (DST == K_NV12) {
-        uint8_t* w = d.p[1] + (size_t)qy * d.pitch[1] + x;
-        w[0] = qu; w[1] = qv;
-      } else {
-        d.p[1][(size_t)qy * d.pitch[1] + qx] = qu; d.p[2][(size_t)qy * d.pitch[2] + qx] = qv;
-      }
     }
   }
 }
@@ -417,25 +423,35 @@ __global__ void __launch_bounds__(kBlock) k_cvt8(const CvtArgs a) {
   q.has_row1 = q.row0 + 1 < H;
   q.lane_valid = q.g < q.groups;
   q.valid_lanes = min(kWave, q.groups - q.wave_g0);
+  q.cut = q.lane_valid && q.x0 + kLanePx > W;
+  q.xs = q.cut ? max(W - kLanePx, 0) : q.x0;
+  q.n_px = min(kLanePx, W);
+  q.full_lanes = min(kWave, W / kLanePx - q.wave_g0);
 
+  // uniform per frame: full 16-pixel groups on 16-byte aligned rows, or the ragged forms of the same accesses
+  // (854x480, 1366x768, 1918x1078, tensors with odd strides): a vector body with a byte-granular tail, never
+  // a scalar frame
   const bool fast = ((W & (kLanePx - 1)) == 0) && (((align_bits_of<SRC>(s) | align_bits_of<DST>(d)) & 15u) == 0);
+  Block b;
   if (fast) {
-    Block b;
     if constexpr (k_ispacked(SRC) && k_is420(DST)) {
-      load_transform_packed_420<SRC, DST>(b, s, q, strips[q.wave], a.p);
+      load_transform_packed_420<SRC, DST, false>(b, s, q, strips[q.wave], a.p);
     } else {
-      load_block<SRC>(b, s, q, strips[q.wave]);
+      load_block<SRC, false>(b, s, q, strips[q.wave]);
       if (q.lane_valid)
         transform_block<SRC, DST>(b, a.p);
     }
-    store_block<DST>(b, d, q, strips[q.wave]);
-    return;
+    store_block<DST, false>(b, d, q, strips[q.wave]);
+  } else {
+    if constexpr (k_ispacked(SRC) && k_is420(DST)) {
+      load_transform_packed_420<SRC, DST, true>(b, s, q, strips[q.wave], a.p);
+    } else {
+      load_block<SRC, true>(b, s, q, strips[q.wave]);
+      if (q.lane_valid)
+        transform_block<SRC, DST>(b, a.p);
+    }
+    store_block<DST, true>(b, d, q, strips[q.wave]);
   }
-  if (!q.lane_valid)
-    return;
-#pragma unroll 1 // the byte-granular path must not set the kernel's register budget
-  for (int k = 0; k < 8; ++k)
-    quad_slow<SRC, DST>(s, d, q.x0 / 2 + k, crow, a.p);
 }
 
 // ---- element-type kernels ------------------------------------------------------------------
@@ -463,38 +479,39 @@ __global__ void __launch_bounds__(kBlock) k_p16_to_nv12(const ElemArgs a) {
     return;
   const SurfRef s = load_surface(a.d_src, a.src, frame);
   const SurfRef d = load_surface(a.d_dst, a.dst, frame);
-  const int W = s.width, rows = s.height + (s.height + 1) / 2; // luma rows + chroma rows (p[0] spans both)
+  const int W = s.width, H = s.height, rows = H + H / 2; // luma rows, then the interleaved chroma rows (same width in elements)
+  auto srow_of = [&](int y) { return y < H ? s.p[0] + (size_t)y * s.pitch[0] : s.p[1] + (size_t)(y - H) * s.pitch[1]; };
+  auto drow_of = [&](int y) { return y < H ? d.p[0] + (size_t)y * d.pitch[0] : d.p[1] + (size_t)(y - H) * d.pitch[1]; };
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int xa = tx * kP16TileW + lane * 8, xb = xa + 512; // the lane's two 8-element groups
   const int y0 = ty * kP16TileH + wave * kP16RowsPerWave;
   if (y0 >= rows || xa >= W)
     return;
-  const bool vec = ((((uintptr_t)s.p[0]) | (uintptr_t)s.pitch[0]) & 15u) == 0 &&
-                   ((((uintptr_t)d.p[0]) | (uintptr_t)d.pitch[0]) & 7u) == 0;
-  // whole 8-element groups go through the vector path (a 3840-wide row ends inside its last
-  // tile); only a group cut by the right edge, or foreign alignment, takes the element loop
-  const bool ga = vec && xa + 8 <= W, gb = vec && xb + 8 <= W;
+  // whole 8-element groups go through the vector path whatever the row alignment (misaligned forms of the same
+  // accesses); only a group cut by the right edge takes the element loop
+  const bool ga = xa + 8 <= W, gb = xb + 8 <= W;
   uint4 v[kP16RowsPerWave][2];
 #pragma unroll
   for (int r = 0; r < kP16RowsPerWave; ++r) {
-    const uint8_t* srow = s.p[0] + (size_t)min(y0 + r, rows - 1) * s.pitch[0];
-    v[r][0] = ga ? load16(srow + (size_t)xa * 2) : make_uint4(0, 0, 0, 0);
-    v[r][1] = gb ? load16(srow + (size_t)xb * 2) : make_uint4(0, 0, 0, 0);
+    const uint8_t* srow = srow_of(min(y0 + r, rows - 1));
+    v[r][0] = ga ? load16_u(srow + (size_t)xa * 2) : make_uint4(0, 0, 0, 0);
+    v[r][1] = gb ? load16_u(srow + (size_t)xb * 2) : make_uint4(0, 0, 0, 0);
   }
 #pragma unroll
   for (int r = 0; r < kP16RowsPerWave; ++r) {
     if (y0 + r >= rows)
       break;
-    uint8_t* drow = d.p[0] + (size_t)(y0 + r) * d.pitch[0];
+    uint8_t* drow = drow_of(y0 + r);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int x = h ? xb : xa;
       if (h ? gb : ga) {
         const uint4 w = v[r][h];
-        *reinterpret_cast<uint2*>(drow + x) =
-            make_uint2(p16_pair(w.x) | (p16_pair(w.y) << 16), p16_pair(w.z) | (p16_pair(w.w) << 16));
+        typedef v2u32 v2u32_u __attribute__((aligned(1)));
+        const v2u32 o = {p16_pair(w.x) | (p16_pair(w.y) << 16), p16_pair(w.z) | (p16_pair(w.w) << 16)};
+        *(v2u32_u*)(drow + x) = o;
       } else if (x < W) {
-        const uint16_t* srow = (const uint16_t*)(s.p[0] + (size_t)(y0 + r) * s.pitch[0]);
+        const u16_u* srow = (const u16_u*)srow_of(y0 + r);
         for (int k = 0; k < 8 && x + k < W; ++k)
           drow[x + k] = (uint8_t)min(((u32)srow[x + k] + 128u) >> 8, 255u);
       }
@@ -519,22 +536,23 @@ __global__ void __launch_bounds__(kBlock) k_rgb8_to_f32(const ElemArgs a) {
   const uint8_t* srow = s.p[0] + (size_t)y * s.pitch[0];
   uint8_t* drow = d.p[0] + (size_t)y * d.pitch[0];
   const int base = tx * kU8F32Tile + threadIdx.x * 4;
-  const bool vec = ((((uintptr_t)srow) & 3u) == 0) && ((((uintptr_t)drow) & 15u) == 0);
+  typedef u32 u32_u __attribute__((aligned(1)));
+  typedef v4f32 v4f32_a4 __attribute__((aligned(4)));   // float rows are 4-byte aligned, not more (foreign tensors)
   u32 w[4];
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int e0 = base + it * 1024;
-    w[it] = (vec && e0 + 4 <= n) ? gload<u32>(srow + e0) : 0u;
+    w[it] = e0 + 4 <= n ? *(const VALI_GLOBAL u32_u*)(srow + e0) : 0u;
   }
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int e0 = base + it * 1024;
     if (e0 >= n)
       break;
-    if (vec && e0 + 4 <= n) {
+    if (e0 + 4 <= n) {
       const u32 q = w[it];
       const v4f32 f = {ubyte_f32<0>(q) / 255.0f, ubyte_f32<1>(q) / 255.0f, ubyte_f32<2>(q) / 255.0f, ubyte_f32<3>(q) / 255.0f};
-      __builtin_nontemporal_store(f, (VALI_GLOBAL v4f32*)(drow + (size_t)e0 * 4));
+      __builtin_nontemporal_store(f, (VALI_GLOBAL v4f32_a4*)(drow + (size_t)e0 * 4));
     } else {
       for (int k = 0; k < 4 && e0 + k < n; ++k)
         gstore<float>(drow + (size_t)(e0 + k) * 4, (float)gload<uint8_t>(srow + e0 + k) / 255.0f);
@@ -563,9 +581,9 @@ __global__ void __launch_bounds__(kBlock) k_f32_deinterleave(const ElemArgs a) {
   const int x0 = xw + lane * 4, y0 = ty * 2;
   if (xw >= W || y0 >= H)
     return;
-  const bool aligned = ((((uintptr_t)s.p[0]) | (uintptr_t)s.pitch[0] | ((uintptr_t)d.p[0]) | ((uintptr_t)d.p[1]) |
-                         ((uintptr_t)d.p[2]) | (uintptr_t)d.pitch[0] | (uintptr_t)d.pitch[1] | (uintptr_t)d.pitch[2]) & 15u) == 0;
-  if (aligned && xw + 256 <= W) {
+  typedef v4u32 v4u32_a4 __attribute__((aligned(4)));   // float rows: 4-byte aligned is all a foreign tensor promises
+  typedef v4f32 v4f32_a4 __attribute__((aligned(4)));
+  if (xw + 256 <= W) {
     F32Strip& st = strips[wave];
     const int rows = min(2, H - y0);
     uint4 v[2][3];
@@ -574,7 +592,10 @@ __global__ void __launch_bounds__(kBlock) k_f32_deinterleave(const ElemArgs a) {
       const uint8_t* srow = s.p[0] + (size_t)min(y0 + r, H - 1) * s.pitch[0] + (size_t)xw * 12;
 #pragma unroll
       for (int i = 0; i < 3; ++i)
-        v[r][i] = load16(srow + i * 1024 + lane * 16);
+      {
+        const v4u32 t = *(const v4u32_a4*)(srow + i * 1024 + lane * 16);
+        v[r][i] = make_uint4(t.x, t.y, t.z, t.w);
+      }
     }
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -589,13 +610,14 @@ __global__ void __launch_bounds__(kBlock) k_f32_deinterleave(const ElemArgs a) {
       const float4 a2 = *reinterpret_cast<const float4*>(&st.b[lane * 48 + 32]);
       wave_lds_sync();
       const int y = y0 + r;
-      store16f(d.p[0] + (size_t)y * d.pitch[0] + (size_t)x0 * 4, make_float4(a0.x, a0.w, a1.z, a2.y));
-      store16f(d.p[1] + (size_t)y * d.pitch[1] + (size_t)x0 * 4, make_float4(a0.y, a1.x, a1.w, a2.z));
-      store16f(d.p[2] + (size_t)y * d.pitch[2] + (size_t)x0 * 4, make_float4(a0.z, a1.y, a2.x, a2.w));
+      const v4f32 c0 = {a0.x, a0.w, a1.z, a2.y}, c1 = {a0.y, a1.x, a1.w, a2.z}, c2 = {a0.z, a1.y, a2.x, a2.w};
+      *(VALI_GLOBAL v4f32_a4*)(d.p[0] + (size_t)y * d.pitch[0] + (size_t)x0 * 4) = c0;
+      *(VALI_GLOBAL v4f32_a4*)(d.p[1] + (size_t)y * d.pitch[1] + (size_t)x0 * 4) = c1;
+      *(VALI_GLOBAL v4f32_a4*)(d.p[2] + (size_t)y * d.pitch[2] + (size_t)x0 * 4) = c2;
     }
     return;
   }
-  // ragged last chunk of a row / foreign alignment: per-lane element path
+  // ragged last chunk of a row (fewer than 256 pixels left): per-lane vectors, elements for the cut group
   if (x0 >= W)
     return;
   for (int r = 0; r < 2 && y0 + r < H; ++r) {
@@ -604,11 +626,12 @@ __global__ void __launch_bounds__(kBlock) k_f32_deinterleave(const ElemArgs a) {
     float* o0 = (float*)(d.p[0] + (size_t)y * d.pitch[0]) + x0;
     float* o1 = (float*)(d.p[1] + (size_t)y * d.pitch[1]) + x0;
     float* o2 = (float*)(d.p[2] + (size_t)y * d.pitch[2]) + x0;
-    if (x0 + 4 <= W && (((uintptr_t)srow | (uintptr_t)o0 | (uintptr_t)o1 | (uintptr_t)o2) & 15u) == 0) {
-      const float4 a0 = ((const float4*)srow)[0], a1 = ((const float4*)srow)[1], a2 = ((const float4*)srow)[2];
-      *(float4*)o0 = make_float4(a0.x, a0.w, a1.z, a2.y);
-      *(float4*)o1 = make_float4(a0.y, a1.x, a1.w, a2.z);
-      *(float4*)o2 = make_float4(a0.z, a1.y, a2.x, a2.w);
+    if (x0 + 4 <= W) {
+      const v4f32 a0 = ((const v4f32_a4*)srow)[0], a1 = ((const v4f32_a4*)srow)[1], a2 = ((const v4f32_a4*)srow)[2];
+      const v4f32 c0 = {a0.x, a0.w, a1.z, a2.y}, c1 = {a0.y, a1.x, a1.w, a2.z}, c2 = {a0.z, a1.y, a2.x, a2.w};
+      *(v4f32_a4*)o0 = c0;
+      *(v4f32_a4*)o1 = c1;
+      *(v4f32_a4*)o2 = c2;
     } else {
       for (int k = 0; k < 4 && x0 + k < W; ++k) { o0[k] = srow[3 * k]; o1[k] = srow[3 * k + 1]; o2[k] = srow[3 * k + 2]; }
     }
@@ -638,6 +661,8 @@ static int launch_convert(CvtArgs& a, ElemArgs& e, int src_fmt, int dst_fmt, int
                           hipStream_t stream) {
   // element-type conversions first
   if ((src_fmt == VALI_FMT_P10 || src_fmt == VALI_FMT_P12) && dst_fmt == VALI_FMT_NV12) {
+    if ((width | height) & 1)
+      return fail(VALI_ERR_INVALID_ARG, "convert: 4:2:0 surfaces need even width and height (%dx%d)", width, height);
     e.map = make_tile_map((width + kP16TileW - 1) / kP16TileW, (height + (height + 1) / 2 + kP16TileH - 1) / kP16TileH, (u32)n);
     hipLaunchKernelGGL(k_p16_to_nv12, tile_grid(e.map), dim3(kBlock), 0, stream, e);
     VALI_LAUNCH_CHECK();
@@ -658,12 +683,16 @@ static int launch_convert(CvtArgs& a, ElemArgs& e, int src_fmt, int dst_fmt, int
   const int sk = kind_of(src_fmt), dk = kind_of(dst_fmt);
   if (sk == K_NONE || dk == K_NONE)
     return fail(VALI_ERR_UNSUPPORTED, "convert: unsupported pair %d -> %d", src_fmt, dst_fmt);
+  // 4:2:0 planes hold (W/2) x (H/2) chroma samples (Surfaces.cpp:231-246): an odd size would put the last
+  // row pair's chroma outside the plane
+  if ((k_is420(sk) || k_is420(dk)) && ((width | height) & 1))
+    return fail(VALI_ERR_INVALID_ARG, "convert: 4:2:0 surfaces need even width and height (%dx%d)", width, height);
   const int groups = (width + kLanePx - 1) / kLanePx;
   int block = ((groups + kWave - 1) / kWave) * kWave;
   if (block > kBlock)
     block = kBlock;
   // narrow frames stack row pairs into a 256-thread workgroup (profiles/r01_variants.md sweep 8)
-  static const int rp_env = [] { const char* e = getenv("VALI_NV12_ROWPAIRS"); return e ? atoi(e) : 0; }();
+  const int rp_env = tuning(VALI_TUNE_NV12_ROWPAIRS);
   const int row_block = block;
   a.rp = rp_env > 0 ? rp_env : kBlock / row_block;
   if (a.rp < 1 || row_block * a.rp > kBlock)
@@ -672,14 +701,11 @@ static int launch_convert(CvtArgs& a, ElemArgs& e, int src_fmt, int dst_fmt, int
   block = row_block * a.rp;
   const dim3 grid = tile_grid(a.map);
   // residency cap: 16 waves/CU measured best for plane -> packed streams (profiles/r01_variants.md);
-  // VALI_WAVES_PER_CU is a tuning knob for A/B runs only
+  // VALI_TUNE_WAVES_PER_CU is an A/B switch
   // Packed SOURCES (global -> LDS strip -> registers before any arithmetic) have a longer
   // dependent chain per wave and want 24 waves/CU (RGB->RGB_PLANAR 5.79 -> 5.98, RGB->YUV444
   // 4.78 -> 5.38, RGB->Y 4.76 -> 5.71 TB/s); everything else keeps 16.
-  static const int waves_override = [] {
-    const char* e = getenv("VALI_WAVES_PER_CU");
-    return e ? atoi(e) : 0;
-  }();
+  const int waves_override = tuning(VALI_TUNE_WAVES_PER_CU);
   const int waves_per_cu = waves_override > 0 ? waves_override : streaming_waves_per_cu(groups, row_block, k_ispacked(sk) ? 24 : 16);
   const unsigned lds = residency_lds_bytes(block, waves_per_cu, (unsigned)sizeof(PackedStrip) * kWavesPerBlock);
 #define VALI_PAIR(S, D)                                                                     \
@@ -718,7 +744,7 @@ int vali_convert(const vali_surface* src, const vali_surface* dst, const vali_cv
   ElemArgs e = {};
   e.src = *src; e.dst = *dst;
   hipStream_t s = as_stream(stream);
-  DeviceScope scope(stream_device(s));
+  VALI_ENTRY(s);
   return launch_convert(a, e, src->format, dst->format, src->width, src->height, 1, s);
 }
 
@@ -735,7 +761,7 @@ int vali_convert_batch(const vali_surface* d_src, const vali_surface* d_dst, int
   ElemArgs e = {};
   e.d_src = d_src; e.d_dst = d_dst;
   hipStream_t s = as_stream(stream);
-  DeviceScope scope(stream_device(s));
+  VALI_ENTRY(s);
   return launch_convert(a, e, src_format, dst_format, width, height, n, s);
 }
 

@@ -22,8 +22,6 @@
 #include "common.hpp"
 #include "dev_util.hpp"
 
-#include <stdlib.h>
-
 namespace vali {
 
 enum : int { LAYOUT_RGB = 0, LAYOUT_BGR = 1, LAYOUT_PLANAR = 2 };
@@ -67,6 +65,29 @@ __device__ __forceinline__ void emit4(u32 y4, const ChromaTerm& c01, const Chrom
     d1 = pack_u8<0>(g1, d1); d1 = pack_u8<1>(l1, d1); d1 = pack_u8<2>(f2, d1); d1 = pack_u8<3>(g2, d1);
     d2 = pack_u8<0>(l2, d2); d2 = pack_u8<1>(f3, d2); d2 = pack_u8<2>(g3, d2); d2 = pack_u8<3>(l3, d2);
     o3[0] = d0; o3[1] = d1; o3[2] = d2;
+  }
+}
+
+// The lane's 16 x 2 pixels: two luma vectors + the shared chroma vector -> packed rows o0 / o1
+// (or r[4] g[4] b[4] per row when planar).
+template <int LAYOUT>
+__device__ __forceinline__ void convert_group(const uint4& ya, const uint4& yb, const uint4& uv, const vali_csc& k,
+                                              u32 (&o0)[12], u32 (&o1)[12]) {
+  const u32 yw0[4] = {ya.x, ya.y, ya.z, ya.w};
+  const u32 yw1[4] = {yb.x, yb.y, yb.z, yb.w};
+  const u32 uvw[4] = {uv.x, uv.y, uv.z, uv.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const ChromaTerm c01 = chroma_term(ubyte_f32<0>(uvw[j]), ubyte_f32<1>(uvw[j]), k);
+    const ChromaTerm c23 = chroma_term(ubyte_f32<2>(uvw[j]), ubyte_f32<3>(uvw[j]), k);
+    if constexpr (LAYOUT == LAYOUT_PLANAR) {
+      emit4<LAYOUT>(yw0[j], c01, c23, k, nullptr, o0[j], o0[4 + j], o0[8 + j]);
+      emit4<LAYOUT>(yw1[j], c01, c23, k, nullptr, o1[j], o1[4 + j], o1[8 + j]);
+    } else {
+      u32 dummy;
+      emit4<LAYOUT>(yw0[j], c01, c23, k, &o0[3 * j], dummy, dummy, dummy);
+      emit4<LAYOUT>(yw1[j], c01, c23, k, &o1[3 * j], dummy, dummy, dummy);
+    }
   }
 }
 
@@ -117,8 +138,7 @@ __global__ void __launch_bounds__(kBlock) k_nv12_rgb8(const Nv12RgbArgs a) {
   const int crow = tile_y * a.rp + wave_all / wpr;          // chroma row = row pair index
   if (crow * 2 >= H)
     return;
-  const int row0 = crow * 2;
-  const bool has_row1 = row0 + 1 < H;
+  const int row0 = crow * 2;          // H is even (checked on the host): row0 + 1 exists
 
   // Uniform (per frame) fast-path test: full 16-px groups and 16-B aligned rows.
   uintptr_t align_bits = (uintptr_t)py | (uintptr_t)puv | (uintptr_t)sp_y |
@@ -132,26 +152,9 @@ __global__ void __launch_bounds__(kBlock) k_nv12_rgb8(const Nv12RgbArgs a) {
     u32 o0[12], o1[12];          // packed rows (or r[4] g[4] b[4] when planar)
     if (lane_valid) {
       const uint4 ya = load16(py + (size_t)row0 * sp_y + x0);
-      // odd height: the last pair re-reads row0 (always a valid address)
-      const uint4 yb =
-          load16(py + (size_t)(row0 + (has_row1 ? 1 : 0)) * sp_y + x0);
+      const uint4 yb = load16(py + (size_t)(row0 + 1) * sp_y + x0);
       const uint4 uv = load16(puv + (size_t)crow * sp_uv + x0);
-      const u32 yw0[4] = {ya.x, ya.y, ya.z, ya.w};
-      const u32 yw1[4] = {yb.x, yb.y, yb.z, yb.w};
-      const u32 uvw[4] = {uv.x, uv.y, uv.z, uv.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const ChromaTerm c01 = chroma_term(ubyte_f32<0>(uvw[j]), ubyte_f32<1>(uvw[j]), k);
-        const ChromaTerm c23 = chroma_term(ubyte_f32<2>(uvw[j]), ubyte_f32<3>(uvw[j]), k);
-        if constexpr (LAYOUT == LAYOUT_PLANAR) {
-          emit4<LAYOUT>(yw0[j], c01, c23, k, nullptr, o0[j], o0[4 + j], o0[8 + j]);
-          emit4<LAYOUT>(yw1[j], c01, c23, k, nullptr, o1[j], o1[4 + j], o1[8 + j]);
-        } else {
-          u32 dummy;
-          emit4<LAYOUT>(yw0[j], c01, c23, k, &o0[3 * j], dummy, dummy, dummy);
-          emit4<LAYOUT>(yw1[j], c01, c23, k, &o1[3 * j], dummy, dummy, dummy);
-        }
-      }
+      convert_group<LAYOUT>(ya, yb, uv, k, o0, o1);
     }
     if constexpr (LAYOUT == LAYOUT_PLANAR) {
       if (lane_valid) {
@@ -160,9 +163,7 @@ __global__ void __launch_bounds__(kBlock) k_nv12_rgb8(const Nv12RgbArgs a) {
         for (int c = 0; c < 3; ++c) {
           uint8_t* p = planes[c] + (size_t)row0 * dp + x0;
           store16_nt(p, make_uint4(o0[4 * c], o0[4 * c + 1], o0[4 * c + 2], o0[4 * c + 3]));
-          if (has_row1)
-            store16_nt(p + dp,
-                       make_uint4(o1[4 * c], o1[4 * c + 1], o1[4 * c + 2], o1[4 * c + 3]));
+          store16_nt(p + dp, make_uint4(o1[4 * c], o1[4 * c + 1], o1[4 * c + 2], o1[4 * c + 3]));
         }
       }
     } else if constexpr (!STAGED) {
@@ -171,12 +172,10 @@ __global__ void __launch_bounds__(kBlock) k_nv12_rgb8(const Nv12RgbArgs a) {
         p[0] = make_uint4(o0[0], o0[1], o0[2], o0[3]);
         p[1] = make_uint4(o0[4], o0[5], o0[6], o0[7]);
         p[2] = make_uint4(o0[8], o0[9], o0[10], o0[11]);
-        if (has_row1) {
-          uint4* q = reinterpret_cast<uint4*>(pd0 + (size_t)(row0 + 1) * dp + (size_t)g * 48);
-          q[0] = make_uint4(o1[0], o1[1], o1[2], o1[3]);
-          q[1] = make_uint4(o1[4], o1[5], o1[6], o1[7]);
-          q[2] = make_uint4(o1[8], o1[9], o1[10], o1[11]);
-        }
+        uint4* q = reinterpret_cast<uint4*>(pd0 + (size_t)(row0 + 1) * dp + (size_t)g * 48);
+        q[0] = make_uint4(o1[0], o1[1], o1[2], o1[3]);
+        q[1] = make_uint4(o1[4], o1[5], o1[6], o1[7]);
+        q[2] = make_uint4(o1[8], o1[9], o1[10], o1[11]);
       }
     } else {
       PackedStrip& strip = strips[wave];
@@ -184,38 +183,49 @@ __global__ void __launch_bounds__(kBlock) k_nv12_rgb8(const Nv12RgbArgs a) {
       const int valid_bytes = valid_lanes * 48;
       uint8_t* rb = pd0 + (size_t)row0 * dp + (size_t)wave_g0 * 48;
       strip_store_row(strip, lane, o0, lane_valid, rb, valid_bytes);
-      if (has_row1)
-        strip_store_row(strip, lane, o1, lane_valid, rb + dp, valid_bytes);
+      strip_store_row(strip, lane, o1, lane_valid, rb + dp, valid_bytes);
     }
     return;
   }
 
-  // Generic path: any width / alignment, byte granular.  Same arithmetic.
-  if (g >= groups)
-    return;
-  for (int r = 0; r < 2; ++r) {
-    const int y = row0 + r;
-    if (y >= H)
-      break;
-    for (int p = 0; p < kLanePx; ++p) {
-      const int x = x0 + p;
-      if (x >= W)
-        break;
-      const float yv = (float)py[(size_t)y * sp_y + x];
-      const uint8_t* c = puv + (size_t)crow * sp_uv + (x & ~1);
-      const ChromaTerm t = chroma_term((float)c[0], (float)c[1], k);
-      const float yf = luma_term(yv, k);
-      const uint8_t R = (uint8_t)quantize_u8(yf + t.rv), G = (uint8_t)quantize_u8(yf + t.guv),
-                    B = (uint8_t)quantize_u8(yf + t.bu);
-      if constexpr (LAYOUT == LAYOUT_PLANAR) {
-        pd0[(size_t)y * dp + x] = R;
-        pd1[(size_t)y * dp + x] = G;
-        pd2[(size_t)y * dp + x] = B;
-      } else {
-        uint8_t* q = pd0 + (size_t)y * dp + (size_t)x * 3;
-        q[0] = LAYOUT == LAYOUT_RGB ? R : B;
-        q[1] = G;
-        q[2] = LAYOUT == LAYOUT_RGB ? B : R;
+  // Ragged path: any (even) width, any base pointer, any pitch -- 854x480, 1366x768, 1918x1078, a torch tensor
+  // with an odd row stride.  The SAME decomposition and arithmetic at (nearly) the same speed: every access is
+  // the misaligned form of the 16-byte access, and the one group per row that the right edge cuts slides its
+  // window left to END with the row -- 16 whole pixels again, the overlap with its neighbour is computed twice
+  // and stored twice with identical bytes.  Its packed pixels are off the strip's 48-byte lane grid, so that
+  // lane stores its 48 bytes itself.  (Byte-granular accesses cost the memory pipeline as much as 16-byte ones:
+  // a first version that moved the cut group's bytes one by one ran at 44-66 % of the aligned speed.)
+  {
+    const bool lane_valid = g < groups;
+    const bool cut = lane_valid && x0 + kLanePx > W;
+    const int xs = cut ? max(W - kLanePx, 0) : x0;
+    const int n_px = min(kLanePx, W);                 // < 16 only for frames narrower than one group (uniform)
+    u32 o0[12], o1[12];
+    if (lane_valid) {
+      const uint4 ya = load16_n(py + (size_t)row0 * sp_y + xs, n_px);
+      const uint4 yb = load16_n(py + (size_t)(row0 + 1) * sp_y + xs, n_px);
+      const uint4 uv = load16_n(puv + (size_t)crow * sp_uv + xs, n_px);
+      convert_group<LAYOUT>(ya, yb, uv, k, o0, o1);
+    }
+    if constexpr (LAYOUT == LAYOUT_PLANAR) {
+      if (lane_valid) {
+        uint8_t* const planes[3] = {pd0, pd1, pd2};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          uint8_t* p = planes[c] + (size_t)row0 * dp + xs;
+          store16_n(p, make_uint4(o0[4 * c], o0[4 * c + 1], o0[4 * c + 2], o0[4 * c + 3]), n_px);
+          store16_n(p + dp, make_uint4(o1[4 * c], o1[4 * c + 1], o1[4 * c + 2], o1[4 * c + 3]), n_px);
+        }
+      }
+    } else {
+      PackedStrip& strip = strips[wave];
+      const int full_lanes = min(kWave, W / kLanePx - wave_g0);      // whole groups of this wave
+      uint8_t* rb = pd0 + (size_t)row0 * dp + (size_t)wave_g0 * 48;
+      strip_store_row_u(strip, lane, o0, lane_valid && !cut, rb, full_lanes * 48);
+      strip_store_row_u(strip, lane, o1, lane_valid && !cut, rb + dp, full_lanes * 48);
+      if (cut) {
+        packed_group_store(pd0 + (size_t)row0 * dp + (size_t)xs * 3, n_px, o0);
+        packed_group_store(pd0 + (size_t)(row0 + 1) * dp + (size_t)xs * 3, n_px, o1);
       }
     }
   }
@@ -231,8 +241,8 @@ static int launch_nv12_rgb(Nv12RgbArgs& a, int width, int height, int n, int dst
   // Narrow frames (a row pair needs <= 128 lanes: up to 2048 px) stack 2 or 4 row pairs in one
   // 256-thread workgroup -- adjacent rows, the same residency in fewer, fuller workgroups:
   // 1080p 5.72 -> 6.03-6.19 TB/s, 720p 5.02 -> 5.11 (profiles/r01_variants.md sweep 8).
-  // VALI_NV12_ROWPAIRS=1 restores one row pair per workgroup (A/B only).
-  static const int rp_env = [] { const char* e = getenv("VALI_NV12_ROWPAIRS"); return e ? atoi(e) : 0; }();
+  // VALI_TUNE_NV12_ROWPAIRS = 1 restores one row pair per workgroup (A/B only).
+  const int rp_env = tuning(VALI_TUNE_NV12_ROWPAIRS);
   const int row_block = block;
   a.rp = rp_env > 0 ? rp_env : kBlock / row_block;
   if (a.rp < 1 || row_block * a.rp > kBlock)
@@ -240,15 +250,9 @@ static int launch_nv12_rgb(Nv12RgbArgs& a, int width, int height, int n, int dst
   a.map = make_tile_map((groups + row_block - 1) / row_block, ((height + 1) / 2 + a.rp - 1) / a.rp, (u32)n);
   block = row_block * a.rp;
   const dim3 grid = tile_grid(a.map);
-  // tuning knobs for A/B measurements only (not part of the API)
-  static const bool direct = [] {
-    const char* e = getenv("VALI_NV12_DIRECT_STORE");
-    return e && e[0] == '1';
-  }();
-  static const int waves_override = [] {
-    const char* e = getenv("VALI_WAVES_PER_CU");
-    return e ? atoi(e) : 0;
-  }();
+  // A/B switches (include/vali_hip.h: vali_tuning_key)
+  const bool direct = tuning(VALI_TUNE_NV12_DIRECT_STORE) == 1;
+  const int waves_override = tuning(VALI_TUNE_WAVES_PER_CU);
   const int waves_per_cu = waves_override > 0 ? waves_override : streaming_waves_per_cu(groups, row_block, 16);
   const unsigned lds =
       residency_lds_bytes(block, waves_per_cu, (unsigned)sizeof(PackedStrip) * (unsigned)((block + kWave - 1) / kWave));
@@ -287,6 +291,7 @@ int vali_nv12_to_rgb(const vali_surface* src, const vali_surface* dst, const val
   VALI_REQUIRE(src->format == VALI_FMT_NV12, "src must be NV12");
   VALI_REQUIRE(src->width > 0 && src->height > 0, "empty src");
   VALI_REQUIRE(src->width == dst->width && src->height == dst->height, "src/dst size mismatch");
+  VALI_REQUIRE(((src->width | src->height) & 1) == 0, "4:2:0 surfaces need even width and height");
   VALI_REQUIRE(src->plane[0] && src->plane[1] && dst->plane[0], "null plane");
   if (dst->format == VALI_FMT_RGB_PLANAR)
     VALI_REQUIRE(dst->plane[1] && dst->plane[2], "null planar plane");
@@ -295,7 +300,7 @@ int vali_nv12_to_rgb(const vali_surface* src, const vali_surface* dst, const val
   a.dst = *dst;
   a.csc = *csc;
   hipStream_t s = as_stream(stream);
-  DeviceScope scope(stream_device(s));
+  VALI_ENTRY(s);
   return launch_nv12_rgb(a, src->width, src->height, 1, dst->format, s);
 }
 
@@ -304,6 +309,7 @@ int vali_nv12_to_rgb_batch(const vali_surface* d_src, const vali_surface* d_dst,
                            vali_stream_t stream) {
   VALI_REQUIRE(d_src && d_dst && csc, "null argument");
   VALI_REQUIRE(width > 0 && height > 0, "empty geometry");
+  VALI_REQUIRE(((width | height) & 1) == 0, "4:2:0 surfaces need even width and height");
   VALI_REQUIRE(n >= 0 && n <= 65535, "batch size out of range (0..65535)");
   if (n == 0)
     return VALI_OK;
@@ -312,7 +318,7 @@ int vali_nv12_to_rgb_batch(const vali_surface* d_src, const vali_surface* d_dst,
   a.d_dst = d_dst;
   a.csc = *csc;
   hipStream_t s = as_stream(stream);
-  DeviceScope scope(stream_device(s));
+  VALI_ENTRY(s);
   return launch_nv12_rgb(a, width, height, n, dst_format, s);
 }
 
@@ -335,7 +341,7 @@ int vali_debug_quantize_u8(const float* d_in, uint8_t* d_out, int n, vali_stream
   if (!n)
     return VALI_OK;
   hipStream_t s = as_stream(stream);
-  DeviceScope scope(stream_device(s));
+  VALI_ENTRY(s);
   hipLaunchKernelGGL(k_debug_quantize, dim3((n + 255) / 256), dim3(256), 0, s, d_in, d_out, n);
   VALI_LAUNCH_CHECK();
   return VALI_OK;
@@ -347,7 +353,7 @@ int vali_debug_quantize_u8_portable(const float* d_in, uint8_t* d_out, int n,
   if (!n)
     return VALI_OK;
   hipStream_t s = as_stream(stream);
-  DeviceScope scope(stream_device(s));
+  VALI_ENTRY(s);
   hipLaunchKernelGGL(k_debug_quantize_portable, dim3((n + 255) / 256), dim3(256), 0, s, d_in,
                      d_out, n);
   VALI_LAUNCH_CHECK();

@@ -132,6 +132,43 @@ __device__ __forceinline__ void store16_nt(void* p, uint4 v) {
 }
 __device__ __forceinline__ void store16(void* p, uint4 v) { *(uint4*)p = v; }
 __device__ __forceinline__ uint4 load16(const void* p) { return *(const uint4*)p; }
+// Forms for rows that are NOT 16-byte aligned (foreign pitches, odd base pointers, ragged widths): the same
+// dwordx4 instruction on an under-aligned type -- gfx950 runs HSA queues in unaligned-access mode, a
+// misaligned wave access only touches one more 128-byte line.  load_bytes16 / store_bytes16 move n < 16
+// bytes one by one (frames narrower than one 16-pixel group only -- a byte access costs the memory pipeline
+// as much as a 16-byte one, so wider frames never use them: their cut group slides left instead); fully
+// unrolled, so the dword array stays in registers.  No form ever touches a byte outside the row.
+typedef v4u32 v4u32_u __attribute__((aligned(1)));
+typedef unsigned short u16_u __attribute__((aligned(1)));
+__device__ __forceinline__ uint4 load16_u(const void* p) {
+  const v4u32 w = *(const v4u32_u*)p;
+  return make_uint4(w.x, w.y, w.z, w.w);
+}
+__device__ __forceinline__ void store16_u(void* p, uint4 v) {
+  const v4u32 w = {v.x, v.y, v.z, v.w};
+  *(v4u32_u*)p = w;
+}
+__device__ __forceinline__ uint4 load_bytes16(const uint8_t* p, int n) {
+  u32 w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    if (k < n)
+      w[k / 4] |= (u32)p[k] << (8 * (k % 4));
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ void store_bytes16(uint8_t* p, uint4 v, int n) {
+  const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    if (k < n)
+      p[k] = (uint8_t)(w[k / 4] >> (8 * (k % 4)));
+}
+// n valid bytes of a 16-byte group: whole group -> one (possibly misaligned) vector access
+__device__ __forceinline__ uint4 load16_n(const uint8_t* p, int n) { return n >= 16 ? load16_u(p) : load_bytes16(p, n); } // n <= 0: zeros
+__device__ __forceinline__ void store16_n(uint8_t* p, uint4 v, int n) {
+  if (n >= 16) store16_u(p, v);
+  else store_bytes16(p, v, n);
+}
 // typed (global address space) forms for the gather kernels
 __device__ __forceinline__ uint4 gload16(const void* p) {
   const v4u32 w = *(const VALI_GLOBAL v4u32*)p;
@@ -364,6 +401,26 @@ __device__ __forceinline__ void strip_store_row(PackedStrip& strip, int lane,
   wave_lds_sync();
 }
 
+// The same for rows of ANY alignment (misaligned forms of the 16-byte stores; plain, not non-temporal: a
+// misaligned wave store leaves partial lines at both ends).  valid_bytes is still a multiple of 48: the group
+// a ragged width cuts does not go through the strip (see the ragged paths of the converters).
+__device__ __forceinline__ void strip_store_row_u(PackedStrip& strip, int lane, const u32 (&o)[12], bool lane_valid,
+                                                  uint8_t* row_base, int valid_bytes) {
+  if (lane_valid) {
+    strip.v[lane * 3 + 0] = make_uint4(o[0], o[1], o[2], o[3]);
+    strip.v[lane * 3 + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+    strip.v[lane * 3 + 2] = make_uint4(o[8], o[9], o[10], o[11]);
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int off = (k * kWave + lane) * 16;
+    if (off < valid_bytes)
+      store16_u(row_base + off, strip.v[k * kWave + lane]);
+  }
+  wave_lds_sync();
+}
+
 // load: the inverse -- 3 x 1 KiB contiguous global reads, then each lane picks
 // up its own 48 bytes.
 __device__ __forceinline__ void strip_load_row(PackedStrip& strip, int lane,
@@ -402,6 +459,31 @@ __device__ __forceinline__ void strip_fetch(StripRegs& r, int lane, const uint8_
     const int off = (k * kWave + lane) * 16;
     r.v[k] = off < valid_bytes ? load16(row_base + off) : make_uint4(0, 0, 0, 0);
   }
+}
+
+// any alignment (see strip_store_row_u)
+__device__ __forceinline__ void strip_fetch_u(StripRegs& r, int lane, const uint8_t* row_base, int valid_bytes) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int off = (k * kWave + lane) * 16;
+    r.v[k] = off < valid_bytes ? load16_u(row_base + off) : make_uint4(0, 0, 0, 0);
+  }
+}
+
+// The 48 bytes of ONE lane's 16 packed pixels straight from / to global memory (the group a ragged width cuts:
+// its window slides left so that it ends with the row, which takes it off the strip's 48-byte lane grid).
+// n_px < 16 only for frames narrower than one group.
+__device__ __forceinline__ void packed_group_load(const uint8_t* p, int n_px, u32 (&o)[12]) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const uint4 v = load16_n(p + 16 * k, n_px * 3 - 16 * k);
+    o[4 * k] = v.x; o[4 * k + 1] = v.y; o[4 * k + 2] = v.z; o[4 * k + 3] = v.w;
+  }
+}
+__device__ __forceinline__ void packed_group_store(uint8_t* p, int n_px, const u32 (&o)[12]) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    store16_n(p + 16 * k, make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]), n_px * 3 - 16 * k);
 }
 
 __device__ __forceinline__ void strip_unpack(PackedStrip& strip, int lane, const StripRegs& r,

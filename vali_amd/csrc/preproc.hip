@@ -325,7 +325,7 @@ int vali_nv12_preproc(const vali_surface* src, const vali_surface* dst, const va
   a.dst = *dst;
   a.prm = *params;
   hipStream_t s = as_stream(stream);
-  DeviceScope scope(stream_device(s));
+  VALI_ENTRY(s);
   return launch_preproc(a, src->width, src->height, dst->width, dst->height, dst->format, 1, s);
 }
 
@@ -344,7 +344,7 @@ int vali_nv12_preproc_batch(const vali_surface* d_src, const vali_surface* d_dst
   a.d_dst = d_dst;
   a.prm = *params;
   hipStream_t s = as_stream(stream);
-  DeviceScope scope(stream_device(s));
+  VALI_ENTRY(s);
   return launch_preproc(a, src_width, src_height, dst_width, dst_height, dst_format, n, s);
 }
 

@@ -208,6 +208,26 @@ PYBIND11_MODULE(_vali_shim, m) {
   py::class_<DLPackHolder>(m, "DLPackHolder");
 
   m.def("last_error", []() { return std::string(vali_last_error()); });
+  // tuning switches / tracing (include/vali_hip.h: vali_tuning_key)
+  for (auto kv : {std::pair<const char*, int>{"TUNE_NV12_ROWPAIRS", VALI_TUNE_NV12_ROWPAIRS},
+                  {"TUNE_WAVES_PER_CU", VALI_TUNE_WAVES_PER_CU},
+                  {"TUNE_NV12_DIRECT_STORE", VALI_TUNE_NV12_DIRECT_STORE},
+                  {"TUNE_RESIZE_FORCE_GATHER", VALI_TUNE_RESIZE_FORCE_GATHER},
+                  {"TUNE_RESIZE_POINT", VALI_TUNE_RESIZE_POINT},
+                  {"TUNE_UD_FORCE_GATHER", VALI_TUNE_UD_FORCE_GATHER},
+                  {"TUNE_UD_DOWN2", VALI_TUNE_UD_DOWN2},
+                  {"TUNE_UD_OCC5", VALI_TUNE_UD_OCC5},
+                  {"TUNE_ROTATE_NO_TILE", VALI_TUNE_ROTATE_NO_TILE},
+                  {"TUNE_ROCTX", VALI_TUNE_ROCTX},
+                  {"TUNE_RESIZE_NO_SEPARABLE", VALI_TUNE_RESIZE_NO_SEPARABLE},
+                  {"TUNE_COUNT", VALI_TUNE_COUNT}})
+    m.attr(kv.first) = kv.second;
+  m.def("tuning_set", [](int key, int value) { return vali_tuning_set(key, value); });
+  m.def("tuning_get", [](int key) {
+    int v = 0;
+    check(vali_tuning_get(key, &v), "vali_tuning_get");
+    return v;
+  });
   m.def("version", []() { return std::string(vali_version()); });
   m.def("device_count", []() {
     int n = 0;

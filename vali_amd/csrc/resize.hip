@@ -406,9 +406,45 @@ __device__ __forceinline__ int clampi(int v, int hi) { return min(max(v, 0), hi)
 
 constexpr int kLzCpr = 4;                              // 16-byte chunks per lane per row
 constexpr int kLzRowBytes = kLzCpr * kWave * 16;       // 4 KiB: the staged source row
+// The staged row carries kLzPad bytes either side: at the left / right edge of the image they hold replicas
+// of the first / last pixel, so the taps of EVERY pixel -- clamped or not -- are TAPS consecutive pixels of
+// the LDS row and come with one wide read (read_taps) instead of TAPS x C element reads.
+constexpr int kLzPad = 64;
 struct alignas(16) LzStage {
-  uint8_t row[kLzRowBytes];
+  uint8_t row[kLzPad + kLzRowBytes + kLzPad];
 };
+
+// The TAPS x C elements of one pixel's horizontal taps from the staged row: misaligned 8-byte LDS reads at
+// the pixel's own byte address (gfx950 LDS serves them in one pass; what made this kernel LDS-bound was the
+// NUMBER of ds_read instructions -- 24 single-byte reads per lane and source row, each costing the LDS pipe a
+// full wave pass, 2-way bank-conflicted at the 2:1 ratio -- not the bytes).  May read up to 7 bytes past the
+// last tap: inside the pad.
+template <typename T, int C, int TAPS>
+__device__ __forceinline__ void read_taps(const uint8_t* lds, float (&t)[TAPS][C]) {
+  constexpr int NB = TAPS * C * (int)sizeof(T), NW = (NB + 3) / 4;
+  typedef v2u32 v2u32_e __attribute__((aligned(1)));
+  typedef u32 u32_e __attribute__((aligned(1)));
+  u32 w[NW + 1];
+#pragma unroll
+  for (int k = 0; k < NW; k += 2) {
+    if (k + 1 < NW) {
+      const v2u32 q = *(const v2u32_e*)(lds + 4 * k);
+      w[k] = q.x; w[k + 1] = q.y;
+    } else {
+      w[k] = *(const u32_e*)(lds + 4 * k);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < TAPS * C; ++e) {
+    float v;
+    if constexpr (sizeof(T) == 1) v = (float)((w[e / 4] >> (8 * (e % 4))) & 0xffu);
+    else if constexpr (sizeof(T) == 2) v = (float)((w[e / 2] >> (16 * (e % 2))) & 0xffffu);
+    else v = __uint_as_float(w[e]);
+    t[e / C][e % C] = v;
+  }
+}
+
+typedef float v2f32 __attribute__((ext_vector_type(2)));
 
 // The window of horizontally filtered rows: six slots of [channel][lane] float4 (the lane's 4
 // pixels).  For 1-channel planes (Y, the planes of YUV4xx / RGB_PLANAR, the luma of NV12) it
@@ -453,8 +489,9 @@ __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int 
     return t;
   };
 
-  const int sx0 = clampi(__builtin_amdgcn_readlane(cx[0].i, 0) - kBefore, sw - 1);
-  const int sx1 = clampi(__builtin_amdgcn_readlane(cx[3].i, 63) + TAPS - 1 - kBefore, sw - 1);
+  const int ux0 = __builtin_amdgcn_readlane(cx[0].i, 0) - kBefore;                  // unclamped span of the tile
+  const int ux1 = __builtin_amdgcn_readlane(cx[3].i, 63) + TAPS - 1 - kBefore;
+  const int sx0 = clampi(ux0, sw - 1), sx1 = clampi(ux1, sw - 1);
   const int byte_begin = (sx0 * PB) & ~15;
   const int nbytes = (((sx1 + 1) * PB + 15) & ~15) - byte_begin;
   const bool staged = stage_all != nullptr && nbytes <= kLzRowBytes && ((((uintptr_t)sp) | (uintptr_t)spitch) & 15u) == 0;
@@ -468,12 +505,21 @@ __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int 
     // time goes through the wave's LDS strip; the next row's loads are in flight meanwhile.
     LzStage& st = stage_all[wave];
     const int nchunks = nbytes / 16;
-    int lo[4][TAPS]; // LDS byte offsets of the column taps (row-invariant)
+    // LDS byte offset of each pixel's FIRST tap (row-invariant); pixel j of the source row sits at
+    // kLzPad + j * PB - byte_begin, also for the replicas j < 0 and j >= sw
+    int lo[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p)
+      lo[p] = kLzPad + (min(cx[p].i, sw) - kBefore) * PB - byte_begin;
+    const bool pad_left = ux0 < 0, pad_right = ux1 > sw - 1;   // wave-uniform
+    const int edge = kLzPad + (sw - 1) * PB - byte_begin;      // the last pixel of the row (when staged)
+    // column weights as pairs (pixels 0,1 and 2,3): the horizontal filter runs as packed FP32
+    v2f32 wq[2][TAPS];
 #pragma unroll
-      for (int k = 0; k < TAPS; ++k)
-        lo[p][k] = clampi(cx[p].i - kBefore + k, sw - 1) * PB - byte_begin;
+    for (int k = 0; k < TAPS; ++k) {
+      wq[0][k] = (v2f32){cx[0].w[k], cx[1].w[k]};
+      wq[1][k] = (v2f32){cx[2].w[k], cx[3].w[k]};
+    }
     constexpr bool kLdsRing = C == 1 && MAXC <= 2;
     float hq[kLdsRing ? 1 : TAPS][4][C]; // register window (3-channel planes only)
     int head = 0;                      // LDS ring: slot of the oldest row
@@ -492,31 +538,43 @@ __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int 
 #pragma unroll
       for (int c = 0; c < kLzCpr; ++c)
         if (lane + c * kWave < nchunks)
-          *reinterpret_cast<uint4*>(&st.row[(lane + c * kWave) * 16]) = pf[c];
+          *reinterpret_cast<uint4*>(&st.row[kLzPad + (lane + c * kWave) * 16]) = pf[c];
       wave_lds_sync();
       issue(logical + 1); // in flight while this row is filtered
+      if (pad_left || pad_right) { // image edges: replicate the first / last pixel into the pad
+        if (pad_left && lane < kBefore * PB)
+          st.row[kLzPad - kBefore * PB + lane] = st.row[kLzPad + lane % PB];
+        if (pad_right && lane < (TAPS - kBefore) * PB)
+          st.row[edge + PB + lane] = st.row[edge + lane % PB];
+        wave_lds_sync();
+      }
+      float hv[C][4];
 #pragma unroll
-      for (int ch = 0; ch < C; ++ch) {
-        float hv[4];
+      for (int q = 0; q < 2; ++q) { // one pixel pair at a time: bounds the live registers
+        float t0[TAPS][C], t1[TAPS][C];
+        read_taps<T, C, TAPS>(st.row + lo[2 * q], t0);
+        read_taps<T, C, TAPS>(st.row + lo[2 * q + 1], t1);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          auto texel = [&](int k) { return (float)((const T*)(st.row + lo[p][k]))[ch]; };
-          float h = cx[p].w[0] * texel(0);
+        for (int ch = 0; ch < C; ++ch) {
+          v2f32 h = wq[q][0] * (v2f32){t0[0][ch], t1[0][ch]};
 #pragma unroll
           for (int k = 1; k < TAPS; ++k)
-            h = __builtin_fmaf(cx[p].w[k], texel(k), h);
-          hv[p] = h;
-          __builtin_amdgcn_sched_barrier(0); // one pixel-channel at a time: bounds the live registers
+            h = __builtin_elementwise_fma(wq[q][k], (v2f32){t0[k][ch], t1[k][ch]}, h);
+          hv[ch][2 * q] = h.x; hv[ch][2 * q + 1] = h.y;
         }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) {
         if constexpr (kLdsRing) {
-          ring_all[wave].slot[head][ch][lane] = make_float4(hv[0], hv[1], hv[2], hv[3]); // replaces the oldest
+          ring_all[wave].slot[head][ch][lane] = make_float4(hv[ch][0], hv[ch][1], hv[ch][2], hv[ch][3]); // replaces the oldest
         } else {
 #pragma unroll
           for (int p = 0; p < 4; ++p) {
 #pragma unroll
             for (int r = 0; r < TAPS - 1; ++r)
               hq[r][p][ch] = hq[r + 1][p][ch];
-            hq[TAPS - 1][p][ch] = hv[p];
+            hq[TAPS - 1][p][ch] = hv[ch][p];
           }
         }
       }
@@ -541,24 +599,22 @@ __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int 
         float res[4][C];
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) {
-          float v[4];
+          v2f32 v01, v23;
 #pragma unroll
           for (int r = 0; r < TAPS; ++r) {
-            float q[4];
+            v2f32 q01, q23;
             if constexpr (kLdsRing) {
               const int sl = head + r >= TAPS ? head + r - TAPS : head + r; // logical row r of the window
               const float4 f = ring_all[wave].slot[sl][ch][lane];
-              q[0] = f.x; q[1] = f.y; q[2] = f.z; q[3] = f.w;
+              q01 = (v2f32){f.x, f.y}; q23 = (v2f32){f.z, f.w};
             } else {
-#pragma unroll
-              for (int p = 0; p < 4; ++p) q[p] = hq[r][p][ch];
+              q01 = (v2f32){hq[r][0][ch], hq[r][1][ch]}; q23 = (v2f32){hq[r][2][ch], hq[r][3][ch]};
             }
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-              v[p] = r == 0 ? cy.w[0] * q[p] : __builtin_fmaf(cy.w[r], q[p], v[p]);
+            const v2f32 wr = (v2f32){cy.w[r], cy.w[r]};
+            v01 = r == 0 ? wr * q01 : __builtin_elementwise_fma(wr, q01, v01);
+            v23 = r == 0 ? wr * q23 : __builtin_elementwise_fma(wr, q23, v23);
           }
-#pragma unroll
-          for (int p = 0; p < 4; ++p) res[p][ch] = v[p];
+          res[0][ch] = v01.x; res[1][ch] = v01.y; res[2][ch] = v23.x; res[3][ch] = v23.y;
         }
         store_px4<T, C>(dp + (u32)(y * dpitch) + (size_t)x0 * PB, res, (1u << n) - 1u);
       }
@@ -708,7 +764,9 @@ static int launch_resize(ResizeArgs& a, int fmt, int src_w, int src_h, int dst_w
     if (dw <= 0 || dh <= 0)
       return fail(VALI_ERR_INVALID_ARG, "resize: destination too small for its chroma planes");
     const int sw = src_w >> a.job[k].sub_x, sh = src_h >> a.job[k].sub_y;
-    integer_scale = integer_scale && sw > 0 && sh > 0 && sw % dw == 0 && sh % dh == 0 && sw < (1 << 23) &&
+    if (sw <= 0 || sh <= 0)   // a 1-pixel-wide 4:2:0 source has no chroma column to sample
+      return fail(VALI_ERR_INVALID_ARG, "resize: source too small for its chroma planes");
+    integer_scale = integer_scale && sw % dw == 0 && sh % dh == 0 && sw < (1 << 23) &&
                     sh < (1 << 23);
     a.job[k].first_tile = total;
     a.job[k].tiles_x = (u32)(dw + 255) / 256;
@@ -726,9 +784,9 @@ static int launch_resize(ResizeArgs& a, int fmt, int src_w, int src_h, int dst_w
     else hipLaunchKernelGGL((KERNEL<T, 3>), grid, block, 0, stream, a);                     \
   } while (0)
   const bool filtered = interp != VALI_INTERP_LINEAR && !(integer_scale && elem != 4);
-  static const bool gather_only = [] { const char* e = getenv("VALI_RESIZE_FORCE_GATHER"); return e && e[0] == '1'; }();
+  const bool gather_only = tuning(VALI_TUNE_RESIZE_FORCE_GATHER) == 1;
   a.force_gather = gather_only ? 1 : 0;
-  static const bool point_on = [] { const char* e = getenv("VALI_RESIZE_POINT"); return !(e && e[0] == '0'); }();
+  const bool point_on = tuning(VALI_TUNE_RESIZE_POINT) != 0;
   if (integer_scale && elem != 4 && point_on) { // every filter is the point sample (see resize_tile)
     if (elem == 1) VALI_RS_LAUNCH(k_resize_point, uint8_t);
     else VALI_RS_LAUNCH(k_resize_point, uint16_t);
@@ -779,7 +837,7 @@ int vali_resize(const vali_surface* src, const vali_surface* dst, int interpolat
     a.job[k].dpitch = dst->pitch[c];
   }
   hipStream_t s = as_stream(stream);
-  DeviceScope scope(stream_device(s));
+  VALI_ENTRY(s);
   return launch_resize(a, src->format, src->width, src->height, dst->width, dst->height, 1, interpolation, s);
 }
 
@@ -798,7 +856,7 @@ int vali_resize_batch(const vali_surface* d_src, const vali_surface* d_dst, int 
   a.d_src = d_src;
   a.d_dst = d_dst;
   hipStream_t s = as_stream(stream);
-  DeviceScope scope(stream_device(s));
+  VALI_ENTRY(s);
   return launch_resize(a, format, src_width, src_height, dst_width, dst_height, n, interpolation, s);
 }
 

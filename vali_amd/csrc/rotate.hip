@@ -506,7 +506,7 @@ static int launch_rotate(RotArgs& a, int fmt, int sw, int sh, int dw, int dh, do
   bool canonical = per_plane_shifts != 0 ||
                    (q90 && shift_x == 0.0 && shift_y == (double)(sw - 1) && a.njobs == 1) ||
                    (q270 && shift_y == 0.0 && shift_x == (double)(sh - 1) && a.njobs == 1);
-  static const bool no_tile = [] { const char* e = getenv("VALI_ROTATE_NO_TILE"); return e && e[0] == '1'; }();
+  const bool no_tile = tuning(VALI_TUNE_ROTATE_NO_TILE) == 1;
   const bool tiled = canonical && (q90 || q270) && !no_tile;
   // half turn with each plane's own (W-1, H-1) shifts: a reversal
   const bool half = q180 && !no_tile && sw == dw && sh == dh &&
@@ -593,7 +593,7 @@ int vali_rotate(const vali_surface* src, const vali_surface* dst, double angle, 
     a.job[k].dpitch = dst->pitch[c];
   }
   hipStream_t s = as_stream(stream);
-  DeviceScope scope(stream_device(s));
+  VALI_ENTRY(s);
   return launch_rotate(a, src->format, src->width, src->height, dst->width, dst->height, angle,
                        shift_x, shift_y, per_plane_shifts, 1, s);
 }
@@ -610,7 +610,7 @@ int vali_rotate_batch(const vali_surface* d_src, const vali_surface* d_dst, int 
   a.d_src = d_src;
   a.d_dst = d_dst;
   hipStream_t s = as_stream(stream);
-  DeviceScope scope(stream_device(s));
+  VALI_ENTRY(s);
   return launch_rotate(a, format, src_width, src_height, dst_width, dst_height, angle, shift_x,
                        shift_y, per_plane_shifts, n, s);
 }

@@ -5,9 +5,79 @@
 // a device is selected per call and a stream carries its device.
 #include "common.hpp"
 
+#include <dlfcn.h>
 #include <stdarg.h>
+#include <stdlib.h>
+
+#include <atomic>
+#include <mutex>
 
 namespace vali {
+
+// ---- the tuning table (include/vali_hip.h: vali_tuning_key) -- the ONLY place the library reads the environment
+namespace {
+struct TuneDef {
+  const char* env;
+  int def;
+};
+const TuneDef kTuneDefs[VALI_TUNE_COUNT] = {
+    {"VALI_NV12_ROWPAIRS", 0}, {"VALI_WAVES_PER_CU", 0},      {"VALI_NV12_DIRECT_STORE", 0}, {"VALI_RESIZE_FORCE_GATHER", 0},
+    {"VALI_RESIZE_POINT", 1},  {"VALI_UD_FORCE_GATHER", 0},   {"VALI_UD_DOWN2", 1},          {"VALI_UD_OCC5", 1},
+    {"VALI_ROTATE_NO_TILE", 0}, {"VALI_ROCTX", 0},            {"VALI_RESIZE_NO_SEPARABLE", 0}};
+std::atomic<int> g_tune[VALI_TUNE_COUNT];
+std::once_flag g_tune_once;
+
+typedef int (*roctx_push_fn)(const char*);
+typedef int (*roctx_pop_fn)(void);
+roctx_push_fn g_roctx_push = nullptr;
+roctx_pop_fn g_roctx_pop = nullptr;
+
+bool load_roctx() {
+  static const bool ok = [] {
+    for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+      void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (!h)
+        continue;
+      g_roctx_push = (roctx_push_fn)dlsym(h, "roctxRangePushA");
+      g_roctx_pop = (roctx_pop_fn)dlsym(h, "roctxRangePop");
+      if (g_roctx_push && g_roctx_pop)
+        return true;
+    }
+    g_roctx_push = nullptr;
+    g_roctx_pop = nullptr;
+    return false;
+  }();
+  return ok;
+}
+
+void tune_init() {
+  std::call_once(g_tune_once, [] {
+    for (int k = 0; k < VALI_TUNE_COUNT; ++k) {
+      const char* e = getenv(kTuneDefs[k].env);
+      g_tune[k].store(e && *e ? atoi(e) : kTuneDefs[k].def, std::memory_order_relaxed);
+    }
+    if (g_tune[VALI_TUNE_ROCTX].load(std::memory_order_relaxed) && !load_roctx())
+      g_tune[VALI_TUNE_ROCTX].store(0, std::memory_order_relaxed);
+  });
+}
+} // namespace
+
+int tuning(int key) {
+  tune_init();
+  return g_tune[key].load(std::memory_order_relaxed);
+}
+
+TraceRange::TraceRange(const char* name) {
+  if (tuning(VALI_TUNE_ROCTX) && g_roctx_push) {
+    g_roctx_push(name);
+    m_pushed = true;
+  }
+}
+
+TraceRange::~TraceRange() {
+  if (m_pushed && g_roctx_pop)
+    g_roctx_pop();
+}
 
 std::string& last_error() {
   static thread_local std::string s;
@@ -86,7 +156,22 @@ extern "C" {
 
 const char* vali_last_error(void) { return last_error().c_str(); }
 
-const char* vali_version(void) { return "vali_hip 0.1 (gfx950)"; }
+const char* vali_version(void) { return "vali_hip 0.2 (gfx950)"; }
+
+int vali_tuning_set(int key, int value) {
+  VALI_REQUIRE(key >= 0 && key < VALI_TUNE_COUNT, "unknown tuning key");
+  tune_init();
+  if (key == VALI_TUNE_ROCTX && value && !load_roctx())
+    return fail(VALI_ERR_UNSUPPORTED, "vali_tuning_set: no roctx library (librocprofiler-sdk-roctx / libroctx64) to trace with");
+  g_tune[key].store(value, std::memory_order_relaxed);
+  return VALI_OK;
+}
+
+int vali_tuning_get(int key, int* value) {
+  VALI_REQUIRE(value && key >= 0 && key < VALI_TUNE_COUNT, "unknown tuning key or null result");
+  *value = tuning(key);
+  return VALI_OK;
+}
 
 int vali_device_count(int* count) {
   VALI_REQUIRE(count, "null count");

@@ -1432,12 +1432,12 @@ static int launch_ud(UdArgs& a, int src_fmt, int src_w, int dst_w, int dst_h, in
   }
   // VALI_UD_FORCE_GATHER=1: the direct-gather form for every geometry, and no exact-2x kernels (tests
   // reach the gather code with ordinary sizes; it normally serves > 4x downscales only)
-  static const bool force_gather = [] { const char* e = getenv("VALI_UD_FORCE_GATHER"); return e && e[0] == '1'; }();
+  const bool force_gather = tuning(VALI_TUNE_UD_FORCE_GATHER) == 1;
   if (force_gather)
     staged = false;
   // exact 2x horizontal downscale of NV12: the division-free, LDS-free kernel (VALI_UD_DOWN2=0
   // keeps the general one, for A/B measurements)
-  static const bool down2_on = [] { const char* e = getenv("VALI_UD_DOWN2"); return !(e && e[0] == '0'); }();
+  const bool down2_on = tuning(VALI_TUNE_UD_DOWN2) != 0;
   if (down2_on && !force_gather && src_fmt == VALI_FMT_NV12 && src_w == dst_w && !(rot & 1) && kind != UD_RGB_F32 &&
       kind != UD_RGB_F32_PLANAR) { // 1:1 width: colour conversion with chroma interpolation
     a.map = make_tile_map((dst_w + kD2WaveW - 1) / kD2WaveW, (dst_h + kUdTileH - 1) / kUdTileH, (u32)n);
@@ -1468,7 +1468,7 @@ static int launch_ud(UdArgs& a, int src_fmt, int src_w, int dst_w, int dst_h, in
     VALI_LAUNCH_CHECK();
     return VALI_OK;
   }
-  static const bool occ5 = [] { const char* e = getenv("VALI_UD_OCC5"); return !(e && e[0] == '0'); }();
+  const bool occ5 = tuning(VALI_TUNE_UD_OCC5) != 0;
 #define VALI_UD_CASE(T, K)                                                                  \
   case K:                                                                                   \
     if (staged && K == UD_RGB_U8 && sizeof(T) == 1 && occ5)                                 \
@@ -1530,7 +1530,7 @@ int vali_ud_nv12(const vali_surface* src, const vali_surface* dst, vali_stream_t
   a.src = *src;
   a.dst = *dst;
   hipStream_t s = as_stream(stream);
-  DeviceScope scope(stream_device(s));
+  VALI_ENTRY(s);
   return launch_ud(a, src->format, src->width, dst->width, dst->height, dst->format, 1, s);
 }
 
@@ -1545,7 +1545,7 @@ int vali_ud_nv12_rot(const vali_surface* src, const vali_surface* dst, int quart
   a.src = *src;
   a.dst = *dst;
   hipStream_t s = as_stream(stream);
-  DeviceScope scope(stream_device(s));
+  VALI_ENTRY(s);
   return launch_ud(a, src->format, src->width, dst->width, dst->height, dst->format, 1, s, quarter_turns);
 }
 
@@ -1561,7 +1561,7 @@ int vali_ud_nv12_rot_batch(const vali_surface* d_src, const vali_surface* d_dst,
   a.d_src = d_src;
   a.d_dst = d_dst;
   hipStream_t s = as_stream(stream);
-  DeviceScope scope(stream_device(s));
+  VALI_ENTRY(s);
   return launch_ud(a, src_format, src_width, dst_width, dst_height, dst_format, n, s, quarter_turns);
 }
 
@@ -1577,7 +1577,7 @@ int vali_ud_nv12_batch(const vali_surface* d_src, const vali_surface* d_dst, int
   a.d_src = d_src;
   a.d_dst = d_dst;
   hipStream_t s = as_stream(stream);
-  DeviceScope scope(stream_device(s));
+  VALI_ENTRY(s);
   return launch_ud(a, src_format, src_width, dst_width, dst_height, dst_format, n, s);
 }
 

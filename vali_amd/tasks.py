@@ -254,8 +254,10 @@ _CONVERSIONS = {
 class _SurfaceTask:
     def __init__(self, gpu_id: int, stream=None):
         self._gpu_id = int(gpu_id)
-        self._stream = (int(stream) if stream is not None
-                        else HipResMgr.Instance().GetStream(self._gpu_id))
+        # stream=None and the NULL stream both mean "this GPU's stream from the resource manager": a null
+        # hipStream_t carries no device, so a task built with (gpu_id=1, stream=0) would otherwise launch on
+        # whatever device happens to be current on the calling thread
+        self._stream = (int(stream) if stream else HipResMgr.Instance().GetStream(self._gpu_id))
         self._event = CudaStreamEvent(self._stream, self._gpu_id)
         # Memo of recent successful single-surface calls: (src descriptor, dst descriptor, extra
         # key...) -> (C-ABI entry, arguments between the descriptors and the stream).
