@@ -292,6 +292,21 @@ VALI_API int vali_resize_batch(const vali_surface* d_src, const vali_surface* d_
                                int format, int src_width, int src_height, int dst_width,
                                int dst_height, int interpolation, vali_stream_t stream);
 
+/*
+ * UDPlanar: every plane of a planar 4:2:0 surface resized to the size of the matching plane of a 4:4:4
+ * surface (chroma 2x up + the common scale), all three planes in ONE launch.  Replaces UDPlanar
+ * (reference: src/TC/src/UDSurface.cpp:33-93, three nppiResize calls) for the planar rows of
+ * UDSurface::SupportedConversions() (:117-133): YUV420 -> YUV444, YUV420_10BIT -> YUV444_10BIT; any other
+ * pair returns VALI_ERR_UNSUPPORTED.  The reference passes NPPI_INTER_LANCZOS (:45,72): pass
+ * VALI_INTERP_LANCZOS for its result; the other modes are accepted too.  As in the reference the
+ * destination size alone defines the scale.
+ */
+VALI_API int vali_ud_planar(const vali_surface* src, const vali_surface* dst, int interpolation,
+                            vali_stream_t stream);
+VALI_API int vali_ud_planar_batch(const vali_surface* d_src, const vali_surface* d_dst, int n,
+                                  int src_format, int dst_format, int src_width, int src_height,
+                                  int dst_width, int dst_height, int interpolation, vali_stream_t stream);
+
 /* ---- rotation: replaces nppiRotate_{8u,16u,32f}_{C1,C3}R_Ctx ------------------------ */
 
 /*

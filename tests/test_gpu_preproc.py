@@ -41,7 +41,7 @@ def chain_gpu(vali, gpu, src, dw, dh, cc, div, mean, std):
     cur = src
     if (sw, sh) != (dw, dh):
         small = vali.Surface.Make(vali.NV12, dw, dh, gpu)
-        assert vali.PySurfaceResizer(vali.NV12, gpu).Run(cur, small)[0]
+        assert vali.PySurfaceResizer(vali.NV12, gpu, interpolation=vali.Interpolation.LINEAR).Run(cur, small)[0]
         cur = small
     cvt = vali.PySurfaceConverter(gpu)
     rgb = vali.Surface.Make(vali.RGB, dw, dh, gpu)
@@ -149,7 +149,7 @@ def test_preproc_u8_equals_resizer_plus_converter(vali, gpu, oracle, dst_fmt, ge
     cur = src
     if (sw, sh) != (dw, dh):
         cur = vali.Surface.Make(vali.NV12, dw, dh, gpu)
-        assert vali.PySurfaceResizer(vali.NV12, gpu).Run(src, cur)[0]
+        assert vali.PySurfaceResizer(vali.NV12, gpu, interpolation=vali.Interpolation.LINEAR).Run(src, cur)[0]
     ref = vali.Surface.Make(pf, dw, dh, gpu)
     assert vali.PySurfaceConverter(gpu).Run(cur, ref, cc)[0]
     assert np.array_equal(got, download(vali, gpu, ref, np.uint8))

@@ -19,7 +19,8 @@ def roundtrip(vali, gpu, fmt, host, sw, sh, dw, dh, is_async=False, interp=None)
     src = vali.Surface.Make(pf, sw, sh, gpu)
     dst = vali.Surface.Make(pf, dw, dh, gpu)
     assert vali.PyFrameUploader(gpu).Run(host.view(np.uint8), src)[0]
-    rs = vali.PySurfaceResizer(pf, gpu) if interp is None else vali.PySurfaceResizer(pf, gpu, interpolation=interp)
+    # (the task's own default is the reference's filter, Lanczos: test_default_filter_is_the_references)
+    rs = vali.PySurfaceResizer(pf, gpu, interpolation=vali.Interpolation.LINEAR if interp is None else interp)
     ok, info = rs.RunAsync(src, dst) if is_async else rs.Run(src, dst)
     assert ok and info == vali.TaskExecInfo.SUCCESS
     if is_async:
@@ -54,6 +55,23 @@ def test_resize_nv12_real_frames(vali, gpu, oracle, is_async):
         assert np.array_equal(got, oracle.resize_surface(frame, "NV12", 424, 232, 212, 116))
 
 
+def test_default_filter_is_the_references(vali, gpu, oracle):
+    """PySurfaceResizer(format, gpu_id) -- the reference's constructor -- resizes with the reference's only
+    filter, Lanczos (NPPI_INTER_LANCZOS at every call site, TaskResizeSurface.cpp:67,116,224,273)."""
+    assert vali.PySurfaceResizer(vali.NV12, gpu).Interpolation == vali.Interpolation.LANCZOS
+    sw, sh, dw, dh = 848, 464, 640, 360
+    rng = np.random.default_rng(12)
+    host = rng.integers(0, 256, sw * sh * 3 // 2, dtype=np.uint8)
+    src = vali.Surface.Make(vali.NV12, sw, sh, gpu)
+    dst = vali.Surface.Make(vali.NV12, dw, dh, gpu)
+    assert vali.PyFrameUploader(gpu).Run(host, src)[0]
+    assert vali.PySurfaceResizer(vali.NV12, gpu).Run(src, dst) == (True, vali.TaskExecInfo.SUCCESS)
+    out = np.zeros(dst.HostSize, np.uint8)
+    assert vali.PySurfaceDownloader(gpu).Run(dst, out)[0]
+    assert np.array_equal(out, oracle.resize_surface(host, "NV12", sw, sh, dw, dh, "lanczos"))
+    assert not np.array_equal(out, oracle.resize_surface(host, "NV12", sw, sh, dw, dh, "linear"))
+
+
 def test_resize_errors(vali, gpu):
     with pytest.raises(RuntimeError):                      # TaskResizeSurface.cpp:307-308
         vali.PySurfaceResizer(vali.PixelFormat.UNDEFINED if False else vali.PixelFormat.GRAY12, gpu)
@@ -66,7 +84,7 @@ def test_resize_errors(vali, gpu):
 def test_resize_batch_2160p_to_720p(vali, gpu, oracle):
     """BASELINE config 3 geometry (batch reduced to 4 for the oracle's sake)."""
     sw, sh, dw, dh, n = 3840, 2160, 1280, 720, 4
-    rs = vali.PySurfaceResizer(vali.NV12, gpu)
+    rs = vali.PySurfaceResizer(vali.NV12, gpu, interpolation=vali.Interpolation.LINEAR)
     rng = np.random.default_rng(5)
     frames = [rng.integers(0, 256, sw * sh * 3 // 2, dtype=np.uint8) for _ in range(2)]
     srcs = [vali.Surface.Make(vali.NV12, sw, sh, gpu) for _ in range(n)]

@@ -83,26 +83,81 @@ def test_batch_2160p_to_1080p(vali, gpu, oracle):
         assert np.array_equal(out, oracle.ud_nv12(f, sw, sh, "NV12", dw, dh, "RGB").reshape(-1))
 
 
-@pytest.mark.parametrize("src_fmt,dst_fmt,dt", [("YUV420", "YUV444", np.uint8),
-                                                ("YUV420_10bit", "YUV444_10bit", np.uint16)])
-def test_planar_sources(vali, gpu, oracle, src_fmt, dst_fmt, dt):
-    """reference tests/test_PySurfaceUD.py:71-132 (CPU-decoded planar sources)."""
-    sw, sh, dw, dh = 848, 464, 640, 360
-    rng = np.random.default_rng(8)
-    src = vali.Surface.Make(vali.PixelFormat[src_fmt], sw, sh, gpu)
-    host = (rng.random(src.HostSize // np.dtype(dt).itemsize) * 1000).astype(dt)
-    assert vali.PyFrameUploader(gpu).Run(host.view(np.uint8), src)[0]
-    dst = vali.Surface.Make(vali.PixelFormat[dst_fmt], dw, dh, gpu)
-    assert vali.PySurfaceUD(gpu).Run(src, dst) == (True, vali.TaskExecInfo.SUCCESS)
-    out = np.zeros(dst.HostSize, np.uint8)
-    assert vali.PySurfaceDownloader(gpu).Run(dst, out)[0]
-    got = out.view(dt)
+def _planar_want(oracle, host, sw, sh, dw, dh):
     off, want = 0, []
     for pw, ph in ((sw, sh), (sw // 2, sh // 2), (sw // 2, sh // 2)):
         plane = np.ascontiguousarray(host[off: off + pw * ph].reshape(ph, pw))
-        want.append(oracle.resize_plane(plane, 1, dw, dh).reshape(-1))
+        want.append(oracle.resize_plane(plane, 1, dw, dh, "lanczos").reshape(-1))
         off += pw * ph
-    assert np.array_equal(got, np.concatenate(want))
+    return np.concatenate(want)
+
+
+@pytest.mark.parametrize("geom", [(848, 464, 640, 360), (640, 360, 1280, 720), (424, 232, 424, 232), (130, 70, 58, 34),
+                                  (1920, 1080, 250, 251)])
+@pytest.mark.parametrize("src_fmt,dst_fmt,dt", [("YUV420", "YUV444", np.uint8),
+                                                ("YUV420_10bit", "YUV444_10bit", np.uint16)])
+def test_planar_sources(vali, gpu, oracle, src_fmt, dst_fmt, dt, geom):
+    """UDPlanar (reference tests/test_PySurfaceUD.py:71-132, CPU-decoded planar sources; UDSurface.cpp:33-93):
+    every plane through the reference's filter, Lanczos, to the size of the matching destination plane."""
+    sw, sh, dw, dh = geom
+    rng = np.random.default_rng(8)
+    src = vali.Surface.Make(vali.PixelFormat[src_fmt], sw, sh, gpu)
+    host = (rng.random(src.HostSize // np.dtype(dt).itemsize) * (255 if dt == np.uint8 else 1023)).astype(dt)
+    assert vali.PyFrameUploader(gpu).Run(host.view(np.uint8), src)[0]
+    dst = vali.Surface.Make(vali.PixelFormat[dst_fmt], dw, dh, gpu)
+    ud = vali.PySurfaceUD(gpu)
+    want = _planar_want(oracle, host, sw, sh, dw, dh)
+    for run in (ud.Run, ud.RunAsync, ud.RunAsync):            # the third call is served by the task's memo
+        assert vali.PyFrameUploader(gpu).Run(np.zeros(dst.HostSize, np.uint8), dst)[0]
+        assert run(src, dst) == (True, vali.TaskExecInfo.SUCCESS)
+        ev = vali.CudaStreamEvent(ud.Stream, gpu)
+        ev.Record()
+        ev.Wait()
+        out = np.zeros(dst.HostSize, np.uint8)
+        assert vali.PySurfaceDownloader(gpu).Run(dst, out)[0]
+        assert np.array_equal(out.view(dt), want)
+
+
+def test_planar_sources_batch(vali, gpu, oracle):
+    sw, sh, dw, dh, n = 424, 232, 640, 360, 5
+    ud = vali.PySurfaceUD(gpu)
+    srcs = [vali.Surface.Make(vali.YUV420, sw, sh, gpu) for _ in range(n)]
+    dsts = [vali.Surface.Make(vali.YUV444, dw, dh, gpu) for _ in range(n)]
+    hosts = [np.random.default_rng(40 + i).integers(0, 256, srcs[0].HostSize, dtype=np.uint8) for i in range(n)]
+    for h, s in zip(hosts, srcs):
+        assert vali.PyFrameUploader(gpu).Run(h, s)[0]
+    assert ud.RunBatch(srcs, dsts) == (True, vali.TaskExecInfo.SUCCESS)
+    for h, d in zip(hosts, dsts):
+        out = np.zeros(d.HostSize, np.uint8)
+        assert vali.PySurfaceDownloader(gpu).Run(d, out)[0]
+        assert np.array_equal(out, _planar_want(oracle, h, sw, sh, dw, dh))
+    bad = [vali.Surface.Make(vali.YUV444, sw, sh, gpu) for _ in range(n)]
+    assert ud.RunBatch(bad, dsts) == (False, vali.TaskExecInfo.NOT_SUPPORTED)
+
+
+def test_planar_ud_matches_the_reference_golden(vali, gpu):
+    """The reference's own UDPlanar output (tests/data/640x360 YUV420 -> YUV444, NPP Lanczos) against this
+    task fed with the frame re-derived from frame_0.jpg: luma >= 45 dB after the frame's common offset is
+    removed (JPEG-noise floor; tests/test_oracle_reference_pins.py explains the offset and shows that every
+    other filter / grid scores lower)."""
+    PIL = pytest.importorskip("PIL.Image")
+    from conftest import GOLDEN
+    rgb = np.asarray(PIL.open(GOLDEN / "frame_0.jpg")).astype(np.float64)
+    y = np.clip(np.rint(16 + 0.1826 * rgb[..., 0] + 0.6142 * rgb[..., 1] + 0.0620 * rgb[..., 2]), 0, 255).astype(np.uint8)
+    u = np.clip(np.rint(128 - 0.1006 * rgb[..., 0] - 0.3386 * rgb[..., 1] + 0.4392 * rgb[..., 2]), 0, 255).astype(np.uint8)
+    v = np.clip(np.rint(128 + 0.4392 * rgb[..., 0] - 0.3989 * rgb[..., 1] - 0.0403 * rgb[..., 2]), 0, 255).astype(np.uint8)
+    host = np.concatenate([y.reshape(-1), u[0::2, 0::2].reshape(-1), v[0::2, 0::2].reshape(-1)])
+    src = vali.Surface.Make(vali.YUV420, 848, 464, gpu)
+    dst = vali.Surface.Make(vali.YUV444, 640, 360, gpu)
+    assert vali.PyFrameUploader(gpu).Run(host, src)[0]
+    assert vali.PySurfaceUD(gpu).Run(src, dst)[0]
+    out = np.zeros(dst.HostSize, np.uint8)
+    assert vali.PySurfaceDownloader(gpu).Run(dst, out)[0]
+    got = out.reshape(3, 360, 640)[:, :120].astype(np.float64)
+    gold = np.load(GOLDEN / "ud_640x360_yuv420_rows120.npz")["yuv444"].astype(np.float64)
+    for c, floor in ((0, 44.5), (1, 47.0), (2, 47.0)):
+        d = (got[c] - gold[c])[4:-4, 4:-4]
+        assert 10 * np.log10(255.0 ** 2 / np.mean((d - d.mean()) ** 2)) >= floor, c
 
 
 # ---- fused UD + quarter-turn rotation (BASELINE config 4 as one pass) ---------------------------

@@ -176,3 +176,15 @@ def test_keyword_names_of_the_hot_path_match_the_reference():
     for (cls, name), names in expect.items():
         params = [p for p in inspect.signature(getattr(cls, name)).parameters if p != "self"]
         assert params[:len(names)] == names, (cls.__name__, name, params)
+
+
+def test_resizer_default_is_the_references_filter():
+    """drop-in callers write PySurfaceResizer(format, gpu_id[, stream]) and must get NPPI_INTER_LANCZOS
+    (TaskResizeSurface.cpp:67); bilinear (BASELINE config 3) and bicubic are explicit opt-ins"""
+    import inspect
+    import vali_amd as vali
+
+    sig = inspect.signature(vali.PySurfaceResizer.__init__)
+    assert list(sig.parameters)[1:4] == ["format", "gpu_id", "stream"]
+    assert sig.parameters["interpolation"].default == vali.Interpolation.LANCZOS
+    assert int(vali.Interpolation.LANCZOS) == 16 and int(vali.Interpolation.LINEAR) == 1 and int(vali.Interpolation.CUBIC) == 4

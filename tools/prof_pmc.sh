@@ -1,0 +1,30 @@
+#!/bin/bash
+# usage: tools/prof_pmc.sh TAG "<command>" : kernel stats + several PMC passes (each its own run), csv under gpurun_out/prof_TAG
+set -u
+TAG=$1; CMD=$2
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/prof_$TAG; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
+i=0
+for SET in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM" "SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL" "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  rocprofv3 --pmc $SET --output-format csv -d $OUT/pmc$i -o p -- $CMD > $OUT/pmc$i.log 2>&1
+done
+python3 - <<PY
+import csv, glob, collections
+out = "$OUT"
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.Counter()
+for f in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"][:70]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        calls[(k, r["Counter_Name"])] += 1
+for k, d in agg.items():
+    if "taps" in k or "resize" in k or "ud_" in k or "rotate" in k or "nv12" in k:
+        print(k)
+        for c, v in sorted(d.items()):
+            print("   %-28s %16.0f  per launch %14.0f" % (c, v, v / max(calls[(k, c)], 1)))
+for f in glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True):
+    print(open(f).read()[:1500])
+PY

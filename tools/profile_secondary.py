@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""HBM traffic of the secondary kernels from rocprofv3 PMC passes (run on the GPU box through gpurun).
+
+For each secondary config of tools/bench_configs.py: one `--kernel-trace --stats` run and two counter runs
+(FETCH_SIZE, WRITE_SIZE -- they do not fit one pass; never combined with tracing).  Per kernel the BATCH
+launch is the dispatch with the largest counter value (the same kernel is also launched on single frames).
+  HBM read  = FETCH_SIZE [KiB] x 1024 x 2   (gfx950 tallies the 128-byte requests of wide coalesced reads at
+                                             64 B: MI355X_MICROARCH.md "HBM"; calibrated on the headline kernel,
+                                             whose corrected sum equals its algorithmic bytes to 4 digits)
+  HBM write = WRITE_SIZE [KiB] x 1024
+Writes gpurun_out/r02_secondary_traffic.json (copied to profiles/ and read by bench_configs.roofline()) and a
+markdown table.
+"""
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+ROOT = Path(os.environ.get("GRAFT_REPO_ROOT", Path(__file__).resolve().parent.parent))
+OUT = ROOT / "gpurun_out" / "prof_r02_secondary"
+# config key -> (bench_configs function, kernel-name substring, frames per launch)
+KEYS = {
+    "hl1080": ("hl1080", "k_nv12_rgb8", 1024),
+    "cfg3": ("cfg3", "k_resize<", 64),
+    "interp_bilinear": ("interp", "k_resize<", 64),
+    "interp_lanczos": ("interp", "k_resize_taps<", 64),
+    "cfg4_ud": ("cfg4", "k_ud_down2<", 64),
+    "cfg4_rot": ("cfg4", "k_rotate_tile", 64),
+    "cfg4_fused": ("cfg4", "k_ud_down2_t<", 64),
+}
+
+
+def run(cmd, log):
+    with open(log, "w") as fh:
+        subprocess.run(cmd, stdout=fh, stderr=subprocess.STDOUT, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+
+
+def collect(cfg):
+    d = OUT / cfg
+    d.mkdir(parents=True, exist_ok=True)
+    cmd = [sys.executable, str(ROOT / "tools" / "bench_configs.py"), cfg]
+    run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", str(d / "trace"), "-o", "t", "--"] + cmd, d / "trace.log")
+    run(["rocprofv3", "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", str(d / "fetch"), "-o", "p", "--"] + cmd, d / "fetch.log")
+    run(["rocprofv3", "--pmc", "WRITE_SIZE", "--output-format", "csv", "-d", str(d / "write"), "-o", "p", "--"] + cmd, d / "write.log")
+    run(cmd, d / "unprofiled.log")
+    pmc = defaultdict(lambda: defaultdict(list))
+    for name, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+        for f in glob.glob(str(d / sub / "**" / "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] == name:
+                    pmc[r["Kernel_Name"]][name].append(float(r["Counter_Value"]))
+    stats = {}
+    for f in glob.glob(str(d / "trace" / "**" / "*kernel_stats.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            stats[r["Name"]] = r
+    return pmc, stats
+
+
+def main():
+    done, table, result = {}, [], {}
+    for key, (cfg, needle, frames) in KEYS.items():
+        if cfg not in done:
+            done[cfg] = collect(cfg)
+        pmc, stats = done[cfg]
+        names = [k for k in pmc if needle in k]
+        if not names:
+            continue
+        k = max(names, key=lambda n: max(pmc[n]["FETCH_SIZE"], default=0))
+        rd = max(pmc[k]["FETCH_SIZE"], default=0) * 1024 * 2
+        wr = max(pmc[k]["WRITE_SIZE"], default=0) * 1024
+        st = stats.get(k, {})
+        result[key] = {"kernel": k.replace("void vali::", "").split("(")[0], "frames": frames,
+                       "hbm_read_bytes_per_launch": rd, "hbm_written_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
+                       "max_ns": float(st.get("MaxNs", 0) or 0), "calls": int(st.get("Calls", 0) or 0),
+                       "source": "profiles/r02_secondary_traffic.json (rocprofv3 --pmc FETCH_SIZE x1024 x2 + WRITE_SIZE x1024, "
+                                 "separate passes, batch launch = largest dispatch)"}
+        table.append(f"| {key} | `{result[key]['kernel']}` | {frames} | {rd:.5g} | {wr:.5g} | {rd + wr:.5g} | {st.get('MaxNs', '')} |")
+    if "cfg4_ud" in result and "cfg4_rot" in result:
+        a, b = result["cfg4_ud"], result["cfg4_rot"]
+        result["cfg4_chain"] = {"kernel": "k_ud_down2 + k_rotate_tile", "frames": 64,
+                                "hbm_bytes_per_launch": a["hbm_bytes_per_launch"] + b["hbm_bytes_per_launch"], "source": a["source"]}
+    (ROOT / "gpurun_out" / "r02_secondary_traffic.json").write_text(json.dumps(result, indent=1) + "\n")
+    md = ["# r02: HBM traffic of the secondary kernels (rocprofv3 PMC, tools/profile_secondary.py)", "",
+          "| config | kernel | frames per launch | HBM read B | HBM written B | sum | longest launch ns |", "|---|---|---|---|---|---|---|"] + table
+    md += ["", "un-profiled bench lines of the same box:", "", "```"]
+    for cfg in done:
+        md += [l for l in (OUT / cfg / "unprofiled.log").read_text().splitlines() if l.startswith("{")]
+    md += ["```", ""]
+    (ROOT / "gpurun_out" / "r02_secondary_traffic.md").write_text("\n".join(md))
+    print("\n".join(md)[:5000])
+
+
+if __name__ == "__main__":
+    main()

@@ -81,14 +81,15 @@ inline bool planes_fit_32bit(const vali_surface& s) {
 // First lines of every operator entry point: trace range, then the device of the stream (the current device
 // for the null stream) is made current for the call.  No usable device -> VALI_ERR_NO_DEVICE, never a silent
 // launch on whatever happens to be current.
-#define VALI_ENTRY(stream)                                                                   \
-  ::vali::TraceRange _trace(__func__);                                                        \
+#define VALI_ENTRY_NAMED(stream, name)                                                       \
+  ::vali::TraceRange _trace(name);                                                            \
   const int _dev = ::vali::stream_device(stream);                                             \
   if (_dev < 0)                                                                               \
-    return ::vali::fail(VALI_ERR_NO_DEVICE, "%s: no usable HIP device", __func__);            \
+    return ::vali::fail(VALI_ERR_NO_DEVICE, "%s: no usable HIP device", name);                \
   ::vali::DeviceScope scope(_dev);                                                            \
   if (!scope.ok())                                                                            \
-    return ::vali::fail(VALI_ERR_NO_DEVICE, "%s: cannot select device %d", __func__, _dev)
+    return ::vali::fail(VALI_ERR_NO_DEVICE, "%s: cannot select device %d", name, _dev)
+#define VALI_ENTRY(stream) VALI_ENTRY_NAMED(stream, __func__)
 
 #define VALI_HIP_CHECK(expr)                                                   \
   do {                                                                         \

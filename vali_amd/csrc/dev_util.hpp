@@ -308,7 +308,8 @@ __device__ __forceinline__ SurfRef load_surface(const vali_surface* arr, const v
 // ---------------------------------------------------------------------------
 struct PlaneJob {
   int comp;           // component index in vali_surface.plane[] / pitch[]
-  int sub_x, sub_y;   // log2 subsampling relative to the surface size
+  int sub_x, sub_y;   // log2 subsampling of the DESTINATION plane relative to the surface size
+  int ssub_x, ssub_y; // the same for the SOURCE plane (differs only for UDPlanar: YUV420 -> YUV444)
   int channels;       // interleaved channels in the plane
   u32 first_tile, tiles_x;
   float shift_x, shift_y; // rotate only
@@ -339,7 +340,7 @@ __device__ __forceinline__ PlaneView plane_view(const vali_surface* d_src, const
   } else {
     v.sp = job.sp; v.dp = job.dp; v.spitch = job.spitch; v.dpitch = job.dpitch;
   }
-  v.sw = sw >> job.sub_x; v.sh = sh >> job.sub_y;
+  v.sw = sw >> job.ssub_x; v.sh = sh >> job.ssub_y;
   v.dw = dw >> job.sub_x; v.dh = dh >> job.sub_y;
   return v;
 }

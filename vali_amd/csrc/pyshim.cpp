@@ -454,6 +454,18 @@ PYBIND11_MODULE(_vali_shim, m) {
                                    format, src_w, src_h, dst_w, dst_h, interp, P(stream));
         },
         py::call_guard<py::gil_scoped_release>());
+  m.def("ud_planar",
+        [](const SurfaceDesc& src, const SurfaceDesc& dst, int interp, uintptr_t stream) {
+          return vali_ud_planar(&src.s, &dst.s, interp, P(stream));
+        },
+        py::call_guard<py::gil_scoped_release>());
+  m.def("ud_planar_batch",
+        [](uintptr_t d_src, uintptr_t d_dst, int n, int src_format, int dst_format, int src_w, int src_h,
+           int dst_w, int dst_h, int interp, uintptr_t stream) {
+          return vali_ud_planar_batch((const vali_surface*)P(d_src), (const vali_surface*)P(d_dst), n,
+                                      src_format, dst_format, src_w, src_h, dst_w, dst_h, interp, P(stream));
+        },
+        py::call_guard<py::gil_scoped_release>());
   m.attr("INTERP_LINEAR") = (int)VALI_INTERP_LINEAR;
   m.attr("INTERP_CUBIC") = (int)VALI_INTERP_CUBIC;
   m.attr("INTERP_LANCZOS") = (int)VALI_INTERP_LANCZOS;

@@ -40,6 +40,7 @@ struct ResizeArgs {
   int njobs;
   TileMap map;
   int force_gather; // VALI_RESIZE_FORCE_GATHER=1: no LDS staging (tests reach the gather forms with ordinary sizes)
+  int variant;      // A/B experiment bits (temporary)
 };
 
 template <typename T> __device__ __forceinline__ float rs_load(const uint8_t* row, int idx) {
@@ -462,7 +463,7 @@ template <int TAPS> struct alignas(16) LzRing<3, TAPS> { // packed 3-channel for
 template <typename T, int C, int MAXC, int TAPS>
 __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int sw, int sh,
                                              uint8_t* dp, int dpitch, int dw, int dh, u32 tx,
-                                             u32 ty, LzStage* stage_all, LzRing<MAXC, TAPS>* ring_all) {
+                                             u32 ty, LzStage* stage_all, LzRing<MAXC, TAPS>* ring_all, int variant = 7) {
   constexpr int kBefore = LzTap<TAPS>::kBefore;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -552,15 +553,35 @@ __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int 
 #pragma unroll
       for (int q = 0; q < 2; ++q) { // one pixel pair at a time: bounds the live registers
         float t0[TAPS][C], t1[TAPS][C];
-        read_taps<T, C, TAPS>(st.row + lo[2 * q], t0);
-        read_taps<T, C, TAPS>(st.row + lo[2 * q + 1], t1);
+        if (variant & 1) {
+          read_taps<T, C, TAPS>(st.row + lo[2 * q], t0);
+          read_taps<T, C, TAPS>(st.row + lo[2 * q + 1], t1);
+        } else {
+#pragma unroll
+          for (int k = 0; k < TAPS; ++k)
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) {
+              t0[k][ch] = (float)((const T*)(st.row + lo[2 * q] + k * PB))[ch];
+              t1[k][ch] = (float)((const T*)(st.row + lo[2 * q + 1] + k * PB))[ch];
+            }
+        }
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) {
-          v2f32 h = wq[q][0] * (v2f32){t0[0][ch], t1[0][ch]};
+          if (variant & 2) {
+            v2f32 h = wq[q][0] * (v2f32){t0[0][ch], t1[0][ch]};
 #pragma unroll
-          for (int k = 1; k < TAPS; ++k)
-            h = __builtin_elementwise_fma(wq[q][k], (v2f32){t0[k][ch], t1[k][ch]}, h);
-          hv[ch][2 * q] = h.x; hv[ch][2 * q + 1] = h.y;
+            for (int k = 1; k < TAPS; ++k)
+              h = __builtin_elementwise_fma(wq[q][k], (v2f32){t0[k][ch], t1[k][ch]}, h);
+            hv[ch][2 * q] = h.x; hv[ch][2 * q + 1] = h.y;
+          } else {
+            float h0 = wq[q][0].x * t0[0][ch], h1 = wq[q][0].y * t1[0][ch];
+#pragma unroll
+            for (int k = 1; k < TAPS; ++k) {
+              h0 = __builtin_fmaf(wq[q][k].x, t0[k][ch], h0);
+              h1 = __builtin_fmaf(wq[q][k].y, t1[k][ch], h1);
+            }
+            hv[ch][2 * q] = h0; hv[ch][2 * q + 1] = h1;
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -611,8 +632,15 @@ __device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int 
               q01 = (v2f32){hq[r][0][ch], hq[r][1][ch]}; q23 = (v2f32){hq[r][2][ch], hq[r][3][ch]};
             }
             const v2f32 wr = (v2f32){cy.w[r], cy.w[r]};
-            v01 = r == 0 ? wr * q01 : __builtin_elementwise_fma(wr, q01, v01);
-            v23 = r == 0 ? wr * q23 : __builtin_elementwise_fma(wr, q23, v23);
+            if (variant & 4) {
+              v01 = r == 0 ? wr * q01 : __builtin_elementwise_fma(wr, q01, v01);
+              v23 = r == 0 ? wr * q23 : __builtin_elementwise_fma(wr, q23, v23);
+            } else {
+              v01.x = r == 0 ? cy.w[r] * q01.x : __builtin_fmaf(cy.w[r], q01.x, v01.x);
+              v01.y = r == 0 ? cy.w[r] * q01.y : __builtin_fmaf(cy.w[r], q01.y, v01.y);
+              v23.x = r == 0 ? cy.w[r] * q23.x : __builtin_fmaf(cy.w[r], q23.x, v23.x);
+              v23.y = r == 0 ? cy.w[r] * q23.y : __builtin_fmaf(cy.w[r], q23.y, v23.y);
+            }
           }
           res[0][ch] = v01.x; res[1][ch] = v01.y; res[2][ch] = v23.x; res[3][ch] = v23.y;
         }
@@ -711,11 +739,11 @@ __global__ void __launch_bounds__(kBlock) k_resize_taps(const ResizeArgs a) {
   __shared__ LzRing<MAXC, TAPS> ring[kWavesPerBlock];
   const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
   if (MAXC >= 3 && job.channels == 3)
-    lanczos_tile<T, 3, MAXC, TAPS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.force_gather ? nullptr : stage, ring);
+    lanczos_tile<T, 3, MAXC, TAPS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.force_gather ? nullptr : stage, ring, a.variant);
   else if (MAXC >= 2 && job.channels == 2)
-    lanczos_tile<T, 2, MAXC, TAPS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.force_gather ? nullptr : stage, ring);
+    lanczos_tile<T, 2, MAXC, TAPS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.force_gather ? nullptr : stage, ring, a.variant);
   else
-    lanczos_tile<T, 1, MAXC, TAPS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.force_gather ? nullptr : stage, ring);
+    lanczos_tile<T, 1, MAXC, TAPS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.force_gather ? nullptr : stage, ring, a.variant);
 }
 
 template <typename T, int MAXC> constexpr auto k_resize_point = k_resize<T, MAXC, true>;
@@ -725,7 +753,7 @@ template <typename T, int MAXC> constexpr auto k_resize_cubic = k_resize_taps<T,
 // plane jobs per pixel format: which components, their subsampling and channel count
 static int resize_jobs(int fmt, ResizeJob* j, int* elem) {
   auto set = [&](int k, int comp, int sx, int sy, int ch) {
-    j[k].comp = comp; j[k].sub_x = sx; j[k].sub_y = sy; j[k].channels = ch;
+    j[k].comp = comp; j[k].sub_x = j[k].ssub_x = sx; j[k].sub_y = j[k].ssub_y = sy; j[k].channels = ch;
   };
   *elem = 1;
   switch (fmt) {
@@ -745,10 +773,32 @@ static int resize_jobs(int fmt, ResizeJob* j, int* elem) {
   }
 }
 
+// UDPlanar (reference: src/TC/src/UDSurface.cpp:33-93, the planar rows of UDSurface::SupportedConversions(),
+// :117-133): the planes of a 4:2:0 surface, each resized to the size of the matching plane of a 4:4:4 surface.
+// The jobs are the destination format's, with the source planes' own subsampling.
+static bool ud_planar_pair(int src_fmt, int dst_fmt) {
+  return (src_fmt == VALI_FMT_YUV420 && dst_fmt == VALI_FMT_YUV444) ||
+         (src_fmt == VALI_FMT_YUV420_10BIT && dst_fmt == VALI_FMT_YUV444_10BIT);
+}
+static int resize_jobs_pair(int src_fmt, int dst_fmt, ResizeJob* j, int* elem) {
+  const int n = resize_jobs(dst_fmt, j, elem);
+  if (src_fmt != dst_fmt) {
+    ResizeJob sj[3];
+    int selem = 1;
+    if (resize_jobs(src_fmt, sj, &selem) != n || selem != *elem)
+      return 0;
+    for (int k = 0; k < n; ++k) {
+      j[k].ssub_x = sj[k].ssub_x;
+      j[k].ssub_y = sj[k].ssub_y;
+    }
+  }
+  return n;
+}
+
 static int launch_resize(ResizeArgs& a, int fmt, int src_w, int src_h, int dst_w, int dst_h, int n, int interp,
-                         hipStream_t stream) {
+                         hipStream_t stream, int src_fmt = -1) {
   int elem = 1;
-  a.njobs = resize_jobs(fmt, a.job, &elem);
+  a.njobs = resize_jobs_pair(src_fmt < 0 ? fmt : src_fmt, fmt, a.job, &elem);
   if (!a.njobs)
     return fail(VALI_ERR_UNSUPPORTED, "resize: unsupported pixel format %d", fmt);
   u32 total = 0;
@@ -763,7 +813,7 @@ static int launch_resize(ResizeArgs& a, int fmt, int src_w, int src_h, int dst_w
     const int dw = dst_w >> a.job[k].sub_x, dh = dst_h >> a.job[k].sub_y;
     if (dw <= 0 || dh <= 0)
       return fail(VALI_ERR_INVALID_ARG, "resize: destination too small for its chroma planes");
-    const int sw = src_w >> a.job[k].sub_x, sh = src_h >> a.job[k].sub_y;
+    const int sw = src_w >> a.job[k].ssub_x, sh = src_h >> a.job[k].ssub_y;
     if (sw <= 0 || sh <= 0)   // a 1-pixel-wide 4:2:0 source has no chroma column to sample
       return fail(VALI_ERR_INVALID_ARG, "resize: source too small for its chroma planes");
     integer_scale = integer_scale && sw % dw == 0 && sh % dh == 0 && sw < (1 << 23) &&
@@ -786,6 +836,7 @@ static int launch_resize(ResizeArgs& a, int fmt, int src_w, int src_h, int dst_w
   const bool filtered = interp != VALI_INTERP_LINEAR && !(integer_scale && elem != 4);
   const bool gather_only = tuning(VALI_TUNE_RESIZE_FORCE_GATHER) == 1;
   a.force_gather = gather_only ? 1 : 0;
+  a.variant = 7 ^ (tuning(VALI_TUNE_RESIZE_NO_SEPARABLE) & 7); // bit 0: wide LDS tap reads, 1 / 2: packed FP32 in the h / v pass
   const bool point_on = tuning(VALI_TUNE_RESIZE_POINT) != 0;
   if (integer_scale && elem != 4 && point_on) { // every filter is the point sample (see resize_tile)
     if (elem == 1) VALI_RS_LAUNCH(k_resize_point, uint8_t);
@@ -812,12 +863,16 @@ static int launch_resize(ResizeArgs& a, int fmt, int src_w, int src_h, int dst_w
 
 using namespace vali;
 
-extern "C" {
-
-int vali_resize(const vali_surface* src, const vali_surface* dst, int interpolation,
-                vali_stream_t stream) {
+static int resize_one(const vali_surface* src, const vali_surface* dst, int interpolation, vali_stream_t stream,
+                      bool ud_planar, const char* entry) {
   VALI_REQUIRE(src && dst, "null argument");
-  VALI_REQUIRE(src->format == dst->format, "src/dst format mismatch");
+  if (ud_planar) {
+    if (!ud_planar_pair(src->format, dst->format))
+      return fail(VALI_ERR_UNSUPPORTED, "ud_planar: unsupported pair %d -> %d", src->format, dst->format);
+    VALI_REQUIRE(((src->width | src->height) & 1) == 0, "4:2:0 surfaces need even width and height");
+  } else {
+    VALI_REQUIRE(src->format == dst->format, "src/dst format mismatch");
+  }
   VALI_REQUIRE(src->width > 0 && src->height > 0 && dst->width > 0 && dst->height > 0, "empty surface");
   VALI_REQUIRE(src->plane[0] && dst->plane[0], "null plane");
   VALI_REQUIRE(planes_fit_32bit(*src) && planes_fit_32bit(*dst), "plane of 4 GiB or more");
@@ -827,7 +882,7 @@ int vali_resize(const vali_surface* src, const vali_surface* dst, int interpolat
   ResizeArgs a = {};
   a.sw = src->width; a.sh = src->height; a.dw = dst->width; a.dh = dst->height;
   int elem = 1;
-  const int nj = resize_jobs(src->format, a.job, &elem);
+  const int nj = resize_jobs_pair(src->format, dst->format, a.job, &elem);
   for (int k = 0; k < nj; ++k) { // resolve the planes on the host (see PlaneJob)
     const int c = a.job[k].comp;
     VALI_REQUIRE(src->plane[c] && dst->plane[c], "null plane");
@@ -837,13 +892,13 @@ int vali_resize(const vali_surface* src, const vali_surface* dst, int interpolat
     a.job[k].dpitch = dst->pitch[c];
   }
   hipStream_t s = as_stream(stream);
-  VALI_ENTRY(s);
-  return launch_resize(a, src->format, src->width, src->height, dst->width, dst->height, 1, interpolation, s);
+  VALI_ENTRY_NAMED(s, entry);
+  return launch_resize(a, dst->format, src->width, src->height, dst->width, dst->height, 1, interpolation, s, src->format);
 }
 
-int vali_resize_batch(const vali_surface* d_src, const vali_surface* d_dst, int n, int format,
-                      int src_width, int src_height, int dst_width, int dst_height, int interpolation,
-                      vali_stream_t stream) {
+static int resize_many(const vali_surface* d_src, const vali_surface* d_dst, int n, int src_format, int format,
+                       int src_width, int src_height, int dst_width, int dst_height, int interpolation,
+                       vali_stream_t stream, const char* entry) {
   VALI_REQUIRE(d_src && d_dst, "null argument");
   VALI_REQUIRE(src_width > 0 && src_height > 0 && dst_width > 0 && dst_height > 0, "empty geometry");
   VALI_REQUIRE(n >= 0 && n <= 65535, "batch size out of range (0..65535)");
@@ -856,8 +911,35 @@ int vali_resize_batch(const vali_surface* d_src, const vali_surface* d_dst, int 
   a.d_src = d_src;
   a.d_dst = d_dst;
   hipStream_t s = as_stream(stream);
-  VALI_ENTRY(s);
-  return launch_resize(a, format, src_width, src_height, dst_width, dst_height, n, interpolation, s);
+  VALI_ENTRY_NAMED(s, entry);
+  return launch_resize(a, format, src_width, src_height, dst_width, dst_height, n, interpolation, s, src_format);
+}
+
+extern "C" {
+
+int vali_resize(const vali_surface* src, const vali_surface* dst, int interpolation, vali_stream_t stream) {
+  return resize_one(src, dst, interpolation, stream, false, __func__);
+}
+
+int vali_resize_batch(const vali_surface* d_src, const vali_surface* d_dst, int n, int format,
+                      int src_width, int src_height, int dst_width, int dst_height, int interpolation,
+                      vali_stream_t stream) {
+  return resize_many(d_src, d_dst, n, format, format, src_width, src_height, dst_width, dst_height, interpolation, stream,
+                     __func__);
+}
+
+int vali_ud_planar(const vali_surface* src, const vali_surface* dst, int interpolation, vali_stream_t stream) {
+  return resize_one(src, dst, interpolation, stream, true, __func__);
+}
+
+int vali_ud_planar_batch(const vali_surface* d_src, const vali_surface* d_dst, int n, int src_format, int dst_format,
+                         int src_width, int src_height, int dst_width, int dst_height, int interpolation,
+                         vali_stream_t stream) {
+  if (!ud_planar_pair(src_format, dst_format))
+    return fail(VALI_ERR_UNSUPPORTED, "ud_planar: unsupported pair %d -> %d", src_format, dst_format);
+  VALI_REQUIRE(((src_width | src_height) & 1) == 0, "4:2:0 surfaces need even width and height");
+  return resize_many(d_src, d_dst, n, src_format, dst_format, src_width, src_height, dst_width, dst_height, interpolation,
+                     stream, __func__);
 }
 
 } // extern "C"

@@ -437,7 +437,7 @@ template <int DUMMY = 0> static int launch_half(const RotArgs& a, int pixel_byte
 // plane jobs per pixel format (RotateSurface::Run switch, RotateSurface.cpp:168-208)
 static int rotate_jobs(int fmt, RotJob* j, int* elem) {
   auto set = [&](int k, int comp, int sx, int sy, int ch) {
-    j[k].comp = comp; j[k].sub_x = sx; j[k].sub_y = sy; j[k].channels = ch;
+    j[k].comp = comp; j[k].sub_x = j[k].ssub_x = sx; j[k].sub_y = j[k].ssub_y = sy; j[k].channels = ch;
   };
   *elem = 1;
   switch (fmt) {

@@ -397,7 +397,7 @@ class SurfaceBatch:
 # ---- PySurfaceUD -------------------------------------------------------------------------
 # UDSurface::SupportedConversions() (src/TC/src/UDSurface.cpp:117-133).  The planar-source
 # rows (YUV420 -> YUV444, YUV420_10bit -> YUV444_10bit) go through NPP Lanczos in the
-# reference (UDPlanar, :84-93); here they use the bilinear plane resizer.
+# reference (UDPlanar, :33-93): here vali_ud_planar, all three planes in one launch, Lanczos-3.
 _UD_CONVERSIONS = [
     (F.NV12, F.YUV444), (F.NV12, F.RGB), (F.NV12, F.RGB_32F), (F.NV12, F.RGB_PLANAR),
     (F.NV12, F.RGB_32F_PLANAR), (F.YUV420, F.YUV444), (F.P10, F.YUV444_10bit), (F.P10, F.RGB_32F),
@@ -423,25 +423,16 @@ class PySurfaceUD(_SurfaceTask):
         if pair not in _UD_CONVERSIONS:                       # UDSurface.cpp:137-149
             return TaskExecDetails.failed(TaskExecInfo.NOT_SUPPORTED)
         if pair not in _UD_SEMIPLANAR:
-            return self._run_planar(src, dst)
+            # UDPlanar (UDSurface.cpp:33-93): every source plane resized to the matching destination plane
+            # with NPPI_INTER_LANCZOS -- one launch over the three planes
+            d = _status(shim.ud_planar(src.desc(), dst.desc(), shim.INTERP_LANCZOS, self._stream))
+            if d is _S_OK:
+                self._memo_put((src.desc(), dst.desc()), shim.ud_planar, (shim.INTERP_LANCZOS,))
+            return d
         d = _status(shim.ud_nv12(src.desc(), dst.desc(), self._stream))
         if d is _S_OK:
             self._memo_put((src.desc(), dst.desc()), shim.ud_nv12, ())
         return d
-
-    def _run_planar(self, src: Surface, dst: Surface) -> TaskExecDetails:
-        """UDPlanar (UDSurface.cpp:84-93): every source plane is resized to the size of the
-        matching destination plane (YUV420 -> YUV444: chroma 2x up + common scale).  The
-        reference uses nppiResize Lanczos; here the bilinear resizer on the same NPP
-        sampling grid (interpolation differs)."""
-        fmt = int(F.Y) if src.ElemSize == 1 else int(F.GRAY12)
-        for sp, dp in zip(src._planes, dst._planes):
-            a = shim.SurfaceDesc([sp.GpuMem], [sp.Pitch], sp.Width, sp.Height, fmt)
-            b = shim.SurfaceDesc([dp.GpuMem], [dp.Pitch], dp.Width, dp.Height, fmt)
-            d = _status(shim.resize(a, b, shim.INTERP_LINEAR, self._stream))
-            if not d.success:
-                return d
-        return TaskExecDetails.ok()
 
     def RunAsync(self, src: Surface, dst: Surface) -> Tuple[bool, TaskExecInfo]:
         try:
@@ -449,7 +440,7 @@ class PySurfaceUD(_SurfaceTask):
             m = self._memo.get((d1, d2))
         except (AttributeError, TypeError):
             m = None
-        if m is not None and m[0](d1, d2, self._stream) == 0:
+        if m is not None and m[0](d1, d2, *m[1], self._stream) == 0:
             return _OK_PAIR
         d = self._run(src, dst)
         return d.success, d.info
@@ -500,8 +491,13 @@ class PySurfaceUD(_SurfaceTask):
     def RunBatchAsync(self, batch, dsts=None) -> Tuple[bool, TaskExecInfo]:
         if not isinstance(batch, SurfaceBatch):
             batch = SurfaceBatch(self._gpu_id, self._stream, batch, dsts)
-        if (batch.src_format, batch.dst_format) not in _UD_SEMIPLANAR:
+        if (batch.src_format, batch.dst_format) not in _UD_CONVERSIONS:
             return False, TaskExecInfo.NOT_SUPPORTED
+        if (batch.src_format, batch.dst_format) not in _UD_SEMIPLANAR:
+            d = _status(shim.ud_planar_batch(batch.d_src, batch.d_dst, batch.n, int(batch.src_format),
+                                             int(batch.dst_format), batch.src_size[0], batch.src_size[1],
+                                             batch.dst_size[0], batch.dst_size[1], shim.INTERP_LANCZOS, self._stream))
+            return d.success, d.info
         d = _status(shim.ud_nv12_batch(batch.d_src, batch.d_dst, batch.n, int(batch.src_format),
                                        batch.src_size[0], batch.dst_size[0], batch.dst_size[1],
                                        int(batch.dst_format), self._stream))
@@ -747,18 +743,20 @@ class PySurfaceResizer(_SurfaceTask):
 
     reference: src/python_vali/src/PySurfaceResizer.cpp:28-147; ResizeSurface
     (src/TC/src/TaskResizeSurface.cpp:293-328).  One launch resizes every plane (NV12 needs
-    five NPP launches and two temporaries in the reference).  Interpolation is bilinear by
-    default (BASELINE.json config 3); `interpolation=Interpolation.LANCZOS` selects the 6x6
-    Lanczos-3 restatement of the reference's hard-coded NPPI_INTER_LANCZOS (same sampling
-    grid; tap arithmetic is this build's, see oracle/vali_oracle.c), `Interpolation.CUBIC`
-    the 4x4 Catmull-Rom bicubic.
+    five NPP launches and two temporaries in the reference).  The default filter is the reference's:
+    every nppiResize call site passes NPPI_INTER_LANCZOS (TaskResizeSurface.cpp:67,116,224,273), so
+    `PySurfaceResizer(format, gpu_id[, stream])` is the 6x6 Lanczos-3 -- 3 lobes, normalised taps on the
+    grid src = dst * scale, pinned against NPP output at a non-integer ratio at 45.6 dB
+    (tests/test_oracle_reference_pins.py).  `interpolation=Interpolation.LINEAR` selects the bilinear
+    filter BASELINE.json config 3 names, `Interpolation.CUBIC` the 4x4 Catmull-Rom bicubic (both
+    extensions: the reference has no switch).
     RGB_PLANAR: the reference resizes the 3 stacked planes as ONE W x 3H image so rows
     bleed across channel seams (TaskResizeSurface.cpp:298, Surfaces.hpp:409); here each
     channel is resized on its own.
     """
 
     def __init__(self, format: PixelFormat, gpu_id: int, stream=None,
-                 interpolation: Interpolation = Interpolation.LINEAR):
+                 interpolation: Interpolation = Interpolation.LANCZOS):
         fmt = PixelFormat(format)
         if fmt not in _RESIZE_FORMATS:                       # TaskResizeSurface.cpp:307-308
             raise RuntimeError("pixel format not supported")
