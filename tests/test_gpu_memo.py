@@ -144,3 +144,43 @@ def test_memo_sees_a_mutated_colour_context(vali, gpu):
         assert np.array_equal(got, get(vali, gpu, fresh)), (space, rng_)
         outs.append(got)
     assert not np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[3])
+
+
+def test_list_form_of_run_batch_uploads_its_descriptors_once(vali, gpu):
+    """RunBatchAsync(srcs, dsts): the descriptor arrays are uploaded on the first call and kept with the task
+    (a temporary SurfaceBatch per call allocated, synchronised and freed around every launch)."""
+    w, h, n = 64, 48, 3
+    cvt = vali.PySurfaceConverter(gpu)
+    srcs = [vali.Surface.Make(vali.NV12, w, h, gpu) for _ in range(n)]
+    dsts = [vali.Surface.Make(vali.RGB, w, h, gpu) for _ in range(n)]
+    for _ in range(4):
+        assert cvt.RunBatchAsync(srcs, dsts) == (True, vali.TaskExecInfo.SUCCESS)
+    assert len(cvt._batches) == 1
+    b = next(iter(cvt._batches.values()))
+    assert cvt.RunBatch(list(srcs), list(dsts))[0] and next(iter(cvt._batches.values())) is b      # equal lists: the same batch
+    other = [vali.Surface.Make(vali.RGB, w, h, gpu) for _ in range(n)]
+    assert cvt.RunBatch(srcs, other)[0] and len(cvt._batches) == 2
+    for _ in range(10):                                                                              # bounded
+        assert cvt.RunBatch(srcs, [vali.Surface.Make(vali.RGB, w, h, gpu) for _ in range(n)])[0]
+    assert len(cvt._batches) <= 8
+    with pytest.raises(ValueError):
+        cvt.RunBatch(srcs)
+
+
+def test_surface_batch_cannot_be_created_while_capturing(vali, gpu):
+    from vali_amd._native import shim
+
+    stream = shim.stream_create(gpu)
+    cvt = vali.PySurfaceConverter(gpu, stream)
+    srcs = [vali.Surface.Make(vali.NV12, 64, 48, gpu) for _ in range(2)]
+    dsts = [vali.Surface.Make(vali.RGB, 64, 48, gpu) for _ in range(2)]
+    ready = cvt.PrepareBatch(srcs, dsts)
+    fresh = [vali.Surface.Make(vali.RGB, 64, 48, gpu) for _ in range(2)]
+    cap = vali.StreamCapture(stream, gpu)
+    with cap:
+        with pytest.raises(RuntimeError, match="capturing"):
+            cvt.RunBatchAsync(srcs, fresh)
+        assert cvt.RunBatchAsync(ready)[0]              # a prepared batch records fine
+    cap.Keep(ready)
+    cap.Launch()
+    shim.stream_sync(gpu, stream)

@@ -144,9 +144,12 @@ def test_planar_ud_matches_the_reference_golden(vali, gpu):
     from conftest import GOLDEN
     rgb = np.asarray(PIL.open(GOLDEN / "frame_0.jpg")).astype(np.float64)
     y = np.clip(np.rint(16 + 0.1826 * rgb[..., 0] + 0.6142 * rgb[..., 1] + 0.0620 * rgb[..., 2]), 0, 255).astype(np.uint8)
-    u = np.clip(np.rint(128 - 0.1006 * rgb[..., 0] - 0.3386 * rgb[..., 1] + 0.4392 * rgb[..., 2]), 0, 255).astype(np.uint8)
-    v = np.clip(np.rint(128 + 0.4392 * rgb[..., 0] - 0.3989 * rgb[..., 1] - 0.0403 * rgb[..., 2]), 0, 255).astype(np.uint8)
-    host = np.concatenate([y.reshape(-1), u[0::2, 0::2].reshape(-1), v[0::2, 0::2].reshape(-1)])
+    uf = 128 - 0.1006 * rgb[..., 0] - 0.3386 * rgb[..., 1] + 0.4392 * rgb[..., 2]
+    vf = 128 + 0.4392 * rgb[..., 0] - 0.3989 * rgb[..., 1] - 0.0403 * rgb[..., 2]
+
+    def block_mean(p):      # the chroma sample the 2x2 block shares (nearest siting): JPEG noise averaged over its 4 copies
+        return np.clip(np.rint(0.25 * (p[0::2, 0::2] + p[0::2, 1::2] + p[1::2, 0::2] + p[1::2, 1::2])), 0, 255).astype(np.uint8)
+    host = np.concatenate([y.reshape(-1), block_mean(uf).reshape(-1), block_mean(vf).reshape(-1)])
     src = vali.Surface.Make(vali.YUV420, 848, 464, gpu)
     dst = vali.Surface.Make(vali.YUV444, 640, 360, gpu)
     assert vali.PyFrameUploader(gpu).Run(host, src)[0]
@@ -155,7 +158,7 @@ def test_planar_ud_matches_the_reference_golden(vali, gpu):
     assert vali.PySurfaceDownloader(gpu).Run(dst, out)[0]
     got = out.reshape(3, 360, 640)[:, :120].astype(np.float64)
     gold = np.load(GOLDEN / "ud_640x360_yuv420_rows120.npz")["yuv444"].astype(np.float64)
-    for c, floor in ((0, 44.5), (1, 47.0), (2, 47.0)):
+    for c, floor in ((0, 44.5), (1, 46.5), (2, 50.5)):      # measured 45.0 / 47.3 / 51.7 dB
         d = (got[c] - gold[c])[4:-4, 4:-4]
         assert 10 * np.log10(255.0 ** 2 / np.mean((d - d.mean()) ** 2)) >= floor, c
 

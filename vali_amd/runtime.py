@@ -88,6 +88,13 @@ class CudaStreamEvent:
             self._event = 0
 
 
+_capturing = set()      # (gpu_id, stream) pairs between StreamCapture.__enter__ and __exit__
+
+
+def is_capturing(gpu_id: int, stream: int) -> bool:
+    return (int(gpu_id), int(stream)) in _capturing
+
+
 class StreamCapture:
     """Record a chain of asynchronous task calls on one stream, replay it as ONE launch.
 
@@ -126,9 +133,11 @@ class StreamCapture:
         if self._graph:
             raise RuntimeError("StreamCapture: already captured")
         shim.graph_capture_begin(self._gpu_id, self._stream)
+        _capturing.add((self._gpu_id, self._stream))
         return self
 
     def __exit__(self, exc_type, exc, tb) -> bool:
+        _capturing.discard((self._gpu_id, self._stream))
         try:
             g = shim.graph_capture_end(self._gpu_id, self._stream)
         except Exception:

@@ -12,7 +12,7 @@ from typing import List, Optional, Sequence, Tuple
 from ._native import shim
 from .enums import (ColorRange, ColorSpace, ColorspaceConversionContext, Interpolation, PixelFormat,
                     TaskExecDetails, TaskExecInfo)
-from .runtime import CudaStreamEvent, HipResMgr
+from .runtime import CudaStreamEvent, HipResMgr, is_capturing
 from .surface import Surface
 
 F = PixelFormat
@@ -268,6 +268,25 @@ class _SurfaceTask:
         # surfaces; a Surface gets a NEW descriptor object when it is re-pointed (Surface._update)
         # and a new Surface has its own, so a stale entry can never match.
         self._memo = {}
+        self._batches = {}    # (src descriptors, dst descriptors) -> SurfaceBatch, see _batch_of
+
+    def _batch_of(self, batch, dsts):
+        """RunBatch*(srcs, dsts): the descriptor arrays of a (srcs, dsts) pair of lists are uploaded ONCE and
+        kept with the task (8 most recent pairs) -- a repeated call costs no allocation, no copy and no
+        synchronisation, and the arrays outlive every launch that reads them.  RunBatch*(batch) passes a
+        prepared SurfaceBatch through."""
+        if isinstance(batch, SurfaceBatch):
+            return batch
+        if dsts is None:
+            raise ValueError("RunBatch: pass a SurfaceBatch, or two lists (srcs, dsts)")
+        srcs, dsts = list(batch), list(dsts)
+        key = (tuple(s.desc() for s in srcs), tuple(d.desc() for d in dsts))
+        b = self._batches.get(key)
+        if b is None:
+            if len(self._batches) >= 8:
+                self._batches.pop(next(iter(self._batches)))
+            b = self._batches[key] = SurfaceBatch(self._gpu_id, self._stream, srcs, dsts)
+        return b
 
     def _memo_put(self, key, fn, args, keep=None):
         if len(self._memo) >= 16:
@@ -342,8 +361,7 @@ class PySurfaceConverter(_SurfaceTask):
         All-or-nothing, no per-item sync (idiom of PyNvJpegEncoder.Run,
         src/python_vali/src/PyNvJpegEncoder.cpp:31-81).  `csc` overrides the matrix
         cc_ctx would select (the multi-GPU pipeline passes the broadcast block)."""
-        if not isinstance(batch, SurfaceBatch):
-            batch = SurfaceBatch(self._gpu_id, self._stream, batch, dsts)
+        batch = self._batch_of(batch, dsts)
         impl = _CONVERSIONS.get((batch.src_format, batch.dst_format))
         if impl is None:
             raise ValueError(f"Unsupported pixel format conversion: {batch.src_format.name} -> "
@@ -371,7 +389,13 @@ class SurfaceBatch:
             for s in group:
                 if s.Format != f0 or (s.Width, s.Height) != s0 or s.IsEmpty:
                     raise ValueError("SurfaceBatch: surfaces of a batch must share format and size")
+        if is_capturing(gpu_id, stream):
+            # the upload allocates and synchronises: both are illegal while the stream records a graph, and the
+            # recorded launches would keep reading arrays that die with this object
+            raise RuntimeError("SurfaceBatch: cannot be created while the stream is capturing -- PrepareBatch() "
+                               "before the StreamCapture block and Keep() the batch with the capture")
         self.gpu_id = gpu_id
+        self._stream = stream
         self.n = len(srcs)
         self.src_format, self.dst_format = srcs[0].Format, dsts[0].Format
         self.src_size = (srcs[0].Width, srcs[0].Height)
@@ -384,6 +408,11 @@ class SurfaceBatch:
         return self.n
 
     def __del__(self):
+        if getattr(self, "d_src", 0) or getattr(self, "d_dst", 0):
+            try:    # a launch issued on the batch's stream may still be reading the arrays
+                shim.stream_sync(self.gpu_id, self._stream)
+            except Exception:
+                pass
         for name in ("d_src", "d_dst"):
             p = getattr(self, name, 0)
             if p:
@@ -473,8 +502,7 @@ class PySurfaceUD(_SurfaceTask):
         return r
 
     def RunRotatedBatchAsync(self, batch, dsts=None, angle: float = 90.0) -> Tuple[bool, TaskExecInfo]:
-        if not isinstance(batch, SurfaceBatch):
-            batch = SurfaceBatch(self._gpu_id, self._stream, batch, dsts)
+        batch = self._batch_of(batch, dsts)
         q = self._quarter(angle)
         if q is None or (batch.src_format, batch.dst_format) != (F.NV12, F.RGB):
             return False, TaskExecInfo.NOT_SUPPORTED
@@ -489,8 +517,7 @@ class PySurfaceUD(_SurfaceTask):
         return r
 
     def RunBatchAsync(self, batch, dsts=None) -> Tuple[bool, TaskExecInfo]:
-        if not isinstance(batch, SurfaceBatch):
-            batch = SurfaceBatch(self._gpu_id, self._stream, batch, dsts)
+        batch = self._batch_of(batch, dsts)
         if (batch.src_format, batch.dst_format) not in _UD_CONVERSIONS:
             return False, TaskExecInfo.NOT_SUPPORTED
         if (batch.src_format, batch.dst_format) not in _UD_SEMIPLANAR:
@@ -599,8 +626,7 @@ class PySurfacePreprocessor(_SurfaceTask):
         return SurfaceBatch(self._gpu_id, self._stream, srcs, dsts)
 
     def RunBatchAsync(self, batch, dsts=None, cc_ctx=None) -> Tuple[bool, TaskExecInfo]:
-        if not isinstance(batch, SurfaceBatch):
-            batch = SurfaceBatch(self._gpu_id, self._stream, batch, dsts)
+        batch = self._batch_of(batch, dsts)
         bad = self._check(batch.src_format, batch.dst_format, *batch.src_size, *batch.dst_size)
         if bad:
             return bad.success, bad.info
@@ -693,8 +719,7 @@ class PySurfaceRotator(_SurfaceTask):
     def RunBatchAsync(self, batch, dsts=None, angle: float = 0.0, shift_x: float = 0.0,
                       shift_y: float = 0.0) -> Tuple[bool, TaskExecInfo]:
         """One launch rotates every plane of every surface of the batch."""
-        if not isinstance(batch, SurfaceBatch):
-            batch = SurfaceBatch(self._gpu_id, self._stream, batch, dsts)
+        batch = self._batch_of(batch, dsts)
         s0 = batch._keep[0][0]
         err = self._check(batch.src_format, batch.dst_format, s0.NumComponents, s0.NumPlanes)
         if err is not None:
@@ -802,8 +827,7 @@ class PySurfaceResizer(_SurfaceTask):
         return SurfaceBatch(self._gpu_id, self._stream, srcs, dsts)
 
     def RunBatchAsync(self, batch, dsts=None) -> Tuple[bool, TaskExecInfo]:
-        if not isinstance(batch, SurfaceBatch):
-            batch = SurfaceBatch(self._gpu_id, self._stream, batch, dsts)
+        batch = self._batch_of(batch, dsts)
         if batch.src_format != batch.dst_format or batch.src_format != self._format:
             return False, TaskExecInfo.INVALID_INPUT
         d = _status(shim.resize_batch(batch.d_src, batch.d_dst, batch.n, int(self._format),
