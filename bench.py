@@ -105,9 +105,32 @@ def cpu_baseline(width, height, coeffs, budget_s):
         "single_thread_fps": round(1.0 / t_single, 3),
         "config1_1080p_single_thread": {"ms_per_frame": round(t_hd * 1e3, 3), "frames_per_s": round(1.0 / t_hd, 2),
                                         "GBps(9331200 B/frame)": round(9331200 / t_hd / 1e9, 3), "cores": 1},
-        "note": "the reference's CPU path is FFmpeg libswscale (not available offline); this "
-                "is the build's own C restatement of the GPU arithmetic",
+        "note": "the reference's CPU path is FFmpeg libswscale; `swscale` below times it through PyAV when the box has "
+                "it (null otherwise); `value` is the build's own C restatement of the GPU arithmetic",
+        "swscale": swscale_baseline(width, height, min(budget_s, 5.0)),
     }
+
+
+def swscale_baseline(width, height, budget_s):
+    """The reference's real CPU path -- PyFrameConverter = sws_scale(SWS_BILINEAR), one frame, one thread
+    (src/TC/src/TaskConvertFrame.cpp:22-25,79-94) -- timed through PyAV when the box has it (it is not part of the
+    build image; never vendored).  None when PyAV is not importable."""
+    try:
+        import av
+    except Exception:
+        return None
+    nv12 = synth_nv12(width, height, 1)
+    frame = av.VideoFrame.from_ndarray(nv12, format="nv12")
+    kw = dict(format="rgb24", src_colorspace="ITU709", dst_colorspace="ITU709", interpolation="BILINEAR")
+    frame.reformat(**kw)                       # untimed: builds the SwsContext
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        frame.reformat(**kw)
+        done += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(done / dt, 3), "unit": "frames/s", "cores": 1, "kind": "swscale",
+            "sample": f"{done} frames {width}x{height} NV12->RGB24 by libswscale (SWS_BILINEAR, BT.709) through PyAV {av.__version__}, "
+                      f"one thread, {dt:.1f} s"}
 
 
 def secondary_configs(pipe):

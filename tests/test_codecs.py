@@ -68,3 +68,81 @@ def test_frame_converter_runs_on_the_gpu(vali, gpu, oracle):
     assert ok and dst.size == w * h * 3 and fc.Format == vali.RGB
     assert np.array_equal(dst, oracle.convert(raw[0], "NV12", "RGB", w, h, oracle.cvt_params(csc_variant=1)))
     assert fc.Run(raw[0][:-1], dst, cc) == (False, vali.TaskExecInfo.INVALID_INPUT)
+
+
+# ---- compressed input through PyAV (optional) -------------------------------------------------------------
+class _FakeFrame:
+    def __init__(self, yuv420, w, h):
+        self._p, self._w, self._h = yuv420, w, h
+
+    def to_ndarray(self, format):  # noqa: A002 -- PyAV's keyword
+        y, c = self._w * self._h, self._w * self._h // 4
+        if format == "yuv420p":
+            return self._p.reshape(self._h * 3 // 2, self._w)
+        assert format == "nv12"
+        uv = np.empty(2 * c, np.uint8)
+        uv[0::2], uv[1::2] = self._p[y:y + c], self._p[y + c:]
+        return np.concatenate([self._p[:y], uv]).reshape(self._h * 3 // 2, self._w)
+
+
+def _fake_av(frames, w, h):
+    """A stand-in for the `av` module with the handful of attributes _AvSource touches, so the adapter logic
+    (format choice per mode, properties, end of stream) is exercised where PyAV is not installed."""
+    import types
+    from fractions import Fraction
+
+    cc = types.SimpleNamespace(width=w, height=h, pix_fmt="yuv420p", colorspace=1, color_range=1)
+    stream = types.SimpleNamespace(codec_context=cc, average_rate=Fraction(30, 1), guessed_rate=None, frames=len(frames),
+                                   format=types.SimpleNamespace(name="yuv420p"))
+    container = types.SimpleNamespace(streams=types.SimpleNamespace(video=[stream]), close=lambda: None,
+                                      decode=lambda s: iter([_FakeFrame(f, w, h) for f in frames]))
+    return types.SimpleNamespace(open=lambda path, options=None: container)
+
+
+def test_compressed_input_through_pyav_adapter_cpu_mode(vali, monkeypatch, tmp_path):
+    import sys
+    w, h = 64, 48
+    rng = np.random.default_rng(0)
+    frames = [rng.integers(0, 256, w * h * 3 // 2, dtype=np.uint8) for _ in range(3)]
+    monkeypatch.setitem(sys.modules, "av", _fake_av(frames, w, h))
+    dec = vali.PyDecoder(str(tmp_path / "movie.mp4"), {}, gpu_id=-1)
+    assert (dec.Width, dec.Height, dec.Format, dec.NumFrames, dec.Framerate) == (w, h, vali.YUV420, 3, 30.0)
+    assert dec.ColorSpace == vali.ColorSpace.BT_709 and dec.ColorRange == vali.ColorRange.MPEG and not dec.IsAccelerated
+    out = np.ndarray(shape=(0,), dtype=np.uint8)
+    for f in frames:
+        assert dec.DecodeSingleFrame(out) == (True, vali.TaskExecInfo.SUCCESS) and np.array_equal(out, f)
+    assert dec.DecodeSingleFrame(out) == (False, vali.TaskExecInfo.END_OF_STREAM)
+
+
+@pytest.mark.gpu
+def test_compressed_input_through_pyav_adapter_uploads_nv12(vali, gpu, monkeypatch, tmp_path):
+    import sys
+    w, h = 64, 48
+    rng = np.random.default_rng(1)
+    frames = [rng.integers(0, 256, w * h * 3 // 2, dtype=np.uint8) for _ in range(2)]
+    monkeypatch.setitem(sys.modules, "av", _fake_av(frames, w, h))
+    dec = vali.PyDecoder(str(tmp_path / "movie.mkv"), {}, gpu_id=gpu)
+    assert dec.Format == vali.NV12 and dec.IsAccelerated
+    surf = vali.Surface.Make(vali.NV12, w, h, gpu)
+    for f in frames:
+        assert dec.DecodeSingleSurface(surf) == (True, vali.TaskExecInfo.SUCCESS)
+        got = np.zeros(surf.HostSize, np.uint8)
+        assert vali.PySurfaceDownloader(gpu, dec.Stream).Run(surf, got)[0]
+        assert np.array_equal(got, _FakeFrame(f, w, h).to_ndarray("nv12").reshape(-1))
+    assert dec.DecodeSingleSurface(surf) == (False, vali.TaskExecInfo.END_OF_STREAM)
+
+
+def test_real_pyav_decodes_the_reference_video_when_installed(vali):
+    """With a real PyAV and the reference's data next to it (never the case in the build container): frame 0 of
+    test.mp4, resized 2:1, is the committed fixture test_small.nv12."""
+    av = pytest.importorskip("av")  # noqa: F841
+    import os
+    path = os.environ.get("VALI_REFERENCE_VIDEO", "/root/reference/tests/data/test.mp4")
+    if not os.path.exists(path):
+        pytest.skip("reference video not present")
+    dec = vali.PyDecoder(path, {}, gpu_id=-1)
+    assert (dec.Width, dec.Height, dec.Format) == (848, 464, vali.YUV420)
+    frame = np.ndarray(shape=(0,), dtype=np.uint8)
+    assert dec.DecodeSingleFrame(frame)[0]
+    small = np.fromfile(GOLDEN / "test_small_2frames.nv12", np.uint8)[:424 * 232].reshape(232, 424)
+    assert np.array_equal(frame[:848 * 464].reshape(464, 848)[0::2, 0::2], small)

@@ -4,12 +4,15 @@ The reference implements these with FFmpeg + NVDEC/NVENC/nvJPEG (SURVEY.md secti
 12-15): decode/encode ASICs and a demuxer are outside this build's scope and no FFmpeg exists
 offline.  What IS provided so pipelines written against python_vali keep running:
 
-* PyDecoder   -- raw-video reader with the reference's constructor and decode methods
-                 (src/python_vali/src/PyDecoder.cpp:77-124, 310-346, 563-680): it accepts the
-                 FFmpeg rawvideo options ({"f": "rawvideo", "video_size": "WxH",
-                 "pixel_format": "nv12"|"yuv420p"|"p010le"|"yuv420p10le"}) or infers them from a
-                 ``.nv12`` / ``.yuv`` / ``.p10`` suffix, and uploads frames into the caller's
-                 Surface on its stream.  Compressed input raises RuntimeError.
+* PyDecoder   -- the reference's constructor and decode methods
+                 (src/python_vali/src/PyDecoder.cpp:77-124, 310-346, 563-680) over two sources:
+                 (a) raw video: the FFmpeg rawvideo options ({"f": "rawvideo", "video_size": "WxH",
+                 "pixel_format": "nv12"|"yuv420p"|"p010le"|"yuv420p10le"}) or a ``.nv12`` / ``.yuv`` /
+                 ``.p10`` suffix; (b) compressed input (mp4 / mkv / ...), when PyAV (`import av`, FFmpeg's
+                 Python binding -- never vendored, absent from the build image) is importable on the box:
+                 demux + decode on the CPU, planar -> semi-planar repack, upload into the caller's Surface
+                 on the decoder's stream (north_star: "PyDecoder ... stubbed to CPU FFmpeg + hipMemcpy
+                 upload").  Without PyAV compressed input raises RuntimeError.
 * PyFrameConverter -- the reference's CPU (libswscale) converter API
                  (src/python_vali/src/PyFrameConverter.cpp:21-129) served by the HIP converter:
                  ndarray -> upload -> kernel -> download.  It is NOT a CPU code path.
@@ -43,13 +46,66 @@ _SUFFIX = {".nv12": "nv12", ".yuv": "yuv420p", ".yuv420": "yuv420p", ".p10": "p0
            ".yuv444": "yuv444p", ".rgb": "rgb24"}
 
 
+def have_av() -> bool:
+    """True when PyAV can be imported on this box (optional; nothing else in the package needs it)."""
+    try:
+        import av  # noqa: F401
+        return True
+    except Exception:
+        return False
+
+
+class _AvSource:
+    """Compressed input through PyAV: CPU demux + decode, one frame at a time, as flat uint8 arrays in the
+    layout the reference's decoder emits -- planar YUV420[_10bit] in CPU mode, NV12 / P10 in accelerated mode
+    (tests/test_PySurfaceUD.py:76-79,140-143; TaskDecodeFrame.cpp:575-650)."""
+
+    _SPACE = {1: ColorSpace.BT_709, 5: ColorSpace.BT_601, 6: ColorSpace.BT_601}     # AVCOL_SPC_BT709 / BT470BG / SMPTE170M
+    _RANGE = {1: ColorRange.MPEG, 2: ColorRange.JPEG}                                # AVCOL_RANGE_MPEG / JPEG
+
+    def __init__(self, path: str, opts: dict, accelerated: bool):
+        import av
+
+        self._container = av.open(path, options={k: str(v) for k, v in opts.items()})
+        self._stream = self._container.streams.video[0]
+        cc = self._stream.codec_context
+        self.width, self.height = int(cc.width), int(cc.height)
+        pix = str(getattr(cc, "pix_fmt", None) or self._stream.format.name)
+        self.high_bit_depth = "10" in pix or "12" in pix
+        if accelerated:
+            self.fmt, self._av_fmt = (F.P10, "p010le") if self.high_bit_depth else (F.NV12, "nv12")
+        else:
+            self.fmt, self._av_fmt = (F.YUV420_10bit, "yuv420p10le") if self.high_bit_depth else (F.YUV420, "yuv420p")
+        rate = self._stream.average_rate or self._stream.guessed_rate
+        self.framerate = float(rate) if rate else 25.0
+        self.num_frames = int(self._stream.frames or 0)
+        self.color_space = self._SPACE.get(int(getattr(cc, "colorspace", 2) or 2), ColorSpace.UNSPEC)
+        self.color_range = self._RANGE.get(int(getattr(cc, "color_range", 0) or 0), ColorRange.UDEF)
+        self._frames = self._container.decode(self._stream)
+
+    def read(self) -> Optional[np.ndarray]:
+        try:
+            frame = next(self._frames)
+        except StopIteration:
+            return None
+        # same colourspace in and out: a byte shuffle (planar <-> semi-planar), never a colour conversion
+        return np.ascontiguousarray(frame.to_ndarray(format=self._av_fmt)).view(np.uint8).reshape(-1)
+
+    def close(self):
+        try:
+            self._container.close()
+        except Exception:
+            pass
+
+
 def _host_frame_size(fmt: PixelFormat, w: int, h: int) -> int:
     spec = FORMATS[fmt]
     return sum(pw * ph for pw, ph in spec.plane_geometry(w, h)) * spec.elem_size
 
 
 class PyDecoder:
-    """Raw-video stand-in for the FFmpeg/NVDEC decoder (same call surface).
+    """CPU-side stand-in for the FFmpeg/NVDEC decoder (same call surface): raw video always, compressed
+    input when PyAV is importable.
 
     gpu_id >= 0: "accelerated" -- only DecodeSingleSurface[Async] works (PyDecoder.cpp:98-123);
     gpu_id <  0: CPU           -- only DecodeSingleFrame works (PyDecoder.cpp:77-96).
@@ -63,11 +119,21 @@ class PyDecoder:
             raise RuntimeError("PyDecoder: only file paths are supported by this build")
         suffix = os.path.splitext(path)[1].lower()
         pix = opts.get("pixel_format") or opts.get("pix_fmt") or _SUFFIX.get(suffix)
+        self._av = None
         if opts.get("f", "rawvideo") != "rawvideo" or pix is None:
-            raise RuntimeError(
-                "PyDecoder: this MI355X build has no demuxer / video decoder (the reference uses "
-                "FFmpeg + NVDEC).  Raw video is supported: opts={'f': 'rawvideo', 'video_size': "
-                "'WxH', 'pixel_format': 'nv12'} or a .nv12/.yuv/.p10 file with 'video_size'.")
+            if not have_av():
+                raise RuntimeError(
+                    "PyDecoder: compressed input needs PyAV (`import av`, FFmpeg's Python binding), which is not "
+                    "importable here; the library itself has no demuxer / video decoder (the reference uses FFmpeg "
+                    "+ NVDEC).  Raw video always works: opts={'f': 'rawvideo', 'video_size': 'WxH', "
+                    "'pixel_format': 'nv12'} or a .nv12/.yuv/.p10 file with 'video_size'.")
+            self._av = _AvSource(path, {k: v for k, v in opts.items() if k not in ("pixel_format", "pix_fmt")},
+                                 self._gpu_id >= 0)
+            self._w, self._h, self._fmt = self._av.width, self._av.height, self._av.fmt
+            self._framerate, self._num_frames = self._av.framerate, self._av.num_frames
+            self._file, self._pos = None, 0
+            self._init_stream(stream)
+            return
         if pix not in _PIX_FMTS:
             raise RuntimeError(f"PyDecoder: unsupported raw pixel_format {pix!r}")
         size = opts.get("video_size") or opts.get("s")
@@ -81,8 +147,11 @@ class PyDecoder:
         self._file_frame = _host_frame_size(_PIX_FMTS[pix][1], self._w, self._h)
         self._num_frames = os.path.getsize(path) // self._file_frame
         self._pos = 0
+        self._init_stream(stream)
+
+    def _init_stream(self, stream):
         if self._gpu_id >= 0:
-            self._stream = int(stream) if stream is not None else HipResMgr.Instance().GetStream(self._gpu_id)
+            self._stream = int(stream) if stream else HipResMgr.Instance().GetStream(self._gpu_id)
             self._uploader = PyFrameUploader(self._gpu_id, self._stream)
         else:
             self._stream = 0
@@ -98,11 +167,13 @@ class PyDecoder:
     IsAccelerated = property(lambda self: self._gpu_id >= 0)
     IsVFR = property(lambda self: False)
     DisplayRotation = property(lambda self: 361.0)           # "no display matrix" value
-    ColorSpace = property(lambda self: ColorSpace.UNSPEC)     # raw video carries no tags
-    ColorRange = property(lambda self: ColorRange.UDEF)
+    ColorSpace = property(lambda self: self._av.color_space if self._av else ColorSpace.UNSPEC)   # raw video carries no tags
+    ColorRange = property(lambda self: self._av.color_range if self._av else ColorRange.UDEF)
     HostFrameSize = property(lambda self: _host_frame_size(self._fmt, self._w, self._h))
 
     def _read(self) -> Optional[np.ndarray]:
+        if self._av is not None:
+            return self._av.read()
         if self._pos >= self._num_frames:
             return None
         self._file.seek(self._pos * self._file_frame)
@@ -154,6 +225,9 @@ class PyDecoder:
         f = getattr(self, "_file", None)
         if f:
             f.close()
+        a = getattr(self, "_av", None)
+        if a is not None:
+            a.close()
 
 
 class PyFrameConverter:
