@@ -438,9 +438,15 @@ int vali_oracle_resize_plane(const void* src, int src_pitch, int src_w, int src_
  *   raw_k = sin(pi t_k) sin(pi t_k / 3) / t_k^2 ,  t_k = a + (2 - k)     (3/pi^2 cancels)
  *   w_k = raw_k / (((((raw_0 + raw_1) + raw_2) + raw_3) + raw_4) + raw_5)
  *   a == 0: w = {0,0,1,0,0,0}
+ * The twelve divisions of that definition are TWO: with d_k = t_k^2 and P = ((d0 d1)(d2 d3))(d4 d5),
+ *   1/d_k = (1/P) * (product of the other five d, grouped as in the code) ;  w_k = raw_k * (1/sum)
+ * (an IEEE division costs a GPU lane a dozen instructions, and every lane of every tile evaluates five
+ * tap sets: the weights were a third of the kernel's arithmetic).  Same weights to ~1e-7.
  * sin/cos are FIXED polynomials (below) so CPU and GPU agree bit for bit; sin(pi(a+m)) =
  * (-1)^m sin(pi a) and sin(pi(a+m)/3) by the angle-sum identity from sin/cos(pi a / 3).
- *   rows:    h_r = w_0 t_0 ; h_r = fma(w_k, t_k, h_r), k = 1..5       (6 source rows)
+ *   rows:    even and odd taps accumulate separately -- e = w_0 t_0 ; e = fma(w_k, t_k, e), k = 2, 4 ;
+ *            o = w_1 t_1 ; o = fma(w_k, t_k, o), k = 3, 5 ; h_r = e + o -- the form a packed-FP32 pipe
+ *            (two lanes of one instruction) evaluates
  *   columns: v = wy_0 h_0 ; v = fma(wy_r, h_r, v), r = 1..5
  *   u8/u16: round-half-even + saturate ; f32: v
  * ========================================================================== */
@@ -477,14 +483,22 @@ void vali_oracle_lanczos3_weights(float a, float w[6]) {
   const float q[6] = {fmaf(c3, h, -0.5f * s3), fmaf(c3, h, 0.5f * s3), s3,
                       fmaf(c3, -h, 0.5f * s3), fmaf(c3, -h, -0.5f * s3), -s3};
   const float sg[6] = {1.0f, -1.0f, 1.0f, -1.0f, 1.0f, -1.0f};
-  float raw[6];
+  float d[6], inv[6], raw[6];
   for (int k = 0; k < 6; ++k) {
     const float t = a + (float)(2 - k);
-    raw[k] = (sg[k] * s1) * q[k] / (t * t);
+    d[k] = t * t;
   }
-  const float sum = ((((raw[0] + raw[1]) + raw[2]) + raw[3]) + raw[4]) + raw[5];
+  const float p01 = d[0] * d[1], p23 = d[2] * d[3], p45 = d[4] * d[5];
+  const float r = 1.0f / ((p01 * p23) * p45);
+  inv[0] = r * ((d[1] * p23) * p45); inv[1] = r * ((d[0] * p23) * p45);
+  inv[2] = r * ((p01 * d[3]) * p45); inv[3] = r * ((p01 * d[2]) * p45);
+  inv[4] = r * ((p01 * p23) * d[5]); inv[5] = r * ((p01 * p23) * d[4]);
   for (int k = 0; k < 6; ++k)
-    w[k] = raw[k] / sum;
+    raw[k] = ((sg[k] * s1) * q[k]) * inv[k];
+  const float sum = ((((raw[0] + raw[1]) + raw[2]) + raw[3]) + raw[4]) + raw[5];
+  const float rs = 1.0f / sum;
+  for (int k = 0; k < 6; ++k)
+    w[k] = raw[k] * rs;
 }
 
 /*
@@ -541,9 +555,13 @@ static int resize_plane_taps(const void* src, int src_pitch, int src_w, int src_
         float v = 0.0f;
         for (int r = 0; r < taps; ++r) {
           const uint8_t* row = (const uint8_t*)src + (size_t)ty.idx[r] * src_pitch;
-          float hsum = tx.w[0] * rot_texel(row, tx.idx[0] * channels + ch, elem);
-          for (int k = 1; k < taps; ++k)
-            hsum = fmaf(tx.w[k], rot_texel(row, tx.idx[k] * channels + ch, elem), hsum);
+          float he = tx.w[0] * rot_texel(row, tx.idx[0] * channels + ch, elem);
+          float ho = tx.w[1] * rot_texel(row, tx.idx[1] * channels + ch, elem);
+          for (int k = 2; k < taps; k += 2) {
+            he = fmaf(tx.w[k], rot_texel(row, tx.idx[k] * channels + ch, elem), he);
+            ho = fmaf(tx.w[k + 1], rot_texel(row, tx.idx[k + 1] * channels + ch, elem), ho);
+          }
+          const float hsum = he + ho;
           v = r == 0 ? ty.w[0] * hsum : fmaf(ty.w[r], hsum, v);
         }
         const int o = x * channels + ch;

@@ -23,25 +23,10 @@
 // One lane = 4 adjacent dst pixels of one plane row; a workgroup = 256 x 16 dst pixels of one
 // plane; plane jobs are concatenated in the XCD-contiguous TileMap.  HBM traffic = touched
 // source rows + dst.
-#include "common.hpp"
-#include "dev_util.hpp"
-#include <stdlib.h>
+#include "resize_common.hpp"
 #include <type_traits>
 
 namespace vali {
-
-typedef PlaneJob ResizeJob; // dev_util.hpp
-
-struct ResizeArgs {
-  const vali_surface* d_src; // batch: device descriptor arrays
-  const vali_surface* d_dst;
-  int sw, sh, dw, dh;        // single frame: surface sizes (planes are resolved into the jobs)
-  ResizeJob job[3];
-  int njobs;
-  TileMap map;
-  int force_gather; // VALI_RESIZE_FORCE_GATHER=1: no LDS staging (tests reach the gather forms with ordinary sizes)
-  int variant;      // A/B experiment bits (temporary)
-};
 
 template <typename T> __device__ __forceinline__ float rs_load(const uint8_t* row, int idx) {
   return (float)((const T*)row)[idx];
@@ -328,427 +313,7 @@ __global__ void __launch_bounds__(kBlock) k_resize(const ResizeArgs a) {
     resize_tile<T, 1, POINT>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.force_gather ? nullptr : stage);
 }
 
-// ---------------------------------------------------------------------------------------
-// Lanczos-3 (VALI_INTERP_LANCZOS): the reference's NPPI_INTER_LANCZOS restated as a 6x6
-// interpolating kernel on the same sampling grid (oracle: vali_oracle_resize_plane_lanczos,
-// which documents the tap arithmetic; parity unpinned against NPP beyond the geometry).
-// Weights come from fixed polynomials with explicit fma so CPU and GPU agree bit for bit.
-// Same decomposition as the bilinear kernel: lane = 4 dst pixels, a wave walks 8 dst rows
-// with the same column weights; the six source rows of a dst row are staged in the wave's LDS
-// strip (lane l owns chunks l and l+64 of every row).  Consecutive dst rows share most of
-// their source rows, so the re-staging is served by L2, not HBM.
-__device__ __forceinline__ float lz_sin_poly(float z) { // sin z, 0 <= z <= pi/2
-  const float z2 = z * z;
-  float p = __builtin_fmaf(z2, -2.5052108e-8f, 2.7557319e-6f);
-  p = __builtin_fmaf(z2, p, -1.9841270e-4f);
-  p = __builtin_fmaf(z2, p, 8.3333333e-3f);
-  p = __builtin_fmaf(z2, p, -1.6666667e-1f);
-  return __builtin_fmaf(z * z2, p, z);
-}
-__device__ __forceinline__ float lz_cos_poly(float z) { // cos z, 0 <= z <= pi/3
-  const float z2 = z * z;
-  float p = __builtin_fmaf(z2, 2.0876757e-9f, -2.7557319e-7f);
-  p = __builtin_fmaf(z2, p, 2.4801587e-5f);
-  p = __builtin_fmaf(z2, p, -1.3888889e-3f);
-  p = __builtin_fmaf(z2, p, 4.1666667e-2f);
-  p = __builtin_fmaf(z2, p, -0.5f);
-  return __builtin_fmaf(z2, p, 1.0f);
-}
-__device__ __forceinline__ void lanczos3_weights(float a, float (&w)[6]) {
-  const float y = a <= 0.5f ? a : 1.0f - a;
-  const float s1 = lz_sin_poly(y * 3.14159265f);
-  const float z = a * 1.04719755f;
-  const float s3 = lz_sin_poly(z), c3 = lz_cos_poly(z);
-  const float h = 0.866025404f;
-  const float q[6] = {__builtin_fmaf(c3, h, -0.5f * s3), __builtin_fmaf(c3, h, 0.5f * s3), s3,
-                      __builtin_fmaf(c3, -h, 0.5f * s3), __builtin_fmaf(c3, -h, -0.5f * s3), -s3};
-  float raw[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const float t = a + (float)(2 - k);
-    const float s = (k & 1) ? -s1 : s1;
-    raw[k] = s * q[k] / (t * t);
-  }
-  const float sum = ((((raw[0] + raw[1]) + raw[2]) + raw[3]) + raw[4]) + raw[5];
-  const bool on_grid = a == 0.0f;
-#pragma unroll
-  for (int k = 0; k < 6; ++k)
-    w[k] = on_grid ? (k == 2 ? 1.0f : 0.0f) : raw[k] / sum;
-}
-
-// Bicubic (VALI_INTERP_CUBIC): Keys / Catmull-Rom cubic convolution (a = -1/2), taps i-1 .. i+2;
-// same Horner forms as the oracle (vali_oracle_cubic_weights), not renormalised.
-__device__ __forceinline__ void cubic_weights(float a, float (&w)[4]) {
-  const float a2 = a * a;
-  w[0] = a * __builtin_fmaf(a, __builtin_fmaf(a, -0.5f, 1.0f), -0.5f);
-  w[1] = __builtin_fmaf(a2, __builtin_fmaf(a, 1.5f, -2.5f), 1.0f);
-  w[2] = a * __builtin_fmaf(a, __builtin_fmaf(a, -1.5f, 2.0f), 0.5f);
-  w[3] = a2 * __builtin_fmaf(a, 0.5f, -0.5f);
-}
-
-// TAPS = 6: Lanczos-3, TAPS = 4: cubic; the taps are i - kBefore .. i + TAPS - 1 - kBefore
-template <int TAPS> struct LzTap {
-  static constexpr int kBefore = TAPS / 2 - 1;
-  int i;      // floor of the source coordinate
-  float w[TAPS];
-};
-template <int TAPS> __device__ __forceinline__ LzTap<TAPS> make_lz_tap(int x, float scale) {
-  const float f = (float)x * scale;
-  const float fl = __builtin_floorf(f);
-  LzTap<TAPS> t;
-  if constexpr (TAPS == 6)
-    lanczos3_weights(f - fl, t.w);
-  else
-    cubic_weights(f - fl, t.w);
-  t.i = (int)fl;
-  return t;
-}
-__device__ __forceinline__ int clampi(int v, int hi) { return min(max(v, 0), hi); }
-
-constexpr int kLzCpr = 4;                              // 16-byte chunks per lane per row
-constexpr int kLzRowBytes = kLzCpr * kWave * 16;       // 4 KiB: the staged source row
-// The staged row carries kLzPad bytes either side: at the left / right edge of the image they hold replicas
-// of the first / last pixel, so the taps of EVERY pixel -- clamped or not -- are TAPS consecutive pixels of
-// the LDS row and come with one wide read (read_taps) instead of TAPS x C element reads.
-constexpr int kLzPad = 64;
-struct alignas(16) LzStage {
-  uint8_t row[kLzPad + kLzRowBytes + kLzPad];
-};
-
-// The TAPS x C elements of one pixel's horizontal taps from the staged row: misaligned 8-byte LDS reads at
-// the pixel's own byte address (gfx950 LDS serves them in one pass; what made this kernel LDS-bound was the
-// NUMBER of ds_read instructions -- 24 single-byte reads per lane and source row, each costing the LDS pipe a
-// full wave pass, 2-way bank-conflicted at the 2:1 ratio -- not the bytes).  May read up to 7 bytes past the
-// last tap: inside the pad.
-template <typename T, int C, int TAPS>
-__device__ __forceinline__ void read_taps(const uint8_t* lds, float (&t)[TAPS][C]) {
-  constexpr int NB = TAPS * C * (int)sizeof(T), NW = (NB + 3) / 4;
-  typedef v2u32 v2u32_e __attribute__((aligned(1)));
-  typedef u32 u32_e __attribute__((aligned(1)));
-  u32 w[NW + 1];
-#pragma unroll
-  for (int k = 0; k < NW; k += 2) {
-    if (k + 1 < NW) {
-      const v2u32 q = *(const v2u32_e*)(lds + 4 * k);
-      w[k] = q.x; w[k + 1] = q.y;
-    } else {
-      w[k] = *(const u32_e*)(lds + 4 * k);
-    }
-  }
-#pragma unroll
-  for (int e = 0; e < TAPS * C; ++e) {
-    float v;
-    if constexpr (sizeof(T) == 1) v = (float)((w[e / 4] >> (8 * (e % 4))) & 0xffu);
-    else if constexpr (sizeof(T) == 2) v = (float)((w[e / 2] >> (16 * (e % 2))) & 0xffffu);
-    else v = __uint_as_float(w[e]);
-    t[e / C][e % C] = v;
-  }
-}
-
-typedef float v2f32 __attribute__((ext_vector_type(2)));
-
-// The window of horizontally filtered rows: six slots of [channel][lane] float4 (the lane's 4
-// pixels).  For 1-channel planes (Y, the planes of YUV4xx / RGB_PLANAR, the luma of NV12) it
-// lives in the wave's LDS (a ring addressed by a scalar head: appending a row is ONE
-// ds_write_b128, no register shifting -- the shifts were 31 % of an append's instructions);
-// 2- and 3-channel planes keep it in registers (12-18 KiB more LDS per wave costs a third of
-// the resident waves: NV12 with both planes in LDS measured 6.9 vs 5.7 us).
-template <int MAXC, int TAPS> struct alignas(16) LzRing { // one channel's window: TAPS KiB per wave
-  float4 slot[TAPS][1][kWave];
-};
-template <int TAPS> struct alignas(16) LzRing<3, TAPS> { // packed 3-channel formats have no 1-channel plane
-  float4 unused;
-};
-
-template <typename T, int C, int MAXC, int TAPS>
-__device__ __forceinline__ void lanczos_tile(const uint8_t* sp, int spitch, int sw, int sh,
-                                             uint8_t* dp, int dpitch, int dw, int dh, u32 tx,
-                                             u32 ty, LzStage* stage_all, LzRing<MAXC, TAPS>* ring_all, int variant = 7) {
-  constexpr int kBefore = LzTap<TAPS>::kBefore;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int x0 = (tx * 64 + lane) * 4;
-  const int y_first = ty * kRsTileH + wave * kRsRowsPerWave; // wave-uniform
-  if (y_first >= dh)
-    return;
-  const float scale_x = (float)sw / (float)dw, scale_y = (float)sh / (float)dh;
-  constexpr int PB = C * (int)sizeof(T);
-
-  LzTap<TAPS> cx[4];
-#pragma unroll
-  for (int p = 0; p < 4; ++p)
-    cx[p] = make_lz_tap<TAPS>(min(x0 + p, dw - 1), scale_x);
-  const int n = min(4, dw - x0);
-  // row taps: lane r evaluates row y_first + r, read back as scalars
-  const LzTap<TAPS> vy = make_lz_tap<TAPS>(y_first + (lane & (kRsRowsPerWave - 1)), scale_y);
-  auto row_tap = [&](int rr) {
-    LzTap<TAPS> t;
-    t.i = __builtin_amdgcn_readlane(vy.i, rr);
-#pragma unroll
-    for (int k = 0; k < TAPS; ++k)
-      t.w[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vy.w[k]), rr));
-    return t;
-  };
-
-  const int ux0 = __builtin_amdgcn_readlane(cx[0].i, 0) - kBefore;                  // unclamped span of the tile
-  const int ux1 = __builtin_amdgcn_readlane(cx[3].i, 63) + TAPS - 1 - kBefore;
-  const int sx0 = clampi(ux0, sw - 1), sx1 = clampi(ux1, sw - 1);
-  const int byte_begin = (sx0 * PB) & ~15;
-  const int nbytes = (((sx1 + 1) * PB + 15) & ~15) - byte_begin;
-  const bool staged = stage_all != nullptr && nbytes <= kLzRowBytes && ((((uintptr_t)sp) | (uintptr_t)spitch) & 15u) == 0;
-
-  if (staged) {
-    // Sliding window: hq[r] = the horizontal 6-tap filter of source row (base + r) at this
-    // lane's 4 columns.  Moving to the next dst row shifts the window by the advance of
-    // floor(y * scale) and filters only the source rows that entered it (an upscale re-uses
-    // almost all of them; a 3x downscale half).  Each h is computed by the same expression
-    // whatever dst row asked for it, so re-use does not change a bit.  One source row at a
-    // time goes through the wave's LDS strip; the next row's loads are in flight meanwhile.
-    LzStage& st = stage_all[wave];
-    const int nchunks = nbytes / 16;
-    // LDS byte offset of each pixel's FIRST tap (row-invariant); pixel j of the source row sits at
-    // kLzPad + j * PB - byte_begin, also for the replicas j < 0 and j >= sw
-    int lo[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-      lo[p] = kLzPad + (min(cx[p].i, sw) - kBefore) * PB - byte_begin;
-    const bool pad_left = ux0 < 0, pad_right = ux1 > sw - 1;   // wave-uniform
-    const int edge = kLzPad + (sw - 1) * PB - byte_begin;      // the last pixel of the row (when staged)
-    // column weights as pairs (pixels 0,1 and 2,3): the horizontal filter runs as packed FP32
-    v2f32 wq[2][TAPS];
-#pragma unroll
-    for (int k = 0; k < TAPS; ++k) {
-      wq[0][k] = (v2f32){cx[0].w[k], cx[1].w[k]};
-      wq[1][k] = (v2f32){cx[2].w[k], cx[3].w[k]};
-    }
-    constexpr bool kLdsRing = C == 1 && MAXC <= 2;
-    float hq[kLdsRing ? 1 : TAPS][4][C]; // register window (3-channel planes only)
-    int head = 0;                      // LDS ring: slot of the oldest row
-    uint4 pf[kLzCpr];
-    int pf_row = -0x40000000; // logical source row held by pf
-    auto issue = [&](int logical) {
-      const uint8_t* row = sp + (u32)(clampi(logical, sh - 1) * spitch + byte_begin);
-#pragma unroll
-      for (int c = 0; c < kLzCpr; ++c)
-        pf[c] = gload16(row + min(lane + c * kWave, nchunks - 1) * 16);
-      pf_row = logical;
-    };
-    auto append = [&](int logical) {
-      if (pf_row != logical) // first row of the wave, or a jump of more than TAPS rows
-        issue(logical);
-#pragma unroll
-      for (int c = 0; c < kLzCpr; ++c)
-        if (lane + c * kWave < nchunks)
-          *reinterpret_cast<uint4*>(&st.row[kLzPad + (lane + c * kWave) * 16]) = pf[c];
-      wave_lds_sync();
-      issue(logical + 1); // in flight while this row is filtered
-      if (pad_left || pad_right) { // image edges: replicate the first / last pixel into the pad
-        if (pad_left && lane < kBefore * PB)
-          st.row[kLzPad - kBefore * PB + lane] = st.row[kLzPad + lane % PB];
-        if (pad_right && lane < (TAPS - kBefore) * PB)
-          st.row[edge + PB + lane] = st.row[edge + lane % PB];
-        wave_lds_sync();
-      }
-      float hv[C][4];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) { // one pixel pair at a time: bounds the live registers
-        float t0[TAPS][C], t1[TAPS][C];
-        if (variant & 1) {
-          read_taps<T, C, TAPS>(st.row + lo[2 * q], t0);
-          read_taps<T, C, TAPS>(st.row + lo[2 * q + 1], t1);
-        } else {
-#pragma unroll
-          for (int k = 0; k < TAPS; ++k)
-#pragma unroll
-            for (int ch = 0; ch < C; ++ch) {
-              t0[k][ch] = (float)((const T*)(st.row + lo[2 * q] + k * PB))[ch];
-              t1[k][ch] = (float)((const T*)(st.row + lo[2 * q + 1] + k * PB))[ch];
-            }
-        }
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) {
-          if (variant & 2) {
-            v2f32 h = wq[q][0] * (v2f32){t0[0][ch], t1[0][ch]};
-#pragma unroll
-            for (int k = 1; k < TAPS; ++k)
-              h = __builtin_elementwise_fma(wq[q][k], (v2f32){t0[k][ch], t1[k][ch]}, h);
-            hv[ch][2 * q] = h.x; hv[ch][2 * q + 1] = h.y;
-          } else {
-            float h0 = wq[q][0].x * t0[0][ch], h1 = wq[q][0].y * t1[0][ch];
-#pragma unroll
-            for (int k = 1; k < TAPS; ++k) {
-              h0 = __builtin_fmaf(wq[q][k].x, t0[k][ch], h0);
-              h1 = __builtin_fmaf(wq[q][k].y, t1[k][ch], h1);
-            }
-            hv[ch][2 * q] = h0; hv[ch][2 * q + 1] = h1;
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int ch = 0; ch < C; ++ch) {
-        if constexpr (kLdsRing) {
-          ring_all[wave].slot[head][ch][lane] = make_float4(hv[ch][0], hv[ch][1], hv[ch][2], hv[ch][3]); // replaces the oldest
-        } else {
-#pragma unroll
-          for (int p = 0; p < 4; ++p) {
-#pragma unroll
-            for (int r = 0; r < TAPS - 1; ++r)
-              hq[r][p][ch] = hq[r + 1][p][ch];
-            hq[TAPS - 1][p][ch] = hv[ch][p];
-          }
-        }
-      }
-      if constexpr (kLdsRing)
-        head = head == TAPS - 1 ? 0 : head + 1;
-      wave_lds_sync(); // the strip is re-filled by the next row
-    };
-    int base = 0;
-#pragma unroll 1
-    for (int rr = 0; rr < kRsRowsPerWave; ++rr) {
-      const int y = y_first + rr;
-      if (y >= dh)
-        break;
-      const LzTap<TAPS> cy = row_tap(rr);
-      const int want = cy.i - kBefore;
-      const int delta = rr == 0 ? TAPS : min(want - base, TAPS);
-#pragma unroll 1
-      for (int s = 0; s < delta; ++s)
-        append(want + TAPS - delta + s);
-      base = want;
-      if (n > 0) {
-        float res[4][C];
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) {
-          v2f32 v01, v23;
-#pragma unroll
-          for (int r = 0; r < TAPS; ++r) {
-            v2f32 q01, q23;
-            if constexpr (kLdsRing) {
-              const int sl = head + r >= TAPS ? head + r - TAPS : head + r; // logical row r of the window
-              const float4 f = ring_all[wave].slot[sl][ch][lane];
-              q01 = (v2f32){f.x, f.y}; q23 = (v2f32){f.z, f.w};
-            } else {
-              q01 = (v2f32){hq[r][0][ch], hq[r][1][ch]}; q23 = (v2f32){hq[r][2][ch], hq[r][3][ch]};
-            }
-            const v2f32 wr = (v2f32){cy.w[r], cy.w[r]};
-            if (variant & 4) {
-              v01 = r == 0 ? wr * q01 : __builtin_elementwise_fma(wr, q01, v01);
-              v23 = r == 0 ? wr * q23 : __builtin_elementwise_fma(wr, q23, v23);
-            } else {
-              v01.x = r == 0 ? cy.w[r] * q01.x : __builtin_fmaf(cy.w[r], q01.x, v01.x);
-              v01.y = r == 0 ? cy.w[r] * q01.y : __builtin_fmaf(cy.w[r], q01.y, v01.y);
-              v23.x = r == 0 ? cy.w[r] * q23.x : __builtin_fmaf(cy.w[r], q23.x, v23.x);
-              v23.y = r == 0 ? cy.w[r] * q23.y : __builtin_fmaf(cy.w[r], q23.y, v23.y);
-            }
-          }
-          res[0][ch] = v01.x; res[1][ch] = v01.y; res[2][ch] = v23.x; res[3][ch] = v23.y;
-        }
-        store_px4<T, C>(dp + (u32)(y * dpitch) + (size_t)x0 * PB, res, (1u << n) - 1u);
-      }
-    }
-  } else {
-    // source span wider than the strip (or foreign unaligned memory): direct gather, TAPS^2 taps.
-    // (No early exit for lanes without pixels: row_tap() reads lanes 0..7, see resize_tile.)
-#pragma unroll 1
-    for (int rr = 0; rr < kRsRowsPerWave; ++rr) {
-      const int y = y_first + rr;
-      if (y >= dh)
-        break;
-      const LzTap<TAPS> cy = row_tap(rr);
-      if (n <= 0)
-        continue;
-      float res[4][C];
-      bool wide = false;
-      if constexpr (sizeof(T) == 4 && C == 3) {
-        // packed float RGB at >= 2x is the one format whose span exceeds the strip.  The TAPS
-        // pixels of a row are 12 TAPS contiguous bytes: in a wave whose taps all lie inside the
-        // image (every tile but the first and last of a row) they come as dwordx4 loads, 5 or 3
-        // instructions per row instead of 18 or 12 (the texture addresser charges per
-        // instruction).  Same taps, same accumulation order: the same bits.
-        bool inside = ((((uintptr_t)sp) | (uintptr_t)spitch) & 3u) == 0;
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-          inside = inside && cx[p].i - kBefore >= 0 && cx[p].i - kBefore + TAPS - 1 <= sw - 1;
-        wide = __builtin_amdgcn_ballot_w64(!inside) == 0; // wave-uniform: no per-lane merge of the two forms
-        if (wide) {
-          typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
-          typedef float v2f_a4 __attribute__((ext_vector_type(2), aligned(4)));
-#pragma unroll
-          for (int p = 0; p < 4; ++p) {
-            float v[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int r = 0; r < TAPS; ++r) {
-              const uint8_t* q = sp + (size_t)clampi(cy.i - kBefore + r, sh - 1) * spitch + (size_t)(cx[p].i - kBefore) * 12;
-              float tv[TAPS * 3];
-#pragma unroll
-              for (int k = 0; k < TAPS * 3 / 4; ++k) {
-                const v4f_a4 w4 = *(const VALI_GLOBAL v4f_a4*)(q + 16 * k);
-                tv[4 * k] = w4.x; tv[4 * k + 1] = w4.y; tv[4 * k + 2] = w4.z; tv[4 * k + 3] = w4.w;
-              }
-              if constexpr ((TAPS * 3) % 4 == 2) {
-                const v2f_a4 w2 = *(const VALI_GLOBAL v2f_a4*)(q + 16 * (TAPS * 3 / 4));
-                tv[TAPS * 3 - 2] = w2.x; tv[TAPS * 3 - 1] = w2.y;
-              }
-#pragma unroll
-              for (int ch = 0; ch < 3; ++ch) {
-                float h = cx[p].w[0] * tv[ch];
-#pragma unroll
-                for (int k = 1; k < TAPS; ++k)
-                  h = __builtin_fmaf(cx[p].w[k], tv[3 * k + ch], h);
-                v[ch] = r == 0 ? cy.w[0] * h : __builtin_fmaf(cy.w[r], h, v[ch]);
-              }
-              __builtin_amdgcn_sched_barrier(0); // one source row at a time: bounds the live registers
-            }
-            res[p][0] = v[0]; res[p][1] = v[1]; res[p][2] = v[2];
-          }
-        }
-      }
-      if (!wide)
-#pragma unroll
-      for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) {
-          float v = 0.0f;
-#pragma unroll
-          for (int r = 0; r < TAPS; ++r) {
-            const uint8_t* row = sp + (size_t)clampi(cy.i - kBefore + r, sh - 1) * spitch;
-            auto texel = [&](int k) {
-              return (float)gload<T>(row + (size_t)clampi(cx[p].i - kBefore + k, sw - 1) * PB + ch * sizeof(T));
-            };
-            float h = cx[p].w[0] * texel(0);
-#pragma unroll
-            for (int k = 1; k < TAPS; ++k)
-              h = __builtin_fmaf(cx[p].w[k], texel(k), h);
-            v = r == 0 ? cy.w[0] * h : __builtin_fmaf(cy.w[r], h, v);
-          }
-          res[p][ch] = v;
-        }
-      store_px4<T, C>(dp + (u32)(y * dpitch) + (size_t)x0 * PB, res, (1u << n) - 1u);
-    }
-  }
-}
-
-template <typename T, int MAXC, int TAPS>
-__global__ void __launch_bounds__(kBlock) k_resize_taps(const ResizeArgs a) {
-  ResizeJob job;
-  u32 tx, ty, frame;
-  if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
-    return;
-  __shared__ LzStage stage[kWavesPerBlock];
-  __shared__ LzRing<MAXC, TAPS> ring[kWavesPerBlock];
-  const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
-  if (MAXC >= 3 && job.channels == 3)
-    lanczos_tile<T, 3, MAXC, TAPS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.force_gather ? nullptr : stage, ring, a.variant);
-  else if (MAXC >= 2 && job.channels == 2)
-    lanczos_tile<T, 2, MAXC, TAPS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.force_gather ? nullptr : stage, ring, a.variant);
-  else
-    lanczos_tile<T, 1, MAXC, TAPS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.force_gather ? nullptr : stage, ring, a.variant);
-}
-
 template <typename T, int MAXC> constexpr auto k_resize_point = k_resize<T, MAXC, true>;
-template <typename T, int MAXC> constexpr auto k_resize_lanczos = k_resize_taps<T, MAXC, 6>;
-template <typename T, int MAXC> constexpr auto k_resize_cubic = k_resize_taps<T, MAXC, 4>;
 
 // plane jobs per pixel format: which components, their subsampling and channel count
 static int resize_jobs(int fmt, ResizeJob* j, int* elem) {
@@ -836,19 +401,12 @@ static int launch_resize(ResizeArgs& a, int fmt, int src_w, int src_h, int dst_w
   const bool filtered = interp != VALI_INTERP_LINEAR && !(integer_scale && elem != 4);
   const bool gather_only = tuning(VALI_TUNE_RESIZE_FORCE_GATHER) == 1;
   a.force_gather = gather_only ? 1 : 0;
-  a.variant = 7 ^ (tuning(VALI_TUNE_RESIZE_NO_SEPARABLE) & 7); // bit 0: wide LDS tap reads, 1 / 2: packed FP32 in the h / v pass
   const bool point_on = tuning(VALI_TUNE_RESIZE_POINT) != 0;
   if (integer_scale && elem != 4 && point_on) { // every filter is the point sample (see resize_tile)
     if (elem == 1) VALI_RS_LAUNCH(k_resize_point, uint8_t);
     else VALI_RS_LAUNCH(k_resize_point, uint16_t);
-  } else if (filtered && interp == VALI_INTERP_LANCZOS) {
-    if (elem == 1) VALI_RS_LAUNCH(k_resize_lanczos, uint8_t);
-    else if (elem == 2) VALI_RS_LAUNCH(k_resize_lanczos, uint16_t);
-    else VALI_RS_LAUNCH(k_resize_lanczos, float);
-  } else if (filtered) {
-    if (elem == 1) VALI_RS_LAUNCH(k_resize_cubic, uint8_t);
-    else if (elem == 2) VALI_RS_LAUNCH(k_resize_cubic, uint16_t);
-    else VALI_RS_LAUNCH(k_resize_cubic, float);
+  } else if (filtered) { // Lanczos-3 / bicubic at a non-integer ratio: resize_taps.hip
+    return launch_resize_taps(a, elem, interp == VALI_INTERP_LANCZOS ? 6 : 4, src_w, src_h, dst_w, dst_h, n, stream);
   } else {
     if (elem == 1) VALI_RS_LAUNCH(k_resize, uint8_t);
     else if (elem == 2) VALI_RS_LAUNCH(k_resize, uint16_t);

@@ -1,0 +1,28 @@
+// Shared between resize.hip (bilinear / point kernels, entry points) and resize_taps.hip (Lanczos-3 / bicubic).
+#pragma once
+#include "common.hpp"
+#include "dev_util.hpp"
+
+namespace vali {
+
+typedef PlaneJob ResizeJob; // dev_util.hpp
+
+struct ResizeArgs {
+  const vali_surface* d_src; // batch: device descriptor arrays
+  const vali_surface* d_dst;
+  int sw, sh, dw, dh;        // single frame: surface sizes (planes are resolved into the jobs)
+  ResizeJob job[3];
+  int njobs;
+  TileMap map;
+  int force_gather; // VALI_TUNE_RESIZE_FORCE_GATHER: no LDS staging (tests reach the gather forms with ordinary sizes)
+  // taps kernels (resize_taps.hip): dynamic LDS layout per wave = [stage_bytes: the staged source row][ring]
+  int stage_bytes;  // bytes of a wave's stage (pads included), multiple of 16; 0 = gather only
+  int lds_per_wave; // stage_bytes + ring bytes
+};
+
+// Lanczos-3 (taps = 6) / bicubic (taps = 4) over the plane jobs of `a` (job[].comp / sub / channels filled in, planes
+// resolved for single-frame launches); one launch per channel count present.  elem = bytes per element.
+int launch_resize_taps(const ResizeArgs& a, int elem, int taps, int src_w, int src_h, int dst_w, int dst_h, int n,
+                       hipStream_t stream);
+
+} // namespace vali
