@@ -275,7 +275,9 @@ VALI_API int vali_ud_nv12_rot_batch(const vali_surface* d_src, const vali_surfac
 enum vali_interpolation {
   VALI_INTERP_LINEAR = 1,   /* bilinear: BASELINE.json config 3 */
   VALI_INTERP_CUBIC = 4,    /* 4x4 Keys / Catmull-Rom cubic convolution (a = -1/2) */
-  VALI_INTERP_LANCZOS = 16  /* 6x6 interpolating Lanczos-3 (TaskResizeSurface.cpp:67,116,224,273) */
+  VALI_INTERP_LANCZOS = 16  /* 6x6 interpolating Lanczos-3 (TaskResizeSurface.cpp:67,116,224,273): the reference's
+                               only filter and PySurfaceResizer's default; taps + grid pinned against NPP output at a
+                               non-integer ratio (tests/test_oracle_reference_pins.py) */
 };
 
 /*
@@ -351,7 +353,7 @@ enum vali_tuning_key {
   VALI_TUNE_UD_OCC5 = 7,              /* 0: default-occupancy instantiation of the staged UD kernel (default 1)    */
   VALI_TUNE_ROTATE_NO_TILE = 8,       /* 1: quarter / half turns through the bilinear kernel                       */
   VALI_TUNE_ROCTX = 9,                /* 1: a roctx range around every operator entry point (see below)            */
-  VALI_TUNE_RESIZE_NO_SEPARABLE = 10, /* 1: Lanczos / bicubic through the sliding-window kernel only               */
+  VALI_TUNE_RESIZE_NO_SEPARABLE = 10, /* 1: Lanczos / bicubic always in 8-row waves (no 32- / 2-row launch forms)   */
   VALI_TUNE_COUNT = 11
 };
 VALI_API int vali_tuning_set(int key, int value);
