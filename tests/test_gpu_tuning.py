@@ -70,7 +70,8 @@ CASES = [
     ("UD_OCC5", (0,), lambda v, g: ud(v, g, 1280, 720, 854, 480, v.RGB)),
     ("UD_FORCE_GATHER", (1,), lambda v, g: ud(v, g, 1280, 720, 854, 480, v.RGB)),
     ("UD_FORCE_GATHER", (1,), lambda v, g: ud(v, g, 1280, 720, 640, 360, v.YUV444)),
-    ("ROTATE_NO_TILE", (1,), lambda v, g: rotate(v, g, 640, 360, 90.0)),
+    ("ROTATE_NO_TILE", (1, 2), lambda v, g: rotate(v, g, 640, 360, 90.0)),
+    ("ROTATE_NO_TILE", (2,), lambda v, g: rotate(v, g, 1000, 600, 270.0)),
     ("ROTATE_NO_TILE", (1,), lambda v, g: rotate(v, g, 640, 360, 180.0)),
 ]
 
