@@ -142,27 +142,30 @@ constexpr int kRotTile = 64;
 // shifts to reassemble them (2.4 -> see profiles/r01_secondary.md), and a row stride of 65
 // dwords makes the (16 row groups) x (4 columns) of a wave hit 64 different banks.
 constexpr int kRotTileHRgb = 64; // 128-row tiles (384-byte destination segments) measured slower: 3.0 vs 2.4 us
+constexpr int kRotTileWRgb = 64; // tile columns for 3-byte pixels; 128 (source segments = 3 whole 128-byte lines, 33 KB of
+                                 // LDS per workgroup) measured slower in round 2: 1080p 3.13 vs 2.71 us, 2160p 11.9 vs 10.2
 template <int QUARTER>
 __device__ __forceinline__ void rotate_tile_rgb8(const PlaneView& v, u32 tile_x, u32 tile_y) {
-  constexpr int P = 3, SD = kRotTile + 1; // LDS row stride in dwords
+  constexpr int P = 3, TW = kRotTileWRgb, SD = TW + 1; // LDS row stride in dwords
   constexpr int TH = kRotTileHRgb;        // tile rows
   __shared__ u32 lds[TH * SD];
   const int src_w = v.sw, src_h = v.sh, dst_w = v.dw, dst_h = v.dh;
   const uint8_t* src = v.sp;
   uint8_t* dst = v.dp;
   const int src_pitch = v.spitch, dst_pitch = v.dpitch;
-  const int cx = tile_x * kRotTile, ry = tile_y * TH; // src tile origin (col, row)
-  const int tw = min(kRotTile, src_w - cx), th = min(TH, src_h - ry);
+  const int cx = tile_x * TW, ry = tile_y * TH; // src tile origin (col, row)
+  const int tw = min(TW, src_w - cx), th = min(TH, src_h - ry);
   const int t = threadIdx.x;
 
-  // phase 1: 16 lanes x 4 pixels (one 12-byte load) per source row, 16 rows per pass
+  // phase 1: TW/4 lanes x 4 pixels (one 12-byte load) per source row
   const uint8_t* sbase = src + (size_t)ry * src_pitch + (size_t)cx * P;
   const bool vec = ((((uintptr_t)sbase) | (uintptr_t)src_pitch) & 3u) == 0;
   {
-  const int chunk = t & 15;
+  constexpr int kLanesPerSrcRow = TW / 4, kSrcRowsPerPass = kBlock / kLanesPerSrcRow;
+  const int chunk = t % kLanesPerSrcRow;
 #pragma unroll
-  for (int pass = 0; pass < TH / 16; ++pass) {
-    const int r = pass * 16 + (t >> 4);
+  for (int pass = 0; pass < TH / kSrcRowsPerPass; ++pass) {
+    const int r = pass * kSrcRowsPerPass + t / kLanesPerSrcRow;
     if (r >= th || chunk * 4 >= tw)
       continue;
     const uint8_t* q = sbase + (size_t)r * src_pitch + chunk * 12;
@@ -192,7 +195,7 @@ __device__ __forceinline__ void rotate_tile_rgb8(const PlaneView& v, u32 tile_x,
   constexpr int kLanesPerRow = TH / 4, kRowsPerPass = kBlock / kLanesPerRow;
   const int chunk = t % kLanesPerRow;
 #pragma unroll
-  for (int pass = 0; pass < kRotTile / kRowsPerPass; ++pass) {
+  for (int pass = 0; pass < TW / kRowsPerPass; ++pass) {
     const int lc = pass * kRowsPerPass + t / kLanesPerRow; // column of the src tile feeding this dst row
     if (lc >= tw)
       continue;
@@ -538,7 +541,8 @@ static int launch_rotate(RotArgs& a, int fmt, int sw, int sh, int dw, int dh, do
     j.first_tile = total;
     if (tiled) {
       const int th = elem * j.channels == 3 ? kRotTileHRgb : kRotTile;
-      j.tiles_x = (u32)(psw + kRotTile - 1) / kRotTile;
+      const int tw = elem * j.channels == 3 ? kRotTileWRgb : kRotTile;
+      j.tiles_x = (u32)(psw + tw - 1) / tw;
       total += j.tiles_x * (u32)((psh + th - 1) / th);
     } else if (half) {
       j.tiles_x = (u32)(pdw + 255) / 256;
