@@ -24,8 +24,10 @@ def test_compressed_input_and_encoders_raise(vali, tmp_path):
         vali.PyDecoder(str(tmp_path / "movie.mp4"), {}, gpu_id=-1)
     with pytest.raises(RuntimeError):
         vali.PyNvEncoder({}, 0)
-    with pytest.raises(RuntimeError):
-        vali.PyNvJpegEncoder(0)
+    with pytest.raises(ValueError):                              # TaskNvJpegEncode.cpp:123
+        vali.NvJpegEncodeContext(90, vali.NV12)
+    ctx = vali.NvJpegEncodeContext(90, vali.RGB)
+    assert ctx.Compression() == 90 and ctx.Format() == vali.RGB
 
 
 @pytest.mark.gpu
@@ -146,3 +148,40 @@ def test_real_pyav_decodes_the_reference_video_when_installed(vali):
     assert dec.DecodeSingleFrame(frame)[0]
     small = np.fromfile(GOLDEN / "test_small_2frames.nv12", np.uint8)[:424 * 232].reshape(232, 424)
     assert np.array_equal(frame[:848 * 464].reshape(464, 848)[0::2, 0::2], small)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["RGB", "YUV420", "RGB_PLANAR", "YUV444"])
+def test_jpeg_encoder_cpu_fallback(vali, gpu, oracle, fmt):
+    """reference tests/test_PyNvJpegEncoder.py:150-222: NV12 -> dst format on the GPU -> JPEG; for RGB the decoded
+    image must be within 42 dB of the raw surface.  Here the compression runs on the CPU (Pillow)."""
+    PIL = pytest.importorskip("PIL.Image")
+    import io
+
+    w, h = 424, 232
+    raw = np.fromfile(GOLDEN / "test_small_2frames.nv12", np.uint8).reshape(2, -1)
+    src = vali.Surface.Make(vali.NV12, w, h, gpu)
+    assert vali.PyFrameUploader(gpu).Run(raw[0], src)[0]
+    dst_fmt = vali.PixelFormat[fmt]
+    cvt = vali.PySurfaceConverter(gpu)
+    if fmt in ("RGB", "YUV420"):
+        dst = vali.Surface.Make(dst_fmt, w, h, gpu)
+        assert cvt.Run(src, dst)[0]
+    else:                                            # two steps, as a reference user would chain them
+        mid = vali.Surface.Make(vali.RGB, w, h, gpu)
+        dst = vali.Surface.Make(dst_fmt, w, h, gpu)
+        assert cvt.Run(src, mid)[0] and cvt.Run(mid, dst)[0]
+    enc = vali.PyNvJpegEncoder(gpu_id=gpu)
+    ctx = enc.Context(compression=100, pixel_format=dst_fmt)
+    buffers, info = enc.Run(ctx, [dst, dst])
+    assert info == vali.TaskExecInfo.SUCCESS and len(buffers) == 2 and buffers[0].dtype == np.uint8 and buffers[0].size > 1000
+    img = PIL.open(io.BytesIO(buffers[0].tobytes()))
+    assert img.size == (w, h)
+    if fmt == "RGB":
+        host = np.zeros(dst.HostSize, np.uint8)
+        assert vali.PySurfaceDownloader(gpu).Run(dst, host)[0]
+        d = np.asarray(img).astype(np.float64).reshape(-1) - host
+        assert 10 * np.log10(255.0 ** 2 / np.mean(d * d)) >= 42.0
+    # all or nothing: a surface of another format fails the whole call (PyNvJpegEncoder.cpp:66-69)
+    other = vali.Surface.Make(vali.BGR if fmt != "BGR" else vali.RGB, w, h, gpu)
+    assert enc.Run(ctx, [dst, other]) == ([], vali.TaskExecInfo.FAIL)

@@ -16,7 +16,8 @@ offline.  What IS provided so pipelines written against python_vali keep running
 * PyFrameConverter -- the reference's CPU (libswscale) converter API
                  (src/python_vali/src/PyFrameConverter.cpp:21-129) served by the HIP converter:
                  ndarray -> upload -> kernel -> download.  It is NOT a CPU code path.
-* PyNvEncoder / PyNvJpegEncoder -- raise: no encoder in scope.
+* PyNvJpegEncoder -- the reference's JPEG encoder API on the CPU (download + Pillow) so that pipelines keep their
+                 output side; PyNvEncoder (video) raises: no encoder in scope.
 """
 from __future__ import annotations
 
@@ -266,7 +267,7 @@ class PyFrameConverter:
 
 class _NoEncoder:
     def __init__(self, *args, **kwargs):
-        raise RuntimeError(f"{type(self).__name__}: video / JPEG encode ASICs are not supported on "
+        raise RuntimeError(f"{type(self).__name__}: video encode ASICs are not supported on "
                            "this backend (out of scope of the surface-processing path)")
 
 
@@ -274,5 +275,80 @@ class PyNvEncoder(_NoEncoder):
     """reference: src/python_vali/src/PyNvEncoder.cpp (NVENC)."""
 
 
-class PyNvJpegEncoder(_NoEncoder):
-    """reference: src/python_vali/src/PyNvJpegEncoder.cpp (nvJPEG)."""
+class NvJpegEncodeContext:
+    """reference: NvJpegEncodeContext (src/TC/inc/Tasks.hpp:251-267, src/TC/src/TaskNvJpegEncode.cpp:93-124):
+    compression coefficient + the pixel format of the surfaces to encode."""
+
+    # format -> PIL JPEG `subsampling` (TaskNvJpegEncode.cpp:101-124: RGB inputs encode 4:4:4, YUV inputs keep theirs)
+    _SUBSAMPLING = {F.RGB: 0, F.BGR: 0, F.RGB_PLANAR: 0, F.YUV444: 0, F.YUV422: 1, F.YUV420: 2}
+
+    def __init__(self, compression: int = 100, pixel_format: PixelFormat = F.RGB):
+        fmt = PixelFormat(pixel_format)
+        if fmt not in self._SUBSAMPLING:
+            raise ValueError("unsupported pixel format")            # std::invalid_argument, :123
+        self._compression, self._format = int(compression), fmt
+
+    def Compression(self) -> int:
+        return self._compression
+
+    def Format(self) -> PixelFormat:
+        return self._format
+
+
+class PyNvJpegEncoder:
+    """JPEG encoder with the reference's call surface (src/python_vali/src/PyNvJpegEncoder.cpp:21-160), served on the
+    CPU: the reference uses the nvJPEG ASIC / CUDA library, this backend downloads the surface on the encoder's stream
+    and compresses with Pillow (libjpeg) when it is importable -- the output side of pipelines written against
+    python_vali keeps working (north_star: decode / encode classes are CPU stubs around the surface path).
+    `Run(context, surfaces)` -> (list of uint8 arrays, TaskExecInfo): all surfaces or none (:36-75)."""
+
+    def __init__(self, gpu_id: int):
+        try:
+            from PIL import Image  # noqa: F401
+        except Exception as exc:  # pragma: no cover - depends on the environment
+            raise RuntimeError("PyNvJpegEncoder: no JPEG ASIC on this backend and Pillow (PIL) is not importable for the "
+                               f"CPU fallback ({exc})") from exc
+        self._gpu_id = int(gpu_id)
+        self._stream = HipResMgr.Instance().GetStream(self._gpu_id)
+        self._down = PySurfaceDownloader(self._gpu_id, self._stream)
+
+    def Context(self, compression: int, pixel_format: PixelFormat) -> NvJpegEncodeContext:
+        return NvJpegEncodeContext(compression, pixel_format)
+
+    def _image(self, fmt: PixelFormat, w: int, h: int, host: np.ndarray):
+        from PIL import Image
+
+        if fmt == F.RGB:
+            return Image.frombuffer("RGB", (w, h), host.tobytes(), "raw", "RGB", 0, 1)
+        if fmt == F.BGR:
+            return Image.fromarray(np.ascontiguousarray(host.reshape(h, w, 3)[..., ::-1]), "RGB")
+        if fmt == F.RGB_PLANAR:
+            return Image.fromarray(np.ascontiguousarray(host.reshape(3, h, w).transpose(1, 2, 0)), "RGB")
+        # planar YUV: JPEG stores YCbCr as it is (no colour conversion, like NVJPEG_INPUT_YUV); chroma planes are
+        # replicated to full size and libjpeg subsamples them again with the context's factors
+        y = host[: w * h].reshape(h, w)
+        cw, ch = (w, h) if fmt == F.YUV444 else (w // 2, h) if fmt == F.YUV422 else (w // 2, h // 2)
+        u = host[w * h: w * h + cw * ch].reshape(ch, cw)
+        v = host[w * h + cw * ch: w * h + 2 * cw * ch].reshape(ch, cw)
+        if (cw, ch) != (w, h):
+            u = np.repeat(np.repeat(u, h // ch, 0), w // cw, 1)[:h, :w]
+            v = np.repeat(np.repeat(v, h // ch, 0), w // cw, 1)[:h, :w]
+        return Image.fromarray(np.ascontiguousarray(np.stack([y, u, v], -1)), "YCbCr")
+
+    def Run(self, context: NvJpegEncodeContext, surfaces) -> Tuple[list, TaskExecInfo]:
+        import io
+
+        buffers = []
+        for surf in surfaces:
+            if surf is None or surf.IsEmpty or surf.Format != context.Format():      # :41-45: all or nothing
+                return [], TaskExecInfo.FAIL
+            host = np.zeros(surf.HostSize, np.uint8)
+            ok, _ = self._down.Run(surf, host)
+            if not ok:
+                return [], TaskExecInfo.FAIL
+            out = io.BytesIO()
+            q = max(1, min(100, context.Compression()))
+            self._image(surf.Format, surf.Width, surf.Height, host).save(
+                out, format="JPEG", quality=q, subsampling=NvJpegEncodeContext._SUBSAMPLING[surf.Format])
+            buffers.append(np.frombuffer(out.getvalue(), np.uint8).copy())
+        return buffers, TaskExecInfo.SUCCESS
