@@ -347,7 +347,7 @@ enum vali_tuning_key {
   VALI_TUNE_WAVES_PER_CU = 1,         /* residency cap of the streaming converters; 0 = auto                      */
   VALI_TUNE_NV12_DIRECT_STORE = 2,    /* 1: NV12->RGB stores 48 B per lane instead of going through the LDS strip */
   VALI_TUNE_RESIZE_FORCE_GATHER = 3,  /* 1: every resize geometry through the direct-gather form                  */
-  VALI_TUNE_RESIZE_POINT = 4,         /* 0: keep the arithmetic form at integer scale factors (default 1)         */
+  VALI_TUNE_RESIZE_POINT = 4,         /* 0: arithmetic form at integer scale factors; 2: staged point form only (default 1) */
   VALI_TUNE_UD_FORCE_GATHER = 5,      /* 1: every UD geometry through the direct-gather form, no exact-ratio kernels */
   VALI_TUNE_UD_DOWN2 = 6,             /* 0: general UD kernel also at the exact 2:1 / 1:1 width ratios (default 1) */
   VALI_TUNE_UD_OCC5 = 7,              /* 0: default-occupancy instantiation of the staged UD kernel (default 1)    */

@@ -58,8 +58,9 @@ CASES = [
     ("WAVES_PER_CU", (4, 8, 24, 32), lambda v, g: nv12_rgb(v, g, 1920, 1080, v.RGB)),
     ("NV12_DIRECT_STORE", (1,), lambda v, g: nv12_rgb(v, g, 1920, 1080, v.BGR)),
     ("NV12_DIRECT_STORE", (1,), lambda v, g: nv12_rgb(v, g, 854, 480, v.RGB)),
-    ("RESIZE_POINT", (0,), lambda v, g: resize(v, g, 1920, 1080, 640, 360, v.Interpolation.LINEAR)),
-    ("RESIZE_POINT", (0,), lambda v, g: resize(v, g, 1920, 1080, 960, 540, v.Interpolation.LANCZOS)),
+    ("RESIZE_POINT", (0, 2), lambda v, g: resize(v, g, 1920, 1080, 640, 360, v.Interpolation.LINEAR)),
+    ("RESIZE_POINT", (0, 2), lambda v, g: resize(v, g, 1920, 1080, 960, 540, v.Interpolation.LANCZOS)),
+    ("RESIZE_POINT", (0, 2), lambda v, g: resize(v, g, 1272, 720, 318, 90, v.Interpolation.CUBIC)),
     ("RESIZE_FORCE_GATHER", (1,), lambda v, g: resize(v, g, 1280, 720, 854, 480, v.Interpolation.LINEAR)),
     ("RESIZE_FORCE_GATHER", (1,), lambda v, g: resize(v, g, 1280, 720, 854, 480, v.Interpolation.LANCZOS)),
     ("RESIZE_FORCE_GATHER", (1,), lambda v, g: resize(v, g, 640, 360, 1280, 720, v.Interpolation.CUBIC)),
