@@ -353,7 +353,7 @@ enum vali_tuning_key {
   VALI_TUNE_UD_OCC5 = 7,              /* 0: default-occupancy instantiation of the staged UD kernel (default 1)    */
   VALI_TUNE_ROTATE_NO_TILE = 8,       /* 1: quarter / half turns through the bilinear kernel; 2: row-major tile walk */
   VALI_TUNE_ROCTX = 9,                /* 1: a roctx range around every operator entry point (see below)            */
-  VALI_TUNE_RESIZE_NO_SEPARABLE = 10, /* 1: Lanczos / bicubic always in 8-row waves (no 32- / 2-row launch forms)   */
+  VALI_TUNE_RESIZE_NO_SEPARABLE = 10, /* Lanczos / bicubic rows per wave: 0 by launch size, 1: 8, 2: 2, 3: 32           */
   VALI_TUNE_COUNT = 11
 };
 VALI_API int vali_tuning_set(int key, int value);

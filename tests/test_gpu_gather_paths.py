@@ -31,6 +31,11 @@ def test_parity_suites_through_the_gather_forms():
     ("VALI_UD_OCC5=0", ["tests/test_gpu_ud.py"]),
     ("VALI_UD_DOWN2=0", ["tests/test_gpu_ud.py", "tests/test_gpu_ud_down2.py"]),
     ("VALI_RESIZE_POINT=0", ["tests/test_gpu_resize.py"]),
+    ("VALI_RESIZE_POINT=2", ["tests/test_gpu_resize.py", "tests/test_gpu_edge_geometry.py"]),
+    # the Lanczos / bicubic kernel picks 2- / 8- / 32-row waves by the size of the launch: single-surface tests only
+    # ever see the 2-row form, so the whole parity suites are replayed through each of the others
+    ("VALI_RESIZE_NO_SEPARABLE=1", ["tests/test_gpu_resize.py", "tests/test_gpu_edge_geometry.py", "tests/test_gpu_random_geometry.py", "tests/test_gpu_ud.py"]),
+    ("VALI_RESIZE_NO_SEPARABLE=3", ["tests/test_gpu_resize.py", "tests/test_gpu_edge_geometry.py", "tests/test_gpu_random_geometry.py", "tests/test_gpu_ud.py"]),
 ])
 def test_parity_suites_under_each_ab_switch(switch, files):
     """the alternative kernel forms kept behind environment switches (tools/README.md) stay bit-exact"""

@@ -230,3 +230,22 @@ def test_integer_scale_foreign_unaligned_source(vali, gpu, oracle):
         assert vali.PySurfaceResizer(vali.NV12, gpu).Run(src, small)[0]
         assert np.array_equal(download(vali, gpu, small), oracle.resize_surface(nv.reshape(-1), "NV12", sw, sh, dw, dh, "linear"))
         del keep
+
+
+def test_lanczos_batch_large_enough_for_32_row_waves(vali, gpu, oracle):
+    """A launch with >= 1024 tiles of 128 rows takes the 32-rows-per-wave form of the Lanczos kernel by itself (the
+    form the batched benchmarks run); every frame bit-exact."""
+    sw, sh, dw, dh, n = 640, 360, 854, 480, 48
+    rs = vali.PySurfaceResizer(vali.NV12, gpu)
+    rng = np.random.default_rng(77)
+    frames = [rng.integers(0, 256, sw * sh * 3 // 2, dtype=np.uint8) for _ in range(3)]
+    srcs = [vali.Surface.Make(vali.NV12, sw, sh, gpu) for _ in range(n)]
+    dsts = [vali.Surface.Make(vali.NV12, dw, dh, gpu) for _ in range(n)]
+    for i, s in enumerate(srcs):
+        assert vali.PyFrameUploader(gpu).Run(frames[i % 3], s)[0]
+    assert rs.RunBatch(srcs, dsts) == (True, vali.TaskExecInfo.SUCCESS)
+    wants = [oracle.resize_surface(f, "NV12", sw, sh, dw, dh, "lanczos") for f in frames]
+    for i, d in enumerate(dsts):
+        out = np.zeros(d.HostSize, np.uint8)
+        assert vali.PySurfaceDownloader(gpu).Run(d, out)[0]
+        assert np.array_equal(out, wants[i % 3]), i

@@ -410,7 +410,8 @@ static void launch_rows(const ResizeArgs& a, int rows, dim3 grid, unsigned lds, 
 int launch_resize_taps(const ResizeArgs& base, int elem, int taps, int src_w, int src_h, int dst_w, int dst_h, int n,
                        hipStream_t stream) {
   const bool gather_only = tuning(VALI_TUNE_RESIZE_FORCE_GATHER) == 1;
-  const bool small_tiles_only = tuning(VALI_TUNE_RESIZE_NO_SEPARABLE) == 1; // A/B: 8-row waves whatever the batch
+  // A/B and path coverage: 1 / 2 / 3 force 8- / 2- / 32-row waves whatever the size of the launch
+  const int force = tuning(VALI_TUNE_RESIZE_NO_SEPARABLE);
   ResizeArgs a = base;
   int span = 0, esset = 0;
   for (int k = 0; k < a.njobs; ++k) {
@@ -441,7 +442,7 @@ int launch_resize_taps(const ResizeArgs& base, int elem, int taps, int src_w, in
   // leave SIMDs idle -- a lone wave is bound by its own instruction latency, so a single frame is cut into many
   // short waves, at the price of filtering more rows twice
   const unsigned long long t32 = (unsigned long long)count(32, false) * (unsigned)n, t8 = (unsigned long long)count(8, false) * (unsigned)n;
-  const int rows = small_tiles_only ? 8 : t32 >= 1024ull ? 32 : t8 >= 768ull ? 8 : 2;
+  const int rows = force == 1 ? 8 : force == 2 ? 2 : force == 3 ? 32 : t32 >= 1024ull ? 32 : t8 >= 768ull ? 8 : 2;
   a.map = make_tile_map_linear(count(rows, true), (u32)n);
   a.force_gather = gather_only ? 1 : 0;
   a.stage_bytes = (span + kLzPadL + kLzPadR <= kLzStageCap && !gather_only) ? ((span + 15) & ~15) + kLzPadL + kLzPadR : 0;
