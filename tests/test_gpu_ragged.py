@@ -246,3 +246,22 @@ def test_odd_stride_torch_tensors_both_sides(vali, gpu, oracle):
     out = dbuf.cpu().numpy()
     assert np.array_equal(out[:, :3 * w], oracle.nv12_to_rgb(nv12, w, h, oracle.csc(1), "RGB"))
     assert np.all(out[:, 3 * w:] == SENTINEL)
+
+
+@pytest.mark.parametrize("pair", [("NV12", "RGB"), ("NV12", "RGB_PLANAR"), ("RGB", "YUV420"), ("RGB", "RGB_PLANAR"), ("YUV420", "BGR")])
+def test_ragged_batch_equals_oracle(vali, gpu, oracle, pair):
+    """the batched launches (device descriptor arrays) take the same ragged path, decided per frame in the kernel"""
+    src, dst = pair
+    w, h, n = 854, 480, 5
+    cvt = vali.PySurfaceConverter(gpu)
+    srcs = [vali.Surface.Make(vali.PixelFormat[src], w, h, gpu) for _ in range(n)]
+    dsts = [vali.Surface.Make(vali.PixelFormat[dst], w, h, gpu) for _ in range(n)]
+    hosts = [host_image(src, w, h, 60 + i, oracle) for i in range(n)]
+    for hst, s in zip(hosts, srcs):
+        assert vali.PyFrameUploader(gpu).Run(hst, s)[0]
+    assert cvt.RunBatch(srcs, dsts) == (True, vali.TaskExecInfo.SUCCESS)
+    _, op = _params(vali, oracle, src, dst)
+    for hst, d in zip(hosts, dsts):
+        got = np.zeros(d.HostSize, np.uint8)
+        assert vali.PySurfaceDownloader(gpu).Run(d, got)[0]
+        assert np.array_equal(got, oracle.convert(hst, src, dst, w, h, op))
