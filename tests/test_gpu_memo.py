@@ -184,3 +184,21 @@ def test_surface_batch_cannot_be_created_while_capturing(vali, gpu):
     cap.Keep(ready)
     cap.Launch()
     shim.stream_sync(gpu, stream)
+
+
+def test_batch_cache_does_not_pin_surfaces(vali, gpu):
+    """the task's descriptor-array cache keeps no reference to the caller's surfaces: dropping the lists frees them"""
+    import gc
+    import weakref
+
+    cvt = vali.PySurfaceConverter(gpu)
+    srcs = [vali.Surface.Make(vali.NV12, 64, 48, gpu) for _ in range(2)]
+    dsts = [vali.Surface.Make(vali.RGB, 64, 48, gpu) for _ in range(2)]
+    assert cvt.RunBatch(srcs, dsts)[0]
+    ref = weakref.ref(dsts[0])
+    del srcs, dsts
+    gc.collect()
+    assert ref() is None
+    kept = cvt.PrepareBatch([vali.Surface.Make(vali.NV12, 64, 48, gpu)], [vali.Surface.Make(vali.RGB, 64, 48, gpu)])
+    gc.collect()
+    assert cvt.RunBatch(kept)[0]          # a PREPARED batch owns its surfaces

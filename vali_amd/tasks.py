@@ -286,6 +286,10 @@ class _SurfaceTask:
             if len(self._batches) >= 8:
                 self._batches.pop(next(iter(self._batches)))
             b = self._batches[key] = SurfaceBatch(self._gpu_id, self._stream, srcs, dsts)
+            # the cache must not pin the caller's surfaces (a task fed fresh lists of 512 2160p frames would hold
+            # 8 x 19 GB): it keeps the descriptor arrays only; a hit needs the SAME descriptor objects, i.e. live
+            # surfaces that were not re-pointed, and a freed surface's descriptors can never match a new one's
+            b._keep = None
         return b
 
     def _memo_put(self, key, fn, args, keep=None):
@@ -400,7 +404,8 @@ class SurfaceBatch:
         self.src_format, self.dst_format = srcs[0].Format, dsts[0].Format
         self.src_size = (srcs[0].Width, srcs[0].Height)
         self.dst_size = (dsts[0].Width, dsts[0].Height)
-        self._keep = (srcs, dsts)
+        self._keep = (srcs, dsts)        # a prepared batch keeps its surfaces alive (the task's own cache does not)
+        self.src_components, self.src_planes = srcs[0].NumComponents, srcs[0].NumPlanes
         self.d_src = shim.descs_upload(gpu_id, [s.desc() for s in srcs], stream)
         self.d_dst = shim.descs_upload(gpu_id, [s.desc() for s in dsts], stream)
 
@@ -720,8 +725,7 @@ class PySurfaceRotator(_SurfaceTask):
                       shift_y: float = 0.0) -> Tuple[bool, TaskExecInfo]:
         """One launch rotates every plane of every surface of the batch."""
         batch = self._batch_of(batch, dsts)
-        s0 = batch._keep[0][0]
-        err = self._check(batch.src_format, batch.dst_format, s0.NumComponents, s0.NumPlanes)
+        err = self._check(batch.src_format, batch.dst_format, batch.src_components, batch.src_planes)
         if err is not None:
             return False, err.info
         angle, per_plane = self._normalise(float(angle), float(shift_x), float(shift_y))
