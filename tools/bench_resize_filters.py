@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Lanczos / bicubic / bilinear throughput over formats and geometries, under the rows-per-wave forms of the taps kernel (the table of profiles/r02_lanczos.md)."""
 import sys, json
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tools')
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent)); sys.path.insert(0, str(Path(__file__).resolve().parent))
 import vali_amd as vali
 import bench_configs as bc
 from bench_configs import DEV, timed, fill
@@ -11,7 +14,7 @@ def run(fmt,sw,sh,dw,dh,interp,n=32):
 L,Cu,Li=vali.Interpolation.LANCZOS,vali.Interpolation.CUBIC,vali.Interpolation.LINEAR
 for small in (0,1):
     vali.tuning.Set("RESIZE_NO_SEPARABLE", small)
-    print('8-row tiles only' if small else 'auto tiles')
+    print('8-row waves only' if small else 'rows per wave by launch size')
     print('  NV12 2160->1088: lanczos', run(vali.NV12,3840,2160,1920,1088,L,64), 'cubic', run(vali.NV12,3840,2160,1920,1088,Cu,64), 'linear', run(vali.NV12,3840,2160,1920,1088,Li,64), flush=True)
     print('  NV12 1080->2160: lanczos', run(vali.NV12,1920,1080,3840,2160,L,16), 'cubic', run(vali.NV12,1920,1080,3840,2160,Cu,16), flush=True)
     print('  Y 2160->1088 lanczos', run(vali.Y,3840,2160,1920,1088,L,64), ' YUV420', run(vali.YUV420,3840,2160,1920,1088,L,64), flush=True)

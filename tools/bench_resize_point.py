@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Integer-factor (point sample) resize: the strided-window kernel (RESIZE_POINT=1) vs the staged point form (2)."""
 import sys
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tools')
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent)); sys.path.insert(0, str(Path(__file__).resolve().parent))
 import vali_amd as vali
 from bench_configs import DEV, timed, fill
 def run(fmt,sw,sh,dw,dh,n=64):

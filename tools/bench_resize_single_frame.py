@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Single-frame (RunAsync / small batch) latency of the resizer: stream time and host time per call."""
 import sys
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tools')
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent)); sys.path.insert(0, str(Path(__file__).resolve().parent))
 import vali_amd as vali
 from bench_configs import DEV, timed, fill
 L,Li=vali.Interpolation.LANCZOS,vali.Interpolation.LINEAR

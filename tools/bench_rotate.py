@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Quarter-turn rotation throughput under the two tile walk orders (ROTATE_NO_TILE 0 / 2)."""
 import sys
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tools')
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent)); sys.path.insert(0, str(Path(__file__).resolve().parent))
 import vali_amd as vali
 from bench_configs import DEV, timed, fill
 def run(fmt, w,h, n=64, angle=90.0):

@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""One batched resize, for profiling: python tools/resize_one.py [lanczos|cubic|linear] SW SH DW DH [FORMAT] (batch 64, 5 timed launches; used with tools/prof_pmc.sh)."""
 import sys
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tools')
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent)); sys.path.insert(0, str(Path(__file__).resolve().parent))
 import vali_amd as vali
 from bench_configs import DEV, timed, fill
 interp = {"lanczos": vali.Interpolation.LANCZOS, "cubic": vali.Interpolation.CUBIC, "linear": vali.Interpolation.LINEAR}[sys.argv[1] if len(sys.argv) > 1 else "lanczos"]
