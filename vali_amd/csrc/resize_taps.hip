@@ -14,16 +14,20 @@
 // (integer ratios never come here: every weight is 0 or 1 and the bilinear kernel's point form gives the same
 // bytes, resize.hip.)
 //
-// Work decomposition: one lane = 4 adjacent dst pixels, one wave = 256 columns x ROWS dst rows, walked top to
-// bottom with a SLIDING WINDOW of horizontally filtered source rows: each source row of the wave's span goes
-// through the wave's LDS strip once (16-byte coalesced loads, next row in flight), every lane filters it at its
-// 4 columns (the TAPS taps of a pixel come with ONE misaligned LDS read), and the result joins the window -- an
-// LDS ring for 1-channel planes, registers for 2 / 3 channels.  ROWS = 32 when the launch has tiles to spare
-// (batches): the TAPS - 1 rows two neighbouring waves both filter and the ~350 instructions of tap-weight set-up
-// are then spread over 4x the pixels; ROWS = 8 keeps 256 CUs busy on a single frame.  Planes of different channel
-// counts (the Y and UV planes of NV12) go in separate launches: the 1-channel kernel -- 80 % of an NV12 frame --
-// is not held to the register count of the 2-channel one.  What bounds it: FP32 VALU (6 converts + 6 FMA per
-// horizontally filtered sample; ~45 instructions per output sample all in), profiles/r02_lanczos.md.
+// Work decomposition: every plane is treated as a 1-channel plane of ELEMENTS (a pixel = ES interleaved elements:
+// 1 for Y and the planes of planar formats, 2 for the UV plane of NV12 / P10, 3 for packed RGB; taps are ES elements
+// apart), so all planes of a surface share one launch and one register budget.  One wave = 256 elements x ROWS dst
+// rows, walked top to bottom over the SOURCE rows it needs: each source row goes through the wave's LDS stage once
+// (16-byte coalesced loads, 4 rows in flight), is filtered horizontally by element-interleaved lanes (lane l:
+// elements l, l+64, l+128, l+192 -- neighbouring lanes read neighbouring LDS dwords; a lane reads the aligned dwords
+// covering its taps and funnel-shifts them with v_alignbyte_b32) and joins a ring of TAPS filtered rows in LDS; a
+// dst row is emitted when its window is complete, by lanes that own 4 ADJACENT elements (the ring transposes the
+// mapping: one float4 per ring row, one wide store).  ROWS = 32 when the launch has tiles to spare (batches): the
+// TAPS - 1 rows two neighbouring waves both filter and the tap-weight set-up are spread over 4x the rows; 8 or 2
+// for small launches, where a lone wave is bound by its own instruction latency.  What bounds it: FP32 VALU
+// (per filtered sample 2 funnel shifts + 6 converts + 3 packed FMA + 1 add; 44 lane-instructions per output sample
+// at a 2:1 ratio, VALU busy 62 %, LDS pipe 44 %) -- profiles/r02_lanczos.md has the counters of this and of the four
+// designs it replaced.
 #include "resize_common.hpp"
 
 #include <type_traits>
