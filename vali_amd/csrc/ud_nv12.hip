@@ -119,14 +119,69 @@ template <typename T, int OUT> struct UdScale {
                                  : (OUT == UD_RGB_U8 || OUT == UD_RGB_U8_PLANAR) ? 256.0f : 1.0f;
 };
 
-// four pre-scaled values -> 4 truncated, saturated bytes in one dword
-// (v_trunc_f32 + v_cvt_pk_u8_f32: the convert saturates and merges the byte; its rounding is
-// a no-op on an integer-valued float) == cvt.rzi.u8.f32 + packing
-__device__ __forceinline__ u32 trunc_pack4(float a, float b, float c, float e) {
-  u32 w = pack_u8<0>(__builtin_truncf(a), 0u);
-  w = pack_u8<1>(__builtin_truncf(b), w);
-  w = pack_u8<2>(__builtin_truncf(c), w);
-  return pack_u8<3>(__builtin_truncf(e), w);
+// Twelve pre-scaled values -> 12 TRUNCATED, saturated bytes == the reference's cvt.rzi.u8.f32 + packing.
+// v_cvt_pk_u8_f32 converts in the wave's FP32 rounding mode (MODE[1:0]; measured on gfx950 over 65536 values incl.
+// ties, negatives, > 255 and NaN: mode 3 = toward zero gives exactly trunc + saturate, tools/exp/rtz.hip), so the
+// separate v_trunc_f32 per byte (12 of the ~86 VALU instructions of four pixels in the exact-2x kernel) becomes two
+// scalar s_setreg around a block of twelve converts.  ONE asm statement: its inputs are finished before it starts
+// and nothing else can be scheduled inside, so no other float instruction ever runs in the switched mode.
+// Layout kQuads: w[d] = bytes v[4d..4d+3]; !kQuads: w[p] = bytes v[3p], v[3p+1], v[3p+2], 0 (one dword per pixel).
+template <bool kQuads>
+__device__ __forceinline__ void trunc_pack12(const float (&v)[12], u32* w) {
+  if constexpr (kQuads) {
+    u32 w0, w1, w2;
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+                 "v_cvt_pk_u8_f32 %0, %3, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %4, 1, %0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %5, 2, %0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %6, 3, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %7, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %8, 1, %1\n\t"
+                 "v_cvt_pk_u8_f32 %1, %9, 2, %1\n\t"
+                 "v_cvt_pk_u8_f32 %1, %10, 3, %1\n\t"
+                 "v_cvt_pk_u8_f32 %2, %11, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %2, %12, 1, %2\n\t"
+                 "v_cvt_pk_u8_f32 %2, %13, 2, %2\n\t"
+                 "v_cvt_pk_u8_f32 %2, %14, 3, %2\n\t"
+                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+                 : "=&v"(w0), "=&v"(w1), "=&v"(w2)
+                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]),
+                   "v"(v[9]), "v"(v[10]), "v"(v[11]));
+    w[0] = w0; w[1] = w1; w[2] = w2;
+  } else {
+    u32 w0, w1, w2, w3;
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+                 "v_cvt_pk_u8_f32 %0, %4, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %5, 1, %0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %6, 2, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %7, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %8, 1, %1\n\t"
+                 "v_cvt_pk_u8_f32 %1, %9, 2, %1\n\t"
+                 "v_cvt_pk_u8_f32 %2, %10, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %2, %11, 1, %2\n\t"
+                 "v_cvt_pk_u8_f32 %2, %12, 2, %2\n\t"
+                 "v_cvt_pk_u8_f32 %3, %13, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %3, %14, 1, %3\n\t"
+                 "v_cvt_pk_u8_f32 %3, %15, 2, %3\n\t"
+                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+                 : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3)
+                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]),
+                   "v"(v[9]), "v"(v[10]), "v"(v[11]));
+    w[0] = w0; w[1] = w1; w[2] = w2; w[3] = w3;
+  }
+}
+// three dwords of four bytes each: (a0..a3), (b0..b3), (c0..c3)
+__device__ __forceinline__ void trunc_pack3x4(float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3,
+                                              float c0, float c1, float c2, float c3, u32& wa, u32& wb, u32& wc) {
+  const float v[12] = {a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3};
+  u32 w[3];
+  trunc_pack12<true>(v, w);
+  wa = w[0]; wb = w[1]; wc = w[2];
+}
+// one dword per pixel (bytes c0, c1, c2, 0) for 4 pixels
+__device__ __forceinline__ void trunc_pack_px4(const float* c0, const float* c1, const float* c2, u32* px) {
+  const float v[12] = {c0[0], c1[0], c2[0], c0[1], c1[1], c2[1], c0[2], c1[2], c2[2], c0[3], c1[3], c2[3]};
+  trunc_pack12<false>(v, px);
 }
 
 // store 4 pixels of one dst row; c0/c1/c2 = Y,U,V or R,G,B already multiplied by
@@ -145,9 +200,8 @@ __device__ __forceinline__ void ud_store(const SurfRef& d, int x0, int y, int n,
     constexpr u32 kA = sizeof(T) == 1 ? 3u : 7u;
     const bool fast = n == 4 && ((((uintptr_t)o0) | ((uintptr_t)o1) | ((uintptr_t)o2)) & kA) == 0;
     if constexpr (sizeof(T) == 1) {
-      const u32 w0 = trunc_pack4(c0[0], c0[1], c0[2], c0[3]);
-      const u32 w1 = trunc_pack4(c1[0], c1[1], c1[2], c1[3]);
-      const u32 w2 = trunc_pack4(c2[0], c2[1], c2[2], c2[3]);
+      u32 w0, w1, w2;
+      trunc_pack3x4(c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3], c2[0], c2[1], c2[2], c2[3], w0, w1, w2);
       if (fast) {
         gstore<u32>(o0, w0); gstore<u32>(o1, w1); gstore<u32>(o2, w2);
       } else {
@@ -173,9 +227,8 @@ __device__ __forceinline__ void ud_store(const SurfRef& d, int x0, int y, int n,
       }
     }
   } else if constexpr (OUT == UD_RGB_U8_PLANAR) {
-    const u32 wr = trunc_pack4(c0[0], c0[1], c0[2], c0[3]);
-    const u32 wg = trunc_pack4(c1[0], c1[1], c1[2], c1[3]);
-    const u32 wb = trunc_pack4(c2[0], c2[1], c2[2], c2[3]);
+    u32 wr, wg, wb;
+    trunc_pack3x4(c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3], c2[0], c2[1], c2[2], c2[3], wr, wg, wb);
     uint8_t* o0 = pd0 + (u32)(y * dp0) + x0;
     uint8_t* o1 = pd1 + (u32)(y * dp0) + x0;
     uint8_t* o2 = pd2 + (u32)(y * dp0) + x0;
@@ -189,9 +242,8 @@ __device__ __forceinline__ void ud_store(const SurfRef& d, int x0, int y, int n,
     }
   } else if constexpr (OUT == UD_RGB_U8) {
     // bytes in memory order: r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3
-    const u32 w0 = trunc_pack4(c0[0], c1[0], c2[0], c0[1]);
-    const u32 w1 = trunc_pack4(c1[1], c2[1], c0[2], c1[2]);
-    const u32 w2 = trunc_pack4(c2[2], c0[3], c1[3], c2[3]);
+    u32 w0, w1, w2;
+    trunc_pack3x4(c0[0], c1[0], c2[0], c0[1], c1[1], c2[1], c0[2], c1[2], c2[2], c0[3], c1[3], c2[3], w0, w1, w2);
     uint8_t* o = pd0 + (u32)(y * dp0) + (size_t)x0 * 3;
     if (n == 4 && (((uintptr_t)o) & 3u) == 0) {
       typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
@@ -267,9 +319,8 @@ __device__ __forceinline__ void ud_emit(const SurfRef& d, uint8_t* rot_tile, int
     ud_store<T, OUT>(d, x0, y, n, c0, c1, c2);
   } else if constexpr (ROT == 2) {
     // dst(uw-1-x, uh-1-y) = ud(x, y): the lane's 4 pixels in reverse order
-    const u32 w0 = trunc_pack4(c0[3], c1[3], c2[3], c0[2]);
-    const u32 w1 = trunc_pack4(c1[2], c2[2], c0[1], c1[1]);
-    const u32 w2 = trunc_pack4(c2[1], c0[0], c1[0], c2[0]);
+    u32 w0, w1, w2;
+    trunc_pack3x4(c0[3], c1[3], c2[3], c0[2], c1[2], c2[2], c0[1], c1[1], c2[1], c0[0], c1[0], c2[0], w0, w1, w2);
     uint8_t* row = d.p[0] + (u32)((dh - 1 - y) * d.pitch[0]);
     uint8_t* o = row + (ptrdiff_t)(dw - 4 - x0) * 3;
     if (n == 4 && (((uintptr_t)o) & 3u) == 0) {
@@ -288,12 +339,7 @@ __device__ __forceinline__ void ud_emit(const SurfRef& d, uint8_t* rot_tile, int
     // row (wave, rr) of the workgroup tile, one dword per pixel; written transposed after the barrier
     u32* t = reinterpret_cast<u32*>(rot_tile + (wave * kUdRowsPerWave + rr) * kRotStride);
     u32 px[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      px[p] = pack_u8<0>(__builtin_truncf(c0[p]), 0u);
-      px[p] = pack_u8<1>(__builtin_truncf(c1[p]), px[p]);
-      px[p] = pack_u8<2>(__builtin_truncf(c2[p]), px[p]);
-    }
+    trunc_pack_px4(c0, c1, c2, px);
     if constexpr (STRIDED) {
 #pragma unroll
       for (int p = 0; p < 4; ++p)
@@ -1005,12 +1051,14 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t strip[kPacked ? kWavesPerBlock : 1][kPacked ? kD2WaveW * 3 : 16];
   auto emit_planar = [&](int y, const float (&c0)[8], const float (&c1)[8], const float (&c2)[8]) {
     const int pp[3] = {d.pitch[0], OUT == UD_YUV444 ? d.pitch[1] : d.pitch[0], OUT == UD_YUV444 ? d.pitch[2] : d.pitch[0]};
-    const float* cc[3] = {c0, c1, c2};
+    // the six dwords of the three planes (lo / hi halves of the lane's 8 pixels)
+    u32 planes_w[6];
+    trunc_pack3x4(c0[0], c0[1], c0[2], c0[3], c0[4], c0[5], c0[6], c0[7], c1[0], c1[1], c1[2], c1[3], planes_w[0], planes_w[1], planes_w[2]);
+    trunc_pack3x4(c1[4], c1[5], c1[6], c1[7], c2[0], c2[1], c2[2], c2[3], c2[4], c2[5], c2[6], c2[7], planes_w[3], planes_w[4], planes_w[5]);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       uint8_t* o = d.p[k] + (u32)(y * pp[k]) + x0;
-      const u32 lo = trunc_pack4(cc[k][0], cc[k][1], cc[k][2], cc[k][3]);
-      const u32 hi = trunc_pack4(cc[k][4], cc[k][5], cc[k][6], cc[k][7]);
+      const u32 lo = planes_w[2 * k], hi = planes_w[2 * k + 1];
       if ((((uintptr_t)o) & 7u) == 0) {
         store8(o, make_uint2(lo, hi));
       } else if ((((uintptr_t)o) & 3u) == 0) {
@@ -1032,9 +1080,8 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       const int a0 = px(4 * g), a1 = px(4 * g + 1), a2 = px(4 * g + 2), a3 = px(4 * g + 3);
-      w[3 * g + 0] = trunc_pack4(c0[a0], c1[a0], c2[a0], c0[a1]);
-      w[3 * g + 1] = trunc_pack4(c1[a1], c2[a1], c0[a2], c1[a2]);
-      w[3 * g + 2] = trunc_pack4(c2[a2], c0[a3], c1[a3], c2[a3]);
+      trunc_pack3x4(c0[a0], c1[a0], c2[a0], c0[a1], c1[a1], c2[a1], c0[a2], c1[a2], c2[a2], c0[a3], c1[a3], c2[a3],
+                    w[3 * g + 0], w[3 * g + 1], w[3 * g + 2]);
     }
     uint8_t* st = strip[kPacked ? wave : 0];
     const int so = ROT == 2 ? (kD2WaveW - kD2LanePx) * 3 - 24 * lane : 24 * lane;
@@ -1345,12 +1392,8 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2_t(const UdArgs a) {
           d2_compute<OUT, false>(cur, q1, c0 + 4, c1 + 4, c2 + 4);
         }
         u32 px[8];
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-          px[p] = pack_u8<0>(__builtin_truncf(c0[p]), 0u);
-          px[p] = pack_u8<1>(__builtin_truncf(c1[p]), px[p]);
-          px[p] = pack_u8<2>(__builtin_truncf(c2[p]), px[p]);
-        }
+        trunc_pack_px4(c0, c1, c2, px);
+        trunc_pack_px4(c0 + 4, c1 + 4, c2 + 4, px + 4);
         u32* t = tile_row(rr) + li * kD2LanePx; // 8-byte aligned (tile rows are 1032 bytes apart)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
