@@ -49,7 +49,7 @@ struct RotArgs {
   int njobs;
   float c, s;
   TileMap map;
-  int tile_order; // quarter-turn tiles: 1 = walk the source tiles column by column (default), 0 = row by row (A/B)
+  int tile_order; // quarter-turn tiles: 0 = walk the source tiles row by row (default), 1 = column by column (A/B)
 };
 
 __device__ __forceinline__ bool rot_tile(const RotArgs& a, RotJob& job, u32& tx, u32& ty, u32& frame) {
@@ -244,7 +244,8 @@ __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
     return;
   const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
   if (a.tile_order == 1) { // walk the source tiles column by column: consecutive workgroups write neighbouring dst
-                           // segments (RGB 2160p 90 deg 10.8 -> 10.15 us, 1080p 270 deg 2.80 -> 2.72; 1080p 90 deg unchanged)
+                           // segments.  Measured both ways round: RGB 2160p 90 deg 10.8 -> 10.15 us and 1080p 270 deg
+                           // 2.80 -> 2.72 in one harness, 1080p 90 deg 2.40 -> 2.62 in BASELINE config 4's: not the default
     const u32 th = P == 3 ? kRotTileHRgb : kRotTile;
     const u32 tiles_y = ((u32)v.sh + th - 1) / th, local = tile_y * job.tiles_x + tile_x;
     tile_x = local / tiles_y;
@@ -518,7 +519,7 @@ static int launch_rotate(RotArgs& a, int fmt, int sw, int sh, int dw, int dh, do
                    (q90 && shift_x == 0.0 && shift_y == (double)(sw - 1) && a.njobs == 1) ||
                    (q270 && shift_y == 0.0 && shift_x == (double)(sh - 1) && a.njobs == 1);
   const bool no_tile = tuning(VALI_TUNE_ROTATE_NO_TILE) == 1;
-  a.tile_order = tuning(VALI_TUNE_ROTATE_NO_TILE) == 2 ? 0 : 1;
+  a.tile_order = tuning(VALI_TUNE_ROTATE_NO_TILE) == 2 ? 1 : 0;
   const bool tiled = canonical && (q90 || q270) && !no_tile;
   // half turn with each plane's own (W-1, H-1) shifts: a reversal
   const bool half = q180 && !no_tile && sw == dw && sh == dh &&
