@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""One-off stress of the Lanczos / bicubic kernel beyond the test-suite: random formats, sizes up to ~2600, extreme
+ratios (both ways), every rows-per-wave form, single surfaces and small batches; every output bit-exact vs the oracle."""
+import sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np
+import vali_amd as vali
+from oracle import oracle as o
+
+DEV = 0
+FORMATS = [("NV12", np.uint8, True), ("Y", np.uint8, False), ("RGB", np.uint8, False), ("YUV420", np.uint8, True), ("P10", np.uint16, True),
+           ("RGB_32F", np.float32, False), ("YUV444", np.uint8, False), ("RGB_PLANAR", np.uint8, False), ("YUV444_10bit", np.uint16, False)]
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
+t0 = time.time(); n_ok = 0
+up, down = vali.PyFrameUploader(DEV), vali.PySurfaceDownloader(DEV)
+while time.time() - t0 < budget:
+    name, dt, even = FORMATS[rng.integers(len(FORMATS))]
+    kind = rng.integers(5)
+    if kind == 0:   sw, sh, dw, dh = rng.integers(2, 200, 4)
+    elif kind == 1: sw, sh = rng.integers(300, 2600), rng.integers(2, 120); dw, dh = rng.integers(2, 2600), rng.integers(2, 200)
+    elif kind == 2: sw, sh = rng.integers(2, 64), rng.integers(2, 64); dw, dh = rng.integers(200, 1800), rng.integers(50, 300)      # big upscale
+    elif kind == 3: sw, sh = rng.integers(1500, 2600), rng.integers(100, 300); dw, dh = rng.integers(2, 120), rng.integers(2, 60)   # big downscale (gather)
+    else:           sw, sh = rng.integers(250, 1100), rng.integers(60, 400); dw = int(sw * rng.uniform(0.4, 2.2)) or 2; dh = int(sh * rng.uniform(0.4, 2.2)) or 2
+    sw, sh, dw, dh = (int(max(2, v)) for v in (sw, sh, dw, dh))
+    if even: sw, sh, dw, dh = (v // 2 * 2 for v in (sw, sh, dw, dh))
+    interp, iname = [(vali.Interpolation.LANCZOS, "lanczos"), (vali.Interpolation.CUBIC, "cubic")][rng.integers(2)]
+    vali.tuning.Set("RESIZE_NO_SEPARABLE", int(rng.integers(4)))
+    pf = vali.PixelFormat[name]
+    src = vali.Surface.Make(pf, sw, sh, DEV)
+    nel = src.HostSize // np.dtype(dt).itemsize
+    host = (rng.random(nel) * (255 if dt == np.uint8 else 1023 if dt == np.uint16 else 1.0)).astype(dt)
+    if name == "P10": host = (host.astype(np.uint16) << 6).astype(np.uint16)
+    assert up.Run(host.view(np.uint8), src)[0]
+    nb = int(rng.integers(1, 4))
+    dsts = [vali.Surface.Make(pf, dw, dh, DEV) for _ in range(nb)]
+    rs = vali.PySurfaceResizer(pf, DEV, interpolation=interp)
+    if nb == 1: assert rs.Run(src, dsts[0])[0]
+    else: assert rs.RunBatch([src] * nb, dsts)[0]
+    want = o.resize_surface(host, name, sw, sh, dw, dh, iname)
+    for d in dsts:
+        out = np.zeros(d.HostSize, np.uint8)
+        assert down.Run(d, out)[0]
+        if not np.array_equal(out, want.view(np.uint8).reshape(-1)):
+            print("MISMATCH", name, sw, sh, dw, dh, iname, "rows-mode", vali.tuning.Get("RESIZE_NO_SEPARABLE"), "batch", nb, flush=True)
+            sys.exit(1)
+    n_ok += 1
+print("stress ok:", n_ok, "cases in", round(time.time() - t0, 1), "s")
