@@ -52,9 +52,26 @@ constexpr int kRsRowsPerWave = 8;
 constexpr int kRsTileH = kWavesPerBlock * kRsRowsPerWave;
 constexpr int kRsChunks = 3;                             // 16-byte chunks per lane per row
 constexpr int kStageRowBytes = kRsChunks * kWave * 16;   // 3072 B = 12x downscale for u8 C1
+// LDS layout of a staged row: 4 bytes of padding after every 128 bytes of row data.  At the common 2x / 4x
+// downscales a lane's taps sit 8 / 16 / 32 bytes from its neighbour's, so 32 lanes of a byte read hit only 16 / 8 / 4
+// of the 32 banks (the unpadded strip spent 52 % of its LDS cycles in bank conflicts: profiles/r02_bilinear_lds.md);
+// the pad moves each following 128-byte group one bank on.  Applied when a pixel never straddles a 128-byte group
+// (pixel size 1, 2, 4, 8, 16 bytes); packed RGB keeps the plain layout.
+template <int PB> constexpr bool kStagePadded = (128 % PB) == 0;
+template <bool PAD> __device__ __forceinline__ int stage_off(int a) { return PAD ? a + ((a >> 7) << 2) : a; }
+constexpr int kStageRowAlloc = kStageRowBytes + 4 * (kStageRowBytes / 128);
 struct alignas(16) StageRows {
-  uint8_t row[2][kStageRowBytes];
+  uint8_t row[2][kStageRowAlloc];
 };
+// one 16-byte chunk -> the strip (4-byte aligned once padded: dword writes, which the pad also keeps conflict-free)
+template <bool PAD> __device__ __forceinline__ void stage_put(uint8_t* row, int k, const uint4& q) {
+  if constexpr (PAD) {
+    u32* w = reinterpret_cast<u32*>(row + k * 16 + ((k >> 3) << 2));
+    w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+  } else {
+    *reinterpret_cast<uint4*>(row + k * 16) = q;
+  }
+}
 
 // 4 pixels of raw elements (no arithmetic: the point-sample path) -> memory, like store_px4
 template <typename T, int C>
@@ -115,6 +132,7 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
     return;
   const float scale_x = (float)sw / (float)dw, scale_y = (float)sh / (float)dh;
   constexpr int PB = C * (int)sizeof(T);
+  constexpr bool PAD = kStagePadded<PB>;
 
   // column taps of the lane's 4 pixels (tail lanes clamp to the last column)
   Lerp lx[4];
@@ -137,6 +155,7 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
   } else {
     vly = make_lerp(y_first + (lane & (kRsRowsPerWave - 1)), scale_y, sh);
   }
+  const int last_rr = min(kRsRowsPerWave, dh - y_first) - 1; // wave-uniform, >= 0
   auto row_lerp = [&](int rr) {
     Lerp l;
     l.i0 = __builtin_amdgcn_readlane(vly.i0, rr);
@@ -158,11 +177,8 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
     float t[4][4][C]; // [pixel][00,10,01,11][channel]
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-#pragma unroll
-      for (int ch = 0; ch < C; ++ch) {
-        t[p][0][ch] = fetch(0, p, 0, ch); t[p][1][ch] = fetch(0, p, 1, ch);
-        t[p][2][ch] = fetch(1, p, 0, ch); t[p][3][ch] = fetch(1, p, 1, ch);
-      }
+      fetch(0, p, 0, t[p][0]); fetch(0, p, 1, t[p][1]);
+      fetch(1, p, 0, t[p][2]); fetch(1, p, 1, t[p][3]);
     }
     float res[4][C];
 #pragma unroll
@@ -182,8 +198,8 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
     int lo[4][2]; // LDS byte offsets of the column taps (row-invariant)
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      lo[p][0] = lx[p].i0 * PB - byte_begin;
-      lo[p][1] = lx[p].i1 * PB - byte_begin;
+      lo[p][0] = stage_off<PAD>(lx[p].i0 * PB - byte_begin);
+      lo[p][1] = stage_off<PAD>(lx[p].i1 * PB - byte_begin);
     }
     // Register prefetch pipeline, DEPTH dst rows ahead, CPR 16-byte chunks per lane per row.
     // HBM latency x per-CU bandwidth share needs ~46 KB in flight per CU; one row of a
@@ -206,9 +222,9 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
 #pragma unroll
         for (int i = 0; i < CPR; ++i) {
           const int k = min(lane + i * kWave, nchunks - 1);
-          q[0][i] = gload16(r0 + k * 16);
+          { const v4u32 w = __builtin_nontemporal_load((const VALI_GLOBAL v4u32*)(r0 + k * 16)); q[0][i] = make_uint4(w.x, w.y, w.z, w.w); }
           if constexpr (!POINT)
-            q[1][i] = gload16(r1 + k * 16);
+          { const v4u32 w = __builtin_nontemporal_load((const VALI_GLOBAL v4u32*)(r1 + k * 16)); q[1][i] = make_uint4(w.x, w.y, w.z, w.w); }
         }
       };
       auto commit = [&](const uint4 (&q)[2][CPR]) {
@@ -216,16 +232,19 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
         for (int i = 0; i < CPR; ++i) {
           const int k = lane + i * kWave;
           if (k < nchunks) {
-            *reinterpret_cast<uint4*>(&st.row[0][k * 16]) = q[0][i];
+            stage_put<PAD>(st.row[0], k, q[0][i]);
             if constexpr (!POINT)
-              *reinterpret_cast<uint4*>(&st.row[1][k * 16]) = q[1][i];
+              stage_put<PAD>(st.row[1], k, q[1][i]);
           }
         }
       };
+      // Every issue is UNCONDITIONAL (rows past the tile's last one re-read it): behind a branch the compiler
+      // cannot count the loads in flight and drains vmcnt to 0 at every commit, which exposes the whole memory
+      // latency once per row (measured: the prefetch depth had no effect at all until this was straight-line).
 #pragma unroll
       for (int k = 0; k < DEPTH; ++k)
-        if (k < kRsRowsPerWave && y_first + k < dh)
-          issue(k, pf[k]);
+        if (k < kRsRowsPerWave)
+          issue(min(k, last_rr), pf[k]);
 #pragma unroll
       for (int rr = 0; rr < kRsRowsPerWave; ++rr) {
         const int y = y_first + rr;
@@ -233,8 +252,8 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
           break;
         commit(pf[rr % DEPTH]);
         wave_lds_sync();
-        if (rr + DEPTH < kRsRowsPerWave && y + DEPTH < dh)
-          issue(rr + DEPTH, pf[rr % DEPTH]); // in flight while rows rr .. rr+DEPTH-1 are sampled
+        if (rr + DEPTH < kRsRowsPerWave)
+          issue(min(rr + DEPTH, last_rr), pf[rr % DEPTH]); // in flight while rows rr .. rr+DEPTH-1 are sampled
         if constexpr (POINT) {
           if (n > 0) {
             u32 e[4][C];
@@ -252,8 +271,15 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
             store_px4_raw<T, C>(dp + (u32)(y * dpitch) + (size_t)x0 * PB, e, (1u << n) - 1u);
           }
         } else if (n > 0) {
-          sample_and_store(row_lerp(rr), y, [&](int r, int p, int t, int ch) {
-            return (float)((const T*)(st.row[r] + lo[p][t]))[ch];
+          sample_and_store(row_lerp(rr), y, [&](int r, int p, int t, float (&out)[C]) {
+            if constexpr (C == 2 && sizeof(T) == 1) { // the interleaved pair in one LDS read
+              const u32 uv = *(const uint16_t*)(st.row[r] + lo[p][t]);
+              out[0] = (float)(uv & 0xffu); out[1] = (float)(uv >> 8);
+            } else {
+#pragma unroll
+              for (int ch = 0; ch < C; ++ch)
+                out[ch] = (float)((const T*)(st.row[r] + lo[p][t]))[ch];
+            }
           });
         }
         wave_lds_sync(); // the strip is re-filled by the next row
@@ -261,6 +287,8 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
     };
     if (nchunks <= kWave)
       pipeline(std::integral_constant<int, 1>{}, std::integral_constant<int, POINT ? kRsRowsPerWave : 4>{});
+    else if (nchunks <= 2 * kWave) // 2x of interleaved UV / 4x of a byte plane: 1024 + 16 bytes = 65 chunks
+      pipeline(std::integral_constant<int, 2>{}, std::integral_constant<int, POINT ? 4 : 2>{});
     else
       pipeline(std::integral_constant<int, kRsChunks>{}, std::integral_constant<int, 1>{});
   } else {
@@ -283,11 +311,17 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
 #pragma unroll
               for (int p = 0; p < 4; ++p)
                 load_tap_pair<T, C>(rows[r], lx[p].i0, sw, pre[r][p][0], pre[r][p][1]);
-            sample_and_store(ly, y, [&](int r, int p, int t, int ch) { return pre[r][p][t][ch]; });
+            sample_and_store(ly, y, [&](int r, int p, int t, float (&out)[C]) {
+#pragma unroll
+              for (int ch = 0; ch < C; ++ch)
+                out[ch] = pre[r][p][t][ch];
+            });
           }
         } else {
-          sample_and_store(ly, y, [&](int r, int p, int t, int ch) {
-            return (float)gload<T>(rows[r] + (size_t)(t ? lx[p].i1 : lx[p].i0) * PB + ch * sizeof(T));
+          sample_and_store(ly, y, [&](int r, int p, int t, float (&out)[C]) {
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch)
+              out[ch] = (float)gload<T>(rows[r] + (size_t)(t ? lx[p].i1 : lx[p].i0) * PB + ch * sizeof(T));
           });
         }
       }
