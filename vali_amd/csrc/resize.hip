@@ -243,8 +243,10 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
       // latency once per row (measured: the prefetch depth had no effect at all until this was straight-line).
 #pragma unroll
       for (int k = 0; k < DEPTH; ++k)
-        if (k < kRsRowsPerWave)
+        if (k < kRsRowsPerWave) {
           issue(min(k, last_rr), pf[k]);
+          __builtin_amdgcn_sched_barrier(0); // rows stay in issue order (vmcnt retires in order)
+        }
 #pragma unroll
       for (int rr = 0; rr < kRsRowsPerWave; ++rr) {
         const int y = y_first + rr;

@@ -266,9 +266,13 @@ __device__ __forceinline__ void taps_tile(const uint8_t* sp, int spitch, int sw,
         for (int c = 0; c < CPR; ++c)
           q[c] = gload16(row + chunk[c]);
       };
+      // (the scheduling barriers keep the rows in ISSUE order: vmcnt retires in order, and the compiler's scheduler
+      // had put row 0 last -- the first wait of every trip through the unrolled walk then drained the whole ring)
 #pragma unroll
-      for (int j = 0; j < D; ++j)
+      for (int j = 0; j < D; ++j) {
         issue(s_begin + j, pf[j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       int rr = 0;          // next dst row to emit
       int slot = 0;        // ring slot the next source row goes to = (row - s_begin) mod TAPS
       int want_end = s_begin + TAPS - 1; // last source row of dst row rr's window
@@ -277,14 +281,21 @@ __device__ __forceinline__ void taps_tile(const uint8_t* sp, int spitch, int sw,
 #pragma unroll
         for (int j = 0; j < D; ++j) {
           const int cur = s0 + j;
-          if (cur > s_end)
-            break;
+          // Rows past s_end (the last trip only) skip the work but NOT the load: every path through the body issues
+          // the same loads in the same order, so the compiler can count them (vmcnt retires in order).  With an
+          // early exit here the walk was re-entered, on paper, right behind a fresh issue and every wait drained
+          // the whole ring -- the 4-row prefetch ran 1 row deep.
+          const bool live = cur <= s_end; // wave-uniform
+          if (live) {
 #pragma unroll
-          for (int c = 0; c < CPR; ++c)
-            if (mine[c])
-              *reinterpret_cast<uint4*>(stage + kLzPadL + chunk[c]) = pf[j][c];
-          wave_lds_sync();
+            for (int c = 0; c < CPR; ++c)
+              if (mine[c])
+                *reinterpret_cast<uint4*>(stage + kLzPadL + chunk[c]) = pf[j][c];
+            wave_lds_sync();
+          }
           issue(cur + D, pf[j]); // D rows ahead, in flight while this and the next D - 1 rows are filtered
+          if (!live)
+            continue;
           if (pad_left || pad_right) { // image edges: replicate the first / last pixel into the pads
             constexpr int PB = ES * EB; // bytes per pixel
             if (pad_left && lane < kBefore * PB)
@@ -301,8 +312,11 @@ __device__ __forceinline__ void taps_tile(const uint8_t* sp, int spitch, int sw,
           }
           slot = slot == TAPS - 1 ? 0 : slot + 1;
           wave_lds_sync(); // the strip is re-filled by the next row; the ring row is read by other lanes
-          // every dst row whose window ends with this source row (an upscale has several)
-          while (rr <= last_rr && want_end == cur) {
+          // Every dst row whose window ends with this source row: one at most when shrinking, several when enlarging.
+          // The first is straight-line code and only the others loop: the compiler drains vmcnt in front of a loop
+          // that stores without loading (its heuristic for gfx9's shared load/store counter), which would throw the
+          // prefetched rows away at every emitted row.
+          auto emit = [&]() {
             const LzTap<TAPS> cy = row_tap(rr);
             if (n > 0) {
               // the window's first row sits TAPS slots behind the next free one
@@ -320,6 +334,11 @@ __device__ __forceinline__ void taps_tile(const uint8_t* sp, int spitch, int sw,
             }
             ++rr;
             want_end = rr <= last_rr ? __builtin_amdgcn_readlane(vy.i, rr) + TAPS - 1 - kBefore : 0x7fffffff;
+          };
+          if (rr <= last_rr && want_end == cur) {
+            emit();
+            while (rr <= last_rr && want_end == cur)
+              emit();
           }
         }
       }
