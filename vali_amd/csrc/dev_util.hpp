@@ -174,6 +174,11 @@ __device__ __forceinline__ uint4 gload16(const void* p) {
   const v4u32 w = *(const VALI_GLOBAL v4u32*)p;
   return make_uint4(w.x, w.y, w.z, w.w);
 }
+// rows that are read ONCE (downscales of 2x and more): the non-temporal form measured 3 % on the bilinear resizer
+__device__ __forceinline__ uint4 gload16_nt(const void* p) {
+  const v4u32 w = __builtin_nontemporal_load((const VALI_GLOBAL v4u32*)p);
+  return make_uint4(w.x, w.y, w.z, w.w);
+}
 __device__ __forceinline__ uint2 load8(const void* p) {
   const v2u32 w = *(const VALI_GLOBAL v2u32*)p;
   return make_uint2(w.x, w.y);
@@ -359,6 +364,25 @@ __device__ __forceinline__ bool plane_tile(const PlaneJob (&jobs)[3], int njobs,
   ty = local / job.tiles_x;
   tx = local - ty * job.tiles_x;
   return true;
+}
+
+// LDS layout of a staged source row (bilinear resize, general UD): 4 bytes of padding after every 128 bytes of row
+// data.  At the common 2x / 4x downscales a lane's taps sit 8 / 16 / 32 bytes from its neighbour's, so 32 lanes of a
+// byte read hit only 16 / 8 / 4 of the 32 banks (the unpadded strip of the bilinear resizer spent 52 % of its LDS
+// cycles in bank conflicts); the pad moves each following 128-byte group one bank on.  Applied when a pixel never
+// straddles a 128-byte group (pixel size 1, 2, 4, 8, 16 bytes); packed RGB keeps the plain layout.
+template <int PB> constexpr bool kStagePadded = (128 % PB) == 0;
+template <bool PAD> __device__ __forceinline__ int stage_off(int a) { return PAD ? a + ((a >> 7) << 2) : a; }
+constexpr int stage_alloc(int row_bytes) { return row_bytes + 4 * (row_bytes / 128); }
+// one 16-byte chunk (chunk index k of the row) -> the strip: 4-byte aligned once padded, so dword writes, which the
+// pad also keeps conflict-free
+template <bool PAD> __device__ __forceinline__ void stage_put(uint8_t* row, int k, const uint4& q) {
+  if constexpr (PAD) {
+    u32* w = reinterpret_cast<u32*>(row + k * 16 + ((k >> 3) << 2));
+    w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+  } else {
+    *reinterpret_cast<uint4*>(row + k * 16) = q;
+  }
 }
 
 // Order LDS traffic of ONE wave: DS instructions of a wave execute in issue

@@ -163,6 +163,26 @@ __device__ __forceinline__ void rotate_tile_rgb8(const PlaneView& v, u32 tile_x,
   {
   constexpr int kLanesPerSrcRow = TW / 4, kSrcRowsPerPass = kBlock / kLanesPerSrcRow;
   const int chunk = t % kLanesPerSrcRow;
+  if (vec && tw == TW && th == TH) {
+    // Whole tiles (all but the frame's right / bottom edge): every load of the thread is issued before the first is
+    // unpacked.  Behind the per-pass edge tests below the compiler waits for each load before it issues the next --
+    // four memory round trips in a row, which is what bounded the kernel (a workgroup lived ~10 us).
+    typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+    constexpr int kPasses = TH / kSrcRowsPerPass;
+    v3u32 w[kPasses];
+    const uint8_t* q = sbase + (size_t)(t / kLanesPerSrcRow) * src_pitch + chunk * 12;
+#pragma unroll
+    for (int pass = 0; pass < kPasses; ++pass)
+      w[pass] = *(const VALI_GLOBAL v3u32*)(q + (size_t)(pass * kSrcRowsPerPass) * src_pitch);
+#pragma unroll
+    for (int pass = 0; pass < kPasses; ++pass) {
+      u32* l = lds + (pass * kSrcRowsPerPass + t / kLanesPerSrcRow) * SD + chunk * 4;
+      l[0] = w[pass].x & 0xffffffu;
+      l[1] = (w[pass].x >> 24) | ((w[pass].y & 0xffffu) << 8);
+      l[2] = (w[pass].y >> 16) | ((w[pass].z & 0xffu) << 16);
+      l[3] = w[pass].z >> 8;
+    }
+  } else
 #pragma unroll
   for (int pass = 0; pass < TH / kSrcRowsPerPass; ++pass) {
     const int r = pass * kSrcRowsPerPass + t / kLanesPerSrcRow;
@@ -266,7 +286,24 @@ __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
   // phase 1: coalesced row segments -> LDS (16-byte / 4-byte vectors when aligned)
   const uint8_t* sbase = src + (size_t)ry * src_pitch + (size_t)cx * P;
   const int row_bytes = tw * P;
-  if ((((uintptr_t)sbase | (uintptr_t)src_pitch) & 15u) == 0 && (row_bytes & 15) == 0) {
+  const bool aligned16 = (((uintptr_t)sbase | (uintptr_t)src_pitch) & 15u) == 0;
+  if (aligned16 && tw == kRotTile && th == kRotTile) {
+    // whole tiles: the thread's P loads are all in flight before the first LDS write (the run-time loop below waits
+    // for each load before it issues the next)
+    constexpr int V = kRotTile * P / 16; // 16-byte vectors per tile row; kRotTile * V / kBlock = P per thread
+    uint4 w[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+      const int k = t + i * kBlock, r = k / V, c = k - r * V;
+      w[i] = gload16(sbase + (size_t)r * src_pitch + c * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+      const int k = t + i * kBlock, r = k / V, c = k - r * V;
+      u32* l = (u32*)(lds + r * S + c * 16);
+      l[0] = w[i].x; l[1] = w[i].y; l[2] = w[i].z; l[3] = w[i].w;
+    }
+  } else if (aligned16 && (row_bytes & 15) == 0) {
     const int v_per_row = row_bytes / 16;
     for (int k = t; k < th * v_per_row; k += kBlock) {
       const int r = k / v_per_row, v = k - r * v_per_row;

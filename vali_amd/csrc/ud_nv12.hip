@@ -103,6 +103,10 @@ template <typename T> __device__ __forceinline__ u32 trunc_sat(float v) {
 constexpr int kUdRowBytes = kWave * 16;         // 1 KiB per staged row
 constexpr int kUdRowsPerWave = 8; // dst rows a wave walks with the same column taps
 constexpr int kUdTileH = kWavesPerBlock * kUdRowsPerWave;
+#ifndef VALI_UD_DEPTH
+#define VALI_UD_DEPTH 2
+#endif
+constexpr int kUdDepth = VALI_UD_DEPTH; // dst rows of prefetch in the staged general kernel
 // CH = 16-byte chunks per lane per row: 1 for 8-bit sources, 2 for 16-bit ones (P10: the same
 // 2x downscale spans twice the bytes; with 1 KiB rows it fell to the gather path, 17.7 us)
 template <int CH> struct alignas(16) UdStage {
@@ -421,9 +425,9 @@ __device__ __forceinline__ void ud_rot_store(const SurfRef& d, const uint8_t* ro
 // For odd ROT the workgroup collects its 256 x 32 output tile in LDS, one dword per pixel, and
 // writes it transposed after a barrier (destination row <-> tile column): see the end of the kernel.
 template <typename T, int OUT, bool STAGED, int ROT = 0, int MINW = 1>
-// (kBlock, 5) on the packed-RGB instantiation: with the two-pixel halves of sample() it fits 96
-// VGPRs (5 waves per SIMD instead of 4) at the price of 3 spilled dwords: 4.65 -> 4.40 us (cfg4a).
-// The other outputs need more registers and would spill for real, so they keep the default.
+// MINW = 5 (VALI_TUNE_UD_OCC5): the packed-RGB instantiation squeezed into 96 VGPRs for 5 waves per SIMD.  It won
+// 5 % in round 1 (4.65 -> 4.40 us, cfg4a) but spills since the truncating pack and the prefetch ring and now runs
+// 1.5x SLOWER than the default (1080p -> 720p RGB 2.3 vs 1.5 us): kept selectable, off by default.
 __global__ void __launch_bounds__(kBlock, MINW) k_ud_nv12(const UdArgs a) {
   static_assert(ROT == 0 || (sizeof(T) == 1 && OUT == UD_RGB_U8), "rotated output: NV12 -> RGB only");
   constexpr int CH = (int)sizeof(T);
@@ -683,8 +687,18 @@ __global__ void __launch_bounds__(kBlock, MINW) k_ud_nv12(const UdArgs a) {
       in_y[c] = off[c] < sp.yn; in_c[c] = off[c] < sp.cn;
       off_y[c] = min(off[c], sp.yn - 16); off_c[c] = min(off[c], sp.cn - 16);
     }
-    uint4 pf[4][CH]; // prefetch registers: this lane's chunks of luma0, luma1, chroma0, chroma1
-    auto issue = [&](const RowTaps& rt) {
+    // Prefetch ring, kUdDepth dst rows deep: per row this lane's chunks of luma0, luma1, chroma0, chroma1.  The walk
+    // is unrolled by the depth so the ring is indexed statically, and EVERY trip issues the same loads in the same
+    // order (rows past the tile's last one re-read it and skip the work): the compiler can then count the loads in
+    // flight -- vmcnt retires in order -- instead of draining them at a branch.  With one row of prefetch the
+    // kernel sat at ~50 % VALU and ~40 % LDS utilisation, waiting a memory latency per row.  (Plain loads: chroma rows
+    // and, below 2x, luma rows are read by several dst rows out of L2 -- the non-temporal form measured 10-35 % slower;
+    // the padded LDS rows of the bilinear resizer measured no different here.)
+    constexpr int DEPTH = kUdDepth;
+    uint4 pf[DEPTH][4][CH];
+    const int last_rr = min(kUdRowsPerWave, dh - y_first) - 1; // wave-uniform, >= 0
+    auto issue = [&](int rr, uint4 (&q)[4][CH]) {
+      const RowTaps rt = row_taps(min(rr, last_rr));
       // scalar address arithmetic; a plane is < 4 GiB, so 32-bit row offsets (s_mul_i32)
       const uint8_t* y0 = py + (u32)(rt.ty.i0 * sp_y + sp.yb);
       const uint8_t* y1 = py + (u32)(rt.ty.i1 * sp_y + sp.yb);
@@ -692,20 +706,20 @@ __global__ void __launch_bounds__(kBlock, MINW) k_ud_nv12(const UdArgs a) {
       const uint8_t* q1 = puv + (u32)(rt.tcy.i1 * sp_uv + sp.cb);
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
-        pf[0][c] = gload16(y0 + off_y[c]); pf[1][c] = gload16(y1 + off_y[c]);
-        pf[2][c] = gload16(q0 + off_c[c]); pf[3][c] = gload16(q1 + off_c[c]);
+        q[0][c] = gload16(y0 + off_y[c]); q[1][c] = gload16(y1 + off_y[c]);
+        q[2][c] = gload16(q0 + off_c[c]); q[3][c] = gload16(q1 + off_c[c]);
       }
     };
-    auto commit = [&]() {
+    auto commit = [&](const uint4 (&q)[4][CH]) {
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
         if (in_y[c]) {
-          *reinterpret_cast<uint4*>(&st.luma[0][off[c]]) = pf[0][c];
-          *reinterpret_cast<uint4*>(&st.luma[1][off[c]]) = pf[1][c];
+          *reinterpret_cast<uint4*>(&st.luma[0][off[c]]) = q[0][c];
+          *reinterpret_cast<uint4*>(&st.luma[1][off[c]]) = q[1][c];
         }
         if (in_c[c]) {
-          *reinterpret_cast<uint4*>(&st.chroma[0][off[c]]) = pf[2][c];
-          *reinterpret_cast<uint4*>(&st.chroma[1][off[c]]) = pf[3][c];
+          *reinterpret_cast<uint4*>(&st.chroma[0][off[c]]) = q[2][c];
+          *reinterpret_cast<uint4*>(&st.chroma[1][off[c]]) = q[3][c];
         }
       }
     };
@@ -716,36 +730,40 @@ __global__ void __launch_bounds__(kBlock, MINW) k_ud_nv12(const UdArgs a) {
       ly[p][0] = tx[p].i0 * E - sp.yb; ly[p][1] = tx[p].i1 * E - sp.yb;
       lc[p][0] = tcx[p].i0 * 2 * E - sp.cb; lc[p][1] = tcx[p].i1 * 2 * E - sp.cb;
     }
-    RowTaps cur = row_taps(0);
-    issue(cur);
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) {
+      issue(k, pf[k]);
+      __builtin_amdgcn_sched_barrier(0); // rows stay in issue order
+    }
 #pragma unroll 1
-    for (int rr = 0; rr < kUdRowsPerWave; ++rr) {
-      const int y = y_first + rr;
-      if (y >= dh)
-        break;
-      commit();
-      wave_lds_sync();
-      const bool more = rr + 1 < kUdRowsPerWave && y + 1 < dh;
-      RowTaps nxt = cur;
-      if (more) {
-        nxt = row_taps(rr + 1);
-        issue(nxt); // in flight while this row is sampled
+    for (int r0 = 0; r0 <= last_rr; r0 += DEPTH) {
+#pragma unroll
+      for (int j = 0; j < DEPTH; ++j) {
+        const int rr = r0 + j;
+        const bool live = rr <= last_rr; // wave-uniform
+        if (live) {
+          commit(pf[j]);
+          wave_lds_sync();
+        }
+        issue(rr + DEPTH, pf[j]); // in flight while rows rr .. rr + DEPTH - 1 are sampled
+        if (live) {
+          if (n > 0) {
+            const RowTaps cur = row_taps(rr);
+            float c0[4], c1[4], c2[4];
+            sample(cur,
+                   [&](int r, int p, int t) { return (u32) * (const T*)(st.luma[r] + ly[p][t]); },
+                   [&](int r, int p, int t) { // U and V are neighbours: one LDS read for the pair
+                     if constexpr (E == 1)
+                       return (u32) * (const uint16_t*)(st.chroma[r] + lc[p][t]);
+                     else
+                       return *(const u32*)(st.chroma[r] + lc[p][t]);
+                   },
+                   c0, c1, c2);
+            emit(rr, y_first + rr, c0, c1, c2);
+          }
+          wave_lds_sync(); // the strip is re-filled by the next row
+        }
       }
-      if (n > 0) {
-        float c0[4], c1[4], c2[4];
-        sample(cur,
-               [&](int r, int p, int t) { return (u32) * (const T*)(st.luma[r] + ly[p][t]); },
-               [&](int r, int p, int t) { // U and V are neighbours: one LDS read for the pair
-                 if constexpr (E == 1)
-                   return (u32) * (const uint16_t*)(st.chroma[r] + lc[p][t]);
-                 else
-                   return *(const u32*)(st.chroma[r] + lc[p][t]);
-               },
-               c0, c1, c2);
-        emit(rr, y, c0, c1, c2);
-      }
-      wave_lds_sync(); // the strip is re-filled by the next row
-      cur = nxt;
     }
   } else {
     gather_rows();
