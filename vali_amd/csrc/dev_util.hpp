@@ -123,9 +123,12 @@ template <typename T> __device__ __forceinline__ void gstore(void* p, T v) {
   *(VALI_GLOBAL T*)p = v;
 }
 
-// The streaming converters deliberately keep GENERIC pointers for their 16-byte accesses:
-// an A/B on NV12->RGB 2160p measured flat_load/flat_store 1.2% FASTER than the
-// global_* forms (6.18 vs 6.11 TB/s, 3 interleaved repetitions, profiles/r01_variants.md).
+// The one-shot streaming converters (cvt_nv12_rgb.hip, cvt_generic.hip: every thread loads, converts, stores, no loop)
+// keep GENERIC pointers for their 16-byte accesses: an A/B on NV12->RGB 2160p measured flat_load/flat_store 1.2%
+// FASTER than the global_* forms (6.18 vs 6.11 TB/s, 3 interleaved repetitions, profiles/r01_variants.md).
+// NEVER in a kernel that keeps loads in flight across a loop: while a flat access is pending the compiler must treat
+// vmcnt as out of order and turns every wait into vmcnt(0) -- one flat_store per row of the exact-2x UD kernel
+// drained its whole prefetch (round 2).  Those kernels use gload16 / gstore16 and the VALI_GLOBAL forms only.
 __device__ __forceinline__ void store16_nt(void* p, uint4 v) {
   const v4u32 w = {v.x, v.y, v.z, v.w};
   __builtin_nontemporal_store(w, (v4u32*)p);
@@ -178,6 +181,10 @@ __device__ __forceinline__ uint4 gload16(const void* p) {
 __device__ __forceinline__ uint4 gload16_nt(const void* p) {
   const v4u32 w = __builtin_nontemporal_load((const VALI_GLOBAL v4u32*)p);
   return make_uint4(w.x, w.y, w.z, w.w);
+}
+__device__ __forceinline__ void gstore16(void* p, uint4 v) {
+  const v4u32 w = {v.x, v.y, v.z, v.w};
+  *(VALI_GLOBAL v4u32*)p = w;
 }
 __device__ __forceinline__ uint2 load8(const void* p) {
   const v2u32 w = *(const VALI_GLOBAL v2u32*)p;

@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
     const int v_per_row = row_bytes / 16;
     for (int k = t; k < th * v_per_row; k += kBlock) {
       const int r = k / v_per_row, v = k - r * v_per_row;
-      const uint4 w = load16(sbase + (size_t)r * src_pitch + v * 16);
+      const uint4 w = gload16(sbase + (size_t)r * src_pitch + v * 16);
       u32* l = (u32*)(lds + r * S + v * 16);
       l[0] = w.x; l[1] = w.y; l[2] = w.z; l[3] = w.w;
     }
@@ -315,12 +315,12 @@ __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
     const int dw_per_row = row_bytes / 4;
     for (int k = t; k < th * dw_per_row; k += kBlock) {
       const int r = k / dw_per_row, v = k - r * dw_per_row;
-      *(u32*)(lds + r * S + v * 4) = *(const u32*)(sbase + (size_t)r * src_pitch + v * 4);
+      *(u32*)(lds + r * S + v * 4) = gload<u32>(sbase + (size_t)r * src_pitch + v * 4);
     }
   } else {
     for (int k = t; k < th * row_bytes; k += kBlock) {
       const int r = k / row_bytes, v = k - r * row_bytes;
-      lds[r * S + v] = sbase[(size_t)r * src_pitch + v];
+      lds[r * S + v] = gload<uint8_t>(sbase + (size_t)r * src_pitch + v);
     }
   }
   __syncthreads();
@@ -382,14 +382,14 @@ __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
         __builtin_memcpy(w, px, 4 * P);
 #pragma unroll
         for (int k = 0; k < P; ++k)
-          ((u32*)o)[k] = w[k];
+          gstore<u32>(o + 4 * k, w[k]);
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           if (ok[q])
 #pragma unroll
             for (int b = 0; b < P; ++b)
-              o[q * P + b] = px[q * P + b];
+              gstore<uint8_t>(o + q * P + b, px[q * P + b]);
       }
     }
   }

@@ -1119,7 +1119,7 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
       if (b < kD2WaveW * 3 && b + 16 > vb0 && b < vb1) {
         const uint4 v = *reinterpret_cast<const uint4*>(st + b);
         if (b >= vb0 && b + 16 <= vb1) {
-          store16(orow + b, v);
+          gstore16(orow + b, v);
         } else {
           const u32 vv[4] = {v.x, v.y, v.z, v.w};
           for (int k = 0; k < 16; ++k)
@@ -1260,17 +1260,26 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
       }
     }
   };
-  // the next row's loads are in flight while a row is computed (measured: keeping two register
-  // sets alive to avoid the copies costs 27 VGPRs and gains nothing)
+  // Two rows in flight: a row's loads are issued right AFTER the row that held its registers is computed, i.e. two
+  // steps before they are needed, and the walk is unrolled by two so that both register sets are named statically
+  // (every trip issues the same loads in the same order -- rows past the last re-read it -- so the compiler counts
+  // vmcnt instead of draining it).  The former shape (issue the next row, compute this one, copy) had the same two
+  // sets live but only one row of distance, and its copy waited for the loads at the end of every row.
   RowTaps ta = row_taps(0);
   Rows ra = issue(ta);
+  __builtin_amdgcn_sched_barrier(0); // rows stay in issue order (vmcnt retires in order)
+  RowTaps tb = row_taps(min(1, last));
+  Rows rb = issue(tb);
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
-  for (int rr = 0; rr <= last; ++rr) {
-    const RowTaps tb = row_taps(min(rr + 1, last));
-    const Rows rb = issue(tb);
+  for (int rr = 0; rr <= last; rr += 2) {
     step(rr, ta, ra);
-    ta = tb;
-    ra = rb;
+    ta = row_taps(min(rr + 2, last));
+    ra = issue(ta);
+    if (rr + 1 <= last)
+      step(rr + 1, tb, rb);
+    tb = row_taps(min(rr + 3, last));
+    rb = issue(tb);
   }
 }
 
