@@ -122,6 +122,11 @@ template <typename T> __device__ __forceinline__ T gload(const void* p) {
 template <typename T> __device__ __forceinline__ void gstore(void* p, T v) {
   *(VALI_GLOBAL T*)p = v;
 }
+// non-temporal: finished output whose wave instruction covers whole 128-byte lines (neighbouring lanes write
+// neighbouring bytes); never for strided pieces
+template <typename T> __device__ __forceinline__ void gstore_nt(void* p, T v) {
+  __builtin_nontemporal_store(v, (VALI_GLOBAL T*)p);
+}
 
 // The one-shot streaming converters (cvt_nv12_rgb.hip, cvt_generic.hip: every thread loads, converts, stores, no loop)
 // keep GENERIC pointers for their 16-byte accesses: an A/B on NV12->RGB 2160p measured flat_load/flat_store 1.2%
@@ -186,6 +191,10 @@ __device__ __forceinline__ void gstore16(void* p, uint4 v) {
   const v4u32 w = {v.x, v.y, v.z, v.w};
   *(VALI_GLOBAL v4u32*)p = w;
 }
+__device__ __forceinline__ void gstore16_nt(void* p, uint4 v) { // whole 128-byte lines per wave instruction only
+  const v4u32 w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, (VALI_GLOBAL v4u32*)p);
+}
 __device__ __forceinline__ uint2 load8(const void* p) {
   const v2u32 w = *(const VALI_GLOBAL v2u32*)p;
   return make_uint2(w.x, w.y);
@@ -193,6 +202,10 @@ __device__ __forceinline__ uint2 load8(const void* p) {
 __device__ __forceinline__ void store8(void* p, uint2 v) {
   const v2u32 w = {v.x, v.y};
   *(VALI_GLOBAL v2u32*)p = w;
+}
+__device__ __forceinline__ void store8_nt(void* p, uint2 v) {
+  const v2u32 w = {v.x, v.y};
+  __builtin_nontemporal_store(w, (VALI_GLOBAL v2u32*)p);
 }
 __device__ __forceinline__ void store16f(void* p, float4 v) {
   const v4f32 w = {v.x, v.y, v.z, v.w};
@@ -587,6 +600,14 @@ template <> __device__ __forceinline__ u32 finish_bits<uint16_t>(float v) {
 }
 template <> __device__ __forceinline__ u32 finish_bits<float>(float v) { return __float_as_uint(v); }
 
+#ifndef VALI_PX4_NT
+#define VALI_PX4_NT 1
+#endif
+#if VALI_PX4_NT
+#define VALI_PX4_ST(T) gstore_nt<T>
+#else
+#define VALI_PX4_ST(T) gstore<T>
+#endif
 template <typename T, int C>
 __device__ __forceinline__ void store_px4(uint8_t* dst, const float (&res)[4][C], u32 mask) {
   constexpr int E = (int)sizeof(T), N = 4 * C, NB = N * E, PER = 4 / E; // PER elements per dword
@@ -604,12 +625,20 @@ __device__ __forceinline__ void store_px4(uint8_t* dst, const float (&res)[4][C]
   }
   constexpr u32 kAlign = NB % 16 == 0 ? 15u : (NB % 8 == 0 ? 7u : 3u);
   if (mask == 0xfu && (((uintptr_t)dst) & kAlign) == 0) {
-    if constexpr (NB % 16 == 0) {
+    // One instruction per lane (NB = 4, 8, 12, 16: neighbouring lanes write neighbouring bytes, the wave instruction
+    // covers whole 128-byte lines) goes out non-temporal; the wider groups are 2-3 pieces per lane, NB bytes apart.
+    if constexpr (NB == 16) {
+      const v4u32 q = {w[0], w[1], w[2], w[3]};
+      VALI_PX4_ST(v4u32)(dst, q);
+    } else if constexpr (NB % 16 == 0) {
 #pragma unroll
       for (int k = 0; k < NB / 16; ++k) {
         const v4u32 q = {w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]};
         ((VALI_GLOBAL v4u32*)dst)[k] = q;
       }
+    } else if constexpr (NB == 8) {
+      const v2u32 q = {w[0], w[1]};
+      VALI_PX4_ST(v2u32)(dst, q);
     } else if constexpr (NB % 8 == 0) {
 #pragma unroll
       for (int k = 0; k < NB / 8; ++k) {
@@ -619,7 +648,9 @@ __device__ __forceinline__ void store_px4(uint8_t* dst, const float (&res)[4][C]
     } else if constexpr (NB == 12) {
       typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
       const v3u32 q = {w[0], w[1], w[2]};
-      *(VALI_GLOBAL v3u32*)dst = q; // global_store_dwordx3 (needs 4-byte alignment only)
+      VALI_PX4_ST(v3u32)(dst, q); // global_store_dwordx3 (needs 4-byte alignment only)
+    } else if constexpr (NB == 4) {
+      VALI_PX4_ST(u32)(dst, w[0]);
     } else {
 #pragma unroll
       for (int k = 0; k < NB / 4; ++k)

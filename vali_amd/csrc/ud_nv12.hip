@@ -190,6 +190,23 @@ __device__ __forceinline__ void trunc_pack_px4(const float* c0, const float* c1,
 
 // store 4 pixels of one dst row; c0/c1/c2 = Y,U,V or R,G,B already multiplied by
 // UdScale<T,OUT>; n = valid pixels; y is wave-uniform
+// The vector stores of ud_store: neighbouring lanes write neighbouring pixels, so a wave instruction covers whole
+// 128-byte lines -> non-temporal (VALI_UD_NT_STORES=0 builds the plain forms for an A/B).  Packed RGB_32F stays
+// plain: its three 16-byte pieces per lane are 48 bytes apart.
+#ifndef VALI_UD_NT_STORES
+#define VALI_UD_NT_STORES 1
+#endif
+#if VALI_UD_NT_STORES
+#define UD_ST(T) gstore_nt<T>
+#define UD_ST8 store8_nt
+#define UD_ST16F store16f_nt
+#define UD_ST16 gstore16_nt
+#else
+#define UD_ST(T) gstore<T>
+#define UD_ST8 store8
+#define UD_ST16F store16f
+#define UD_ST16 gstore16
+#endif
 template <typename T, int OUT>
 __device__ __forceinline__ void ud_store(const SurfRef& d, int x0, int y, int n, const float (&c0)[4],
                                          const float (&c1)[4], const float (&c2)[4]) {
@@ -207,7 +224,7 @@ __device__ __forceinline__ void ud_store(const SurfRef& d, int x0, int y, int n,
       u32 w0, w1, w2;
       trunc_pack3x4(c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3], c2[0], c2[1], c2[2], c2[3], w0, w1, w2);
       if (fast) {
-        gstore<u32>(o0, w0); gstore<u32>(o1, w1); gstore<u32>(o2, w2);
+        UD_ST(u32)(o0, w0); UD_ST(u32)(o1, w1); UD_ST(u32)(o2, w2);
       } else {
         for (int p = 0; p < n; ++p) {
           gstore<uint8_t>(o0 + p, (uint8_t)(w0 >> (8 * p))); gstore<uint8_t>(o1 + p, (uint8_t)(w1 >> (8 * p)));
@@ -221,9 +238,9 @@ __device__ __forceinline__ void ud_store(const SurfRef& d, int x0, int y, int n,
         q0[p] = trunc_sat<T>(c0[p]); q1[p] = trunc_sat<T>(c1[p]); q2[p] = trunc_sat<T>(c2[p]);
       }
       if (fast) {
-        store8(o0, make_uint2(q0[0] | (q0[1] << 16), q0[2] | (q0[3] << 16)));
-        store8(o1, make_uint2(q1[0] | (q1[1] << 16), q1[2] | (q1[3] << 16)));
-        store8(o2, make_uint2(q2[0] | (q2[1] << 16), q2[2] | (q2[3] << 16)));
+        UD_ST8(o0, make_uint2(q0[0] | (q0[1] << 16), q0[2] | (q0[3] << 16)));
+        UD_ST8(o1, make_uint2(q1[0] | (q1[1] << 16), q1[2] | (q1[3] << 16)));
+        UD_ST8(o2, make_uint2(q2[0] | (q2[1] << 16), q2[2] | (q2[3] << 16)));
       } else {
         for (int p = 0; p < n; ++p) {
           gstore<T>(o0 + p * sizeof(T), (T)q0[p]); gstore<T>(o1 + p * sizeof(T), (T)q1[p]); gstore<T>(o2 + p * sizeof(T), (T)q2[p]);
@@ -237,7 +254,7 @@ __device__ __forceinline__ void ud_store(const SurfRef& d, int x0, int y, int n,
     uint8_t* o1 = pd1 + (u32)(y * dp0) + x0;
     uint8_t* o2 = pd2 + (u32)(y * dp0) + x0;
     if (n == 4 && ((((uintptr_t)o0) | ((uintptr_t)o1) | ((uintptr_t)o2)) & 3u) == 0) {
-      gstore<u32>(o0, wr); gstore<u32>(o1, wg); gstore<u32>(o2, wb);
+      UD_ST(u32)(o0, wr); UD_ST(u32)(o1, wg); UD_ST(u32)(o2, wb);
     } else {
       for (int p = 0; p < n; ++p) {
         gstore<uint8_t>(o0 + p, (uint8_t)(wr >> (8 * p))); gstore<uint8_t>(o1 + p, (uint8_t)(wg >> (8 * p)));
@@ -252,7 +269,7 @@ __device__ __forceinline__ void ud_store(const SurfRef& d, int x0, int y, int n,
     if (n == 4 && (((uintptr_t)o) & 3u) == 0) {
       typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
       const v3u32 w = {w0, w1, w2};
-      *(VALI_GLOBAL v3u32*)o = w; // global_store_dwordx3
+      UD_ST(v3u32)(o, w); // global_store_dwordx3
     } else {
       const u32 ww[3] = {w0, w1, w2};
       for (int k = 0; k < 3 * n; ++k)
@@ -263,9 +280,9 @@ __device__ __forceinline__ void ud_store(const SurfRef& d, int x0, int y, int n,
     uint8_t* o1 = pd1 + (u32)(y * dp0) + (size_t)x0 * 4;
     uint8_t* o2 = pd2 + (u32)(y * dp0) + (size_t)x0 * 4;
     if (n == 4 && ((((uintptr_t)o0) | ((uintptr_t)o1) | ((uintptr_t)o2)) & 15u) == 0) {
-      store16f(o0, make_float4(c0[0], c0[1], c0[2], c0[3]));
-      store16f(o1, make_float4(c1[0], c1[1], c1[2], c1[3]));
-      store16f(o2, make_float4(c2[0], c2[1], c2[2], c2[3]));
+      UD_ST16F(o0, make_float4(c0[0], c0[1], c0[2], c0[3]));
+      UD_ST16F(o1, make_float4(c1[0], c1[1], c1[2], c1[3]));
+      UD_ST16F(o2, make_float4(c2[0], c2[1], c2[2], c2[3]));
     } else {
       for (int p = 0; p < n; ++p) { gstore<float>(o0 + 4 * p, c0[p]); gstore<float>(o1 + 4 * p, c1[p]); gstore<float>(o2 + 4 * p, c2[p]); }
     }
@@ -1078,7 +1095,7 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
       uint8_t* o = d.p[k] + (u32)(y * pp[k]) + x0;
       const u32 lo = planes_w[2 * k], hi = planes_w[2 * k + 1];
       if ((((uintptr_t)o) & 7u) == 0) {
-        store8(o, make_uint2(lo, hi));
+        UD_ST8(o, make_uint2(lo, hi));
       } else if ((((uintptr_t)o) & 3u) == 0) {
         gstore<u32>(o, lo);
         gstore<u32>(o + 4, hi);
@@ -1119,7 +1136,7 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
       if (b < kD2WaveW * 3 && b + 16 > vb0 && b < vb1) {
         const uint4 v = *reinterpret_cast<const uint4*>(st + b);
         if (b >= vb0 && b + 16 <= vb1) {
-          gstore16(orow + b, v);
+          UD_ST16(orow + b, v);
         } else {
           const u32 vv[4] = {v.x, v.y, v.z, v.w};
           for (int k = 0; k < 16; ++k)
