@@ -153,7 +153,7 @@ def cfg3(n=64):
     ms, wall = timed(rs.Stream, lambda: rs.RunBatchAsync(batch), 50)
     touched = 720 * 3840 + 360 * 3840 + 1382400  # one source row per dst row (weight of the 2nd is 0) + dst
     return {"config": f"cfg3 PySurfaceResizer NV12 3840x2160->1280x720 bilinear, batch={n}, one launch",
-            "kernel": "k_resize<u8, 2, POINT>", "ms_per_batch": round(ms, 4), "us_per_frame": round(ms * 1e3 / n, 3),
+            "kernel": "k_resize_pointk<3>", "ms_per_batch": round(ms, 4), "us_per_frame": round(ms * 1e3 / n, 3),
             "frames_per_s": round(n / (ms * 1e-3), 1),
             "bytes_moved_per_frame": touched,
             "bytes_note": "exact 3x: the NPP grid samples src[3y][3x] (weights 1,0); the kernel fetches the 1080 source rows it "
@@ -213,6 +213,25 @@ def cfg4(n=64):
                                                    "bytes_note": "one pass: the 6 220 800 B intermediate is neither written nor re-read",
                                                    "roofline": roofline("cfg4_fused", b_ud, n, ms_fused),
                                                    "speedup_vs_chain": round((ms_ud + ms_rot) / ms_fused, 3)}}
+
+
+def udgen(n=64):
+    """PySurfaceUD at ratios the exact-2x kernel does not cover (the any-ratio kernel k_ud_nv12, staged form): the
+    pre-processing geometries of a 1080p stream -- 720p (1.5x), 640x384 (3x / 2.8x) -- NV12 -> packed RGB."""
+    out = []
+    ud = vali.PySurfaceUD(DEV)
+    for (sw, sh, dw, dh) in ((1920, 1080, 1280, 720), (1920, 1080, 640, 384)):
+        srcs = [vali.Surface.Make(vali.NV12, sw, sh, DEV) for _ in range(n)]
+        dsts = [vali.Surface.Make(vali.RGB, dw, dh, DEV) for _ in range(n)]
+        fill(srcs)
+        batch = ud.PrepareBatch(srcs, dsts)
+        ms, _ = timed(ud.Stream, lambda: ud.RunBatchAsync(batch), 30)
+        b = sw * sh * 3 // 2 + dw * dh * 3
+        out.append({"geometry": f"{sw}x{sh}->{dw}x{dh}", "kernel": "k_ud_nv12<u8, RGB, staged>", "us_per_frame": round(ms * 1e3 / n, 3),
+                    "bytes_moved_per_frame": b, "roofline": roofline(f"udgen_{dw}x{dh}", b, n, ms)})
+        del srcs, dsts, batch
+    return {"config": f"udgen PySurfaceUD NV12 1080p -> RGB at non-2x ratios, batch={n}, one launch each",
+            "bytes_note": "whole NV12 source + RGB destination", "results": out}
 
 
 def cfg3_lanczos(n=64):
@@ -288,6 +307,6 @@ def ud_scales(n=32):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["hl1080", "cfg2", "cfg3", "interp", "cfg4"]
+    which = sys.argv[1:] or ["hl1080", "cfg2", "cfg3", "interp", "cfg4", "udgen"]
     for name in which:
         print(json.dumps(globals()[name]()), flush=True)

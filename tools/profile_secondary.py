@@ -25,12 +25,13 @@ OUT = ROOT / "gpurun_out" / "prof_r02_secondary"
 # config key -> (bench_configs function, kernel-name substring, frames per launch)
 KEYS = {
     "hl1080": ("hl1080", "k_nv12_rgb8", 1024),
-    "cfg3": ("cfg3", "k_resize<", 64),
+    "cfg3": ("cfg3", "k_resize_pointk<", 64),
     "interp_bilinear": ("interp", "k_resize<", 64),
     "interp_lanczos": ("interp", "k_resize_taps<", 64),
     "cfg4_ud": ("cfg4", "k_ud_down2<", 64),
     "cfg4_rot": ("cfg4", "k_rotate_tile", 64),
     "cfg4_fused": ("cfg4", "k_ud_down2_t<", 64),
+    "udgen_1280x720": ("udgen", "k_ud_nv12<", 64),   # (the larger of udgen's two geometries = the largest dispatch)
 }
 
 
