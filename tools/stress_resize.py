@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One-off stress of the Lanczos / bicubic kernel beyond the test-suite: random formats, sizes up to ~2600, extreme
+"""One-off stress of the resize kernels (Lanczos / bicubic / bilinear) beyond the test-suite: random formats, sizes up to ~2600, extreme
 ratios (both ways), every rows-per-wave form, single surfaces and small batches; every output bit-exact vs the oracle."""
 import sys, time
 from pathlib import Path
@@ -25,7 +25,7 @@ while time.time() - t0 < budget:
     else:           sw, sh = rng.integers(250, 1100), rng.integers(60, 400); dw = int(sw * rng.uniform(0.4, 2.2)) or 2; dh = int(sh * rng.uniform(0.4, 2.2)) or 2
     sw, sh, dw, dh = (int(max(2, v)) for v in (sw, sh, dw, dh))
     if even: sw, sh, dw, dh = (v // 2 * 2 for v in (sw, sh, dw, dh))
-    interp, iname = [(vali.Interpolation.LANCZOS, "lanczos"), (vali.Interpolation.CUBIC, "cubic")][rng.integers(2)]
+    interp, iname = [(vali.Interpolation.LANCZOS, "lanczos"), (vali.Interpolation.CUBIC, "cubic"), (vali.Interpolation.LINEAR, "linear")][rng.integers(3)]
     vali.tuning.Set("RESIZE_NO_SEPARABLE", int(rng.integers(4)))
     pf = vali.PixelFormat[name]
     src = vali.Surface.Make(pf, sw, sh, DEV)
