@@ -100,6 +100,31 @@ def test_unsupported_params(vali, gpu):
     assert vali.PixelFormat.RGB in rot.SupportedFormats and vali.PixelFormat.NV12 not in rot.SupportedFormats
 
 
+@pytest.mark.parametrize("angle", [90.0, 270.0])
+@pytest.mark.parametrize("size", [(2432, 1792), (2435, 1731)])
+@pytest.mark.parametrize("fmt", ["RGB", "BGR"])
+def test_quarter_turns_of_large_packed_frames(vali, gpu, fmt, angle, size):
+    """Frames of 4 Mpixel and more take the 64x128-pixel tile form of the 3-byte transpose (rotate.hip kRotTallPixels): a
+    whole-tile and a ragged geometry, single call and batch, against numpy's rot90 (a quarter turn is a permutation)."""
+    w, h = size
+    pf = vali.PixelFormat[fmt]
+    rot = vali.PySurfaceRotator(gpu)
+    srcs = [vali.Surface.Make(pf, w, h, gpu) for _ in range(2)]
+    dsts = [vali.Surface.Make(pf, h, w, gpu) for _ in range(3)]
+    imgs = []
+    for i, s in enumerate(srcs):
+        host = np.random.default_rng(40 + i).integers(0, 256, s.HostSize, dtype=np.uint8)
+        imgs.append(host.reshape(h, w, 3))
+        assert vali.PyFrameUploader(gpu).Run(host, s)[0]
+    assert rot.Run(srcs[0], dsts[0], angle) == (True, vali.TaskExecInfo.SUCCESS)
+    assert rot.RunBatch(srcs, dsts[1:], angle) == (True, vali.TaskExecInfo.SUCCESS)
+    k = 1 if angle == 90.0 else 3
+    # the reference's 90 degree turn = NPP's rotation about the origin + shift: dst(x', y') = src(W-1-y', x') = rot90 k=1
+    for d, img in zip(dsts, [imgs[0], imgs[0], imgs[1]]):
+        got = download(vali, gpu, d).reshape(w, h, 3)
+        assert np.array_equal(got, np.rot90(img, k=k))
+
+
 @pytest.mark.parametrize("fmt,angle", [("RGB", 90.0), ("RGB", 270.0), ("YUV420", 90.0), ("RGB", 33.0)])
 def test_rotate_batch(vali, gpu, oracle, fmt, angle):
     """One launch over a batch == per-surface Run."""

@@ -122,6 +122,16 @@ template <typename T> __device__ __forceinline__ T gload(const void* p) {
 template <typename T> __device__ __forceinline__ void gstore(void* p, T v) {
   *(VALI_GLOBAL T*)p = v;
 }
+// any byte alignment: the same instruction on an under-aligned type (gfx950 runs HSA queues in unaligned-access mode;
+// a misaligned wave access touches at most one more line)
+template <typename T> __device__ __forceinline__ T gload_u(const void* p) {
+  typedef T TU __attribute__((aligned(1)));
+  return *(const VALI_GLOBAL TU*)p;
+}
+template <typename T> __device__ __forceinline__ void gstore_u(void* p, T v) {
+  typedef T TU __attribute__((aligned(1)));
+  *(VALI_GLOBAL TU*)p = v;
+}
 // non-temporal: finished output whose wave instruction covers whole 128-byte lines (neighbouring lanes write
 // neighbouring bytes); never for strided pieces
 template <typename T> __device__ __forceinline__ void gstore_nt(void* p, T v) {

@@ -141,13 +141,18 @@ constexpr int kRotTile = 64;
 // store then costs one aligned ds_read_b32 per pixel instead of three ds_read_u8 plus the
 // shifts to reassemble them (2.4 -> see profiles/r01_secondary.md), and a row stride of 65
 // dwords makes the (16 row groups) x (4 columns) of a wave hit 64 different banks.
-constexpr int kRotTileHRgb = 64; // 128-row tiles (384-byte destination segments) measured slower: 3.0 vs 2.4 us
+constexpr int kRotTileHRgb = 64;     // tile rows: 64, or kRotTileHRgbTall for large frames (below)
+constexpr int kRotTileHRgbTall = 128; // 384-byte destination segments = 3 whole lines.  Round 2, one box, batch 64: 2160p
+                                      // 8.8 -> 8.3 us (10.8 -> 8.4-9.2 on a slower box), 1080p equal, 720p 0.91 -> 1.0,
+                                      // 640x360 0.25 -> 0.30 (33 KB of LDS: too few workgroups for small frames) -> used
+                                      // from kRotTallPixels source pixels per plane on; 64x256, 128x128, 128x64, 32x128
+                                      // and 32x256 tiles all measured slower than one of these two
+constexpr int kRotTallPixels = 4 << 20;
 constexpr int kRotTileWRgb = 64; // tile columns for 3-byte pixels; 128 (source segments = 3 whole 128-byte lines, 33 KB of
                                  // LDS per workgroup) measured slower in round 2: 1080p 3.13 vs 2.71 us, 2160p 11.9 vs 10.2
-template <int QUARTER>
+template <int QUARTER, int TH>
 __device__ __forceinline__ void rotate_tile_rgb8(const PlaneView& v, u32 tile_x, u32 tile_y) {
-  constexpr int P = 3, TW = kRotTileWRgb, SD = TW + 1; // LDS row stride in dwords
-  constexpr int TH = kRotTileHRgb;        // tile rows
+  constexpr int P = 3, TW = kRotTileWRgb, SD = TW + 1; // LDS row stride in dwords; TH = tile rows
   __shared__ u32 lds[TH * SD];
   const int src_w = v.sw, src_h = v.sh, dst_w = v.dw, dst_h = v.dh;
   const uint8_t* src = v.sp;
@@ -159,7 +164,9 @@ __device__ __forceinline__ void rotate_tile_rgb8(const PlaneView& v, u32 tile_x,
 
   // phase 1: TW/4 lanes x 4 pixels (one 12-byte load) per source row
   const uint8_t* sbase = src + (size_t)ry * src_pitch + (size_t)cx * P;
-  const bool vec = ((((uintptr_t)sbase) | (uintptr_t)src_pitch) & 3u) == 0;
+  // (vector accesses at ANY byte alignment: a 270 degree turn of a frame whose height is not a multiple of 4 starts
+  // its destination segments at odd offsets -- through the byte path that measured 10.5 instead of 4.3 us, 2720x1530)
+  constexpr bool vec = true;
   {
   constexpr int kLanesPerSrcRow = TW / 4, kSrcRowsPerPass = kBlock / kLanesPerSrcRow;
   const int chunk = t % kLanesPerSrcRow;
@@ -173,7 +180,7 @@ __device__ __forceinline__ void rotate_tile_rgb8(const PlaneView& v, u32 tile_x,
     const uint8_t* q = sbase + (size_t)(t / kLanesPerSrcRow) * src_pitch + chunk * 12;
 #pragma unroll
     for (int pass = 0; pass < kPasses; ++pass)
-      w[pass] = *(const VALI_GLOBAL v3u32*)(q + (size_t)(pass * kSrcRowsPerPass) * src_pitch);
+      w[pass] = gload_u<v3u32>(q + (size_t)(pass * kSrcRowsPerPass) * src_pitch);
 #pragma unroll
     for (int pass = 0; pass < kPasses; ++pass) {
       u32* l = lds + (pass * kSrcRowsPerPass + t / kLanesPerSrcRow) * SD + chunk * 4;
@@ -192,7 +199,7 @@ __device__ __forceinline__ void rotate_tile_rgb8(const PlaneView& v, u32 tile_x,
     u32 px[4];
     if (vec && chunk * 4 + 4 <= tw) {
       typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
-      const v3u32 w = *(const VALI_GLOBAL v3u32*)q;
+      const v3u32 w = gload_u<v3u32>(q);
       px[0] = w.x & 0xffffffu;
       px[1] = (w.x >> 24) | ((w.y & 0xffffu) << 8);
       px[2] = (w.y >> 16) | ((w.z & 0xffu) << 16);
@@ -238,10 +245,10 @@ __device__ __forceinline__ void rotate_tile_rgb8(const PlaneView& v, u32 tile_x,
       px[q] = ok[q] ? lds[jj * SD + lc] : 0u;
     }
     uint8_t* o = dst + (size_t)dy_ * dst_pitch + (ptrdiff_t)dx0 * P;
-    if (ok[0] && ok[1] && ok[2] && ok[3] && (((uintptr_t)o) & 3u) == 0) {
+    if (ok[0] && ok[1] && ok[2] && ok[3]) {
       typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
       const v3u32 w = {px[0] | (px[1] << 24), (px[1] >> 8) | (px[2] << 16), (px[2] >> 16) | (px[3] << 8)};
-      *(VALI_GLOBAL v3u32*)o = w;
+      gstore_u<v3u32>(o, w);
     } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -254,7 +261,12 @@ __device__ __forceinline__ void rotate_tile_rgb8(const PlaneView& v, u32 tile_x,
   }
 }
 
-template <int P, int QUARTER>
+__device__ __forceinline__ uint4 rot_load16(const void* p) {
+  const v4u32 w = gload_u<v4u32>(p);
+  return make_uint4(w.x, w.y, w.z, w.w);
+}
+
+template <int P, int QUARTER, int THR = kRotTileHRgb> // THR: tile rows of the 3-byte form
 __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
   constexpr int S = kRotTile * P + 4; // LDS row stride in bytes (dword aligned, odd dwords)
   __shared__ __attribute__((aligned(16))) uint8_t lds[P == 3 ? 16 : kRotTile * S];
@@ -266,13 +278,13 @@ __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
   if (a.tile_order == 1) { // walk the source tiles column by column: consecutive workgroups write neighbouring dst
                            // segments.  Measured both ways round: RGB 2160p 90 deg 10.8 -> 10.15 us and 1080p 270 deg
                            // 2.80 -> 2.72 in one harness, 1080p 90 deg 2.40 -> 2.62 in BASELINE config 4's: not the default
-    const u32 th = P == 3 ? kRotTileHRgb : kRotTile;
+    const u32 th = P == 3 ? THR : kRotTile;
     const u32 tiles_y = ((u32)v.sh + th - 1) / th, local = tile_y * job.tiles_x + tile_x;
     tile_x = local / tiles_y;
     tile_y = local - tile_x * tiles_y;
   }
   if constexpr (P == 3) {
-    rotate_tile_rgb8<QUARTER>(v, tile_x, tile_y);
+    rotate_tile_rgb8<QUARTER, THR>(v, tile_x, tile_y);
   } else {
   const int src_w = v.sw, src_h = v.sh, dst_w = v.dw, dst_h = v.dh;
   const uint8_t* src = v.sp;
@@ -286,7 +298,7 @@ __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
   // phase 1: coalesced row segments -> LDS (16-byte / 4-byte vectors when aligned)
   const uint8_t* sbase = src + (size_t)ry * src_pitch + (size_t)cx * P;
   const int row_bytes = tw * P;
-  const bool aligned16 = (((uintptr_t)sbase | (uintptr_t)src_pitch) & 15u) == 0;
+  constexpr bool aligned16 = true; // (16-byte loads at any alignment, see rotate_tile_rgb8)
   if (aligned16 && tw == kRotTile && th == kRotTile) {
     // whole tiles: the thread's P loads are all in flight before the first LDS write (the run-time loop below waits
     // for each load before it issues the next)
@@ -295,7 +307,7 @@ __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
 #pragma unroll
     for (int i = 0; i < P; ++i) {
       const int k = t + i * kBlock, r = k / V, c = k - r * V;
-      w[i] = gload16(sbase + (size_t)r * src_pitch + c * 16);
+      w[i] = rot_load16(sbase + (size_t)r * src_pitch + c * 16);
     }
 #pragma unroll
     for (int i = 0; i < P; ++i) {
@@ -307,7 +319,7 @@ __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
     const int v_per_row = row_bytes / 16;
     for (int k = t; k < th * v_per_row; k += kBlock) {
       const int r = k / v_per_row, v = k - r * v_per_row;
-      const uint4 w = gload16(sbase + (size_t)r * src_pitch + v * 16);
+      const uint4 w = rot_load16(sbase + (size_t)r * src_pitch + v * 16);
       u32* l = (u32*)(lds + r * S + v * 16);
       l[0] = w.x; l[1] = w.y; l[2] = w.z; l[3] = w.w;
     }
@@ -355,10 +367,10 @@ __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
         for (int k = 0; k < D; ++k)
           w[q * D + k] = ok[q] ? *reinterpret_cast<const u32*>(lds + jj * S + lc * P + 4 * k) : 0u;
       }
-      if (ok[0] && ok[1] && ok[2] && ok[3] && (((uintptr_t)o) & 3u) == 0) {
+      if (ok[0] && ok[1] && ok[2] && ok[3]) {
 #pragma unroll
         for (int k = 0; k < 4 * D; ++k)
-          gstore<u32>(o + 4 * k, w[k]);
+          gstore_u<u32>(o + 4 * k, w[k]);
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -377,12 +389,12 @@ __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
         for (int b = 0; b < P; ++b)
           px[q * P + b] = ok[q] ? lds[jj * S + lc * P + b] : (uint8_t)0;
       }
-      if (ok[0] && ok[1] && ok[2] && ok[3] && (((uintptr_t)o) & 3u) == 0) {
+      if (ok[0] && ok[1] && ok[2] && ok[3]) {
         u32 w[P];
         __builtin_memcpy(w, px, 4 * P);
 #pragma unroll
         for (int k = 0; k < P; ++k)
-          gstore<u32>(o + 4 * k, w[k]);
+          gstore_u<u32>(o + 4 * k, w[k]);
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -518,8 +530,12 @@ static void rotate_coeffs(double angle_deg, float* c, float* s) {
   }
 }
 
-template <int QUARTER> static int launch_tile(const RotArgs& a, int pixel_bytes, dim3 grid, hipStream_t s) {
+template <int QUARTER> static int launch_tile(const RotArgs& a, int pixel_bytes, bool tall, dim3 grid, hipStream_t s) {
   const dim3 block(kBlock);
+  if (pixel_bytes == 3 && tall) {
+    hipLaunchKernelGGL((k_rotate_tile<3, QUARTER, kRotTileHRgbTall>), grid, block, 0, s, a);
+    return VALI_OK;
+  }
   switch (pixel_bytes) {
 #define VALI_ROT_CASE(P)                                                                    \
   case P:                                                                                   \
@@ -563,6 +579,7 @@ static int launch_rotate(RotArgs& a, int fmt, int sw, int sh, int dw, int dh, do
                     (per_plane_shifts != 0 ||
                      (a.njobs == 1 && shift_x == (double)(sw - 1) && shift_y == (double)(sh - 1)));
 
+  const bool tall = (long long)sw * sh >= kRotTallPixels; // 3-byte pixels only (one plane: the surface size is the plane's)
   u32 total = 0;
   for (int k = 0; k < a.njobs; ++k) {
     RotJob& j = a.job[k];
@@ -578,7 +595,7 @@ static int launch_rotate(RotArgs& a, int fmt, int sw, int sh, int dw, int dh, do
     }
     j.first_tile = total;
     if (tiled) {
-      const int th = elem * j.channels == 3 ? kRotTileHRgb : kRotTile;
+      const int th = elem * j.channels == 3 ? (tall ? kRotTileHRgbTall : kRotTileHRgb) : kRotTile;
       const int tw = elem * j.channels == 3 ? kRotTileWRgb : kRotTile;
       j.tiles_x = (u32)(psw + tw - 1) / tw;
       total += j.tiles_x * (u32)((psh + th - 1) / th);
@@ -594,7 +611,7 @@ static int launch_rotate(RotArgs& a, int fmt, int sw, int sh, int dw, int dh, do
   const dim3 grid = tile_grid(a.map), block(kBlock);
   if (tiled) {
     const int pixel_bytes = elem * a.job[0].channels; // all jobs of a format share it
-    const int rc = q90 ? launch_tile<1>(a, pixel_bytes, grid, stream) : launch_tile<3>(a, pixel_bytes, grid, stream);
+    const int rc = q90 ? launch_tile<1>(a, pixel_bytes, tall, grid, stream) : launch_tile<3>(a, pixel_bytes, tall, grid, stream);
     if (rc != VALI_OK)
       return rc;
   } else if (half) {
