@@ -166,7 +166,8 @@ def test_planar_ud_matches_the_reference_golden(vali, gpu):
 # ---- fused UD + quarter-turn rotation (BASELINE config 4 as one pass) ---------------------------
 @pytest.mark.parametrize("angle", [90.0, 180.0, 270.0, -90.0])
 @pytest.mark.parametrize("geom", [(3840, 2160, 1920, 1080), (848, 464, 640, 360), (640, 360, 1280, 720),
-                                  (424, 232, 421, 233), (64, 48, 7, 5), (130, 70, 58, 34), (1920, 1080, 250, 251)])
+                                  (424, 232, 421, 233), (64, 48, 7, 5), (130, 70, 58, 34), (1920, 1080, 250, 251),
+                                  (1684, 466, 842, 233)])   # exact 2x, width % 16 != 0: the half turn's rows start at odd offsets
 def test_ud_rotated_equals_ud_then_rotator(vali, gpu, oracle, angle, geom):
     sw, sh, uw, uh = geom                       # uw x uh = size of the un-rotated UD output
     nv = make_nv12(sw, sh, 23)

@@ -10,7 +10,7 @@ w, h = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 108
 angle = float(sys.argv[4]) if len(sys.argv) > 4 else 90.0
 n = 64
 rot = vali.PySurfaceRotator(DEV)
-srcs = [vali.Surface.Make(fmt, w, h, DEV) for _ in range(n)]; dsts = [vali.Surface.Make(fmt, h, w, DEV) for _ in range(n)]
+srcs = [vali.Surface.Make(fmt, w, h, DEV) for _ in range(n)]; dsts = [vali.Surface.Make(fmt, *((w, h) if angle % 180.0 == 0.0 else (h, w)), DEV) for _ in range(n)]
 fill(srcs); b = rot.PrepareBatch(srcs, dsts)
 ms, _ = timed(rot.Stream, lambda: rot.RunBatchAsync(b, angle=angle), 5, 1)
 print('us/frame', round(ms * 1e3 / n, 3), 'TB/s', round(2 * srcs[0].HostSize / (ms * 1e-3 / n) / 1e12, 3))

@@ -428,8 +428,9 @@ __global__ void __launch_bounds__(kBlock) k_rotate_half(const RotArgs a) {
     return;
   const int n = min(4, W - x0);
   constexpr int ND = P; // dwords of a 4-pixel group
-  const bool vec = n == 4 && ((((uintptr_t)v.sp) | ((uintptr_t)v.dp) | (uintptr_t)v.spitch | (uintptr_t)v.dpitch) & 3u) == 0 &&
-                   ((((W - 4 - x0) * P) | (x0 * P)) & 3) == 0;
+  // dword accesses at any byte alignment (a width that is not a multiple of 4 mirrors the groups onto odd offsets: the
+  // whole frame used to take the byte loop); the byte loop is left to the last, partial group of a row
+  const bool vec = n == 4;
   u32 in[kHalfRowsPerWave][ND];
   const int y_first = tile_y * kHalfTileH + wave * kHalfRowsPerWave;
   if (vec) {
@@ -438,7 +439,7 @@ __global__ void __launch_bounds__(kBlock) k_rotate_half(const RotArgs a) {
       const int y = min(y_first + r, H - 1);
       const uint8_t* q = v.sp + (size_t)(H - 1 - y) * v.spitch + (size_t)(W - 4 - x0) * P;
 #pragma unroll
-      for (int k = 0; k < ND; ++k) in[r][k] = gload<u32>(q + 4 * k);
+      for (int k = 0; k < ND; ++k) in[r][k] = gload_u<u32>(q + 4 * k);
     }
 #pragma unroll
     for (int r = 0; r < kHalfRowsPerWave; ++r) {
@@ -458,7 +459,7 @@ __global__ void __launch_bounds__(kBlock) k_rotate_half(const RotArgs a) {
       }
       uint8_t* o = v.dp + (size_t)y * v.dpitch + (size_t)x0 * P;
 #pragma unroll
-      for (int k = 0; k < ND; ++k) gstore<u32>(o + 4 * k, out[k]);
+      for (int k = 0; k < ND; ++k) gstore_u<u32>(o + 4 * k, out[k]);
     }
     return;
   }

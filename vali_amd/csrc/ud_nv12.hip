@@ -1136,7 +1136,10 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
       if (b < kD2WaveW * 3 && b + 16 > vb0 && b < vb1) {
         const uint4 v = *reinterpret_cast<const uint4*>(st + b);
         if (b >= vb0 && b + 16 <= vb1) {
-          UD_ST16(orow + b, v);
+          if ((((uintptr_t)orow) & 15u) == 0) // wave-uniform
+            UD_ST16(orow + b, v);
+          else
+            gstore_u<v4u32>(orow + b, (v4u32){v.x, v.y, v.z, v.w});
         } else {
           const u32 vv[4] = {v.x, v.y, v.z, v.w};
           for (int k = 0; k < 16; ++k)
@@ -1217,7 +1220,8 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
     if constexpr (kPacked) {
       orow = ROT == 2 ? d.p[0] + (u32)((dh - 1 - y) * d.pitch[0]) + (ptrdiff_t)(dw - xw - kD2WaveW) * 3
                       : d.p[0] + (u32)(y * d.pitch[0]) + (size_t)xw * 3;
-      vec = (((uintptr_t)orow) & 15u) == 0; // wave-uniform; else every lane takes the general store
+      // (any alignment: a half turn of an output whose width is not a multiple of 16 starts its rows at odd offsets;
+      // the strip then leaves through misaligned 16-byte stores instead of sending every lane to the general store)
     }
     // (broadcast BEFORE the divergent branch below: inside it only the lanes with 8 pixels run, and
     // a load whose only reader sits there may be sunk into it -- lanes 1..3 of a wave whose lane 0
