@@ -29,7 +29,7 @@ while time.time() - t0 < budget:
     sw, sh = (int(max(2, v)) // 2 * 2 for v in (sw, sh))
     dw, dh = (int(max(1, v)) for v in (dw, dh))
     for k, lo in (("UD_DOWN2", 2), ("UD_FORCE_GATHER", 2), ("UD_OCC5", 2)):
-        vali.tuning.Set(k, int(rng.integers(lo)) if k != "UD_DOWN2" else int(rng.integers(4) != 0))
+        vali.tuning.Set(k, int(rng.integers(lo)) if k != "UD_DOWN2" else int(rng.integers(3)))
     spf, dpf = vali.PixelFormat[src_name], vali.PixelFormat[out]
     src = vali.Surface.Make(spf, sw, sh, DEV)
     dt = np.uint8 if src_name == "NV12" else np.uint16

@@ -1528,7 +1528,12 @@ static int launch_ud(UdArgs& a, int src_fmt, int src_w, int dst_w, int dst_h, in
     staged = false;
   // exact 2x horizontal downscale of NV12: the division-free, LDS-free kernel (VALI_UD_DOWN2=0
   // keeps the general one, for A/B measurements)
-  const bool down2_on = tuning(VALI_TUNE_UD_DOWN2) != 0;
+  // The exact-ratio kernels own 8 output pixels per lane; a width that is not a multiple of 8 leaves one lane per row
+  // on their byte-gather path, and the whole wave waits for it: 1916x1076 -> 958x538 2.13 us against 0.89 for 960x540 and
+  // 1.12 through the general kernel; 1918x1078 at 1:1 4.75 / 2.16 / 3.31 (tools/cliffs.py).  Such widths therefore go
+  // to the general kernel; VALI_TUNE_UD_DOWN2 = 2 keeps them here (A/B, and the tests of that path).
+  const int down2_mode = tuning(VALI_TUNE_UD_DOWN2);
+  const bool down2_on = down2_mode != 0 && (down2_mode == 2 || dst_w % kD2LanePx == 0);
   if (down2_on && !force_gather && src_fmt == VALI_FMT_NV12 && src_w == dst_w && !(rot & 1) && kind != UD_RGB_F32 &&
       kind != UD_RGB_F32_PLANAR) { // 1:1 width: colour conversion with chroma interpolation
     a.map = make_tile_map((dst_w + kD2WaveW - 1) / kD2WaveW, (dst_h + kUdTileH - 1) / kUdTileH, (u32)n);
