@@ -30,6 +30,10 @@ cc = vali.ColorspaceConversionContext(vali.ColorSpace.BT_709, vali.ColorRange.MP
 for name, fd in (("cvt_nv12_rgb", vali.RGB), ("cvt_nv12_planar", vali.RGB_PLANAR)):
     OPS[name] = [(lambda: vali.PySurfaceConverter(DEV), vali.NV12, fd, (w, h), (w, h), lambda t, b: t.RunBatchAsync(b, cc))
                  for (w, h) in ((1920, 1080), (1918, 1078), (1366, 768), (1914, 1082))]
+for a, b in (("RGB", "RGB_PLANAR"), ("RGB_PLANAR", "RGB"), ("RGB", "YUV420"), ("YUV420", "RGB"), ("YUV420", "NV12"), ("NV12", "YUV420"),
+             ("RGB", "BGR"), ("RGB", "YUV444"), ("RGB_PLANAR", "YUV444"), ("P10", "NV12"), ("RGB", "RGB_32F"), ("RGB_32F", "RGB_32F_PLANAR")):
+    OPS[f"cvt_{a}_{b}"] = [(lambda: vali.PySurfaceConverter(DEV), vali.PixelFormat[a], vali.PixelFormat[b], (w, h), (w, h),
+                            lambda t, bt: t.RunBatchAsync(bt, cc)) for (w, h) in ((1920, 1080), (1918, 1078), (1366, 768))]
 for filt in ("LINEAR", "LANCZOS"):
     it = vali.Interpolation[filt]
     OPS["resize_" + filt.lower()] = [(lambda it=it: vali.PySurfaceResizer(vali.NV12, DEV, interpolation=it), vali.NV12, vali.NV12, s, d,

@@ -39,6 +39,24 @@ def _run(cmd):
     subprocess.run([str(c) for c in cmd], check=True, stdout=sys.stderr)
 
 
+def _compile_kernel(job):
+    """One translation unit; the compiler's per-kernel resource remarks (registers, scratch, occupancy) go to
+    <obj>.resources.txt -- tests/test_kernel_resources.py refuses scratch memory in any kernel: a rolled loop over a
+    register array once moved a whole struct to scratch and cost every packed-destination converter half its speed
+    without failing a single parity test."""
+    cmd, report = job
+    print("  $", " ".join(str(c) for c in cmd), file=sys.stderr, flush=True)
+    r = subprocess.run([str(c) for c in cmd] + ["-Rpass-analysis=kernel-resource-usage", "-fno-caret-diagnostics"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True)
+    remarks = [l for l in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" in l]
+    other = [l for l in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in l]
+    if other:
+        print("\n".join(other), file=sys.stderr, flush=True)
+    if r.returncode != 0:
+        raise subprocess.CalledProcessError(r.returncode, cmd)
+    Path(report).write_text("\n".join(remarks) + "\n")
+
+
 def _stale(product: Path, sources) -> bool:
     if not product.exists():
         return True
@@ -64,14 +82,15 @@ def build_kernels(force=False):
     objs, todo = [], []
     for src in sorted(CSRC.glob("*.hip")):
         obj = OBJ / (src.stem + ".o")
-        if force or _stale(obj, [src] + headers):
-            todo.append([HIPCC, *HIP_FLAGS, "-c", src, "-o", obj])
+        report = OBJ / (src.stem + ".resources.txt")
+        if force or _stale(obj, [src] + headers) or not report.exists():
+            todo.append(([HIPCC, *HIP_FLAGS, "-c", src, "-o", obj], report))
         objs.append(obj)
     if todo:   # the translation units are independent: compile them side by side
         from concurrent.futures import ThreadPoolExecutor
 
         with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 1)) as pool:
-            list(pool.map(_run, todo))
+            list(pool.map(_compile_kernel, todo))
     lib = lib_path()
     if force or _stale(lib, objs):
         _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", lib,

@@ -211,7 +211,13 @@ __device__ __forceinline__ void store_block(const Block& b, const SurfRef& d, co
     uint8_t* rb = d.p[0] + (size_t)q.row0 * d.pitch[0] + (size_t)q.wave_g0 * 48;
     const int vb = ANY ? q.full_lanes * 48 : q.valid_lanes * 48;
     u32 o[12];
-    for (int r = 0; r < (q.has_row1 ? 2 : 1); ++r) {
+    // (a compile-time trip count: with `r < (has_row1 ? 2 : 1)` the loop stayed rolled once the ragged forms were
+    // added, b.c0[r] became a run-time index and the whole Block moved to scratch memory -- 116 bytes per lane and
+    // every packed-destination pair at 2.5-4.3 TB/s instead of 5.9-6.2, found late in round 2 by tools/cliffs.py)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (r == 1 && !q.has_row1)
+        break;
       if (q.lane_valid) {
         if constexpr (DST == K_RGB) interleave3(b.c0[r], b.c1[r], b.c2[r], o);
         else interleave3(b.c2[r], b.c1[r], b.c0[r], o);
