@@ -52,6 +52,13 @@ for fd in ("RGB", "RGB_PLANAR", "YUV444", "RGB_32F_PLANAR"):
     OPS["ud_" + fd] = [(lambda: vali.PySurfaceUD(DEV), vali.NV12, vali.PixelFormat[fd], s, d, lambda t, b: t.RunBatchAsync(b))
                        for (s, d) in (((1920, 1080), (960, 540)), ((1916, 1076), (958, 538)), ((1920, 1080), (1280, 720)), ((1918, 1078), (1277, 717)),
                                       ((1920, 1080), (1920, 1080)), ((1918, 1078), (1918, 1078)))]
+OPS["ud_P10_YUV444_10bit"] = [(lambda: vali.PySurfaceUD(DEV), vali.P10, vali.YUV444_10bit, s, d, lambda t, b: t.RunBatchAsync(b))
+                              for (s, d) in (((1920, 1080), (960, 540)), ((1920, 1080), (1280, 720)), ((1918, 1078), (1277, 717)))]
+OPS["ud_planar_YUV420_YUV444"] = [(lambda: vali.PySurfaceUD(DEV), vali.YUV420, vali.YUV444, s, d, lambda t, b: t.RunBatchAsync(b))
+                                  for (s, d) in (((1920, 1080), (960, 540)), ((1920, 1080), (1280, 720)), ((1918, 1078), (1277, 717)))]
+for out in ("RGB_32F_PLANAR", "RGB"):
+    OPS["preproc_" + out] = [(lambda: vali.PySurfacePreprocessor(DEV), vali.NV12, vali.PixelFormat[out], s, d, lambda t, b: t.RunBatchAsync(b, cc))
+                             for (s, d) in (((1920, 1080), (1920, 1080)), ((1918, 1078), (1918, 1078)), ((1920, 1080), (640, 384)), ((1918, 1078), (638, 382)))]
 for ang in (90.0, 180.0):
     OPS[f"ud_rot_{int(ang)}"] = [(lambda: vali.PySurfaceUD(DEV), vali.NV12, vali.RGB, s, ((d[1], d[0]) if ang == 90.0 else d),
                                   lambda t, b, ang=ang: t.RunRotatedBatchAsync(b, angle=ang))
