@@ -32,6 +32,10 @@ def test_parity_suites_through_the_gather_forms():
     ("VALI_UD_DOWN2=0", ["tests/test_gpu_ud.py", "tests/test_gpu_ud_down2.py"]),
     # widths that are not multiples of 8 leave the exact-ratio kernels by default: their ragged-lane path is replayed here
     ("VALI_UD_DOWN2=2", ["tests/test_gpu_ud.py", "tests/test_gpu_ud_down2.py", "tests/test_gpu_edge_geometry.py", "tests/test_gpu_random_geometry.py"]),
+    # single surfaces and small batches take 2- or 4-row waves by themselves: the whole parity suites once more through
+    # the 8-row form that batches use
+    ("VALI_ROWS_PER_WAVE=8", ["tests/test_gpu_ud.py", "tests/test_gpu_ud_down2.py", "tests/test_gpu_resize.py", "tests/test_gpu_preproc.py",
+                              "tests/test_gpu_edge_geometry.py", "tests/test_gpu_random_geometry.py"]),
     ("VALI_RESIZE_POINT=0", ["tests/test_gpu_resize.py"]),
     ("VALI_RESIZE_POINT=2", ["tests/test_gpu_resize.py", "tests/test_gpu_edge_geometry.py"]),
     # the Lanczos / bicubic kernel picks 2- / 8- / 32-row waves by the size of the launch: single-surface tests only

@@ -43,6 +43,15 @@ def ud(vali, gpu, sw, sh, dw, dh, dst):
     return download(vali, gpu, d)
 
 
+def preproc(vali, gpu, sw, sh, dw, dh):
+    src = upload(vali, gpu, vali.NV12, sw, sh, make_nv12(sw, sh, 5))
+    d = vali.Surface.Make(vali.RGB_32F_PLANAR, dw, dh, gpu)
+    cc = vali.ColorspaceConversionContext(vali.ColorSpace.BT_709, vali.ColorRange.MPEG)
+    pp = vali.PySurfacePreprocessor(gpu, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), div=1.0)
+    assert pp.Run(src, d, cc)[0]
+    return download(vali, gpu, d)
+
+
 def rotate(vali, gpu, w, h, angle):
     rng = np.random.default_rng(4)
     src = upload(vali, gpu, vali.RGB, w, h, rng.integers(0, 256, w * h * 3, dtype=np.uint8))
@@ -75,6 +84,15 @@ CASES = [
     ("ROTATE_NO_TILE", (1, 2), lambda v, g: rotate(v, g, 640, 360, 90.0)),
     ("ROTATE_NO_TILE", (2,), lambda v, g: rotate(v, g, 1000, 600, 270.0)),
     ("ROTATE_NO_TILE", (1,), lambda v, g: rotate(v, g, 640, 360, 180.0)),
+    # rows per wave (small launches pick 2 or 4 by themselves; batches 8)
+    ("ROWS_PER_WAVE", (2, 4, 8), lambda v, g: ud(v, g, 1280, 720, 640, 358, v.RGB)),           # exact-2x kernel
+    ("ROWS_PER_WAVE", (2, 4, 8), lambda v, g: ud(v, g, 1280, 720, 1280, 717, v.YUV444)),       # 1:1 kernel
+    ("ROWS_PER_WAVE", (2, 4, 8), lambda v, g: ud(v, g, 1280, 720, 854, 477, v.RGB_PLANAR)),    # any-ratio kernel, staged
+    ("ROWS_PER_WAVE", (2, 4, 8), lambda v, g: ud(v, g, 3000, 200, 300, 61, v.RGB)),            # any-ratio kernel, gather
+    ("ROWS_PER_WAVE", (2, 4, 8), lambda v, g: resize(v, g, 1280, 720, 854, 478, v.Interpolation.LINEAR)),
+    ("ROWS_PER_WAVE", (2, 4, 8), lambda v, g: resize(v, g, 1920, 1080, 480, 270, v.Interpolation.LINEAR)),   # point form, 4x
+    ("ROWS_PER_WAVE", (2, 4, 8), lambda v, g: preproc(v, g, 1280, 720, 640, 382)),
+    ("ROWS_PER_WAVE", (2, 4, 8), lambda v, g: preproc(v, g, 640, 362, 640, 362)),
 ]
 
 

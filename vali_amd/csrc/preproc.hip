@@ -38,6 +38,7 @@ struct PreprocArgs {
   vali_surface src, dst;
   vali_preproc_params prm;
   TileMap map;
+  int row_pairs; // dst row pairs a wave walks: kPpRowPairsPerWave, or 2 / 1 when the launch is small
 };
 
 constexpr int kPpRowPairsPerWave = 4;
@@ -98,8 +99,8 @@ __global__ void __launch_bounds__(kBlock) k_nv12_preproc(const PreprocArgs a) {
   }
 
 #pragma unroll 1
-  for (int it = 0; it < kPpRowPairsPerWave; ++it) {
-    const int y0 = tile_y * kPpTileH + it * 2; // wave-uniform
+  for (int it = 0; it < a.row_pairs; ++it) {
+    const int y0 = (tile_y * a.row_pairs + it) * 2; // wave-uniform
     if (y0 >= dh)
       break;
     // ---- the resized NV12' texels of this lane: 2 x 4 luma, 2 chroma pairs ----
@@ -282,7 +283,19 @@ static int launch_preproc(PreprocArgs& a, int src_w, int src_h, int dst_w, int d
     return fail(VALI_ERR_UNSUPPORTED,
                 "nv12_preproc: destination must be RGB_32F[_PLANAR], RGB, BGR or RGB_PLANAR (got %d)", dst_fmt);
   }
-  a.map = make_tile_map((dst_w + kPpTileW - 1) / kPpTileW, (dst_h + kPpTileH - 1) / kPpTileH, (u32)n);
+  // Row pairs per wave: 4, or 2 / 1 while that would leave SIMDs without a wave (the pairs of a wave run one memory round
+  // trip after the other: ONE 1080p -> 640x384 frame took 8.3 us through 4-pair waves, 48 workgroups on 256 CUs).
+  a.row_pairs = kPpRowPairsPerWave;
+  {
+    const int forced = tuning(VALI_TUNE_ROWS_PER_WAVE); // 2 / 4 / 8 dst rows
+    const long long tiles_x = (dst_w + kPpTileW - 1) / kPpTileW;
+    if (forced == 2 || forced == 4 || forced == 8)
+      a.row_pairs = forced / 2;
+    else
+      while (a.row_pairs > 1 && tiles_x * ((dst_h + 2 * a.row_pairs - 1) / (2 * a.row_pairs)) * n * kWavesPerBlock < 2048)
+        a.row_pairs /= 2;
+  }
+  a.map = make_tile_map((dst_w + kPpTileW - 1) / kPpTileW, (dst_h + 2 * a.row_pairs - 1) / (2 * a.row_pairs), (u32)n);
   const dim3 grid = tile_grid(a.map), block(kBlock);
   const bool same = src_w == dst_w && src_h == dst_h;
 #define VALI_PP_CASE(O)                                                                      \

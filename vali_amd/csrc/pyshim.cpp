@@ -220,6 +220,7 @@ PYBIND11_MODULE(_vali_shim, m) {
                   {"TUNE_ROTATE_NO_TILE", VALI_TUNE_ROTATE_NO_TILE},
                   {"TUNE_ROCTX", VALI_TUNE_ROCTX},
                   {"TUNE_RESIZE_NO_SEPARABLE", VALI_TUNE_RESIZE_NO_SEPARABLE},
+                  {"TUNE_ROWS_PER_WAVE", VALI_TUNE_ROWS_PER_WAVE},
                   {"TUNE_COUNT", VALI_TUNE_COUNT}})
     m.attr(kv.first) = kv.second;
   m.def("tuning_set", [](int key, int value) { return vali_tuning_set(key, value); });

@@ -105,12 +105,14 @@ __device__ __forceinline__ void store_px4_raw(uint8_t* dst, const u32 (&e)[4][C]
 template <typename T, int C, bool POINT = false>
 __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int sw, int sh,
                                             uint8_t* dp, int dpitch, int dw, int dh, u32 tx,
-                                            u32 ty, StageRows* stage_all) {
+                                            u32 ty, StageRows* stage_all, int rows) {
   static_assert(!POINT || sizeof(T) < 4, "float planes keep the arithmetic (0 * inf must stay NaN)");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int x0 = (tx * 64 + lane) * 4;
-  const int y_first = ty * kRsTileH + wave * kRsRowsPerWave; // wave-uniform
+  // `rows` dst rows per wave: kRsRowsPerWave for batches, 4 or 2 when the launch is small (launch_resize): a wave walks
+  // its rows one after the other, so a lone frame is done sooner by more, shorter waves
+  const int y_first = ((int)ty * kWavesPerBlock + wave) * rows; // wave-uniform
   if (y_first >= dh)
     return;
   const float scale_x = (float)sw / (float)dw, scale_y = (float)sh / (float)dh;
@@ -138,7 +140,7 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
   } else {
     vly = make_lerp(y_first + (lane & (kRsRowsPerWave - 1)), scale_y, sh);
   }
-  const int last_rr = min(kRsRowsPerWave, dh - y_first) - 1; // wave-uniform, >= 0
+  const int last_rr = min(rows, dh - y_first) - 1; // wave-uniform, >= 0
   auto row_lerp = [&](int rr) {
     Lerp l;
     l.i0 = __builtin_amdgcn_readlane(vly.i0, rr);
@@ -235,7 +237,7 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
 #pragma unroll
       for (int rr = 0; rr < kRsRowsPerWave; ++rr) {
         const int y = y_first + rr;
-        if (y >= dh)
+        if (rr > last_rr)
           break;
         commit(pf[rr % DEPTH]);
         wave_lds_sync();
@@ -283,13 +285,11 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
     // lane that has left the kernel holds whatever the compiler computed for it AFTER the exit --
     // a ragged last tile of < 32 pixels would take its row taps from such lanes.)
 #pragma unroll 1
-    for (int rr = 0; rr < kRsRowsPerWave; ++rr) {
+    for (int rr = 0; rr <= last_rr; ++rr) {
       const int y = y_first + rr;
-      if (y >= dh)
-        break;
       const Lerp ly = row_lerp(rr);
       if (n > 0) {
-        const uint8_t* rows[2] = {sp + (size_t)ly.i0 * spitch, sp + (size_t)ly.i1 * spitch};
+        const uint8_t* srows[2] = {sp + (size_t)ly.i0 * spitch, sp + (size_t)ly.i1 * spitch};
         if (PairLoad<T, C>::kMerged && sw >= 3) { // both horizontal taps of a row from one unaligned load
           if constexpr (PairLoad<T, C>::kMerged) {
             float pre[2][4][2][C];
@@ -297,7 +297,7 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
             for (int r = 0; r < 2; ++r)
 #pragma unroll
               for (int p = 0; p < 4; ++p)
-                load_tap_pair<T, C>(rows[r], lx[p].i0, sw, pre[r][p][0], pre[r][p][1]);
+                load_tap_pair<T, C>(srows[r], lx[p].i0, sw, pre[r][p][0], pre[r][p][1]);
             sample_and_store(ly, y, [&](int r, int p, int t, float (&out)[C]) {
 #pragma unroll
               for (int ch = 0; ch < C; ++ch)
@@ -308,7 +308,7 @@ __device__ __forceinline__ void resize_tile(const uint8_t* sp, int spitch, int s
           sample_and_store(ly, y, [&](int r, int p, int t, float (&out)[C]) {
 #pragma unroll
             for (int ch = 0; ch < C; ++ch)
-              out[ch] = (float)gload<T>(rows[r] + (size_t)(t ? lx[p].i1 : lx[p].i0) * PB + ch * sizeof(T));
+              out[ch] = (float)gload<T>(srows[r] + (size_t)(t ? lx[p].i1 : lx[p].i0) * PB + ch * sizeof(T));
           });
         }
       }
@@ -327,11 +327,11 @@ __global__ void __launch_bounds__(kBlock) k_resize(const ResizeArgs a) {
   __shared__ StageRows stage[kWavesPerBlock];
   const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
   if (MAXC >= 3 && job.channels == 3)
-    resize_tile<T, 3, POINT>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.force_gather ? nullptr : stage);
+    resize_tile<T, 3, POINT>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.force_gather ? nullptr : stage, a.rows);
   else if (MAXC >= 2 && job.channels == 2)
-    resize_tile<T, 2, POINT>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.force_gather ? nullptr : stage);
+    resize_tile<T, 2, POINT>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.force_gather ? nullptr : stage, a.rows);
   else
-    resize_tile<T, 1, POINT>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.force_gather ? nullptr : stage);
+    resize_tile<T, 1, POINT>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.force_gather ? nullptr : stage, a.rows);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -484,6 +484,34 @@ static int launch_resize(ResizeArgs& a, int fmt, int src_w, int src_h, int dst_w
     a.job[k].first_tile = total;
     a.job[k].tiles_x = (u32)(dw + 255) / 256;
     total += a.job[k].tiles_x * (u32)((dh + kRsTileH - 1) / kRsTileH);
+  }
+  // Rows per wave of k_resize: 8, or 4 / 2 while 8-row waves would leave SIMDs without a wave (a wave walks its rows one
+  // memory round trip after the other: ONE NV12 1080p -> 960x548 frame took 5.9 us through 8-row waves).  The taps and
+  // point-by-factor kernels have their own tiling and ignore it.
+  a.rows = kRsRowsPerWave;
+  {
+    const int forced = tuning(VALI_TUNE_ROWS_PER_WAVE);
+    auto tiles = [&](int rows) {
+      u32 t = 0;
+      for (int k = 0; k < a.njobs; ++k) {
+        const int dh = dst_h >> a.job[k].sub_y;
+        t += a.job[k].tiles_x * (u32)((dh + kWavesPerBlock * rows - 1) / (kWavesPerBlock * rows));
+      }
+      return t;
+    };
+    if (forced == 2 || forced == 4 || forced == 8)
+      a.rows = forced;
+    else
+      while (a.rows > 2 && (unsigned long long)tiles(a.rows) * (unsigned)n * kWavesPerBlock < 2048ull)
+        a.rows /= 2;
+    if (a.rows != kRsRowsPerWave) {
+      total = 0;
+      for (int k = 0; k < a.njobs; ++k) {
+        const int dh = dst_h >> a.job[k].sub_y;
+        a.job[k].first_tile = total;
+        total += a.job[k].tiles_x * (u32)((dh + kWavesPerBlock * a.rows - 1) / (kWavesPerBlock * a.rows));
+      }
+    }
   }
   a.map = make_tile_map_linear(total, (u32)n);
   const dim3 grid = tile_grid(a.map), block(kBlock);

@@ -14,6 +14,7 @@ struct ResizeArgs {
   ResizeJob job[3];
   int njobs;
   TileMap map;
+  int rows;         // k_resize: dst rows per wave (8; 4 or 2 for small launches)
   int force_gather; // VALI_TUNE_RESIZE_FORCE_GATHER: no LDS staging (tests reach the gather forms with ordinary sizes)
   // taps kernels (resize_taps.hip): dynamic LDS layout per wave = [stage_bytes: the staged source row][ring]
   int stage_bytes;  // bytes of a wave's stage (pads included), multiple of 16; 0 = gather only

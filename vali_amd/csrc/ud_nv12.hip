@@ -56,6 +56,7 @@ struct UdArgs {
   const vali_surface* d_dst;
   vali_surface src, dst;
   TileMap map;
+  int rows; // dst rows a wave walks: kUdRowsPerWave, or fewer when the launch is small (ud_rows_for); rotated outputs: always 8
 };
 
 template <typename T> struct TexelTraits;
@@ -472,7 +473,8 @@ __global__ void __launch_bounds__(kBlock, MINW) k_ud_nv12(const UdArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int x0 = (tile_x * 64 + lane) * 4;
-  const int y_first = tile_y * kUdTileH + wave * kUdRowsPerWave; // wave-uniform
+  const int rpw = ROT == 0 ? a.rows : kUdRowsPerWave;             // rows of this wave (the row taps are still evaluated for 8)
+  const int y_first = (tile_y * kWavesPerBlock + wave) * rpw;     // wave-uniform
   // odd ROT: the workgroup's output tile is collected in LDS and written transposed (ud_emit)
   __shared__ __attribute__((aligned(16))) uint8_t rot_tile[(ROT & 1) ? kRotTileBytes : 16];
   auto body = [&]() { // (a lambda so that its early exits still reach the transposed store below)
@@ -630,7 +632,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_ud_nv12(const UdArgs a) {
     // (no early exit for lanes without pixels: row_taps() reads lanes 0..7 with v_readlane, and a
     // lane that has left holds whatever the compiler computed for it after the exit)
 #pragma unroll 1
-    for (int rr = 0; rr < kUdRowsPerWave; ++rr) {
+    for (int rr = 0; rr < rpw; ++rr) {
       const int y = y_first + rr;
       if (y >= dh)
         break;
@@ -713,7 +715,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_ud_nv12(const UdArgs a) {
     // the padded LDS rows of the bilinear resizer measured no different here.)
     constexpr int DEPTH = kUdDepth;
     uint4 pf[DEPTH][4][CH];
-    const int last_rr = min(kUdRowsPerWave, dh - y_first) - 1; // wave-uniform, >= 0
+    const int last_rr = min(rpw, dh - y_first) - 1; // wave-uniform, >= 0
     auto issue = [&](int rr, uint4 (&q)[4][CH]) {
       const RowTaps rt = row_taps(min(rr, last_rr));
       // scalar address arithmetic; a plane is < 4 GiB, so 32-bit row offsets (s_mul_i32)
@@ -1044,7 +1046,8 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int xw = tile_x * kD2WaveW;          // first column of the wave
   const int x0 = xw + lane * kD2LanePx;      // first column of the lane
-  const int y_first = tile_y * kUdTileH + wave * kUdRowsPerWave; // wave-uniform
+  const int rpw = ROT == 0 ? a.rows : kUdRowsPerWave;
+  const int y_first = (tile_y * kWavesPerBlock + wave) * rpw; // wave-uniform
   if (y_first >= dh)
     return;
   const int n = min(kD2LanePx, dw - x0);
@@ -1175,7 +1178,7 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
                        sw >= kLaneBytes;
   if (!aligned) {
 #pragma unroll 1
-    for (int rr = 0; rr < kUdRowsPerWave; ++rr) {
+    for (int rr = 0; rr < rpw; ++rr) {
       const int y = y_first + rr;
       if (y >= dh)
         break;
@@ -1210,7 +1213,7 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
     r.before = gload<u32>(rb + (u32)offw);
     return r;
   };
-  const int last = min(kUdRowsPerWave - 1, dh - 1 - y_first); // last valid row of the wave
+  const int last = min(rpw - 1, dh - 1 - y_first); // last valid row of the wave
   // one row: `rows` (loaded an iteration ago) -> pixels -> stores
   auto step = [&](int rr, const RowTaps& cur, const Rows& rows) {
     const int y = y_first + rr;
@@ -1508,7 +1511,22 @@ static int launch_ud(UdArgs& a, int src_fmt, int src_w, int dst_w, int dst_h, in
     dst_w = dst_h;
     dst_h = t;
   }
-  a.map = make_tile_map((dst_w + 255) / 256, (dst_h + kUdTileH - 1) / kUdTileH, (u32)n);
+  // Rows per wave: 8 -- the column taps are paid once per 8 rows -- unless that leaves SIMDs without a wave.  A wave
+  // walks its rows one memory round trip after the other, so ONE 1080p frame through 8-row waves (136 waves on 1024
+  // SIMDs) took 9.2 us however little work it is; 2- or 4-row waves give the same frame 4x / 2x the waves, each a
+  // quarter / half as long.  Batches keep 8.  (Un-rotated outputs only: the transposed forms collect 256 x 32 tiles.)
+  auto rows_for = [&](int tiles_x) {
+    const int forced = tuning(VALI_TUNE_ROWS_PER_WAVE);
+    if (rot == 0 && (forced == 2 || forced == 4 || forced == 8))
+      return forced;
+    int rows = kUdRowsPerWave;
+    while (rot == 0 && rows > 2 &&
+           (long long)tiles_x * ((dst_h + kWavesPerBlock * rows - 1) / (kWavesPerBlock * rows)) * n * kWavesPerBlock < 2048)
+      rows /= 2;
+    return rows;
+  };
+  a.rows = rows_for((dst_w + 255) / 256);
+  a.map = make_tile_map((dst_w + 255) / 256, (dst_h + kWavesPerBlock * a.rows - 1) / (kWavesPerBlock * a.rows), (u32)n);
   const dim3 grid = tile_grid(a.map), block(kBlock);
   // staged kernel iff every tile's source spans fit the strip (same float math as the device)
   bool staged = true;
@@ -1536,7 +1554,8 @@ static int launch_ud(UdArgs& a, int src_fmt, int src_w, int dst_w, int dst_h, in
   const bool down2_on = down2_mode != 0 && (down2_mode == 2 || dst_w % kD2LanePx == 0);
   if (down2_on && !force_gather && src_fmt == VALI_FMT_NV12 && src_w == dst_w && !(rot & 1) && kind != UD_RGB_F32 &&
       kind != UD_RGB_F32_PLANAR) { // 1:1 width: colour conversion with chroma interpolation
-    a.map = make_tile_map((dst_w + kD2WaveW - 1) / kD2WaveW, (dst_h + kUdTileH - 1) / kUdTileH, (u32)n);
+    a.rows = rows_for((dst_w + kD2WaveW - 1) / kD2WaveW);
+    a.map = make_tile_map((dst_w + kD2WaveW - 1) / kD2WaveW, (dst_h + kWavesPerBlock * a.rows - 1) / (kWavesPerBlock * a.rows), (u32)n);
     const dim3 g1 = tile_grid(a.map);
     if (rot == 2) hipLaunchKernelGGL((k_ud_down2<UD_RGB_U8, 2, 1>), g1, block, 0, stream, a);
     else if (kind == UD_YUV444) hipLaunchKernelGGL((k_ud_down2<UD_YUV444, 0, 1>), g1, block, 0, stream, a);
@@ -1547,7 +1566,8 @@ static int launch_ud(UdArgs& a, int src_fmt, int src_w, int dst_w, int dst_h, in
   }
   if (down2_on && !force_gather && src_fmt == VALI_FMT_NV12 && src_w == 2 * dst_w && !(rot & 1) && kind != UD_RGB_F32 &&
       kind != UD_RGB_F32_PLANAR) { // (float outputs are store-bound: 4 pixels per lane fill their stores better)
-    a.map = make_tile_map((dst_w + kD2WaveW - 1) / kD2WaveW, (dst_h + kUdTileH - 1) / kUdTileH, (u32)n);
+    a.rows = rows_for((dst_w + kD2WaveW - 1) / kD2WaveW);
+    a.map = make_tile_map((dst_w + kD2WaveW - 1) / kD2WaveW, (dst_h + kWavesPerBlock * a.rows - 1) / (kWavesPerBlock * a.rows), (u32)n);
     const dim3 g2 = tile_grid(a.map);
 #define VALI_UD_D2(K, R) hipLaunchKernelGGL((k_ud_down2<K, R>), g2, block, 0, stream, a)
     if (rot == 2) VALI_UD_D2(UD_RGB_U8, 2);
