@@ -34,6 +34,7 @@ for (w, h) in ((1920, 1080), (3840, 2160)):
     run("resize bilinear NV12 3x (point)", lambda: vali.PySurfaceResizer(vali.NV12, DEV, interpolation=Li), vali.NV12, vali.NV12, (w, h), (w // 3, h // 3), lambda t, a, b: t.RunAsync(a, b), lambda t, b: t.RunBatchAsync(b))
     run("UD NV12->RGB 2x", lambda: vali.PySurfaceUD(DEV), vali.NV12, vali.RGB, (w, h), (w // 2, h // 2), lambda t, a, b: t.RunAsync(a, b), lambda t, b: t.RunBatchAsync(b))
     run("UD NV12->RGB 1.5x", lambda: vali.PySurfaceUD(DEV), vali.NV12, vali.RGB, (w, h), (w * 2 // 3, h * 2 // 3), lambda t, a, b: t.RunAsync(a, b), lambda t, b: t.RunBatchAsync(b))
+    run("UD 2x + 90 deg in one pass", lambda: vali.PySurfaceUD(DEV), vali.NV12, vali.RGB, (w, h), (h // 2, w // 2), lambda t, a, b: t.RunRotatedAsync(a, b, 90.0), lambda t, b: t.RunRotatedBatchAsync(b, angle=90.0))
     run("rotate RGB 90", lambda: vali.PySurfaceRotator(DEV), vali.RGB, vali.RGB, (w, h), (h, w), lambda t, a, b: t.RunAsync(a, b, 90.0), lambda t, b: t.RunBatchAsync(b, angle=90.0))
     run("rotate RGB 180", lambda: vali.PySurfaceRotator(DEV), vali.RGB, vali.RGB, (w, h), (w, h), lambda t, a, b: t.RunAsync(a, b, 180.0), lambda t, b: t.RunBatchAsync(b, angle=180.0))
     run("preproc NV12->RGB_32F_PLANAR 640x384", lambda: vali.PySurfacePreprocessor(DEV), vali.NV12, vali.RGB_32F_PLANAR, (w, h), (640, 384), lambda t, a, b: t.RunAsync(a, b, cc), lambda t, b: t.RunBatchAsync(b, cc))

@@ -59,6 +59,10 @@ OPS["ud_planar_YUV420_YUV444"] = [(lambda: vali.PySurfaceUD(DEV), vali.YUV420, v
 for out in ("RGB_32F_PLANAR", "RGB"):
     OPS["preproc_" + out] = [(lambda: vali.PySurfacePreprocessor(DEV), vali.NV12, vali.PixelFormat[out], s, d, lambda t, b: t.RunBatchAsync(b, cc))
                              for (s, d) in (((1920, 1080), (1920, 1080)), ((1918, 1078), (1918, 1078)), ((1920, 1080), (640, 384)), ((1918, 1078), (638, 382)))]
+for ang in (270.0,):   # heights that are not multiples of 4 mirror the transposed segments onto odd offsets
+    OPS[f"ud_rot_{int(ang)}"] = [(lambda: vali.PySurfaceUD(DEV), vali.NV12, vali.RGB, s, (d[1], d[0]),
+                                  lambda t, b, ang=ang: t.RunRotatedBatchAsync(b, angle=ang))
+                                 for (s, d) in (((1920, 1080), (960, 540)), ((1920, 1084), (960, 542)), ((1920, 1080), (1280, 718)))]
 for ang in (90.0, 180.0):
     OPS[f"ud_rot_{int(ang)}"] = [(lambda: vali.PySurfaceUD(DEV), vali.NV12, vali.RGB, s, ((d[1], d[0]) if ang == 90.0 else d),
                                   lambda t, b, ang=ang: t.RunRotatedBatchAsync(b, angle=ang))

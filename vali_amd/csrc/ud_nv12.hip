@@ -345,10 +345,10 @@ __device__ __forceinline__ void ud_emit(const SurfRef& d, uint8_t* rot_tile, int
     trunc_pack3x4(c0[3], c1[3], c2[3], c0[2], c1[2], c2[2], c0[1], c1[1], c2[1], c0[0], c1[0], c2[0], w0, w1, w2);
     uint8_t* row = d.p[0] + (u32)((dh - 1 - y) * d.pitch[0]);
     uint8_t* o = row + (ptrdiff_t)(dw - 4 - x0) * 3;
-    if (n == 4 && (((uintptr_t)o) & 3u) == 0) {
+    if (n == 4) { // (any byte alignment: a width that is not a multiple of 4 mirrors the groups onto odd offsets)
       typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
       const v3u32 w = {w0, w1, w2};
-      *(VALI_GLOBAL v3u32*)o = w;
+      gstore_u<v3u32>(o, w);
     } else {
       const u32 ww[3] = {w0, w1, w2};
       for (int p = 0; p < n; ++p) // pixel p sits at bytes 3 (3 - p) .. of the reversed group
@@ -407,10 +407,10 @@ __device__ __forceinline__ void ud_rot_store(const SurfRef& d, const uint8_t* ro
     const int drow = ROT == 1 ? dw - 1 - x : x;
     const int dx0 = ROT == 1 ? yb + 4 * g : dh - 1 - yb - (kUdTileH - 1 - 4 * g);
     uint8_t* o = d.p[0] + (u32)(drow * d.pitch[0]) + (ptrdiff_t)dx0 * 3;
-    if (ok[0] && ok[1] && ok[2] && ok[3] && (((uintptr_t)o) & 3u) == 0) {
+    if (ok[0] && ok[1] && ok[2] && ok[3]) { // (any byte alignment: ROT 3 with a height that is not a multiple of 4)
       typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
       const v3u32 w = {px[0] | (px[1] << 24), (px[1] >> 8) | (px[2] << 16), (px[2] >> 16) | (px[3] << 8)};
-      *(VALI_GLOBAL v3u32*)o = w;
+      gstore_u<v3u32>(o, w);
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
