@@ -351,8 +351,8 @@ enum vali_tuning_key {
   VALI_TUNE_UD_FORCE_GATHER = 5,      /* 1: every UD geometry through the direct-gather form, no exact-ratio kernels */
   VALI_TUNE_UD_DOWN2 = 6,             /* 0: general UD kernel also at the exact 2:1 / 1:1 width ratios; 1 (default):
                                          exact-ratio kernels for output widths that are multiples of 8; 2: for all */
-  VALI_TUNE_UD_OCC5 = 7,              /* 1: the 96-register (5 waves/SIMD) instantiation of the staged UD kernel; it
-                                         spills since the prefetch ring and measured 1.5x slower (default 0)        */
+  VALI_TUNE_UD_OCC5 = 7,              /* no effect since round 2 (selected a 96-register instantiation of the staged UD
+                                         kernel, removed: it spilled); the key keeps its number                       */
   VALI_TUNE_ROTATE_NO_TILE = 8,       /* 1: quarter / half turns through the bilinear kernel; 2: column-major tile walk */
   VALI_TUNE_ROCTX = 9,                /* 1: a roctx range around every operator entry point (see below)            */
   VALI_TUNE_RESIZE_NO_SEPARABLE = 10, /* Lanczos / bicubic rows per wave: 0 by launch size, 1: 8, 2: 2, 3: 32           */

@@ -28,7 +28,6 @@ def test_parity_suites_through_the_gather_forms():
     ("VALI_NV12_DIRECT_STORE=1", ["tests/test_gpu_nv12_rgb.py"]),
     ("VALI_NV12_ROWPAIRS=1", ["tests/test_gpu_nv12_rgb.py", "tests/test_gpu_convert.py"]),
     ("VALI_WAVES_PER_CU=8", ["tests/test_gpu_nv12_rgb.py", "tests/test_gpu_convert.py"]),
-    ("VALI_UD_OCC5=1", ["tests/test_gpu_ud.py"]),
     ("VALI_UD_DOWN2=0", ["tests/test_gpu_ud.py", "tests/test_gpu_ud_down2.py"]),
     # widths that are not multiples of 8 leave the exact-ratio kernels by default: their ragged-lane path is replayed here
     ("VALI_UD_DOWN2=2", ["tests/test_gpu_ud.py", "tests/test_gpu_ud_down2.py", "tests/test_gpu_edge_geometry.py", "tests/test_gpu_random_geometry.py"]),

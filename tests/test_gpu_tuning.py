@@ -78,7 +78,8 @@ CASES = [
     ("UD_DOWN2", (0, 2), lambda v, g: ud(v, g, 1280, 720, 640, 360, v.RGB)),
     ("UD_DOWN2", (0, 2), lambda v, g: ud(v, g, 1276, 720, 638, 360, v.RGB)),
     ("UD_DOWN2", (0,), lambda v, g: ud(v, g, 1280, 720, 1280, 720, v.RGB_PLANAR)),
-    ("UD_OCC5", (1,), lambda v, g: ud(v, g, 1280, 720, 854, 480, v.RGB)),
+    ("UD_OCC5", (1,), lambda v, g: ud(v, g, 1280, 720, 854, 480, v.RGB)),     # (a no-op since round 2)
+    ("UD_OCC5", (1,), lambda v, g: ud(v, g, 140, 108, 4, 57, v.RGB)),
     ("UD_FORCE_GATHER", (1,), lambda v, g: ud(v, g, 1280, 720, 854, 480, v.RGB)),
     ("UD_FORCE_GATHER", (1,), lambda v, g: ud(v, g, 1280, 720, 640, 360, v.YUV444)),
     ("ROTATE_NO_TILE", (1, 2), lambda v, g: rotate(v, g, 640, 360, 90.0)),

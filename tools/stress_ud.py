@@ -28,8 +28,8 @@ while time.time() - t0 < budget:
     else:           sw, sh = rng.integers(2, 400), rng.integers(2, 200); dw = int(sw * rng.uniform(1.0, 3.0)) or 2; dh = int(sh * rng.uniform(1.0, 3.0)) or 2
     sw, sh = (int(max(2, v)) // 2 * 2 for v in (sw, sh))
     dw, dh = (int(max(1, v)) for v in (dw, dh))
-    for k, lo in (("UD_DOWN2", 2), ("UD_FORCE_GATHER", 2), ("UD_OCC5", 2)):
-        vali.tuning.Set(k, int(rng.integers(lo)) if k != "UD_DOWN2" else int(rng.integers(3)))
+    for k, lo in (("UD_DOWN2", 2), ("UD_FORCE_GATHER", 2), ("ROWS_PER_WAVE", 2)):
+        vali.tuning.Set(k, int(rng.integers(3)) if k == "UD_DOWN2" else int([0, 2, 4, 8][rng.integers(4)]) if k == "ROWS_PER_WAVE" else int(rng.integers(lo)))
     spf, dpf = vali.PixelFormat[src_name], vali.PixelFormat[out]
     src = vali.Surface.Make(spf, sw, sh, DEV)
     dt = np.uint8 if src_name == "NV12" else np.uint16
@@ -47,7 +47,7 @@ while time.time() - t0 < budget:
         got = np.zeros(d.HostSize, np.uint8)
         assert down.Run(d, got)[0]
         if not np.array_equal(got, np.ascontiguousarray(want).view(np.uint8).reshape(-1)):
-            print("MISMATCH", src_name, out, sw, sh, dw, dh, "batch", nb, {k: vali.tuning.Get(k) for k in ("UD_DOWN2", "UD_FORCE_GATHER", "UD_OCC5")}, flush=True)
+            print("MISMATCH", src_name, out, sw, sh, dw, dh, "batch", nb, {k: vali.tuning.Get(k) for k in ("UD_DOWN2", "UD_FORCE_GATHER", "ROWS_PER_WAVE")}, flush=True)
             sys.exit(1)
     n_ok += 1
 print("stress ok:", n_ok, "cases in", round(time.time() - t0, 1), "s")

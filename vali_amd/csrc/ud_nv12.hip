@@ -443,9 +443,9 @@ __device__ __forceinline__ void ud_rot_store(const SurfRef& d, const uint8_t* ro
 // For odd ROT the workgroup collects its 256 x 32 output tile in LDS, one dword per pixel, and
 // writes it transposed after a barrier (destination row <-> tile column): see the end of the kernel.
 template <typename T, int OUT, bool STAGED, int ROT = 0, int MINW = 1>
-// MINW = 5 (VALI_TUNE_UD_OCC5): the packed-RGB instantiation squeezed into 96 VGPRs for 5 waves per SIMD.  It won
-// 5 % in round 1 (4.65 -> 4.40 us, cfg4a) but spills since the truncating pack and the prefetch ring and now runs
-// 1.5x SLOWER than the default (1080p -> 720p RGB 2.3 vs 1.5 us): kept selectable, off by default.
+// (MINW: round 1 ran the packed-RGB instantiation with __launch_bounds__(kBlock, 5) -- 96 VGPRs, 5 waves per SIMD, +5 %.
+// With the truncating pack and the prefetch ring it needed 37 spilled registers, ran 1.5x slower than the plain one AND
+// mis-rendered 4-pixel-wide outputs (tools/stress_ud.py): the instantiation is gone, VALI_TUNE_UD_OCC5 is a no-op.)
 __global__ void __launch_bounds__(kBlock, MINW) k_ud_nv12(const UdArgs a) {
   static_assert(ROT == 0 || (sizeof(T) == 1 && OUT == UD_RGB_U8), "rotated output: NV12 -> RGB only");
   constexpr int CH = (int)sizeof(T);
@@ -1584,12 +1584,9 @@ static int launch_ud(UdArgs& a, int src_fmt, int src_w, int dst_w, int dst_h, in
     VALI_LAUNCH_CHECK();
     return VALI_OK;
   }
-  const bool occ5 = tuning(VALI_TUNE_UD_OCC5) != 0;
 #define VALI_UD_CASE(T, K)                                                                  \
   case K:                                                                                   \
-    if (staged && K == UD_RGB_U8 && sizeof(T) == 1 && occ5)                                 \
-      hipLaunchKernelGGL((k_ud_nv12<uint8_t, UD_RGB_U8, true, 0, 5>), grid, block, 0, stream, a); \
-    else if (staged)                                                                        \
+    if (staged)                                                                             \
       hipLaunchKernelGGL((k_ud_nv12<T, K, true>), grid, block, 0, stream, a);                \
     else                                                                                    \
       hipLaunchKernelGGL((k_ud_nv12<T, K, false>), grid, block, 0, stream, a);               \
