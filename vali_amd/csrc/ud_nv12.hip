@@ -1087,7 +1087,7 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
   // consecutive bytes per lane (24-byte lane groups would fill half of every instruction).
   constexpr bool kPacked = OUT == UD_RGB_U8;
   __shared__ __attribute__((aligned(16))) uint8_t strip[kPacked ? kWavesPerBlock : 1][kPacked ? kD2WaveW * 3 : 16];
-  auto emit_planar = [&](int y, const float (&c0)[8], const float (&c1)[8], const float (&c2)[8]) {
+  auto emit_planar = [&](int y, int xo, const float (&c0)[8], const float (&c1)[8], const float (&c2)[8]) {
     const int pp[3] = {d.pitch[0], OUT == UD_YUV444 ? d.pitch[1] : d.pitch[0], OUT == UD_YUV444 ? d.pitch[2] : d.pitch[0]};
     // the six dwords of the three planes (lo / hi halves of the lane's 8 pixels)
     u32 planes_w[6];
@@ -1095,24 +1095,19 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
     trunc_pack3x4(c1[4], c1[5], c1[6], c1[7], c2[0], c2[1], c2[2], c2[3], c2[4], c2[5], c2[6], c2[7], planes_w[3], planes_w[4], planes_w[5]);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      uint8_t* o = d.p[k] + (u32)(y * pp[k]) + x0;
+      uint8_t* o = d.p[k] + (u32)(y * pp[k]) + xo;
       const u32 lo = planes_w[2 * k], hi = planes_w[2 * k + 1];
-      if ((((uintptr_t)o) & 7u) == 0) {
+      if ((((uintptr_t)o) & 7u) == 0)
         UD_ST8(o, make_uint2(lo, hi));
-      } else if ((((uintptr_t)o) & 3u) == 0) {
-        gstore<u32>(o, lo);
-        gstore<u32>(o + 4, hi);
-      } else {
-        for (int b = 0; b < 4; ++b) {
-          gstore<uint8_t>(o + b, (uint8_t)(lo >> (8 * b)));
-          gstore<uint8_t>(o + 4 + b, (uint8_t)(hi >> (8 * b)));
-        }
-      }
+      else // the slid last lane of a ragged row, foreign pitches: the same 8 bytes at any alignment
+        gstore_u<v2u32>(o, (v2u32){lo, hi});
     }
   };
   // packed RGB, step 1 (lanes with 8 valid pixels): the lane's 24 bytes into the wave's strip, in
   // memory order: pixels 0..7 (ROT 0) or 7..0 from the far end (ROT 2: the row reversed)
-  auto strip_put = [&](const float (&c0)[8], const float (&c1)[8], const float (&c2)[8]) {
+  // (`direct` != nullptr: the slid last lane of a ragged row -- its 24 bytes go straight to memory, they are not on the
+  // strip's 24-byte lane grid)
+  auto strip_put = [&](const float (&c0)[8], const float (&c1)[8], const float (&c2)[8], uint8_t* direct) {
     auto px = [&](int j) { return ROT == 2 ? 7 - j : j; };
     u32 w[6];
 #pragma unroll
@@ -1120,6 +1115,12 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
       const int a0 = px(4 * g), a1 = px(4 * g + 1), a2 = px(4 * g + 2), a3 = px(4 * g + 3);
       trunc_pack3x4(c0[a0], c1[a0], c2[a0], c0[a1], c1[a1], c2[a1], c0[a2], c1[a2], c2[a2], c0[a3], c1[a3], c2[a3],
                     w[3 * g + 0], w[3 * g + 1], w[3 * g + 2]);
+    }
+    if (direct) {
+      gstore_u<v2u32>(direct, (v2u32){w[0], w[1]});
+      gstore_u<v2u32>(direct + 8, (v2u32){w[2], w[3]});
+      gstore_u<v2u32>(direct + 16, (v2u32){w[4], w[5]});
+      return;
     }
     uint8_t* st = strip[kPacked ? wave : 0];
     const int so = ROT == 2 ? (kD2WaveW - kD2LanePx) * 3 - 24 * lane : 24 * lane;
@@ -1192,10 +1193,18 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
   // next row's loads in flight while this row is computed
   struct Rows {
     uint4 v[4]; // the lane's 16 bytes of luma i0, luma i1, chroma i0, chroma i1
-    u32 before; // lane k < 4: the dword before the WAVE's first byte in row k
+    u32 before; // lane k < 4: the dword before the WAVE's first byte in row k; lane 4 + k: before the SLID lane's
   };
-  const int off16 = min(RATIO * x0, (sw - kLaneBytes) & ~(kLaneBytes - 1));
-  const int offw = max(RATIO * xw - 4, 0);
+  // Ragged widths (dw % 8 != 0, un-rotated output): the row's last lane has n < 8 pixels.  Instead of sending it down the
+  // byte-gather path (the whole wave waits for it: 2.1 us instead of 0.9 at 958x538) its window SLIDES left to end with
+  // the row -- pixels dw-8 .. dw-1, a full group again, from a misaligned 16-byte load; the pixels it shares with its
+  // neighbour are computed and stored twice with identical bytes.  Its "byte before" cannot come from the neighbour's
+  // registers: lanes 4..7 fetch it with the load that lanes 0..3 use for the wave's own first column.
+  const bool slid = ROT == 0 && n > 0 && n < kD2LanePx && dw >= kD2LanePx;
+  const int xs = slid ? dw - kD2LanePx : x0;                 // first column of the lane's window
+  const int xs_w = dw - kD2LanePx;                           // ... of the slid lane, wave-uniform (used only when one exists)
+  const int off16 = slid ? RATIO * xs : min(RATIO * x0, (sw - kLaneBytes) & ~(kLaneBytes - 1));
+  const int offw = (lane & 4) ? max(RATIO * xs_w - 4, 0) : max(RATIO * xw - 4, 0);
   auto issue = [&](const RowTaps& rt) {
     Rows r;
     const uint8_t* row[4] = {py + (u32)(rt.ty.i0 * sp_y), py + (u32)(rt.ty.i1 * sp_y),
@@ -1203,14 +1212,16 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if constexpr (RATIO == 2) {
-        r.v[k] = gload16(row[k] + (u32)off16);
+        const v4u32 w = gload_u<v4u32>(row[k] + (u32)off16); // (16-byte aligned but for the slid lane)
+        r.v[k] = make_uint4(w.x, w.y, w.z, w.w);
       } else {
-        const uint2 w = load8(row[k] + (u32)off16);
+        const v2u32 w = gload_u<v2u32>(row[k] + (u32)off16);
         r.v[k] = make_uint4(w.x, w.y, 0u, 0u);
       }
     }
-    const uint8_t* rb = lane == 0 ? row[0] : lane == 1 ? row[1] : lane == 2 ? row[2] : row[3];
-    r.before = gload<u32>(rb + (u32)offw);
+    const int lk = lane & 3;
+    const uint8_t* rb = lk == 0 ? row[0] : lk == 1 ? row[1] : lk == 2 ? row[2] : row[3];
+    r.before = gload_u<u32>(rb + (u32)offw);
     return r;
   };
   const int last = min(rpw - 1, dh - 1 - y_first); // last valid row of the wave
@@ -1229,11 +1240,13 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
     // (broadcast BEFORE the divergent branch below: inside it only the lanes with 8 pixels run, and
     // a load whose only reader sits there may be sunk into it -- lanes 1..3 of a wave whose lane 0
     // alone is full would then never fetch their dword)
-    u32 before[4];
+    u32 before[4], before_s[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < 4; ++k) {
       before[k] = (u32)__builtin_amdgcn_readlane((int)rows.before, k);
-    if (n == kD2LanePx && vec) {
+      before_s[k] = (u32)__builtin_amdgcn_readlane((int)rows.before, 4 + k);
+    }
+    if ((n == kD2LanePx || slid) && vec) {
       // the 4 bytes before the lane's own: the previous lane's last dword; lane 0 takes the
       // wave's extra load, or the clamp (column -1 = column 0) at the left edge of the image
       u32 prev[4];
@@ -1241,8 +1254,9 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
       for (int k = 0; k < 4; ++k) {
         const u32 edge = k < 2 ? rows.v[k].x << 24 : rows.v[k].x << 16;
         const u32 first = xw == 0 ? edge : before[k];
+        const u32 first_s = xs_w == 0 ? edge : before_s[k];
         const u32 sh1 = wave_shr1(RATIO == 2 ? rows.v[k].w : rows.v[k].y);
-        prev[k] = lane == 0 ? first : sh1;
+        prev[k] = slid ? first_s : lane == 0 ? first : sh1;
       }
       float c0[8], c1[8], c2[8];
       const bool even = cur.ty.w0 == 128u && cur.tcy.w0 == 128u; // (w1 = 256 - w0) wave-uniform
@@ -1270,10 +1284,10 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
           d1_compute<OUT, false>(cur, o, c0, c1, c2);
       }
       if constexpr (kPacked)
-        strip_put(c0, c1, c2);
+        strip_put(c0, c1, c2, slid ? d.p[0] + (u32)(y * d.pitch[0]) + (size_t)xs * 3 : nullptr);
       else
-        emit_planar(y, c0, c1, c2);
-    } else if (n > 0) { // the one tail lane of a ragged row (or a destination row that is not 16-byte aligned)
+        emit_planar(y, xs, c0, c1, c2);
+    } else if (n > 0) { // frames narrower than one group, and the tail lane of a ragged HALF-TURNED row
       slow_lane(cur, y);
     }
     if constexpr (kPacked) {
@@ -1546,12 +1560,12 @@ static int launch_ud(UdArgs& a, int src_fmt, int src_w, int dst_w, int dst_h, in
     staged = false;
   // exact 2x horizontal downscale of NV12: the division-free, LDS-free kernel (VALI_UD_DOWN2=0
   // keeps the general one, for A/B measurements)
-  // The exact-ratio kernels own 8 output pixels per lane; a width that is not a multiple of 8 leaves one lane per row
-  // on their byte-gather path, and the whole wave waits for it: 1916x1076 -> 958x538 2.13 us against 0.89 for 960x540 and
-  // 1.12 through the general kernel; 1918x1078 at 1:1 4.75 / 2.16 / 3.31 (tools/cliffs.py).  Such widths therefore go
-  // to the general kernel; VALI_TUNE_UD_DOWN2 = 2 keeps them here (A/B, and the tests of that path).
+  // The exact-ratio kernels own 8 output pixels per lane.  Un-rotated, a width that is not a multiple of 8 slides its
+  // last lane left (k_ud_down2: `slid`); the turned forms have no such lane and would leave it on their byte-gather path
+  // with the whole wave waiting (1916x1076 -> 958x538 half-turned: 2.4 us against 1.1 through the general kernel), so
+  // those geometries go to the general kernel.  VALI_TUNE_UD_DOWN2 = 2 keeps them here (A/B, tests of that path).
   const int down2_mode = tuning(VALI_TUNE_UD_DOWN2);
-  const bool down2_on = down2_mode != 0 && (down2_mode == 2 || dst_w % kD2LanePx == 0);
+  const bool down2_on = down2_mode != 0 && (down2_mode == 2 || dst_w % kD2LanePx == 0 || (rot == 0 && dst_w >= kD2LanePx));
   if (down2_on && !force_gather && src_fmt == VALI_FMT_NV12 && src_w == dst_w && !(rot & 1) && kind != UD_RGB_F32 &&
       kind != UD_RGB_F32_PLANAR) { // 1:1 width: colour conversion with chroma interpolation
     a.rows = rows_for((dst_w + kD2WaveW - 1) / kD2WaveW);
