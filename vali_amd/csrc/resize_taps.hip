@@ -461,13 +461,16 @@ int launch_resize_taps(const ResizeArgs& base, int elem, int taps, int src_w, in
     }
     return total;
   };
+  // (8-row waves from 320 workgroups on, re-measured with the prefetch really 4 rows deep: ONE NV12 2160p -> 1088p frame
+  // = 352 such workgroups 15.0 us against 17.4 through 2-row waves, two Y frames 17.6 against 21.3; one Y frame = 280
+  // workgroups stays on 2-row waves, 13.6 against 14.7)
   // rows per wave: 32 when the launch still fills the chip 4 times over (batches), 2 when 8-row waves would
   // leave SIMDs idle -- a lone wave is bound by its own instruction latency, so a single frame is cut into many
   // short waves, at the price of filtering more rows twice
   const unsigned long long t32 = (unsigned long long)count(32, false) * (unsigned)n, t8 = (unsigned long long)count(8, false) * (unsigned)n;
   // (float planes: 8-row waves measured 4 % faster than 32-row ones on batches -- RGB_32F 2160p -> 1080p 22.0 vs 23.0 us --
   // their rows are 4x the bytes, so the 5 rows two neighbouring tiles both filter weigh less than the longer tail)
-  const int rows = force == 1 ? 8 : force == 2 ? 2 : force == 3 ? 32 : (t32 >= 1024ull && elem < 4) ? 32 : t8 >= 768ull ? 8 : 2;
+  const int rows = force == 1 ? 8 : force == 2 ? 2 : force == 3 ? 32 : (t32 >= 1024ull && elem < 4) ? 32 : t8 >= 320ull ? 8 : 2;
   a.map = make_tile_map_linear(count(rows, true), (u32)n);
   a.force_gather = gather_only ? 1 : 0;
   a.stage_bytes = (span + kLzPadL + kLzPadR <= kLzStageCap && !gather_only) ? ((span + 15) & ~15) + kLzPadL + kLzPadR : 0;
