@@ -27,6 +27,7 @@ while time.time() - t0 < budget:
     if even: sw, sh, dw, dh = (v // 2 * 2 for v in (sw, sh, dw, dh))
     interp, iname = [(vali.Interpolation.LANCZOS, "lanczos"), (vali.Interpolation.CUBIC, "cubic"), (vali.Interpolation.LINEAR, "linear")][rng.integers(3)]
     vali.tuning.Set("RESIZE_NO_SEPARABLE", int(rng.integers(4)))
+    vali.tuning.Set("ROWS_PER_WAVE", int([0, 2, 4, 8][rng.integers(4)]))   # bilinear / point forms
     pf = vali.PixelFormat[name]
     src = vali.Surface.Make(pf, sw, sh, DEV)
     nel = src.HostSize // np.dtype(dt).itemsize
@@ -43,7 +44,7 @@ while time.time() - t0 < budget:
         out = np.zeros(d.HostSize, np.uint8)
         assert down.Run(d, out)[0]
         if not np.array_equal(out, want.view(np.uint8).reshape(-1)):
-            print("MISMATCH", name, sw, sh, dw, dh, iname, "rows-mode", vali.tuning.Get("RESIZE_NO_SEPARABLE"), "batch", nb, flush=True)
+            print("MISMATCH", name, sw, sh, dw, dh, iname, "rows-mode", vali.tuning.Get("RESIZE_NO_SEPARABLE"), vali.tuning.Get("ROWS_PER_WAVE"), "batch", nb, flush=True)
             sys.exit(1)
     n_ok += 1
 print("stress ok:", n_ok, "cases in", round(time.time() - t0, 1), "s")
