@@ -554,7 +554,23 @@ static int launch_resize(ResizeArgs& a, int fmt, int src_w, int src_h, int dst_w
     if (elem == 1) VALI_RS_LAUNCH(k_resize_point, uint8_t);
     else VALI_RS_LAUNCH(k_resize_point, uint16_t);
   } else if (filtered) { // Lanczos-3 / bicubic at a non-integer ratio: resize_taps.hip
-    return launch_resize_taps(a, elem, interp == VALI_INTERP_LANCZOS ? 6 : 4, src_w, src_h, dst_w, dst_h, n, stream);
+    // planes that shrink vertically are filtered columns first, the others rows first (the specification's rule:
+    // oracle/vali_oracle.c resize_plane_taps); a surface whose planes differ (YUV420 -> YUV444 through UDPlanar: luma
+    // shrinks, chroma grows) takes one launch per order
+    const int taps = interp == VALI_INTERP_LANCZOS ? 6 : 4;
+    ResizeArgs cols = a, rows = a;
+    cols.njobs = rows.njobs = 0;
+    for (int k = 0; k < a.njobs; ++k) {
+      const bool shrinks = (src_h >> a.job[k].ssub_y) >= (dst_h >> a.job[k].sub_y);
+      ResizeArgs& t = shrinks ? cols : rows;
+      t.job[t.njobs++] = a.job[k];
+    }
+    int rc = VALI_OK;
+    if (cols.njobs)
+      rc = launch_resize_cols(cols, elem, taps, src_w, src_h, dst_w, dst_h, n, stream);
+    if (rc == VALI_OK && rows.njobs)
+      rc = launch_resize_taps(rows, elem, taps, src_w, src_h, dst_w, dst_h, n, stream);
+    return rc;
   } else {
     if (elem == 1) VALI_RS_LAUNCH(k_resize, uint8_t);
     else if (elem == 2) VALI_RS_LAUNCH(k_resize, uint16_t);

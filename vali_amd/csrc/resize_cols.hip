@@ -1,0 +1,534 @@
+// Lanczos-3 / bicubic resize of planes that SHRINK vertically (src_h >= dst_h): columns first.
+//
+// The reference's only resize filter is Lanczos (src/TC/src/TaskResizeSurface.cpp:67,116,224,273; UDPlanar
+// src/TC/src/UDSurface.cpp:45,72); its dominant use is the downscale in front of an encoder or a network.  The
+// rows-first kernel (resize_taps.hip) filtered every SOURCE row along x -- at 2:1 that is 2.16 gathered, converted and
+// filtered samples per output sample, 44 lane-instructions per output, FP32-VALU-bound at 0.37 of the HBM roofline
+// (profiles/r02_lanczos.md).  Columns first (specification: oracle/vali_oracle.c resize_plane_taps, the src_h >= dst_h
+// branch) turns the expensive half into streaming work:
+//
+//   vertical pass   a lane owns 8 ADJACENT source elements (one 8 / 16 / 32-byte load per source row straight from
+//                   global memory, no staging) and walks the source rows of its tile ONCE, top to bottom.  Every element is
+//                   converted to float once and SCATTERED: each of the <= P dst rows whose window contains this source row
+//                   has an accumulator (P x 8 registers) and takes fma(w, f, acc) with a WAVE-UNIFORM weight -- a
+//                   scalar operand, no per-lane tap fetch.  P = ceil(TAPS / scale_y) slots; dst row rr lives in slot
+//                   rr mod P (the slot is free again before row rr + P starts because floor((rr + P) s) - floor(rr s) >=
+//                   TAPS).  The weights of all rows of the tile are computed once (lane r = row r), transposed through
+//                   LDS into one register per slot (lane 8 m + k = tap k of the slot's m-th row) and fetched with
+//                   v_readlane at a scalar lane index.
+//   horizontal pass when a dst row's window is complete its accumulators go to a float strip in LDS (channels of
+//                   interleaved planes de-interleaved into segments, so every plane is the 1-channel problem) and the
+//                   wave filters along x: lane l takes elements l, l + 64, l + 128, l + 192 of the tile (neighbouring
+//                   lanes read neighbouring 8-byte slots: conflict free at 2:1), reads its taps as ALIGNED float pairs
+//                   (ds_read_b64; a window that starts on an odd float starts one earlier with weight 0: the even / odd
+//                   accumulators of the specification swap halves and h = e + o is commutative), 4 packed FMAs, one add;
+//                   the results are transposed through 1 KiB of LDS so a lane stores 4 adjacent elements.
+//
+// Per output sample at 2:1: 4 conversions + 6 packed FMAs (vertical) + 4 packed FMAs + 1 add (horizontal) + the
+// quantiser, against 13 conversions + 2.16 x (funnel shifts + 3 packed FMAs) + 3 before.  Planes that grow
+// vertically stay on resize_taps.hip (rows first: there the row pass is the smaller half).
+#include "resize_common.hpp"
+#include "resize_weights.hpp"
+
+#include <type_traits>
+
+namespace vali {
+
+constexpr int kColEl = 8;                    // source elements per lane and row
+constexpr int kColSpan = kWave * kColEl;     // 512 source elements per tile row
+constexpr int kColPadL = 4, kColPadR = 6;    // replicas of the first / last pixel (even: the pairs stay aligned)
+constexpr int kColStrip = 576;               // floats of a wave's strip: ES segments, pads included
+constexpr int kColLds = kColStrip + 256;     // + the output transposition
+constexpr int kColProgRows = 56;             // source rows a wave may walk: its program is one lane per row, D rows of slack
+
+// segment stride (floats) of the de-interleaved strip: even, and chosen so that the ES channels of one pixel -- read by
+// neighbouring lanes -- sit in different banks (ds_read_b64: 64 banks)
+template <int ES> constexpr int kColSeg = ES == 1 ? 0 : ES == 2 ? 288 : 184;
+
+typedef u32 u32_u __attribute__((aligned(1)));
+
+template <typename T, int ES, int TAPS, int P>
+__device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw, int sh, uint8_t* dp, int dpitch,
+                                          int dw, int dh, u32 tx, u32 ty, int N, int rps, float* strip, float* obuf) {
+  constexpr int kBefore = LzTap<TAPS>::kBefore;
+  constexpr int EB = (int)sizeof(T);
+  constexpr int ND = 2 * EB;                                    // dwords of a lane's 8 elements
+  constexpr int D = EB == 4 ? 2 : 4;                            // source rows in flight
+  constexpr int NP = EB == 4 ? TAPS / 2 : TAPS / 2 + 1;         // float pairs of a horizontal window
+  constexpr int SEG = kColSeg<ES>;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const u32 lds_base = (u32)(uintptr_t)(__attribute__((address_space(3))) float*)strip; // LDS byte address of the strip
+  const int rows = P * rps;                                     // dst rows of this wave, <= 8 P <= 64
+  const int y_first = (int)(ty * kWavesPerBlock + wave) * rows; // wave-uniform
+  if (y_first >= dh)
+    return;
+  const int last_rr = min(rows, dh - y_first) - 1;
+  const int dwe = dw * ES, row_el = sw * ES;
+  const int e0 = (int)tx * N, e_last = min(e0 + N, dwe) - 1;
+  const float scale_x = (float)sw / (float)dw, scale_y = (float)sh / (float)dh;
+
+  // ---- row taps: lane r evaluates row y_first + r; the weights go through LDS into one register per slot ----
+  const LzTap<TAPS> vy = make_lz_tap<TAPS>(y_first + min(lane, rows - 1), scale_y);
+  if (lane < rows) {
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k)
+      strip[lane * 8 + k] = vy.w[k];
+  }
+  wave_lds_sync();
+  float ws[P]; // lane 8 m + k: tap k of dst row m P + j
+#pragma unroll
+  for (int j = 0; j < P; ++j)
+    ws[j] = (lane & 7) < TAPS ? strip[((lane >> 3) * P + j) * 8 + (lane & 7)] : 0.0f;
+  wave_lds_sync();
+
+  // ---- the tile's source span along x (wave-uniform), one element more on either side than the taps need: a window
+  // that starts on an odd float is read from the even float in front of it ----
+  const int px_first = e0 / ES, px_last = e_last / ES;
+  const int ux0 = (int)__builtin_floorf((float)px_first * scale_x) - kBefore - 1;
+  const int ux1 = (int)__builtin_floorf((float)px_last * scale_x) + TAPS + 1 - kBefore;
+  const int sx0 = clampi(ux0, sw - 1), sx1 = clampi(ux1, sw - 1);
+  const int j_begin = (sx0 * ES) & ~(kColEl - 1);               // first element the wave loads
+  const int px_begin = j_begin / ES;
+  const int nl = min((((sx1 + 1) * ES - j_begin) + kColEl - 1) / kColEl, kWave); // lanes with data
+  // the last chunk of a row slides left to END with the row: no byte outside the row is ever read (borrowed surfaces
+  // end where their last row ends); the elements it shares with its neighbour are written twice with the same value
+  const bool ragged = j_begin + kColEl * nl > row_el;           // wave-uniform: only a row's last tile
+  const int j0 = min(j_begin + kColEl * min(lane, nl - 1), row_el - kColEl);
+  const bool has = lane < nl;
+  const u32 lane_off = (u32)(j0 * EB);
+
+  // strip positions of this lane's 8 elements
+  int wpos[ES == 3 ? kColEl : 2];
+  if constexpr (ES == 3) {
+#pragma unroll
+    for (int q = 0; q < kColEl; ++q) {
+      const int j = j0 + q, px = j / 3;
+      wpos[q] = (j - px * 3) * SEG + kColPadL + px - px_begin;
+    }
+  } else if constexpr (ES == 2) {
+    wpos[0] = kColPadL + (j0 >> 1) - px_begin; // j0 is even: (U, V) pairs
+    wpos[1] = SEG + wpos[0];
+  } else {
+    wpos[0] = kColPadL + j0 - px_begin;
+    wpos[1] = 0;
+  }
+
+  // ---- horizontal pass set-up: this lane's 4 elements, their window start and (even, odd) weight pairs ----
+  v2f32 wq[4][NP];
+  int ho[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int e = min(e0 + p * kWave + lane, e_last);
+    const int px = e / ES, ch = e - px * ES;
+    const LzTap<TAPS> c = make_lz_tap<TAPS>(px, scale_x);
+    const int o = kColPadL + (min(c.i, sw - 1) - kBefore - px_begin); // >= kColPadL - kBefore
+    if constexpr (EB == 4) { // float planes: exactly the TAPS taps (a zero weight on a non-finite neighbour is not a no-op)
+      ho[p] = ch * SEG + o;
+#pragma unroll
+      for (int j = 0; j < NP; ++j)
+        wq[p][j] = (v2f32){c.w[2 * j], c.w[2 * j + 1]};
+    } else {
+      const bool odd = (o & 1) != 0;
+      ho[p] = ch * SEG + (o & ~1);
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        // even start: (w0,w1) (w2,w3) .. (0,0) ; odd start: (0,w0) (w1,w2) .. (w_last,0)
+        const float a0 = 2 * j < TAPS ? c.w[2 * j < TAPS ? 2 * j : 0] : 0.0f;
+        const float a1 = 2 * j + 1 < TAPS ? c.w[2 * j + 1 < TAPS ? 2 * j + 1 : 0] : 0.0f;
+        const float b0 = j > 0 ? c.w[j > 0 ? 2 * j - 1 : 0] : 0.0f;
+        const float b1 = 2 * j < TAPS ? c.w[2 * j < TAPS ? 2 * j : 0] : 0.0f;
+        wq[p][j] = odd ? (v2f32){b0, b1} : (v2f32){a0, a1};
+      }
+    }
+  }
+  const bool pad_left = ux0 < 0, pad_right = ux1 > sw - 1;                 // wave-uniform
+  const int edge = kColPadL + (sw - 1) - px_begin;                         // the last pixel of the row
+  const int eb = e0 + 4 * lane;                                            // store: 4 adjacent elements
+  const int n_out = min(4, e_last + 1 - eb);
+
+  // ---- the wave's program: what every source row it walks does, as data instead of control flow ----
+  // Byte j of row t's word = the lane of ws[j] that holds the weight slot j applies to this row (lane 8 m + 7 holds 0.0:
+  // the slot has no use for the row -- a zero weight is an exact no-op on an accumulator that is never -0, for the finite
+  // values integer planes have; float planes skip the slot instead), bit 7 of the byte = this row completes the slot's
+  // window.  Written by the lanes that own the dst rows (lane r: 6 bytes), read back one word per lane; a second register
+  // holds the rows' byte offsets.  The walk then costs one v_readlane + s_bfe per slot and row instead of the dozen scalar
+  // compares, branches and counters of the control-flow form (the kernel was bound by its total instruction issue).
+  const int s_begin = __builtin_amdgcn_readlane(vy.i, 0) - kBefore;
+  const int ns = __builtin_amdgcn_readlane(vy.i, last_rr) + TAPS - kBefore - s_begin; // source rows, <= kColProgRows (host)
+  uint8_t* const prog = reinterpret_cast<uint8_t*>(strip);
+  reinterpret_cast<uint2*>(prog)[lane] = make_uint2(0x07070707u, 0x00000707u);
+  wave_lds_sync();
+  if (lane <= last_rr) {
+    const int j = lane % P, m = lane / P;
+    const int t0 = vy.i - kBefore - s_begin;
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k)
+      prog[(t0 + k) * 8 + j] = (uint8_t)(m * 8 + k + (k == TAPS - 1 ? 0x80 : 0));
+  }
+  wave_lds_sync();
+  const uint2 pw = reinterpret_cast<const uint2*>(prog)[lane];
+  const u32 roff = (u32)(clampi(s_begin + lane, sh - 1) * spitch); // lane t: byte offset of the wave's t-th source row
+  wave_lds_sync();
+
+  v2f32 acc[P][4];
+#pragma unroll
+  for (int j = 0; j < P; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      acc[j][i] = (v2f32){0.0f, 0.0f};
+
+  u32 pf[D][ND];
+  auto issue = [&](int t, u32 (&q)[ND]) { // t < 64 (host: ns <= kColProgRows, rounded up to D, + D)
+    const uint8_t* p = sp + (u32)__builtin_amdgcn_readlane((int)roff, t);
+    if constexpr (ND == 2) {
+      const v2u32 w = gload_u<v2u32>(p + lane_off);
+      q[0] = w.x; q[1] = w.y;
+    } else {
+#pragma unroll
+      for (int c = 0; c < ND / 4; ++c) {
+        const v4u32 w = gload_u<v4u32>(p + lane_off + 16 * c);
+        q[4 * c] = w.x; q[4 * c + 1] = w.y; q[4 * c + 2] = w.z; q[4 * c + 3] = w.w;
+      }
+    }
+  };
+  // (scheduling barriers: vmcnt retires in order, the rows must be ISSUED in order -- DESIGN.md 5d)
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    issue(j, pf[j]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  int emit_rr = 0, eslot = 0; // the next dst row to complete and its slot: rows complete in order, slots in turn
+#pragma unroll 1
+  for (int t0 = 0; t0 < ns; t0 += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int t = t0 + d;
+      v2f32 f[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (EB == 1)
+          f[i] = (v2f32){(float)((pf[d][i / 2] >> (16 * (i % 2))) & 0xffu), (float)((pf[d][i / 2] >> (16 * (i % 2) + 8)) & 0xffu)};
+        else if constexpr (EB == 2)
+          f[i] = (v2f32){(float)(pf[d][i] & 0xffffu), (float)(pf[d][i] >> 16)};
+        else
+          f[i] = (v2f32){__uint_as_float(pf[d][2 * i]), __uint_as_float(pf[d][2 * i + 1])};
+      }
+      issue(t + D, pf[d]);
+      if (t >= ns) // the last trip only: rows past the end are loaded (the issue order stays countable), not used
+        continue;
+      const u32 w_lo = (u32)__builtin_amdgcn_readlane((int)pw.x, t);
+      const u32 w_hi = P > 4 ? (u32)__builtin_amdgcn_readlane((int)pw.y, t) : 0u;
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        const u32 code = ((j < 4 ? w_lo : w_hi) >> (8 * (j & 3))) & 0x3fu; // wave-uniform
+        if constexpr (EB == 4) {
+          if ((code & 7u) == 7u)
+            continue;
+        }
+        const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ws[j]), (int)code));
+        const v2f32 wv = (v2f32){w, w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[j][i] = __builtin_elementwise_fma(wv, f[i], acc[j][i]);
+      }
+      const bool emit = ((w_lo & 0x80808080u) | (w_hi & 0x8080u)) != 0u; // at most one dst row per source row (scale_y >= 1)
+      if (emit) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+          if (eslot == j) { // the window of dst row emit_rr is complete: its columns go to the strip
+            if (has) {
+              if constexpr (ES == 3) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  strip[wpos[2 * i]] = acc[j][i].x;
+                  strip[wpos[2 * i + 1]] = acc[j][i].y;
+                }
+              } else if (ragged) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  if constexpr (ES == 2) {
+                    strip[wpos[0] + i] = acc[j][i].x;
+                    strip[wpos[1] + i] = acc[j][i].y;
+                  } else {
+                    strip[wpos[0] + 2 * i] = acc[j][i].x;
+                    strip[wpos[0] + 2 * i + 1] = acc[j][i].y;
+                  }
+                }
+              } else if constexpr (ES == 2) {
+                *reinterpret_cast<float4*>(strip + wpos[0]) = make_float4(acc[j][0].x, acc[j][1].x, acc[j][2].x, acc[j][3].x);
+                *reinterpret_cast<float4*>(strip + wpos[1]) = make_float4(acc[j][0].y, acc[j][1].y, acc[j][2].y, acc[j][3].y);
+              } else {
+                *reinterpret_cast<float4*>(strip + wpos[0]) = make_float4(acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y);
+                *reinterpret_cast<float4*>(strip + wpos[0] + 4) = make_float4(acc[j][2].x, acc[j][2].y, acc[j][3].x, acc[j][3].y);
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              acc[j][i] = (v2f32){0.0f, 0.0f};
+          }
+        }
+        eslot = eslot == P - 1 ? 0 : eslot + 1;
+ // at most one dst row per source row (scale_y >= 1)
+        wave_lds_sync();
+        if (pad_left || pad_right) { // image edges: replicas of the first / last pixel of every channel segment
+          const int ch = lane >> 3, i = lane & 7;
+          if (pad_left && ch < ES && i < kColPadL)
+            strip[ch * SEG + kColPadL - 1 - i] = strip[ch * SEG + kColPadL];
+          if (pad_right && ch < ES && i < kColPadR)
+            strip[ch * SEG + edge + 1 + i] = strip[ch * SEG + edge];
+          wave_lds_sync();
+        }
+        // All four windows are fetched before any arithmetic (one LDS round trip per dst row, not four), every float
+        // pair with its own ds_read_b64: left to itself the compiler fuses two into a ds_read2_b64, which takes twice the
+        // LDS cycles per byte and banks modulo 32 dwords instead of 64 (MI355X_MICROARCH.md, LDS: 56 % LDS-busy with 29 %
+        // of it bank conflicts).  Hence the assembly; the wait names every loaded register, so nothing reads one early.
+        // (two windows per round trip: all four at once need 32 registers, which cost the kernel its fourth wave per SIMD)
+        float hs[4];
+#pragma unroll
+        for (int half = 0; half < 4; half += 2) {
+          v2f32 t[2][NP];
+          if constexpr (EB == 4) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+              for (int jj = 0; jj < NP; ++jj)
+                t[p][jj] = (v2f32){strip[ho[half + p] + 2 * jj], strip[ho[half + p] + 2 * jj + 1]};
+          } else {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+              const u32 la = lds_base + 4u * (u32)ho[half + p];
+              if constexpr (NP == 4)
+                asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24"
+                             : "=&v"(t[p][0]), "=&v"(t[p][1]), "=&v"(t[p][2]), "=&v"(t[p][3]) : "v"(la) : "memory");
+              else
+                asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:8\n\tds_read_b64 %2, %3 offset:16"
+                             : "=&v"(t[p][0]), "=&v"(t[p][1]), "=&v"(t[p][2]) : "v"(la) : "memory");
+            }
+            if constexpr (NP == 4)
+              asm volatile("s_waitcnt lgkmcnt(0)"
+                           : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[0][3]), "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[1][2]), "+v"(t[1][3]));
+            else
+              asm volatile("s_waitcnt lgkmcnt(0)"
+                           : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[1][2]));
+          }
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            v2f32 h = (v2f32){0.0f, 0.0f};
+#pragma unroll
+            for (int jj = 0; jj < NP; ++jj)
+              h = __builtin_elementwise_fma(wq[half + p][jj], t[p][jj], h);
+            hs[half + p] = h.x + h.y;
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          obuf[p * kWave + lane] = hs[p];
+        wave_lds_sync();
+        if (n_out > 0) {
+          const float4 v = *reinterpret_cast<const float4*>(obuf + 4 * lane);
+          const float res[4][1] = {{v.x}, {v.y}, {v.z}, {v.w}};
+          store_px4<T, 1>(dp + (u32)((y_first + emit_rr) * dpitch) + (size_t)eb * EB, res, (1u << n_out) - 1u);
+        }
+        ++emit_rr;
+        wave_lds_sync();
+      }
+    }
+  }
+}
+
+// ESSET as in resize_taps.hip: 1 = one-channel planes, 12 = NV12 / P10 (Y + UV), 3 = packed RGB
+template <typename T, int ESSET, int TAPS, int P>
+__global__ void __launch_bounds__(kBlock) k_resize_cols(const ResizeArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kColLds];
+  ResizeJob job;
+  u32 tx, ty, frame;
+  if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
+    return;
+  const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float* const strip = lds[wave];
+  float* const obuf = strip + kColStrip;
+  if constexpr (ESSET == 3) {
+    cols_tile<T, 3, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_n, a.cols_rps, strip, obuf);
+  } else {
+    if (ESSET == 12 && job.channels == 2)
+      cols_tile<T, 2, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_n, a.cols_rps, strip, obuf);
+    else
+      cols_tile<T, 1, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_n, a.cols_rps, strip, obuf);
+  }
+}
+
+// The same arithmetic one output element per thread, TAPS x TAPS global loads each: planes narrower than one lane's 8
+// elements, scale factors whose tile would be narrower than 8 elements, and -- under VALI_TUNE_RESIZE_FORCE_GATHER --
+// an independent second implementation the parity suites are replayed through (tests/test_gpu_gather_paths.py).
+template <typename T, int TAPS>
+__global__ void __launch_bounds__(kBlock) k_resize_cols_direct(const ResizeArgs a) {
+  constexpr int kBefore = LzTap<TAPS>::kBefore;
+  constexpr int EB = (int)sizeof(T);
+  ResizeJob job;
+  u32 tx, ty, frame;
+  if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
+    return;
+  const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
+  const int es = job.channels;
+  const int e = (int)tx * kBlock + (int)threadIdx.x, y = (int)ty;
+  if (e >= v.dw * es)
+    return;
+  const float scale_x = (float)v.sw / (float)v.dw, scale_y = (float)v.sh / (float)v.dh;
+  const int px = e / es, ch = e - px * es;
+  const LzTap<TAPS> cx = make_lz_tap<TAPS>(px, scale_x), cy = make_lz_tap<TAPS>(y, scale_y);
+  float eo[2] = {0.0f, 0.0f};
+#pragma unroll
+  for (int k = 0; k < TAPS; ++k) {
+    const size_t col = (size_t)(clampi(cx.i - kBefore + k, v.sw - 1) * es + ch) * EB;
+    float c = 0.0f;
+#pragma unroll
+    for (int r = 0; r < TAPS; ++r) {
+      const uint8_t* row = v.sp + (size_t)clampi(cy.i - kBefore + r, v.sh - 1) * v.spitch;
+      c = __builtin_fmaf(cy.w[r], (float)gload<T>(row + col), c);
+    }
+    eo[k & 1] = __builtin_fmaf(cx.w[k], c, eo[k & 1]);
+  }
+  const float res = eo[0] + eo[1];
+  T* out = reinterpret_cast<T*>(v.dp + (size_t)y * v.dpitch) + e;
+  if constexpr (EB == 4)
+    *(VALI_GLOBAL float*)out = res;
+  else
+    *(VALI_GLOBAL T*)out = (T)finish_bits<T>(res);
+}
+
+template <typename T, int ESSET, int TAPS>
+static void launch_slots(const ResizeArgs& a, int slots, dim3 grid, hipStream_t stream) {
+  constexpr int P0 = TAPS == 6 ? 3 : 2, P1 = TAPS == 6 ? 4 : 3, P2 = TAPS == 6 ? 6 : 4;
+  if (slots <= P0)
+    hipLaunchKernelGGL((k_resize_cols<T, ESSET, TAPS, P0>), grid, dim3(kBlock), 0, stream, a);
+  else if (slots <= P1)
+    hipLaunchKernelGGL((k_resize_cols<T, ESSET, TAPS, P1>), grid, dim3(kBlock), 0, stream, a);
+  else
+    hipLaunchKernelGGL((k_resize_cols<T, ESSET, TAPS, P2>), grid, dim3(kBlock), 0, stream, a);
+}
+
+// Every job of `base` shrinks (or keeps) its plane height.  Returns VALI_OK after launching.
+int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, int src_h, int dst_w, int dst_h, int n,
+                       hipStream_t stream) {
+  const bool direct_only = tuning(VALI_TUNE_RESIZE_FORCE_GATHER) == 1;
+  const int force = tuning(VALI_TUNE_RESIZE_NO_SEPARABLE); // rows per wave: 1 / 2 / 3 force 2 / 1 / 8 rows per slot
+  ResizeArgs a = base;
+  int esset = 0, tile_n = 256, slots = 1;
+  bool narrow = false;
+  for (int k = 0; k < a.njobs; ++k) {
+    const ResizeJob& j = a.job[k];
+    const int c = j.channels;
+    esset = c == 3 ? 3 : (c == 2 || esset == 12) ? 12 : (esset ? esset : 1);
+    const int sw = src_w >> j.ssub_x, dw = dst_w >> j.sub_x, sh = src_h >> j.ssub_y, dh = dst_h >> j.sub_y;
+    narrow = narrow || sw * c < kColEl;
+    // dst elements per tile: the source span of its pixels (+ taps, + the two extra elements, + alignment slop) must fit
+    // the 512 elements a wave loads per row.  A tile starts on a pixel unless pixels are 3 elements (N is a multiple of 4).
+    const double sx = (double)sw / (double)dw * (1.0 + 1e-6);
+    int nn = 256;
+    while (nn >= 8 && (((c == 3 ? nn / 3 + 2 : nn / c) - 1) * sx + taps + 4) * c + kColEl - 1 > (double)kColSpan)
+      nn -= 4;
+    tile_n = nn < tile_n ? nn : tile_n;
+    // slots: the smallest P with P * scale_y >= taps (and a margin for the rounding of y * scale_y in FP32)
+    const double sy = (double)sh / (double)dh;
+    int p = 1;
+    while (p < 6 && p * sy < taps + sh * 2.5e-7 + 1e-6)
+      ++p;
+    slots = p > slots ? p : slots;
+  }
+  auto launch_direct = [&]() {
+    u32 total = 0;
+    for (int k = 0; k < a.njobs; ++k) {
+      const int dwe = (dst_w >> a.job[k].sub_x) * a.job[k].channels, dh = dst_h >> a.job[k].sub_y;
+      a.job[k].first_tile = total;
+      a.job[k].tiles_x = (u32)(dwe + kBlock - 1) / kBlock;
+      total += a.job[k].tiles_x * (u32)dh;
+    }
+    a.map = make_tile_map_linear(total, (u32)n);
+    const dim3 grid = tile_grid(a.map);
+#define VALI_COLS_DIRECT(T)                                                                          \
+  do {                                                                                               \
+    if (taps == 6) hipLaunchKernelGGL((k_resize_cols_direct<T, 6>), grid, dim3(kBlock), 0, stream, a); \
+    else hipLaunchKernelGGL((k_resize_cols_direct<T, 4>), grid, dim3(kBlock), 0, stream, a);           \
+  } while (0)
+    if (elem == 1) VALI_COLS_DIRECT(uint8_t);
+    else if (elem == 2) VALI_COLS_DIRECT(uint16_t);
+    else VALI_COLS_DIRECT(float);
+#undef VALI_COLS_DIRECT
+    VALI_LAUNCH_CHECK();
+    return (int)VALI_OK;
+  };
+  if (narrow || tile_n < 8 || direct_only)
+    return launch_direct();
+  const int pmin = taps == 6 ? 3 : 2, pmid = taps == 6 ? 4 : 3, pmax = taps == 6 ? 6 : 4;
+  const int P = slots <= pmin ? pmin : slots <= pmid ? pmid : pmax;
+  // rows per wave = P x rps, rps <= 8 (a slot's weights are one register: 8 rows x 8 lanes) and small enough for the
+  // wave's program: (rows - 1) scale_y + taps + 1 source rows <= kColProgRows
+  int rps_max = 8;
+  for (int k = 0; k < a.njobs; ++k) {
+    const double sy = (double)(src_h >> a.job[k].ssub_y) / (double)(dst_h >> a.job[k].sub_y) * (1.0 + 1e-6);
+    while (rps_max > 0 && (P * rps_max - 1) * sy + taps + 1 > (double)kColProgRows)
+      --rps_max;
+  }
+  if (rps_max < 1)
+    return launch_direct();
+  // even tiles: the same number of tiles along x, none of them nearly empty
+  {
+    int widest = 0;
+    for (int k = 0; k < a.njobs; ++k) {
+      const int dwe = (dst_w >> a.job[k].sub_x) * a.job[k].channels;
+      widest = dwe > widest ? dwe : widest;
+    }
+    const int tiles = (widest + tile_n - 1) / tile_n;
+    const int even = (((widest + tiles - 1) / tiles) + 3) & ~3;
+    tile_n = even < tile_n ? even : tile_n;
+  }
+  auto count = [&](int rps, bool assign) {
+    u32 total = 0;
+    const int rows = kWavesPerBlock * P * rps;
+    for (int k = 0; k < a.njobs; ++k) {
+      const int dwe = (dst_w >> a.job[k].sub_x) * a.job[k].channels, dh = dst_h >> a.job[k].sub_y;
+      const u32 tiles_x = (u32)(dwe + tile_n - 1) / (u32)tile_n;
+      if (assign) {
+        a.job[k].first_tile = total;
+        a.job[k].tiles_x = tiles_x;
+      }
+      total += tiles_x * (u32)((dh + rows - 1) / rows);
+    }
+    return total;
+  };
+  // rows per slot: as many as the program allows (the tile's TAPS - 1 shared source rows weigh least) while the launch still
+  // fills the chip, fewer for small launches -- a lone wave walks its rows one memory round trip after the other
+  int rps = rps_max;
+  if (force == 1) rps = rps_max < 2 ? rps_max : 2;
+  else if (force == 2) rps = 1;
+  else if (force == 3) rps = rps_max;
+  else
+    while (rps > 1 && (unsigned long long)count(rps, false) * (unsigned)n < 1024ull)
+      rps = rps > 2 ? rps / 2 : 1;
+  a.map = make_tile_map_linear(count(rps, true), (u32)n);
+  a.cols_n = tile_n;
+  a.cols_rps = rps;
+  const dim3 grid = tile_grid(a.map);
+#define VALI_COLS_T(T)                                                               \
+  do {                                                                               \
+    if (taps == 6) {                                                                 \
+      if (esset == 1) launch_slots<T, 1, 6>(a, P, grid, stream);                      \
+      else if (esset == 12) launch_slots<T, 12, 6>(a, P, grid, stream);               \
+      else launch_slots<T, 3, 6>(a, P, grid, stream);                                 \
+    } else {                                                                         \
+      if (esset == 1) launch_slots<T, 1, 4>(a, P, grid, stream);                      \
+      else if (esset == 12) launch_slots<T, 12, 4>(a, P, grid, stream);               \
+      else launch_slots<T, 3, 4>(a, P, grid, stream);                                 \
+    }                                                                                \
+  } while (0)
+  if (elem == 1) VALI_COLS_T(uint8_t);
+  else if (elem == 2) VALI_COLS_T(uint16_t);
+  else VALI_COLS_T(float);
+#undef VALI_COLS_T
+  VALI_LAUNCH_CHECK();
+  return VALI_OK;
+}
+
+} // namespace vali

@@ -19,11 +19,19 @@ struct ResizeArgs {
   // taps kernels (resize_taps.hip): dynamic LDS layout per wave = [stage_bytes: the staged source row][ring]
   int stage_bytes;  // bytes of a wave's stage (pads included), multiple of 16; 0 = gather only
   int lds_per_wave; // stage_bytes + ring bytes
+  // columns-first taps kernel (resize_cols.hip)
+  int cols_n;       // dst elements per tile along x (multiple of 4, <= 256)
+  int cols_rps;     // dst rows per slot of a wave (1, 2, 4, 8): a wave owns slots x cols_rps rows
 };
 
 // Lanczos-3 (taps = 6) / bicubic (taps = 4) over the plane jobs of `a` (job[].comp / sub / channels filled in, planes
 // resolved for single-frame launches); one launch per channel count present.  elem = bytes per element.
 int launch_resize_taps(const ResizeArgs& a, int elem, int taps, int src_w, int src_h, int dst_w, int dst_h, int n,
+                       hipStream_t stream);
+
+// The same filters for jobs whose planes all SHRINK (or keep) their height -- columns first (resize_cols.hip).  Which
+// plane takes which order is part of the specification (oracle/vali_oracle.c resize_plane_taps): src_h >= dst_h.
+int launch_resize_cols(const ResizeArgs& a, int elem, int taps, int src_w, int src_h, int dst_w, int dst_h, int n,
                        hipStream_t stream);
 
 } // namespace vali
