@@ -16,6 +16,7 @@ for small in (0,1):
     vali.tuning.Set("RESIZE_NO_SEPARABLE", small)
     print('8-row waves only' if small else 'rows per wave by launch size')
     print('  NV12 2160->1088: lanczos', run(vali.NV12,3840,2160,1920,1088,L,64), 'cubic', run(vali.NV12,3840,2160,1920,1088,Cu,64), 'linear', run(vali.NV12,3840,2160,1920,1088,Li,64), flush=True)
+    print('  NV12 2160->1936x1088 (no integer ratio on either axis): lanczos', run(vali.NV12,3840,2160,1936,1088,L,64), 'cubic', run(vali.NV12,3840,2160,1936,1088,Cu,64), flush=True)
     print('  NV12 1080->2160: lanczos', run(vali.NV12,1920,1080,3840,2160,L,16), 'cubic', run(vali.NV12,1920,1080,3840,2160,Cu,16), flush=True)
     print('  Y 2160->1088 lanczos', run(vali.Y,3840,2160,1920,1088,L,64), ' YUV420', run(vali.YUV420,3840,2160,1920,1088,L,64), flush=True)
     print('  RGB 2160->1080(x1.99) lanczos', run(vali.RGB,3840,2160,1930,1086,L,32), ' RGB_32F 2160->1080 lanczos', run(vali.RGB_32F,3840,2160,1920,1080,L,8), 'RGB_32F x1.99', run(vali.RGB_32F,3840,2160,1930,1086,L,8), flush=True)

@@ -47,6 +47,157 @@ template <int ES> constexpr int kColSeg = ES == 1 ? 0 : ES == 2 ? 288 : 184;
 
 typedef u32 u32_u __attribute__((aligned(1)));
 
+// ---- the rows of a wave: tap weights per slot, the program, the row offsets ----
+template <int P> struct ColRows {
+  float ws[P];        // lane 8 m + k: tap k of dst row m P + j (lanes 8 m + 6, 8 m + 7: 0.0)
+  u32 prog_lo, prog_hi; // lane t: the program word of the wave's t-th source row (below)
+  u32 roff;           // lane t: byte offset of that row in the source plane
+  int ns;             // source rows the wave walks, <= kColProgRows
+  int y_first, last_rr;
+};
+
+// false: the wave has no rows.  `strip` is scratch here (>= 512 bytes).
+template <int TAPS, int P>
+__device__ __forceinline__ bool cols_rows(int sh, int dh, int spitch, u32 ty, int rps, float* strip, ColRows<P>& r) {
+  constexpr int kBefore = LzTap<TAPS>::kBefore;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int rows = P * rps;                                     // dst rows of this wave, <= 8 P <= 64
+  r.y_first = (int)(ty * kWavesPerBlock + wave) * rows;         // wave-uniform
+  if (r.y_first >= dh)
+    return false;
+  r.last_rr = min(rows, dh - r.y_first) - 1;
+  const float scale_y = (float)sh / (float)dh;
+  // row taps: lane r evaluates row y_first + r; the weights go through LDS into one register per slot
+  const LzTap<TAPS> vy = make_lz_tap<TAPS>(r.y_first + min(lane, rows - 1), scale_y);
+  if (lane < rows) {
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k)
+      strip[lane * 8 + k] = vy.w[k];
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int j = 0; j < P; ++j)
+    r.ws[j] = (lane & 7) < TAPS ? strip[((lane >> 3) * P + j) * 8 + (lane & 7)] : 0.0f;
+  wave_lds_sync();
+  // The wave's program: what every source row it walks does, as data instead of control flow.  Byte j of row t's word =
+  // the lane of ws[j] that holds the weight slot j applies to this row (lane 8 m + 7 holds 0.0: the slot has no use for
+  // the row -- a zero weight is an exact no-op on an accumulator that is never -0, for the finite values integer planes
+  // have; float planes skip the slot instead), bit 7 of the byte = this row completes the slot's window.  Written by the
+  // lanes that own the dst rows (lane r: TAPS bytes), read back one word per lane.  The walk then costs one v_readlane +
+  // one scalar shift per slot and row instead of the dozen scalar compares, branches and counters of a control-flow
+  // form: the kernel is bound by the TOTAL number of instructions its waves issue (profiles/r03_lanczos.md).
+  const int s_begin = __builtin_amdgcn_readlane(vy.i, 0) - kBefore;
+  r.ns = __builtin_amdgcn_readlane(vy.i, r.last_rr) + TAPS - kBefore - s_begin;
+  uint8_t* const prog = reinterpret_cast<uint8_t*>(strip);
+  reinterpret_cast<uint2*>(prog)[lane] = make_uint2(0x07070707u, 0x00000707u);
+  wave_lds_sync();
+  if (lane <= r.last_rr) {
+    const int j = lane % P, m = lane / P;
+    const int t0 = vy.i - kBefore - s_begin;
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k)
+      prog[(t0 + k) * 8 + j] = (uint8_t)(m * 8 + k + (k == TAPS - 1 ? 0x80 : 0));
+  }
+  wave_lds_sync();
+  const uint2 pw = reinterpret_cast<const uint2*>(prog)[lane];
+  r.prog_lo = pw.x;
+  r.prog_hi = pw.y;
+  r.roff = (u32)(clampi(s_begin + lane, sh - 1) * spitch);
+  wave_lds_sync();
+  return true;
+}
+
+// The walk over the wave's source rows.  A lane loads ND dwords per row at sp + row offset + lane_off (D rows in
+// flight), conv() turns them into the 8 floats it filters, every slot takes fma(w, f, acc) with its scalar weight, and
+// when a row completes a dst row emit(rr, acc) gets that row's 8 column results.
+template <typename T, int TAPS, int P, int ND, int D, typename Conv, typename Emit>
+__device__ __forceinline__ void cols_walk(const ColRows<P>& r, const uint8_t* sp, u32 lane_off, Conv conv, Emit emit) {
+  constexpr int EB = (int)sizeof(T);
+  v2f32 acc[P][4];
+#pragma unroll
+  for (int j = 0; j < P; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      acc[j][i] = (v2f32){0.0f, 0.0f};
+  u32 pf[D][ND];
+  auto issue = [&](int t, u32 (&q)[ND]) { // t < 64 (host: ns <= kColProgRows, rounded up to D, + D)
+    const uint8_t* p = sp + (u32)__builtin_amdgcn_readlane((int)r.roff, t);
+    if constexpr (ND == 2) {
+      const v2u32 w = gload_u<v2u32>(p + lane_off);
+      q[0] = w.x; q[1] = w.y;
+    } else {
+#pragma unroll
+      for (int c = 0; c < ND / 4; ++c) {
+        const v4u32 w = gload_u<v4u32>(p + lane_off + 16 * c);
+        q[4 * c] = w.x; q[4 * c + 1] = w.y; q[4 * c + 2] = w.z; q[4 * c + 3] = w.w;
+      }
+    }
+  };
+  // (scheduling barriers: vmcnt retires in order, the rows must be ISSUED in order -- DESIGN.md 5d)
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    issue(j, pf[j]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  int emit_rr = 0, eslot = 0; // the next dst row to complete and its slot: rows complete in order, slots in turn
+#pragma unroll 1
+  for (int t0 = 0; t0 < r.ns; t0 += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int t = t0 + d;
+      v2f32 f[4];
+      conv(pf[d], f);
+      issue(t + D, pf[d]);
+      if (t >= r.ns) // the last trip only: rows past the end are loaded (the issue order stays countable), not used
+        continue;
+      const u32 w_lo = (u32)__builtin_amdgcn_readlane((int)r.prog_lo, t);
+      const u32 w_hi = P > 4 ? (u32)__builtin_amdgcn_readlane((int)r.prog_hi, t) : 0u;
+      float w[P];
+#pragma unroll
+      for (int j = 0; j < P; ++j) // (the weights first, the arithmetic after: no wait states between a v_readlane and its use)
+        w[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.ws[j]),
+                                                                   (int)(((j < 4 ? w_lo : w_hi) >> (8 * (j & 3))) & 0x3fu)));
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        if constexpr (EB == 4) {
+          if (((((j < 4 ? w_lo : w_hi) >> (8 * (j & 3))) & 7u) == 7u)) // wave-uniform
+            continue;
+        }
+        const v2f32 wv = (v2f32){w[j], w[j]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[j][i] = __builtin_elementwise_fma(wv, f[i], acc[j][i]);
+      }
+      if (((w_lo & 0x80808080u) | (w_hi & 0x8080u)) != 0u) { // at most one dst row per source row (scale_y >= 1)
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+          if (eslot == j) {
+            emit(emit_rr, acc[j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              acc[j][i] = (v2f32){0.0f, 0.0f};
+          }
+        }
+        eslot = eslot == P - 1 ? 0 : eslot + 1;
+        ++emit_rr;
+      }
+    }
+  }
+}
+
+template <typename T> __device__ __forceinline__ void conv8(const u32 (&d)[2 * sizeof(T)], v2f32 (&f)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if constexpr (sizeof(T) == 1)
+      f[i] = (v2f32){(float)((d[i / 2] >> (16 * (i % 2))) & 0xffu), (float)((d[i / 2] >> (16 * (i % 2) + 8)) & 0xffu)};
+    else if constexpr (sizeof(T) == 2)
+      f[i] = (v2f32){(float)(d[i] & 0xffffu), (float)(d[i] >> 16)};
+    else
+      f[i] = (v2f32){__uint_as_float(d[2 * i]), __uint_as_float(d[2 * i + 1])};
+  }
+}
+
 template <typename T, int ES, int TAPS, int P>
 __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw, int sh, uint8_t* dp, int dpitch,
                                           int dw, int dh, u32 tx, u32 ty, int N, int rps, float* strip, float* obuf) {
@@ -57,30 +208,13 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
   constexpr int NP = EB == 4 ? TAPS / 2 : TAPS / 2 + 1;         // float pairs of a horizontal window
   constexpr int SEG = kColSeg<ES>;
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const u32 lds_base = (u32)(uintptr_t)(__attribute__((address_space(3))) float*)strip; // LDS byte address of the strip
-  const int rows = P * rps;                                     // dst rows of this wave, <= 8 P <= 64
-  const int y_first = (int)(ty * kWavesPerBlock + wave) * rows; // wave-uniform
-  if (y_first >= dh)
+  ColRows<P> r;
+  if (!cols_rows<TAPS, P>(sh, dh, spitch, ty, rps, strip, r))
     return;
-  const int last_rr = min(rows, dh - y_first) - 1;
   const int dwe = dw * ES, row_el = sw * ES;
   const int e0 = (int)tx * N, e_last = min(e0 + N, dwe) - 1;
-  const float scale_x = (float)sw / (float)dw, scale_y = (float)sh / (float)dh;
-
-  // ---- row taps: lane r evaluates row y_first + r; the weights go through LDS into one register per slot ----
-  const LzTap<TAPS> vy = make_lz_tap<TAPS>(y_first + min(lane, rows - 1), scale_y);
-  if (lane < rows) {
-#pragma unroll
-    for (int k = 0; k < TAPS; ++k)
-      strip[lane * 8 + k] = vy.w[k];
-  }
-  wave_lds_sync();
-  float ws[P]; // lane 8 m + k: tap k of dst row m P + j
-#pragma unroll
-  for (int j = 0; j < P; ++j)
-    ws[j] = (lane & 7) < TAPS ? strip[((lane >> 3) * P + j) * 8 + (lane & 7)] : 0.0f;
-  wave_lds_sync();
+  const float scale_x = (float)sw / (float)dw;
 
   // ---- the tile's source span along x (wave-uniform), one element more on either side than the taps need: a window
   // that starts on an odd float is read from the even float in front of it ----
@@ -96,7 +230,6 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
   const bool ragged = j_begin + kColEl * nl > row_el;           // wave-uniform: only a row's last tile
   const int j0 = min(j_begin + kColEl * min(lane, nl - 1), row_el - kColEl);
   const bool has = lane < nl;
-  const u32 lane_off = (u32)(j0 * EB);
 
   // strip positions of this lane's 8 elements
   int wpos[ES == 3 ? kColEl : 2];
@@ -146,195 +279,163 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
   const int edge = kColPadL + (sw - 1) - px_begin;                         // the last pixel of the row
   const int eb = e0 + 4 * lane;                                            // store: 4 adjacent elements
   const int n_out = min(4, e_last + 1 - eb);
+  // whole dwords from every lane that stores, on 4-byte aligned rows: one store, no per-lane alignment test
+  const bool plain_store = EB == 1 && ((e_last + 1 - e0) & 3) == 0 && ((((uintptr_t)dp) | (uintptr_t)dpitch) & 3u) == 0; // wave-uniform
 
-  // ---- the wave's program: what every source row it walks does, as data instead of control flow ----
-  // Byte j of row t's word = the lane of ws[j] that holds the weight slot j applies to this row (lane 8 m + 7 holds 0.0:
-  // the slot has no use for the row -- a zero weight is an exact no-op on an accumulator that is never -0, for the finite
-  // values integer planes have; float planes skip the slot instead), bit 7 of the byte = this row completes the slot's
-  // window.  Written by the lanes that own the dst rows (lane r: 6 bytes), read back one word per lane; a second register
-  // holds the rows' byte offsets.  The walk then costs one v_readlane + s_bfe per slot and row instead of the dozen scalar
-  // compares, branches and counters of the control-flow form (the kernel was bound by its total instruction issue).
-  const int s_begin = __builtin_amdgcn_readlane(vy.i, 0) - kBefore;
-  const int ns = __builtin_amdgcn_readlane(vy.i, last_rr) + TAPS - kBefore - s_begin; // source rows, <= kColProgRows (host)
-  uint8_t* const prog = reinterpret_cast<uint8_t*>(strip);
-  reinterpret_cast<uint2*>(prog)[lane] = make_uint2(0x07070707u, 0x00000707u);
-  wave_lds_sync();
-  if (lane <= last_rr) {
-    const int j = lane % P, m = lane / P;
-    const int t0 = vy.i - kBefore - s_begin;
+  auto emit = [&](int rr, v2f32 (&c)[4]) { // dst row rr: its columns c go to the strip, the wave filters along x
+    if (has) {
+      if constexpr (ES == 3) {
 #pragma unroll
-    for (int k = 0; k < TAPS; ++k)
-      prog[(t0 + k) * 8 + j] = (uint8_t)(m * 8 + k + (k == TAPS - 1 ? 0x80 : 0));
-  }
-  wave_lds_sync();
-  const uint2 pw = reinterpret_cast<const uint2*>(prog)[lane];
-  const u32 roff = (u32)(clampi(s_begin + lane, sh - 1) * spitch); // lane t: byte offset of the wave's t-th source row
-  wave_lds_sync();
-
-  v2f32 acc[P][4];
+        for (int i = 0; i < 4; ++i) {
+          strip[wpos[2 * i]] = c[i].x;
+          strip[wpos[2 * i + 1]] = c[i].y;
+        }
+      } else if (ragged) {
 #pragma unroll
-  for (int j = 0; j < P; ++j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      acc[j][i] = (v2f32){0.0f, 0.0f};
-
-  u32 pf[D][ND];
-  auto issue = [&](int t, u32 (&q)[ND]) { // t < 64 (host: ns <= kColProgRows, rounded up to D, + D)
-    const uint8_t* p = sp + (u32)__builtin_amdgcn_readlane((int)roff, t);
-    if constexpr (ND == 2) {
-      const v2u32 w = gload_u<v2u32>(p + lane_off);
-      q[0] = w.x; q[1] = w.y;
-    } else {
-#pragma unroll
-      for (int c = 0; c < ND / 4; ++c) {
-        const v4u32 w = gload_u<v4u32>(p + lane_off + 16 * c);
-        q[4 * c] = w.x; q[4 * c + 1] = w.y; q[4 * c + 2] = w.z; q[4 * c + 3] = w.w;
+        for (int i = 0; i < 4; ++i) {
+          if constexpr (ES == 2) {
+            strip[wpos[0] + i] = c[i].x;
+            strip[wpos[1] + i] = c[i].y;
+          } else {
+            strip[wpos[0] + 2 * i] = c[i].x;
+            strip[wpos[0] + 2 * i + 1] = c[i].y;
+          }
+        }
+      } else if constexpr (ES == 2) {
+        *reinterpret_cast<float4*>(strip + wpos[0]) = make_float4(c[0].x, c[1].x, c[2].x, c[3].x);
+        *reinterpret_cast<float4*>(strip + wpos[1]) = make_float4(c[0].y, c[1].y, c[2].y, c[3].y);
+      } else {
+        *reinterpret_cast<float4*>(strip + wpos[0]) = make_float4(c[0].x, c[0].y, c[1].x, c[1].y);
+        *reinterpret_cast<float4*>(strip + wpos[0] + 4) = make_float4(c[2].x, c[2].y, c[3].x, c[3].y);
       }
+    }
+    wave_lds_sync();
+    if (pad_left || pad_right) { // image edges: replicas of the first / last pixel of every channel segment
+      const int ch = lane >> 3, i = lane & 7;
+      if (pad_left && ch < ES && i < kColPadL)
+        strip[ch * SEG + kColPadL - 1 - i] = strip[ch * SEG + kColPadL];
+      if (pad_right && ch < ES && i < kColPadR)
+        strip[ch * SEG + edge + 1 + i] = strip[ch * SEG + edge];
+      wave_lds_sync();
+    }
+    // Two windows per LDS round trip (all four need 32 registers, which cost the kernel its fourth wave per SIMD), every
+    // float pair with its own ds_read_b64: left to itself the compiler fuses two into a ds_read2_b64, which takes twice
+    // the LDS cycles per byte and banks modulo 32 dwords instead of 64 (MI355X_MICROARCH.md, LDS: measured 56 % LDS-busy,
+    // 29 % of it bank conflicts).  Hence the assembly; the wait names every loaded register, so nothing reads one early.
+    float hs[4];
+#pragma unroll
+    for (int half = 0; half < 4; half += 2) {
+      v2f32 t[2][NP];
+      if constexpr (EB == 4) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int jj = 0; jj < NP; ++jj)
+            t[p][jj] = (v2f32){strip[ho[half + p] + 2 * jj], strip[ho[half + p] + 2 * jj + 1]};
+      } else {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const u32 la = lds_base + 4u * (u32)ho[half + p];
+          if constexpr (NP == 4)
+            asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24"
+                         : "=&v"(t[p][0]), "=&v"(t[p][1]), "=&v"(t[p][2]), "=&v"(t[p][3]) : "v"(la) : "memory");
+          else
+            asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:8\n\tds_read_b64 %2, %3 offset:16"
+                         : "=&v"(t[p][0]), "=&v"(t[p][1]), "=&v"(t[p][2]) : "v"(la) : "memory");
+        }
+        if constexpr (NP == 4)
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[0][3]), "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[1][2]), "+v"(t[1][3]));
+        else
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[1][2]));
+      }
+      // (the two chains interleaved: a v_pk_fma_f32 that reads the result of the one before it costs a wait state)
+      v2f32 h0 = (v2f32){0.0f, 0.0f}, h1 = (v2f32){0.0f, 0.0f};
+#pragma unroll
+      for (int jj = 0; jj < NP; ++jj) {
+        h0 = __builtin_elementwise_fma(wq[half][jj], t[0][jj], h0);
+        h1 = __builtin_elementwise_fma(wq[half + 1][jj], t[1][jj], h1);
+      }
+      hs[half] = h0.x + h0.y;
+      hs[half + 1] = h1.x + h1.y;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      obuf[p * kWave + lane] = hs[p];
+    wave_lds_sync();
+    if (n_out > 0) {
+      const float4 v = *reinterpret_cast<const float4*>(obuf + 4 * lane);
+      uint8_t* const out = dp + (u32)((r.y_first + rr) * dpitch) + (size_t)eb * EB;
+      if (plain_store) {
+        u32 q = __builtin_amdgcn_cvt_pk_u8_f32(v.x, 0u, 0u);
+        q = __builtin_amdgcn_cvt_pk_u8_f32(v.y, 1u, q);
+        q = __builtin_amdgcn_cvt_pk_u8_f32(v.z, 2u, q);
+        q = __builtin_amdgcn_cvt_pk_u8_f32(v.w, 3u, q);
+        gstore_nt<u32>(out, q);
+      } else {
+        const float res[4][1] = {{v.x}, {v.y}, {v.z}, {v.w}};
+        store_px4<T, 1>(out, res, (1u << n_out) - 1u);
+      }
+    }
+    wave_lds_sync();
+  };
+  cols_walk<T, TAPS, P, ND, D>(r, sp, (u32)(j0 * EB), [](const u32 (&d)[ND], v2f32 (&f)[4]) { conv8<T>(d, f); }, emit);
+}
+
+// Exactly 2:1 along x (src_w == 2 dst_w: x * scale_x is an integer, every column weight is 0 or 1 and the pass along the
+// row is the point sample c[2 x] -- bit for bit: fma(0, c, e) == e, and 1 * c + 0 == c).  The columns that are never
+// sampled are never filtered: a lane loads 16 source elements per row and filters the 8 that survive, which are the 8
+// dst elements it stores -- no strip, no gather, no transposition; half the conversions and FMAs per source byte.  Planes
+// of 1- and 2-element pixels of 8 / 16-bit types (NV12, P10, YUV4xx, Y, RGB_PLANAR); floats keep the general form (a zero
+// weight on a non-finite neighbour is not a no-op).
+template <typename T, int ES, int TAPS, int P>
+__device__ __forceinline__ void cols_tile_x2(const uint8_t* sp, int spitch, int sw, int sh, uint8_t* dp, int dpitch,
+                                             int dw, int dh, u32 tx, u32 ty, int rps, float* strip) {
+  constexpr int EB = (int)sizeof(T);
+  static_assert(EB <= 2 && ES <= 2, "cols_tile_x2: 8 / 16-bit planes of 1 or 2 channels");
+  constexpr int ND = 4 * EB;                                    // dwords of a lane's 16 source elements
+  constexpr int D = EB == 1 ? 4 : 2;
+  const int lane = threadIdx.x & 63;
+  ColRows<P> r;
+  if (!cols_rows<TAPS, P>(sh, dh, spitch, ty, rps, strip, r))
+    return;
+  const int dwe = dw * ES;                                      // >= 8 (host)
+  const int e0 = (int)tx * (kWave * 8);
+  const bool has = e0 + 8 * lane < dwe;
+  const int eo = min(e0 + 8 * lane, dwe - 8);                   // a row's last lane slides left to end with the row
+  const bool slid = dwe - e0 < kWave * 8 && ((dwe - e0) & 7) != 0;                                          // wave-uniform
+  const bool plain_store = !slid && ((((uintptr_t)dp) | (uintptr_t)dpitch) & (8u * EB - 1u)) == 0;
+  auto conv = [](const u32 (&d)[ND], v2f32 (&f)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (EB == 1 && ES == 1)      // bytes 4 i, 4 i + 2
+        f[i] = (v2f32){(float)(d[i] & 0xffu), (float)((d[i] >> 16) & 0xffu)};
+      else if constexpr (EB == 1)            // the (U, V) pair of every other pixel: bytes 4 i, 4 i + 1
+        f[i] = (v2f32){(float)(d[i] & 0xffu), (float)((d[i] >> 8) & 0xffu)};
+      else if constexpr (ES == 1)            // elements 4 i, 4 i + 2: the low halves of dwords 2 i, 2 i + 1
+        f[i] = (v2f32){(float)(d[2 * i] & 0xffffu), (float)(d[2 * i + 1] & 0xffffu)};
+      else                                   // elements 4 i, 4 i + 1: dword 2 i
+        f[i] = (v2f32){(float)(d[2 * i] & 0xffffu), (float)(d[2 * i] >> 16)};
     }
   };
-  // (scheduling barriers: vmcnt retires in order, the rows must be ISSUED in order -- DESIGN.md 5d)
-#pragma unroll
-  for (int j = 0; j < D; ++j) {
-    issue(j, pf[j]);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  int emit_rr = 0, eslot = 0; // the next dst row to complete and its slot: rows complete in order, slots in turn
-#pragma unroll 1
-  for (int t0 = 0; t0 < ns; t0 += D) {
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      const int t = t0 + d;
-      v2f32 f[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if constexpr (EB == 1)
-          f[i] = (v2f32){(float)((pf[d][i / 2] >> (16 * (i % 2))) & 0xffu), (float)((pf[d][i / 2] >> (16 * (i % 2) + 8)) & 0xffu)};
-        else if constexpr (EB == 2)
-          f[i] = (v2f32){(float)(pf[d][i] & 0xffffu), (float)(pf[d][i] >> 16)};
-        else
-          f[i] = (v2f32){__uint_as_float(pf[d][2 * i]), __uint_as_float(pf[d][2 * i + 1])};
-      }
-      issue(t + D, pf[d]);
-      if (t >= ns) // the last trip only: rows past the end are loaded (the issue order stays countable), not used
-        continue;
-      const u32 w_lo = (u32)__builtin_amdgcn_readlane((int)pw.x, t);
-      const u32 w_hi = P > 4 ? (u32)__builtin_amdgcn_readlane((int)pw.y, t) : 0u;
-#pragma unroll
-      for (int j = 0; j < P; ++j) {
-        const u32 code = ((j < 4 ? w_lo : w_hi) >> (8 * (j & 3))) & 0x3fu; // wave-uniform
-        if constexpr (EB == 4) {
-          if ((code & 7u) == 7u)
-            continue;
-        }
-        const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ws[j]), (int)code));
-        const v2f32 wv = (v2f32){w, w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          acc[j][i] = __builtin_elementwise_fma(wv, f[i], acc[j][i]);
-      }
-      const bool emit = ((w_lo & 0x80808080u) | (w_hi & 0x8080u)) != 0u; // at most one dst row per source row (scale_y >= 1)
-      if (emit) {
-#pragma unroll
-        for (int j = 0; j < P; ++j) {
-          if (eslot == j) { // the window of dst row emit_rr is complete: its columns go to the strip
-            if (has) {
-              if constexpr (ES == 3) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                  strip[wpos[2 * i]] = acc[j][i].x;
-                  strip[wpos[2 * i + 1]] = acc[j][i].y;
-                }
-              } else if (ragged) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                  if constexpr (ES == 2) {
-                    strip[wpos[0] + i] = acc[j][i].x;
-                    strip[wpos[1] + i] = acc[j][i].y;
-                  } else {
-                    strip[wpos[0] + 2 * i] = acc[j][i].x;
-                    strip[wpos[0] + 2 * i + 1] = acc[j][i].y;
-                  }
-                }
-              } else if constexpr (ES == 2) {
-                *reinterpret_cast<float4*>(strip + wpos[0]) = make_float4(acc[j][0].x, acc[j][1].x, acc[j][2].x, acc[j][3].x);
-                *reinterpret_cast<float4*>(strip + wpos[1]) = make_float4(acc[j][0].y, acc[j][1].y, acc[j][2].y, acc[j][3].y);
-              } else {
-                *reinterpret_cast<float4*>(strip + wpos[0]) = make_float4(acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y);
-                *reinterpret_cast<float4*>(strip + wpos[0] + 4) = make_float4(acc[j][2].x, acc[j][2].y, acc[j][3].x, acc[j][3].y);
-              }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              acc[j][i] = (v2f32){0.0f, 0.0f};
-          }
-        }
-        eslot = eslot == P - 1 ? 0 : eslot + 1;
- // at most one dst row per source row (scale_y >= 1)
-        wave_lds_sync();
-        if (pad_left || pad_right) { // image edges: replicas of the first / last pixel of every channel segment
-          const int ch = lane >> 3, i = lane & 7;
-          if (pad_left && ch < ES && i < kColPadL)
-            strip[ch * SEG + kColPadL - 1 - i] = strip[ch * SEG + kColPadL];
-          if (pad_right && ch < ES && i < kColPadR)
-            strip[ch * SEG + edge + 1 + i] = strip[ch * SEG + edge];
-          wave_lds_sync();
-        }
-        // All four windows are fetched before any arithmetic (one LDS round trip per dst row, not four), every float
-        // pair with its own ds_read_b64: left to itself the compiler fuses two into a ds_read2_b64, which takes twice the
-        // LDS cycles per byte and banks modulo 32 dwords instead of 64 (MI355X_MICROARCH.md, LDS: 56 % LDS-busy with 29 %
-        // of it bank conflicts).  Hence the assembly; the wait names every loaded register, so nothing reads one early.
-        // (two windows per round trip: all four at once need 32 registers, which cost the kernel its fourth wave per SIMD)
-        float hs[4];
-#pragma unroll
-        for (int half = 0; half < 4; half += 2) {
-          v2f32 t[2][NP];
-          if constexpr (EB == 4) {
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-              for (int jj = 0; jj < NP; ++jj)
-                t[p][jj] = (v2f32){strip[ho[half + p] + 2 * jj], strip[ho[half + p] + 2 * jj + 1]};
-          } else {
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-              const u32 la = lds_base + 4u * (u32)ho[half + p];
-              if constexpr (NP == 4)
-                asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24"
-                             : "=&v"(t[p][0]), "=&v"(t[p][1]), "=&v"(t[p][2]), "=&v"(t[p][3]) : "v"(la) : "memory");
-              else
-                asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:8\n\tds_read_b64 %2, %3 offset:16"
-                             : "=&v"(t[p][0]), "=&v"(t[p][1]), "=&v"(t[p][2]) : "v"(la) : "memory");
-            }
-            if constexpr (NP == 4)
-              asm volatile("s_waitcnt lgkmcnt(0)"
-                           : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[0][3]), "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[1][2]), "+v"(t[1][3]));
-            else
-              asm volatile("s_waitcnt lgkmcnt(0)"
-                           : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[1][2]));
-          }
-#pragma unroll
-          for (int p = 0; p < 2; ++p) {
-            v2f32 h = (v2f32){0.0f, 0.0f};
-#pragma unroll
-            for (int jj = 0; jj < NP; ++jj)
-              h = __builtin_elementwise_fma(wq[half + p][jj], t[p][jj], h);
-            hs[half + p] = h.x + h.y;
-          }
-        }
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-          obuf[p * kWave + lane] = hs[p];
-        wave_lds_sync();
-        if (n_out > 0) {
-          const float4 v = *reinterpret_cast<const float4*>(obuf + 4 * lane);
-          const float res[4][1] = {{v.x}, {v.y}, {v.z}, {v.w}};
-          store_px4<T, 1>(dp + (u32)((y_first + emit_rr) * dpitch) + (size_t)eb * EB, res, (1u << n_out) - 1u);
-        }
-        ++emit_rr;
-        wave_lds_sync();
-      }
+  auto emit = [&](int rr, v2f32 (&c)[4]) {
+    if (!has)
+      return;
+    uint8_t* const out = dp + (u32)((r.y_first + rr) * dpitch) + (size_t)eo * EB;
+    const float res[4][2] = {{c[0].x, c[0].y}, {c[1].x, c[1].y}, {c[2].x, c[2].y}, {c[3].x, c[3].y}};
+    if (plain_store && EB == 1) {
+      u32 q0 = __builtin_amdgcn_cvt_pk_u8_f32(c[0].x, 0u, 0u), q1 = __builtin_amdgcn_cvt_pk_u8_f32(c[2].x, 0u, 0u);
+      q0 = __builtin_amdgcn_cvt_pk_u8_f32(c[0].y, 1u, q0); q1 = __builtin_amdgcn_cvt_pk_u8_f32(c[2].y, 1u, q1);
+      q0 = __builtin_amdgcn_cvt_pk_u8_f32(c[1].x, 2u, q0); q1 = __builtin_amdgcn_cvt_pk_u8_f32(c[3].x, 2u, q1);
+      q0 = __builtin_amdgcn_cvt_pk_u8_f32(c[1].y, 3u, q0); q1 = __builtin_amdgcn_cvt_pk_u8_f32(c[3].y, 3u, q1);
+      const v2u32 q = {q0, q1};
+      gstore_nt<v2u32>(out, q);
+    } else {
+      store_px4<T, 2>(out, res, 0xfu);
     }
-  }
+  };
+  cols_walk<T, TAPS, P, ND, D>(r, sp, (u32)(2 * eo * EB), conv, emit);
 }
 
 // ESSET as in resize_taps.hip: 1 = one-channel planes, 12 = NV12 / P10 (Y + UV), 3 = packed RGB
@@ -357,6 +458,21 @@ __global__ void __launch_bounds__(kBlock) k_resize_cols(const ResizeArgs a) {
     else
       cols_tile<T, 1, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_n, a.cols_rps, strip, obuf);
   }
+}
+
+template <typename T, int ESSET, int TAPS, int P>
+__global__ void __launch_bounds__(kBlock) k_resize_cols_x2(const ResizeArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][384]; // scratch of cols_rows: 8 P rows x 8 weights
+  ResizeJob job;
+  u32 tx, ty, frame;
+  if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
+    return;
+  const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (ESSET == 12 && job.channels == 2)
+    cols_tile_x2<T, 2, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_rps, lds[wave]);
+  else
+    cols_tile_x2<T, 1, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_rps, lds[wave]);
 }
 
 // The same arithmetic one output element per thread, TAPS x TAPS global loads each: planes narrower than one lane's 8
@@ -399,8 +515,19 @@ __global__ void __launch_bounds__(kBlock) k_resize_cols_direct(const ResizeArgs 
 }
 
 template <typename T, int ESSET, int TAPS>
-static void launch_slots(const ResizeArgs& a, int slots, dim3 grid, hipStream_t stream) {
+static void launch_slots(const ResizeArgs& a, int slots, bool x2, dim3 grid, hipStream_t stream) {
   constexpr int P0 = TAPS == 6 ? 3 : 2, P1 = TAPS == 6 ? 4 : 3, P2 = TAPS == 6 ? 6 : 4;
+  if constexpr (sizeof(T) <= 2 && ESSET != 3) {
+    if (x2) {
+      if (slots <= P0)
+        hipLaunchKernelGGL((k_resize_cols_x2<T, ESSET, TAPS, P0>), grid, dim3(kBlock), 0, stream, a);
+      else if (slots <= P1)
+        hipLaunchKernelGGL((k_resize_cols_x2<T, ESSET, TAPS, P1>), grid, dim3(kBlock), 0, stream, a);
+      else
+        hipLaunchKernelGGL((k_resize_cols_x2<T, ESSET, TAPS, P2>), grid, dim3(kBlock), 0, stream, a);
+      return;
+    }
+  }
   if (slots <= P0)
     hipLaunchKernelGGL((k_resize_cols<T, ESSET, TAPS, P0>), grid, dim3(kBlock), 0, stream, a);
   else if (slots <= P1)
@@ -416,13 +543,14 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
   const int force = tuning(VALI_TUNE_RESIZE_NO_SEPARABLE); // rows per wave: 1 / 2 / 3 force 2 / 1 / 8 rows per slot
   ResizeArgs a = base;
   int esset = 0, tile_n = 256, slots = 1;
-  bool narrow = false;
+  bool narrow = false, x2 = elem <= 2 && tuning(VALI_TUNE_RESIZE_POINT) != 0; // exactly 2:1 along x on every plane
   for (int k = 0; k < a.njobs; ++k) {
     const ResizeJob& j = a.job[k];
     const int c = j.channels;
     esset = c == 3 ? 3 : (c == 2 || esset == 12) ? 12 : (esset ? esset : 1);
     const int sw = src_w >> j.ssub_x, dw = dst_w >> j.sub_x, sh = src_h >> j.ssub_y, dh = dst_h >> j.sub_y;
     narrow = narrow || sw * c < kColEl;
+    x2 = x2 && c <= 2 && sw == 2 * dw && dw * c >= 8;
     // dst elements per tile: the source span of its pixels (+ taps, + the two extra elements, + alignment slop) must fit
     // the 512 elements a wave loads per row.  A tile starts on a pixel unless pixels are 3 elements (N is a multiple of 4).
     const double sx = (double)sw / (double)dw * (1.0 + 1e-6);
@@ -483,6 +611,8 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
     const int tiles = (widest + tile_n - 1) / tile_n;
     const int even = (((widest + tiles - 1) / tiles) + 3) & ~3;
     tile_n = even < tile_n ? even : tile_n;
+    if (x2)
+      tile_n = kWave * 8; // 8 dst elements per lane, nothing shared between tiles
   }
   auto count = [&](int rps, bool assign) {
     u32 total = 0;
@@ -514,13 +644,13 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
 #define VALI_COLS_T(T)                                                               \
   do {                                                                               \
     if (taps == 6) {                                                                 \
-      if (esset == 1) launch_slots<T, 1, 6>(a, P, grid, stream);                      \
-      else if (esset == 12) launch_slots<T, 12, 6>(a, P, grid, stream);               \
-      else launch_slots<T, 3, 6>(a, P, grid, stream);                                 \
+      if (esset == 1) launch_slots<T, 1, 6>(a, P, x2, grid, stream);                      \
+      else if (esset == 12) launch_slots<T, 12, 6>(a, P, x2, grid, stream);               \
+      else launch_slots<T, 3, 6>(a, P, x2, grid, stream);                                 \
     } else {                                                                         \
-      if (esset == 1) launch_slots<T, 1, 4>(a, P, grid, stream);                      \
-      else if (esset == 12) launch_slots<T, 12, 4>(a, P, grid, stream);               \
-      else launch_slots<T, 3, 4>(a, P, grid, stream);                                 \
+      if (esset == 1) launch_slots<T, 1, 4>(a, P, x2, grid, stream);                      \
+      else if (esset == 12) launch_slots<T, 12, 4>(a, P, x2, grid, stream);               \
+      else launch_slots<T, 3, 4>(a, P, x2, grid, stream);                                 \
     }                                                                                \
   } while (0)
   if (elem == 1) VALI_COLS_T(uint8_t);
