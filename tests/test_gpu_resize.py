@@ -249,3 +249,66 @@ def test_lanczos_batch_large_enough_for_32_row_waves(vali, gpu, oracle):
         out = np.zeros(d.HostSize, np.uint8)
         assert vali.PySurfaceDownloader(gpu).Run(d, out)[0]
         assert np.array_equal(out, wants[i % 3]), i
+
+
+# ---- the columns-first kernels (planes that shrink vertically, vali_amd/csrc/resize_cols.hip) -------------------
+# geometry -> what it reaches: slot counts 3 / 4 / 6 (Lanczos) and 2 / 3 / 4 (bicubic) by the vertical ratio, the 2:1-along-x
+# form (src_w == 2 dst_w) and the general one, ragged last tiles, planes narrower than one lane's 8 elements (direct form),
+# a vertical shrink with a horizontal stretch, rows kept (src_h == dst_h), a plane pair that takes BOTH orders (YUV420 ->
+# taller: luma shrinks, chroma ... ) is covered by the planar UD tests.
+COLS_GEOMS = [(1280, 722, 640, 364),      # x2, ratio 1.98: 4 slots (3 bicubic)
+              (1280, 720, 640, 238),      # x2, ratio 3.03: 3 slots (2)
+              (636, 364, 318, 310),       # x2, ratio 1.17: 6 slots (4), ragged tile
+              (1282, 360, 640, 250),      # general, 2.003 along x
+              (1000, 700, 1400, 300),     # shrink rows, stretch columns
+              (700, 540, 334, 540),       # rows kept: every row weight is 0 or 1
+              (12, 300, 6, 100),          # narrow planes: the direct form for the chroma planes / x2 refused
+              (2600, 800, 90, 64)]        # 29:1 along x, 12.5:1 along y: tiles of a few elements, sparse rows
+
+
+@pytest.mark.parametrize("fmt", ["NV12", "YUV420", "RGB", "RGB_32F", "Y", "P10", "YUV444_10bit"])
+@pytest.mark.parametrize("geom", COLS_GEOMS)
+@pytest.mark.parametrize("interp", ["lanczos", "cubic"])
+def test_columns_first_forms_bit_exact(vali, gpu, oracle, fmt, geom, interp):
+    sw, sh, dw, dh = geom
+    dt = DT.get(fmt, np.uint8)
+    n = vali.Surface.Make(vali.PixelFormat[fmt], sw, sh, gpu).HostSize // np.dtype(dt).itemsize
+    rng = np.random.default_rng(sw * 7 + dh)
+    host = (rng.random(n) * (1000 if dt == np.uint16 else 255)).astype(dt)
+    mode = vali.Interpolation.LANCZOS if interp == "lanczos" else vali.Interpolation.CUBIC
+    want = oracle.resize_surface(host, fmt, sw, sh, dw, dh, interp)
+    assert np.array_equal(roundtrip(vali, gpu, fmt, host, sw, sh, dw, dh, interp=mode), want)
+    with vali.tuning.Override(RESIZE_POINT=0):           # the general columns-first form where the 2:1 one applies
+        assert np.array_equal(roundtrip(vali, gpu, fmt, host, sw, sh, dw, dh, interp=mode), want)
+    with vali.tuning.Override(RESIZE_FORCE_GATHER=1):    # one output element per thread
+        assert np.array_equal(roundtrip(vali, gpu, fmt, host, sw, sh, dw, dh, interp=mode), want)
+
+
+@pytest.mark.parametrize("rows_mode", [0, 1, 2, 3])
+def test_columns_first_batch_and_rows_per_wave(vali, gpu, oracle, rows_mode):
+    """a batch (every frame through the same launch) under every rows-per-wave form; float planes skip idle slots
+    instead of multiplying by zero: an infinity next to the window must not leak into it"""
+    sw, sh, dw, dh, n = 1280, 722, 640, 364, 5
+    rng = np.random.default_rng(77)
+    frames = [rng.integers(0, 256, sw * sh * 3 // 2, dtype=np.uint8) for _ in range(2)]
+    srcs = [vali.Surface.Make(vali.NV12, sw, sh, gpu) for _ in range(n)]
+    dsts = [vali.Surface.Make(vali.NV12, dw, dh, gpu) for _ in range(n)]
+    for i, s in enumerate(srcs):
+        assert vali.PyFrameUploader(gpu).Run(frames[i % 2], s)[0]
+    with vali.tuning.Override(RESIZE_NO_SEPARABLE=rows_mode):
+        assert vali.PySurfaceResizer(vali.NV12, gpu).RunBatch(srcs, dsts) == (True, vali.TaskExecInfo.SUCCESS)
+    wants = [oracle.resize_surface(f, "NV12", sw, sh, dw, dh, "lanczos") for f in frames]
+    for i, d in enumerate(dsts):
+        out = np.zeros(d.HostSize, np.uint8)
+        assert vali.PySurfaceDownloader(gpu).Run(d, out)[0]
+        assert np.array_equal(out, wants[i % 2])
+    # float plane with infinities and NaNs sprinkled in: bit-identical to the oracle, NaN payloads aside
+    fw, fh = 400, 300
+    host = rng.random(fw * fh * 3).astype(np.float32)
+    host[rng.integers(0, host.size, 40)] = np.inf
+    host[rng.integers(0, host.size, 10)] = -np.inf
+    with vali.tuning.Override(RESIZE_NO_SEPARABLE=rows_mode):
+        got = roundtrip(vali, gpu, "RGB_32F", host, fw, fh, 180, 140, interp=vali.Interpolation.LANCZOS)
+    want = oracle.resize_surface(host, "RGB_32F", fw, fh, 180, 140, "lanczos")
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan) and np.array_equal(got[~nan].view(np.uint32), want[~nan].view(np.uint32))
