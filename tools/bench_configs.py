@@ -22,10 +22,28 @@ DEV = 0
 PEAK = 8000.0
 
 
+WORKING_SET = 1.5 * 2 ** 30   # distinct surface pairs cycled per timed loop, against the 256 MiB Infinity Cache
+
+
+def sets_needed(bytes_per_batch):
+    """how many distinct src/dst batches a timed loop must rotate through so that it touches >= 1.5 GiB between two
+    visits of the same surface (FETCH_SIZE / WRITE_SIZE count Infinity-Cache hits, so the counters cannot show it)"""
+    return max(1, -(-int(WORKING_SET) // int(bytes_per_batch)))
+
+
 def timed(stream, fn, reps, warm=3, warm_s=0.15):
-    """HIP-event time per call of `fn` on `stream` (ms) and host time per call (ms).  Untimed warm-up: at least `warm` calls
-    AND `warm_s` seconds -- the first launches on freshly allocated surfaces of a fresh process measured 8-10 % slow
-    (rotate 2.62 vs 2.40 us, fused UD 4.19 vs 3.80: clocks and TLBs), whatever the kernel variant."""
+    """HIP-event time per call on `stream` (ms) and host time per call (ms).  `fn` is a callable or a LIST of callables
+    that is cycled (one per rotating set of surfaces).  Untimed warm-up: at least `warm` calls AND `warm_s` seconds -- the
+    first launches on freshly allocated surfaces of a fresh process measured 8-10 % slow (rotate 2.62 vs 2.40 us, fused UD
+    4.19 vs 3.80: clocks and TLBs), whatever the kernel variant."""
+    if isinstance(fn, (list, tuple)):
+        fns, state = list(fn), [0]
+        reps = -(-reps // len(fns)) * len(fns)    # whole cycles
+
+        def fn():
+            fns[state[0] % len(fns)]()
+            state[0] += 1
+        warm = max(warm, len(fns))
     t_w = time.perf_counter()
     k = 0
     while k < warm or time.perf_counter() - t_w < warm_s:
@@ -75,7 +93,7 @@ def hl1080(n=1024):
     ms, _ = timed(cvt.Stream, lambda: cvt.RunBatchAsync(batch, cc_ctx=cc), 20)
     return {"config": f"NV12->RGB 1920x1080, batch={n}, one launch (the headline kernel at 1080p)", "kernel": "k_nv12_rgb8",
             "frames_per_s": round(n / (ms * 1e-3), 1), "us_per_frame": round(ms * 1e3 / n, 3),
-            "bytes_moved_per_frame": int(w * h * 4.5), "roofline": roofline("hl1080", w * h * 4.5, n, ms)}
+            "bytes_moved_per_frame": int(w * h * 4.5), "roofline": roofline("hl1080", w * h * 4.5, n, ms, 1)}
 
 
 def cfg2():
@@ -127,91 +145,114 @@ def cfg2():
 TRAFFIC = None
 
 
-def roofline(key, bytes_per_frame, n, ms):
+def roofline(key, bytes_per_frame, n, ms, sets=1):
     """HBM roofline entry of one secondary kernel: `achieved` = the bytes the kernel really has to move (stated per
     config) / its HIP-event time; `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes
     (profiles/r02_secondary_traffic.json, tools/profile_secondary.py), when there is an entry for this config."""
     global TRAFFIC
     if TRAFFIC is None:
-        f = Path(__file__).resolve().parent.parent / "profiles" / "r02_secondary_traffic.json"
-        TRAFFIC = json.loads(f.read_text()) if f.exists() else {}
+        prof = Path(__file__).resolve().parent.parent / "profiles"
+        f = next((q for q in (prof / "r03_secondary_traffic.json", prof / "r02_secondary_traffic.json") if q.exists()), None)
+        TRAFFIC = json.loads(f.read_text()) if f else {}
     gbps = bytes_per_frame * n / (ms * 1e-3) / 1e9
     t = TRAFFIC.get(key, {})
     return {"bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK, "unit": "GB/s", "frac": round(gbps / PEAK, 4),
             "bytes_per_launch": int(bytes_per_frame * n),
+            "working_set_bytes": int(bytes_per_frame * n * sets), "surface_sets_cycled": sets,
             "traffic": t.get("hbm_bytes_per_launch") if t.get("frames") == n else None,
             "traffic_source": t.get("source") if t.get("frames") == n else None}
+
+
+def make_sets(k, make):
+    """k independent sets of whatever `make()` builds (surfaces + a prepared batch)"""
+    return [make() for _ in range(k)]
 
 
 def cfg3(n=64):
     sw, sh, dw, dh = 3840, 2160, 1280, 720
     rs = vali.PySurfaceResizer(vali.NV12, DEV, interpolation=vali.Interpolation.LINEAR)   # config 3 names bilinear
-    srcs = [vali.Surface.Make(vali.NV12, sw, sh, DEV) for _ in range(n)]
-    dsts = [vali.Surface.Make(vali.NV12, dw, dh, DEV) for _ in range(n)]
-    fill(srcs)
-    batch = rs.PrepareBatch(srcs, dsts)
-    ms, wall = timed(rs.Stream, lambda: rs.RunBatchAsync(batch), 50)
     touched = 720 * 3840 + 360 * 3840 + 1382400  # one source row per dst row (weight of the 2nd is 0) + dst
+    k = sets_needed(touched * n)
+
+    def make():
+        srcs = [vali.Surface.Make(vali.NV12, sw, sh, DEV) for _ in range(n)]
+        dsts = [vali.Surface.Make(vali.NV12, dw, dh, DEV) for _ in range(n)]
+        fill(srcs)
+        return srcs, dsts, rs.PrepareBatch(srcs, dsts)
+    sets = make_sets(k, make)
+    ms, wall = timed(rs.Stream, [lambda b=b: rs.RunBatchAsync(b) for _, _, b in sets], 50)
     return {"config": f"cfg3 PySurfaceResizer NV12 3840x2160->1280x720 bilinear, batch={n}, one launch",
             "kernel": "k_resize_pointk<3>", "ms_per_batch": round(ms, 4), "us_per_frame": round(ms * 1e3 / n, 3),
             "frames_per_s": round(n / (ms * 1e-3), 1),
             "bytes_moved_per_frame": touched,
             "bytes_note": "exact 3x: the NPP grid samples src[3y][3x] (weights 1,0); the kernel fetches the 1080 source rows it "
                           "samples (4 147 200 B) and writes 1 382 400 B; SURVEY 8d's 13 824 000 B assumes the whole source is read",
-            "roofline": roofline("cfg3", touched, n, ms),
+            "roofline": roofline("cfg3", touched, n, ms, k),
             "speedup_vs_reading_the_whole_source_at_8TBps": round((13824000 / 8e12) / (ms * 1e-3 / n), 3)}
 
 
 def interp(n=64):
-    """A resize that really interpolates (every source row and column contributes): NV12 2160p -> 1920x1088, the
-    bilinear filter of BASELINE config 3 and the reference's own filter (Lanczos-3, the PySurfaceResizer default)."""
-    sw, sh, dw, dh = 3840, 2160, 1920, 1088
+    """A resize that really interpolates: NV12 2160p -> 1920x1088 (every source row contributes; exactly 2:1 along x, so the
+    Lanczos kernel takes its 2:1-along-x form) and -> 1936x1088 (no integer ratio on either axis: the general form), with
+    the bilinear filter of BASELINE config 3 and the reference's own filter (Lanczos-3, the PySurfaceResizer default)."""
+    sw, sh = 3840, 2160
     out = []
-    b = (sw * sh + dw * dh) * 3 // 2
-    for name, it in (("bilinear", vali.Interpolation.LINEAR), ("lanczos", vali.Interpolation.LANCZOS)):
-        rs = vali.PySurfaceResizer(vali.NV12, DEV, interpolation=it)
-        srcs = [vali.Surface.Make(vali.NV12, sw, sh, DEV) for _ in range(n)]
-        dsts = [vali.Surface.Make(vali.NV12, dw, dh, DEV) for _ in range(n)]
-        fill(srcs)
-        batch = rs.PrepareBatch(srcs, dsts)
-        ms, _ = timed(rs.Stream, lambda: rs.RunBatchAsync(batch), 20)
-        out.append({"filter": name, "kernel": "k_resize<u8, 2>" if name == "bilinear" else "k_resize_taps<u8, *, 6>",
-                    "us_per_frame": round(ms * 1e3 / n, 3), "bytes_moved_per_frame": b,
-                    "roofline": roofline("interp_" + name, b, n, ms)})
-        del srcs, dsts, batch
-    return {"config": f"interp PySurfaceResizer NV12 3840x2160->1920x1088 (non-integer ratio), batch={n}, one launch per filter",
-            "bytes_note": "whole source + destination: 12 441 600 + 3 133 440 B per frame", "results": out}
+    for (dw, dh) in ((1920, 1088), (1936, 1088)):
+        b = (sw * sh + dw * dh) * 3 // 2
+        for name, it in (("bilinear", vali.Interpolation.LINEAR), ("lanczos", vali.Interpolation.LANCZOS)):
+            if (dw, name) == (1936, "bilinear"):
+                continue
+            rs = vali.PySurfaceResizer(vali.NV12, DEV, interpolation=it)
+            k = sets_needed(b * n)
+
+            def make():
+                srcs = [vali.Surface.Make(vali.NV12, sw, sh, DEV) for _ in range(n)]
+                dsts = [vali.Surface.Make(vali.NV12, dw, dh, DEV) for _ in range(n)]
+                fill(srcs)
+                return srcs, dsts, rs.PrepareBatch(srcs, dsts)
+            sets = make_sets(k, make)
+            ms, _ = timed(rs.Stream, [lambda q=q: rs.RunBatchAsync(q) for _, _, q in sets], 20)
+            kern = "k_resize<u8, 2>" if name == "bilinear" else ("k_resize_cols_x2<u8, 12, 6, 4>" if dw == 1920 else "k_resize_cols<u8, 12, 6, 4>")
+            key = "interp_" + name + ("" if dw == 1920 else "_1936")
+            out.append({"filter": name, "geometry": f"{sw}x{sh}->{dw}x{dh}", "kernel": kern,
+                        "us_per_frame": round(ms * 1e3 / n, 3), "bytes_moved_per_frame": b,
+                        "roofline": roofline(key, b, n, ms, k)})
+            del sets
+    return {"config": f"interp PySurfaceResizer NV12 3840x2160->1920x1088 / 1936x1088 (non-integer ratios), batch={n}, one launch per filter",
+            "bytes_note": "whole source + destination: 12 441 600 + 3 133 440 (3 159 552) B per frame", "results": out}
 
 
 def cfg4(n=64):
     sw, sh, dw, dh = 3840, 2160, 1920, 1080
     ud = vali.PySurfaceUD(DEV)
     rot = vali.PySurfaceRotator(DEV, ud.Stream)
-    srcs = [vali.Surface.Make(vali.NV12, sw, sh, DEV) for _ in range(n)]
-    mids = [vali.Surface.Make(vali.RGB, dw, dh, DEV) for _ in range(n)]
-    outs = [vali.Surface.Make(vali.RGB, dh, dw, DEV) for _ in range(n)]
-    fill(srcs)
-    batch = ud.PrepareBatch(srcs, mids)
-    ms_ud, _ = timed(ud.Stream, lambda: ud.RunBatchAsync(batch), 30)
-
-    rbatch = rot.PrepareBatch(mids, outs)
-    ms_rot, wall_rot = timed(ud.Stream, lambda: rot.RunBatchAsync(rbatch, angle=90.0), 30)
-    ms_rot1, wall_rot1 = timed(ud.Stream, lambda: rot.RunAsync(mids[0], outs[0], 90.0), 200, 20)
-    fbatch = ud.PrepareBatch(srcs, outs)
-    ms_fused, _ = timed(ud.Stream, lambda: ud.RunRotatedBatchAsync(fbatch, angle=90.0), 30)
     b_ud, b_rot = 18662400, 12441600
+    k = sets_needed(b_rot * n)    # the smallest of the three working sets decides (2 sets: 1.6 / 2.4 GB)
+
+    def make():
+        srcs = [vali.Surface.Make(vali.NV12, sw, sh, DEV) for _ in range(n)]
+        mids = [vali.Surface.Make(vali.RGB, dw, dh, DEV) for _ in range(n)]
+        outs = [vali.Surface.Make(vali.RGB, dh, dw, DEV) for _ in range(n)]
+        fill(srcs)
+        return srcs, mids, outs, ud.PrepareBatch(srcs, mids), rot.PrepareBatch(mids, outs), ud.PrepareBatch(srcs, outs)
+    sets = make_sets(k, make)
+    ms_ud, _ = timed(ud.Stream, [lambda q=q[3]: ud.RunBatchAsync(q) for q in sets], 30)
+    ms_rot, wall_rot = timed(ud.Stream, [lambda q=q[4]: rot.RunBatchAsync(q, angle=90.0) for q in sets], 30)
+    mids, outs = sets[0][1], sets[0][2]
+    ms_rot1, wall_rot1 = timed(ud.Stream, lambda: rot.RunAsync(mids[0], outs[0], 90.0), 200, 20)
+    ms_fused, _ = timed(ud.Stream, [lambda q=q[5]: ud.RunRotatedBatchAsync(q, angle=90.0) for q in sets], 30)
     return {"config": f"cfg4 PySurfaceUD NV12 2160p->RGB 1080p (batch={n}, one launch) + PySurfaceRotator 90deg (batch, one launch)",
             "ud": {"kernel": "k_ud_down2<RGB>", "us_per_frame": round(ms_ud * 1e3 / n, 3), "bytes_moved_per_frame": b_ud,
-                   "roofline": roofline("cfg4_ud", b_ud, n, ms_ud)},
+                   "roofline": roofline("cfg4_ud", b_ud, n, ms_ud, k)},
             "rot": {"kernel": "k_rotate_tile<3, 90>", "us_per_frame": round(ms_rot * 1e3 / n, 3), "bytes_moved_per_frame": b_rot,
-                    "roofline": roofline("cfg4_rot", b_rot, n, ms_rot),
+                    "roofline": roofline("cfg4_rot", b_rot, n, ms_rot, k),
                     "single_call_us(stream)": round(ms_rot1 * 1e3, 3), "single_call_us(host)": round(wall_rot1 * 1e3, 3)},
             "chain": {"us_per_frame": round((ms_ud + ms_rot) * 1e3 / n, 3), "bytes_moved_per_frame": b_ud + b_rot,
-                      "roofline": roofline("cfg4_chain", b_ud + b_rot, n, ms_ud + ms_rot)},
+                      "roofline": roofline("cfg4_chain", b_ud + b_rot, n, ms_ud + ms_rot, k)},
             "fused(PySurfaceUD.RunRotatedBatch)": {"kernel": "k_ud_down2_t<90>", "us_per_frame": round(ms_fused * 1e3 / n, 3),
                                                    "bytes_moved_per_frame": b_ud,
                                                    "bytes_note": "one pass: the 6 220 800 B intermediate is neither written nor re-read",
-                                                   "roofline": roofline("cfg4_fused", b_ud, n, ms_fused),
+                                                   "roofline": roofline("cfg4_fused", b_ud, n, ms_fused, k),
                                                    "speedup_vs_chain": round((ms_ud + ms_rot) / ms_fused, 3)}}
 
 
@@ -221,15 +262,19 @@ def udgen(n=64):
     out = []
     ud = vali.PySurfaceUD(DEV)
     for (sw, sh, dw, dh) in ((1920, 1080, 1280, 720), (1920, 1080, 640, 384)):
-        srcs = [vali.Surface.Make(vali.NV12, sw, sh, DEV) for _ in range(n)]
-        dsts = [vali.Surface.Make(vali.RGB, dw, dh, DEV) for _ in range(n)]
-        fill(srcs)
-        batch = ud.PrepareBatch(srcs, dsts)
-        ms, _ = timed(ud.Stream, lambda: ud.RunBatchAsync(batch), 30)
         b = sw * sh * 3 // 2 + dw * dh * 3
+        k = sets_needed(b * n)
+
+        def make():
+            srcs = [vali.Surface.Make(vali.NV12, sw, sh, DEV) for _ in range(n)]
+            dsts = [vali.Surface.Make(vali.RGB, dw, dh, DEV) for _ in range(n)]
+            fill(srcs)
+            return srcs, dsts, ud.PrepareBatch(srcs, dsts)
+        sets = make_sets(k, make)
+        ms, _ = timed(ud.Stream, [lambda q=q: ud.RunBatchAsync(q) for _, _, q in sets], 30)
         out.append({"geometry": f"{sw}x{sh}->{dw}x{dh}", "kernel": "k_ud_nv12<u8, RGB, staged>", "us_per_frame": round(ms * 1e3 / n, 3),
-                    "bytes_moved_per_frame": b, "roofline": roofline(f"udgen_{dw}x{dh}", b, n, ms)})
-        del srcs, dsts, batch
+                    "bytes_moved_per_frame": b, "roofline": roofline(f"udgen_{dw}x{dh}", b, n, ms, k)})
+        del sets
     return {"config": f"udgen PySurfaceUD NV12 1080p -> RGB at non-2x ratios, batch={n}, one launch each",
             "bytes_note": "whole NV12 source + RGB destination", "results": out}
 
