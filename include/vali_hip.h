@@ -102,6 +102,17 @@ VALI_API const char* vali_version(void);
 
 /* cuDeviceGetCount (CudaUtils.cpp:185-205) */
 VALI_API int vali_device_count(int* count);
+/* Sizes of surfaces with subsampled chroma -- ONE rule for every entry point below: 4:2:0 formats (NV12, P10, P12,
+ * YUV420, YUV420_10BIT) need an even width AND height, YUV422 an even width (their chroma planes hold W/2 x H/2 resp.
+ * W/2 x H samples; the reference allocates with integer division and would read past them).  VALI_ERR_INVALID_ARG
+ * otherwise; python_vali reports (False, TaskExecInfo.INVALID_INPUT) at Run time -- Surface.Make itself, like the
+ * reference's, allocates any size. */
+
+/* cuCtxPushCurrent of the reference's CudaCtxPush (CudaUtils.hpp:29-47), without the pop: makes `device` the calling
+ * thread's current device.  Every entry point that takes a stream runs on the STREAM's device; the null stream has
+ * none and means "the legacy default stream of the thread's current device" -- a host that is handed stream 0 together
+ * with a GPU index (python_vali's Task(gpu_id, stream) constructors) calls this first. */
+VALI_API int vali_device_set(int device);
 /* device of a device pointer: GetDeviceIdByDptr (CudaUtils.cpp:150-163) */
 VALI_API int vali_ptr_device(const void* dptr, int* device);
 

@@ -105,3 +105,67 @@ int vali_oracle_nv12_to_rgb_simd_mt(const vali_surface* src, const vali_surface*
   }
   return rc;
 }
+
+/*
+ * The CPU baseline of bench.py, NUMA-fair: every OpenMP thread converts ITS OWN frame -- source copied from the template
+ * and destination first-touched by the thread itself, so both live on the thread's memory node -- over and over for
+ * `seconds`, and the function returns the total number of frames converted.  (Round 2 handed all threads the same
+ * read-only inputs and outputs first-touched by one thread: 20 % parallel efficiency on a 2-socket host, the second
+ * socket's threads pulling every byte across the fabric.)  Threads are pinned when the caller exports
+ * OMP_PROC_BIND=close / OMP_PLACES=threads before the OpenMP runtime starts (bench.py does).
+ */
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+long long vali_oracle_nv12_to_rgb_bench(const uint8_t* nv12, int width, int height, const vali_csc* csc, int threads,
+                                         double seconds, int simd, double* elapsed) {
+  if (!nv12 || !csc || width <= 0 || height <= 0 || (width & 1) || (height & 1))
+    return -1;
+  long long total = 0;
+  double t_all = 0.0;
+  const size_t src_bytes = (size_t)width * height * 3 / 2, dst_bytes = (size_t)width * height * 3;
+#ifdef _OPENMP
+  if (threads < 1)
+    threads = 1;
+#pragma omp parallel num_threads(threads) reduction(+ : total) reduction(max : t_all)
+#endif
+  {
+    uint8_t* in = (uint8_t*)malloc(src_bytes);
+    uint8_t* out = (uint8_t*)malloc(dst_bytes);
+    long long mine = 0;
+    if (in && out) {
+      memcpy(in, nv12, src_bytes);   /* first touch by the thread that will read it */
+      memset(out, 0, dst_bytes);
+      vali_surface s, d;
+      memset(&s, 0, sizeof s);
+      memset(&d, 0, sizeof d);
+      s.plane[0] = in; s.plane[1] = in + (size_t)width * height; s.pitch[0] = s.pitch[1] = width;
+      s.width = width; s.height = height; s.format = VALI_FMT_NV12;
+      d.plane[0] = out; d.pitch[0] = 3 * width; d.width = width; d.height = height; d.format = VALI_FMT_RGB;
+      (simd ? vali_oracle_nv12_to_rgb_simd : vali_oracle_nv12_to_rgb)(&s, &d, csc); /* untimed: page tables, caches */
+#ifdef _OPENMP
+#pragma omp barrier
+      const double t0 = omp_get_wtime();
+      double t = t0;
+      while (t - t0 < seconds) {
+        (simd ? vali_oracle_nv12_to_rgb_simd : vali_oracle_nv12_to_rgb)(&s, &d, csc);
+        ++mine;
+        t = omp_get_wtime();
+      }
+      t_all = t - t0;
+#else
+      (void)seconds;
+      mine = 1;
+#endif
+    }
+    free(in);
+    free(out);
+    total += mine;
+  }
+  if (elapsed)
+    *elapsed = t_all;
+  return total;
+}

@@ -22,8 +22,9 @@ def test_raw_decoder_cpu_mode(vali):
 def test_compressed_input_and_encoders_raise(vali, tmp_path):
     with pytest.raises(RuntimeError):
         vali.PyDecoder(str(tmp_path / "movie.mp4"), {}, gpu_id=-1)
-    with pytest.raises(RuntimeError):
-        vali.PyNvEncoder({}, 0)
+    if not vali.codecs.have_av():
+        with pytest.raises(RuntimeError, match="PyAV"):      # the only condition under which the encoder class raises
+            vali.PyNvEncoder({"s": "64x48"}, 0)
     with pytest.raises(ValueError):                              # TaskNvJpegEncode.cpp:123
         vali.NvJpegEncodeContext(90, vali.NV12)
     ctx = vali.NvJpegEncodeContext(90, vali.RGB)
@@ -185,3 +186,98 @@ def test_jpeg_encoder_cpu_fallback(vali, gpu, oracle, fmt):
     # all or nothing: a surface of another format fails the whole call (PyNvJpegEncoder.cpp:66-69)
     other = vali.Surface.Make(vali.BGR if fmt != "BGR" else vali.RGB, w, h, gpu)
     assert enc.Run(ctx, [dst, other]) == ([], vali.TaskExecInfo.FAIL)
+
+
+# ---- PacketData / SeekContext (VALI.cpp:216-279) and the encoder over PyAV -------------------------------------------
+def test_packet_data_and_seek_context_exist_and_drive_the_raw_decoder(vali, tmp_path):
+    pd = vali.PacketData()
+    assert (pd.key, pd.pts, pd.dts, pd.pos, pd.bsl, pd.duration) == (0, 0, 0, 0, 0, 0) and "pts:" in repr(pd)
+    by_frame, by_ts = vali.SeekContext(3), vali.SeekContext(0.2)
+    assert (by_frame.seek_frame, by_ts.seek_tssec) == (3, 0.2) and vali.SeekContext(seek_ts=1.5).seek_tssec == 1.5
+    with pytest.raises(TypeError):
+        vali.SeekContext()
+    w, h, n = 32, 16, 6
+    frames = np.arange(n * w * h * 3 // 2, dtype=np.uint32).astype(np.uint8).reshape(n, -1)
+    path = tmp_path / "clip.yuv"
+    frames.tofile(path)
+    dec = vali.PyDecoder(str(path), {"video_size": f"{w}x{h}", "framerate": "10"}, gpu_id=-1)
+    out = np.ndarray(shape=(0,), dtype=np.uint8)
+    assert dec.DecodeSingleFrame(out, pd) == (True, vali.TaskExecInfo.SUCCESS) and pd.pts == 0 and pd.key == 1
+    assert dec.DecodeSingleFrame(out, pd, by_frame)[0] and np.array_equal(out, frames[3]) and pd.pts == 3   # reference-style loop
+    assert dec.DecodeSingleFrame(out, pd, by_ts)[0] and np.array_equal(out, frames[2])                     # 0.2 s at 10 fps
+    assert dec.DecodeSingleFrame(out, pd)[0] and np.array_equal(out, frames[3])
+
+
+class _FakeEncoder:
+    """the handful of av.CodecContext attributes PyNvEncoder touches; a 'packet' is the frame's first 8 bytes, one frame late"""
+
+    def __init__(self):
+        self.options, self._held = {}, None
+
+    def encode(self, frame):
+        out = [] if self._held is None else [self._held]
+        self._held = None if frame is None else bytes(frame.data[:8])
+        return out
+
+
+@pytest.mark.gpu
+def test_video_encoder_through_the_pyav_adapter(vali, gpu, monkeypatch):
+    import sys
+    import types
+    made = []
+
+    def create(name, mode):
+        assert mode == "w"
+        if name == "libx264":
+            raise ValueError("no such encoder")        # falls through to the next name
+        made.append(name)
+        return _FakeEncoder()
+    frame_cls = types.SimpleNamespace(from_ndarray=lambda a, format: types.SimpleNamespace(data=a.reshape(-1).tobytes(), pts=0))
+    monkeypatch.setitem(sys.modules, "av", types.SimpleNamespace(CodecContext=types.SimpleNamespace(create=create), VideoFrame=frame_cls))
+    w, h = 64, 48
+    enc = vali.PyNvEncoder({"s": f"{w}x{h}", "codec": "h264", "fps": "25", "bitrate": "2M", "gop": "30", "preset": "fast"}, gpu)
+    assert made == ["h264"] and (enc.Width, enc.Height, enc.Format) == (w, h, vali.NV12) and enc.FrameSizeInBytes == w * h * 3 // 2
+    surf = vali.Surface.Make(vali.NV12, w, h, gpu)
+    rng = np.random.default_rng(3)
+    pkt = np.ndarray(shape=(0,), dtype=np.uint8)
+    sent = []
+    for i in range(3):
+        nv12 = rng.integers(0, 256, w * h * 3 // 2, dtype=np.uint8)
+        assert vali.PyFrameUploader(gpu).Run(nv12, surf)[0]
+        sent.append(nv12[:8].copy())
+        got = enc.EncodeSingleSurface(surf, pkt)
+        assert got == (i > 0)                           # the encoder holds one frame back: False is "nothing yet", not an error
+        if got:
+            assert np.array_equal(pkt, sent[i - 1])     # luma bytes survive the NV12 -> planar repack in front of the codec
+    assert enc.Flush(pkt) and np.array_equal(pkt, sent[2]) and not enc.Flush(pkt)
+    assert not enc.EncodeSingleSurface(vali.Surface.Make(vali.NV12, 32, 32, gpu), pkt)      # wrong size
+    with pytest.raises(RuntimeError):
+        vali.PyNvEncoder({"codec": "h264"}, gpu)        # no size
+
+
+def test_pyav_frames_are_repacked_from_their_planes(vali):
+    """_frame_to_flat builds nv12 / p010le / planar layouts from the PLANES of a planar frame (line_size > width honoured): no
+    reliance on to_ndarray(format='p010le'), which several PyAV releases reject"""
+    import types
+    from vali_amd.codecs import _frame_to_flat
+    w, h, ls = 16, 8, 24
+
+    def frame(dt, name):
+        rng = np.random.default_rng(9)
+        planes, packed = [], []
+        for pw, ph in ((w, h), (w // 2, h // 2), (w // 2, h // 2)):
+            a = rng.integers(0, 1024 if dt == np.uint16 else 256, (ph, pw)).astype(dt)
+            pad = np.zeros((ph, ls // (2 if pw < w else 1) * dt().itemsize), np.uint8)
+            pad[:, :pw * dt().itemsize] = a.view(np.uint8).reshape(ph, -1)
+            planes.append(pad.tobytes())
+            packed.append(a.reshape(-1))
+        f = types.SimpleNamespace(planes=planes, format=types.SimpleNamespace(name=name))
+        f.reformat = lambda format: f
+        return f, packed
+    f8, (y, u, v) = frame(np.uint8, "yuv420p")
+    assert np.array_equal(_frame_to_flat(f8, "yuv420p", w, h), np.concatenate([y, u, v]))
+    uv = np.empty(u.size * 2, np.uint8); uv[0::2], uv[1::2] = u, v
+    assert np.array_equal(_frame_to_flat(f8, "nv12", w, h), np.concatenate([y, uv]))
+    f10, (y, u, v) = frame(np.uint16, "yuv420p10le")
+    uv = np.empty(u.size * 2, np.uint16); uv[0::2], uv[1::2] = u, v
+    assert np.array_equal(_frame_to_flat(f10, "p010le", w, h).view(np.uint16), np.concatenate([y, uv]) << 6)

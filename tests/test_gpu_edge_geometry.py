@@ -144,3 +144,29 @@ def test_batches_mix_pitches_and_alignment(vali, gpu, oracle):
         n12 = oracle.resize_surface(flat, "NV12", sw, sh, dw, dh).reshape(dh * 3 // 2, dw)
         assert np.array_equal(download(vali, gpu, pre[i]), oracle.nv12_to_rgb(n12, dw, dh, oracle.csc(1), "RGB_PLANAR").reshape(-1))
     del keep
+
+
+def test_odd_sizes_of_subsampled_formats_are_refused_everywhere(vali, gpu):
+    """ONE rule (include/vali_hip.h): 4:2:0 surfaces need an even width and height, YUV422 an even width -- converter,
+    resizer, UD (single and batch), fused pre-processing all answer (False, INVALID_INPUT); Surface.Make itself allocates any
+    size like the reference's (the entry points used to disagree)."""
+    T = vali.TaskExecInfo
+    odd = vali.Surface.Make(vali.NV12, 65, 49, gpu)
+    even = vali.Surface.Make(vali.NV12, 64, 48, gpu)
+    rgb_odd, rgb = vali.Surface.Make(vali.RGB, 65, 49, gpu), vali.Surface.Make(vali.RGB, 64, 48, gpu)
+    assert vali.PySurfaceConverter(gpu).Run(odd, rgb_odd, None) == (False, T.INVALID_INPUT)
+    for interp in (vali.Interpolation.LINEAR, vali.Interpolation.LANCZOS):
+        rs = vali.PySurfaceResizer(vali.NV12, gpu, interpolation=interp)
+        assert rs.Run(odd, even) == (False, T.INVALID_INPUT)
+        assert rs.Run(even, odd) == (False, T.INVALID_INPUT)
+        assert rs.RunBatch([odd, odd], [even, even]) == (False, T.INVALID_INPUT)
+        assert rs.Run(even, vali.Surface.Make(vali.NV12, 32, 24, gpu)) == (True, T.SUCCESS)
+    ud = vali.PySurfaceUD(gpu)
+    assert ud.Run(odd, rgb) == (False, T.INVALID_INPUT)
+    assert ud.RunBatch([odd], [rgb]) == (False, T.INVALID_INPUT)
+    assert ud.RunRotatedBatch([odd], [rgb], 180.0) == (False, T.INVALID_INPUT)
+    assert ud.Run(even, rgb_odd) == (True, T.SUCCESS)          # the 4:4:4 side may have any size
+    y422 = vali.Surface.Make(vali.YUV422, 33, 20, gpu)
+    assert vali.PySurfaceResizer(vali.YUV422, gpu).Run(y422, vali.Surface.Make(vali.YUV422, 32, 21, gpu)) == (False, T.INVALID_INPUT)
+    assert vali.PySurfaceResizer(vali.YUV422, gpu).Run(vali.Surface.Make(vali.YUV422, 34, 21, gpu),
+                                                       vali.Surface.Make(vali.YUV422, 32, 19, gpu)) == (True, T.SUCCESS)

@@ -119,8 +119,31 @@ def test_tracing_on_leaves_results_alone(vali, gpu):
     assert vali.tuning.Get("ROCTX") == 0
 
 
-def test_null_stream_means_the_gpus_own_stream(vali, gpu):
-    """PySurfaceConverter(gpu_id, stream=0): a null stream carries no device, the task uses the resource
-    manager's stream of ITS gpu_id instead."""
+def test_null_stream_is_the_legacy_default_stream_of_the_tasks_gpu(vali, gpu, oracle):
+    """PySurfaceConverter(gpu_id, 0) runs on stream 0 as handed over (the reference uses the stream it is given,
+    PySurfaceConverter.cpp:33-45; torch's default stream is 0, and a caller who passes it expects ordering with their own
+    work there -- ADVICE r02); the device a null stream does not carry is the task's gpu_id, made current before every call.
+    No stream at all = the resource manager's stream."""
+    import torch
     cvt = vali.PySurfaceConverter(gpu, 0)
-    assert cvt.Stream != 0 and cvt.Stream == vali.HipResMgr.Instance().GetStream(gpu)
+    assert cvt.Stream == 0
+    assert vali.PySurfaceConverter(gpu).Stream == vali.HipResMgr.Instance().GetStream(gpu) != 0
+    w, h = 640, 360
+    rng = np.random.default_rng(5)
+    nv12 = rng.integers(0, 256, (h * 3 // 2, w), dtype=np.uint8)
+    # the source is WRITTEN on torch's default stream (0) right before the conversion reads it, the result is read by
+    # torch on stream 0 right after: no synchronisation anywhere in between
+    t_src = torch.zeros((h * 3 // 2, w), dtype=torch.uint8, device=f"cuda:{gpu}")
+    t_dst = torch.zeros((h, w * 3), dtype=torch.uint8, device=f"cuda:{gpu}")
+    src = vali.Surface.from_dlpack(t_src, vali.NV12)
+    dst = vali.Surface.from_dlpack(t_dst, vali.RGB)
+    cc = vali.ColorspaceConversionContext(vali.ColorSpace.BT_709, vali.ColorRange.MPEG)
+    host = torch.from_numpy(nv12).pin_memory()
+    for _ in range(3):
+        t_src.copy_(host, non_blocking=True)
+        assert cvt.RunAsync(src, dst, cc) == (True, vali.TaskExecInfo.SUCCESS)
+        got = t_dst.cpu().numpy()
+    from vali_amd import tasks
+    want = oracle.nv12_to_rgb(nv12, w, h, oracle.csc_from_tuple(tasks.CSC_NPP_709CSC), "RGB")
+    assert np.array_equal(got.reshape(-1), want.reshape(-1))
+    assert cvt.Run(src, dst, cc)[0] and vali.PySurfaceResizer(vali.NV12, gpu, 0).Stream == 0

@@ -11,7 +11,8 @@ import sys as _sys
 _BUILDING = "vali_amd.build" in getattr(_sys, "orig_argv", [])
 if not _BUILDING:
     from ._native import shim as _shim  # noqa: F401  (fails loudly if the HIP library is absent)
-    from .codecs import NvJpegEncodeContext, PyDecoder, PyFrameConverter, PyNvEncoder, PyNvJpegEncoder
+    from .codecs import (NvJpegEncodeContext, PacketData, PyDecoder, PyFrameConverter, PyNvEncoder, PyNvJpegEncoder,
+                         SeekContext)
     from .enums import (ColorRange, ColorSpace, ColorspaceConversionContext, DLDeviceType, Interpolation,
                         PixelFormat, TaskExecDetails, TaskExecInfo, TaskExecStatus, export_values)
     from .runtime import CudaStreamEvent, GetNumGpus, HipResMgr, StreamCapture

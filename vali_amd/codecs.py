@@ -17,7 +17,11 @@ offline.  What IS provided so pipelines written against python_vali keep running
                  (src/python_vali/src/PyFrameConverter.cpp:21-129) served by the HIP converter:
                  ndarray -> upload -> kernel -> download.  It is NOT a CPU code path.
 * PyNvJpegEncoder -- the reference's JPEG encoder API on the CPU (download + Pillow) so that pipelines keep their
-                 output side; PyNvEncoder (video) raises: no encoder in scope.
+                 output side.
+* PyNvEncoder  -- the reference's video encoder API (src/python_vali/src/PyNvEncoder.cpp:388-630) as "download + CPU
+                 FFmpeg": the surface is downloaded on the encoder's stream and handed to a libavcodec encoder through
+                 PyAV (libx264 / libx265 by default); raises RuntimeError only when PyAV is not importable.
+* PacketData / SeekContext -- the plain data classes of VALI.cpp:216-279 the decoder calls take.
 """
 from __future__ import annotations
 
@@ -56,6 +60,67 @@ def have_av() -> bool:
         return False
 
 
+class PacketData:
+    """Video frame metadata container (reference: VALI.cpp:250-279, MemoryInterfaces.hpp PacketData)."""
+
+    __slots__ = ("key", "pts", "dts", "pos", "bsl", "duration")
+
+    def __init__(self):
+        self.key = self.pts = self.dts = self.pos = self.bsl = self.duration = 0
+
+    def __repr__(self) -> str:
+        return "".join(f"{name + ':':<10}{getattr(self, name)}\n" for name in self.__slots__)
+
+
+class SeekContext:
+    """SeekContext(seek_frame: int) / SeekContext(seek_ts: float) (reference: VALI.cpp:216-248): the type of the
+    argument selects frame- or timestamp-based seeking, exactly like the two pybind11 constructors."""
+
+    def __init__(self, seek_frame=None, seek_ts=None):
+        if seek_ts is None and isinstance(seek_frame, float):
+            seek_frame, seek_ts = None, seek_frame
+        if (seek_frame is None) == (seek_ts is None):
+            raise TypeError("SeekContext(seek_frame: int) or SeekContext(seek_ts: float)")
+        self.seek_frame = -1 if seek_frame is None else int(seek_frame)
+        self.seek_tssec = -1.0 if seek_ts is None else float(seek_ts)
+
+    @property
+    def IsByNumber(self) -> bool:
+        return self.seek_frame >= 0
+
+    @property
+    def IsByTimestamp(self) -> bool:
+        return self.seek_tssec >= 0.0
+
+
+def _frame_to_flat(frame, av_fmt: str, w: int, h: int) -> np.ndarray:
+    """One decoded PyAV frame -> the flat uint8 layout of `av_fmt` (yuv420p / yuv420p10le / nv12 / p010le).  Built from
+    the PLANES of the planar form (every PyAV release exposes those), not from to_ndarray(format=...): several releases
+    reject the semi-planar and 10-bit names there.  Same colourspace in and out: a byte shuffle, never a colour conversion."""
+    ten = "10" in av_fmt
+    planar = "yuv420p10le" if ten else "yuv420p"
+    dt = np.uint16 if ten else np.uint8
+    if hasattr(frame, "reformat") and hasattr(frame, "planes"):
+        fr = frame.reformat(format=planar) if getattr(getattr(frame, "format", None), "name", planar) != planar else frame
+        planes = []
+        for i, pl in enumerate(fr.planes):
+            pw, ph = (w, h) if i == 0 else (w // 2, h // 2)
+            a = np.frombuffer(pl, np.uint8).reshape(ph, -1)[:, :pw * dt().itemsize]     # line_size >= row bytes
+            planes.append(np.ascontiguousarray(a).view(dt).reshape(-1))
+        y, u, v = planes
+    else:                                       # minimal frame objects (tests): the planar array itself
+        a = np.ascontiguousarray(frame.to_ndarray(format=planar)).view(dt).reshape(-1)
+        y, u, v = a[:w * h], a[w * h:w * h + w * h // 4], a[w * h + w * h // 4:]
+    if av_fmt in ("yuv420p", "yuv420p10le"):
+        return np.concatenate([y, u, v]).view(np.uint8)
+    uv = np.empty(u.size + v.size, dt)
+    uv[0::2], uv[1::2] = u, v
+    out = np.concatenate([y, uv])
+    if ten:                                     # P010: the 10 bits sit in the high bits of each 16-bit word
+        out = (out.astype(np.uint16) << 6).astype(np.uint16)
+    return out.view(np.uint8)
+
+
 class _AvSource:
     """Compressed input through PyAV: CPU demux + decode, one frame at a time, as flat uint8 arrays in the
     layout the reference's decoder emits -- planar YUV420[_10bit] in CPU mode, NV12 / P10 in accelerated mode
@@ -83,14 +148,35 @@ class _AvSource:
         self.color_space = self._SPACE.get(int(getattr(cc, "colorspace", 2) or 2), ColorSpace.UNSPEC)
         self.color_range = self._RANGE.get(int(getattr(cc, "color_range", 0) or 0), ColorRange.UDEF)
         self._frames = self._container.decode(self._stream)
+        self.last_error = None
+        self.last_frame = None      # the PyAV frame behind the most recent read() (pts / key frame for PacketData)
+        if "12" in pix:
+            import warnings
+            warnings.warn("PyDecoder: 12-bit source is delivered as 10-bit (P10 / YUV420_10bit), like the reference's "
+                          "decoder surfaces")
+
+    def seek(self, ctx: "SeekContext") -> None:
+        ts = ctx.seek_tssec if ctx.IsByTimestamp else ctx.seek_frame / self.framerate
+        tb = getattr(self._stream, "time_base", None)
+        self._container.seek(int(ts / float(tb)) if tb else int(ts * 1e6), stream=self._stream if tb else None)
+        self._frames = self._container.decode(self._stream)
 
     def read(self) -> Optional[np.ndarray]:
+        """next frame as a flat uint8 array, None at the end of the stream or on a decode error (last_error is set then)"""
+        self.last_error = None
         try:
             frame = next(self._frames)
         except StopIteration:
             return None
-        # same colourspace in and out: a byte shuffle (planar <-> semi-planar), never a colour conversion
-        return np.ascontiguousarray(frame.to_ndarray(format=self._av_fmt)).view(np.uint8).reshape(-1)
+        except Exception as e:       # av.error.* : invalid data, truncated file ...
+            self.last_error = e
+            return None
+        self.last_frame = frame
+        try:
+            return _frame_to_flat(frame, self._av_fmt, self.width, self.height)
+        except Exception as e:       # a pixel format this PyAV cannot reformat
+            self.last_error = e
+            return None
 
     def close(self):
         try:
@@ -152,7 +238,7 @@ class PyDecoder:
 
     def _init_stream(self, stream):
         if self._gpu_id >= 0:
-            self._stream = int(stream) if stream else HipResMgr.Instance().GetStream(self._gpu_id)
+            self._stream = int(stream) if stream is not None else HipResMgr.Instance().GetStream(self._gpu_id)
             self._uploader = PyFrameUploader(self._gpu_id, self._stream)
         else:
             self._stream = 0
@@ -171,6 +257,33 @@ class PyDecoder:
     ColorSpace = property(lambda self: self._av.color_space if self._av else ColorSpace.UNSPEC)   # raw video carries no tags
     ColorRange = property(lambda self: self._av.color_range if self._av else ColorRange.UDEF)
     HostFrameSize = property(lambda self: _host_frame_size(self._fmt, self._w, self._h))
+
+    def _seek(self, seek_ctx) -> None:
+        if seek_ctx is None:
+            return
+        if self._av is not None:
+            self._av.seek(seek_ctx)
+        else:
+            n = seek_ctx.seek_frame if seek_ctx.IsByNumber else int(round(seek_ctx.seek_tssec * self._framerate))
+            self._pos = max(0, min(int(n), self._num_frames))
+
+    def _fill(self, pkt_data) -> None:
+        """PacketData of the frame just read (the CPU stand-in knows the presentation order only)"""
+        if pkt_data is None:
+            return
+        fr = self._av.last_frame if self._av is not None else None
+        if fr is not None:
+            pkt_data.pts = int(getattr(fr, "pts", 0) or 0)
+            pkt_data.dts = int(getattr(fr, "dts", pkt_data.pts) or pkt_data.pts)
+            pkt_data.key = int(bool(getattr(fr, "key_frame", 0)))
+        else:
+            pkt_data.pts = pkt_data.dts = self._pos - 1
+            pkt_data.key, pkt_data.duration = 1, 1
+            pkt_data.pos, pkt_data.bsl = (self._pos - 1) * self._file_frame, self._file_frame
+
+    def _end(self) -> TaskExecInfo:
+        failed = self._av is not None and self._av.last_error is not None
+        return TaskExecInfo.FAIL if failed else TaskExecInfo.END_OF_STREAM
 
     def _read(self) -> Optional[np.ndarray]:
         if self._av is not None:
@@ -196,9 +309,11 @@ class PyDecoder:
                           ) -> Tuple[bool, TaskExecInfo]:
         if self.IsAccelerated:
             return False, TaskExecInfo.FAIL
+        self._seek(seek_ctx)
         data = self._read()
         if data is None:
-            return False, TaskExecInfo.END_OF_STREAM
+            return False, self._end()
+        self._fill(pkt_data)
         if frame.nbytes != data.nbytes:
             frame.resize((data.nbytes // frame.itemsize,), refcheck=False)
         frame.view(np.uint8).reshape(-1)[:] = data
@@ -217,9 +332,11 @@ class PyDecoder:
             return False, TaskExecInfo.INVALID_INPUT
         if (surf.Width, surf.Height) != (self._w, self._h) or surf.Format != self._fmt:
             return False, TaskExecInfo.INVALID_INPUT
+        self._seek(seek_ctx)
         data = self._read()
         if data is None:
-            return False, TaskExecInfo.END_OF_STREAM
+            return False, self._end()
+        self._fill(pkt_data)
         return self._uploader.Run(data, surf)
 
     def __del__(self):
@@ -265,14 +382,126 @@ class PyFrameConverter:
         return self._down.Run(self._dst, dst)
 
 
-class _NoEncoder:
-    def __init__(self, *args, **kwargs):
-        raise RuntimeError(f"{type(self).__name__}: video encode ASICs are not supported on "
-                           "this backend (out of scope of the surface-processing path)")
+class PyNvEncoder:
+    """Video encode with the reference's call surface (src/python_vali/src/PyNvEncoder.cpp:388-630), as the north_star
+    asks: "stubbed to CPU FFmpeg".  The surface is downloaded on the encoder's stream and compressed by libavcodec through
+    PyAV; RuntimeError when PyAV is not importable (the library itself has no encoder).
 
+    settings (strings, like the reference's): 's': 'WxH' (required), 'codec': 'h264' | 'hevc' (default h264), 'fps',
+    'bitrate' (e.g. '5M'), 'gop', 'preset'; anything else is passed to the codec as a private option.
+    EncodeSingleSurface(surface, packet[, sei][, sync][, append]) -> True when `packet` received bytes (encoders buffer
+    frames: False is not an error); Flush(packets) drains."""
 
-class PyNvEncoder(_NoEncoder):
-    """reference: src/python_vali/src/PyNvEncoder.cpp (NVENC)."""
+    _CODECS = {"h264": ("libx264", "h264"), "hevc": ("libx265", "hevc"), "h265": ("libx265", "hevc")}
+
+    def __init__(self, settings, gpu_id: int, *args, format: PixelFormat = None, verbose: bool = False, stream=None):  # noqa: A002
+        rest = list(args)
+        if rest and not isinstance(rest[0], PixelFormat) and isinstance(rest[0], int) and stream is None:
+            stream = rest.pop(0)                   # (settings, gpu_id, stream, format, verbose)
+        if rest and format is None:
+            format = rest.pop(0)                   # noqa: A001
+        if rest:
+            verbose = bool(rest.pop(0))
+        self._fmt = PixelFormat(format) if format is not None else F.NV12
+        if self._fmt not in (F.NV12, F.YUV420):
+            raise RuntimeError(f"PyNvEncoder: unsupported input format {self._fmt.name} (NV12 or YUV420)")
+        if not have_av():
+            raise RuntimeError("PyNvEncoder: video encode needs PyAV (`import av`, FFmpeg's Python binding), which is not "
+                               "importable here; encode ASICs are outside the surface-processing path")
+        import av
+        from fractions import Fraction
+
+        st = {str(k): str(v) for k, v in dict(settings).items()}
+        size = st.pop("s", None) or st.pop("video_size", None)
+        if not size or "x" not in size.lower():
+            raise RuntimeError("PyNvEncoder: settings['s'] = 'WxH' is required")
+        self._w, self._h = (int(v) for v in size.lower().split("x"))
+        names = self._CODECS.get(st.pop("codec", "h264").lower())
+        if names is None:
+            raise RuntimeError("PyNvEncoder: codec must be h264 or hevc")
+        ctx = None
+        for name in names:
+            try:
+                ctx = av.CodecContext.create(name, "w")
+                break
+            except Exception:           # this FFmpeg build lacks the encoder: try the next name
+                continue
+        if ctx is None:
+            raise RuntimeError(f"PyNvEncoder: no {names[-1]} encoder in this FFmpeg build")
+        fps = int(float(st.pop("fps", "30")))
+        ctx.width, ctx.height = self._w, self._h
+        ctx.pix_fmt = "yuv420p"
+        ctx.time_base = Fraction(1, max(fps, 1))
+        try:
+            ctx.framerate = Fraction(max(fps, 1), 1)
+        except Exception:
+            pass
+        if "bitrate" in st:
+            b = st.pop("bitrate").upper()
+            ctx.bit_rate = int(float(b.rstrip("KM")) * (1000 if b.endswith("K") else 1000000 if b.endswith("M") else 1))
+        if "gop" in st:
+            ctx.gop_size = int(st.pop("gop"))
+        ctx.options = st
+        self._ctx, self._av, self._n = ctx, av, 0
+        self._gpu_id = int(gpu_id)
+        self._stream = int(stream) if stream is not None else HipResMgr.Instance().GetStream(self._gpu_id)
+        self._down = PySurfaceDownloader(self._gpu_id, self._stream)
+        self._verbose = verbose
+
+    Width = property(lambda self: self._w)
+    Height = property(lambda self: self._h)
+    Format = property(lambda self: self._fmt)
+    FrameSizeInBytes = property(lambda self: _host_frame_size(self._fmt, self._w, self._h))
+    Capabilities = property(lambda self: {})       # NV_ENC_CAPS of an NVENC session: none on this backend
+
+    @staticmethod
+    def _emit(packets, out: np.ndarray, append: bool) -> bool:
+        data = b"".join(bytes(p) for p in packets)
+        if not data and not append:
+            out.resize((0,), refcheck=False)
+            return False
+        new = np.frombuffer(data, np.uint8)
+        keep = out.copy() if append else out[:0].copy()
+        out.resize((keep.size + new.size,), refcheck=False)
+        out[:keep.size], out[keep.size:] = keep, new
+        return bool(data)
+
+    def EncodeSingleSurface(self, surface: Surface, packet: np.ndarray, *args, sei=None, sync=False, append=False) -> bool:
+        """EncodeSingleSurface(surface, packet[, sei][, sync][, append]): the reference's five overloads
+        (PyNvEncoder.cpp:496-602); `sei` is accepted and ignored (no SEI insertion through libavcodec here)."""
+        rest = list(args)
+        if rest and isinstance(rest[0], np.ndarray):
+            sei = rest.pop(0)
+        if rest:
+            sync = bool(rest.pop(0))
+        if rest:
+            append = bool(rest.pop(0))
+        if surface is None or surface.IsEmpty or surface.Format != self._fmt or \
+                (surface.Width, surface.Height) != (self._w, self._h):
+            return False
+        host = np.zeros(surface.HostSize, np.uint8)
+        if not self._down.Run(surface, host)[0]:
+            return False
+        w, h = self._w, self._h
+        if self._fmt == F.NV12:                    # -> planar 4:2:0, the one layout every libavcodec encoder takes
+            y, uv = host[:w * h], host[w * h:]
+            host = np.concatenate([y, uv[0::2], uv[1::2]])
+        frame = self._av.VideoFrame.from_ndarray(host.reshape(h * 3 // 2, w), format="yuv420p")
+        frame.pts = self._n
+        self._n += 1
+        got = self._emit(self._ctx.encode(frame), packet, append)
+        if sync and not got:                       # the reference's sync mode returns every frame's packet at once
+            got = self._emit(self._ctx.encode(None), packet, append)
+        return got
+
+    def Flush(self, packets: np.ndarray) -> bool:
+        return self._emit(self._ctx.encode(None), packets, False)
+
+    def FlushSinglePacket(self, packets: np.ndarray) -> bool:
+        return self.Flush(packets)
+
+    def Reconfigure(self, settings, force_idr: bool = False, reset_encoder: bool = False, verbose: bool = False) -> bool:
+        return False                               # libavcodec contexts are not reconfigurable in flight
 
 
 class NvJpegEncodeContext:

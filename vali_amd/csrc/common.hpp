@@ -76,6 +76,21 @@ inline bool planes_fit_32bit(const vali_surface& s) {
   return true;
 }
 
+// ONE rule for sizes of surfaces with subsampled chroma, applied by every entry point: the chroma planes hold
+// (W / 2) x (H / 2) samples (4:2:0: NV12, P10, P12, YUV420, YUV420_10bit) or (W / 2) x H (YUV422), so W (and H) must be
+// even -- an odd size would address a chroma sample the plane does not have.  VALI_ERR_INVALID_ARG otherwise
+// (python_vali: (False, TaskExecInfo.INVALID_INPUT)).
+inline bool subsampled_sizes_ok(int format, int width, int height) {
+  switch (format) {
+  case VALI_FMT_NV12: case VALI_FMT_P10: case VALI_FMT_P12: case VALI_FMT_YUV420: case VALI_FMT_YUV420_10BIT:
+    return ((width | height) & 1) == 0;
+  case VALI_FMT_YUV422:
+    return (width & 1) == 0;
+  default:
+    return true;
+  }
+}
+
 } // namespace vali
 
 // First lines of every operator entry point: trace range, then the device of the stream (the current device

@@ -235,6 +235,7 @@ PYBIND11_MODULE(_vali_shim, m) {
     (void)vali_device_count(&n); // "no device" is a count of 0, not an exception
     return n;
   });
+  m.def("device_set", [](int device) { check(vali_device_set(device), "device_set"); });
   m.def("ptr_device", [](uintptr_t p) {
     int d = -1;
     check(vali_ptr_device(P(p), &d), "vali_ptr_device");

@@ -377,9 +377,10 @@ __global__ void __launch_bounds__(kBlock) k_resize_pointk(const ResizeArgs a) {
       const uint8_t* srow = v.sp + (u32)(y * ky * v.spitch) + (u32)(xb * K);
 #pragma unroll
       for (int i = 0; i < K; ++i) {
-        // a chunk cut by the end of the row may reach past the pitch with its later loads: those bytes feed no
-        // dst byte that exists (the pitch is a multiple of 16: whole 16-byte pieces are inside or outside)
-        const uint4 q = xb * K + 16 * i + 16 <= v.spitch ? gload16(srow + 16 * i) : make_uint4(0, 0, 0, 0);
+        // a chunk cut by the end of the ROW (not of the pitch: a borrowed view may end where its last row ends) is
+        // fetched byte by byte; pieces past the row feed no dst byte that exists
+        const int valid = sbytes - (xb * K + 16 * i);
+        const uint4 q = valid >= 16 ? gload16(srow + 16 * i) : load_bytes16(srow + 16 * i, valid);
         w[r][4 * i] = q.x; w[r][4 * i + 1] = q.y; w[r][4 * i + 2] = q.z; w[r][4 * i + 3] = q.w;
       }
     }
@@ -399,7 +400,6 @@ __global__ void __launch_bounds__(kBlock) k_resize_pointk(const ResizeArgs a) {
     }
     return;
   }
-  (void)sbytes;
   for (int r = 0; r < 2; ++r) { // foreign rows: byte by byte
     const int y = y0 + 16 * r;
     if (y >= v.dh)
@@ -596,6 +596,8 @@ static int resize_one(const vali_surface* src, const vali_surface* dst, int inte
     VALI_REQUIRE(src->format == dst->format, "src/dst format mismatch");
   }
   VALI_REQUIRE(src->width > 0 && src->height > 0 && dst->width > 0 && dst->height > 0, "empty surface");
+  VALI_REQUIRE(subsampled_sizes_ok(src->format, src->width, src->height) && subsampled_sizes_ok(dst->format, dst->width, dst->height),
+               "surfaces with subsampled chroma need a width / height that is a multiple of the subsampling");
   VALI_REQUIRE(src->plane[0] && dst->plane[0], "null plane");
   VALI_REQUIRE(planes_fit_32bit(*src) && planes_fit_32bit(*dst), "plane of 4 GiB or more");
   if (interpolation != VALI_INTERP_LINEAR && interpolation != VALI_INTERP_LANCZOS &&
@@ -623,6 +625,8 @@ static int resize_many(const vali_surface* d_src, const vali_surface* d_dst, int
                        vali_stream_t stream, const char* entry) {
   VALI_REQUIRE(d_src && d_dst, "null argument");
   VALI_REQUIRE(src_width > 0 && src_height > 0 && dst_width > 0 && dst_height > 0, "empty geometry");
+  VALI_REQUIRE(subsampled_sizes_ok(src_format, src_width, src_height) && subsampled_sizes_ok(format, dst_width, dst_height),
+               "surfaces with subsampled chroma need a width / height that is a multiple of the subsampling");
   VALI_REQUIRE(n >= 0 && n <= 65535, "batch size out of range (0..65535)");
   if (interpolation != VALI_INTERP_LINEAR && interpolation != VALI_INTERP_LANCZOS &&
       interpolation != VALI_INTERP_CUBIC)

@@ -187,6 +187,11 @@ int vali_device_count(int* count) {
   return VALI_OK;
 }
 
+int vali_device_set(int device) {
+  VALI_HIP_CHECK(hipSetDevice(device));
+  return VALI_OK;
+}
+
 int vali_ptr_device(const void* dptr, int* device) {
   VALI_REQUIRE(dptr && device, "null argument");
   hipPointerAttribute_t attr;

@@ -1649,6 +1649,7 @@ int vali_ud_nv12(const vali_surface* src, const vali_surface* dst, vali_stream_t
   VALI_REQUIRE(src && dst, "null argument");
   VALI_REQUIRE(src->width >= 2 && src->height >= 2 && dst->width > 0 && dst->height > 0,
                "empty surface");
+  VALI_REQUIRE(subsampled_sizes_ok(src->format, src->width, src->height), "4:2:0 surfaces need even width and height");
   VALI_REQUIRE(src->plane[0] && src->plane[1] && dst->plane[0], "null plane");
   VALI_REQUIRE(planes_fit_32bit(*src) && planes_fit_32bit(*dst), "plane of 4 GiB or more");
   if (dst->format != VALI_FMT_RGB && dst->format != VALI_FMT_RGB_32F)
@@ -1666,6 +1667,7 @@ int vali_ud_nv12_rot(const vali_surface* src, const vali_surface* dst, int quart
   VALI_REQUIRE(src && dst, "null argument");
   VALI_REQUIRE(src->width >= 2 && src->height >= 2 && dst->width > 0 && dst->height > 0,
                "empty surface");
+  VALI_REQUIRE(subsampled_sizes_ok(src->format, src->width, src->height), "4:2:0 surfaces need even width and height");
   VALI_REQUIRE(src->plane[0] && src->plane[1] && dst->plane[0], "null plane");
   VALI_REQUIRE(planes_fit_32bit(*src) && planes_fit_32bit(*dst), "plane of 4 GiB or more");
   UdArgs a = {};
@@ -1681,6 +1683,7 @@ int vali_ud_nv12_rot_batch(const vali_surface* d_src, const vali_surface* d_dst,
                            int quarter_turns, vali_stream_t stream) {
   VALI_REQUIRE(d_src && d_dst, "null argument");
   VALI_REQUIRE(src_width >= 2 && dst_width > 0 && dst_height > 0, "empty geometry");
+  VALI_REQUIRE((src_width & 1) == 0, "4:2:0 surfaces need even width and height");
   VALI_REQUIRE(n >= 0 && n <= 65535, "batch size out of range (0..65535)");
   if (n == 0)
     return VALI_OK;
@@ -1697,6 +1700,7 @@ int vali_ud_nv12_batch(const vali_surface* d_src, const vali_surface* d_dst, int
                        vali_stream_t stream) {
   VALI_REQUIRE(d_src && d_dst, "null argument");
   VALI_REQUIRE(src_width >= 2 && dst_width > 0 && dst_height > 0, "empty geometry");
+  VALI_REQUIRE((src_width & 1) == 0, "4:2:0 surfaces need even width and height");
   VALI_REQUIRE(n >= 0 && n <= 65535, "batch size out of range (0..65535)");
   if (n == 0)
     return VALI_OK;

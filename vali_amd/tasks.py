@@ -254,10 +254,14 @@ _CONVERSIONS = {
 class _SurfaceTask:
     def __init__(self, gpu_id: int, stream=None):
         self._gpu_id = int(gpu_id)
-        # stream=None and the NULL stream both mean "this GPU's stream from the resource manager": a null
-        # hipStream_t carries no device, so a task built with (gpu_id=1, stream=0) would otherwise launch on
-        # whatever device happens to be current on the calling thread
-        self._stream = (int(stream) if stream else HipResMgr.Instance().GetStream(self._gpu_id))
+        # stream=None: this GPU's stream from the resource manager (the reference's one-argument constructors,
+        # CudaResMgr::GetStream).  An explicit stream is used as handed over (PySurfaceConverter.cpp:33-45) -- also 0,
+        # the legacy default stream: torch.cuda.current_stream().cuda_stream is 0 for torch's default stream, and a
+        # caller who passes it expects the task to be ordered with their own work there.  A null hipStream_t carries no
+        # device, so such a task makes its GPU current on the calling thread before every call (_bind_null_stream).
+        self._stream = HipResMgr.Instance().GetStream(self._gpu_id) if stream is None else int(stream)
+        if self._stream == 0:
+            self._bind_null_stream()
         self._event = CudaStreamEvent(self._stream, self._gpu_id)
         # Memo of recent successful single-surface calls: (src descriptor, dst descriptor, extra
         # key...) -> (C-ABI entry, arguments between the descriptors and the stream).
@@ -270,6 +274,20 @@ class _SurfaceTask:
         self._memo = {}
         self._batches = {}    # (src descriptors, dst descriptors) -> SurfaceBatch, see _batch_of
 
+    def _bind_null_stream(self):
+        """Tasks on the null stream: every Run* / PrepareBatch first makes the task's GPU the thread's current device
+        (vali_device_set).  Done by wrapping the bound methods of THIS instance, so tasks on real streams -- whose device
+        the library reads off the stream -- keep their call path untouched."""
+        gpu = self._gpu_id
+        for name in dir(type(self)):
+            if name.startswith("Run") or name == "PrepareBatch":
+                fn = getattr(self, name)
+
+                def call(*a, _fn=fn, **k):
+                    shim.device_set(gpu)
+                    return _fn(*a, **k)
+                setattr(self, name, call)
+
     def _batch_of(self, batch, dsts):
         """RunBatch*(srcs, dsts): the descriptor arrays of a (srcs, dsts) pair of lists are uploaded ONCE and
         kept with the task (8 most recent pairs) -- a repeated call costs no allocation, no copy and no
@@ -281,15 +299,21 @@ class _SurfaceTask:
             raise ValueError("RunBatch: pass a SurfaceBatch, or two lists (srcs, dsts)")
         srcs, dsts = list(batch), list(dsts)
         key = (tuple(s.desc() for s in srcs), tuple(d.desc() for d in dsts))
-        b = self._batches.get(key)
+        b = self._batches.pop(key, None)
         if b is None:
-            if len(self._batches) >= 8:
-                self._batches.pop(next(iter(self._batches)))
-            b = self._batches[key] = SurfaceBatch(self._gpu_id, self._stream, srcs, dsts)
+            # a miss while the stream is capturing must fail BEFORE anything is evicted: dropping a cached batch
+            # synchronises its stream (SurfaceBatch.__del__), which would invalidate the capture instead of reporting it
+            if is_capturing(self._gpu_id, self._stream):
+                raise RuntimeError("RunBatch(srcs, dsts): these lists have no prepared batch and one cannot be created "
+                                   "while the stream is capturing -- call PrepareBatch() before the capture")
+            b = SurfaceBatch(self._gpu_id, self._stream, srcs, dsts)
             # the cache must not pin the caller's surfaces (a task fed fresh lists of 512 2160p frames would hold
             # 8 x 19 GB): it keeps the descriptor arrays only; a hit needs the SAME descriptor objects, i.e. live
             # surfaces that were not re-pointed, and a freed surface's descriptors can never match a new one's
             b._keep = None
+            while len(self._batches) >= 8:                     # least recently used first (a hit re-inserts below)
+                self._batches.pop(next(iter(self._batches)))
+        self._batches[key] = b
         return b
 
     def _memo_put(self, key, fn, args, keep=None):
@@ -511,6 +535,8 @@ class PySurfaceUD(_SurfaceTask):
         q = self._quarter(angle)
         if q is None or (batch.src_format, batch.dst_format) != (F.NV12, F.RGB):
             return False, TaskExecInfo.NOT_SUPPORTED
+        if (batch.src_size[0] | batch.src_size[1]) & 1:       # the one rule for 4:2:0 sizes (include/vali_hip.h)
+            return False, TaskExecInfo.INVALID_INPUT
         d = _status(shim.ud_nv12_rot_batch(batch.d_src, batch.d_dst, batch.n, int(batch.src_format),
                                            batch.src_size[0], batch.dst_size[0], batch.dst_size[1],
                                            int(batch.dst_format), q, self._stream))
@@ -525,6 +551,8 @@ class PySurfaceUD(_SurfaceTask):
         batch = self._batch_of(batch, dsts)
         if (batch.src_format, batch.dst_format) not in _UD_CONVERSIONS:
             return False, TaskExecInfo.NOT_SUPPORTED
+        if (batch.src_size[0] | batch.src_size[1]) & 1:       # every UD source is 4:2:0: even sizes (include/vali_hip.h)
+            return False, TaskExecInfo.INVALID_INPUT
         if (batch.src_format, batch.dst_format) not in _UD_SEMIPLANAR:
             d = _status(shim.ud_planar_batch(batch.d_src, batch.d_dst, batch.n, int(batch.src_format),
                                              int(batch.dst_format), batch.src_size[0], batch.src_size[1],
