@@ -121,6 +121,11 @@ VALI_API int vali_ptr_device(const void* dptr, int* device);
 VALI_API int vali_stream_create(int device, vali_stream_t* stream);
 VALI_API int vali_stream_destroy(int device, vali_stream_t stream);
 VALI_API int vali_stream_sync(int device, vali_stream_t stream);
+/* the same guarantee -- everything issued on `stream` so far has finished -- through a host-visible completion word the
+ * stream writes (hipStreamWriteValue32 into pinned memory) and the caller spins on: 3 us less per blocking call than
+ * hipStreamSynchronize around a small kernel; falls back to it after ~150 us.  The blocking Run forms of python_vali
+ * (Run = RunAsync + event record + host wait, PySurfaceConverter.cpp:76-86) end here. */
+VALI_API int vali_stream_wait(int device, vali_stream_t stream);
 
 /* CudaStreamEvent (CudaUtils.cpp:35-68); timing enabled so bench.py can use them */
 VALI_API int vali_event_create(int device, vali_event_t* event);
@@ -369,7 +374,8 @@ enum vali_tuning_key {
   VALI_TUNE_RESIZE_NO_SEPARABLE = 10, /* Lanczos / bicubic rows per wave: 0 by launch size, 1: 8, 2: 2, 3: 32           */
   VALI_TUNE_ROWS_PER_WAVE = 11,       /* UD, bilinear / point resize, fused pre-processing: dst rows (row pairs) a wave
                                          walks: 0 by launch size (8 for batches, 4 or 2 for small launches), 2 / 4 / 8  */
-  VALI_TUNE_COUNT = 12
+  VALI_TUNE_BLOCKING_WAIT = 12,       /* vali_stream_wait: 0 completion word + spin (default), 1 hipStreamSynchronize */
+  VALI_TUNE_COUNT = 13
 };
 VALI_API int vali_tuning_set(int key, int value);
 VALI_API int vali_tuning_get(int key, int* value);

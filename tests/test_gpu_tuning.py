@@ -94,6 +94,9 @@ CASES = [
     ("ROWS_PER_WAVE", (2, 4, 8), lambda v, g: resize(v, g, 1920, 1080, 480, 270, v.Interpolation.LINEAR)),   # point form, 4x
     ("ROWS_PER_WAVE", (2, 4, 8), lambda v, g: preproc(v, g, 1280, 720, 640, 382)),
     ("ROWS_PER_WAVE", (2, 4, 8), lambda v, g: preproc(v, g, 640, 362, 640, 362)),
+    # how the blocking Run forms wait: completion word + spin (0) or hipStreamSynchronize (1)
+    ("BLOCKING_WAIT", (1,), lambda v, g: nv12_rgb(v, g, 1920, 1080, v.RGB)),
+    ("BLOCKING_WAIT", (1,), lambda v, g: ud(v, g, 1280, 720, 854, 480, v.RGB)),
 ]
 
 
@@ -147,3 +150,41 @@ def test_null_stream_is_the_legacy_default_stream_of_the_tasks_gpu(vali, gpu, or
     want = oracle.nv12_to_rgb(nv12, w, h, oracle.csc_from_tuple(tasks.CSC_NPP_709CSC), "RGB")
     assert np.array_equal(got.reshape(-1), want.reshape(-1))
     assert cvt.Run(src, dst, cc)[0] and vali.PySurfaceResizer(vali.NV12, gpu, 0).Stream == 0
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_blocking_run_returns_after_the_work_not_before(vali, gpu, oracle, mode):
+    """Run = RunAsync + host wait (PySurfaceConverter.cpp:76-86).  The wait is a completion word the stream writes into
+    pinned host memory (vali_stream_wait): a long launch (a batch of 2160p frames: past the 150 us of spinning, into the
+    hipStreamSynchronize fallback) and many short ones must all be finished when the call returns -- the result is read
+    back through a DIFFERENT stream right after, with no other synchronisation."""
+    from vali_amd._native import shim
+    w, h, n = 3840, 2160, 24
+    rng = np.random.default_rng(8)
+    nv12 = rng.integers(0, 256, (h * 3 // 2, w), dtype=np.uint8)
+    srcs = [vali.Surface.Make(vali.NV12, w, h, gpu) for _ in range(n)]
+    dsts = [vali.Surface.Make(vali.RGB, w, h, gpu) for _ in range(n)]
+    for s in srcs:
+        assert vali.PyFrameUploader(gpu).Run(nv12.reshape(-1), s)[0]
+    cc = vali.ColorspaceConversionContext(vali.ColorSpace.BT_709, vali.ColorRange.MPEG)
+    from vali_amd import tasks
+    want = oracle.nv12_to_rgb(nv12, w, h, oracle.csc_from_tuple(tasks.CSC_NPP_709CSC), "RGB").reshape(-1)
+    other = shim.stream_create(gpu)
+    down = vali.PySurfaceDownloader(gpu, other)
+    with vali.tuning.Override(BLOCKING_WAIT=mode):
+        cvt = vali.PySurfaceConverter(gpu)
+        for d in dsts:
+            shim.memset2d_async(gpu, d.Planes[0].GpuMem, d.Planes[0].Pitch, 0, w * 3, h, cvt.Stream)
+        assert cvt.RunBatch(srcs, dsts, cc) == (True, vali.TaskExecInfo.SUCCESS)
+        got = np.zeros(dsts[-1].HostSize, np.uint8)
+        assert down.Run(dsts[-1], got)[0] and np.array_equal(got, want)
+        small_s, small_d = vali.Surface.Make(vali.NV12, 64, 48, gpu), vali.Surface.Make(vali.RGB, 64, 48, gpu)
+        tiny = rng.integers(0, 256, (72, 64), dtype=np.uint8)
+        tiny_want = oracle.nv12_to_rgb(tiny, 64, 48, oracle.csc_from_tuple(tasks.CSC_NPP_709CSC), "RGB").reshape(-1)
+        for i in range(200):
+            assert vali.PyFrameUploader(gpu, cvt.Stream).Run(np.roll(tiny.reshape(-1), 0), small_s)[0]
+            shim.memset2d_async(gpu, small_d.Planes[0].GpuMem, small_d.Planes[0].Pitch, i & 0xff, 64 * 3, 48, cvt.Stream)
+            assert cvt.Run(small_s, small_d, cc)[0]
+            out = np.zeros(small_d.HostSize, np.uint8)
+            assert down.Run(small_d, out)[0] and np.array_equal(out, tiny_want)
+    shim.stream_destroy(gpu, other)

@@ -221,6 +221,7 @@ PYBIND11_MODULE(_vali_shim, m) {
                   {"TUNE_ROCTX", VALI_TUNE_ROCTX},
                   {"TUNE_RESIZE_NO_SEPARABLE", VALI_TUNE_RESIZE_NO_SEPARABLE},
                   {"TUNE_ROWS_PER_WAVE", VALI_TUNE_ROWS_PER_WAVE},
+                  {"TUNE_BLOCKING_WAIT", VALI_TUNE_BLOCKING_WAIT},
                   {"TUNE_COUNT", VALI_TUNE_COUNT}})
     m.attr(kv.first) = kv.second;
   m.def("tuning_set", [](int key, int value) { return vali_tuning_set(key, value); });
@@ -250,6 +251,9 @@ PYBIND11_MODULE(_vali_shim, m) {
   m.def("stream_destroy", [](int device, uintptr_t s) {
     check(vali_stream_destroy(device, P(s)), "vali_stream_destroy");
   });
+  m.def("stream_wait",
+        [](int device, uintptr_t s) { check(vali_stream_wait(device, P(s)), "vali_stream_wait"); },
+        py::call_guard<py::gil_scoped_release>());
   m.def("stream_sync",
         [](int device, uintptr_t s) { check(vali_stream_sync(device, P(s)), "vali_stream_sync"); },
         py::call_guard<py::gil_scoped_release>());

@@ -10,7 +10,9 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <chrono>
 #include <mutex>
+#include <unordered_map>
 
 namespace vali {
 
@@ -24,7 +26,7 @@ const TuneDef kTuneDefs[VALI_TUNE_COUNT] = {
     {"VALI_NV12_ROWPAIRS", 0}, {"VALI_WAVES_PER_CU", 0},      {"VALI_NV12_DIRECT_STORE", 0}, {"VALI_RESIZE_FORCE_GATHER", 0},
     {"VALI_RESIZE_POINT", 1},  {"VALI_UD_FORCE_GATHER", 0},   {"VALI_UD_DOWN2", 1},          {"VALI_UD_OCC5", 0},
     {"VALI_ROTATE_NO_TILE", 0}, {"VALI_ROCTX", 0},            {"VALI_RESIZE_NO_SEPARABLE", 0},
-    {"VALI_ROWS_PER_WAVE", 0}};
+    {"VALI_ROWS_PER_WAVE", 0}, {"VALI_BLOCKING_WAIT", 0}};
 std::atomic<int> g_tune[VALI_TUNE_COUNT];
 std::once_flag g_tune_once;
 
@@ -219,6 +221,69 @@ int vali_stream_destroy(int device, vali_stream_t stream) {
 int vali_stream_sync(int device, vali_stream_t stream) {
   VALI_DEVICE(device);
   VALI_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+  return VALI_OK;
+}
+
+// ---- vali_stream_wait: the host side of the blocking Run forms --------------------------------------------------
+// hipStreamSynchronize costs 11.8-12.6 us around a 1 us kernel on this stack, 3-4 us of it inside the runtime's signal
+// wait (tools/exp/sync_latency.hip: interrupts off and ROC_ACTIVE_WAIT_TIMEOUT change nothing).  A 4-byte word in
+// pinned, device-mapped host memory that the stream itself writes when it gets there (hipStreamWriteValue32) and the host
+// spins on takes 8.7 us -- 0.6 us above a kernel that announces its own end, the floor of a launch -> completion round
+// trip on this hardware.  One word per stream; after ~150 us of spinning (a long kernel, or a stream that will never get
+// there) the wait falls back to hipStreamSynchronize, which also surfaces errors.
+namespace {
+struct WaitSlot {
+  unsigned* host = nullptr;
+  unsigned* dev = nullptr;
+  unsigned value = 0;
+};
+std::mutex g_wait_mutex;
+std::unordered_map<uint64_t, WaitSlot> g_wait_slots; // (device, stream) -> slot; slots live as long as the library
+
+WaitSlot* wait_slot(int device, hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_wait_mutex);
+  const uint64_t key = ((uint64_t)(unsigned)device << 56) ^ (uint64_t)(uintptr_t)s;
+  auto it = g_wait_slots.find(key);
+  if (it != g_wait_slots.end())
+    return &it->second;
+  WaitSlot w;
+  void* h = nullptr;
+  if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipHostFree(h);
+    return nullptr;
+  }
+  w.host = (unsigned*)h;
+  w.dev = (unsigned*)d;
+  *w.host = 0;
+  return &g_wait_slots.emplace(key, w).first->second;
+}
+} // namespace
+
+int vali_stream_wait(int device, vali_stream_t stream) {
+  VALI_DEVICE(device);
+  hipStream_t s = as_stream(stream);
+  WaitSlot* w = tuning(VALI_TUNE_BLOCKING_WAIT) == 0 ? wait_slot(device, s) : nullptr;
+  if (w) {
+    const unsigned v = ++w->value;
+    if (hipStreamWriteValue32(s, w->dev, v, 0) == hipSuccess) {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (unsigned spin = 1;; ++spin) {
+        if ((int)(__atomic_load_n((volatile unsigned*)w->host, __ATOMIC_ACQUIRE) - v) >= 0)
+          return VALI_OK;
+        if ((spin & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(150))
+          break;
+      }
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  VALI_HIP_CHECK(hipStreamSynchronize(s));
   return VALI_OK;
 }
 

@@ -326,10 +326,12 @@ class _SurfaceTask:
         return self._stream
 
     def _sync(self):
-        # the blocking Run* forms: everything issued on the task's stream has finished.
-        # (hipStreamSynchronize measured 15.2 us per 1080p Run against 18.1 us for an event
-        # record + hipEventSynchronize; the floor is the GPU's ~4 us plus the wake-up)
-        shim.stream_sync(self._gpu_id, self._stream)
+        # the blocking Run* forms: everything issued on the task's stream has finished.  vali_stream_wait = a completion
+        # word the stream writes into pinned host memory, spun on with the GIL released: 8.7 us around a 1 us kernel
+        # against 11.8-12.6 us for hipStreamSynchronize (an event record + hipEventSynchronize: the same or worse;
+        # interrupts off / ROC_ACTIVE_WAIT_TIMEOUT: no change) -- tools/exp/sync_latency.hip; the launch -> completion
+        # round trip of a kernel that announces its own end is 8.15 us on the same box, so that is the floor.
+        shim.stream_wait(self._gpu_id, self._stream)
 
 
 class PySurfaceConverter(_SurfaceTask):
@@ -375,9 +377,9 @@ class PySurfaceConverter(_SurfaceTask):
 
     def Run(self, src: Surface, dst: Surface,
             cc_ctx: Optional[ColorspaceConversionContext] = None) -> Tuple[bool, TaskExecInfo]:
-        d = self._run(src, dst, cc_ctx)
+        r = self.RunAsync(src, dst, cc_ctx)     # (the memoised C call when the pair repeats)
         self._sync()
-        return d.success, d.info
+        return r
 
     # -- batched form ------------------------------------------------------------------
     def PrepareBatch(self, srcs: Sequence[Surface], dsts: Sequence[Surface]) -> "SurfaceBatch":
@@ -504,9 +506,9 @@ class PySurfaceUD(_SurfaceTask):
         return d.success, d.info
 
     def Run(self, src: Surface, dst: Surface) -> Tuple[bool, TaskExecInfo]:
-        d = self._run(src, dst)
+        r = self.RunAsync(src, dst)
         self._sync()
-        return d.success, d.info
+        return r
 
     # -- fused UD + quarter-turn rotation (new; BASELINE config 4 as ONE pass) ----------------
     @staticmethod
@@ -651,9 +653,9 @@ class PySurfacePreprocessor(_SurfaceTask):
         return d.success, d.info
 
     def Run(self, src: Surface, dst: Surface, cc_ctx=None) -> Tuple[bool, TaskExecInfo]:
-        d = self._run(src, dst, cc_ctx)
+        r = self.RunAsync(src, dst, cc_ctx)
         self._sync()
-        return d.success, d.info
+        return r
 
     def PrepareBatch(self, srcs: Sequence[Surface], dsts: Sequence[Surface]) -> "SurfaceBatch":
         return SurfaceBatch(self._gpu_id, self._stream, srcs, dsts)
@@ -784,9 +786,9 @@ class PySurfaceRotator(_SurfaceTask):
 
     def Run(self, src: Surface, dst: Surface, angle: float, shift_x: float = 0.0,
             shift_y: float = 0.0) -> Tuple[bool, TaskExecInfo]:
-        d = self._run(src, dst, float(angle), float(shift_x), float(shift_y))
+        r = self.RunAsync(src, dst, angle, shift_x, shift_y)
         self._sync()
-        return d.success, d.info
+        return r
 
 
 # ---- PySurfaceResizer --------------------------------------------------------------------
@@ -851,9 +853,9 @@ class PySurfaceResizer(_SurfaceTask):
         return d.success, d.info
 
     def Run(self, src: Surface, dst: Surface) -> Tuple[bool, TaskExecInfo]:
-        d = self._run(src, dst)
+        r = self.RunAsync(src, dst)
         self._sync()
-        return d.success, d.info
+        return r
 
     def PrepareBatch(self, srcs: Sequence[Surface], dsts: Sequence[Surface]) -> "SurfaceBatch":
         return SurfaceBatch(self._gpu_id, self._stream, srcs, dsts)
