@@ -264,8 +264,9 @@ VALI_API int vali_nv12_preproc_batch(const vali_surface* d_src, const vali_surfa
  */
 VALI_API int vali_ud_nv12(const vali_surface* src, const vali_surface* dst,
                           vali_stream_t stream);
+/* (the frames of a batch share one geometry: src_width x src_height -> dst_width x dst_height) */
 VALI_API int vali_ud_nv12_batch(const vali_surface* d_src, const vali_surface* d_dst, int n,
-                                int src_format, int src_width, int dst_width, int dst_height,
+                                int src_format, int src_width, int src_height, int dst_width, int dst_height,
                                 int dst_format, vali_stream_t stream);
 
 /*
@@ -278,7 +279,7 @@ VALI_API int vali_ud_nv12_batch(const vali_surface* d_src, const vali_surface* d
 VALI_API int vali_ud_nv12_rot(const vali_surface* src, const vali_surface* dst, int quarter_turns,
                               vali_stream_t stream);
 VALI_API int vali_ud_nv12_rot_batch(const vali_surface* d_src, const vali_surface* d_dst, int n,
-                                    int src_format, int src_width, int dst_width, int dst_height,
+                                    int src_format, int src_width, int src_height, int dst_width, int dst_height,
                                     int dst_format, int quarter_turns, vali_stream_t stream);
 
 /* ---- resize: replaces nppiResize_{8u,32f}_C{1,3}R_Ctx --------------------------------- */

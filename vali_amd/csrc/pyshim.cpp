@@ -427,10 +427,10 @@ PYBIND11_MODULE(_vali_shim, m) {
         },
         py::call_guard<py::gil_scoped_release>());
   m.def("ud_nv12_batch",
-        [](uintptr_t d_src, uintptr_t d_dst, int n, int src_format, int src_w, int dst_w,
+        [](uintptr_t d_src, uintptr_t d_dst, int n, int src_format, int src_w, int src_h, int dst_w,
            int dst_h, int dst_format, uintptr_t stream) {
           return vali_ud_nv12_batch((const vali_surface*)P(d_src), (const vali_surface*)P(d_dst),
-                                    n, src_format, src_w, dst_w, dst_h, dst_format, P(stream));
+                                    n, src_format, src_w, src_h, dst_w, dst_h, dst_format, P(stream));
         },
         py::call_guard<py::gil_scoped_release>());
 
@@ -440,10 +440,10 @@ PYBIND11_MODULE(_vali_shim, m) {
         },
         py::call_guard<py::gil_scoped_release>());
   m.def("ud_nv12_rot_batch",
-        [](uintptr_t d_src, uintptr_t d_dst, int n, int src_format, int src_w, int dst_w,
+        [](uintptr_t d_src, uintptr_t d_dst, int n, int src_format, int src_w, int src_h, int dst_w,
            int dst_h, int dst_format, int quarter_turns, uintptr_t stream) {
           return vali_ud_nv12_rot_batch((const vali_surface*)P(d_src), (const vali_surface*)P(d_dst),
-                                        n, src_format, src_w, dst_w, dst_h, dst_format,
+                                        n, src_format, src_w, src_h, dst_w, dst_h, dst_format,
                                         quarter_turns, P(stream));
         },
         py::call_guard<py::gil_scoped_release>());

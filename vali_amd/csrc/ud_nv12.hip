@@ -1321,6 +1321,135 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
   }
 }
 
+// ---- exactly 2:1 in BOTH directions (src = 2 dw x 2 dh), output width a multiple of 8: BASELINE config 4's UD ----
+// k_ud_down2 serves every height, ragged widths, foreign alignment and the half turn from one body, and pays for it on
+// the geometry that matters most: 667 instructions per wave and row in the hot loop, 77 of them v_readlane (16 needed:
+// 75 spilled SGPRs come back through lanes), 39 skipped-over exec-mask branches of the byte-wise strip flush -- and the
+// kernel is bound by the instructions it issues (73 M VALU + 26 M scalar per 64-frame launch = 75 % of its 221 us at
+// one instruction per 4 cycles and SIMD; profiles/r03_ud_half.md).  Here every row's vertical weights are 128 / 128 by
+// construction (rows 2y-1, 2y of luma, y-1, y of chroma: make_tap(2y) and make_tap(y)), so there are no row taps to
+// broadcast and no second arithmetic form; every lane has 8 pixels or none; accesses are the unaligned-tolerant forms of
+// the same instructions, so alignment needs no second path either.  Same bytes as k_ud_down2 (d2_compute<OUT, true>).
+template <int OUT>
+__global__ void __launch_bounds__(kBlock) k_ud_half(const UdArgs a) {
+  using T = uint8_t;
+  constexpr bool kPacked = OUT == UD_RGB_U8;
+  u32 tile_x, tile_y, frame;
+  if (!tile_of_block(a.map, tile_x, tile_y, frame))
+    return;
+  const SurfRef s = load_surface(a.d_src, a.src, frame);
+  const SurfRef d = load_surface(a.d_dst, a.dst, frame);
+  const int dw = d.width, dh = d.height;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int xw = tile_x * kD2WaveW;
+  const int y_first = (int)(tile_y * kWavesPerBlock + wave) * a.rows; // wave-uniform
+  if (y_first >= dh)
+    return;
+  const int last = min(a.rows, dh - y_first) - 1;
+  const int x0 = xw + lane * kD2LanePx;
+  const bool has = x0 < dw;                                            // dw % 8 == 0: 8 pixels or none
+  const u32 off16 = (u32)(2 * min(x0, dw - kD2LanePx));                // idle lanes re-read the row's last group
+  const u32 offw = (u32)max(2 * xw - 4, 0);
+  struct Rows {
+    uint4 v[4]; // the lane's 16 bytes of luma 2y-1, luma 2y, chroma y-1, chroma y
+    u32 before; // lane k < 4: the dword before the wave's first byte in row k
+  };
+  auto issue = [&](int rr) {
+    const int y = y_first + min(rr, last);
+    const uint8_t* row[4] = {s.p[0] + (u32)(max(2 * y - 1, 0) * s.pitch[0]), s.p[0] + (u32)(2 * y * s.pitch[0]),
+                             s.p[1] + (u32)(max(y - 1, 0) * s.pitch[1]), s.p[1] + (u32)(y * s.pitch[1])};
+    Rows r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const v4u32 w = gload_u<v4u32>(row[k] + off16);
+      r.v[k] = make_uint4(w.x, w.y, w.z, w.w);
+    }
+    const int lk = lane & 3;
+    const uint8_t* rb = lk == 0 ? row[0] : lk == 1 ? row[1] : lk == 2 ? row[2] : row[3];
+    r.before = gload_u<u32>(rb + offw);
+    return r;
+  };
+  __shared__ __attribute__((aligned(16))) uint8_t strip[kPacked ? kWavesPerBlock : 1][kPacked ? kD2WaveW * 3 : 16];
+  const int nbytes = min(kD2WaveW, dw - xw) * 3;                        // packed RGB bytes of the wave's row, a multiple of 24
+  const bool dst16 = ((((uintptr_t)d.p[0]) | (uintptr_t)d.pitch[0]) & 15u) == 0 && (xw * 3 & 15) == 0; // wave-uniform
+  auto step = [&](int rr, const Rows& rows) {
+    const int y = y_first + rr;
+    u32 prev[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { // the 4 bytes before the lane's own: the previous lane's last dword; lane 0: the wave's extra
+      const u32 before = (u32)__builtin_amdgcn_readlane((int)rows.before, k); // load, or the clamp at the image's left edge
+      const u32 edge = k < 2 ? rows.v[k].x << 24 : rows.v[k].x << 16;
+      const u32 sh1 = wave_shr1(rows.v[k].w);
+      prev[k] = lane == 0 ? (xw == 0 ? edge : before) : sh1;
+    }
+    D2Quad q0, q1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      q0.p[k] = prev[k]; q0.a[k] = rows.v[k].x; q0.b[k] = rows.v[k].y;
+      q1.p[k] = rows.v[k].y; q1.a[k] = rows.v[k].z; q1.b[k] = rows.v[k].w;
+    }
+    float c0[8], c1[8], c2[8];
+    const D2Taps none = {};
+    d2_compute<OUT, true>(none, q0, c0, c1, c2);
+    d2_compute<OUT, true>(none, q1, c0 + 4, c1 + 4, c2 + 4);
+    if constexpr (kPacked) {
+      u32 w[6];
+      trunc_pack3x4(c0[0], c1[0], c2[0], c0[1], c1[1], c2[1], c0[2], c1[2], c2[2], c0[3], c1[3], c2[3], w[0], w[1], w[2]);
+      trunc_pack3x4(c0[4], c1[4], c2[4], c0[5], c1[5], c2[5], c0[6], c1[6], c2[6], c0[7], c1[7], c2[7], w[3], w[4], w[5]);
+      uint8_t* st = strip[kPacked ? wave : 0];
+      if (has) {
+        *reinterpret_cast<uint2*>(st + 24 * lane) = make_uint2(w[0], w[1]);
+        *reinterpret_cast<uint2*>(st + 24 * lane + 8) = make_uint2(w[2], w[3]);
+        *reinterpret_cast<uint2*>(st + 24 * lane + 16) = make_uint2(w[4], w[5]);
+      }
+      wave_lds_sync();
+      uint8_t* orow = d.p[0] + (u32)(y * d.pitch[0]) + (u32)(xw * 3);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) { // strip byte b -> destination byte orow + b, 16 bytes per lane (nbytes: a multiple of 24, so
+        const int b = (lane + kWave * h) * 16; // the last piece may be 8 bytes)
+        if (b + 16 <= nbytes) {
+          const uint4 v = *reinterpret_cast<const uint4*>(st + b);
+          if (dst16)
+            UD_ST16(orow + b, v);
+          else
+            gstore_u<v4u32>(orow + b, (v4u32){v.x, v.y, v.z, v.w});
+        } else if (b < nbytes) {
+          const uint2 v = *reinterpret_cast<const uint2*>(st + b);
+          gstore_u<v2u32>(orow + b, (v2u32){v.x, v.y});
+        }
+      }
+      wave_lds_sync(); // the strip is re-used by the next row
+    } else if (has) {
+      const int pp[3] = {d.pitch[0], OUT == UD_YUV444 ? d.pitch[1] : d.pitch[0], OUT == UD_YUV444 ? d.pitch[2] : d.pitch[0]};
+      u32 pw[6]; // lo / hi dwords of the lane's 8 pixels in the three planes
+      trunc_pack3x4(c0[0], c0[1], c0[2], c0[3], c0[4], c0[5], c0[6], c0[7], c1[0], c1[1], c1[2], c1[3], pw[0], pw[1], pw[2]);
+      trunc_pack3x4(c1[4], c1[5], c1[6], c1[7], c2[0], c2[1], c2[2], c2[3], c2[4], c2[5], c2[6], c2[7], pw[3], pw[4], pw[5]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        uint8_t* o = d.p[k] + (u32)(y * pp[k]) + (u32)x0;
+        if ((((uintptr_t)d.p[k] | (uintptr_t)pp[k]) & 7u) == 0) // wave-uniform
+          UD_ST8(o, make_uint2(pw[2 * k], pw[2 * k + 1]));
+        else
+          gstore_u<v2u32>(o, (v2u32){pw[2 * k], pw[2 * k + 1]});
+      }
+    }
+  };
+  // two rows in flight, the walk unrolled by two so that both register sets are named statically
+  Rows ra = issue(0);
+  __builtin_amdgcn_sched_barrier(0);
+  Rows rb = issue(1);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+  for (int rr = 0; rr <= last; rr += 2) {
+    step(rr, ra);
+    ra = issue(rr + 2);
+    if (rr + 1 <= last)
+      step(rr + 1, rb);
+    rb = issue(rr + 3);
+  }
+}
+
 // The same arithmetic with the output written turned by 90 / 270 degrees (ROT 1 / 3; NV12 -> packed
 // RGB): BASELINE config 4 as one pass.  The transposed store needs the 256 x 32 workgroup tile of
 // k_ud_nv12 (one dword per pixel in LDS, ud_rot_store), so a wave covers 256 columns and fetches TWO
@@ -1511,7 +1640,7 @@ static int ud_out_kind(int src_fmt, int dst_fmt) {
 
 // dst_w / dst_h: size of the DESTINATION surface; for odd `rot` the UD output itself is
 // dst_h x dst_w and is written turned.
-static int launch_ud(UdArgs& a, int src_fmt, int src_w, int dst_w, int dst_h, int dst_fmt, int n,
+static int launch_ud(UdArgs& a, int src_fmt, int src_w, int src_h, int dst_w, int dst_h, int dst_fmt, int n,
                      hipStream_t stream, int rot = 0) {
   const int kind = ud_out_kind(src_fmt, dst_fmt);
   if (kind < 0)
@@ -1575,6 +1704,17 @@ static int launch_ud(UdArgs& a, int src_fmt, int src_w, int dst_w, int dst_h, in
     else if (kind == UD_YUV444) hipLaunchKernelGGL((k_ud_down2<UD_YUV444, 0, 1>), g1, block, 0, stream, a);
     else if (kind == UD_RGB_U8) hipLaunchKernelGGL((k_ud_down2<UD_RGB_U8, 0, 1>), g1, block, 0, stream, a);
     else hipLaunchKernelGGL((k_ud_down2<UD_RGB_U8_PLANAR, 0, 1>), g1, block, 0, stream, a);
+    VALI_LAUNCH_CHECK();
+    return VALI_OK;
+  }
+  if (down2_mode == 1 && !force_gather && src_fmt == VALI_FMT_NV12 && src_w == 2 * dst_w && src_h == 2 * dst_h && rot == 0 &&
+      dst_w % kD2LanePx == 0 && kind != UD_RGB_F32 && kind != UD_RGB_F32_PLANAR) { // exactly 2:1 both ways: the lean kernel
+    a.rows = rows_for((dst_w + kD2WaveW - 1) / kD2WaveW);
+    a.map = make_tile_map((dst_w + kD2WaveW - 1) / kD2WaveW, (dst_h + kWavesPerBlock * a.rows - 1) / (kWavesPerBlock * a.rows), (u32)n);
+    const dim3 gh = tile_grid(a.map);
+    if (kind == UD_YUV444) hipLaunchKernelGGL((k_ud_half<UD_YUV444>), gh, block, 0, stream, a);
+    else if (kind == UD_RGB_U8) hipLaunchKernelGGL((k_ud_half<UD_RGB_U8>), gh, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_ud_half<UD_RGB_U8_PLANAR>), gh, block, 0, stream, a);
     VALI_LAUNCH_CHECK();
     return VALI_OK;
   }
@@ -1659,7 +1799,7 @@ int vali_ud_nv12(const vali_surface* src, const vali_surface* dst, vali_stream_t
   a.dst = *dst;
   hipStream_t s = as_stream(stream);
   VALI_ENTRY(s);
-  return launch_ud(a, src->format, src->width, dst->width, dst->height, dst->format, 1, s);
+  return launch_ud(a, src->format, src->width, src->height, dst->width, dst->height, dst->format, 1, s);
 }
 
 int vali_ud_nv12_rot(const vali_surface* src, const vali_surface* dst, int quarter_turns,
@@ -1675,15 +1815,15 @@ int vali_ud_nv12_rot(const vali_surface* src, const vali_surface* dst, int quart
   a.dst = *dst;
   hipStream_t s = as_stream(stream);
   VALI_ENTRY(s);
-  return launch_ud(a, src->format, src->width, dst->width, dst->height, dst->format, 1, s, quarter_turns);
+  return launch_ud(a, src->format, src->width, src->height, dst->width, dst->height, dst->format, 1, s, quarter_turns);
 }
 
 int vali_ud_nv12_rot_batch(const vali_surface* d_src, const vali_surface* d_dst, int n, int src_format,
-                           int src_width, int dst_width, int dst_height, int dst_format,
+                           int src_width, int src_height, int dst_width, int dst_height, int dst_format,
                            int quarter_turns, vali_stream_t stream) {
   VALI_REQUIRE(d_src && d_dst, "null argument");
-  VALI_REQUIRE(src_width >= 2 && dst_width > 0 && dst_height > 0, "empty geometry");
-  VALI_REQUIRE((src_width & 1) == 0, "4:2:0 surfaces need even width and height");
+  VALI_REQUIRE(src_width >= 2 && src_height >= 2 && dst_width > 0 && dst_height > 0, "empty geometry");
+  VALI_REQUIRE(((src_width | src_height) & 1) == 0, "4:2:0 surfaces need even width and height");
   VALI_REQUIRE(n >= 0 && n <= 65535, "batch size out of range (0..65535)");
   if (n == 0)
     return VALI_OK;
@@ -1692,15 +1832,15 @@ int vali_ud_nv12_rot_batch(const vali_surface* d_src, const vali_surface* d_dst,
   a.d_dst = d_dst;
   hipStream_t s = as_stream(stream);
   VALI_ENTRY(s);
-  return launch_ud(a, src_format, src_width, dst_width, dst_height, dst_format, n, s, quarter_turns);
+  return launch_ud(a, src_format, src_width, src_height, dst_width, dst_height, dst_format, n, s, quarter_turns);
 }
 
 int vali_ud_nv12_batch(const vali_surface* d_src, const vali_surface* d_dst, int n, int src_format,
-                       int src_width, int dst_width, int dst_height, int dst_format,
+                       int src_width, int src_height, int dst_width, int dst_height, int dst_format,
                        vali_stream_t stream) {
   VALI_REQUIRE(d_src && d_dst, "null argument");
-  VALI_REQUIRE(src_width >= 2 && dst_width > 0 && dst_height > 0, "empty geometry");
-  VALI_REQUIRE((src_width & 1) == 0, "4:2:0 surfaces need even width and height");
+  VALI_REQUIRE(src_width >= 2 && src_height >= 2 && dst_width > 0 && dst_height > 0, "empty geometry");
+  VALI_REQUIRE(((src_width | src_height) & 1) == 0, "4:2:0 surfaces need even width and height");
   VALI_REQUIRE(n >= 0 && n <= 65535, "batch size out of range (0..65535)");
   if (n == 0)
     return VALI_OK;
@@ -1709,7 +1849,7 @@ int vali_ud_nv12_batch(const vali_surface* d_src, const vali_surface* d_dst, int
   a.d_dst = d_dst;
   hipStream_t s = as_stream(stream);
   VALI_ENTRY(s);
-  return launch_ud(a, src_format, src_width, dst_width, dst_height, dst_format, n, s);
+  return launch_ud(a, src_format, src_width, src_height, dst_width, dst_height, dst_format, n, s);
 }
 
 } // extern "C"

@@ -540,7 +540,7 @@ class PySurfaceUD(_SurfaceTask):
         if (batch.src_size[0] | batch.src_size[1]) & 1:       # the one rule for 4:2:0 sizes (include/vali_hip.h)
             return False, TaskExecInfo.INVALID_INPUT
         d = _status(shim.ud_nv12_rot_batch(batch.d_src, batch.d_dst, batch.n, int(batch.src_format),
-                                           batch.src_size[0], batch.dst_size[0], batch.dst_size[1],
+                                           batch.src_size[0], batch.src_size[1], batch.dst_size[0], batch.dst_size[1],
                                            int(batch.dst_format), q, self._stream))
         return d.success, d.info
 
@@ -561,7 +561,7 @@ class PySurfaceUD(_SurfaceTask):
                                              batch.dst_size[0], batch.dst_size[1], shim.INTERP_LANCZOS, self._stream))
             return d.success, d.info
         d = _status(shim.ud_nv12_batch(batch.d_src, batch.d_dst, batch.n, int(batch.src_format),
-                                       batch.src_size[0], batch.dst_size[0], batch.dst_size[1],
+                                       batch.src_size[0], batch.src_size[1], batch.dst_size[0], batch.dst_size[1],
                                        int(batch.dst_format), self._stream))
         return d.success, d.info
 
