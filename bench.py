@@ -27,9 +27,8 @@ import sys
 import time
 from pathlib import Path
 
-# the CPU baseline's OpenMP threads stay where they first ran (read by libgomp when it loads, i.e. before the oracle does)
-os.environ.setdefault("OMP_PROC_BIND", "close")
-os.environ.setdefault("OMP_PLACES", "threads")
+# every CPU this process may use, BEFORE a rank narrows itself to its GPU's NUMA node: the CPU baseline runs on all of them
+HOST_CPUS = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
 
 import numpy as np  # noqa: E402
 
@@ -55,6 +54,15 @@ def parse():
                     help="untimed pre-conditioning before the W warm-up steps: the same launch repeated for this long, so "
                          "that the timed steps see the clocks the chip holds under this load and not the idle state of a "
                          "fresh box (the first bench process on a box measured 2.6 %% below the following ones); 0 disables")
+    ap.add_argument("--op", default="convert", choices=["convert", "resize", "ud", "preproc"],
+                    help="what the sharded pipeline runs on its NV12 frames: convert = NV12->RGB at the same size (the headline; "
+                         "BASELINE configs[4]); resize = NV12->NV12 Lanczos to --dst-size; ud = PySurfaceUD NV12->RGB at --dst-size; "
+                         "preproc = fused NV12->normalised RGB_32F_PLANAR at --dst-size")
+    ap.add_argument("--dst-size", default=None, help="WxH of the output for --op resize / ud / preproc (default: half the source)")
+    ap.add_argument("--ingest-seconds", type=float, default=1.5,
+                    help="N=1: also time the HOST-FED pipeline (pinned staging + H2D on a copy stream overlapped with the "
+                         "conversion, IngestRing) for this long and report it beside the resident number; 0 disables")
+    ap.add_argument("--no-numa-bind", action="store_true", help="do not pin each rank to the CPUs of its GPU's NUMA node")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip BASELINE configs[1..3] (tools/bench_configs.py; a few seconds, N=1 only)")
@@ -81,15 +89,32 @@ def cpu_baseline(width, height, coeffs, budget_s):
     from oracle import oracle as o
 
     k = o.csc_from_tuple(coeffs)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = len(HOST_CPUS)
     frame = synth_nv12(width, height, 1)
     # one thread alone, then every core: each thread converts its own copy of the frame, input and output first-touched by
-    # the thread itself (NUMA-fair; threads pinned through OMP_PROC_BIND / OMP_PLACES, exported at the top of this file
-    # before the OpenMP runtime starts).  Sharing read-only inputs and main-thread-touched outputs measured 550 frames/s on
-    # 256 cores against 10.9 on one (20 % parallel efficiency, round 2).
-    n1, t1 = o.nv12_to_rgb_bench(frame, width, height, k, 1, min(1.0, budget_s / 8))
-    t_single = t1 / max(n1, 1)
-    done, t_all = o.nv12_to_rgb_bench(frame, width, height, k, cores, budget_s)
+    # the thread itself, thread i pinned to the i-th CPU of the host (NUMA-fair).  Sharing read-only inputs and
+    # main-thread-touched outputs measured 550 frames/s on 256 cores against 10.9 on one (20 % parallel efficiency, round 2).
+    if hasattr(os, "sched_setaffinity"):
+        mine = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, HOST_CPUS)          # (the rank itself sits on its GPU's NUMA node: widen for the baseline)
+    try:
+        n1, t1 = o.nv12_to_rgb_bench(frame, width, height, k, 1, min(1.0, budget_s / 8), cpus=HOST_CPUS[:1])
+        t_single = t1 / max(n1, 1)
+        # all CPUs, then half and a quarter of them (spread over the whole list, i.e. over both sockets): a host whose memory
+        # system saturates below its thread count is faster with fewer threads, and the baseline should be its best
+        scan = []
+        for div in (1, 2, 4):
+            n_thr = max(1, cores // div)
+            cp = HOST_CPUS[::div][:n_thr]
+            d_, t_ = o.nv12_to_rgb_bench(frame, width, height, k, n_thr, budget_s / 3.5, cpus=cp)
+            scan.append((d_ / t_, n_thr, d_, t_))
+            if n_thr == 1:
+                break
+        best = max(scan)
+        done, t_all, used = best[2], best[3], best[1]
+    finally:
+        if hasattr(os, "sched_setaffinity"):
+            os.sched_setaffinity(0, mine)
     # BASELINE config 1 stand-in: ONE 1080p frame on ONE thread, like the reference's
     # PyFrameConverter (sws_scale on a single frame); best of 5
     hd = synth_nv12(1920, 1080, 1)
@@ -101,10 +126,11 @@ def cpu_baseline(width, height, coeffs, budget_s):
         t_hd.append(time.perf_counter() - t1)
     t_hd = min(t_hd[1:])
     return {
-        "value": round(done / t_all, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+        "value": round(done / t_all, 3), "unit": "frames/s", "cores": used, "kind": "port", "host_cpus": cores,
+        "thread_scan_frames_per_s": {str(n_): round(r_, 1) for r_, n_, _d, _t in scan},
         "sample": f"{done} frames {width}x{height} NV12->RGB by oracle/vali_oracle_simd.c (AVX2, bit-identical to the scalar oracle), "
-                  f"{cores} pinned OpenMP threads, each on its own first-touched copy of the frame, {t_all:.1f} s",
-        "parallel_efficiency": round((done / t_all) * t_single / cores, 3),
+                  f"{used} pinned OpenMP threads, each on its own first-touched copy of the frame, {t_all:.1f} s",
+        "parallel_efficiency": round((done / t_all) * t_single / used, 3),
         "single_thread_fps": round(1.0 / t_single, 3),
         "config1_1080p_single_thread": {"ms_per_frame": round(t_hd * 1e3, 3), "frames_per_s": round(1.0 / t_hd, 2),
                                         "GBps(9331200 B/frame)": round(9331200 / t_hd / 1e9, 3), "cores": 1},
@@ -205,9 +231,71 @@ def spawn_ranks(n):
     return rc
 
 
+def preflight_parent(args):
+    """Fail fast, before any rank is spawned, on what would otherwise surface as N half-started processes: more ranks
+    than GPUs (RCCL needs one GPU per rank)."""
+    if os.environ.get("VALI_BENCH_BACKEND", "nccl") != "nccl":
+        return
+    try:
+        import vali_amd as vali
+        ngpu = vali.GetNumGpus()
+    except Exception as e:      # noqa: BLE001 -- the ranks will report it properly
+        print(f"bench.py: pre-flight skipped ({type(e).__name__}: {e})", file=sys.stderr)
+        return
+    if args.gpus > ngpu:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but this node shows {ngpu} GPU(s) (GetNumGpus): nothing was launched. "
+                         "Use --gpus <= that, or VALI_BENCH_BACKEND=gloo to let ranks share a GPU for functional tests.")
+
+
+def preflight_memory(shim, dev, need_bytes, what):
+    """frames x (src + dst) must fit the device BEFORE the shard is allocated: a clear message instead of an allocation
+    failure half-way through 1024 hipMallocs (or worse, a box driven out of memory)."""
+    free_b, total_b = shim.mem_info(dev)
+    if need_bytes > free_b * 0.92:
+        raise SystemExit(f"bench.py: {what} needs {need_bytes / 2**30:.1f} GiB on GPU {dev}, {free_b / 2**30:.1f} GiB of "
+                         f"{total_b / 2**30:.1f} GiB are free -- lower --frames")
+    return free_b, total_b
+
+
+def host_fed_rate(vali, pipe_args, coeffs_ctx, seconds, W, H):
+    """The same operator fed from host memory through the ingest ring (pinned staging, H2D on a copy stream overlapped
+    with the previous slot's conversion): frames/s a decoder-fed pipeline would see -- PCIe-bound, never `value`."""
+    dev, dst_fmt, op, dst_size = pipe_args
+    per = 16
+    pipe = vali.BatchedFramePipeline(dev, W, H, per, dst_fmt, op=op, dst_size=dst_size)
+    pipe.set_coefficients(coeffs_ctx)
+    ring = pipe.ingest_ring(slots=3, frames_per_slot=per)
+    frame = synth_nv12(W, H, 1).reshape(-1)
+    chunk = np.tile(frame, per)
+
+    def chunks():
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            yield chunk
+    rates = {}
+    for name, fill in (("producer_copies_into_pinned_memory", lambda host, item: host.__setitem__(slice(0, item.size), item)),
+                       ("producer_writes_in_place", lambda host, item: None)):
+        t0 = time.perf_counter()
+        n = 0
+        for _tag, _dsts in ring.feed(chunks(), fill=fill):
+            n += per
+        rates[name] = n / (time.perf_counter() - t0)
+    ring.close()
+    n_dt = rates["producer_copies_into_pinned_memory"]
+    return {"frames_per_s": round(n_dt, 1), "GBps_over_pcie": round(n_dt * frame.size / 1e9, 2),
+            "frames_per_s_when_the_producer_writes_in_place": round(rates["producer_writes_in_place"], 1),
+            "GBps_over_pcie_in_place": round(rates["producer_writes_in_place"] * frame.size / 1e9, 2),
+            "slots": 3, "frames_per_slot": per,
+            "note": "host -> pinned staging -> H2D on a copy stream, overlapped with the operator on the task stream.  First "
+                    "figure: ONE host thread memcpy's every frame into the staging slot (a decoder that hands over pageable "
+                    "frames); second: the producer writes the slot in place (a decoder given the pinned buffer), i.e. the "
+                    "ring's own ceiling = PCIe"}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        preflight_parent(args)
         raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -253,10 +341,23 @@ def main():
 
     W, H, F = args.width, args.height, args.frames
     dst_fmt = vali.PixelFormat[args.dst]
+    dst_size = None
+    if args.op != "convert":
+        dst_size = tuple(int(v) for v in args.dst_size.lower().split("x")) if args.dst_size else (W // 2, H // 2)
+    out_fmt, out_size, bytes_per_frame = vali.pipeline.op_geometry(args.op, W, H, dst_fmt, dst_size)
+    # each rank next to its GPU: the launch thread and the pinned staging memory on the GPU's NUMA node
+    numa_cpus = None if args.no_numa_bind else vali.pipeline.bind_to_gpu_numa(dev)
+    # frames x (src + dst), pitches rounded to 256 B: must fit before anything is allocated
+    from vali_amd.surface import FORMATS
+    def _alloc_bytes(fmt, w, h):
+        spec = FORMATS[fmt]
+        return sum(-(-pw * spec.elem_size // 256) * 256 * ph for pw, ph in spec.plane_geometry(w, h))
+    preflight_memory(shim, dev, F * (_alloc_bytes(vali.NV12, W, H) + _alloc_bytes(out_fmt, *out_size)),
+                     f"{F} frames of NV12 {W}x{H} + {out_fmt.name} {out_size[0]}x{out_size[1]}")
     # this rank's shard of the global batch (weak scaling: F frames per GPU)
     begin, end = vali.shard_frames(F * world, rank, world)
     assert end - begin == F
-    pipe = vali.BatchedFramePipeline(dev, W, H, F, dst_fmt)
+    pipe = vali.BatchedFramePipeline(dev, W, H, F, dst_fmt, op=args.op, dst_size=dst_size)
     # the one collective of the path: rank 0 resolves the colour context to a matrix,
     # everyone receives the 32-byte block over RCCL/xGMI
     cc = vali.ColorspaceConversionContext(vali.ColorSpace.BT_709, vali.ColorRange.MPEG)
@@ -343,7 +444,7 @@ def main():
         del outs
 
     parity = None
-    if not args.no_parity and rank == 0:
+    if not args.no_parity and rank == 0 and args.op == "convert":
         from oracle import oracle as o
 
         dwn = vali.PySurfaceDownloader(dev, stream)
@@ -359,22 +460,25 @@ def main():
         parity = {"frames_checked": len(checked), "max_abs_diff_lsb": worst}
 
     if rank == 0:
-        bytes_per_frame = W * H * 3 // 2 + W * H * 3            # algorithmic: read NV12 + write RGB
         avg_kernel_ms = float(np.mean(kernel_ms))
         achieved = bytes_per_frame * F / (avg_kernel_ms * 1e-3) / 1e9
         fps = world * F * args.steps / elapsed
-        traffic, traffic_src = measured_traffic(bytes_per_frame, F, args.dst, W, H)
+        traffic, traffic_src = measured_traffic(bytes_per_frame, F, args.dst, W, H) if args.op == "convert" else (None, None)
+        op_name = {"convert": "nv12_to_rgb", "resize": "nv12_lanczos_resize", "ud": "nv12_ud_rgb", "preproc": "nv12_preproc_f32"}[args.op]
+        what = {"convert": f"PySurfaceConverter.RunBatch NV12->{args.dst} {W}x{H}, BT.709 limited range",
+                "resize": f"PySurfaceResizer.RunBatch NV12 {W}x{H}->{out_size[0]}x{out_size[1]} Lanczos",
+                "ud": f"PySurfaceUD.RunBatch NV12 {W}x{H}->RGB {out_size[0]}x{out_size[1]}",
+                "preproc": f"PySurfacePreprocessor.RunBatch NV12 {W}x{H}->RGB_32F_PLANAR {out_size[0]}x{out_size[1]} normalised"}[args.op]
         out = {
-            "metric": "nv12_to_rgb_2160p_frames_per_s" if (W, H) == (3840, 2160)
-                      else f"nv12_to_rgb_{W}x{H}_frames_per_s",
+            "metric": f"{op_name}_2160p_frames_per_s" if (W, H) == (3840, 2160)
+                      else f"{op_name}_{W}x{H}_frames_per_s",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ramp_ms_untimed": args.ramp_ms, "ramp_steps_untimed": ramp_steps,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": f"BatchedFramePipeline / PySurfaceConverter.RunBatch "
-                                   f"NV12->{args.dst} {W}x{H}, BT.709 limited range, "
-                                   f"{F} frames/GPU per step (BASELINE configs[4] geometry)",
+            "config": {"workload": f"BatchedFramePipeline / {what}, "
+                                   f"{F} frames/GPU per step" + (" (BASELINE configs[4] geometry)" if args.op == "convert" else ""),
                        "frames_per_gpu": F, "global_batch": F * world,
                        "bytes_per_frame": bytes_per_frame,
                        "parallelism": f"frame-sharded x{world}, RCCL broadcast of coefficients"},
@@ -387,7 +491,8 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "ratio_to_the_guides_6290GBps_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBPS, 4),
                          "traffic": traffic, "traffic_unit": "B per launch",
-                         "traffic_source": traffic_src, "kernel": "k_nv12_rgb8",
+                         "traffic_source": traffic_src,
+                         "kernel": {"convert": "k_nv12_rgb8", "resize": "k_resize_cols*", "ud": "k_ud_*", "preproc": "k_nv12_preproc"}[args.op],
                          "avg_kernel_ms": round(avg_kernel_ms, 4),
                          "median_kernel_ms": round(float(np.median(kernel_ms)), 4),
                          "min_kernel_ms": round(float(np.min(kernel_ms)), 4)},
@@ -396,7 +501,15 @@ def main():
             out["parity_vs_oracle"] = parity
         if verification is not None:
             out["verification"] = verification
-        if world == 1 and args.cpu_seconds > 0:
+        out["host_placement"] = {"numa_bound_cpus": (f"{numa_cpus[0]}-{numa_cpus[-1]} ({len(numa_cpus)} CPUs)" if numa_cpus else None),
+                                 "pci_bus_id": shim.device_pci_bus_id(dev)}
+        if world == 1 and args.ingest_seconds > 0:
+            try:
+                pipe.srcs.clear(); pipe.dsts.clear()          # the ring allocates its own slots
+                out["host_fed"] = host_fed_rate(vali, (dev, dst_fmt, args.op, dst_size), cc, args.ingest_seconds, W, H)
+            except Exception as e:  # noqa: BLE001 -- a side measurement must not take the headline line down
+                out["host_fed"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and args.cpu_seconds > 0 and args.op == "convert":
             out["cpu_baseline"] = cpu_baseline(W, H, coeffs, args.cpu_seconds)
         if world == 1 and not args.no_secondary:
             out["secondary"] = secondary_configs(pipe)

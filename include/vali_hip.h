@@ -132,6 +132,11 @@ VALI_API int vali_event_create(int device, vali_event_t* event);
 VALI_API int vali_event_destroy(int device, vali_event_t event);
 VALI_API int vali_event_record(int device, vali_event_t event, vali_stream_t stream);
 VALI_API int vali_event_sync(int device, vali_event_t event);
+/* cuEventQuery: *done = 1 when the event has happened, 0 while work in front of it is still running (no wait) */
+VALI_API int vali_event_query(int device, vali_event_t event, int* done);
+/* cuStreamWaitEvent: work issued on `stream` after this call starts only when `event` has happened (no host wait).  The
+ * ingest ring of the batched pipeline orders its copy stream and its compute stream with it. */
+VALI_API int vali_stream_wait_event(int device, vali_stream_t stream, vali_event_t event);
 VALI_API int vali_event_elapsed_ms(vali_event_t start, vali_event_t stop, float* ms);
 
 /*
@@ -154,6 +159,14 @@ VALI_API int vali_mem_alloc_pitch(int device, size_t width_bytes, size_t height,
                                   void** dptr, size_t* pitch);
 VALI_API int vali_mem_alloc(int device, size_t bytes, void** dptr);
 VALI_API int vali_mem_free(int device, void* dptr);
+/* page-locked host memory (cuMemAllocHost): the staging buffers of asynchronous host <-> device copies; pageable memory
+ * makes vali_memcpy2d_async synchronous and halves its rate */
+VALI_API int vali_host_alloc(int device, size_t bytes, void** hptr);
+VALI_API int vali_host_free(int device, void* hptr);
+/* free / total bytes of the device (cuMemGetInfo): bench.py's pre-flight check */
+VALI_API int vali_mem_info(int device, size_t* free_bytes, size_t* total_bytes);
+/* PCI address "dddd:bb:dd.f" of the device (cuDeviceGetPCIBusId), for NUMA placement of its host thread */
+VALI_API int vali_device_pci_bus_id(int device, char* out, int len);
 
 /* cuMemcpy2DAsync (TaskCudaUploadFrame.cpp:54-72, TaskCudaDownloadSurface.cpp:54-72,
  * MemoryInterfaces.cpp:413-431).  kind: 0 = host->device, 1 = device->host,

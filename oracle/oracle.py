@@ -140,15 +140,19 @@ def nv12_to_rgb_mt(frames, width, height, k: Csc, threads: int, outs=None, simd:
     return outs
 
 
-def nv12_to_rgb_bench(frame: np.ndarray, width: int, height: int, k: Csc, threads: int, seconds: float, simd: bool = True):
-    """(frames converted, seconds): `threads` OpenMP threads, each on its own first-touched copy of `frame` (NUMA-fair
-    CPU baseline of bench.py; vali_oracle_simd.c)."""
+def nv12_to_rgb_bench(frame: np.ndarray, width: int, height: int, k: Csc, threads: int, seconds: float, simd: bool = True,
+                      cpus=None):
+    """(frames converted, seconds): `threads` OpenMP threads, each on its own first-touched copy of `frame` and pinned to
+    cpus[i] (NUMA-fair CPU baseline of bench.py; vali_oracle_simd.c)."""
     fn = lib().vali_oracle_nv12_to_rgb_bench
     fn.restype = C.c_longlong
-    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_double)]
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_double),
+                   C.POINTER(C.c_int), C.c_int]
     a = np.ascontiguousarray(frame, np.uint8)
     dt = C.c_double(0.0)
-    n = fn(a.ctypes.data, int(width), int(height), C.cast(C.byref(k), C.c_void_p), int(threads), float(seconds), int(simd), C.byref(dt))
+    ids = (C.c_int * len(cpus))(*cpus) if cpus else None
+    n = fn(a.ctypes.data, int(width), int(height), C.cast(C.byref(k), C.c_void_p), int(threads), float(seconds), int(simd),
+           C.byref(dt), ids, len(cpus) if cpus else 0)
     if n < 0:
         raise RuntimeError("vali_oracle_nv12_to_rgb_bench: bad arguments")
     return int(n), float(dt.value)

@@ -102,9 +102,11 @@ VALI_API int vali_oracle_nv12_to_rgb_simd(const vali_surface* src, const vali_su
 VALI_API int vali_oracle_nv12_to_rgb_simd_mt(const vali_surface* src, const vali_surface* dst, int n,
                                              const vali_csc* csc, int threads);
 /* bench.py's CPU baseline: `threads` OpenMP threads, each converting its own first-touched copy of `nv12` for `seconds`;
- * returns the frames converted by all threads together (< 0: bad arguments), *elapsed = the longest thread's time */
+ * returns the frames converted by all threads together (< 0: bad arguments), *elapsed = the longest thread's time;
+ * thread i pins itself to cpus[i % n_cpus] (cpus == NULL: no pinning) */
 VALI_API long long vali_oracle_nv12_to_rgb_bench(const uint8_t* nv12, int width, int height, const vali_csc* csc,
-                                                 int threads, double seconds, int simd, double* elapsed);
+                                                 int threads, double seconds, int simd, double* elapsed,
+                                                 const int* cpus, int n_cpus);
 
 /* Lanczos-3 (6x6 taps, interpolating, same sampling grid) variant: the reference's
  * NPPI_INTER_LANCZOS restated with this build's own tap arithmetic (weights from fixed

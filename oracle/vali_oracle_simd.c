@@ -111,9 +111,14 @@ int vali_oracle_nv12_to_rgb_simd_mt(const vali_surface* src, const vali_surface*
  * and destination first-touched by the thread itself, so both live on the thread's memory node -- over and over for
  * `seconds`, and the function returns the total number of frames converted.  (Round 2 handed all threads the same
  * read-only inputs and outputs first-touched by one thread: 20 % parallel efficiency on a 2-socket host, the second
- * socket's threads pulling every byte across the fabric.)  Threads are pinned when the caller exports
- * OMP_PROC_BIND=close / OMP_PLACES=threads before the OpenMP runtime starts (bench.py does).
+ * socket's threads pulling every byte across the fabric.)  Thread i pins itself to the i-th CPU of `cpus` (n_cpus
+ * entries; NULL: no pinning) before it touches its buffers; the calling thread's own affinity is restored on return.
+ * (Not OMP_PROC_BIND: that also binds the process's INITIAL thread -- the one that launches GPU work -- to one CPU.)
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
+#include <sched.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -121,7 +126,9 @@ int vali_oracle_nv12_to_rgb_simd_mt(const vali_surface* src, const vali_surface*
 #endif
 
 long long vali_oracle_nv12_to_rgb_bench(const uint8_t* nv12, int width, int height, const vali_csc* csc, int threads,
-                                         double seconds, int simd, double* elapsed) {
+                                         double seconds, int simd, double* elapsed, const int* cpus, int n_cpus) {
+  cpu_set_t original;
+  const int have_original = sched_getaffinity(0, sizeof original, &original) == 0;
   if (!nv12 || !csc || width <= 0 || height <= 0 || (width & 1) || (height & 1))
     return -1;
   long long total = 0;
@@ -133,6 +140,14 @@ long long vali_oracle_nv12_to_rgb_bench(const uint8_t* nv12, int width, int heig
 #pragma omp parallel num_threads(threads) reduction(+ : total) reduction(max : t_all)
 #endif
   {
+#ifdef _OPENMP
+    if (cpus && n_cpus > 0) {
+      cpu_set_t one;
+      CPU_ZERO(&one);
+      CPU_SET(cpus[omp_get_thread_num() % n_cpus], &one);
+      (void)sched_setaffinity(0, sizeof one, &one);
+    }
+#endif
     uint8_t* in = (uint8_t*)malloc(src_bytes);
     uint8_t* out = (uint8_t*)malloc(dst_bytes);
     long long mine = 0;
@@ -165,6 +180,8 @@ long long vali_oracle_nv12_to_rgb_bench(const uint8_t* nv12, int width, int heig
     free(out);
     total += mine;
   }
+  if (have_original)
+    (void)sched_setaffinity(0, sizeof original, &original);
   if (elapsed)
     *elapsed = t_all;
   return total;

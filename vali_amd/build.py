@@ -121,7 +121,7 @@ def build_oracle(force=False):
         # -mfma so fmaf() is the hardware instruction (same value either way);
         # -ffp-contract=off so nothing else gets fused.  AVX2+FMA exists on every
         # x86-64 host an MI355X ships in.
-        _run(["gcc", "-O3", "-std=c11", "-fPIC", "-shared", "-mavx2", "-mfma",
+        _run(["gcc", "-O3", "-std=c11", "-D_GNU_SOURCE", "-fPIC", "-shared", "-mavx2", "-mfma",
               "-ffp-contract=off", "-fno-math-errno", "-fopenmp", *srcs, "-o", out, "-lm"])
     return out
 

@@ -269,6 +269,30 @@ PYBIND11_MODULE(_vali_shim, m) {
   m.def("event_record", [](int device, uintptr_t e, uintptr_t s) {
     check(vali_event_record(device, P(e), P(s)), "vali_event_record");
   });
+  m.def("event_query", [](int device, uintptr_t e) {
+    int done = 0;
+    check(vali_event_query(device, P(e), &done), "vali_event_query");
+    return done != 0;
+  });
+  m.def("stream_wait_event", [](int device, uintptr_t s, uintptr_t e) {
+    check(vali_stream_wait_event(device, P(s), P(e)), "vali_stream_wait_event");
+  });
+  m.def("host_alloc", [](int device, size_t bytes) {
+    void* p = nullptr;
+    check(vali_host_alloc(device, bytes, &p), "vali_host_alloc");
+    return (uintptr_t)p;
+  });
+  m.def("host_free", [](int device, uintptr_t p) { check(vali_host_free(device, P(p)), "vali_host_free"); });
+  m.def("mem_info", [](int device) {
+    size_t f = 0, t = 0;
+    check(vali_mem_info(device, &f, &t), "vali_mem_info");
+    return py::make_tuple(f, t);
+  });
+  m.def("device_pci_bus_id", [](int device) {
+    char buf[32] = {0};
+    check(vali_device_pci_bus_id(device, buf, (int)sizeof buf), "vali_device_pci_bus_id");
+    return std::string(buf);
+  });
   m.def("event_sync",
         [](int device, uintptr_t e) { check(vali_event_sync(device, P(e)), "vali_event_sync"); },
         py::call_guard<py::gil_scoped_release>());

@@ -287,6 +287,56 @@ int vali_stream_wait(int device, vali_stream_t stream) {
   return VALI_OK;
 }
 
+int vali_event_query(int device, vali_event_t event, int* done) {
+  VALI_REQUIRE(event && done, "null argument");
+  VALI_DEVICE(device);
+  const hipError_t e = hipEventQuery((hipEvent_t)event);
+  if (e == hipErrorNotReady) {
+    (void)hipGetLastError();
+    *done = 0;
+    return VALI_OK;
+  }
+  VALI_HIP_CHECK(e);
+  *done = 1;
+  return VALI_OK;
+}
+
+int vali_stream_wait_event(int device, vali_stream_t stream, vali_event_t event) {
+  VALI_REQUIRE(event, "null event");
+  VALI_DEVICE(device);
+  VALI_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), (hipEvent_t)event, 0));
+  return VALI_OK;
+}
+
+int vali_host_alloc(int device, size_t bytes, void** hptr) {
+  VALI_REQUIRE(hptr && bytes > 0, "bad argument");
+  VALI_DEVICE(device);
+  void* p = nullptr;
+  VALI_HIP_CHECK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+  *hptr = p;
+  return VALI_OK;
+}
+
+int vali_host_free(int device, void* hptr) {
+  VALI_DEVICE(device);
+  if (hptr)
+    VALI_HIP_CHECK(hipHostFree(hptr));
+  return VALI_OK;
+}
+
+int vali_mem_info(int device, size_t* free_bytes, size_t* total_bytes) {
+  VALI_REQUIRE(free_bytes && total_bytes, "null argument");
+  VALI_DEVICE(device);
+  VALI_HIP_CHECK(hipMemGetInfo(free_bytes, total_bytes));
+  return VALI_OK;
+}
+
+int vali_device_pci_bus_id(int device, char* out, int len) {
+  VALI_REQUIRE(out && len >= 16, "buffer of at least 16 bytes");
+  VALI_HIP_CHECK(hipDeviceGetPCIBusId(out, len, device));
+  return VALI_OK;
+}
+
 int vali_event_create(int device, vali_event_t* event) {
   VALI_REQUIRE(event, "null event");
   VALI_DEVICE(device);

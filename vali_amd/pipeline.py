@@ -1,19 +1,27 @@
-"""Batched, frame-sharded conversion pipeline: one process per GPU.
+"""Batched, frame-sharded surface pipeline: one process per GPU.
 
 New design (the reference has no multi-GPU code: SURVEY.md 2.1 / 8e).  Frames are
 independent, so N frames are split into contiguous blocks, one per rank; no frame ever
 crosses xGMI.  The only exchange step is a broadcast of the 32-byte colour-coefficient
 block (vali_csc) from rank 0 over torch.distributed (backend "nccl" = RCCL on ROCm;
 "gloo" in the CPU tests), so that every GPU converts with the same matrix.
+
+Two ways to feed a rank's GPU:
+* resident: the shard's surfaces are filled once and converted with one launch per step (`run_async`) -- what the
+  headline number measures (inputs already in HBM);
+* host-fed: `IngestRing` -- K slots of pinned host memory + device surfaces; the H2D copy of slot i+1 runs on a copy
+  stream while slot i is converted on the task's stream (events order the two; no host synchronisation per slot).  This
+  is what a decoder-fed pipeline delivers: bound by PCIe (53-55 GB/s / 12.4 MB = ~4.3 k 2160p NV12 frames/s per GPU).
 """
 from __future__ import annotations
 
-from typing import Optional, Sequence, Tuple
+import os
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
 from . import tasks
-from .enums import ColorspaceConversionContext, PixelFormat, TaskExecInfo
+from .enums import ColorspaceConversionContext, Interpolation, PixelFormat, TaskExecInfo
 from .surface import Surface
 
 
@@ -47,23 +55,112 @@ def broadcast_coefficients(coeffs: Optional[Sequence[float]], src: int = 0, devi
     return tuple(float(x) for x in block[:6].cpu().numpy())
 
 
+# ---- NUMA placement of a rank's host thread ---------------------------------------------------------------------
+def _parse_cpulist(text: str) -> List[int]:
+    cpus: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_cpus(pci_bus_id: str, sysfs: str = "/sys") -> Optional[List[int]]:
+    """CPUs of the NUMA node the GPU at PCI address `pci_bus_id` ("0000:c1:00.0") hangs off, from sysfs
+    (/sys/bus/pci/devices/<id>/numa_node, /sys/devices/system/node/node<N>/cpulist); None when the platform does not say
+    (single-node hosts report -1)."""
+    try:
+        dev = pci_bus_id.strip().lower()
+        if dev.count(":") == 1:
+            dev = "0000:" + dev
+        with open(os.path.join(sysfs, "bus/pci/devices", dev, "numa_node")) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None
+        with open(os.path.join(sysfs, "devices/system/node", f"node{node}", "cpulist")) as f:
+            cpus = _parse_cpulist(f.read())
+        return cpus or None
+    except (OSError, ValueError):
+        return None
+
+
+def bind_to_gpu_numa(gpu_id: int, sysfs: str = "/sys", pci_bus_id: Optional[str] = None) -> Optional[List[int]]:
+    """Restrict the calling process to the CPUs next to `gpu_id` (its uploads then come from local memory and its launch
+    thread does not hop sockets): one rank per GPU calls this once.  Returns the CPU list it bound to, None when the
+    topology is unknown or the platform has no affinity call -- never an error."""
+    if pci_bus_id is None:
+        from ._native import shim
+        try:
+            pci_bus_id = shim.device_pci_bus_id(int(gpu_id))
+        except Exception:
+            return None
+    cpus = gpu_numa_cpus(pci_bus_id, sysfs)
+    if not cpus or not hasattr(os, "sched_setaffinity"):
+        return None
+    allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+    if not allowed:
+        return None
+    os.sched_setaffinity(0, allowed)
+    return allowed
+
+
+# ---- the operators a pipeline can run -------------------------------------------------------------------------
+OPS = ("convert", "resize", "ud", "preproc")
+
+
+def op_geometry(op: str, width: int, height: int, dst_format: PixelFormat, dst_size=None):
+    """(destination format, (dst_w, dst_h), algorithmic bytes per frame) of `op` on NV12 width x height frames."""
+    if op not in OPS:
+        raise ValueError(f"op must be one of {OPS}")
+    dw, dh = (width, height) if op == "convert" or dst_size is None else dst_size
+    src = width * height * 3 // 2
+    if op == "convert":
+        fmt = dst_format
+        out = width * height * 3
+    elif op == "resize":
+        fmt, out = PixelFormat.NV12, dw * dh * 3 // 2
+    elif op == "ud":
+        fmt, out = PixelFormat.RGB, dw * dh * 3
+    else:
+        fmt, out = PixelFormat.RGB_32F_PLANAR, dw * dh * 12
+    return fmt, (int(dw), int(dh)), src + out
+
+
 class BatchedFramePipeline:
-    """Owns this rank's shard of surfaces and converts it with one launch per step."""
+    """Owns this rank's shard of surfaces and runs `op` over it with one launch per step.
+
+    op = "convert"  NV12 -> dst_format (RGB / BGR / RGB_PLANAR) at the same size: PySurfaceConverter, the headline
+         "resize"   NV12 -> NV12 at dst_size, the reference's filter (Lanczos): PySurfaceResizer
+         "ud"       NV12 -> RGB at dst_size: PySurfaceUD
+         "preproc"  NV12 -> normalised RGB_32F_PLANAR at dst_size: PySurfacePreprocessor
+    """
 
     def __init__(self, gpu_id: int, width: int, height: int, frames: int,
-                 dst_format: PixelFormat = PixelFormat.RGB, stream=None):
-        from .tasks import PySurfaceConverter
-
-        self.gpu_id, self.width, self.height, self.frames = gpu_id, width, height, frames
-        self.converter = PySurfaceConverter(gpu_id, stream)
-        self.srcs = [Surface.Make(PixelFormat.NV12, width, height, gpu_id) for _ in range(frames)]
-        self.dsts = [Surface.Make(dst_format, width, height, gpu_id) for _ in range(frames)]
-        self.batch = self.converter.PrepareBatch(self.srcs, self.dsts)
+                 dst_format: PixelFormat = PixelFormat.RGB, stream=None, op: str = "convert", dst_size=None):
+        self.gpu_id, self.width, self.height, self.frames, self.op = gpu_id, width, height, frames, op
+        self.dst_format, self.dst_size, self.bytes_per_frame = op_geometry(op, width, height, dst_format, dst_size)
+        if op == "convert":
+            self.task = tasks.PySurfaceConverter(gpu_id, stream)
+        elif op == "resize":
+            self.task = tasks.PySurfaceResizer(PixelFormat.NV12, gpu_id, stream, interpolation=Interpolation.LANCZOS)
+        elif op == "ud":
+            self.task = tasks.PySurfaceUD(gpu_id, stream)
+        else:
+            self.task = tasks.PySurfacePreprocessor(gpu_id, stream, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), div=255.0)
+        self.converter = self.task            # (the name round 1-2 callers use)
+        self.srcs, self.dsts, self.batch = self._make_batch(frames)
         self._csc = None
+        self._cc = None
+
+    def _make_batch(self, n: int):
+        srcs = [Surface.Make(PixelFormat.NV12, self.width, self.height, self.gpu_id) for _ in range(n)]
+        dsts = [Surface.Make(self.dst_format, self.dst_size[0], self.dst_size[1], self.gpu_id) for _ in range(n)]
+        return srcs, dsts, self.task.PrepareBatch(srcs, dsts)
 
     @property
     def Stream(self) -> int:
-        return self.converter.Stream
+        return self.task.Stream
 
     def set_coefficients(self, cc_ctx: Optional[ColorspaceConversionContext], src: int = 0,
                          device=None, group=None) -> Tuple[float, ...]:
@@ -77,14 +174,192 @@ class BatchedFramePipeline:
             raise ValueError("unsupported colour conversion parameters")
         coeffs = broadcast_coefficients(coeffs, src, device, group)
         self._csc = tasks._csc(coeffs)
+        self._cc = cc_ctx if cc_ctx is not None else ColorspaceConversionContext()
         return coeffs
 
+    def _launch(self, batch) -> Tuple[bool, TaskExecInfo]:
+        if self.op == "convert":
+            if self._csc is None:
+                raise RuntimeError("set_coefficients() first")
+            return self.task.RunBatchAsync(batch, csc=self._csc)
+        if self.op == "preproc":
+            return self.task.RunBatchAsync(batch, cc_ctx=self._cc)
+        return self.task.RunBatchAsync(batch)
+
     def run_async(self) -> Tuple[bool, TaskExecInfo]:
-        if self._csc is None:
-            raise RuntimeError("set_coefficients() first")
-        return self.converter.RunBatchAsync(self.batch, csc=self._csc)
+        return self._launch(self.batch)
 
     def run(self) -> Tuple[bool, TaskExecInfo]:
         r = self.run_async()
-        self.converter._sync()
+        self.task._sync()
         return r
+
+    def ingest_ring(self, slots: int = 3, frames_per_slot: Optional[int] = None, backend=None) -> "IngestRing":
+        return IngestRing(self, slots, frames_per_slot or min(self.frames, 16), backend)
+
+
+# ---- host-fed operation: pinned staging + overlapped H2D ---------------------------------------------------------
+class _HipBackend:
+    """the device side of the ring: pinned host memory, a copy stream, events (vali_host_alloc, vali_stream_wait_event ...)"""
+
+    def __init__(self, gpu_id: int):
+        from ._native import shim
+        self.shim, self.gpu = shim, int(gpu_id)
+        self.copy_stream = shim.stream_create(self.gpu)
+        self._host = []
+
+    def host_buffer(self, nbytes: int) -> np.ndarray:
+        import ctypes
+        p = self.shim.host_alloc(self.gpu, int(nbytes))
+        self._host.append(p)
+        return np.ctypeslib.as_array((ctypes.c_uint8 * int(nbytes)).from_address(p))
+
+    def new_event(self):
+        return self.shim.event_create(self.gpu)
+
+    def upload(self, host: np.ndarray, frame_bytes: int, srcs: Sequence[Surface]) -> None:
+        base = host.ctypes.data
+        for i, s in enumerate(srcs):
+            off = 0
+            for p in s._planes:
+                row = p.Width * p.ElemSize
+                self.shim.memcpy2d_async(self.gpu, p.GpuMem, p.Pitch, base + i * frame_bytes + off, row, row, p.Height, 0,
+                                         self.copy_stream)
+                off += row * p.Height
+
+    def record(self, event, stream) -> None:
+        self.shim.event_record(self.gpu, event, stream)
+
+    def stream_wait(self, stream, event) -> None:
+        self.shim.stream_wait_event(self.gpu, stream, event)
+
+    def host_wait(self, event) -> None:
+        self.shim.event_sync(self.gpu, event)
+
+    def is_done(self, event) -> bool:
+        return bool(self.shim.event_query(self.gpu, event))
+
+    def close(self) -> None:
+        for p in self._host:
+            try:
+                self.shim.host_free(self.gpu, p)
+            except Exception:
+                pass
+        self._host = []
+        if self.copy_stream:
+            try:
+                self.shim.stream_destroy(self.gpu, self.copy_stream)
+            except Exception:
+                pass
+            self.copy_stream = 0
+
+
+class _Slot:
+    __slots__ = ("host", "srcs", "dsts", "batch", "uploaded", "done", "busy", "tag")
+
+
+class IngestRing:
+    """Host frames -> GPU operator, K slots deep.
+
+        ring = pipe.ingest_ring(slots=3, frames_per_slot=16)
+        for chunk_id, chunk in enumerate(decoder):         # chunk: up to 16 frames
+            for s in ring.reap():                          # finished slots, oldest first; blocks only when the slot that is
+                consume(s.dsts, s.tag)                     #   about to be reused has not finished yet
+            slot = ring.acquire()
+            slot.host[:n * ring.frame_bytes] = ...         # the decoder writes straight into pinned memory
+            ring.submit(slot, tag=chunk_id)                # H2D on the copy stream, then the operator on the task's stream
+        for s in ring.drain():
+            consume(s.dsts, s.tag)
+
+    (`feed(chunks)` is that loop as a generator.)  Order per slot: [copy stream] H2D of the slot -> event `uploaded`;
+    [task stream] waits `uploaded`, runs the operator on the slot's batch -> event `done`.  The copy stream never waits for
+    the task stream, so the upload of slot i+1 overlaps the conversion of slot i.  A slot's outputs must be consumed before
+    the slot is acquired again: reap() hands them out first, acquire() refuses a slot whose outputs were not reaped.
+    `backend` abstracts the device calls (tests run the ring's ordering logic without a GPU)."""
+
+    def __init__(self, pipe: BatchedFramePipeline, slots: int = 3, frames_per_slot: int = 16, backend=None):
+        if slots < 2:
+            raise ValueError("an ingest ring needs at least 2 slots to overlap anything")
+        self.pipe, self.n = pipe, int(frames_per_slot)
+        self.frame_bytes = pipe.width * pipe.height * 3 // 2
+        self.backend = backend if backend is not None else _HipBackend(pipe.gpu_id)
+        self.slots: List[_Slot] = []
+        for _ in range(slots):
+            s = _Slot()
+            s.host = self.backend.host_buffer(self.n * self.frame_bytes)
+            s.srcs, s.dsts, s.batch = pipe._make_batch(self.n)
+            s.uploaded, s.done = self.backend.new_event(), self.backend.new_event()
+            s.busy, s.tag = False, None
+            self.slots.append(s)
+        self._next = 0
+        self._pending: List[_Slot] = []        # submitted, outputs not handed out yet; submission order
+        self.frames_submitted = 0
+
+    def reap(self, make_room: bool = True) -> List[_Slot]:
+        """slots whose outputs are ready, oldest first.  make_room: if the slot acquire() would hand out next is still
+        pending, wait for it (and everything submitted before it) -- the only place the host blocks."""
+        out: List[_Slot] = []
+        must = self.slots[self._next] if make_room else None
+        while self._pending:
+            s = self._pending[0]
+            blocking = must is not None and must in self._pending
+            if not blocking and not self.backend.is_done(s.done):
+                break
+            if blocking:
+                self.backend.host_wait(s.done)
+            self._pending.pop(0)
+            s.busy = False
+            out.append(s)
+        return out
+
+    def acquire(self) -> _Slot:
+        s = self.slots[self._next]
+        if s in self._pending:
+            raise RuntimeError("IngestRing.acquire: the next slot still holds outputs nobody took -- call reap() first")
+        self._next = (self._next + 1) % len(self.slots)
+        return s
+
+    def submit(self, slot: _Slot, tag=None) -> Tuple[bool, TaskExecInfo]:
+        b = self.backend
+        b.upload(slot.host, self.frame_bytes, slot.srcs)
+        b.record(slot.uploaded, b.copy_stream)
+        b.stream_wait(self.pipe.Stream, slot.uploaded)
+        r = self.pipe._launch(slot.batch)
+        b.record(slot.done, self.pipe.Stream)
+        slot.busy, slot.tag = True, tag
+        self._pending.append(slot)
+        self.frames_submitted += self.n
+        return r
+
+    def drain(self) -> List[_Slot]:
+        out = []
+        while self._pending:
+            s = self._pending.pop(0)
+            self.backend.host_wait(s.done)
+            s.busy = False
+            out.append(s)
+        return out
+
+    def feed(self, chunks, fill: Optional[Callable] = None):
+        """The loop of the class comment as a generator: every item of `chunks` is a uint8 array of up to n frames (or
+        anything `fill(slot.host, item)` understands); yields (tag, dsts) of finished slots in submission order.  The
+        consumer runs between two submissions, i.e. before the slot it is looking at can be reused."""
+        for tag, item in enumerate(chunks):
+            for s in self.reap():
+                yield s.tag, s.dsts
+            slot = self.acquire()
+            if fill is not None:
+                fill(slot.host, item)
+            else:
+                a = np.asarray(item, np.uint8).reshape(-1)
+                slot.host[:a.size] = a
+            ok, info = self.submit(slot, tag)
+            if not ok:
+                raise RuntimeError(f"IngestRing: operator failed: {info}")
+        for s in self.drain():
+            yield s.tag, s.dsts
+
+    def close(self) -> None:
+        self.drain()
+        if hasattr(self.backend, "close"):
+            self.backend.close()
