@@ -36,6 +36,13 @@ p10 = {
 # NON-integer ratio (848x464 -> 640x360 luma, 424x232 -> 640x360 chroma).  tests/test_oracle_lanczos_pin.py
 planar = {"yuv444": load("YUV420_PixelFormat.YUV444", np.uint8).reshape(3, H, W)[:, :ROWS]}
 np.savez_compressed(OUT / "ud_640x360_yuv420_rows120.npz", **planar)
+# the same for the 10-bit source (frame 0 of test_hevc10.mkv, CPU-decoded YUV420_10bit): NPP Lanczos on 16-bit planes
+# (UDSurface.cpp:60-93) -- the only reference-held output of the u16 resize path.  Its input needs a decoder (and is a
+# different picture from test.mp4's: correlation 0.00 with the 8-bit golden), so offline it pins only its own value
+# range; tests/test_gpu_reference_video.py compares it with the HIP path on a box that has PyAV.
+planar10 = {"yuv444_10bit": load("YUV420_10bit_PixelFormat.YUV444_10bit", np.uint16).reshape(3, H, W)[:, :ROWS]}
+np.savez_compressed(OUT / "ud_640x360_yuv420_10bit_rows120.npz", **planar10)
+print("ud_640x360_yuv420_10bit_rows120.npz", (OUT / "ud_640x360_yuv420_10bit_rows120.npz").stat().st_size)
 print("ud_640x360_yuv420_rows120.npz", (OUT / "ud_640x360_yuv420_rows120.npz").stat().st_size)
 # whole-file identities, checked here once on the full files (recorded in DESIGN.md)
 full_rgb = load("NV12_PixelFormat.RGB", np.uint8)

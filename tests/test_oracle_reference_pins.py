@@ -208,3 +208,20 @@ def test_lanczos_taps_against_npp_at_a_non_integer_ratio(oracle, frame):
     # the float64 model of the SAME filter agrees with the C restatement (so the comparison above is apples to apples)
     same, _ = score(lanczos_np(luma, 640, 360))
     assert abs(same - mine) < 0.05
+
+
+def test_what_the_10bit_lanczos_golden_states_by_itself():
+    """The reference's only u16 resize output (UDPlanar YUV420_10bit -> YUV444_10bit, NPP Lanczos on 16-bit planes,
+    UDSurface.cpp:60-93; frame 0 of test_hevc10.mkv).  Its input needs a decoder and is a DIFFERENT picture from the 8-bit
+    fixtures (correlation 0.00 with the 8-bit golden), so offline it cannot decide rounding or saturation of the u16 path
+    -- tests/test_gpu_reference_video.py does on a box with PyAV.  What it states alone: samples are LSB-aligned 10-bit
+    values, and no sample of the crop reaches 0 or 1023, i.e. the fixture never exercises a clamp (neither to 10 bits nor
+    to 16): the oracle's choice -- round-half-even, saturate at 65535 like nppiResize_16u -- is not contradicted, and not
+    confirmed."""
+    g = np.load(GOLDEN / "ud_640x360_yuv420_10bit_rows120.npz")["yuv444_10bit"]
+    assert g.dtype == np.uint16 and g.shape == (3, 120, 640)
+    assert int(g.max()) <= 1023 and int(g.min()) >= 0
+    assert int((g == 1023).sum()) == 0 and int((g == 0).sum()) == 0       # no clamp event to learn from
+    assert np.any(g & 1) and np.any(g & 2)                                # LSB-aligned, all ten bits in use
+    luma, cb, cr = (p.astype(np.float64) for p in g)
+    assert 300 < luma.mean() < 800 and abs(cb.mean() - 512) < 40 and abs(cr.mean() - 512) < 40   # limited-range video
