@@ -60,3 +60,85 @@ def test_every_8bit_pair_keeps_up_with_the_headline_pair(vali, gpu):
         if r < FLOOR * ref:
             slow.append(f"{sf.name}->{df.name}: {r / 1e12:.2f} TB/s = {r / ref:.2f} of NV12->RGB ({ref / 1e12:.2f} TB/s)")
     assert not slow, "converter pairs below the floor:\n" + "\n".join(slow)
+
+
+# ---- the gather kernels (resize, UD, quarter turn): same idea, same process, their own floors -------------------------
+# (ratio to NV12 -> RGB at 2160p measured in this process; typical values in the comment, floor ~0.72 of them: a silent
+# scratch spill, a prefetch that stopped running ahead, a fall back to a byte path all cost far more than that -- those
+# were found by hand with tools/cliffs.py until round 3)
+def _timed(vali, gpu, stream, fn, reps=8):
+    from vali_amd._native import shim
+    best = 1e9
+    for _ in range(3):
+        for _ in range(2):
+            fn()
+        e0, e1 = shim.event_create(gpu), shim.event_create(gpu)
+        shim.event_record(gpu, e0, stream)
+        for _ in range(reps):
+            fn()
+        shim.event_record(gpu, e1, stream)
+        shim.event_sync(gpu, e1)
+        best = min(best, shim.event_elapsed_ms(e0, e1) / reps)
+        shim.event_destroy(gpu, e0)
+        shim.event_destroy(gpu, e1)
+    return best
+
+
+def _surfaces(vali, gpu, fmt, w, h, n, fill=True):
+    out = [vali.Surface.Make(fmt, w, h, gpu) for _ in range(n)]
+    if fill:
+        host = np.random.default_rng(1).integers(16, 236, out[0].HostSize, dtype=np.uint8)
+        up = vali.PyFrameUploader(gpu)
+        for s in out:
+            assert up.Run(host, s)[0]
+    return out
+
+
+GATHER_CASES = [
+    # name, typical ratio, floor, builder -> (task, batch, bytes per frame, launch)
+    ("lanczos NV12 2160p->1920x1088 (2:1 along x)", 0.78, 0.55, "resize", (3840, 2160, 1920, 1088)),
+    ("lanczos NV12 2160p->1936x1088 (general)", 0.48, 0.34, "resize", (3840, 2160, 1936, 1088)),
+    ("bilinear NV12 2160p->1920x1088", 0.93, 0.66, "bilinear", (3840, 2160, 1920, 1088)),
+    ("UD NV12 2160p->RGB 1080p (exact 2x)", 0.84, 0.60, "ud", (3840, 2160, 1920, 1080)),
+    ("UD NV12 1080p->RGB 720p (any ratio)", 0.62, 0.44, "ud", (1920, 1080, 1280, 720)),
+    ("rotate RGB 1080p 90 degrees", 0.75, 0.52, "rot", (1920, 1080, 1080, 1920)),
+]
+
+
+def test_gather_kernels_keep_their_distance_to_the_headline_kernel(vali, gpu):
+    cc = vali.ColorspaceConversionContext(vali.ColorSpace.BT_709, vali.ColorRange.MPEG)
+    n = 24
+    cvt = vali.PySurfaceConverter(gpu)
+    s0, d0 = _surfaces(vali, gpu, vali.NV12, 3840, 2160, n), _surfaces(vali, gpu, vali.RGB, 3840, 2160, n, fill=False)
+    b0 = cvt.PrepareBatch(s0, d0)
+    ref = 37324800 * n / (_timed(vali, gpu, cvt.Stream, lambda: cvt.RunBatchAsync(b0, cc)) * 1e-3)
+    del b0, s0, d0
+    slow, report = [], []
+    for name, typical, floor, kind, (sw, sh, dw, dh) in GATHER_CASES:
+        if kind in ("resize", "bilinear"):
+            task = vali.PySurfaceResizer(vali.NV12, gpu, interpolation=vali.Interpolation.LANCZOS if kind == "resize"
+                                         else vali.Interpolation.LINEAR)
+            srcs, dsts = _surfaces(vali, gpu, vali.NV12, sw, sh, n), _surfaces(vali, gpu, vali.NV12, dw, dh, n, fill=False)
+            nbytes = (sw * sh + dw * dh) * 3 // 2
+            b = task.PrepareBatch(srcs, dsts)
+            run = lambda: task.RunBatchAsync(b)           # noqa: E731
+        elif kind == "ud":
+            task = vali.PySurfaceUD(gpu)
+            srcs, dsts = _surfaces(vali, gpu, vali.NV12, sw, sh, n), _surfaces(vali, gpu, vali.RGB, dw, dh, n, fill=False)
+            nbytes = sw * sh * 3 // 2 + dw * dh * 3
+            b = task.PrepareBatch(srcs, dsts)
+            run = lambda: task.RunBatchAsync(b)           # noqa: E731
+        else:
+            task = vali.PySurfaceRotator(gpu)
+            srcs, dsts = _surfaces(vali, gpu, vali.RGB, sw, sh, n), _surfaces(vali, gpu, vali.RGB, dw, dh, n, fill=False)
+            nbytes = 2 * sw * sh * 3
+            b = task.PrepareBatch(srcs, dsts)
+            run = lambda: task.RunBatchAsync(b, angle=90.0)   # noqa: E731
+        assert run()[0]
+        r = nbytes * n / (_timed(vali, gpu, task.Stream, run) * 1e-3) / ref
+        report.append(f"{name}: {r:.2f} of NV12->RGB (typical {typical}, floor {floor})")
+        if r < (9.0 if FLOOR > 1 else floor):
+            slow.append(report[-1])
+        del b, srcs, dsts
+    print("\n" + "\n".join(report))
+    assert not slow, f"gather kernels below their floor (NV12->RGB: {ref / 1e12:.2f} TB/s):\n" + "\n".join(slow)
