@@ -8,7 +8,7 @@ launch is the dispatch with the largest counter value (the same kernel is also l
                                              64 B: MI355X_MICROARCH.md "HBM"; calibrated on the headline kernel,
                                              whose corrected sum equals its algorithmic bytes to 4 digits)
   HBM write = WRITE_SIZE [KiB] x 1024
-Writes gpurun_out/r02_secondary_traffic.json (copied to profiles/ and read by bench_configs.roofline()) and a
+Writes gpurun_out/<TAG>_secondary_traffic.json (TAG = $VALI_PROFILE_TAG, default r03) (copied to profiles/ and read by bench_configs.roofline()) and a
 markdown table.
 """
 import csv
@@ -21,14 +21,16 @@ from collections import defaultdict
 from pathlib import Path
 
 ROOT = Path(os.environ.get("GRAFT_REPO_ROOT", Path(__file__).resolve().parent.parent))
-OUT = ROOT / "gpurun_out" / "prof_r02_secondary"
+TAG = os.environ.get("VALI_PROFILE_TAG", "r03")
+OUT = ROOT / "gpurun_out" / f"prof_{TAG}_secondary"
 # config key -> (bench_configs function, kernel-name substring, frames per launch)
 KEYS = {
     "hl1080": ("hl1080", "k_nv12_rgb8", 1024),
     "cfg3": ("cfg3", "k_resize_pointk<", 64),
     "interp_bilinear": ("interp", "k_resize<", 64),
-    "interp_lanczos": ("interp", "k_resize_taps<", 64),
-    "cfg4_ud": ("cfg4", "k_ud_down2<", 64),
+    "interp_lanczos": ("interp", "k_resize_cols_x2<", 64),        # 2160p -> 1920x1088: exactly 2:1 along x
+    "interp_lanczos_1936": ("interp", "k_resize_cols<", 64),      # 2160p -> 1936x1088: the general columns-first form
+    "cfg4_ud": ("cfg4", "k_ud_half<", 64),
     "cfg4_rot": ("cfg4", "k_rotate_tile", 64),
     "cfg4_fused": ("cfg4", "k_ud_down2_t<", 64),
     "udgen_1280x720": ("udgen", "k_ud_nv12<", 64),   # (the larger of udgen's two geometries = the largest dispatch)
@@ -77,21 +79,28 @@ def main():
         result[key] = {"kernel": k.replace("void vali::", "").split("(")[0], "frames": frames,
                        "hbm_read_bytes_per_launch": rd, "hbm_written_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
                        "max_ns": float(st.get("MaxNs", 0) or 0), "calls": int(st.get("Calls", 0) or 0),
-                       "source": "profiles/r02_secondary_traffic.json (rocprofv3 --pmc FETCH_SIZE x1024 x2 + WRITE_SIZE x1024, "
+                       "source": f"profiles/{TAG}_secondary_traffic.json (rocprofv3 --pmc FETCH_SIZE x1024 x2 + WRITE_SIZE x1024, "
                                  "separate passes, batch launch = largest dispatch)"}
         table.append(f"| {key} | `{result[key]['kernel']}` | {frames} | {rd:.5g} | {wr:.5g} | {rd + wr:.5g} | {st.get('MaxNs', '')} |")
     if "cfg4_ud" in result and "cfg4_rot" in result:
         a, b = result["cfg4_ud"], result["cfg4_rot"]
-        result["cfg4_chain"] = {"kernel": "k_ud_down2 + k_rotate_tile", "frames": 64,
+        result["cfg4_chain"] = {"kernel": "k_ud_half + k_rotate_tile", "frames": 64,
                                 "hbm_bytes_per_launch": a["hbm_bytes_per_launch"] + b["hbm_bytes_per_launch"], "source": a["source"]}
-    (ROOT / "gpurun_out" / "r02_secondary_traffic.json").write_text(json.dumps(result, indent=1) + "\n")
-    md = ["# r02: HBM traffic of the secondary kernels (rocprofv3 PMC, tools/profile_secondary.py)", "",
+    (ROOT / "gpurun_out" / f"{TAG}_secondary_traffic.json").write_text(json.dumps(result, indent=1) + "\n")
+    # the kernel-stats table of every config's trace run, as rocprofv3 wrote it: frac can be recomputed from these alone
+    import shutil
+    for cfg in done:
+        for f in glob.glob(str(OUT / cfg / "trace" / "**" / "*kernel_stats.csv"), recursive=True):
+            shutil.copy(f, ROOT / "gpurun_out" / f"{TAG}_{cfg}_kernel_stats.csv")
+    md = [f"# {TAG}: HBM traffic of the secondary kernels (rocprofv3 PMC, tools/profile_secondary.py)", "",
+          "Every config cycles >= 1.5 GiB of distinct surface sets per timed loop (tools/bench_configs.py); counters are per launch "
+          "of one 64-frame set.", "",
           "| config | kernel | frames per launch | HBM read B | HBM written B | sum | longest launch ns |", "|---|---|---|---|---|---|---|"] + table
     md += ["", "un-profiled bench lines of the same box:", "", "```"]
     for cfg in done:
         md += [l for l in (OUT / cfg / "unprofiled.log").read_text().splitlines() if l.startswith("{")]
     md += ["```", ""]
-    (ROOT / "gpurun_out" / "r02_secondary_traffic.md").write_text("\n".join(md))
+    (ROOT / "gpurun_out" / f"{TAG}_secondary_traffic.md").write_text("\n".join(md))
     print("\n".join(md)[:5000])
 
 
