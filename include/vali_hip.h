@@ -383,7 +383,8 @@ enum vali_tuning_key {
                                          exact-ratio kernels for output widths that are multiples of 8; 2: for all */
   VALI_TUNE_UD_OCC5 = 7,              /* no effect since round 2 (selected a 96-register instantiation of the staged UD
                                          kernel, removed: it spilled); the key keeps its number                       */
-  VALI_TUNE_ROTATE_NO_TILE = 8,       /* 1: quarter / half turns through the bilinear kernel; 2: column-major tile walk */
+  VALI_TUNE_ROTATE_NO_TILE = 8,       /* 1: quarter / half turns through the bilinear kernel; 2: column-major tile walk;
+                                         3: fused UD + quarter turn on 128-row tiles (default 64)                  */
   VALI_TUNE_ROCTX = 9,                /* 1: a roctx range around every operator entry point (see below)            */
   VALI_TUNE_RESIZE_NO_SEPARABLE = 10, /* Lanczos / bicubic rows per wave: 0 by launch size, 1: 8, 2: 2, 3: 32           */
   VALI_TUNE_ROWS_PER_WAVE = 11,       /* UD, bilinear / point resize, fused pre-processing: dst rows (row pairs) a wave

@@ -73,7 +73,8 @@ def test_down2_foreign_memory(vali, gpu, oracle, pad, skew):
 
 
 @pytest.mark.parametrize("angle", [90.0, 180.0, 270.0])
-@pytest.mark.parametrize("geom", [(3840, 2160, 1920, 1080), (1002, 500, 501, 333), (70, 48, 35, 5), (8, 8, 4, 4)])
+@pytest.mark.parametrize("geom", [(3840, 2160, 1920, 1080), (1002, 500, 501, 333), (70, 48, 35, 5), (8, 8, 4, 4),
+                                  (1040, 200, 520, 100), (144, 24, 72, 12), (2064, 520, 1032, 260)])   # exactly 2:1 both ways: the 64 x 64 tile form
 def test_down2_rotated(vali, gpu, oracle, angle, geom):
     sw, sh, uw, uh = geom
     nv = make_nv12(sw, sh, 23)

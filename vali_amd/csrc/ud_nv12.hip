@@ -1450,6 +1450,122 @@ __global__ void __launch_bounds__(kBlock) k_ud_half(const UdArgs a) {
   }
 }
 
+// ---- the same lean form with the output written turned by 90 / 270 degrees: BASELINE config 4 as ONE pass ----
+// k_ud_down2_t collects 256 x 32 tiles, so a destination row receives 32 pixels = 96 bytes per tile: three quarters of a
+// line, 1.13x the written bytes at the memory (profiles/r02_secondary_traffic.md).  Here a workgroup owns 64 columns x 128
+// (or 64: the default, see the launch) rows of the (virtual) un-rotated output: a destination row then gets 128 pixels =
+// 384 bytes = three whole lines per tile (64: 192 bytes, completed by the next tile of the same XCD).  Compute phase: 8 lanes x 8 pixels cover a row of the tile (one 128-byte line of luma per source row), 8 rows per
+// wave instruction, each wave walks 32 (16) rows in 4 (2) steps; pixels go to LDS as one dword each (row stride 65 dwords: the
+// 8 x 8 lanes of a step and the 16 x 4 lanes of a store hit all banks twice at most).  Store phase: 16 lanes x 4 pixels
+// (12 bytes, one dwordx3) walk half a destination segment for 4 neighbouring destination rows.
+template <int ROT, int TH>
+__global__ void __launch_bounds__(kBlock) k_ud_half_t(const UdArgs a) {
+  static_assert(ROT == 1 || ROT == 3, "quarter turns only");
+  constexpr int TW = 64, SD = TW + 1, RW = TH / kWavesPerBlock, STEPS = RW / 8; // rows per wave, 8-row steps per wave
+  static_assert(TH == 64 || TH == 128, "tile rows");
+  __shared__ u32 tile[TH * SD];
+  u32 tile_x, tile_y, frame;
+  {
+    u32 t;
+    if (!frame_tile_of_block(a.map, frame, t))
+      return;
+    const u32 tiles_y = a.map.per_frame / a.map.tiles_x; // consecutive workgroups walk DOWN the UD image: neighbouring
+    tile_x = t / tiles_y;                                // segments of the same destination rows
+    tile_y = t - tile_x * tiles_y;
+  }
+  const SurfRef s = load_surface(a.d_src, a.src, frame);
+  const SurfRef d = load_surface(a.d_dst, a.dst, frame);
+  const int dw = d.height, dh = d.width; // size of the (virtual) un-rotated UD output; dw % 8 == 0, dh % 4 == 0 (host)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int g = lane >> 3, c = lane & 7;
+  const int xw = tile_x * TW, yb = tile_y * TH;
+  const int x0 = xw + 8 * c;
+  const bool has = x0 < dw;
+  const u32 off16 = (u32)(2 * min(x0, dw - kD2LanePx));
+  const u32 offb = (u32)max(2 * min(x0, dw - kD2LanePx) - 4, 0);   // the dword before the lane's own bytes
+  struct Rows {
+    uint4 v[4];     // the lane's 16 bytes of luma 2y-1, luma 2y, chroma y-1, chroma y
+    u32 before[4];  // the dword in front of them
+  };
+  auto issue = [&](int step) {
+    const int y = min(yb + wave * RW + min(step, STEPS - 1) * 8 + g, dh - 1);
+    const u32 ro[4] = {(u32)(max(2 * y - 1, 0) * s.pitch[0]), (u32)(2 * y * s.pitch[0]),
+                       (u32)(max(y - 1, 0) * s.pitch[1]), (u32)(y * s.pitch[1])};
+    Rows r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint8_t* row = (k < 2 ? s.p[0] : s.p[1]) + ro[k];
+      const v4u32 w = gload_u<v4u32>(row + off16);
+      r.v[k] = make_uint4(w.x, w.y, w.z, w.w);
+      r.before[k] = gload_u<u32>(row + offb);
+    }
+    return r;
+  };
+  auto compute = [&](int step, const Rows& r) {
+    const int rr = wave * RW + step * 8 + g;
+    D2Quad q0, q1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const u32 edge = k < 2 ? r.v[k].x << 24 : r.v[k].x << 16;       // column -1 = column 0 at the image's left edge
+      q0.p[k] = x0 == 0 ? edge : r.before[k]; q0.a[k] = r.v[k].x; q0.b[k] = r.v[k].y;
+      q1.p[k] = r.v[k].y; q1.a[k] = r.v[k].z; q1.b[k] = r.v[k].w;
+    }
+    float c0[8], c1[8], c2[8];
+    const D2Taps none = {};
+    d2_compute<UD_RGB_U8, true>(none, q0, c0, c1, c2);
+    d2_compute<UD_RGB_U8, true>(none, q1, c0 + 4, c1 + 4, c2 + 4);
+    u32 px[8];
+    trunc_pack_px4(c0, c1, c2, px);
+    trunc_pack_px4(c0 + 4, c1 + 4, c2 + 4, px + 4);
+    if (has && yb + rr < dh) {
+      u32* t = tile + rr * SD + 8 * c;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        t[j] = px[j];
+    }
+  };
+  // two steps in flight, both register sets named statically
+  Rows ra = issue(0);
+  __builtin_amdgcn_sched_barrier(0);
+  Rows rb = issue(1);
+  __builtin_amdgcn_sched_barrier(0);
+  compute(0, ra);
+  if constexpr (STEPS == 4) {
+    ra = issue(2);
+    compute(1, rb);
+    rb = issue(3);
+    compute(2, ra);
+    compute(3, rb);
+  } else {
+    compute(1, rb);
+  }
+  __syncthreads();
+  // transposed store: destination row <-> tile column.  ROT 1: dst(y, uw-1-x) = ud(x, y), pixels in rising y;
+  // ROT 3: dst(uh-1-y, x) = ud(x, y), pixels in falling y (ud_rot_store)
+  const int t = threadIdx.x, qd = t & 15, cc = (t >> 4) & 3, grp = t >> 6; // row quad, column in the group of 4, wave
+  constexpr int HALVES = TH / 64;                                           // 16 row quads per store instruction
+#pragma unroll 1
+  for (int pass = 0; pass < 4 * HALVES; ++pass) {
+    const int half = pass % HALVES, lc = ((pass / HALVES) * 4 + grp) * 4 + cc; // 16 groups of 4 columns x the halves of the rows
+    const int x = xw + lc;
+    const int quad = half * 16 + qd;                                       // rows 4 quad .. 4 quad + 3 of the tile
+    const int r0 = ROT == 1 ? 4 * quad : TH - 4 - 4 * quad;                // lowest tile row of the quad
+    if (x >= dw || yb + r0 >= dh)                                          // (dh % 4 == 0: a quad is whole or absent)
+      continue;
+    u32 pxl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      pxl[j] = tile[(ROT == 1 ? r0 + j : r0 + 3 - j) * SD + lc];
+    const int drow = ROT == 1 ? dw - 1 - x : x;
+    const int dx0 = ROT == 1 ? yb + r0 : dh - 1 - (yb + r0 + 3);
+    uint8_t* o = d.p[0] + (u32)(drow * d.pitch[0]) + (u32)(dx0 * 3);
+    typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+    const v3u32 w = {pxl[0] | (pxl[1] << 24), (pxl[1] >> 8) | (pxl[2] << 16), (pxl[2] >> 16) | (pxl[3] << 8)};
+    gstore_u<v3u32>(o, w);
+  }
+}
+
 // The same arithmetic with the output written turned by 90 / 270 degrees (ROT 1 / 3; NV12 -> packed
 // RGB): BASELINE config 4 as one pass.  The transposed store needs the 256 x 32 workgroup tile of
 // k_ud_nv12 (one dword per pixel in LDS, ud_rot_store), so a wave covers 256 columns and fetches TWO
@@ -1729,6 +1845,24 @@ static int launch_ud(UdArgs& a, int src_fmt, int src_w, int src_h, int dst_w, in
     else if (kind == UD_RGB_U8) VALI_UD_D2(UD_RGB_U8, 0);
     else VALI_UD_D2(UD_RGB_U8_PLANAR, 0);
 #undef VALI_UD_D2
+    VALI_LAUNCH_CHECK();
+    return VALI_OK;
+  }
+  if (down2_mode == 1 && !force_gather && src_fmt == VALI_FMT_NV12 && src_w == 2 * dst_w && src_h == 2 * dst_h && (rot & 1) &&
+      dst_w % kD2LanePx == 0 && dst_h % 4 == 0) { // exactly 2:1 both ways: 64 x 128 tiles, whole-line destination segments
+    // 64-row tiles (17 KB of LDS, 9 workgroups per CU) beat 128-row ones (33 KB, 4 per CU) although their destination segments
+    // are 192 bytes instead of three whole lines -- the neighbouring tile follows on the same XCD and the L2 merges the halves:
+    // 2160p -> 1080p 90 deg 3.67 vs 3.75 us, 270 deg 3.71 vs 4.15, 1080p -> 540p 0.87 vs 0.93 (VALI_TUNE_ROTATE_NO_TILE = 3: the tall form)
+    const bool tall = tuning(VALI_TUNE_ROTATE_NO_TILE) == 3;
+    a.map = make_tile_map((dst_w + 63) / 64, tall ? (dst_h + 127) / 128 : (dst_h + 63) / 64, (u32)n);
+    const dim3 gt = tile_grid(a.map);
+    if (tall) {
+      if (rot == 1) hipLaunchKernelGGL((k_ud_half_t<1, 128>), gt, block, 0, stream, a);
+      else hipLaunchKernelGGL((k_ud_half_t<3, 128>), gt, block, 0, stream, a);
+    } else {
+      if (rot == 1) hipLaunchKernelGGL((k_ud_half_t<1, 64>), gt, block, 0, stream, a);
+      else hipLaunchKernelGGL((k_ud_half_t<3, 64>), gt, block, 0, stream, a);
+    }
     VALI_LAUNCH_CHECK();
     return VALI_OK;
   }
