@@ -13,6 +13,19 @@ OBJ = ROOT / "vali_amd" / "csrc" / "_obj"
 
 ALLOWED = set()   # (round 2 had one A/B instantiation that spilled; it also turned out to mis-render and was removed)
 
+# SGPR spills (scalars parked in VGPR lanes: v_writelane / v_readlane on the critical path).  Zero for every kernel except
+# the any-height / ragged-width forms of the exact-ratio UD kernel listed here with the count the compiler reports today --
+# the hot geometry (exactly 2:1 both ways) runs on k_ud_half / k_ud_half_t, which spill nothing (profiles/r03_ud_half.md).
+# A count may only go DOWN: a kernel that appears here or grows fails the test.
+SGPR_SPILLS_ALLOWED = {
+    "_ZN4vali10k_ud_down2ILi1ELi2ELi1EEEvNS_6UdArgsE": 46,   # RGB, half turn, 1:1 width
+    "_ZN4vali10k_ud_down2ILi1ELi0ELi1EEEvNS_6UdArgsE": 56,   # RGB, 1:1 width
+    "_ZN4vali10k_ud_down2ILi1ELi2ELi2EEEvNS_6UdArgsE": 65,   # RGB, half turn, 2:1 width
+    "_ZN4vali10k_ud_down2ILi0ELi0ELi2EEEvNS_6UdArgsE": 22,   # YUV444, 2:1 width
+    "_ZN4vali10k_ud_down2ILi1ELi0ELi2EEEvNS_6UdArgsE": 75,   # RGB, 2:1 width, any height
+    "_ZN4vali10k_ud_down2ILi2ELi0ELi2EEEvNS_6UdArgsE": 13,   # RGB_PLANAR, 2:1 width
+}
+
 
 def kernels():
     out = {}
@@ -43,6 +56,21 @@ def test_no_kernel_uses_scratch_or_spills():
     for name, r in kernels().items():
         if name in ALLOWED:
             continue
-        if r.get("ScratchSize", 0) or r.get("VGPRs Spill", 0) or r.get("SGPRs Spill", 0) > 128:
+        if r.get("ScratchSize", 0) or r.get("VGPRs Spill", 0) or r.get("SGPRs Spill", 0) > SGPR_SPILLS_ALLOWED.get(name, 0):
             bad.append((name, r))
     assert not bad, "kernels with scratch / spills:\n" + "\n".join(f"{n}: {r}" for n, r in bad)
+
+
+def test_the_hot_kernels_spill_nothing_and_keep_their_occupancy():
+    """the kernels the bench lines are quoted on: no spilled SGPR, and the waves per SIMD their design counts on"""
+    k = kernels()
+    want = {"k_nv12_rgb8": 8, "k_ud_half": 8, "k_ud_half_t": 4, "k_resize_cols_x2IhLi12ELi6ELi4E": 6, "k_resize_colsIhLi12ELi6ELi4E": 4}
+    seen = set()
+    for name, r in k.items():
+        for needle, occ in want.items():
+            if needle in name and ("_x2" in name) == ("_x2" in needle) and ("half_t" in name) == ("half_t" in needle):
+                seen.add(needle)
+                assert r.get("SGPRs Spill", 0) == 0 and r.get("ScratchSize", 0) == 0, (name, r)
+                if "Occupancy" in r:
+                    assert r["Occupancy"] >= occ, (name, r["Occupancy"], occ)
+    assert seen == set(want), seen
