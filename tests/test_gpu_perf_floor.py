@@ -100,7 +100,8 @@ GATHER_CASES = [
     ("lanczos NV12 2160p->1936x1088 (general)", 0.48, 0.34, "resize", (3840, 2160, 1936, 1088)),
     ("bilinear NV12 2160p->1920x1088", 0.93, 0.66, "bilinear", (3840, 2160, 1920, 1088)),
     ("UD NV12 2160p->RGB 1080p (exact 2x)", 0.84, 0.60, "ud", (3840, 2160, 1920, 1080)),
-    ("UD NV12 1080p->RGB 720p (any ratio)", 0.62, 0.44, "ud", (1920, 1080, 1280, 720)),
+    ("UD NV12 1080p->RGB 720p (exact 3:2)", 0.75, 0.52, "ud", (1920, 1080, 1280, 720)),
+    ("UD NV12 1080p->RGB 1024x576 (any ratio)", 0.50, 0.34, "ud", (1920, 1080, 1024, 576)),
     ("rotate RGB 1080p 90 degrees", 0.75, 0.52, "rot", (1920, 1080, 1080, 1920)),
 ]
 

@@ -237,3 +237,50 @@ def test_same_width_random_geometries_rotation_and_foreign_memory(vali, gpu, ora
             want = np.rot90(want.reshape(dh, sw, 3), k=2)
         assert np.array_equal(download(vali, gpu, out), np.ascontiguousarray(want).reshape(-1)), (case, sw, sh, dh, dst, k)
         del keep
+
+
+# ---- exactly 3:2 both ways (1080p -> 720p ...): the dot-product kernel k_ud_32 ------------------------------------------
+@pytest.mark.parametrize("dst", ["RGB", "RGB_PLANAR", "YUV444"])
+@pytest.mark.parametrize("geom", [(1920, 1080, 1280, 720), (96, 48, 64, 32), (1536, 24, 1024, 16), (12, 6, 8, 4),
+                                  (3840, 2160, 2560, 1440), (1548, 54, 1032, 36)])     # one full wave + a partial second one
+def test_three_to_two_bit_exact(vali, gpu, oracle, dst, geom):
+    sw, sh, dw, dh = geom
+    assert 2 * sw == 3 * dw and 2 * sh == 3 * dh and dw % 8 == 0 and dh % 4 == 0
+    for seed in (41, 42):
+        nv = make_nv12(sw, sh, seed)
+        if seed == 42:
+            nv[:] = np.where(np.random.default_rng(1).random(nv.shape) < 0.5, 0, 255)     # extreme values: saturation both ways
+        src = vali.Surface.Make(vali.NV12, sw, sh, gpu)
+        assert vali.PyFrameUploader(gpu).Run(nv.reshape(-1), src)[0]
+        out = vali.Surface.Make(vali.PixelFormat[dst], dw, dh, gpu)
+        want = oracle.ud_nv12(nv, sw, sh, "NV12", dw, dh, dst).reshape(-1)
+        assert vali.PySurfaceUD(gpu).Run(src, out) == (True, vali.TaskExecInfo.SUCCESS)
+        assert np.array_equal(download(vali, gpu, out), want)
+        with vali.tuning.Override(UD_DOWN2=0):                 # the general kernel on the same geometry
+            assert vali.PySurfaceUD(gpu).Run(src, out)[0] and np.array_equal(download(vali, gpu, out), want)
+        for rows in (2, 4):                                    # short waves (what single frames pick)
+            with vali.tuning.Override(ROWS_PER_WAVE=rows):
+                assert vali.PySurfaceUD(gpu).Run(src, out)[0] and np.array_equal(download(vali, gpu, out), want)
+
+
+def test_three_to_two_batch_and_foreign_memory(vali, gpu, oracle):
+    import torch
+    sw, sh, dw, dh, n = 960, 540, 640, 360, 5
+    frames = [make_nv12(sw, sh, 50 + i) for i in range(2)]
+    srcs = [vali.Surface.Make(vali.NV12, sw, sh, gpu) for _ in range(n)]
+    dsts = [vali.Surface.Make(vali.RGB, dw, dh, gpu) for _ in range(n)]
+    for i, s in enumerate(srcs):
+        assert vali.PyFrameUploader(gpu).Run(frames[i % 2].reshape(-1), s)[0]
+    assert vali.PySurfaceUD(gpu).RunBatch(srcs, dsts) == (True, vali.TaskExecInfo.SUCCESS)
+    wants = [oracle.ud_nv12(f, sw, sh, "NV12", dw, dh, "RGB").reshape(-1) for f in frames]
+    for i, d in enumerate(dsts):
+        assert np.array_equal(download(vali, gpu, d), wants[i % 2])
+    # source and destination borrowed from torch tensors at odd byte offsets and foreign pitches
+    t_src = torch.zeros((sh * 3 // 2, sw + 37), dtype=torch.uint8, device=f"cuda:{gpu}")
+    t_dst = torch.zeros((dh, dw * 3 + 11), dtype=torch.uint8, device=f"cuda:{gpu}")
+    t_src[:, 5:5 + sw] = torch.from_numpy(frames[0]).to(t_src.device)
+    src = vali.Surface.from_dlpack(t_src[:, 5:5 + sw], vali.NV12)
+    dst = vali.Surface.from_dlpack(t_dst[:, 7:7 + dw * 3], vali.RGB)
+    assert vali.PySurfaceUD(gpu).Run(src, dst)[0]
+    assert np.array_equal(t_dst[:, 7:7 + dw * 3].cpu().numpy().reshape(-1), wants[0])
+    assert int(t_dst[:, :7].sum()) == 0 and int(t_dst[:, 7 + dw * 3:].sum()) == 0      # nothing outside the rows

@@ -1450,6 +1450,204 @@ __global__ void __launch_bounds__(kBlock) k_ud_half(const UdArgs a) {
   }
 }
 
+// ---- exactly 3:2 in both directions (1080p -> 720p, 2160p -> 1440p: THE pre-processing / transcode ratio) ----
+// X = 1.5 x: even x sample between two texels (weights 128 / 128), odd x ON a texel (256 / 0); the chroma coordinate
+// 0.75 x walks through the fractions .5 / .25 / 0 / .75, i.e. weights (128,128) (192,64) (256,0) (64,192); the same vertically
+// with the period of four rows.  The integer filter sum of the general kernel, S = sum_r wy_r (wx_0 T[r][i] + wx_1 T[r][i+1]),
+// is therefore a sum of texels with small constant weights -- 128 * 128 * (a_r b_t) for luma with a, b in {1,1} / {2},
+// 64 * 64 * (a_r b_t) for chroma with a, b in {2,2} {3,1} {4,0} {1,3} -- which v_dot4_u32_u8 evaluates against constant byte
+// masks: one or two dot products per component and pixel (the general kernel: 15 vector instructions), no LDS, no column
+// taps, no row taps.  A lane owns 8 output pixels = 12 luma bytes and 6 chroma pairs per source row (one dwordx3 each), the
+// bytes before them come from the neighbouring lane (DPP).  Same bits as k_ud_nv12 / the oracle: float(2^k S') * c ==
+// float(S') * (2^k c); where the reference's float coordinate lands a hair below an integer the tap pair (i-1, i) carries
+// the weights (0, 256), which is the same sample.  Source = 1.5 x the output both ways, width % 8 == 0, height % 4 == 0.
+template <int OUT, int M> struct Ud32Masks {                       // M = y & 3
+  static constexpr u32 ay0 = (M & 1) ? 2u : 1u, ay1 = (M & 1) ? 0u : 1u;                    // luma row weights / 128
+  static constexpr u32 ac0 = M == 0 ? 2u : M == 1 ? 3u : M == 2 ? 4u : 1u, ac1 = 4u - ac0;  // chroma row weights / 64
+};
+template <int OUT, int M>
+__device__ __forceinline__ void ud32_compute(const u32 (&P)[4], const uint4 (&R)[4], float (&c0)[8], float (&c1)[8], float (&c2)[8]) {
+  using T = uint8_t;
+  using W = Ud32Masks<OUT, M>;
+  // rows 0, 1 = luma i0, i1 ; rows 2, 3 = chroma i0, i1 ; R[k].x/.y/.z = the lane's 12 bytes, P[k] = the 4 bytes before them
+  u32 lq[2], cq0[2], cq2[2], cq6[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    lq[r] = __builtin_amdgcn_alignbyte(R[r].x, P[r], 3);              // luma bytes -1 .. 2
+    cq0[r] = __builtin_amdgcn_alignbyte(R[2 + r].x, P[2 + r], 2);      // chroma bytes -2 .. 1 (pairs 6m-1, 6m)
+    cq2[r] = __builtin_amdgcn_alignbyte(R[2 + r].y, R[2 + r].x, 2);    // bytes 2 .. 5
+    cq6[r] = __builtin_amdgcn_alignbyte(R[2 + r].z, R[2 + r].y, 2);    // bytes 6 .. 9
+  }
+  constexpr u32 kLuma[8] = {0x00000101u, 0x00000200u, 0x01010000u, 0x00000002u, 0x00010100u, 0x02000000u, 0x00000101u, 0x00020000u};
+  constexpr u32 kChroma[4] = {0x00020002u, 0x00010003u, 0x00000004u, 0x00030001u};   // (b0, b1) of x & 3 on the U bytes 0, 2
+  u32 sy[8], su[8], sv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const u32 lo[2] = {j == 0 ? lq[0] : j < 3 ? R[0].x : j < 6 ? R[0].y : R[0].z, j == 0 ? lq[1] : j < 3 ? R[1].x : j < 6 ? R[1].y : R[1].z};
+    sy[j] = __builtin_amdgcn_udot4(lo[0], kLuma[j] * W::ay0, 0u, false);
+    if constexpr (W::ay1 != 0)
+      sy[j] = __builtin_amdgcn_udot4(lo[1], kLuma[j] * W::ay1, sy[j], false);
+    const u32 co[2] = {j == 0 ? cq0[0] : j == 1 ? R[2].x : j < 4 ? cq2[0] : j == 4 ? R[2].y : j == 5 ? cq6[0] : R[2].z,
+                       j == 0 ? cq0[1] : j == 1 ? R[3].x : j < 4 ? cq2[1] : j == 4 ? R[3].y : j == 5 ? cq6[1] : R[3].z};
+    su[j] = __builtin_amdgcn_udot4(co[0], kChroma[j & 3] * W::ac0, 0u, false);
+    sv[j] = __builtin_amdgcn_udot4(co[0], (kChroma[j & 3] * W::ac0) << 8, 0u, false);
+    if constexpr (W::ac1 != 0) {
+      su[j] = __builtin_amdgcn_udot4(co[1], kChroma[j & 3] * W::ac1, su[j], false);
+      sv[j] = __builtin_amdgcn_udot4(co[1], (kChroma[j & 3] * W::ac1) << 8, sv[j], false);
+    }
+  }
+  constexpr float kScale = UdScale<T, OUT>::value;
+  constexpr float kNl = TexelTraits<T>::kInvDen * kScale * 16384.0f, kNc = TexelTraits<T>::kInvDen * kScale * 4096.0f;
+  typedef float v2f __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int p = 0; p < 8; p += 2) {
+    const v2f ny = (v2f){(float)sy[p], (float)sy[p + 1]} * (v2f){kNl, kNl};
+    const v2f nu = (v2f){(float)su[p], (float)su[p + 1]} * (v2f){kNc, kNc};
+    const v2f nv = (v2f){(float)sv[p], (float)sv[p + 1]} * (v2f){kNc, kNc};
+    if constexpr (OUT == UD_YUV444) {
+      c0[p] = ny.x; c0[p + 1] = ny.y; c1[p] = nu.x; c1[p + 1] = nu.y; c2[p] = nv.x; c2[p + 1] = nv.y;
+    } else {
+      const v2f half = {0.5f * kScale, 0.5f * kScale};
+      const v2f u = nu - half, v = nv - half;
+      const v2f r = __builtin_elementwise_fma((v2f){1.140f, 1.140f}, v, ny);
+      const v2f g = __builtin_elementwise_fma((v2f){-0.581f, -0.581f}, v, __builtin_elementwise_fma((v2f){-0.394f, -0.394f}, u, ny));
+      const v2f bl = __builtin_elementwise_fma((v2f){2.032f, 2.032f}, u, ny);
+      c0[p] = r.x; c0[p + 1] = r.y; c1[p] = g.x; c1[p + 1] = g.y; c2[p] = bl.x; c2[p + 1] = bl.y;
+    }
+  }
+}
+
+template <int OUT>
+__global__ void __launch_bounds__(kBlock) k_ud_32(const UdArgs a) {
+  constexpr bool kPacked = OUT == UD_RGB_U8;
+  u32 tile_x, tile_y, frame;
+  if (!tile_of_block(a.map, tile_x, tile_y, frame))
+    return;
+  const SurfRef s = load_surface(a.d_src, a.src, frame);
+  const SurfRef d = load_surface(a.d_dst, a.dst, frame);
+  const int dw = d.width, dh = d.height, sh = s.height;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int xw = tile_x * kD2WaveW;
+  const int y_first = (int)(tile_y * kWavesPerBlock + wave) * a.rows; // wave-uniform
+  if (y_first >= dh)
+    return;
+  const int last = min(a.rows, dh - y_first) - 1;
+  const int x0 = xw + lane * kD2LanePx;
+  const bool has = x0 < dw;                                            // dw % 8 == 0: 8 pixels or none
+  const u32 off12 = (u32)(3 * (min(x0, dw - kD2LanePx) >> 1));         // 1.5 x0: idle lanes re-read the row's last group
+  const u32 offw = (u32)max(3 * (xw >> 1) - 4, 0);
+  typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+  struct Rows {
+    uint4 v[4]; // .x .y .z = the lane's 12 bytes of luma i0, luma i1, chroma i0, chroma i1
+    u32 before; // lane k < 4: the dword before the wave's first byte in row k
+  };
+  // byte offsets of the four source rows of every dst row of the wave, lane-parallel (lane r = row y_first + r) and read
+  // back as scalars: the clamps, shifts and multiplies cost a wave ~25 scalar instructions per row otherwise -- and this
+  // kernel, like its siblings, is bound by the instructions it issues.  make_tap clamps BOTH taps: for y = 0 the pair
+  // (-1, 0) becomes (0, 0).
+  u32 vro[4];
+  {
+    const int y = y_first + min(lane & 31, last);
+    const int l0 = (3 * y - 1) >> 1, c0r = (3 * y - 2) >> 2;       // floor(1.5 y - 0.5), floor(0.75 y - 0.5): -1 for y = 0
+    vro[0] = (u32)(max(l0, 0) * s.pitch[0]);
+    vro[1] = (u32)(min(max(l0 + 1, 0), sh - 1) * s.pitch[0]);
+    vro[2] = (u32)(max(c0r, 0) * s.pitch[1]);
+    vro[3] = (u32)(min(max(c0r + 1, 0), sh / 2 - 1) * s.pitch[1]);
+  }
+  auto issue = [&](int rr) {
+    const int r = min(rr, last);
+    const uint8_t* row[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      row[k] = (k < 2 ? s.p[0] : s.p[1]) + (u32)__builtin_amdgcn_readlane((int)vro[k], r);
+    Rows rws;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const v3u32 w = gload_u<v3u32>(row[k] + off12);
+      rws.v[k] = make_uint4(w.x, w.y, w.z, 0u);
+    }
+    const int lk = lane & 3;
+    const uint8_t* rb = lk == 0 ? row[0] : lk == 1 ? row[1] : lk == 2 ? row[2] : row[3];
+    rws.before = gload_u<u32>(rb + offw);
+    return rws;
+  };
+  __shared__ __attribute__((aligned(16))) uint8_t strip[kPacked ? kWavesPerBlock : 1][kPacked ? kD2WaveW * 3 : 16];
+  const int nbytes = min(kD2WaveW, dw - xw) * 3;
+  const bool dst16 = ((((uintptr_t)d.p[0]) | (uintptr_t)d.pitch[0]) & 15u) == 0 && (xw * 3 & 15) == 0; // wave-uniform
+  auto step = [&](int rr, const Rows& rows) {
+    const int y = y_first + rr;
+    u32 prev[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const u32 before = (u32)__builtin_amdgcn_readlane((int)rows.before, k);
+      const u32 edge = k < 2 ? rows.v[k].x << 24 : rows.v[k].x << 16;
+      const u32 sh1 = wave_shr1(rows.v[k].z);
+      prev[k] = lane == 0 ? (xw == 0 ? edge : before) : sh1;
+    }
+    float c0[8], c1[8], c2[8];
+    switch (y & 3) { // wave-uniform
+    case 0: ud32_compute<OUT, 0>(prev, rows.v, c0, c1, c2); break;
+    case 1: ud32_compute<OUT, 1>(prev, rows.v, c0, c1, c2); break;
+    case 2: ud32_compute<OUT, 2>(prev, rows.v, c0, c1, c2); break;
+    default: ud32_compute<OUT, 3>(prev, rows.v, c0, c1, c2); break;
+    }
+    if constexpr (kPacked) {
+      u32 w[6];
+      trunc_pack3x4(c0[0], c1[0], c2[0], c0[1], c1[1], c2[1], c0[2], c1[2], c2[2], c0[3], c1[3], c2[3], w[0], w[1], w[2]);
+      trunc_pack3x4(c0[4], c1[4], c2[4], c0[5], c1[5], c2[5], c0[6], c1[6], c2[6], c0[7], c1[7], c2[7], w[3], w[4], w[5]);
+      uint8_t* st = strip[kPacked ? wave : 0];
+      if (has) {
+        *reinterpret_cast<uint2*>(st + 24 * lane) = make_uint2(w[0], w[1]);
+        *reinterpret_cast<uint2*>(st + 24 * lane + 8) = make_uint2(w[2], w[3]);
+        *reinterpret_cast<uint2*>(st + 24 * lane + 16) = make_uint2(w[4], w[5]);
+      }
+      wave_lds_sync();
+      uint8_t* orow = d.p[0] + (u32)(y * d.pitch[0]) + (u32)(xw * 3);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int b = (lane + kWave * h) * 16;
+        if (b + 16 <= nbytes) {
+          const uint4 v = *reinterpret_cast<const uint4*>(st + b);
+          if (dst16)
+            UD_ST16(orow + b, v);
+          else
+            gstore_u<v4u32>(orow + b, (v4u32){v.x, v.y, v.z, v.w});
+        } else if (b < nbytes) {
+          const uint2 v = *reinterpret_cast<const uint2*>(st + b);
+          gstore_u<v2u32>(orow + b, (v2u32){v.x, v.y});
+        }
+      }
+      wave_lds_sync();
+    } else if (has) {
+      const int pp[3] = {d.pitch[0], OUT == UD_YUV444 ? d.pitch[1] : d.pitch[0], OUT == UD_YUV444 ? d.pitch[2] : d.pitch[0]};
+      u32 pw[6];
+      trunc_pack3x4(c0[0], c0[1], c0[2], c0[3], c0[4], c0[5], c0[6], c0[7], c1[0], c1[1], c1[2], c1[3], pw[0], pw[1], pw[2]);
+      trunc_pack3x4(c1[4], c1[5], c1[6], c1[7], c2[0], c2[1], c2[2], c2[3], c2[4], c2[5], c2[6], c2[7], pw[3], pw[4], pw[5]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        uint8_t* o = d.p[k] + (u32)(y * pp[k]) + (u32)x0;
+        if ((((uintptr_t)d.p[k] | (uintptr_t)pp[k]) & 7u) == 0) // wave-uniform
+          UD_ST8(o, make_uint2(pw[2 * k], pw[2 * k + 1]));
+        else
+          gstore_u<v2u32>(o, (v2u32){pw[2 * k], pw[2 * k + 1]});
+      }
+    }
+  };
+  Rows ra = issue(0);
+  __builtin_amdgcn_sched_barrier(0);
+  Rows rb = issue(1);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+  for (int rr = 0; rr <= last; rr += 2) {
+    step(rr, ra);
+    ra = issue(rr + 2);
+    if (rr + 1 <= last)
+      step(rr + 1, rb);
+    rb = issue(rr + 3);
+  }
+}
+
 // ---- the same lean form with the output written turned by 90 / 270 degrees: BASELINE config 4 as ONE pass ----
 // k_ud_down2_t collects 256 x 32 tiles, so a destination row receives 32 pixels = 96 bytes per tile: three quarters of a
 // line, 1.13x the written bytes at the memory (profiles/r02_secondary_traffic.md).  Here a workgroup owns 64 columns x 128
@@ -1820,6 +2018,17 @@ static int launch_ud(UdArgs& a, int src_fmt, int src_w, int src_h, int dst_w, in
     else if (kind == UD_YUV444) hipLaunchKernelGGL((k_ud_down2<UD_YUV444, 0, 1>), g1, block, 0, stream, a);
     else if (kind == UD_RGB_U8) hipLaunchKernelGGL((k_ud_down2<UD_RGB_U8, 0, 1>), g1, block, 0, stream, a);
     else hipLaunchKernelGGL((k_ud_down2<UD_RGB_U8_PLANAR, 0, 1>), g1, block, 0, stream, a);
+    VALI_LAUNCH_CHECK();
+    return VALI_OK;
+  }
+  if (down2_mode == 1 && !force_gather && src_fmt == VALI_FMT_NV12 && 2 * src_w == 3 * dst_w && 2 * src_h == 3 * dst_h && rot == 0 &&
+      dst_w % kD2LanePx == 0 && dst_h % 4 == 0 && kind != UD_RGB_F32 && kind != UD_RGB_F32_PLANAR) { // exactly 3:2 both ways
+    a.rows = rows_for((dst_w + kD2WaveW - 1) / kD2WaveW);
+    a.map = make_tile_map((dst_w + kD2WaveW - 1) / kD2WaveW, (dst_h + kWavesPerBlock * a.rows - 1) / (kWavesPerBlock * a.rows), (u32)n);
+    const dim3 g32 = tile_grid(a.map);
+    if (kind == UD_YUV444) hipLaunchKernelGGL((k_ud_32<UD_YUV444>), g32, block, 0, stream, a);
+    else if (kind == UD_RGB_U8) hipLaunchKernelGGL((k_ud_32<UD_RGB_U8>), g32, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_ud_32<UD_RGB_U8_PLANAR>), g32, block, 0, stream, a);
     VALI_LAUNCH_CHECK();
     return VALI_OK;
   }
