@@ -19,11 +19,13 @@ ud = vali.PySurfaceUD(DEV)
 while time.time() - t0 < budget:
     src_name = "NV12" if rng.integers(4) else "P10"
     out = OUTS[rng.integers(len(OUTS))] if src_name == "NV12" else ["YUV444_10bit", "RGB_32F", "RGB_32F_PLANAR"][rng.integers(3)]
-    kind = rng.integers(6)
+    kind = rng.integers(8)
     if kind == 0:   sw, sh, dw, dh = rng.integers(2, 260, 4)
     elif kind == 1: dw, dh = rng.integers(2, 1400), rng.integers(2, 300); sw, sh = 2 * dw, int(dh * rng.uniform(0.5, 3.0)) or 2   # exact 2x width
     elif kind == 2: dw, dh = rng.integers(2, 2000), rng.integers(2, 300); sw, sh = dw, int(dh * rng.uniform(0.5, 2.0)) or 2       # exact 1x width
     elif kind == 3: sw, sh = rng.integers(300, 2600), rng.integers(2, 200); dw = int(sw / rng.uniform(1.05, 3.9)) or 2; dh = int(sh / rng.uniform(0.7, 3.0)) or 2
+    elif kind == 6: dw, dh = 8 * int(rng.integers(1, 200)), 4 * int(rng.integers(1, 90)); sw, sh = dw * 3 // 2, dh * 3 // 2           # exactly 3:2 both ways: k_ud_32
+    elif kind == 7: dw, dh = 8 * int(rng.integers(1, 200)), 4 * int(rng.integers(1, 90)); sw, sh = 2 * dw, 2 * dh                     # exactly 2:1 both ways: k_ud_half[_t]
     elif kind == 4: sw, sh = rng.integers(1500, 4000), rng.integers(60, 200); dw, dh = rng.integers(2, 300), rng.integers(2, 60)   # gather form
     else:           sw, sh = rng.integers(2, 400), rng.integers(2, 200); dw = int(sw * rng.uniform(1.0, 3.0)) or 2; dh = int(sh * rng.uniform(1.0, 3.0)) or 2
     sw, sh = (int(max(2, v)) // 2 * 2 for v in (sw, sh))
