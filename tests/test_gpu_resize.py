@@ -256,7 +256,11 @@ def test_lanczos_batch_large_enough_for_32_row_waves(vali, gpu, oracle):
 # form (src_w == 2 dst_w) and the general one, ragged last tiles, planes narrower than one lane's 8 elements (direct form),
 # a vertical shrink with a horizontal stretch, rows kept (src_h == dst_h), a plane pair that takes BOTH orders (YUV420 ->
 # taller: luma shrinks, chroma ... ) is covered by the planar UD tests.
-COLS_GEOMS = [(1280, 722, 640, 364),      # x2, ratio 1.98: 4 slots (3 bicubic)
+COLS_GEOMS = [(1920, 1080, 1280, 720),    # 3:2 along x AND y: the uniform-weight form, 4 slots
+              (1536, 600, 1024, 280),     # 3:2 along x, 2.14 down the rows: 3 slots
+              (1488, 404, 992, 400),      # 3:2 along x (two waves per row + a partial one: 992 = 2 x 496), 6 slots
+              (24, 100, 16, 50),          # 3:2, one lane of outputs per plane row (chroma: 12 -> 8 elements)
+              (1280, 722, 640, 364),      # x2, ratio 1.98: 4 slots (3 bicubic)
               (1280, 720, 640, 238),      # x2, ratio 3.03: 3 slots (2)
               (636, 364, 318, 310),       # x2, ratio 1.17: 6 slots (4), ragged tile
               (1282, 360, 640, 250),      # general, 2.003 along x

@@ -193,14 +193,14 @@ def cfg3(n=64):
 
 def interp(n=64):
     """A resize that really interpolates: NV12 2160p -> 1920x1088 (every source row contributes; exactly 2:1 along x, so the
-    Lanczos kernel takes its 2:1-along-x form) and -> 1936x1088 (no integer ratio on either axis: the general form), with
-    the bilinear filter of BASELINE config 3 and the reference's own filter (Lanczos-3, the PySurfaceResizer default)."""
-    sw, sh = 3840, 2160
+    Lanczos kernel takes its 2:1-along-x form), -> 1936x1088 (no integer ratio on either axis: the general form) and 1080p ->
+    720p (3:2 both ways: the uniform-weight form), with the bilinear filter of BASELINE config 3 and the reference's own
+    filter (Lanczos-3, the PySurfaceResizer default)."""
     out = []
-    for (dw, dh) in ((1920, 1088), (1936, 1088)):
+    for (sw, sh, dw, dh) in ((3840, 2160, 1920, 1088), (3840, 2160, 1936, 1088), (1920, 1080, 1280, 720)):
         b = (sw * sh + dw * dh) * 3 // 2
         for name, it in (("bilinear", vali.Interpolation.LINEAR), ("lanczos", vali.Interpolation.LANCZOS)):
-            if (dw, name) == (1936, "bilinear"):
+            if (dw, name) != (1920, "bilinear") and name == "bilinear":
                 continue
             rs = vali.PySurfaceResizer(vali.NV12, DEV, interpolation=it)
             k = sets_needed(b * n)
@@ -212,14 +212,15 @@ def interp(n=64):
                 return srcs, dsts, rs.PrepareBatch(srcs, dsts)
             sets = make_sets(k, make)
             ms, _ = timed(rs.Stream, [lambda q=q: rs.RunBatchAsync(q) for _, _, q in sets], 20)
-            kern = "k_resize<u8, 2>" if name == "bilinear" else ("k_resize_cols_x2<u8, 12, 6, 4>" if dw == 1920 else "k_resize_cols<u8, 12, 6, 4>")
-            key = "interp_" + name + ("" if dw == 1920 else "_1936")
+            kern = "k_resize<u8, 2>" if name == "bilinear" else {1920: "k_resize_cols_x2<u8, 12, 6, 4>", 1936: "k_resize_cols<u8, 12, 6, 4>",
+                                                                  1280: "k_resize_cols_x32<u8, 12, 6, 4>"}[dw]
+            key = "interp_" + name + {1920: "", 1936: "_1936", 1280: "_720p"}[dw]
             out.append({"filter": name, "geometry": f"{sw}x{sh}->{dw}x{dh}", "kernel": kern,
                         "us_per_frame": round(ms * 1e3 / n, 3), "bytes_moved_per_frame": b,
                         "roofline": roofline(key, b, n, ms, k)})
             del sets
-    return {"config": f"interp PySurfaceResizer NV12 3840x2160->1920x1088 / 1936x1088 (non-integer ratios), batch={n}, one launch per filter",
-            "bytes_note": "whole source + destination: 12 441 600 + 3 133 440 (3 159 552) B per frame", "results": out}
+    return {"config": f"interp PySurfaceResizer NV12 3840x2160->1920x1088 / 1936x1088, 1920x1080->1280x720 (non-integer ratios), batch={n}, one launch per filter",
+            "bytes_note": "whole source + destination per frame", "results": out}
 
 
 def cfg4(n=64):

@@ -30,10 +30,12 @@ KEYS = {
     "interp_bilinear": ("interp", "k_resize<", 64),
     "interp_lanczos": ("interp", "k_resize_cols_x2<", 64),        # 2160p -> 1920x1088: exactly 2:1 along x
     "interp_lanczos_1936": ("interp", "k_resize_cols<", 64),      # 2160p -> 1936x1088: the general columns-first form
+    "interp_lanczos_720p": ("interp", "k_resize_cols_x32<", 64),  # 1080p -> 720p: 3:2 both ways
     "cfg4_ud": ("cfg4", "k_ud_half<", 64),
     "cfg4_rot": ("cfg4", "k_rotate_tile", 64),
     "cfg4_fused": ("cfg4", "k_ud_down2_t<", 64),
-    "udgen_1280x720": ("udgen", "k_ud_nv12<", 64),   # (the larger of udgen's two geometries = the largest dispatch)
+    "udgen_1280x720": ("udgen", "k_ud_32<", 64),     # 1080p -> 720p: exactly 3:2
+    "udgen_640x384": ("udgen", "k_ud_nv12<", 64),    # the any-ratio kernel
 }
 
 

@@ -113,14 +113,15 @@ __device__ __forceinline__ bool cols_rows(int sh, int dh, int spitch, u32 ty, in
 // The walk over the wave's source rows.  A lane loads ND dwords per row at sp + row offset + lane_off (D rows in
 // flight), conv() turns them into the 8 floats it filters, every slot takes fma(w, f, acc) with its scalar weight, and
 // when a row completes a dst row emit(rr, acc) gets that row's 8 column results.
-template <typename T, int TAPS, int P, int ND, int D, typename Conv, typename Emit>
+// NF = float pairs a lane filters per row (4: 8 elements; 6: the 12 elements of the 3:2-along-x form).
+template <typename T, int TAPS, int P, int ND, int D, int NF = 4, typename Conv, typename Emit>
 __device__ __forceinline__ void cols_walk(const ColRows<P>& r, const uint8_t* sp, u32 lane_off, Conv conv, Emit emit) {
   constexpr int EB = (int)sizeof(T);
-  v2f32 acc[P][4];
+  v2f32 acc[P][NF];
 #pragma unroll
   for (int j = 0; j < P; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NF; ++i)
       acc[j][i] = (v2f32){0.0f, 0.0f};
   u32 pf[D][ND];
   auto issue = [&](int t, u32 (&q)[ND]) { // t < 64 (host: ns <= kColProgRows, rounded up to D, + D)
@@ -128,6 +129,14 @@ __device__ __forceinline__ void cols_walk(const ColRows<P>& r, const uint8_t* sp
     if constexpr (ND == 2) {
       const v2u32 w = gload_u<v2u32>(p + lane_off);
       q[0] = w.x; q[1] = w.y;
+    } else if constexpr (ND == 3) {
+      typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+      const v3u32 w = gload_u<v3u32>(p + lane_off);
+      q[0] = w.x; q[1] = w.y; q[2] = w.z;
+    } else if constexpr (ND == 6) {
+      typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+      const v3u32 w0 = gload_u<v3u32>(p + lane_off), w1 = gload_u<v3u32>(p + lane_off + 12);
+      q[0] = w0.x; q[1] = w0.y; q[2] = w0.z; q[3] = w1.x; q[4] = w1.y; q[5] = w1.z;
     } else {
 #pragma unroll
       for (int c = 0; c < ND / 4; ++c) {
@@ -148,7 +157,7 @@ __device__ __forceinline__ void cols_walk(const ColRows<P>& r, const uint8_t* sp
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       const int t = t0 + d;
-      v2f32 f[4];
+      v2f32 f[NF];
       conv(pf[d], f);
       issue(t + D, pf[d]);
       if (t >= r.ns) // the last trip only: rows past the end are loaded (the issue order stays countable), not used
@@ -168,7 +177,7 @@ __device__ __forceinline__ void cols_walk(const ColRows<P>& r, const uint8_t* sp
         }
         const v2f32 wv = (v2f32){w[j], w[j]};
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NF; ++i)
           acc[j][i] = __builtin_elementwise_fma(wv, f[i], acc[j][i]);
       }
       if (((w_lo & 0x80808080u) | (w_hi & 0x8080u)) != 0u) { // at most one dst row per source row (scale_y >= 1)
@@ -177,7 +186,7 @@ __device__ __forceinline__ void cols_walk(const ColRows<P>& r, const uint8_t* sp
           if (eslot == j) {
             emit(emit_rr, acc[j]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NF; ++i)
               acc[j][i] = (v2f32){0.0f, 0.0f};
           }
         }
@@ -440,6 +449,139 @@ __device__ __forceinline__ void cols_tile_x2(const uint8_t* sp, int spitch, int 
   cols_walk<T, TAPS, P, ND, D>(r, sp, (u32)(2 * eo * EB), conv, emit);
 }
 
+// Exactly 3:2 along x (2 src_w == 3 dst_w: x * scale_x is an integer for even x -- the column weights are {0,0,1,0,0,0}: the
+// point sample c[1.5 x] -- and an integer + 1/2 for odd x: ONE set of six weights, the same for every odd pixel of the
+// plane).  The pass along the row then needs no per-lane weights and no gather: a lane owns 12 source elements (one 12-byte
+// load per row for 8-bit planes) = 8 dst elements; the even ones are copies, the odd ones six FMAs with WAVE-UNIFORM weights
+// on its own column results plus the one (two) before and the two (four) after, which come from the neighbouring lanes by
+// DPP -- lanes 0 and 63 of a wave only supply those halos (62 x 8 dst elements per wave and row).  Same specification
+// arithmetic (e over the even taps, o over the odd ones, e + o), same bits.  1080p -> 720p, 2160p -> 1440p, their chroma
+// planes; 8 / 16-bit planes of 1- and 2-element pixels whose dst rows are whole groups of 8 elements.
+__device__ __forceinline__ float wave_shr1_f(float v) { // lane l gets lane l - 1's value
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_shl1_f(float v) { // lane l gets lane l + 1's value
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+constexpr int kX32Out = 62 * 8; // dst elements of a wave's row
+
+template <typename T, int ES, int TAPS, int P>
+__device__ __forceinline__ void cols_tile_x32(const uint8_t* sp, int spitch, int sw, int sh, uint8_t* dp, int dpitch,
+                                              int dw, int dh, u32 tx, u32 ty, int rps, float* strip) {
+  constexpr int EB = (int)sizeof(T);
+  static_assert(EB <= 2 && ES <= 2, "cols_tile_x32: 8 / 16-bit planes of 1 or 2 channels");
+  constexpr int ND = 3 * EB;                                    // dwords of a lane's 12 source elements
+  constexpr int D = EB == 1 ? 4 : 2;
+  constexpr int kBefore = LzTap<TAPS>::kBefore;
+  const int lane = threadIdx.x & 63;
+  ColRows<P> r;
+  if (!cols_rows<TAPS, P>(sh, dh, spitch, ty, rps, strip, r))
+    return;
+  const int dwe = dw * ES, row_el = sw * ES;                    // dwe % 8 == 0 (host), so row_el % 12 == 0
+  const int e0 = (int)tx * kX32Out;                             // first dst element of the wave
+  const int eo = e0 + 8 * (lane - 1);                           // this lane's 8 dst elements (lane 0 / 63: halo only)
+  const int j0 = (eo >> 1) * 3;                                 // = 1.5 eo: its 12 source elements
+  const bool outs = lane >= 1 && lane <= 62 && eo < dwe;
+  const bool first = j0 <= 0, beyond = j0 >= row_el;            // lane in front of the row / behind it
+  const bool left_edge = j0 == 0, right_edge = j0 + 12 == row_el; // its neighbour is outside the image: replicate
+  const u32 lane_off = (u32)(min(max(j0, 0), row_el - 12) * EB);
+  // the one weight set of the odd pixels: a = 1/2 exactly (1.5 x is exact in FP32)
+  LzTap<TAPS> odd;
+  if constexpr (TAPS == 6)
+    lanczos3_weights(0.5f, odd.w);
+  else
+    cubic_weights(0.5f, odd.w);
+  float wx[TAPS];
+#pragma unroll
+  for (int k = 0; k < TAPS; ++k)
+    wx[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, odd.w[k])));
+  const bool plain_store = ((((uintptr_t)dp) | (uintptr_t)dpitch) & (8u * EB - 1u)) == 0;        // wave-uniform
+  auto conv = [](const u32 (&d)[ND], v2f32 (&f)[6]) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      if constexpr (EB == 1)
+        f[i] = (v2f32){(float)((d[i / 2] >> (16 * (i % 2))) & 0xffu), (float)((d[i / 2] >> (16 * (i % 2) + 8)) & 0xffu)};
+      else
+        f[i] = (v2f32){(float)(d[i] & 0xffffu), (float)(d[i] >> 16)};
+    }
+  };
+  auto emit = [&](int rr, v2f32 (&cc)[6]) {
+    // c[0..11]: this lane's column results; halo: HB elements before, HA after (one pixel before, two after)
+    constexpr int HB = ES, HA = 2 * ES;
+    float c[HB + 12 + HA];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      c[HB + 2 * i] = cc[i].x;
+      c[HB + 2 * i + 1] = cc[i].y;
+    }
+#pragma unroll
+    for (int h = 0; h < HB; ++h) {                      // the previous lane's last pixel, or this lane's first one at the edge
+      const float pv = wave_shr1_f(c[HB + 12 - HB + h]);
+      c[h] = left_edge ? c[HB + h] : pv;
+    }
+#pragma unroll
+    for (int h = 0; h < HA; ++h) {                      // the next lane's first two pixels, or this lane's last one
+      const float nx = wave_shl1_f(c[HB + h]);
+      c[HB + 12 + h] = right_edge ? c[HB + 12 - ES + (h % ES)] : nx;
+    }
+    if (!outs)
+      return;
+    // dst pixel 2 t = source pixel 3 t (a copy); dst pixel 2 t + 1: taps on source pixels 3 t + 1 - kBefore .. , e over the
+    // even taps, o over the odd ones -- two results per packed instruction (ES = 1: two odd pixels; ES = 2: the two channels)
+    float out[8];
+    constexpr int NPX = 8 / ES;                         // dst pixels of the lane
+#pragma unroll
+    for (int px = 0; px < NPX; px += 2)
+#pragma unroll
+      for (int ch = 0; ch < ES; ++ch)
+        out[px * ES + ch] = c[HB + (3 * (px >> 1)) * ES + ch];
+    if constexpr (ES == 1) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int ta = 2 * q, tb = 2 * q + 1;
+        v2f32 e = (v2f32){0.0f, 0.0f}, o = (v2f32){0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < TAPS; k += 2) {
+          e = __builtin_elementwise_fma((v2f32){wx[k], wx[k]}, (v2f32){c[HB + 3 * ta + 1 - kBefore + k], c[HB + 3 * tb + 1 - kBefore + k]}, e);
+          o = __builtin_elementwise_fma((v2f32){wx[k + 1], wx[k + 1]}, (v2f32){c[HB + 3 * ta + 2 - kBefore + k], c[HB + 3 * tb + 2 - kBefore + k]}, o);
+        }
+        const v2f32 v = e + o;
+        out[2 * ta + 1] = v.x;
+        out[2 * tb + 1] = v.y;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        v2f32 e = (v2f32){0.0f, 0.0f}, o = (v2f32){0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < TAPS; k += 2) {
+          const int ia = HB + (3 * t + 1 - kBefore + k) * 2, ib = HB + (3 * t + 2 - kBefore + k) * 2;
+          e = __builtin_elementwise_fma((v2f32){wx[k], wx[k]}, (v2f32){c[ia], c[ia + 1]}, e);
+          o = __builtin_elementwise_fma((v2f32){wx[k + 1], wx[k + 1]}, (v2f32){c[ib], c[ib + 1]}, o);
+        }
+        const v2f32 v = e + o;
+        out[(2 * t + 1) * 2] = v.x;
+        out[(2 * t + 1) * 2 + 1] = v.y;
+      }
+    }
+    uint8_t* const o8 = dp + (u32)((r.y_first + rr) * dpitch) + (size_t)eo * EB;
+    if (plain_store && EB == 1) {
+      u32 q0 = __builtin_amdgcn_cvt_pk_u8_f32(out[0], 0u, 0u), q1 = __builtin_amdgcn_cvt_pk_u8_f32(out[4], 0u, 0u);
+      q0 = __builtin_amdgcn_cvt_pk_u8_f32(out[1], 1u, q0); q1 = __builtin_amdgcn_cvt_pk_u8_f32(out[5], 1u, q1);
+      q0 = __builtin_amdgcn_cvt_pk_u8_f32(out[2], 2u, q0); q1 = __builtin_amdgcn_cvt_pk_u8_f32(out[6], 2u, q1);
+      q0 = __builtin_amdgcn_cvt_pk_u8_f32(out[3], 3u, q0); q1 = __builtin_amdgcn_cvt_pk_u8_f32(out[7], 3u, q1);
+      const v2u32 q = {q0, q1};
+      gstore_nt<v2u32>(o8, q);
+    } else {
+      const float res[4][2] = {{out[0], out[1]}, {out[2], out[3]}, {out[4], out[5]}, {out[6], out[7]}};
+      store_px4<T, 2>(o8, res, 0xfu);
+    }
+  };
+  (void)first; (void)beyond;
+  cols_walk<T, TAPS, P, ND, D, 6>(r, sp, lane_off, conv, emit);
+}
+
 // ESSET as in resize_taps.hip: 1 = one-channel planes, 12 = NV12 / P10 (Y + UV), 3 = packed RGB
 template <typename T, int ESSET, int TAPS, int P>
 __global__ void __launch_bounds__(kBlock) k_resize_cols(const ResizeArgs a) {
@@ -475,6 +617,21 @@ __global__ void __launch_bounds__(kBlock) k_resize_cols_x2(const ResizeArgs a) {
     cols_tile_x2<T, 2, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_rps, lds[wave]);
   else
     cols_tile_x2<T, 1, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_rps, lds[wave]);
+}
+
+template <typename T, int ESSET, int TAPS, int P>
+__global__ void __launch_bounds__(kBlock) k_resize_cols_x32(const ResizeArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][384]; // scratch of cols_rows
+  ResizeJob job;
+  u32 tx, ty, frame;
+  if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
+    return;
+  const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (ESSET == 12 && job.channels == 2)
+    cols_tile_x32<T, 2, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_rps, lds[wave]);
+  else
+    cols_tile_x32<T, 1, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_rps, lds[wave]);
 }
 
 // The same arithmetic one output element per thread, TAPS x TAPS global loads each: planes narrower than one lane's 8
@@ -517,16 +674,25 @@ __global__ void __launch_bounds__(kBlock) k_resize_cols_direct(const ResizeArgs 
 }
 
 template <typename T, int ESSET, int TAPS>
-static void launch_slots(const ResizeArgs& a, int slots, bool x2, dim3 grid, hipStream_t stream) {
+static void launch_slots(const ResizeArgs& a, int slots, int xform, dim3 grid, hipStream_t stream) { // xform: 0 general, 2 / 3: the 2:1 / 3:2-along-x forms
   constexpr int P0 = TAPS == 6 ? 3 : 2, P1 = TAPS == 6 ? 4 : 3, P2 = TAPS == 6 ? 6 : 4;
   if constexpr (sizeof(T) <= 2 && ESSET != 3) {
-    if (x2) {
+    if (xform == 2) {
       if (slots <= P0)
         hipLaunchKernelGGL((k_resize_cols_x2<T, ESSET, TAPS, P0>), grid, dim3(kBlock), 0, stream, a);
       else if (slots <= P1)
         hipLaunchKernelGGL((k_resize_cols_x2<T, ESSET, TAPS, P1>), grid, dim3(kBlock), 0, stream, a);
       else
         hipLaunchKernelGGL((k_resize_cols_x2<T, ESSET, TAPS, P2>), grid, dim3(kBlock), 0, stream, a);
+      return;
+    }
+    if (xform == 3) {
+      if (slots <= P0)
+        hipLaunchKernelGGL((k_resize_cols_x32<T, ESSET, TAPS, P0>), grid, dim3(kBlock), 0, stream, a);
+      else if (slots <= P1)
+        hipLaunchKernelGGL((k_resize_cols_x32<T, ESSET, TAPS, P1>), grid, dim3(kBlock), 0, stream, a);
+      else
+        hipLaunchKernelGGL((k_resize_cols_x32<T, ESSET, TAPS, P2>), grid, dim3(kBlock), 0, stream, a);
       return;
     }
   }
@@ -546,6 +712,7 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
   ResizeArgs a = base;
   int esset = 0, tile_n = 256, slots = 1;
   bool narrow = false, x2 = elem <= 2 && tuning(VALI_TUNE_RESIZE_POINT) != 0; // exactly 2:1 along x on every plane
+  bool x32 = x2;                                                              // exactly 3:2 along x on every plane
   for (int k = 0; k < a.njobs; ++k) {
     const ResizeJob& j = a.job[k];
     const int c = j.channels;
@@ -553,6 +720,7 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
     const int sw = src_w >> j.ssub_x, dw = dst_w >> j.sub_x, sh = src_h >> j.ssub_y, dh = dst_h >> j.sub_y;
     narrow = narrow || sw * c < kColEl;
     x2 = x2 && c <= 2 && sw == 2 * dw && dw * c >= 8;
+    x32 = x32 && c <= 2 && 2 * sw == 3 * dw && (dw * c) % 8 == 0;
     // dst elements per tile: the source span of its pixels (+ taps, + the two extra elements, + alignment slop) must fit
     // the 512 elements a wave loads per row.  A tile starts on a pixel unless pixels are 3 elements (N is a multiple of 4).
     const double sx = (double)sw / (double)dw * (1.0 + 1e-6);
@@ -561,9 +729,12 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
       nn -= 4;
     tile_n = nn < tile_n ? nn : tile_n;
     // slots: the smallest P with P * scale_y >= taps (and a margin for the rounding of y * scale_y in FP32)
+    // (a ratio FP32 represents exactly -- 3:2, 2:1, 5:4 ... -- makes y * scale_y exact: no margin, 3:2 runs on 4 slots, not 6)
     const double sy = (double)sh / (double)dh;
+    const float syf = (float)sh / (float)dh;
+    const bool exact = (double)syf * (double)dh == (double)sh && sh < (1 << 20);
     int p = 1;
-    while (p < 6 && p * sy < taps + sh * 2.5e-7 + 1e-6)
+    while (p < 6 && p * sy < taps + (exact ? 0.0 : sh * 2.5e-7 + 1e-6))
       ++p;
     slots = p > slots ? p : slots;
   }
@@ -615,6 +786,8 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
     tile_n = even < tile_n ? even : tile_n;
     if (x2)
       tile_n = kWave * 8; // 8 dst elements per lane, nothing shared between tiles
+    else if (x32)
+      tile_n = kX32Out;   // 62 lanes x 8 dst elements, lanes 0 and 63 supply the halos
   }
   auto count = [&](int rps, bool assign) {
     u32 total = 0;
@@ -637,7 +810,9 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
   else if (force == 2) rps = 1;
   else if (force == 3) rps = rps_max;
   else
-    while (rps > 1 && (unsigned long long)count(rps, false) * (unsigned)n < 1024ull)
+    // (2048 workgroups = 8 waves per SIMD: with fewer the launch's last round leaves SIMDs idle -- 64 frames of 1080p -> 720p
+    // were 6912 waves of 30 rows, 1.4 rounds)
+    while (rps > 1 && (unsigned long long)count(rps, false) * (unsigned)n < 2048ull)
       rps = rps > 2 ? rps / 2 : 1;
   a.map = make_tile_map_linear(count(rps, true), (u32)n);
   a.cols_n = tile_n;
@@ -646,13 +821,13 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
 #define VALI_COLS_T(T)                                                               \
   do {                                                                               \
     if (taps == 6) {                                                                 \
-      if (esset == 1) launch_slots<T, 1, 6>(a, P, x2, grid, stream);                      \
-      else if (esset == 12) launch_slots<T, 12, 6>(a, P, x2, grid, stream);               \
-      else launch_slots<T, 3, 6>(a, P, x2, grid, stream);                                 \
+      if (esset == 1) launch_slots<T, 1, 6>(a, P, x2 ? 2 : x32 ? 3 : 0, grid, stream);                      \
+      else if (esset == 12) launch_slots<T, 12, 6>(a, P, x2 ? 2 : x32 ? 3 : 0, grid, stream);               \
+      else launch_slots<T, 3, 6>(a, P, x2 ? 2 : x32 ? 3 : 0, grid, stream);                                 \
     } else {                                                                         \
-      if (esset == 1) launch_slots<T, 1, 4>(a, P, x2, grid, stream);                      \
-      else if (esset == 12) launch_slots<T, 12, 4>(a, P, x2, grid, stream);               \
-      else launch_slots<T, 3, 4>(a, P, x2, grid, stream);                                 \
+      if (esset == 1) launch_slots<T, 1, 4>(a, P, x2 ? 2 : x32 ? 3 : 0, grid, stream);                      \
+      else if (esset == 12) launch_slots<T, 12, 4>(a, P, x2 ? 2 : x32 ? 3 : 0, grid, stream);               \
+      else launch_slots<T, 3, 4>(a, P, x2 ? 2 : x32 ? 3 : 0, grid, stream);                                 \
     }                                                                                \
   } while (0)
   if (elem == 1) VALI_COLS_T(uint8_t);
