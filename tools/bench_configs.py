@@ -243,14 +243,14 @@ def cfg4(n=64):
     ms_rot1, wall_rot1 = timed(ud.Stream, lambda: rot.RunAsync(mids[0], outs[0], 90.0), 200, 20)
     ms_fused, _ = timed(ud.Stream, [lambda q=q[5]: ud.RunRotatedBatchAsync(q, angle=90.0) for q in sets], 30)
     return {"config": f"cfg4 PySurfaceUD NV12 2160p->RGB 1080p (batch={n}, one launch) + PySurfaceRotator 90deg (batch, one launch)",
-            "ud": {"kernel": "k_ud_down2<RGB>", "us_per_frame": round(ms_ud * 1e3 / n, 3), "bytes_moved_per_frame": b_ud,
+            "ud": {"kernel": "k_ud_half<RGB>", "us_per_frame": round(ms_ud * 1e3 / n, 3), "bytes_moved_per_frame": b_ud,
                    "roofline": roofline("cfg4_ud", b_ud, n, ms_ud, k)},
             "rot": {"kernel": "k_rotate_tile<3, 90>", "us_per_frame": round(ms_rot * 1e3 / n, 3), "bytes_moved_per_frame": b_rot,
                     "roofline": roofline("cfg4_rot", b_rot, n, ms_rot, k),
                     "single_call_us(stream)": round(ms_rot1 * 1e3, 3), "single_call_us(host)": round(wall_rot1 * 1e3, 3)},
             "chain": {"us_per_frame": round((ms_ud + ms_rot) * 1e3 / n, 3), "bytes_moved_per_frame": b_ud + b_rot,
                       "roofline": roofline("cfg4_chain", b_ud + b_rot, n, ms_ud + ms_rot, k)},
-            "fused(PySurfaceUD.RunRotatedBatch)": {"kernel": "k_ud_down2_t<90>", "us_per_frame": round(ms_fused * 1e3 / n, 3),
+            "fused(PySurfaceUD.RunRotatedBatch)": {"kernel": "k_ud_half_t<90, 64>", "us_per_frame": round(ms_fused * 1e3 / n, 3),
                                                    "bytes_moved_per_frame": b_ud,
                                                    "bytes_note": "one pass: the 6 220 800 B intermediate is neither written nor re-read",
                                                    "roofline": roofline("cfg4_fused", b_ud, n, ms_fused, k),
@@ -273,7 +273,7 @@ def udgen(n=64):
             return srcs, dsts, ud.PrepareBatch(srcs, dsts)
         sets = make_sets(k, make)
         ms, _ = timed(ud.Stream, [lambda q=q: ud.RunBatchAsync(q) for _, _, q in sets], 30)
-        out.append({"geometry": f"{sw}x{sh}->{dw}x{dh}", "kernel": "k_ud_nv12<u8, RGB, staged>", "us_per_frame": round(ms * 1e3 / n, 3),
+        out.append({"geometry": f"{sw}x{sh}->{dw}x{dh}", "kernel": "k_ud_32<RGB>" if 2 * sw == 3 * dw and 2 * sh == 3 * dh else "k_ud_nv12<u8, RGB, staged>", "us_per_frame": round(ms * 1e3 / n, 3),
                     "bytes_moved_per_frame": b, "roofline": roofline(f"udgen_{dw}x{dh}", b, n, ms, k)})
         del sets
     return {"config": f"udgen PySurfaceUD NV12 1080p -> RGB at non-2x ratios, batch={n}, one launch each",

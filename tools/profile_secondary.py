@@ -33,7 +33,7 @@ KEYS = {
     "interp_lanczos_720p": ("interp", "k_resize_cols_x32<", 64),  # 1080p -> 720p: 3:2 both ways
     "cfg4_ud": ("cfg4", "k_ud_half<", 64),
     "cfg4_rot": ("cfg4", "k_rotate_tile", 64),
-    "cfg4_fused": ("cfg4", "k_ud_down2_t<", 64),
+    "cfg4_fused": ("cfg4", "k_ud_half_t<", 64),
     "udgen_1280x720": ("udgen", "k_ud_32<", 64),     # 1080p -> 720p: exactly 3:2
     "udgen_640x384": ("udgen", "k_ud_nv12<", 64),    # the any-ratio kernel
 }

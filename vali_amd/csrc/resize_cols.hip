@@ -36,14 +36,17 @@ namespace vali {
 
 constexpr int kColEl = 8;                    // source elements per lane and row
 constexpr int kColSpan = kWave * kColEl;     // 512 source elements per tile row
-constexpr int kColPadL = 4, kColPadR = 6;    // replicas of the first / last pixel (even: the pairs stay aligned)
-constexpr int kColStrip = 576;               // floats of a wave's strip: ES segments, pads included
-constexpr int kColLds = kColStrip + 256;     // + the output transposition
+constexpr int kColPadL = 4, kColPadR = 4;    // replicas of the first / last pixel
+constexpr int kColStrip = 560;               // SLOTS (float pairs: one column of two dst rows) of a wave's strip: ES segments, pads included
+constexpr int kColLds = 2 * (kColStrip + 256); // floats: + the output transposition (256 elements x 2 rows)
 constexpr int kColProgRows = 56;             // source rows a wave may walk: its program is one lane per row, D rows of slack
 
-// segment stride (floats) of the de-interleaved strip: even, and chosen so that the ES channels of one pixel -- read by
-// neighbouring lanes -- sit in different banks (ds_read_b64: 64 banks)
-template <int ES> constexpr int kColSeg = ES == 1 ? 0 : ES == 2 ? 288 : 184;
+// A channel segment of the strip is two halves of kColHalf slots: positions (pixels) of even index in front, of odd index
+// behind.  Around 2:1 the windows of neighbouring dst pixels start two positions apart: their k-th taps are then
+// NEIGHBOURING slots of one half (conflict-free ds_read_b64; in a linear strip they are 16 bytes apart: two lanes per
+// bank).  Sizes: >= (positions + pads) / 2; chosen so that the ES channels of one pixel -- read by neighbouring lanes --
+// and the two halves sit in different banks.
+template <int ES> constexpr int kColHalf = ES == 1 ? 272 : ES == 2 ? 136 : 91;
 
 typedef u32 u32_u __attribute__((aligned(1)));
 
@@ -209,26 +212,29 @@ template <typename T> __device__ __forceinline__ void conv8(const u32 (&d)[2 * s
   }
 }
 
+// slot of strip position q: even positions in the front half of a channel segment, odd ones in the back half
+template <int ES> __device__ __forceinline__ int col_slot(int q) { return (q >> 1) + (q & 1) * kColHalf<ES>; }
+
 template <typename T, int ES, int TAPS, int P>
 __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw, int sh, uint8_t* dp, int dpitch,
-                                          int dw, int dh, u32 tx, u32 ty, int N, int rps, float* strip, float* obuf) {
+                                          int dw, int dh, u32 tx, u32 ty, int N, int rps, float* lds) {
   constexpr int kBefore = LzTap<TAPS>::kBefore;
   constexpr int EB = (int)sizeof(T);
   constexpr int ND = 2 * EB;                                    // dwords of a lane's 8 elements
   constexpr int D = EB == 4 ? 2 : 4;                            // source rows in flight
-  constexpr int NP = EB == 4 ? TAPS / 2 : TAPS / 2 + 1;         // float pairs of a horizontal window
-  constexpr int SEG = kColSeg<ES>;
+  constexpr int HALF = kColHalf<ES>, SEG = 2 * HALF;            // slots
   const int lane = threadIdx.x & 63;
-  const u32 lds_base = (u32)(uintptr_t)(__attribute__((address_space(3))) float*)strip; // LDS byte address of the strip
+  v2f32* const strip = reinterpret_cast<v2f32*>(lds);           // one slot = one column of TWO dst rows
+  v2f32* const obuf = strip + kColStrip;
+  const u32 lds_base = (u32)(uintptr_t)(__attribute__((address_space(3))) float*)lds; // LDS byte address of the strip
   ColRows<P> r;
-  if (!cols_rows<TAPS, P>(sh, dh, spitch, ty, rps, strip, r))
+  if (!cols_rows<TAPS, P>(sh, dh, spitch, ty, rps, lds, r))
     return;
   const int dwe = dw * ES, row_el = sw * ES;
   const int e0 = (int)tx * N, e_last = min(e0 + N, dwe) - 1;
   const float scale_x = (float)sw / (float)dw;
 
-  // ---- the tile's source span along x (wave-uniform), one element more on either side than the taps need: a window
-  // that starts on an odd float is read from the even float in front of it ----
+  // ---- the tile's source span along x (wave-uniform) ----
   const int px_first = e0 / ES, px_last = e_last / ES;
   const int ux0 = (int)__builtin_floorf((float)px_first * scale_x) - kBefore - 1;
   const int ux1 = (int)__builtin_floorf((float)px_last * scale_x) + TAPS + 1 - kBefore;
@@ -242,49 +248,36 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
   const int j0 = min(j_begin + kColEl * min(lane, nl - 1), row_el - kColEl);
   const bool has = lane < nl;
 
-  // strip positions of this lane's 8 elements
+  // strip slots of this lane's 8 elements.  1- and 2-element pixels: its pixels are consecutive positions q0 .. -- those
+  // of q0's parity are one run of adjacent slots (wpos[0] ..), the others another (wpos[1] ..); q0 % 4 == 0 unless the
+  // chunk slid (kColPadL = 4): the runs then start on 16 bytes
   int wpos[ES == 3 ? kColEl : 2];
   if constexpr (ES == 3) {
 #pragma unroll
     for (int q = 0; q < kColEl; ++q) {
       const int j = j0 + q, px = j / 3;
-      wpos[q] = (j - px * 3) * SEG + kColPadL + px - px_begin;
+      wpos[q] = (j - px * 3) * SEG + col_slot<ES>(kColPadL + px - px_begin);
     }
-  } else if constexpr (ES == 2) {
-    wpos[0] = kColPadL + (j0 >> 1) - px_begin; // j0 is even: (U, V) pairs
-    wpos[1] = SEG + wpos[0];
   } else {
-    wpos[0] = kColPadL + j0 - px_begin;
-    wpos[1] = 0;
+    const int q0 = kColPadL + j0 / ES - px_begin;
+    wpos[0] = col_slot<ES>(q0);
+    wpos[1] = col_slot<ES>(q0 + 1);
   }
 
-  // ---- horizontal pass set-up: this lane's 4 elements, their window start and (even, odd) weight pairs ----
-  v2f32 wq[4][NP];
-  int ho[4];
+  // ---- horizontal pass set-up: this lane's 4 elements: the slots of their even and odd taps, their weights ----
+  float wq[4][TAPS];
+  u32 ha[4][2]; // LDS byte addresses: taps 0, 2, 4 at ha[p][0] + 0, 8, 16; taps 1, 3, 5 at ha[p][1] + 0, 8, 16
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int e = min(e0 + p * kWave + lane, e_last);
     const int px = e / ES, ch = e - px * ES;
     const LzTap<TAPS> c = make_lz_tap<TAPS>(px, scale_x);
-    const int o = kColPadL + (min(c.i, sw - 1) - kBefore - px_begin); // >= kColPadL - kBefore
-    if constexpr (EB == 4) { // float planes: exactly the TAPS taps (a zero weight on a non-finite neighbour is not a no-op)
-      ho[p] = ch * SEG + o;
+    const int q = kColPadL + (min(c.i, sw - 1) - kBefore - px_begin); // >= kColPadL - kBefore
+    ha[p][0] = lds_base + 8u * (u32)(ch * SEG + col_slot<ES>(q));
+    ha[p][1] = lds_base + 8u * (u32)(ch * SEG + col_slot<ES>(q + 1));
 #pragma unroll
-      for (int j = 0; j < NP; ++j)
-        wq[p][j] = (v2f32){c.w[2 * j], c.w[2 * j + 1]};
-    } else {
-      const bool odd = (o & 1) != 0;
-      ho[p] = ch * SEG + (o & ~1);
-#pragma unroll
-      for (int j = 0; j < NP; ++j) {
-        // even start: (w0,w1) (w2,w3) .. (0,0) ; odd start: (0,w0) (w1,w2) .. (w_last,0)
-        const float a0 = 2 * j < TAPS ? c.w[2 * j < TAPS ? 2 * j : 0] : 0.0f;
-        const float a1 = 2 * j + 1 < TAPS ? c.w[2 * j + 1 < TAPS ? 2 * j + 1 : 0] : 0.0f;
-        const float b0 = j > 0 ? c.w[j > 0 ? 2 * j - 1 : 0] : 0.0f;
-        const float b1 = 2 * j < TAPS ? c.w[2 * j < TAPS ? 2 * j : 0] : 0.0f;
-        wq[p][j] = odd ? (v2f32){b0, b1} : (v2f32){a0, a1};
-      }
-    }
+    for (int k = 0; k < TAPS; ++k)
+      wq[p][k] = c.w[k];
   }
   const bool pad_left = ux0 < 0, pad_right = ux1 > sw - 1;                 // wave-uniform
   const int edge = kColPadL + (sw - 1) - px_begin;                         // the last pixel of the row
@@ -293,100 +286,128 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
   // whole dwords from every lane that stores, on 4-byte aligned rows: one store, no per-lane alignment test
   const bool plain_store = EB == 1 && ((e_last + 1 - e0) & 3) == 0 && ((((uintptr_t)dp) | (uintptr_t)dpitch) & 3u) == 0; // wave-uniform
 
-  auto emit = [&](int rr, v2f32 (&c)[4]) { // dst row rr: its columns c go to the strip, the wave filters along x
+  auto store_row = [&](int rr, float v0, float v1, float v2, float v3) {
+    uint8_t* const out = dp + (u32)((r.y_first + rr) * dpitch) + (size_t)eb * EB;
+    if (plain_store) {
+      u32 q = __builtin_amdgcn_cvt_pk_u8_f32(v0, 0u, 0u);
+      q = __builtin_amdgcn_cvt_pk_u8_f32(v1, 1u, q);
+      q = __builtin_amdgcn_cvt_pk_u8_f32(v2, 2u, q);
+      q = __builtin_amdgcn_cvt_pk_u8_f32(v3, 3u, q);
+      gstore_nt<u32>(out, q);
+    } else {
+      const float res[4][1] = {{v0}, {v1}, {v2}, {v3}};
+      store_px4<T, 1>(out, res, (1u << n_out) - 1u);
+    }
+  };
+
+  // The pass along the rows takes dst rows in PAIRS: the columns of row rr (even) wait in registers until row rr + 1
+  // completes, then a strip slot holds one column of BOTH rows and a tap is one ds_read_b64 + one v_pk_fma_f32 whose weight
+  // is the same for both halves -- six of each per two output samples, at any window start (the r03 form read aligned float
+  // pairs of ONE row: eight of each, and an add).  A wave's last row may be single: it runs as a pair with itself.
+  v2f32 hold[4];
+  auto emit = [&](int rr, v2f32 (&c)[4]) {
+    const bool single = (rr & 1) == 0;                 // wave-uniform
+    if (single && rr != r.last_rr) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        hold[i] = c[i];
+      return;
+    }
+    if (single) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        hold[i] = c[i];
+    }
     if (has) {
       if constexpr (ES == 3) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          strip[wpos[2 * i]] = c[i].x;
-          strip[wpos[2 * i + 1]] = c[i].y;
+          strip[wpos[2 * i]] = (v2f32){hold[i].x, c[i].x};
+          strip[wpos[2 * i + 1]] = (v2f32){hold[i].y, c[i].y};
         }
       } else if (ragged) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          if constexpr (ES == 2) {
-            strip[wpos[0] + i] = c[i].x;
-            strip[wpos[1] + i] = c[i].y;
-          } else {
-            strip[wpos[0] + 2 * i] = c[i].x;
-            strip[wpos[0] + 2 * i + 1] = c[i].y;
+          if constexpr (ES == 2) { // pixel i: (U, V)
+            strip[wpos[i & 1] + (i >> 1)] = (v2f32){hold[i].x, c[i].x};
+            strip[SEG + wpos[i & 1] + (i >> 1)] = (v2f32){hold[i].y, c[i].y};
+          } else {                 // pixels 2 i, 2 i + 1
+            strip[wpos[0] + i] = (v2f32){hold[i].x, c[i].x};
+            strip[wpos[1] + i] = (v2f32){hold[i].y, c[i].y};
           }
         }
       } else if constexpr (ES == 2) {
-        *reinterpret_cast<float4*>(strip + wpos[0]) = make_float4(c[0].x, c[1].x, c[2].x, c[3].x);
-        *reinterpret_cast<float4*>(strip + wpos[1]) = make_float4(c[0].y, c[1].y, c[2].y, c[3].y);
+        *reinterpret_cast<float4*>(strip + wpos[0]) = make_float4(hold[0].x, c[0].x, hold[2].x, c[2].x);
+        *reinterpret_cast<float4*>(strip + wpos[1]) = make_float4(hold[1].x, c[1].x, hold[3].x, c[3].x);
+        *reinterpret_cast<float4*>(strip + SEG + wpos[0]) = make_float4(hold[0].y, c[0].y, hold[2].y, c[2].y);
+        *reinterpret_cast<float4*>(strip + SEG + wpos[1]) = make_float4(hold[1].y, c[1].y, hold[3].y, c[3].y);
       } else {
-        *reinterpret_cast<float4*>(strip + wpos[0]) = make_float4(c[0].x, c[0].y, c[1].x, c[1].y);
-        *reinterpret_cast<float4*>(strip + wpos[0] + 4) = make_float4(c[2].x, c[2].y, c[3].x, c[3].y);
+        *reinterpret_cast<float4*>(strip + wpos[0]) = make_float4(hold[0].x, c[0].x, hold[1].x, c[1].x);
+        *reinterpret_cast<float4*>(strip + wpos[0] + 2) = make_float4(hold[2].x, c[2].x, hold[3].x, c[3].x);
+        *reinterpret_cast<float4*>(strip + wpos[1]) = make_float4(hold[0].y, c[0].y, hold[1].y, c[1].y);
+        *reinterpret_cast<float4*>(strip + wpos[1] + 2) = make_float4(hold[2].y, c[2].y, hold[3].y, c[3].y);
       }
     }
     wave_lds_sync();
     if (pad_left || pad_right) { // image edges: replicas of the first / last pixel of every channel segment
       const int ch = lane >> 3, i = lane & 7;
       if (pad_left && ch < ES && i < kColPadL)
-        strip[ch * SEG + kColPadL - 1 - i] = strip[ch * SEG + kColPadL];
+        strip[ch * SEG + col_slot<ES>(kColPadL - 1 - i)] = strip[ch * SEG + col_slot<ES>(kColPadL)];
       if (pad_right && ch < ES && i < kColPadR)
-        strip[ch * SEG + edge + 1 + i] = strip[ch * SEG + edge];
+        strip[ch * SEG + col_slot<ES>(edge + 1 + i)] = strip[ch * SEG + col_slot<ES>(edge)];
       wave_lds_sync();
     }
-    // Two windows per LDS round trip (all four need 32 registers, which cost the kernel its fourth wave per SIMD), every
-    // float pair with its own ds_read_b64: left to itself the compiler fuses two into a ds_read2_b64, which takes twice
-    // the LDS cycles per byte and banks modulo 32 dwords instead of 64 (MI355X_MICROARCH.md, LDS: measured 56 % LDS-busy,
-    // 29 % of it bank conflicts).  Hence the assembly; the wait names every loaded register, so nothing reads one early.
-    float hs[4];
+    // Two windows per LDS round trip, every slot with its own ds_read_b64: left to itself the compiler fuses two into a
+    // ds_read2_b64, which takes twice the LDS cycles per byte and banks modulo 32 dwords instead of 64
+    // (MI355X_MICROARCH.md, LDS).  Hence the assembly; the wait names every loaded register, so nothing reads one early.
 #pragma unroll
     for (int half = 0; half < 4; half += 2) {
-      v2f32 t[2][NP];
-      if constexpr (EB == 4) {
+      v2f32 t[2][TAPS];
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
+      for (int p = 0; p < 2; ++p) {
+        if constexpr (TAPS == 6)
+          asm volatile("ds_read_b64 %0, %6\n\tds_read_b64 %1, %7\n\tds_read_b64 %2, %6 offset:8\n\t"
+                       "ds_read_b64 %3, %7 offset:8\n\tds_read_b64 %4, %6 offset:16\n\tds_read_b64 %5, %7 offset:16"
+                       : "=&v"(t[p][0]), "=&v"(t[p][1]), "=&v"(t[p][2]), "=&v"(t[p][3]), "=&v"(t[p][4]), "=&v"(t[p][5])
+                       : "v"(ha[half + p][0]), "v"(ha[half + p][1]) : "memory");
+        else
+          asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %4 offset:8\n\tds_read_b64 %3, %5 offset:8"
+                       : "=&v"(t[p][0]), "=&v"(t[p][1]), "=&v"(t[p][2]), "=&v"(t[p][3])
+                       : "v"(ha[half + p][0]), "v"(ha[half + p][1]) : "memory");
+      }
+      if constexpr (TAPS == 6)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[0][3]), "+v"(t[0][4]), "+v"(t[0][5]),
+                       "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[1][2]), "+v"(t[1][3]), "+v"(t[1][4]), "+v"(t[1][5]));
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[0][3]), "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[1][2]), "+v"(t[1][3]));
+      // specification order: e over the even taps, o over the odd ones, e + o; the four chains interleaved (a v_pk_fma_f32
+      // that reads the result of the one before it costs a wait state)
+      v2f32 e[2], o[2];
 #pragma unroll
-          for (int jj = 0; jj < NP; ++jj)
-            t[p][jj] = (v2f32){strip[ho[half + p] + 2 * jj], strip[ho[half + p] + 2 * jj + 1]};
-      } else {
+      for (int p = 0; p < 2; ++p)
+        e[p] = o[p] = (v2f32){0.0f, 0.0f};
+#pragma unroll
+      for (int k = 0; k < TAPS; k += 2)
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-          const u32 la = lds_base + 4u * (u32)ho[half + p];
-          if constexpr (NP == 4)
-            asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24"
-                         : "=&v"(t[p][0]), "=&v"(t[p][1]), "=&v"(t[p][2]), "=&v"(t[p][3]) : "v"(la) : "memory");
-          else
-            asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:8\n\tds_read_b64 %2, %3 offset:16"
-                         : "=&v"(t[p][0]), "=&v"(t[p][1]), "=&v"(t[p][2]) : "v"(la) : "memory");
+          e[p] = __builtin_elementwise_fma((v2f32){wq[half + p][k], wq[half + p][k]}, t[p][k], e[p]);
+          o[p] = __builtin_elementwise_fma((v2f32){wq[half + p][k + 1], wq[half + p][k + 1]}, t[p][k + 1], o[p]);
         }
-        if constexpr (NP == 4)
-          asm volatile("s_waitcnt lgkmcnt(0)"
-                       : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[0][3]), "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[1][2]), "+v"(t[1][3]));
-        else
-          asm volatile("s_waitcnt lgkmcnt(0)"
-                       : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[1][2]));
-      }
-      // (the two chains interleaved: a v_pk_fma_f32 that reads the result of the one before it costs a wait state)
-      v2f32 h0 = (v2f32){0.0f, 0.0f}, h1 = (v2f32){0.0f, 0.0f};
 #pragma unroll
-      for (int jj = 0; jj < NP; ++jj) {
-        h0 = __builtin_elementwise_fma(wq[half][jj], t[0][jj], h0);
-        h1 = __builtin_elementwise_fma(wq[half + 1][jj], t[1][jj], h1);
-      }
-      hs[half] = h0.x + h0.y;
-      hs[half + 1] = h1.x + h1.y;
+      for (int p = 0; p < 2; ++p)
+        obuf[(half + p) * kWave + lane] = e[p] + o[p];
     }
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-      obuf[p * kWave + lane] = hs[p];
     wave_lds_sync();
     if (n_out > 0) {
-      const float4 v = *reinterpret_cast<const float4*>(obuf + 4 * lane);
-      uint8_t* const out = dp + (u32)((r.y_first + rr) * dpitch) + (size_t)eb * EB;
-      if (plain_store) {
-        u32 q = __builtin_amdgcn_cvt_pk_u8_f32(v.x, 0u, 0u);
-        q = __builtin_amdgcn_cvt_pk_u8_f32(v.y, 1u, q);
-        q = __builtin_amdgcn_cvt_pk_u8_f32(v.z, 2u, q);
-        q = __builtin_amdgcn_cvt_pk_u8_f32(v.w, 3u, q);
-        gstore_nt<u32>(out, q);
+      const float4 v0 = *reinterpret_cast<const float4*>(obuf + 4 * lane);     // (a0, b0, a1, b1)
+      const float4 v1 = *reinterpret_cast<const float4*>(obuf + 4 * lane + 2); // (a2, b2, a3, b3)
+      if (single) {
+        store_row(rr, v0.x, v0.z, v1.x, v1.z);
       } else {
-        const float res[4][1] = {{v.x}, {v.y}, {v.z}, {v.w}};
-        store_px4<T, 1>(out, res, (1u << n_out) - 1u);
+        store_row(rr - 1, v0.x, v0.z, v1.x, v1.z);
+        store_row(rr, v0.y, v0.w, v1.y, v1.w);
       }
     }
     wave_lds_sync();
@@ -593,14 +614,13 @@ __global__ void __launch_bounds__(kBlock) k_resize_cols(const ResizeArgs a) {
   const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float* const strip = lds[wave];
-  float* const obuf = strip + kColStrip;
   if constexpr (ESSET == 3) {
-    cols_tile<T, 3, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_n, a.cols_rps, strip, obuf);
+    cols_tile<T, 3, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_n, a.cols_rps, strip);
   } else {
     if (ESSET == 12 && job.channels == 2)
-      cols_tile<T, 2, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_n, a.cols_rps, strip, obuf);
+      cols_tile<T, 2, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_n, a.cols_rps, strip);
     else
-      cols_tile<T, 1, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_n, a.cols_rps, strip, obuf);
+      cols_tile<T, 1, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_n, a.cols_rps, strip);
   }
 }
 
