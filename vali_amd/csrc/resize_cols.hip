@@ -50,6 +50,39 @@ template <int ES> constexpr int kColHalf = ES == 1 ? 272 : ES == 2 ? 136 : 91;
 
 typedef u32 u32_u __attribute__((aligned(1)));
 
+// v_pk_fma_f32 with ONE half of the weight pair w for both halves of the result (op_sel: tools/exp/pk_probe.hip): the
+// compiler broadcasts a 32-bit register only from the low half of an even-aligned pair and copies every other weight
+// first (or, hoisting the (w, w) pairs out of the walk, doubles the registers they take).
+__device__ __forceinline__ v2f32 pk_fma_lo(v2f32 w, v2f32 t, v2f32 acc) { // (w.x t.x + acc.x, w.x t.y + acc.y)
+  v2f32 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(w), "v"(t), "v"(acc));
+  return r;
+}
+__device__ __forceinline__ v2f32 pk_fma_hi(v2f32 w, v2f32 t, v2f32 acc) { // (w.y t.x + acc.x, w.y t.y + acc.y)
+  v2f32 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(w), "v"(t), "v"(acc));
+  return r;
+}
+__device__ __forceinline__ v2f32 pk_fma0_lo(v2f32 w, v2f32 t) { // fma(w.x, t, +0): the specification's chains start at +0
+  v2f32 r;
+  asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(r) : "v"(w), "v"(t));
+  return r;
+}
+__device__ __forceinline__ v2f32 pk_fma0_hi(v2f32 w, v2f32 t) {
+  v2f32 r;
+  asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(w), "v"(t));
+  return r;
+}
+// (a[HA], b[HB]) in one instruction
+template <int HA, int HB> __device__ __forceinline__ v2f32 pk_mov(v2f32 a, v2f32 b) {
+  v2f32 r;
+  if constexpr (HA == 0 && HB == 0) asm("v_pk_mov_b32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  else if constexpr (HA == 1 && HB == 1) asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+  else if constexpr (HA == 1) asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+  else asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // ---- the rows of a wave: tap weights per slot, the program, the row offsets ----
 template <int P> struct ColRows {
   float ws[P];        // lane 8 m + k: tap k of dst row m P + j (lanes 8 m + 6, 8 m + 7: 0.0)
@@ -162,7 +195,14 @@ __device__ __forceinline__ void cols_walk(const ColRows<P>& r, const uint8_t* sp
       const int t = t0 + d;
       v2f32 f[NF];
       conv(pf[d], f);
+      // (the load after the conversions, into the registers they just freed: hoisted above them it gets new registers,
+      // which the compiler copies back at the end of every trip -- behind a wait for ALL loads in flight)
+#pragma unroll
+      for (int i = 0; i < NF; ++i)
+        asm volatile("" : "+v"(f[i])); // (pins the conversions in front of the barrier: they have no other order)
+      __builtin_amdgcn_sched_barrier(0);
       issue(t + D, pf[d]);
+      __builtin_amdgcn_sched_barrier(0);
       if (t >= r.ns) // the last trip only: rows past the end are loaded (the issue order stays countable), not used
         continue;
       const u32 w_lo = (u32)__builtin_amdgcn_readlane((int)r.prog_lo, t);
@@ -221,18 +261,42 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
   constexpr int kBefore = LzTap<TAPS>::kBefore;
   constexpr int EB = (int)sizeof(T);
   constexpr int ND = 2 * EB;                                    // dwords of a lane's 8 elements
-  constexpr int D = EB == 4 ? 2 : 4;                            // source rows in flight
+  constexpr int D = EB == 4 ? 2 : EB == 2 ? 3 : 4;               // source rows in flight (registers: 8 EB bytes per lane and row)
   constexpr int HALF = kColHalf<ES>, SEG = 2 * HALF;            // slots
   const int lane = threadIdx.x & 63;
   v2f32* const strip = reinterpret_cast<v2f32*>(lds);           // one slot = one column of TWO dst rows
   v2f32* const obuf = strip + kColStrip;
   const u32 lds_base = (u32)(uintptr_t)(__attribute__((address_space(3))) float*)lds; // LDS byte address of the strip
-  ColRows<P> r;
-  if (!cols_rows<TAPS, P>(sh, dh, spitch, ty, rps, lds, r))
-    return;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int dwe = dw * ES, row_el = sw * ES;
   const int e0 = (int)tx * N, e_last = min(e0 + N, dwe) - 1;
   const float scale_x = (float)sw / (float)dw;
+
+  // ---- column taps: a lane filters elements lane, lane + 64, lane + 128, lane + 192 of the tile.  The four waves of the
+  // workgroup work on the same tile columns (rows ty * 4 + wave): wave w evaluates the w-th set, all four read them back --
+  // a tap set is ~130 instructions, four of them per wave were a quarter of the kernel's vector instructions ----
+  v2f32 wq[4][TAPS / 2]; // (w0, w1), (w2, w3), ..
+  int ci[4];
+  {
+    const LzTap<TAPS> c = make_lz_tap<TAPS>(min(e0 + wave * kWave + lane, e_last) / ES, scale_x);
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k)
+      lds[k * kWave + lane] = c.w[k];
+    reinterpret_cast<int*>(lds)[TAPS * kWave + lane] = c.i;
+    __syncthreads();
+    const float* const all = lds - wave * kColLds;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+#pragma unroll
+      for (int k = 0; k < TAPS / 2; ++k)
+        wq[p][k] = (v2f32){all[p * kColLds + 2 * k * kWave + lane], all[p * kColLds + (2 * k + 1) * kWave + lane]};
+      ci[p] = reinterpret_cast<const int*>(all)[p * kColLds + TAPS * kWave + lane];
+    }
+    __syncthreads();
+  }
+  ColRows<P> r;
+  if (!cols_rows<TAPS, P>(sh, dh, spitch, ty, rps, lds, r))
+    return;
 
   // ---- the tile's source span along x (wave-uniform) ----
   const int px_first = e0 / ES, px_last = e_last / ES;
@@ -264,20 +328,15 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
     wpos[1] = col_slot<ES>(q0 + 1);
   }
 
-  // ---- horizontal pass set-up: this lane's 4 elements: the slots of their even and odd taps, their weights ----
-  float wq[4][TAPS];
+  // ---- horizontal pass set-up: the strip slots of the even and odd taps of this lane's 4 elements ----
   u32 ha[4][2]; // LDS byte addresses: taps 0, 2, 4 at ha[p][0] + 0, 8, 16; taps 1, 3, 5 at ha[p][1] + 0, 8, 16
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int e = min(e0 + p * kWave + lane, e_last);
     const int px = e / ES, ch = e - px * ES;
-    const LzTap<TAPS> c = make_lz_tap<TAPS>(px, scale_x);
-    const int q = kColPadL + (min(c.i, sw - 1) - kBefore - px_begin); // >= kColPadL - kBefore
+    const int q = kColPadL + (min(ci[p], sw - 1) - kBefore - px_begin); // >= kColPadL - kBefore
     ha[p][0] = lds_base + 8u * (u32)(ch * SEG + col_slot<ES>(q));
     ha[p][1] = lds_base + 8u * (u32)(ch * SEG + col_slot<ES>(q + 1));
-#pragma unroll
-    for (int k = 0; k < TAPS; ++k)
-      wq[p][k] = c.w[k];
   }
   const bool pad_left = ux0 < 0, pad_right = ux1 > sw - 1;                 // wave-uniform
   const int edge = kColPadL + (sw - 1) - px_begin;                         // the last pixel of the row
@@ -301,51 +360,55 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
   };
 
   // The pass along the rows takes dst rows in PAIRS: the columns of row rr (even) wait in registers until row rr + 1
-  // completes, then a strip slot holds one column of BOTH rows and a tap is one ds_read_b64 + one v_pk_fma_f32 whose weight
-  // is the same for both halves -- six of each per two output samples, at any window start (the r03 form read aligned float
-  // pairs of ONE row: eight of each, and an add).  A wave's last row may be single: it runs as a pair with itself.
-  v2f32 hold[4];
+  // completes, then a strip slot holds one column of BOTH rows, so a tap is one ds_read_b64 + one v_pk_fma_f32 whose
+  // weight is the same for both halves -- six of each per two output samples, at any window start (the first r03 form
+  // read aligned float pairs of ONE row: eight of each, and an add).  A wave's last row may be single: it runs as a
+  // pair with itself.  (Writing the halves of a slot as the rows complete, ds_write_b32 at a stride of 8 dwords between
+  // lanes, is an 8-way bank conflict per instruction: measured slower than the r03 form.)
+  v2f32 hold[4]; // the columns of the pair's first row
   auto emit = [&](int rr, v2f32 (&c)[4]) {
     const bool single = (rr & 1) == 0;                 // wave-uniform
-    if (single && rr != r.last_rr) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        hold[i] = c[i];
-      return;
-    }
     if (single) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         hold[i] = c[i];
+      if (rr != r.last_rr)
+        return;
     }
     if (has) {
+      v2f32 lo[4], hi[4]; // (row a, row b) of this lane's columns 2 i / 2 i + 1 (ES = 2: U / V of pixel i)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        lo[i] = pk_mov<0, 0>(hold[i], c[i]);
+        hi[i] = pk_mov<1, 1>(hold[i], c[i]);
+      }
       if constexpr (ES == 3) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          strip[wpos[2 * i]] = (v2f32){hold[i].x, c[i].x};
-          strip[wpos[2 * i + 1]] = (v2f32){hold[i].y, c[i].y};
+          strip[wpos[2 * i]] = lo[i];
+          strip[wpos[2 * i + 1]] = hi[i];
         }
       } else if (ragged) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          if constexpr (ES == 2) { // pixel i: (U, V)
-            strip[wpos[i & 1] + (i >> 1)] = (v2f32){hold[i].x, c[i].x};
-            strip[SEG + wpos[i & 1] + (i >> 1)] = (v2f32){hold[i].y, c[i].y};
-          } else {                 // pixels 2 i, 2 i + 1
-            strip[wpos[0] + i] = (v2f32){hold[i].x, c[i].x};
-            strip[wpos[1] + i] = (v2f32){hold[i].y, c[i].y};
+          if constexpr (ES == 2) { // pixel i: (U, V); pixels 0, 2 in the run of wpos[0], 1, 3 in that of wpos[1]
+            strip[wpos[i & 1] + (i >> 1)] = lo[i];
+            strip[SEG + wpos[i & 1] + (i >> 1)] = hi[i];
+          } else {                 // pixels 2 i (run of wpos[0]) and 2 i + 1 (run of wpos[1])
+            strip[wpos[0] + i] = lo[i];
+            strip[wpos[1] + i] = hi[i];
           }
         }
       } else if constexpr (ES == 2) {
-        *reinterpret_cast<float4*>(strip + wpos[0]) = make_float4(hold[0].x, c[0].x, hold[2].x, c[2].x);
-        *reinterpret_cast<float4*>(strip + wpos[1]) = make_float4(hold[1].x, c[1].x, hold[3].x, c[3].x);
-        *reinterpret_cast<float4*>(strip + SEG + wpos[0]) = make_float4(hold[0].y, c[0].y, hold[2].y, c[2].y);
-        *reinterpret_cast<float4*>(strip + SEG + wpos[1]) = make_float4(hold[1].y, c[1].y, hold[3].y, c[3].y);
+        *reinterpret_cast<float4*>(strip + wpos[0]) = make_float4(lo[0].x, lo[0].y, lo[2].x, lo[2].y);
+        *reinterpret_cast<float4*>(strip + wpos[1]) = make_float4(lo[1].x, lo[1].y, lo[3].x, lo[3].y);
+        *reinterpret_cast<float4*>(strip + SEG + wpos[0]) = make_float4(hi[0].x, hi[0].y, hi[2].x, hi[2].y);
+        *reinterpret_cast<float4*>(strip + SEG + wpos[1]) = make_float4(hi[1].x, hi[1].y, hi[3].x, hi[3].y);
       } else {
-        *reinterpret_cast<float4*>(strip + wpos[0]) = make_float4(hold[0].x, c[0].x, hold[1].x, c[1].x);
-        *reinterpret_cast<float4*>(strip + wpos[0] + 2) = make_float4(hold[2].x, c[2].x, hold[3].x, c[3].x);
-        *reinterpret_cast<float4*>(strip + wpos[1]) = make_float4(hold[0].y, c[0].y, hold[1].y, c[1].y);
-        *reinterpret_cast<float4*>(strip + wpos[1] + 2) = make_float4(hold[2].y, c[2].y, hold[3].y, c[3].y);
+        *reinterpret_cast<float4*>(strip + wpos[0]) = make_float4(lo[0].x, lo[0].y, lo[1].x, lo[1].y);
+        *reinterpret_cast<float4*>(strip + wpos[0] + 2) = make_float4(lo[2].x, lo[2].y, lo[3].x, lo[3].y);
+        *reinterpret_cast<float4*>(strip + wpos[1]) = make_float4(hi[0].x, hi[0].y, hi[1].x, hi[1].y);
+        *reinterpret_cast<float4*>(strip + wpos[1] + 2) = make_float4(hi[2].x, hi[2].y, hi[3].x, hi[3].y);
       }
     }
     wave_lds_sync();
@@ -382,18 +445,19 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
       else
         asm volatile("s_waitcnt lgkmcnt(0)"
                      : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[0][3]), "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[1][2]), "+v"(t[1][3]));
-      // specification order: e over the even taps, o over the odd ones, e + o; the four chains interleaved (a v_pk_fma_f32
-      // that reads the result of the one before it costs a wait state)
+      // specification order: e over the even taps, o over the odd ones, e + o
       v2f32 e[2], o[2];
 #pragma unroll
-      for (int p = 0; p < 2; ++p)
-        e[p] = o[p] = (v2f32){0.0f, 0.0f};
+      for (int p = 0; p < 2; ++p) {
+        e[p] = pk_fma0_lo(wq[half + p][0], t[p][0]);
+        o[p] = pk_fma0_hi(wq[half + p][0], t[p][1]);
+      }
 #pragma unroll
-      for (int k = 0; k < TAPS; k += 2)
+      for (int k = 2; k < TAPS; k += 2)
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-          e[p] = __builtin_elementwise_fma((v2f32){wq[half + p][k], wq[half + p][k]}, t[p][k], e[p]);
-          o[p] = __builtin_elementwise_fma((v2f32){wq[half + p][k + 1], wq[half + p][k + 1]}, t[p][k + 1], o[p]);
+          e[p] = pk_fma_lo(wq[half + p][k / 2], t[p][k], e[p]);
+          o[p] = pk_fma_hi(wq[half + p][k / 2], t[p][k + 1], o[p]);
         }
 #pragma unroll
       for (int p = 0; p < 2; ++p)
@@ -401,8 +465,11 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
     }
     wave_lds_sync();
     if (n_out > 0) {
-      const float4 v0 = *reinterpret_cast<const float4*>(obuf + 4 * lane);     // (a0, b0, a1, b1)
-      const float4 v1 = *reinterpret_cast<const float4*>(obuf + 4 * lane + 2); // (a2, b2, a3, b3)
+      // (two ds_read_b128: the compiler reads the halves it uses as four ds_read2_b32 at a lane stride of 32 bytes --
+      // 8 LDS slots each instead of 2, tools/exp/lds_patterns.hip)
+      float4 v0, v1; // (a0, b0, a1, b1), (a2, b2, a3, b3)
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(v0), "=&v"(v1) : "v"(lds_base + 8u * (u32)kColStrip + 32u * (u32)lane) : "memory");
       if (single) {
         store_row(rr, v0.x, v0.z, v1.x, v1.z);
       } else {
