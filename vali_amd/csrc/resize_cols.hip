@@ -83,62 +83,67 @@ template <int HA, int HB> __device__ __forceinline__ v2f32 pk_mov(v2f32 a, v2f32
   return r;
 }
 
-// ---- the rows of a wave: tap weights per slot, the program, the row offsets ----
+// ---- the rows of a wave: per slot the weight of every source row, the rows that complete a dst row, the row offsets ----
+typedef unsigned long long u64;
 template <int P> struct ColRows {
-  float ws[P];        // lane 8 m + k: tap k of dst row m P + j (lanes 8 m + 6, 8 m + 7: 0.0)
-  u32 prog_lo, prog_hi; // lane t: the program word of the wave's t-th source row (below)
+  float ws[P];        // lane t: the weight slot j applies to the wave's t-th source row (0.0: it has no use for the row)
+  u64 done;           // bit t: source row t completes a dst row (rows complete in order, slots in turn)
+  u64 act[P];         // float planes: bit t: slot j uses source row t (a zero weight on a non-finite sample is no no-op)
   u32 roff;           // lane t: byte offset of that row in the source plane
   int ns;             // source rows the wave walks, <= kColProgRows
   int y_first, last_rr;
 };
 
-// false: the wave has no rows.  `strip` is scratch here (>= 512 bytes).
-template <int TAPS, int P>
-__device__ __forceinline__ bool cols_rows(int sh, int dh, int spitch, u32 ty, int rps, float* strip, ColRows<P>& r) {
+// false: the wave has no rows.  `scratch`: (P + 1) x 64 floats of this wave's LDS, (2 P + 1) x 64 for float planes (ACT).
+template <int TAPS, int P, bool ACT>
+__device__ __forceinline__ bool cols_rows(int sh, int dh, int spitch, u32 ty, int rps, float* scratch, ColRows<P>& r) {
   constexpr int kBefore = LzTap<TAPS>::kBefore;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int rows = P * rps;                                     // dst rows of this wave, <= 8 P <= 64
+  const int rows = P * rps;                                     // dst rows of this wave, <= 64
   r.y_first = (int)(ty * kWavesPerBlock + wave) * rows;         // wave-uniform
   if (r.y_first >= dh)
     return false;
   r.last_rr = min(rows, dh - r.y_first) - 1;
   const float scale_y = (float)sh / (float)dh;
-  // row taps: lane r evaluates row y_first + r; the weights go through LDS into one register per slot
+  // Lane r evaluates the taps of dst row y_first + r (slot r mod P) and scatters them through LDS into the slot's
+  // row-indexed weight register: the windows of a slot's rows do not overlap (floor((rr + P) s) - floor(rr s) >= TAPS), so
+  // every (slot, source row) has at most one writer.  The walk then fetches a row's P weights with v_readlane at the
+  // row index -- the wave's control flow is data, not compares and branches: the kernel is bound by the TOTAL number of
+  // instructions its waves issue (profiles/r03_lanczos.md).  A zero weight is an exact no-op on an accumulator that is
+  // never -0, for the finite values integer planes have; float planes skip the slot instead (act).
   const LzTap<TAPS> vy = make_lz_tap<TAPS>(r.y_first + min(lane, rows - 1), scale_y);
-  if (lane < rows) {
+  const int s_begin = __builtin_amdgcn_readlane(vy.i, 0) - kBefore;
+  r.ns = __builtin_amdgcn_readlane(vy.i, r.last_rr) + TAPS - kBefore - s_begin;
+  u32* const flags = reinterpret_cast<u32*>(scratch) + P * kWave; // [0]: the row completes a dst row; [1 + j]: slot j uses it
+#pragma unroll
+  for (int j = 0; j < P; ++j)
+    scratch[j * kWave + lane] = 0.0f;
+#pragma unroll
+  for (int j = 0; j < (ACT ? P + 1 : 1); ++j)
+    flags[j * kWave + lane] = 0u;
+  wave_lds_sync();
+  if (lane <= r.last_rr) {
+    const int j = lane % P;
+    const int t0 = vy.i - kBefore - s_begin;
 #pragma unroll
     for (int k = 0; k < TAPS; ++k)
-      strip[lane * 8 + k] = vy.w[k];
+      scratch[j * kWave + t0 + k] = vy.w[k];
+    if constexpr (ACT) {
+#pragma unroll
+      for (int k = 0; k < TAPS; ++k)
+        flags[(1 + j) * kWave + t0 + k] = 1u;
+    }
+    flags[t0 + TAPS - 1] = 1u; // (at most one dst row completes per source row: scale_y >= 1)
   }
   wave_lds_sync();
 #pragma unroll
   for (int j = 0; j < P; ++j)
-    r.ws[j] = (lane & 7) < TAPS ? strip[((lane >> 3) * P + j) * 8 + (lane & 7)] : 0.0f;
-  wave_lds_sync();
-  // The wave's program: what every source row it walks does, as data instead of control flow.  Byte j of row t's word =
-  // the lane of ws[j] that holds the weight slot j applies to this row (lane 8 m + 7 holds 0.0: the slot has no use for
-  // the row -- a zero weight is an exact no-op on an accumulator that is never -0, for the finite values integer planes
-  // have; float planes skip the slot instead), bit 7 of the byte = this row completes the slot's window.  Written by the
-  // lanes that own the dst rows (lane r: TAPS bytes), read back one word per lane.  The walk then costs one v_readlane +
-  // one scalar shift per slot and row instead of the dozen scalar compares, branches and counters of a control-flow
-  // form: the kernel is bound by the TOTAL number of instructions its waves issue (profiles/r03_lanczos.md).
-  const int s_begin = __builtin_amdgcn_readlane(vy.i, 0) - kBefore;
-  r.ns = __builtin_amdgcn_readlane(vy.i, r.last_rr) + TAPS - kBefore - s_begin;
-  uint8_t* const prog = reinterpret_cast<uint8_t*>(strip);
-  reinterpret_cast<uint2*>(prog)[lane] = make_uint2(0x07070707u, 0x00000707u);
-  wave_lds_sync();
-  if (lane <= r.last_rr) {
-    const int j = lane % P, m = lane / P;
-    const int t0 = vy.i - kBefore - s_begin;
+    r.ws[j] = scratch[j * kWave + lane];
+  r.done = __ballot(flags[lane] != 0u);
 #pragma unroll
-    for (int k = 0; k < TAPS; ++k)
-      prog[(t0 + k) * 8 + j] = (uint8_t)(m * 8 + k + (k == TAPS - 1 ? 0x80 : 0));
-  }
-  wave_lds_sync();
-  const uint2 pw = reinterpret_cast<const uint2*>(prog)[lane];
-  r.prog_lo = pw.x;
-  r.prog_hi = pw.y;
+  for (int j = 0; j < P; ++j)
+    r.act[j] = ACT ? __ballot(flags[(1 + j) * kWave + lane] != 0u) : 0ull;
   // (lanes past the wave's last row repeat it: the walk's prefetch runs D rows ahead, and rows that belong to the wave
   // below are long gone from the L2 when that wave started on them -- 8 % more HBM reads)
   r.roff = (u32)(clampi(s_begin + min(lane, r.ns - 1), sh - 1) * spitch);
@@ -205,17 +210,14 @@ __device__ __forceinline__ void cols_walk(const ColRows<P>& r, const uint8_t* sp
       __builtin_amdgcn_sched_barrier(0);
       if (t >= r.ns) // the last trip only: rows past the end are loaded (the issue order stays countable), not used
         continue;
-      const u32 w_lo = (u32)__builtin_amdgcn_readlane((int)r.prog_lo, t);
-      const u32 w_hi = P > 4 ? (u32)__builtin_amdgcn_readlane((int)r.prog_hi, t) : 0u;
       float w[P];
 #pragma unroll
       for (int j = 0; j < P; ++j) // (the weights first, the arithmetic after: no wait states between a v_readlane and its use)
-        w[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.ws[j]),
-                                                                   (int)(((j < 4 ? w_lo : w_hi) >> (8 * (j & 3))) & 0x3fu)));
+        w[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.ws[j]), t));
 #pragma unroll
       for (int j = 0; j < P; ++j) {
         if constexpr (EB == 4) {
-          if (((((j < 4 ? w_lo : w_hi) >> (8 * (j & 3))) & 7u) == 7u)) // wave-uniform
+          if (((r.act[j] >> t) & 1ull) == 0ull) // wave-uniform
             continue;
         }
         const v2f32 wv = (v2f32){w[j], w[j]};
@@ -223,7 +225,7 @@ __device__ __forceinline__ void cols_walk(const ColRows<P>& r, const uint8_t* sp
         for (int i = 0; i < NF; ++i)
           acc[j][i] = __builtin_elementwise_fma(wv, f[i], acc[j][i]);
       }
-      if (((w_lo & 0x80808080u) | (w_hi & 0x8080u)) != 0u) { // at most one dst row per source row (scale_y >= 1)
+      if ((r.done >> t) & 1ull) { // at most one dst row per source row (scale_y >= 1)
 #pragma unroll
         for (int j = 0; j < P; ++j) {
           if (eslot == j) {
@@ -295,7 +297,7 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
     __syncthreads();
   }
   ColRows<P> r;
-  if (!cols_rows<TAPS, P>(sh, dh, spitch, ty, rps, lds, r))
+  if (!cols_rows<TAPS, P, EB == 4>(sh, dh, spitch, ty, rps, lds, r))
     return;
 
   // ---- the tile's source span along x (wave-uniform) ----
@@ -423,45 +425,71 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
     // Two windows per LDS round trip, every slot with its own ds_read_b64: left to itself the compiler fuses two into a
     // ds_read2_b64, which takes twice the LDS cycles per byte and banks modulo 32 dwords instead of 64
     // (MI355X_MICROARCH.md, LDS).  Hence the assembly; the wait names every loaded register, so nothing reads one early.
+    // Two windows per block of assembly: their ds_read_b64s (every slot with its own: left to itself the compiler fuses
+    // two into a ds_read2_b64, four times the LDS time -- tools/exp/lds_patterns.hip), the wait for the first window
+    // only, its chains (specification order: e over the even taps, o over the odd ones, e + o; one half of a weight
+    // pair for both halves of the result by op_sel) while the second window's reads are still in flight.  One block: the
+    // compiler pads every boundary between assembly and its own code with an s_nop.
 #pragma unroll
     for (int half = 0; half < 4; half += 2) {
-      v2f32 t[2][TAPS];
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        if constexpr (TAPS == 6)
-          asm volatile("ds_read_b64 %0, %6\n\tds_read_b64 %1, %7\n\tds_read_b64 %2, %6 offset:8\n\t"
-                       "ds_read_b64 %3, %7 offset:8\n\tds_read_b64 %4, %6 offset:16\n\tds_read_b64 %5, %7 offset:16"
-                       : "=&v"(t[p][0]), "=&v"(t[p][1]), "=&v"(t[p][2]), "=&v"(t[p][3]), "=&v"(t[p][4]), "=&v"(t[p][5])
-                       : "v"(ha[half + p][0]), "v"(ha[half + p][1]) : "memory");
-        else
-          asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %4 offset:8\n\tds_read_b64 %3, %5 offset:8"
-                       : "=&v"(t[p][0]), "=&v"(t[p][1]), "=&v"(t[p][2]), "=&v"(t[p][3])
-                       : "v"(ha[half + p][0]), "v"(ha[half + p][1]) : "memory");
+      v2f32 t0, t1, t2, t3, t4, t5, u0, u1, u2, u3, u4, u5;
+      if constexpr (TAPS == 6) {
+        asm volatile(
+            "ds_read_b64 %[t0], %[a0]\n\tds_read_b64 %[t1], %[a1]\n\tds_read_b64 %[t2], %[a0] offset:8\n\t"
+            "ds_read_b64 %[t3], %[a1] offset:8\n\tds_read_b64 %[t4], %[a0] offset:16\n\tds_read_b64 %[t5], %[a1] offset:16\n\t"
+            "ds_read_b64 %[u0], %[b0]\n\tds_read_b64 %[u1], %[b1]\n\tds_read_b64 %[u2], %[b0] offset:8\n\t"
+            "ds_read_b64 %[u3], %[b1] offset:8\n\tds_read_b64 %[u4], %[b0] offset:16\n\tds_read_b64 %[u5], %[b1] offset:16\n\t"
+            "s_waitcnt lgkmcnt(6)\n\t"
+            "v_pk_fma_f32 %[t0], %[w0], %[t0], 0 op_sel_hi:[0,1,0]\n\t"
+            "v_pk_fma_f32 %[t1], %[w0], %[t1], 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]\n\t"
+            "v_pk_fma_f32 %[t0], %[w1], %[t2], %[t0] op_sel_hi:[0,1,1]\n\t"
+            "v_pk_fma_f32 %[t1], %[w1], %[t3], %[t1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+            "v_pk_fma_f32 %[t0], %[w2], %[t4], %[t0] op_sel_hi:[0,1,1]\n\t"
+            "v_pk_fma_f32 %[t1], %[w2], %[t5], %[t1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_pk_fma_f32 %[u0], %[x0], %[u0], 0 op_sel_hi:[0,1,0]\n\t"
+            "v_pk_fma_f32 %[u1], %[x0], %[u1], 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]\n\t"
+            "v_pk_add_f32 %[t0], %[t0], %[t1]\n\t"
+            "v_pk_fma_f32 %[u0], %[x1], %[u2], %[u0] op_sel_hi:[0,1,1]\n\t"
+            "v_pk_fma_f32 %[u1], %[x1], %[u3], %[u1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+            "v_pk_fma_f32 %[u0], %[x2], %[u4], %[u0] op_sel_hi:[0,1,1]\n\t"
+            "v_pk_fma_f32 %[u1], %[x2], %[u5], %[u1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+            "s_nop 0\n\t"
+            "v_pk_add_f32 %[u0], %[u0], %[u1]"
+            : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+              [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [u0] "=&v"(u0), [u1] "=&v"(u1), [u2] "=&v"(u2), [u3] "=&v"(u3),
+              [u4] "=&v"(u4), [u5] "=&v"(u5)
+            : [a0] "v"(ha[half][0]), [a1] "v"(ha[half][1]), [b0] "v"(ha[half + 1][0]), [b1] "v"(ha[half + 1][1]),
+              [w0] "v"(wq[half][0]), [w1] "v"(wq[half][1]), [w2] "v"(wq[half][TAPS / 2 - 1]), [x0] "v"(wq[half + 1][0]),
+              [x1] "v"(wq[half + 1][1]), [x2] "v"(wq[half + 1][TAPS / 2 - 1])
+            : "memory");
+      } else {
+        asm volatile(
+            "ds_read_b64 %[t0], %[a0]\n\tds_read_b64 %[t1], %[a1]\n\tds_read_b64 %[t2], %[a0] offset:8\n\t"
+            "ds_read_b64 %[t3], %[a1] offset:8\n\t"
+            "ds_read_b64 %[u0], %[b0]\n\tds_read_b64 %[u1], %[b1]\n\tds_read_b64 %[u2], %[b0] offset:8\n\t"
+            "ds_read_b64 %[u3], %[b1] offset:8\n\t"
+            "s_waitcnt lgkmcnt(4)\n\t"
+            "v_pk_fma_f32 %[t0], %[w0], %[t0], 0 op_sel_hi:[0,1,0]\n\t"
+            "v_pk_fma_f32 %[t1], %[w0], %[t1], 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]\n\t"
+            "v_pk_fma_f32 %[t0], %[w1], %[t2], %[t0] op_sel_hi:[0,1,1]\n\t"
+            "v_pk_fma_f32 %[t1], %[w1], %[t3], %[t1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_pk_fma_f32 %[u0], %[x0], %[u0], 0 op_sel_hi:[0,1,0]\n\t"
+            "v_pk_fma_f32 %[u1], %[x0], %[u1], 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]\n\t"
+            "v_pk_add_f32 %[t0], %[t0], %[t1]\n\t"
+            "v_pk_fma_f32 %[u0], %[x1], %[u2], %[u0] op_sel_hi:[0,1,1]\n\t"
+            "v_pk_fma_f32 %[u1], %[x1], %[u3], %[u1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+            "s_nop 0\n\t"
+            "v_pk_add_f32 %[u0], %[u0], %[u1]"
+            : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+              [t3] "=&v"(t3), [u0] "=&v"(u0), [u1] "=&v"(u1), [u2] "=&v"(u2), [u3] "=&v"(u3)
+            : [a0] "v"(ha[half][0]), [a1] "v"(ha[half][1]), [b0] "v"(ha[half + 1][0]), [b1] "v"(ha[half + 1][1]),
+              [w0] "v"(wq[half][0]), [w1] "v"(wq[half][1]), [x0] "v"(wq[half + 1][0]), [x1] "v"(wq[half + 1][1])
+            : "memory");
       }
-      if constexpr (TAPS == 6)
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[0][3]), "+v"(t[0][4]), "+v"(t[0][5]),
-                       "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[1][2]), "+v"(t[1][3]), "+v"(t[1][4]), "+v"(t[1][5]));
-      else
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[0][3]), "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[1][2]), "+v"(t[1][3]));
-      // specification order: e over the even taps, o over the odd ones, e + o
-      v2f32 e[2], o[2];
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        e[p] = pk_fma0_lo(wq[half + p][0], t[p][0]);
-        o[p] = pk_fma0_hi(wq[half + p][0], t[p][1]);
-      }
-#pragma unroll
-      for (int k = 2; k < TAPS; k += 2)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          e[p] = pk_fma_lo(wq[half + p][k / 2], t[p][k], e[p]);
-          o[p] = pk_fma_hi(wq[half + p][k / 2], t[p][k + 1], o[p]);
-        }
-#pragma unroll
-      for (int p = 0; p < 2; ++p)
-        obuf[(half + p) * kWave + lane] = e[p] + o[p];
+      obuf[half * kWave + lane] = t0;       // (the chains accumulate in the registers of their first taps)
+      obuf[(half + 1) * kWave + lane] = u0;
     }
     wave_lds_sync();
     if (n_out > 0) {
@@ -497,7 +525,7 @@ __device__ __forceinline__ void cols_tile_x2(const uint8_t* sp, int spitch, int 
   constexpr int D = EB == 1 ? 4 : 2;
   const int lane = threadIdx.x & 63;
   ColRows<P> r;
-  if (!cols_rows<TAPS, P>(sh, dh, spitch, ty, rps, strip, r))
+  if (!cols_rows<TAPS, P, false>(sh, dh, spitch, ty, rps, strip, r))
     return;
   const int dwe = dw * ES;                                      // >= 8 (host)
   const int e0 = (int)tx * (kWave * 8);
@@ -564,7 +592,7 @@ __device__ __forceinline__ void cols_tile_x32(const uint8_t* sp, int spitch, int
   constexpr int kBefore = LzTap<TAPS>::kBefore;
   const int lane = threadIdx.x & 63;
   ColRows<P> r;
-  if (!cols_rows<TAPS, P>(sh, dh, spitch, ty, rps, strip, r))
+  if (!cols_rows<TAPS, P, false>(sh, dh, spitch, ty, rps, strip, r))
     return;
   const int dwe = dw * ES, row_el = sw * ES;                    // dwe % 8 == 0 (host), so row_el % 12 == 0
   const int e0 = (int)tx * kX32Out;                             // first dst element of the wave
@@ -693,7 +721,7 @@ __global__ void __launch_bounds__(kBlock) k_resize_cols(const ResizeArgs a) {
 
 template <typename T, int ESSET, int TAPS, int P>
 __global__ void __launch_bounds__(kBlock) k_resize_cols_x2(const ResizeArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][384]; // scratch of cols_rows: 8 P rows x 8 weights
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][448]; // scratch of cols_rows: (P + 1) x 64
   ResizeJob job;
   u32 tx, ty, frame;
   if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
@@ -708,7 +736,7 @@ __global__ void __launch_bounds__(kBlock) k_resize_cols_x2(const ResizeArgs a) {
 
 template <typename T, int ESSET, int TAPS, int P>
 __global__ void __launch_bounds__(kBlock) k_resize_cols_x32(const ResizeArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][384]; // scratch of cols_rows
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][448]; // scratch of cols_rows: (P + 1) x 64
   ResizeJob job;
   u32 tx, ty, frame;
   if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
