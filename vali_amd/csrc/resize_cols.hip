@@ -263,7 +263,7 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
   constexpr int kBefore = LzTap<TAPS>::kBefore;
   constexpr int EB = (int)sizeof(T);
   constexpr int ND = 2 * EB;                                    // dwords of a lane's 8 elements
-  constexpr int D = EB == 4 ? 2 : EB == 2 ? 3 : 4;               // source rows in flight (registers: 8 EB bytes per lane and row)
+  constexpr int D = EB == 4 ? 3 : EB == 2 ? 3 : 4;               // source rows in flight (registers: 8 EB bytes per lane and row)
   constexpr int HALF = kColHalf<ES>, SEG = 2 * HALF;            // slots
   const int lane = threadIdx.x & 63;
   v2f32* const strip = reinterpret_cast<v2f32*>(lds);           // one slot = one column of TWO dst rows
@@ -279,7 +279,16 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
   // a tap set is ~130 instructions, four of them per wave were a quarter of the kernel's vector instructions ----
   v2f32 wq[4][TAPS / 2]; // (w0, w1), (w2, w3), ..
   int ci[4];
-  {
+  if constexpr (EB == 4) { // float planes are bound by their memory stream: no workgroup barriers in front of the walk
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const LzTap<TAPS> c = make_lz_tap<TAPS>(min(e0 + p * kWave + lane, e_last) / ES, scale_x);
+#pragma unroll
+      for (int k = 0; k < TAPS / 2; ++k)
+        wq[p][k] = (v2f32){c.w[2 * k], c.w[2 * k + 1]};
+      ci[p] = c.i;
+    }
+  } else {
     const LzTap<TAPS> c = make_lz_tap<TAPS>(min(e0 + wave * kWave + lane, e_last) / ES, scale_x);
 #pragma unroll
     for (int k = 0; k < TAPS; ++k)
