@@ -316,3 +316,64 @@ def test_columns_first_batch_and_rows_per_wave(vali, gpu, oracle, rows_mode):
     want = oracle.resize_surface(host, "RGB_32F", fw, fh, 180, 140, "lanczos")
     nan = np.isnan(want)
     assert np.array_equal(np.isnan(got), nan) and np.array_equal(got[~nan].view(np.uint32), want[~nan].view(np.uint32))
+
+
+# ---- one-channel planes exactly doubled both ways (vali_amd/csrc/resize_up2.hip) -------------------------------------
+# (source size): widths that are / are not multiples of 4 per plane (the second kind keeps the general kernel), one wave per
+# row and several, 1 .. 3 rows (every tap clamped), heights around the rows-per-wave forms
+UP2_SIZES = [(8, 2), (16, 6), (248, 20), (256, 64), (500, 37), (1000, 130), (960, 540), (36, 4), (1928, 70), (6, 10)]
+
+
+@pytest.mark.parametrize("fmt", ["Y", "YUV420", "YUV444", "RGB_PLANAR", "YUV444_10bit", "NV12"])
+@pytest.mark.parametrize("size", UP2_SIZES)
+@pytest.mark.parametrize("interp", ["lanczos", "cubic"])
+def test_doubled_planes_bit_exact(vali, gpu, oracle, fmt, size, interp):
+    sw, sh = size
+    if fmt in ("YUV420", "NV12") and (sw | sh) & 1:
+        pytest.skip("4:2:0 needs even sizes")
+    dt = DT.get(fmt, np.uint8)
+    n = vali.Surface.Make(vali.PixelFormat[fmt], sw, sh, gpu).HostSize // np.dtype(dt).itemsize
+    rng = np.random.default_rng(sw * 13 + sh)
+    host = (rng.random(n) * (1023 if dt == np.uint16 else 255)).astype(dt)
+    host[:: max(1, n // 50)] = np.iinfo(dt).max if dt != np.uint16 else 1023   # saturation / overshoot next to dark pixels
+    mode = vali.Interpolation.LANCZOS if interp == "lanczos" else vali.Interpolation.CUBIC
+    want = oracle.resize_surface(host, fmt, sw, sh, 2 * sw, 2 * sh, interp)
+    assert np.array_equal(roundtrip(vali, gpu, fmt, host, sw, sh, 2 * sw, 2 * sh, interp=mode), want)
+    for rows_mode in (1, 2, 3):                            # 8 / 2 / 64 source rows per wave
+        with vali.tuning.Override(RESIZE_NO_SEPARABLE=rows_mode):
+            assert np.array_equal(roundtrip(vali, gpu, fmt, host, sw, sh, 2 * sw, 2 * sh, interp=mode), want)
+    with vali.tuning.Override(RESIZE_POINT=0):            # the general rows-first kernel
+        assert np.array_equal(roundtrip(vali, gpu, fmt, host, sw, sh, 2 * sw, 2 * sh, interp=mode), want)
+
+
+@pytest.mark.parametrize("pair", [("YUV420", "YUV444", np.uint8), ("YUV420_10bit", "YUV444_10bit", np.uint16)])
+@pytest.mark.parametrize("size", [(640, 360), (1920, 1080), (72, 34)])
+def test_planar_ud_at_unchanged_size_takes_the_plane_forms(vali, gpu, oracle, pair, size):
+    """UDPlanar's everyday case: luma 1:1 (the point form = a copy), chroma doubled (resize_up2.hip), one batch of 3"""
+    sf, df, dt = pair
+    w, h = size
+    rng = np.random.default_rng(w + h)
+    frames = [(rng.random(w * h * 3 // 2) * (1023 if dt == np.uint16 else 255)).astype(dt) for _ in range(2)]
+    srcs = [vali.Surface.Make(vali.PixelFormat[sf], w, h, gpu) for _ in range(3)]
+    dsts = [vali.Surface.Make(vali.PixelFormat[df], w, h, gpu) for _ in range(3)]
+    for i, s in enumerate(srcs):
+        assert vali.PyFrameUploader(gpu).Run(frames[i % 2].view(np.uint8), s)[0]
+    ud = vali.PySurfaceUD(gpu)
+    assert ud.RunBatch(srcs, dsts) == (True, vali.TaskExecInfo.SUCCESS)
+    def planar_want(host):
+        off, want = 0, []
+        for pw, ph in ((w, h), (w // 2, h // 2), (w // 2, h // 2)):
+            plane = np.ascontiguousarray(host[off: off + pw * ph].reshape(ph, pw))
+            want.append(oracle.resize_plane(plane, 1, w, h, "lanczos").reshape(-1))
+            off += pw * ph
+        return np.concatenate(want)
+    wants = [planar_want(f) for f in frames]
+    for i, d in enumerate(dsts):
+        out = np.zeros(d.HostSize, np.uint8)
+        assert vali.PySurfaceDownloader(gpu).Run(d, out)[0]
+        assert np.array_equal(out.view(dt), np.asarray(wants[i % 2]).reshape(-1).view(dt))
+    one = vali.Surface.Make(vali.PixelFormat[df], w, h, gpu)
+    assert ud.Run(srcs[0], one) == (True, vali.TaskExecInfo.SUCCESS)
+    out = np.zeros(one.HostSize, np.uint8)
+    assert vali.PySurfaceDownloader(gpu).Run(one, out)[0]
+    assert np.array_equal(out.view(dt), np.asarray(wants[0]).reshape(-1).view(dt))

@@ -458,10 +458,16 @@ static int resize_jobs_pair(int src_fmt, int dst_fmt, ResizeJob* j, int* elem) {
   return n;
 }
 
+// `subset`: a.job[0 .. a.njobs) is a subset of the surface's planes chosen by the caller (below), not to be rebuilt
 static int launch_resize(ResizeArgs& a, int fmt, int src_w, int src_h, int dst_w, int dst_h, int n, int interp,
-                         hipStream_t stream, int src_fmt = -1) {
+                         hipStream_t stream, int src_fmt = -1, bool subset = false) {
   int elem = 1;
-  a.njobs = resize_jobs_pair(src_fmt < 0 ? fmt : src_fmt, fmt, a.job, &elem);
+  if (subset) {
+    ResizeJob all[3];
+    resize_jobs_pair(src_fmt < 0 ? fmt : src_fmt, fmt, all, &elem);
+  } else {
+    a.njobs = resize_jobs_pair(src_fmt < 0 ? fmt : src_fmt, fmt, a.job, &elem);
+  }
   if (!a.njobs)
     return fail(VALI_ERR_UNSUPPORTED, "resize: unsupported pixel format %d", fmt);
   u32 total = 0;
@@ -558,15 +564,25 @@ static int launch_resize(ResizeArgs& a, int fmt, int src_w, int src_h, int dst_w
     // oracle/vali_oracle.c resize_plane_taps); a surface whose planes differ (YUV420 -> YUV444 through UDPlanar: luma
     // shrinks, chroma grows) takes one launch per order
     const int taps = interp == VALI_INTERP_LANCZOS ? 6 : 4;
-    ResizeArgs cols = a, rows = a;
-    cols.njobs = rows.njobs = 0;
+    // ... and, plane by plane (UDPlanar at unchanged size: luma 1:1, chroma 1:2): planes at an integer ratio are the point
+    // sample whatever the others need; one-channel planes exactly doubled both ways have their own kernel (resize_up2.hip)
+    ResizeArgs pts = a, up2 = a, cols = a, rows = a;
+    pts.njobs = up2.njobs = cols.njobs = rows.njobs = 0;
+    const bool special = point_on && !gather_only && elem != 4;
     for (int k = 0; k < a.njobs; ++k) {
-      const bool shrinks = (src_h >> a.job[k].ssub_y) >= (dst_h >> a.job[k].sub_y);
-      ResizeArgs& t = shrinks ? cols : rows;
+      const int sw = src_w >> a.job[k].ssub_x, sh = src_h >> a.job[k].ssub_y;
+      const int dw = dst_w >> a.job[k].sub_x, dh = dst_h >> a.job[k].sub_y;
+      const bool integer = special && sw % dw == 0 && sh % dh == 0 && sw < (1 << 23) && sh < (1 << 23);
+      const bool doubled = special && a.job[k].channels == 1 && dw == 2 * sw && dh == 2 * sh && sw % 4 == 0;
+      ResizeArgs& t = integer ? pts : doubled ? up2 : sh >= dh ? cols : rows;
       t.job[t.njobs++] = a.job[k];
     }
     int rc = VALI_OK;
-    if (cols.njobs)
+    if (pts.njobs) // (never all of them: integer_scale would have been true)
+      rc = launch_resize(pts, fmt, src_w, src_h, dst_w, dst_h, n, interp, stream, src_fmt, true);
+    if (rc == VALI_OK && up2.njobs)
+      rc = launch_resize_up2(up2, elem, taps, src_w, src_h, n, stream);
+    if (rc == VALI_OK && cols.njobs)
       rc = launch_resize_cols(cols, elem, taps, src_w, src_h, dst_w, dst_h, n, stream);
     if (rc == VALI_OK && rows.njobs)
       rc = launch_resize_taps(rows, elem, taps, src_w, src_h, dst_w, dst_h, n, stream);

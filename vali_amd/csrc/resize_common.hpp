@@ -21,7 +21,7 @@ struct ResizeArgs {
   int lds_per_wave; // stage_bytes + ring bytes
   // columns-first taps kernel (resize_cols.hip)
   int cols_n;       // dst elements per tile along x (multiple of 4, <= 256)
-  int cols_rps;     // dst rows per slot of a wave (1, 2, 4, 8): a wave owns slots x cols_rps rows
+  int cols_rps;     // dst rows per slot of a wave (1, 2, 4, 8): a wave owns slots x cols_rps rows; resize_up2.hip: source rows per wave
 };
 
 // Lanczos-3 (taps = 6) / bicubic (taps = 4) over the plane jobs of `a` (job[].comp / sub / channels filled in, planes
@@ -33,5 +33,9 @@ int launch_resize_taps(const ResizeArgs& a, int elem, int taps, int src_w, int s
 // plane takes which order is part of the specification (oracle/vali_oracle.c resize_plane_taps): src_h >= dst_h.
 int launch_resize_cols(const ResizeArgs& a, int elem, int taps, int src_w, int src_h, int dst_w, int dst_h, int n,
                        hipStream_t stream);
+
+// The same filters for jobs whose one-channel planes are exactly doubled in both directions (resize_up2.hip): source width a
+// multiple of 4, 8 / 16-bit elements.
+int launch_resize_up2(const ResizeArgs& a, int elem, int taps, int src_w, int src_h, int n, hipStream_t stream);
 
 } // namespace vali

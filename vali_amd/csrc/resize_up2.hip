@@ -1,0 +1,231 @@
+// Lanczos-3 / bicubic of one-channel planes that are exactly DOUBLED in both directions (dst_w = 2 src_w, dst_h = 2 src_h).
+//
+// This is what the reference's UDPlanar does to the chroma planes of every 4:2:0 -> 4:4:4 surface of unchanged size
+// (src/TC/src/UDSurface.cpp:33-93: nppiResize with NPPI_INTER_LANCZOS per plane; YUV420 -> YUV444 and the 10-bit pair), and
+// what PySurfaceResizer does to planar surfaces at 2x.  The general rows-first kernel (resize_taps.hip) ran it at 0.2 of the
+// HBM roofline: per-lane tap weights, an LDS gather per source row, an LDS ring for the vertical pass.  At exactly 1:2 none of
+// that is needed (specification: oracle/vali_oracle.c resize_plane_taps, the src_h < dst_h branch -- rows first):
+//
+//   x * 0.5 is exact: an even dst column 2 j sits ON source pixel j -- its weights are {0,0,1,0,0,0} ({-0,1,0,-0} for the
+//   cubic) and the specification's chains reduce to that pixel bit for bit (0 * t = +0 for t >= 0, fma(1, t, 0) = t,
+//   fma(0, u, t) = t) -- and an odd column 2 j + 1 sits at j + 1/2: ONE weight set W = w(1/2) for every odd column of the
+//   plane, on pixels j - 2 .. j + 3.  Rows likewise: dst row 2 r is the row-filtered source row r, dst row 2 r + 1 the chain
+//   v = W0 h(r-2) ; v = fma(Wk, h(r-2+k), v).
+//
+// So: a lane owns 4 adjacent source pixels (one 4- / 8-byte load per row, 6 rows in flight), gets the 2 + 3 pixels around them
+// from its neighbours by DPP (lanes 0 and 63 of a wave only supply those), filters its 4 odd columns with WAVE-UNIFORM weights
+// in registers (e over the even taps, o over the odd ones, e + o: the specification's order), and has the row-filtered row h:
+// 8 dst columns.  Down the columns every source row is scattered into TAPS accumulator slots (dst row 2 r' + 1 lives in slot
+// r' mod TAPS); with the walk unrolled TAPS times, which weight a slot takes on which trip is STATIC: no tap fetch, no
+// control flow, `acc = W0 * h` starts a slot (nothing to clear) and the slot that took W(TAPS-1) is complete.  Per source
+// row a wave stores two dst rows of 496 elements; rows outside the plane are their clamped neighbours (the walk simply visits
+// the clamped row again).  8 / 16-bit planes whose width is a multiple of 4; everything else keeps the general kernel.
+#include "resize_common.hpp"
+#include "resize_weights.hpp"
+
+namespace vali {
+
+constexpr int kUp2Px = 4;                       // source pixels per lane
+constexpr int kUp2Span = 62 * kUp2Px;           // source pixels of a wave's row: lanes 1 .. 62
+
+__device__ __forceinline__ float up2_shr1(float v) { // lane l gets lane l - 1's value
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float up2_shl1(float v) { // lane l gets lane l + 1's value
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+template <typename T, int TAPS>
+__global__ void __launch_bounds__(kBlock) k_resize_up2(const ResizeArgs a) {
+  constexpr int EB = (int)sizeof(T);
+  constexpr int kBefore = LzTap<TAPS>::kBefore, kAfter = TAPS - 1 - kBefore;
+  constexpr int ND = EB;                                        // dwords of a lane's 4 pixels
+  ResizeJob job;
+  u32 tx, ty, frame;
+  if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
+    return;
+  const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int rpw = a.cols_rps;                                   // source rows per wave
+  const int r_first = (int)(ty * kWavesPerBlock + wave) * rpw;  // wave-uniform
+  if (r_first >= v.sh)
+    return;
+  const int r_last = min(r_first + rpw, v.sh) - 1;
+  const int sw = v.sw;                                          // sw % 4 == 0, sw >= 4 (host)
+  const int j0 = (int)tx * kUp2Span + kUp2Px * (lane - 1);      // this lane's source pixels j0 .. j0 + 3
+  const bool outs = lane >= 1 && lane <= 62 && j0 < sw;
+  const bool left_edge = j0 == 0, right_edge = j0 + kUp2Px == sw; // its neighbour is outside the plane: replicate
+  const u32 lane_off = (u32)(min(max(j0, 0), sw - kUp2Px) * EB);
+
+  // the one weight set of the odd columns and rows: a = 1/2 exactly
+  LzTap<TAPS> odd;
+  if constexpr (TAPS == 6)
+    lanczos3_weights(0.5f, odd.w);
+  else
+    cubic_weights(0.5f, odd.w);
+  float W[TAPS];
+#pragma unroll
+  for (int k = 0; k < TAPS; ++k)
+    W[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, odd.w[k])));
+
+  const int q_begin = r_first - kBefore;                        // the walk visits rows q_begin .. r_last + kAfter, clamped
+  const int steps = r_last + kAfter - q_begin + 1;
+  uint8_t* const out0 = v.dp + (size_t)(2 * max(j0, 0)) * EB;
+  const bool plain_store = EB == 1 && ((((uintptr_t)v.dp) | (uintptr_t)v.dpitch) & 7u) == 0; // wave-uniform
+
+  auto row_ptr = [&](int q) { // q may run past the walk (the prefetch): clamped to the plane
+    const int rv = min(max(q_begin + q, 0), v.sh - 1);
+    return v.sp + (u32)(rv * v.spitch) + lane_off;
+  };
+  auto issue = [&](int q, u32 (&d)[ND]) {
+    if constexpr (ND == 1) {
+      d[0] = gload_u<u32>(row_ptr(q));
+    } else {
+      const v2u32 w = gload_u<v2u32>(row_ptr(q));
+      d[0] = w.x; d[1] = w.y;
+    }
+  };
+  auto store8 = [&](int dst_row, const v2f32 (&h)[4]) {
+    if (!outs)
+      return;
+    uint8_t* const o = out0 + (u32)(dst_row * v.dpitch);
+    if (plain_store) {
+      u32 q0 = __builtin_amdgcn_cvt_pk_u8_f32(h[0].x, 0u, 0u), q1 = __builtin_amdgcn_cvt_pk_u8_f32(h[2].x, 0u, 0u);
+      q0 = __builtin_amdgcn_cvt_pk_u8_f32(h[0].y, 1u, q0); q1 = __builtin_amdgcn_cvt_pk_u8_f32(h[2].y, 1u, q1);
+      q0 = __builtin_amdgcn_cvt_pk_u8_f32(h[1].x, 2u, q0); q1 = __builtin_amdgcn_cvt_pk_u8_f32(h[3].x, 2u, q1);
+      q0 = __builtin_amdgcn_cvt_pk_u8_f32(h[1].y, 3u, q0); q1 = __builtin_amdgcn_cvt_pk_u8_f32(h[3].y, 3u, q1);
+      const v2u32 q = {q0, q1};
+      gstore_nt<v2u32>(o, q);
+    } else {
+      const float res[4][2] = {{h[0].x, h[0].y}, {h[1].x, h[1].y}, {h[2].x, h[2].y}, {h[3].x, h[3].y}};
+      store_px4<T, 2>(o, res, 0xfu);
+    }
+  };
+
+  v2f32 acc[TAPS][4];
+#pragma unroll
+  for (int s = 0; s < TAPS; ++s)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      acc[s][i] = (v2f32){0.0f, 0.0f};
+  u32 pf[TAPS][ND];
+#pragma unroll
+  for (int d = 0; d < TAPS; ++d) {
+    issue(d, pf[d]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll 1
+  for (int q0 = 0; q0 < steps; q0 += TAPS) {
+#pragma unroll
+    for (int d = 0; d < TAPS; ++d) {
+      const int q = q0 + d;
+      // ---- the source row: pixels j0 - 2 .. j0 + 6 as floats ----
+      float c[9];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (EB == 1)
+          c[2 + i] = (float)((pf[d][0] >> (8 * i)) & 0xffu);
+        else
+          c[2 + i] = (float)((pf[d][i / 2] >> (16 * (i % 2))) & 0xffffu);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        asm volatile("" : "+v"(c[2 + i])); // (pins the conversions in front of the load that takes their registers)
+      __builtin_amdgcn_sched_barrier(0);
+      issue(q + TAPS, pf[d]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q >= steps) // the last trip only
+        continue;
+      {
+        const float p0 = up2_shr1(c[4]), p1 = up2_shr1(c[5]);
+        const float n0 = up2_shl1(c[2]), n1 = up2_shl1(c[3]), n2 = up2_shl1(c[4]);
+        c[0] = left_edge ? c[2] : p0;
+        c[1] = left_edge ? c[2] : p1;
+        c[6] = right_edge ? c[5] : n0;
+        c[7] = right_edge ? c[5] : n1;
+        c[8] = right_edge ? c[5] : n2;
+      }
+      // ---- along the row: even columns are the pixels, odd columns the taps on c[i + 2 - kBefore ..] ----
+      v2f32 h[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int b = i + 2 - kBefore;
+        float he = W[0] * c[b], ho = W[1] * c[b + 1];
+#pragma unroll
+        for (int k = 2; k < TAPS; k += 2) {
+          he = __builtin_fmaf(W[k], c[b + k], he);
+          ho = __builtin_fmaf(W[k + 1], c[b + k + 1], ho);
+        }
+        h[i] = (v2f32){c[2 + i], he + ho};
+      }
+      // ---- down the columns: slot s takes tap (d - s) mod TAPS of this row ----
+#pragma unroll
+      for (int s = 0; s < TAPS; ++s) {
+        const int k = (d - s + TAPS) % TAPS;
+        const v2f32 wv = (v2f32){W[k], W[k]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[s][i] = k == 0 ? wv * h[i] : __builtin_elementwise_fma(wv, h[i], acc[s][i]);
+      }
+      const int rv = q_begin + q;                               // this (virtual) source row
+      if (rv >= r_first && rv <= r_last)                        // dst row 2 rv: the row-filtered row itself
+        store8(2 * rv, h);
+      const int ro = rv - kAfter;                               // the odd row whose last tap this was
+      if (ro >= r_first && ro <= r_last)
+        store8(2 * ro + 1, acc[(d + 1) % TAPS]);
+    }
+  }
+}
+
+// Every job of `base`: one channel, dst = 2 x src in both directions, source width a multiple of 4.
+int launch_resize_up2(const ResizeArgs& base, int elem, int taps, int src_w, int src_h, int n, hipStream_t stream) {
+  ResizeArgs a = base;
+  auto count = [&](int rpw, bool assign) {
+    u32 total = 0;
+    for (int k = 0; k < a.njobs; ++k) {
+      const int sw = src_w >> a.job[k].ssub_x, sh = src_h >> a.job[k].ssub_y;
+      const u32 tiles_x = (u32)(sw + kUp2Span - 1) / (u32)kUp2Span;
+      if (assign) {
+        a.job[k].first_tile = total;
+        a.job[k].tiles_x = tiles_x;
+      }
+      total += tiles_x * (u32)((sh + kWavesPerBlock * rpw - 1) / (kWavesPerBlock * rpw));
+    }
+    return total;
+  };
+  // Source rows per wave.  TAPS - 1 rows of every wave are its neighbours' (walked, not stored): tall waves -- but a launch
+  // of few, long workgroups runs in ROUNDS (256 CUs x the kernel's workgroups per CU), and 1.2 rounds cost 2: 64 frames of
+  // 1080p luma in 64-row waves are 2176 workgroups on 1792 slots.  Cheapest (rounds x rows walked per wave) wins; a single
+  // frame ends up in the shortest waves that still fit one round.
+  const int occ = taps == 6 ? (elem == 1 ? 7 : 5) : 8;        // workgroups per CU (registers: see the resource test)
+  int rpw = 64;
+  const int forced = tuning(VALI_TUNE_RESIZE_NO_SEPARABLE); // 1 / 2 / 3: 8 / 2 / 64 rows per wave
+  if (forced == 1) rpw = 8;
+  else if (forced == 2) rpw = 2;
+  else if (forced != 3) {
+    unsigned long long best = ~0ull;
+    for (int r = 96; r >= 2; r -= (r > 16 ? 4 : 2)) {
+      const unsigned long long wgs = (unsigned long long)count(r, false) * (unsigned)n;
+      const unsigned long long cost = ((wgs + 256ull * occ - 1) / (256ull * occ)) * (unsigned)(r + taps - 1);
+      if (cost < best) {
+        best = cost;
+        rpw = r;
+      }
+    }
+  }
+  a.map = make_tile_map_linear(count(rpw, true), (u32)n);
+  a.cols_rps = rpw;
+  const dim3 grid = tile_grid(a.map);
+  if (elem == 1) {
+    if (taps == 6) hipLaunchKernelGGL((k_resize_up2<uint8_t, 6>), grid, dim3(kBlock), 0, stream, a);
+    else hipLaunchKernelGGL((k_resize_up2<uint8_t, 4>), grid, dim3(kBlock), 0, stream, a);
+  } else {
+    if (taps == 6) hipLaunchKernelGGL((k_resize_up2<uint16_t, 6>), grid, dim3(kBlock), 0, stream, a);
+    else hipLaunchKernelGGL((k_resize_up2<uint16_t, 4>), grid, dim3(kBlock), 0, stream, a);
+  }
+  VALI_LAUNCH_CHECK();
+  return VALI_OK;
+}
+
+} // namespace vali
