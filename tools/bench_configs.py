@@ -280,6 +280,31 @@ def udgen(n=64):
             "bytes_note": "whole NV12 source + RGB destination", "results": out}
 
 
+def udplanar(n=64):
+    """PySurfaceUD on planar sources (the reference's UDPlanar, UDSurface.cpp:33-93: every plane through NPP Lanczos to the
+    size of the matching dst plane) at unchanged size -- YUV420 -> YUV444: luma 1:1 (point form = a copy), chroma exactly
+    doubled (k_resize_up2) -- and the 10-bit pair of the reference's own golden."""
+    out = []
+    ud = vali.PySurfaceUD(DEV)
+    for (sf, df, w, h, eb) in ((vali.YUV420, vali.YUV444, 1920, 1080, 1), (vali.YUV420_10bit, vali.YUV444_10bit, 1920, 1080, 2)):
+        b = (w * h * 3 // 2 + w * h * 3) * eb
+        k = sets_needed(b * n)
+
+        def make():
+            srcs = [vali.Surface.Make(sf, w, h, DEV) for _ in range(n)]
+            dsts = [vali.Surface.Make(df, w, h, DEV) for _ in range(n)]
+            fill(srcs)
+            return srcs, dsts, ud.PrepareBatch(srcs, dsts)
+        sets = make_sets(k, make)
+        ms, _ = timed(ud.Stream, [lambda q=q: ud.RunBatchAsync(q) for _, _, q in sets], 30)
+        out.append({"formats": f"{sf.name}->{df.name}", "geometry": f"{w}x{h}->{w}x{h}", "kernel": "k_resize_point (Y) + k_resize_up2<6> (U, V)",
+                    "us_per_frame": round(ms * 1e3 / n, 3), "bytes_moved_per_frame": b,
+                    "roofline": roofline(f"udplanar_{eb * 8}bit", b, n, ms, k)})
+        del sets
+    return {"config": f"udplanar PySurfaceUD YUV420 -> YUV444 1080p at unchanged size (Lanczos like UDPlanar), batch={n}, one launch per plane class",
+            "bytes_note": "whole 4:2:0 source + 4:4:4 destination", "results": out}
+
+
 def cfg3_lanczos(n=64):
     """cfg3 geometries with the reference's own filter (Lanczos-3) -- exact 3x and a non-integer factor"""
     out = []
@@ -353,6 +378,6 @@ def ud_scales(n=32):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["hl1080", "cfg2", "cfg3", "interp", "cfg4", "udgen"]
+    which = sys.argv[1:] or ["hl1080", "cfg2", "cfg3", "interp", "cfg4", "udgen", "udplanar"]
     for name in which:
         print(json.dumps(globals()[name]()), flush=True)

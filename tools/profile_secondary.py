@@ -36,6 +36,10 @@ KEYS = {
     "cfg4_fused": ("cfg4", "k_ud_half_t<", 64),
     "udgen_1280x720": ("udgen", "k_ud_32<", 64),     # 1080p -> 720p: exactly 3:2
     "udgen_640x384": ("udgen", "k_ud_nv12<", 64),    # the any-ratio kernel
+    "udplanar_up2": ("udplanar", "k_resize_up2<unsigned char", 64),   # YUV420 -> YUV444 1080p: the chroma planes ...
+    "udplanar_luma": ("udplanar", "k_resize_point<unsigned char", 64),  # ... and the luma copy (summed into udplanar_8bit below)
+    "udplanar_up2_16": ("udplanar", "k_resize_up2<unsigned short", 64),
+    "udplanar_luma_16": ("udplanar", "k_resize_point<unsigned short", 64),
 }
 
 
@@ -88,6 +92,11 @@ def main():
         a, b = result["cfg4_ud"], result["cfg4_rot"]
         result["cfg4_chain"] = {"kernel": "k_ud_half + k_rotate_tile", "frames": 64,
                                 "hbm_bytes_per_launch": a["hbm_bytes_per_launch"] + b["hbm_bytes_per_launch"], "source": a["source"]}
+    for bits, (x, y) in (("8bit", ("udplanar_up2", "udplanar_luma")), ("16bit", ("udplanar_up2_16", "udplanar_luma_16"))):
+        if x in result and y in result:
+            result[f"udplanar_{bits}"] = {"kernel": "k_resize_point + k_resize_up2", "frames": 64,
+                                          "hbm_bytes_per_launch": result[x]["hbm_bytes_per_launch"] + result[y]["hbm_bytes_per_launch"],
+                                          "source": result[x]["source"]}
     (ROOT / "gpurun_out" / f"{TAG}_secondary_traffic.json").write_text(json.dumps(result, indent=1) + "\n")
     # the kernel-stats table of every config's trace run, as rocprofv3 wrote it: frac can be recomputed from these alone
     import shutil
