@@ -36,7 +36,7 @@ def test_bench_single_gpu_contract(gpu):
     assert "workload" in j["config"] and "model" not in j["config"]
     assert j["verification"] == {"frames_verified_on_gpu": 16, "frames_mismatching": 0,
                                  "checksum_of_checksums": j["verification"]["checksum_of_checksums"]}
-    assert [c["config"][:4] for c in j["secondary"]] == ["NV12", "cfg2", "cfg3", "inte", "cfg4", "udge"]
+    assert [c["config"][:4] for c in j["secondary"]] == ["NV12", "cfg2", "cfg3", "inte", "cfg4", "udge", "udpl"]
     assert 0.3 < j["secondary"][0]["roofline"]["frac"] < 1.0
 
     def fracs(o):      # every roofline entry anywhere in the line: a fraction of the HBM peak, never above it

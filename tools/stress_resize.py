@@ -22,6 +22,7 @@ while time.time() - t0 < budget:
     elif kind == 1: sw, sh = rng.integers(300, 2600), rng.integers(2, 120); dw, dh = rng.integers(2, 2600), rng.integers(2, 200)
     elif kind == 2: sw, sh = rng.integers(2, 64), rng.integers(2, 64); dw, dh = rng.integers(200, 1800), rng.integers(50, 300)      # big upscale
     elif kind == 3: sw, sh = rng.integers(1500, 2600), rng.integers(100, 300); dw, dh = rng.integers(2, 120), rng.integers(2, 60)   # big downscale (gather)
+    elif kind == 4: sw, sh = 4 * int(rng.integers(1, 500)), int(rng.integers(1, 300)); dw, dh = 2 * sw, 2 * sh                     # doubled both ways: resize_up2 for one-channel planes
     elif kind == 5: dw, dh = rng.integers(4, 1300), rng.integers(2, 400); sw = 2 * dw; sh = int(dh * rng.uniform(1.0, 4.5)) + 1        # 2:1 along x, shrinking rows: columns-first x2 form
     elif kind == 7: dw, dh = 16 * int(rng.integers(1, 110)), rng.integers(2, 400); sw = dw * 3 // 2; sh = int(dh * rng.uniform(1.0, 4.5)) + 1   # 3:2 along x, shrinking rows: the uniform-weight form
     elif kind == 6: sw, sh = rng.integers(8, 2600), rng.integers(100, 900); dw = int(sw * rng.uniform(0.3, 1.6)) or 2; dh = int(sh / rng.uniform(1.0, 7.0)) or 2  # every slot count of the columns-first form
