@@ -933,6 +933,7 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
   if (force == 1) rps = rps_max < 2 ? rps_max : 2;
   else if (force == 2) rps = 1;
   else if (force == 3) rps = rps_max;
+  else if (force >= 11 && force <= 18) rps = force - 10 < rps_max ? force - 10 : rps_max; // (measurements: rows per slot = value - 10)
   else
     // (2048 workgroups = 8 waves per SIMD: with fewer the launch's last round leaves SIMDs idle -- 64 frames of 1080p -> 720p
     // were 6912 waves of 30 rows, 1.4 rounds)
