@@ -297,7 +297,7 @@ def udplanar(n=64):
             return srcs, dsts, ud.PrepareBatch(srcs, dsts)
         sets = make_sets(k, make)
         ms, _ = timed(ud.Stream, [lambda q=q: ud.RunBatchAsync(q) for _, _, q in sets], 30)
-        out.append({"formats": f"{sf.name}->{df.name}", "geometry": f"{w}x{h}->{w}x{h}", "kernel": "k_resize_point (Y) + k_resize_up2<6> (U, V)",
+        out.append({"formats": f"{sf.name}->{df.name}", "geometry": f"{w}x{h}->{w}x{h}", "kernel": "k_resize<T,1,point> (Y: a copy) + k_resize_up2<T,6> (U, V)",
                     "us_per_frame": round(ms * 1e3 / n, 3), "bytes_moved_per_frame": b,
                     "roofline": roofline(f"udplanar_{eb * 8}bit", b, n, ms, k)})
         del sets

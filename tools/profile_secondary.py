@@ -37,9 +37,9 @@ KEYS = {
     "udgen_1280x720": ("udgen", "k_ud_32<", 64),     # 1080p -> 720p: exactly 3:2
     "udgen_640x384": ("udgen", "k_ud_nv12<", 64),    # the any-ratio kernel
     "udplanar_up2": ("udplanar", "k_resize_up2<unsigned char", 64),   # YUV420 -> YUV444 1080p: the chroma planes ...
-    "udplanar_luma": ("udplanar", "k_resize_point<unsigned char", 64),  # ... and the luma copy (summed into udplanar_8bit below)
+    "udplanar_luma": ("udplanar", "k_resize<unsigned char, 1, true", 64),  # ... and the luma copy (summed into udplanar_8bit below)
     "udplanar_up2_16": ("udplanar", "k_resize_up2<unsigned short", 64),
-    "udplanar_luma_16": ("udplanar", "k_resize_point<unsigned short", 64),
+    "udplanar_luma_16": ("udplanar", "k_resize<unsigned short, 1, true", 64),
 }
 
 

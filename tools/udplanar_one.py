@@ -11,8 +11,13 @@ hbd = len(sys.argv) > 5 and sys.argv[5] == "10"
 sf, df = (vali.YUV420_10bit, vali.YUV444_10bit) if hbd else (vali.YUV420, vali.YUV444)
 n = 64
 ud = vali.PySurfaceUD(DEV)
-srcs = [vali.Surface.Make(sf, sw, sh, DEV) for _ in range(n)]; dsts = [vali.Surface.Make(df, dw, dh, DEV) for _ in range(n)]
-fill(srcs); b = ud.PrepareBatch(srcs, dsts)
-ms, _ = timed(ud.Stream, lambda: ud.RunBatchAsync(b), 5, 1)
-bytes_ = srcs[0].HostSize + dsts[0].HostSize
+from bench_configs import sets_needed, make_sets
+def make():
+    srcs = [vali.Surface.Make(sf, sw, sh, DEV) for _ in range(n)]; dsts = [vali.Surface.Make(df, dw, dh, DEV) for _ in range(n)]
+    fill(srcs)
+    return srcs, dsts, ud.PrepareBatch(srcs, dsts)
+probe = vali.Surface.Make(sf, sw, sh, DEV).HostSize + vali.Surface.Make(df, dw, dh, DEV).HostSize
+sets = make_sets(sets_needed(probe * n), make)   # >= 1.5 GiB of distinct surfaces per timed loop
+ms, _ = timed(ud.Stream, [lambda q=q: ud.RunBatchAsync(q) for _, _, q in sets], 12, 1)
+bytes_ = probe
 print('us/frame', round(ms * 1e3 / n, 3), 'TB/s', round(bytes_ / (ms * 1e-3 / n) / 1e12, 3))

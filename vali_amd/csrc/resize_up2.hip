@@ -194,18 +194,21 @@ int launch_resize_up2(const ResizeArgs& base, int elem, int taps, int src_w, int
     }
     return total;
   };
-  // Source rows per wave.  TAPS - 1 rows of every wave are its neighbours' (walked, not stored): tall waves -- but a launch
-  // of few, long workgroups runs in ROUNDS (256 CUs x the kernel's workgroups per CU), and 1.2 rounds cost 2: 64 frames of
-  // 1080p luma in 64-row waves are 2176 workgroups on 1792 slots.  Cheapest (rounds x rows walked per wave) wins; a single
-  // frame ends up in the shortest waves that still fit one round.
+  // Source rows per wave.  TAPS - 1 rows of every wave are its neighbours' (walked, not stored), which argues for tall waves;
+  // measured, 16 rows are as good as it gets and taller ones lose on some boxes by a third (64 frames of 1080p luma in 92-row
+  // waves: 3.03 us on one box, 2.08 on the next; 16-row waves 2.9 / 2.2, 8-row waves 2.55 / 2.45) -- thousands of waves each
+  // streaming down its own column strip.  Below 16 the launch's ROUNDS decide (256 CUs x the kernel's workgroups per CU; 1.2
+  // rounds cost 2): the cheapest (rounds x rows walked per wave) wins, a single frame ends up in the shortest waves that
+  // still fit one round.
   const int occ = taps == 6 ? (elem == 1 ? 7 : 5) : 8;        // workgroups per CU (registers: see the resource test)
   int rpw = 64;
   const int forced = tuning(VALI_TUNE_RESIZE_NO_SEPARABLE); // 1 / 2 / 3: 8 / 2 / 64 rows per wave
   if (forced == 1) rpw = 8;
   else if (forced == 2) rpw = 2;
+  else if (forced >= 11 && forced <= 40) rpw = 2 * (forced - 10); // (measurements)
   else if (forced != 3) {
     unsigned long long best = ~0ull;
-    for (int r = 96; r >= 2; r -= (r > 16 ? 4 : 2)) {
+    for (int r = 16; r >= 2; r -= 2) {
       const unsigned long long wgs = (unsigned long long)count(r, false) * (unsigned)n;
       const unsigned long long cost = ((wgs + 256ull * occ - 1) / (256ull * occ)) * (unsigned)(r + taps - 1);
       if (cost < best) {
