@@ -377,3 +377,23 @@ def test_planar_ud_at_unchanged_size_takes_the_plane_forms(vali, gpu, oracle, pa
     out = np.zeros(one.HostSize, np.uint8)
     assert vali.PySurfaceDownloader(gpu).Run(one, out)[0]
     assert np.array_equal(out.view(dt), np.asarray(wants[0]).reshape(-1).view(dt))
+
+
+@pytest.mark.parametrize("fmt,size", [("NV12", (1920, 1080)), ("RGB", (333, 77)), ("Y", (17, 5)), ("P10", (130, 66)),
+                                      ("YUV420", (2050, 38)), ("RGB_PLANAR", (1366, 20)), ("YUV444_10bit", (1031, 9))])
+@pytest.mark.parametrize("interp", ["lanczos", "cubic", "linear"])
+def test_unchanged_size_is_a_copy(vali, gpu, oracle, fmt, size, interp):
+    """every filter at 1:1 is the identity for integer element types (the specification's chains reduce to the centre
+    tap): planes of unchanged size go through k_plane_copy -- rows that are not multiples of 16 bytes, several tiles wide"""
+    w, h = size
+    dt = DT.get(fmt, np.uint8)
+    n = vali.Surface.Make(vali.PixelFormat[fmt], w, h, gpu).HostSize // np.dtype(dt).itemsize
+    host = (np.random.default_rng(w + h).random(n) * (1023 if dt == np.uint16 else 255)).astype(dt)
+    if fmt == "P10":
+        host = (host.astype(np.uint16) << 6).astype(np.uint16)
+    mode = {"lanczos": vali.Interpolation.LANCZOS, "cubic": vali.Interpolation.CUBIC, "linear": vali.Interpolation.LINEAR}[interp]
+    got = roundtrip(vali, gpu, fmt, host, w, h, w, h, interp=mode)
+    assert np.array_equal(got, host)
+    assert np.array_equal(oracle.resize_surface(host, fmt, w, h, w, h, interp), host)   # (the specification agrees)
+    with vali.tuning.Override(RESIZE_POINT=0):            # the arithmetic forms
+        assert np.array_equal(roundtrip(vali, gpu, fmt, host, w, h, w, h, interp=mode), host)
