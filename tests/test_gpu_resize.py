@@ -321,21 +321,23 @@ def test_columns_first_batch_and_rows_per_wave(vali, gpu, oracle, rows_mode):
 # ---- one-channel planes exactly doubled both ways (vali_amd/csrc/resize_up2.hip) -------------------------------------
 # (source size): widths that are / are not multiples of 4 per plane (the second kind keeps the general kernel), one wave per
 # row and several, 1 .. 3 rows (every tap clamped), heights around the rows-per-wave forms
-UP2_SIZES = [(8, 2), (16, 6), (248, 20), (256, 64), (500, 37), (1000, 130), (960, 540), (36, 4), (1928, 70), (6, 10)]
+UP2_SIZES = [(8, 2), (16, 6), (248, 20), (256, 64), (500, 37), (1000, 130), (960, 540), (36, 4), (1928, 70), (6, 10), (244, 12), (492, 8)]
 
 
-@pytest.mark.parametrize("fmt", ["Y", "YUV420", "YUV444", "RGB_PLANAR", "YUV444_10bit", "NV12"])
+@pytest.mark.parametrize("fmt", ["Y", "YUV420", "YUV444", "RGB_PLANAR", "YUV444_10bit", "NV12", "P10"])
 @pytest.mark.parametrize("size", UP2_SIZES)
 @pytest.mark.parametrize("interp", ["lanczos", "cubic"])
 def test_doubled_planes_bit_exact(vali, gpu, oracle, fmt, size, interp):
     sw, sh = size
-    if fmt in ("YUV420", "NV12") and (sw | sh) & 1:
+    if fmt in ("YUV420", "NV12", "P10") and (sw | sh) & 1:
         pytest.skip("4:2:0 needs even sizes")
     dt = DT.get(fmt, np.uint8)
     n = vali.Surface.Make(vali.PixelFormat[fmt], sw, sh, gpu).HostSize // np.dtype(dt).itemsize
     rng = np.random.default_rng(sw * 13 + sh)
     host = (rng.random(n) * (1023 if dt == np.uint16 else 255)).astype(dt)
     host[:: max(1, n // 50)] = np.iinfo(dt).max if dt != np.uint16 else 1023   # saturation / overshoot next to dark pixels
+    if fmt == "P10":
+        host = (host.astype(np.uint16) << 6).astype(np.uint16)
     mode = vali.Interpolation.LANCZOS if interp == "lanczos" else vali.Interpolation.CUBIC
     want = oracle.resize_surface(host, fmt, sw, sh, 2 * sw, 2 * sh, interp)
     assert np.array_equal(roundtrip(vali, gpu, fmt, host, sw, sh, 2 * sw, 2 * sh, interp=mode), want)

@@ -632,7 +632,7 @@ static int launch_resize(ResizeArgs& a, int fmt, int src_w, int src_h, int dst_w
       const int sw = src_w >> a.job[k].ssub_x, sh = src_h >> a.job[k].ssub_y;
       const int dw = dst_w >> a.job[k].sub_x, dh = dst_h >> a.job[k].sub_y;
       const bool integer = special && sw % dw == 0 && sh % dh == 0 && sw < (1 << 23) && sh < (1 << 23);
-      const bool doubled = special && a.job[k].channels == 1 && dw == 2 * sw && dh == 2 * sh && sw % 4 == 0;
+      const bool doubled = special && a.job[k].channels <= 2 && dw == 2 * sw && dh == 2 * sh && sw % (4 / a.job[k].channels) == 0;
       ResizeArgs& t = integer && sw == dw && sh == dh ? cpy : integer ? pts : doubled ? up2 : sh >= dh ? cols : rows;
       t.job[t.njobs++] = a.job[k];
     }

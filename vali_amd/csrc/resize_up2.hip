@@ -1,4 +1,4 @@
-// Lanczos-3 / bicubic of one-channel planes that are exactly DOUBLED in both directions (dst_w = 2 src_w, dst_h = 2 src_h).
+// Lanczos-3 / bicubic of one- and two-channel planes that are exactly DOUBLED in both directions (dst_w = 2 src_w, dst_h = 2 src_h).
 //
 // This is what the reference's UDPlanar does to the chroma planes of every 4:2:0 -> 4:4:4 surface of unchanged size
 // (src/TC/src/UDSurface.cpp:33-93: nppiResize with NPPI_INTER_LANCZOS per plane; YUV420 -> YUV444 and the 10-bit pair), and
@@ -19,14 +19,15 @@
 // r' mod TAPS); with the walk unrolled TAPS times, which weight a slot takes on which trip is STATIC: no tap fetch, no
 // control flow, `acc = W0 * h` starts a slot (nothing to clear) and the slot that took W(TAPS-1) is complete.  Per source
 // row a wave stores two dst rows of 496 elements; rows outside the plane are their clamped neighbours (the walk simply visits
-// the clamped row again).  8 / 16-bit planes whose width is a multiple of 4; everything else keeps the general kernel.
+// the clamped row again).  8 / 16-bit planes whose width is a multiple of 4 (of 2 pixels for the UV plane of NV12 / P10, where a
+// lane owns 2 pixels); everything else keeps the general kernel.
 #include "resize_common.hpp"
 #include "resize_weights.hpp"
 
 namespace vali {
 
-constexpr int kUp2Px = 4;                       // source pixels per lane
-constexpr int kUp2Span = 62 * kUp2Px;           // source pixels of a wave's row: lanes 1 .. 62
+constexpr int kUp2El = 4;                       // source elements per lane: 4 pixels of one channel, 2 of two
+constexpr int up2_span(int channels) { return channels == 1 ? 62 * 4 : 61 * 2; } // source pixels of a wave's row
 
 __device__ __forceinline__ float up2_shr1(float v) { // lane l gets lane l - 1's value
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
@@ -35,28 +36,28 @@ __device__ __forceinline__ float up2_shl1(float v) { // lane l gets lane l + 1's
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
 
-template <typename T, int TAPS>
-__global__ void __launch_bounds__(kBlock) k_resize_up2(const ResizeArgs a) {
+// ES = interleaved channels of the plane: 1 (Y, U, V, the planes of RGB_PLANAR) or 2 (the UV plane of NV12 / P10: a lane then
+// owns 2 pixels = 4 elements, the three pixels after them are the next lane's two and the first of the lane after that)
+template <typename T, int TAPS, int ES>
+__device__ __forceinline__ void up2_tile(const PlaneView& v, u32 tx, u32 ty, int rpw) {
   constexpr int EB = (int)sizeof(T);
   constexpr int kBefore = LzTap<TAPS>::kBefore, kAfter = TAPS - 1 - kBefore;
-  constexpr int ND = EB;                                        // dwords of a lane's 4 pixels
-  ResizeJob job;
-  u32 tx, ty, frame;
-  if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
-    return;
-  const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
+  constexpr int ND = EB;                                        // dwords of a lane's 4 elements
+  constexpr int PXL = kUp2El / ES;                              // pixels per lane
+  constexpr int LAST = ES == 1 ? 62 : 61;                       // lanes 1 .. LAST produce output, the others supply halos
+  constexpr int NC = (PXL + 5) * ES;                            // elements of pixels j0 - 2 .. j0 + PXL + 2
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int rpw = a.cols_rps;                                   // source rows per wave
   const int r_first = (int)(ty * kWavesPerBlock + wave) * rpw;  // wave-uniform
   if (r_first >= v.sh)
     return;
   const int r_last = min(r_first + rpw, v.sh) - 1;
-  const int sw = v.sw;                                          // sw % 4 == 0, sw >= 4 (host)
-  const int j0 = (int)tx * kUp2Span + kUp2Px * (lane - 1);      // this lane's source pixels j0 .. j0 + 3
-  const bool outs = lane >= 1 && lane <= 62 && j0 < sw;
-  const bool left_edge = j0 == 0, right_edge = j0 + kUp2Px == sw; // its neighbour is outside the plane: replicate
-  const u32 lane_off = (u32)(min(max(j0, 0), sw - kUp2Px) * EB);
+  const int sw = v.sw;                                          // sw % PXL == 0, sw >= PXL (host)
+  const int j0 = (int)tx * (LAST * PXL) + PXL * (lane - 1);     // this lane's source pixels j0 .. j0 + PXL - 1
+  const bool outs = lane >= 1 && lane <= LAST && j0 < sw;
+  const bool left_edge = j0 == 0, right_edge = j0 + PXL == sw;  // its neighbour is outside the plane: replicate
+  const bool next_last = j0 + 2 * PXL == sw;                    // (ES = 2) the next lane's pixels are the row's last
+  const u32 lane_off = (u32)(min(max(j0, 0), sw - PXL) * ES * EB);
 
   // the one weight set of the odd columns and rows: a = 1/2 exactly
   LzTap<TAPS> odd;
@@ -71,7 +72,7 @@ __global__ void __launch_bounds__(kBlock) k_resize_up2(const ResizeArgs a) {
 
   const int q_begin = r_first - kBefore;                        // the walk visits rows q_begin .. r_last + kAfter, clamped
   const int steps = r_last + kAfter - q_begin + 1;
-  uint8_t* const out0 = v.dp + (size_t)(2 * max(j0, 0)) * EB;
+  uint8_t* const out0 = v.dp + (size_t)(2 * max(j0, 0)) * ES * EB;
   const bool plain_store = EB == 1 && ((((uintptr_t)v.dp) | (uintptr_t)v.dpitch) & 7u) == 0; // wave-uniform
 
   auto row_ptr = [&](int q) { // q may run past the walk (the prefetch): clamped to the plane
@@ -120,44 +121,72 @@ __global__ void __launch_bounds__(kBlock) k_resize_up2(const ResizeArgs a) {
 #pragma unroll
     for (int d = 0; d < TAPS; ++d) {
       const int q = q0 + d;
-      // ---- the source row: pixels j0 - 2 .. j0 + 6 as floats ----
-      float c[9];
+      // ---- the source row: the elements of pixels j0 - 2 .. j0 + PXL + 2 as floats; the lane's own start at c[2 ES] ----
+      float c[NC];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if constexpr (EB == 1)
-          c[2 + i] = (float)((pf[d][0] >> (8 * i)) & 0xffu);
+          c[2 * ES + i] = (float)((pf[d][0] >> (8 * i)) & 0xffu);
         else
-          c[2 + i] = (float)((pf[d][i / 2] >> (16 * (i % 2))) & 0xffffu);
+          c[2 * ES + i] = (float)((pf[d][i / 2] >> (16 * (i % 2))) & 0xffffu);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        asm volatile("" : "+v"(c[2 + i])); // (pins the conversions in front of the load that takes their registers)
+        asm volatile("" : "+v"(c[2 * ES + i])); // (pins the conversions in front of the load that takes their registers)
       __builtin_amdgcn_sched_barrier(0);
       issue(q + TAPS, pf[d]);
       __builtin_amdgcn_sched_barrier(0);
       if (q >= steps) // the last trip only
         continue;
-      {
-        const float p0 = up2_shr1(c[4]), p1 = up2_shr1(c[5]);
-        const float n0 = up2_shl1(c[2]), n1 = up2_shl1(c[3]), n2 = up2_shl1(c[4]);
-        c[0] = left_edge ? c[2] : p0;
-        c[1] = left_edge ? c[2] : p1;
-        c[6] = right_edge ? c[5] : n0;
-        c[7] = right_edge ? c[5] : n1;
-        c[8] = right_edge ? c[5] : n2;
+#pragma unroll
+      for (int t = 0; t < 2 * ES; ++t) {                        // the two pixels before: the previous lane's last two
+        const float p = up2_shr1(c[PXL * ES + t]);
+        c[t] = left_edge ? c[2 * ES + t % ES] : p;
       }
-      // ---- along the row: even columns are the pixels, odd columns the taps on c[i + 2 - kBefore ..] ----
-      v2f32 h[4];
+      if constexpr (ES == 1) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int b = i + 2 - kBefore;
-        float he = W[0] * c[b], ho = W[1] * c[b + 1];
-#pragma unroll
-        for (int k = 2; k < TAPS; k += 2) {
-          he = __builtin_fmaf(W[k], c[b + k], he);
-          ho = __builtin_fmaf(W[k + 1], c[b + k + 1], ho);
+        for (int t = 0; t < 3; ++t) {                           // the three after: the next lane's first three
+          const float nx = up2_shl1(c[2 + t]);
+          c[6 + t] = right_edge ? c[5] : nx;
         }
-        h[i] = (v2f32){c[2 + i], he + ho};
+      } else {
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+          const float n0 = up2_shl1(c[4 + ch]), n1 = up2_shl1(c[6 + ch]); // the next lane's two pixels ...
+          const float n2 = up2_shl1(n0);                                   // ... and the first of the lane after it
+          const float own_last = c[6 + ch];
+          c[8 + ch] = right_edge ? own_last : n0;
+          c[10 + ch] = right_edge ? own_last : n1;
+          c[12 + ch] = right_edge ? own_last : next_last ? n1 : n2;
+        }
+      }
+      // ---- along the row: even dst pixels are the source pixels, odd ones the taps on pixels i + 2 - kBefore .. ----
+      v2f32 h[4];
+      if constexpr (ES == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int b = i + 2 - kBefore;
+          float he = W[0] * c[b], ho = W[1] * c[b + 1];
+#pragma unroll
+          for (int k = 2; k < TAPS; k += 2) {
+            he = __builtin_fmaf(W[k], c[b + k], he);
+            ho = __builtin_fmaf(W[k + 1], c[b + k + 1], ho);
+          }
+          h[i] = (v2f32){c[2 + i], he + ho};
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int b = (i + 2 - kBefore) * 2;
+          v2f32 he = (v2f32){W[0], W[0]} * (v2f32){c[b], c[b + 1]}, ho = (v2f32){W[1], W[1]} * (v2f32){c[b + 2], c[b + 3]};
+#pragma unroll
+          for (int k = 2; k < TAPS; k += 2) {
+            he = __builtin_elementwise_fma((v2f32){W[k], W[k]}, (v2f32){c[b + 2 * k], c[b + 2 * k + 1]}, he);
+            ho = __builtin_elementwise_fma((v2f32){W[k + 1], W[k + 1]}, (v2f32){c[b + 2 * k + 2], c[b + 2 * k + 3]}, ho);
+          }
+          h[2 * i] = (v2f32){c[(2 + i) * 2], c[(2 + i) * 2 + 1]};
+          h[2 * i + 1] = he + ho;
+        }
       }
       // ---- down the columns: slot s takes tap (d - s) mod TAPS of this row ----
 #pragma unroll
@@ -178,14 +207,28 @@ __global__ void __launch_bounds__(kBlock) k_resize_up2(const ResizeArgs a) {
   }
 }
 
-// Every job of `base`: one channel, dst = 2 x src in both directions, source width a multiple of 4.
+// UV: the launch has two-channel planes (NV12 / P10); planar surfaces take the one-channel kernel (one register fewer: 7 waves)
+template <typename T, int TAPS, bool UV>
+__global__ void __launch_bounds__(kBlock) k_resize_up2(const ResizeArgs a) {
+  ResizeJob job;
+  u32 tx, ty, frame;
+  if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
+    return;
+  const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
+  if (UV && job.channels == 2)
+    up2_tile<T, TAPS, 2>(v, tx, ty, a.cols_rps);
+  else
+    up2_tile<T, TAPS, 1>(v, tx, ty, a.cols_rps);
+}
+
+// Every job of `base`: one or two channels, dst = 2 x src in both directions, source width a multiple of 4 / channels.
 int launch_resize_up2(const ResizeArgs& base, int elem, int taps, int src_w, int src_h, int n, hipStream_t stream) {
   ResizeArgs a = base;
   auto count = [&](int rpw, bool assign) {
     u32 total = 0;
     for (int k = 0; k < a.njobs; ++k) {
       const int sw = src_w >> a.job[k].ssub_x, sh = src_h >> a.job[k].ssub_y;
-      const u32 tiles_x = (u32)(sw + kUp2Span - 1) / (u32)kUp2Span;
+      const u32 tiles_x = (u32)(sw + up2_span(a.job[k].channels) - 1) / (u32)up2_span(a.job[k].channels);
       if (assign) {
         a.job[k].first_tile = total;
         a.job[k].tiles_x = tiles_x;
@@ -200,7 +243,10 @@ int launch_resize_up2(const ResizeArgs& base, int elem, int taps, int src_w, int
   // streaming down its own column strip.  Below 16 the launch's ROUNDS decide (256 CUs x the kernel's workgroups per CU; 1.2
   // rounds cost 2): the cheapest (rounds x rows walked per wave) wins, a single frame ends up in the shortest waves that
   // still fit one round.
-  const int occ = taps == 6 ? (elem == 1 ? 7 : 5) : 8;        // workgroups per CU (registers: see the resource test)
+  bool uv = false;
+  for (int k = 0; k < a.njobs; ++k)
+    uv = uv || a.job[k].channels == 2;
+  const int occ = taps == 6 ? (elem == 1 ? (uv ? 6 : 7) : 5) : 8; // workgroups per CU (registers: tests/test_kernel_resources.py)
   int rpw = 64;
   const int forced = tuning(VALI_TUNE_RESIZE_NO_SEPARABLE); // 1 / 2 / 3: 8 / 2 / 64 rows per wave
   if (forced == 1) rpw = 8;
@@ -220,13 +266,19 @@ int launch_resize_up2(const ResizeArgs& base, int elem, int taps, int src_w, int
   a.map = make_tile_map_linear(count(rpw, true), (u32)n);
   a.cols_rps = rpw;
   const dim3 grid = tile_grid(a.map);
+#define VALI_UP2(T, TAPS)                                                                                   \
+  do {                                                                                                      \
+    if (uv) hipLaunchKernelGGL((k_resize_up2<T, TAPS, true>), grid, dim3(kBlock), 0, stream, a);            \
+    else hipLaunchKernelGGL((k_resize_up2<T, TAPS, false>), grid, dim3(kBlock), 0, stream, a);              \
+  } while (0)
   if (elem == 1) {
-    if (taps == 6) hipLaunchKernelGGL((k_resize_up2<uint8_t, 6>), grid, dim3(kBlock), 0, stream, a);
-    else hipLaunchKernelGGL((k_resize_up2<uint8_t, 4>), grid, dim3(kBlock), 0, stream, a);
+    if (taps == 6) VALI_UP2(uint8_t, 6);
+    else VALI_UP2(uint8_t, 4);
   } else {
-    if (taps == 6) hipLaunchKernelGGL((k_resize_up2<uint16_t, 6>), grid, dim3(kBlock), 0, stream, a);
-    else hipLaunchKernelGGL((k_resize_up2<uint16_t, 4>), grid, dim3(kBlock), 0, stream, a);
+    if (taps == 6) VALI_UP2(uint16_t, 6);
+    else VALI_UP2(uint16_t, 4);
   }
+#undef VALI_UP2
   VALI_LAUNCH_CHECK();
   return VALI_OK;
 }
