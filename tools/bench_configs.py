@@ -282,7 +282,7 @@ def udgen(n=64):
 
 def udplanar(n=64):
     """PySurfaceUD on planar sources (the reference's UDPlanar, UDSurface.cpp:33-93: every plane through NPP Lanczos to the
-    size of the matching dst plane) at unchanged size -- YUV420 -> YUV444: luma 1:1 (point form = a copy), chroma exactly
+    size of the matching dst plane) at unchanged size -- YUV420 -> YUV444: luma 1:1 (k_plane_copy), chroma exactly
     doubled (k_resize_up2) -- and the 10-bit pair of the reference's own golden."""
     out = []
     ud = vali.PySurfaceUD(DEV)
@@ -297,7 +297,7 @@ def udplanar(n=64):
             return srcs, dsts, ud.PrepareBatch(srcs, dsts)
         sets = make_sets(k, make)
         ms, _ = timed(ud.Stream, [lambda q=q: ud.RunBatchAsync(q) for _, _, q in sets], 30)
-        out.append({"formats": f"{sf.name}->{df.name}", "geometry": f"{w}x{h}->{w}x{h}", "kernel": "k_resize<T,1,point> (Y: a copy) + k_resize_up2<T,6> (U, V)",
+        out.append({"formats": f"{sf.name}->{df.name}", "geometry": f"{w}x{h}->{w}x{h}", "kernel": "k_plane_copy (Y) + k_resize_up2<T,6> (U, V)",
                     "us_per_frame": round(ms * 1e3 / n, 3), "bytes_moved_per_frame": b,
                     "roofline": roofline(f"udplanar_{eb * 8}bit", b, n, ms, k)})
         del sets
