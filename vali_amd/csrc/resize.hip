@@ -369,7 +369,11 @@ __global__ void __launch_bounds__(kBlock) k_resize_pointk(const ResizeArgs a) {
   const int ky = v.sh / v.dh;
   const bool aligned = ((((uintptr_t)v.sp) | (uintptr_t)v.spitch | ((uintptr_t)v.dp) | (uintptr_t)v.dpitch) & 15u) == 0;
   const int y0 = ty * kPkRows + (threadIdx.x >> 4);
-  if (aligned) {
+  // The K source chunks of this lane all inside the ROW (not the pitch: a borrowed view may end where its last row ends):
+  // everything but a row's last lane.  That lane takes the byte path below -- ONE branch around the vector path; a guard
+  // per chunk put 238 predicated regions into this kernel, paid by every lane whether taken or not.
+  const bool inside = xb * K + 16 * K <= sbytes;
+  if (aligned && inside) {
     u32 w[2][4 * K];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -377,10 +381,7 @@ __global__ void __launch_bounds__(kBlock) k_resize_pointk(const ResizeArgs a) {
       const uint8_t* srow = v.sp + (u32)(y * ky * v.spitch) + (u32)(xb * K);
 #pragma unroll
       for (int i = 0; i < K; ++i) {
-        // a chunk cut by the end of the ROW (not of the pitch: a borrowed view may end where its last row ends) is
-        // fetched byte by byte; pieces past the row feed no dst byte that exists
-        const int valid = sbytes - (xb * K + 16 * i);
-        const uint4 q = valid >= 16 ? gload16(srow + 16 * i) : load_bytes16(srow + 16 * i, valid);
+        const uint4 q = gload16(srow + 16 * i);
         w[r][4 * i] = q.x; w[r][4 * i + 1] = q.y; w[r][4 * i + 2] = q.z; w[r][4 * i + 3] = q.w;
       }
     }
@@ -400,14 +401,23 @@ __global__ void __launch_bounds__(kBlock) k_resize_pointk(const ResizeArgs a) {
     }
     return;
   }
-  for (int r = 0; r < 2; ++r) { // foreign rows: byte by byte
+  for (int r = 0; r < 2; ++r) { // foreign rows and a row's last lane: byte by byte (16 loads in flight, then the stores)
     const int y = y0 + 16 * r;
     if (y >= v.dh)
       break;
     const uint8_t* srow = v.sp + (size_t)(y * ky) * v.spitch;
     uint8_t* drow = v.dp + (size_t)y * v.dpitch;
-    for (int b = xb; b < min(xb + 16, dbytes); ++b)
-      gstore<uint8_t>(drow + b, gload<uint8_t>(srow + (size_t)(b / pb) * K * pb + b % pb));
+    const int nb = min(16, dbytes - xb);
+    u32 t[16];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      const int bb = xb + min(b, nb - 1);
+      t[b] = gload<uint8_t>(srow + (size_t)(bb / pb) * K * pb + bb % pb);
+    }
+#pragma unroll
+    for (int b = 0; b < 16; ++b)
+      if (b < nb)
+        gstore<uint8_t>(drow + xb + b, (uint8_t)t[b]);
   }
 }
 
