@@ -399,3 +399,24 @@ def test_unchanged_size_is_a_copy(vali, gpu, oracle, fmt, size, interp):
     assert np.array_equal(oracle.resize_surface(host, fmt, w, h, w, h, interp), host)   # (the specification agrees)
     with vali.tuning.Override(RESIZE_POINT=0):            # the arithmetic forms
         assert np.array_equal(roundtrip(vali, gpu, fmt, host, w, h, w, h, interp=mode), host)
+
+
+# ---- exactly 3:2 both ways: the statically scheduled walk of resize_cols.hip (k_resize_cols_x32<..., SROWS>) --------------
+@pytest.mark.parametrize("fmt", ["NV12", "YUV420", "Y", "P10", "YUV444", "RGB_PLANAR"])
+@pytest.mark.parametrize("dst", [(16, 2), (16, 8), (32, 10), (496, 26), (1280, 720), (992, 100), (512, 258)])
+def test_three_to_two_both_ways_bit_exact(vali, gpu, oracle, fmt, dst):
+    dw, dh = dst
+    if fmt in ("NV12", "YUV420", "P10"):
+        dw, dh = 2 * dw, 2 * dh                         # so that the chroma planes are whole 8-element groups and row pairs too
+    sw, sh = dw * 3 // 2, dh * 3 // 2
+    dt = DT.get(fmt, np.uint8)
+    n = vali.Surface.Make(vali.PixelFormat[fmt], sw, sh, gpu).HostSize // np.dtype(dt).itemsize
+    rng = np.random.default_rng(dw * 3 + dh)
+    host = (rng.random(n) * (1023 if dt == np.uint16 else 255)).astype(dt)
+    host[:: max(1, n // 40)] = 1023 if dt == np.uint16 else 255
+    if fmt == "P10":
+        host = (host.astype(np.uint16) << 6).astype(np.uint16)
+    want = oracle.resize_surface(host, fmt, sw, sh, dw, dh, "lanczos")
+    for mode in (0, 1, 2, 3):                           # pairs per wave by launch size / 1 pair / the slot walk / 12 pairs
+        with vali.tuning.Override(RESIZE_NO_SEPARABLE=mode):
+            assert np.array_equal(roundtrip(vali, gpu, fmt, host, sw, sh, dw, dh, interp=vali.Interpolation.LANCZOS), want), mode

@@ -591,18 +591,29 @@ __device__ __forceinline__ float wave_shl1_f(float v) { // lane l gets lane l + 
 
 constexpr int kX32Out = 62 * 8; // dst elements of a wave's row
 
-template <typename T, int ES, int TAPS, int P>
+// SROWS: the plane is 3:2 down the rows as well (1080p -> 720p, 2160p -> 1440p: the whole surface).  Then the walk needs no
+// per-row weights either: dst row 2 m sits on source row 3 m (weights {0,0,1,0,0,0}: the column pass is that row, bit for
+// bit), dst row 2 m + 1 at 3 m + 1 1/2: the one weight set w(1/2) on rows 3 m - 1 .. 3 m + 4.  A source row s is tap
+// k = (s + 1) mod 3 of one odd row and tap k + 3 of the one before it: TWO accumulator slots, and with the walk unrolled
+// six times which slot takes which weight on which trip is static -- 12 packed FMAs per row instead of the general
+// walk's 24 (four slots at this ratio, a third of their weights zero) + 5 v_readlane.
+template <typename T, int ES, int TAPS, int P, bool SROWS>
 __device__ __forceinline__ void cols_tile_x32(const uint8_t* sp, int spitch, int sw, int sh, uint8_t* dp, int dpitch,
                                               int dw, int dh, u32 tx, u32 ty, int rps, float* strip) {
   constexpr int EB = (int)sizeof(T);
   static_assert(EB <= 2 && ES <= 2, "cols_tile_x32: 8 / 16-bit planes of 1 or 2 channels");
+  static_assert(!SROWS || TAPS == 6, "cols_tile_x32: the static rows are Lanczos-3's");
   constexpr int ND = 3 * EB;                                    // dwords of a lane's 12 source elements
   constexpr int D = EB == 1 ? 4 : 2;
   constexpr int kBefore = LzTap<TAPS>::kBefore;
   const int lane = threadIdx.x & 63;
   ColRows<P> r;
-  if (!cols_rows<TAPS, P, false>(sh, dh, spitch, ty, rps, strip, r))
-    return;
+  int y_first = 0;                                              // dst row of emit()'s row 0
+  if constexpr (!SROWS) {
+    if (!cols_rows<TAPS, P, false>(sh, dh, spitch, ty, rps, strip, r))
+      return;
+    y_first = r.y_first;
+  }
   const int dwe = dw * ES, row_el = sw * ES;                    // dwe % 8 == 0 (host), so row_el % 12 == 0
   const int e0 = (int)tx * kX32Out;                             // first dst element of the wave
   const int eo = e0 + 8 * (lane - 1);                           // this lane's 8 dst elements (lane 0 / 63: halo only)
@@ -690,7 +701,7 @@ __device__ __forceinline__ void cols_tile_x32(const uint8_t* sp, int spitch, int
         out[(2 * t + 1) * 2 + 1] = v.y;
       }
     }
-    uint8_t* const o8 = dp + (u32)((r.y_first + rr) * dpitch) + (size_t)eo * EB;
+    uint8_t* const o8 = dp + (u32)((y_first + rr) * dpitch) + (size_t)eo * EB;
     if (plain_store && EB == 1) {
       u32 q0 = __builtin_amdgcn_cvt_pk_u8_f32(out[0], 0u, 0u), q1 = __builtin_amdgcn_cvt_pk_u8_f32(out[4], 0u, 0u);
       q0 = __builtin_amdgcn_cvt_pk_u8_f32(out[1], 1u, q0); q1 = __builtin_amdgcn_cvt_pk_u8_f32(out[5], 1u, q1);
@@ -704,7 +715,73 @@ __device__ __forceinline__ void cols_tile_x32(const uint8_t* sp, int spitch, int
     }
   };
   (void)first; (void)beyond;
-  cols_walk<T, TAPS, P, ND, D, 6>(r, sp, lane_off, conv, emit);
+  if constexpr (!SROWS) {
+    cols_walk<T, TAPS, P, ND, D, 6>(r, sp, lane_off, conv, emit);
+  } else {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int m_first = (int)(ty * kWavesPerBlock + wave) * rps;  // rps: dst row PAIRS per wave here
+    const int pairs = dh >> 1;                                    // dh is even (host)
+    if (m_first >= pairs)
+      return;
+    const int m_last = min(m_first + rps, pairs) - 1;
+    const int s_begin = 3 * m_first - 1;                          // the walk visits rows s_begin .. 3 m_last + 4, clamped
+    const int steps = 3 * (m_last - m_first + 1) + 3;
+    constexpr int DS = EB == 1 ? 6 : 3;                           // rows in flight (a divisor of the unroll)
+    auto issue = [&](int q, u32 (&d)[ND]) {
+      const int sr = min(max(s_begin + q, 0), sh - 1);
+      const uint8_t* p = sp + (u32)(sr * spitch) + lane_off;
+      typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+      const v3u32 w0 = gload_u<v3u32>(p);
+      d[0] = w0.x; d[1] = w0.y; d[2] = w0.z;
+      if constexpr (ND == 6) {
+        const v3u32 w1 = gload_u<v3u32>(p + 12);
+        d[3] = w1.x; d[4] = w1.y; d[5] = w1.z;
+      }
+    };
+    v2f32 acc[2][6];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        acc[j][i] = (v2f32){0.0f, 0.0f};
+    u32 pf[DS][ND];
+#pragma unroll
+    for (int d = 0; d < DS; ++d) {
+      issue(d, pf[d]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll 1
+    for (int q0 = 0; q0 < steps; q0 += 6) {
+#pragma unroll
+      for (int d = 0; d < 6; ++d) {
+        const int q = q0 + d;
+        constexpr int kNone = 0;
+        (void)kNone;
+        v2f32 f[6];
+        conv(pf[d % DS], f);
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+          asm volatile("" : "+v"(f[i])); // (pins the conversions in front of the load that takes their registers)
+        __builtin_amdgcn_sched_barrier(0);
+        issue(q + DS, pf[d % DS]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (q >= steps) // the last trip only
+          continue;
+        const int ph = d % 3, ja = (d / 3) & 1, jb = ja ^ 1;      // static
+        const v2f32 wa = (v2f32){wx[ph], wx[ph]}, wb = (v2f32){wx[ph + 3], wx[ph + 3]};
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          acc[ja][i] = __builtin_elementwise_fma(wa, f[i], ph == 0 ? (v2f32){0.0f, 0.0f} : acc[ja][i]); // tap 0 starts the slot at +0
+          acc[jb][i] = __builtin_elementwise_fma(wb, f[i], acc[jb][i]);
+        }
+        const int m = m_first + q / 3;                            // the pair whose even row sits on this source row (ph == 1)
+        if (ph == 1 && m <= m_last)
+          emit(2 * m, f);
+        if (ph == 2 && m - 1 >= m_first && m - 1 <= m_last)       // tap 5 of the odd row of the pair before
+          emit(2 * (m - 1) + 1, acc[jb]);
+      }
+    }
+  }
 }
 
 // ESSET as in resize_taps.hip: 1 = one-channel planes, 12 = NV12 / P10 (Y + UV), 3 = packed RGB
@@ -743,7 +820,7 @@ __global__ void __launch_bounds__(kBlock) k_resize_cols_x2(const ResizeArgs a) {
     cols_tile_x2<T, 1, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_rps, lds[wave]);
 }
 
-template <typename T, int ESSET, int TAPS, int P>
+template <typename T, int ESSET, int TAPS, int P, bool SROWS = false>
 __global__ void __launch_bounds__(kBlock) k_resize_cols_x32(const ResizeArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][448]; // scratch of cols_rows: (P + 1) x 64
   ResizeJob job;
@@ -753,9 +830,9 @@ __global__ void __launch_bounds__(kBlock) k_resize_cols_x32(const ResizeArgs a) 
   const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (ESSET == 12 && job.channels == 2)
-    cols_tile_x32<T, 2, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_rps, lds[wave]);
+    cols_tile_x32<T, 2, TAPS, P, SROWS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_rps, lds[wave]);
   else
-    cols_tile_x32<T, 1, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_rps, lds[wave]);
+    cols_tile_x32<T, 1, TAPS, P, SROWS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_rps, lds[wave]);
 }
 
 // The same arithmetic one output element per thread, TAPS x TAPS global loads each: planes narrower than one lane's 8
@@ -798,7 +875,7 @@ __global__ void __launch_bounds__(kBlock) k_resize_cols_direct(const ResizeArgs 
 }
 
 template <typename T, int ESSET, int TAPS>
-static void launch_slots(const ResizeArgs& a, int slots, int xform, dim3 grid, hipStream_t stream) { // xform: 0 general, 2 / 3: the 2:1 / 3:2-along-x forms
+static void launch_slots(const ResizeArgs& a, int slots, int xform, dim3 grid, hipStream_t stream) { // xform: 0 general, 2 / 3: the 2:1 / 3:2-along-x forms, 4: 3:2 both ways
   constexpr int P0 = TAPS == 6 ? 3 : 2, P1 = TAPS == 6 ? 4 : 3, P2 = TAPS == 6 ? 6 : 4;
   if constexpr (sizeof(T) <= 2 && ESSET != 3) {
     if (xform == 2) {
@@ -808,6 +885,11 @@ static void launch_slots(const ResizeArgs& a, int slots, int xform, dim3 grid, h
         hipLaunchKernelGGL((k_resize_cols_x2<T, ESSET, TAPS, P1>), grid, dim3(kBlock), 0, stream, a);
       else
         hipLaunchKernelGGL((k_resize_cols_x2<T, ESSET, TAPS, P2>), grid, dim3(kBlock), 0, stream, a);
+      return;
+    }
+    if (xform == 4) { // 3:2 along x AND y (Lanczos-3): the static walk, no slots
+      if constexpr (TAPS == 6)
+        hipLaunchKernelGGL((k_resize_cols_x32<T, ESSET, TAPS, P0, true>), grid, dim3(kBlock), 0, stream, a);
       return;
     }
     if (xform == 3) {
@@ -837,6 +919,7 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
   int esset = 0, tile_n = 256, slots = 1;
   bool narrow = false, x2 = elem <= 2 && tuning(VALI_TUNE_RESIZE_POINT) != 0; // exactly 2:1 along x on every plane
   bool x32 = x2;                                                              // exactly 3:2 along x on every plane
+  bool y32 = taps == 6;                                                       // ... and down the rows (dst height even)
   for (int k = 0; k < a.njobs; ++k) {
     const ResizeJob& j = a.job[k];
     const int c = j.channels;
@@ -845,6 +928,7 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
     narrow = narrow || sw * c < kColEl;
     x2 = x2 && c <= 2 && sw == 2 * dw && dw * c >= 8;
     x32 = x32 && c <= 2 && 2 * sw == 3 * dw && (dw * c) % 8 == 0;
+    y32 = y32 && 2 * sh == 3 * dh && dh % 2 == 0;
     // dst elements per tile: the source span of its pixels (+ taps, + the two extra elements, + alignment slop) must fit
     // the 512 elements a wave loads per row.  A tile starts on a pixel unless pixels are 3 elements (N is a multiple of 4).
     const double sx = (double)sw / (double)dw * (1.0 + 1e-6);
@@ -939,16 +1023,41 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
     // were 6912 waves of 30 rows, 1.4 rounds)
     while (rps > 1 && (unsigned long long)count(rps, false) * (unsigned)n < 2048ull)
       rps = rps > 2 ? rps / 2 : 1;
-  a.map = make_tile_map_linear(count(rps, true), (u32)n);
-  a.cols_n = tile_n;
-  a.cols_rps = rps;
+  const bool srows = x32 && !x2 && y32 && force != 2;                         // (RESIZE_NO_SEPARABLE = 2: the slot walk, for A/B and tests)
+  if (srows) {
+    // dst row PAIRS per wave: 3 of a wave's 3 n + 3 source rows are its neighbours'; 12 pairs (24 rows) unless that
+    // leaves the chip short of workgroups
+    auto count_pairs = [&](int pw, bool assign) {
+      u32 total = 0;
+      for (int k = 0; k < a.njobs; ++k) {
+        const int dwe = (dst_w >> a.job[k].sub_x) * a.job[k].channels, pairs = (dst_h >> a.job[k].sub_y) / 2;
+        const u32 tiles_x = (u32)(dwe + tile_n - 1) / (u32)tile_n;
+        if (assign) {
+          a.job[k].first_tile = total;
+          a.job[k].tiles_x = tiles_x;
+        }
+        total += tiles_x * (u32)((pairs + kWavesPerBlock * pw - 1) / (kWavesPerBlock * pw));
+      }
+      return total;
+    };
+    int pw = force == 1 ? 1 : 12;
+    while (pw > 1 && (unsigned long long)count_pairs(pw, false) * (unsigned)n < 2048ull)
+      pw = pw > 2 ? pw / 2 : 1;
+    a.map = make_tile_map_linear(count_pairs(pw, true), (u32)n);
+    a.cols_n = tile_n;
+    a.cols_rps = pw;
+  } else {
+    a.map = make_tile_map_linear(count(rps, true), (u32)n);
+    a.cols_n = tile_n;
+    a.cols_rps = rps;
+  }
   const dim3 grid = tile_grid(a.map);
 #define VALI_COLS_T(T)                                                               \
   do {                                                                               \
     if (taps == 6) {                                                                 \
-      if (esset == 1) launch_slots<T, 1, 6>(a, P, x2 ? 2 : x32 ? 3 : 0, grid, stream);                      \
-      else if (esset == 12) launch_slots<T, 12, 6>(a, P, x2 ? 2 : x32 ? 3 : 0, grid, stream);               \
-      else launch_slots<T, 3, 6>(a, P, x2 ? 2 : x32 ? 3 : 0, grid, stream);                                 \
+      if (esset == 1) launch_slots<T, 1, 6>(a, P, x2 ? 2 : srows ? 4 : x32 ? 3 : 0, grid, stream);                      \
+      else if (esset == 12) launch_slots<T, 12, 6>(a, P, x2 ? 2 : srows ? 4 : x32 ? 3 : 0, grid, stream);               \
+      else launch_slots<T, 3, 6>(a, P, x2 ? 2 : srows ? 4 : x32 ? 3 : 0, grid, stream);                                 \
     } else {                                                                         \
       if (esset == 1) launch_slots<T, 1, 4>(a, P, x2 ? 2 : x32 ? 3 : 0, grid, stream);                      \
       else if (esset == 12) launch_slots<T, 12, 4>(a, P, x2 ? 2 : x32 ? 3 : 0, grid, stream);               \
