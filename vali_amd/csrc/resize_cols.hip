@@ -50,29 +50,6 @@ template <int ES> constexpr int kColHalf = ES == 1 ? 272 : ES == 2 ? 136 : 91;
 
 typedef u32 u32_u __attribute__((aligned(1)));
 
-// v_pk_fma_f32 with ONE half of the weight pair w for both halves of the result (op_sel: tools/exp/pk_probe.hip): the
-// compiler broadcasts a 32-bit register only from the low half of an even-aligned pair and copies every other weight
-// first (or, hoisting the (w, w) pairs out of the walk, doubles the registers they take).
-__device__ __forceinline__ v2f32 pk_fma_lo(v2f32 w, v2f32 t, v2f32 acc) { // (w.x t.x + acc.x, w.x t.y + acc.y)
-  v2f32 r;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(w), "v"(t), "v"(acc));
-  return r;
-}
-__device__ __forceinline__ v2f32 pk_fma_hi(v2f32 w, v2f32 t, v2f32 acc) { // (w.y t.x + acc.x, w.y t.y + acc.y)
-  v2f32 r;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(w), "v"(t), "v"(acc));
-  return r;
-}
-__device__ __forceinline__ v2f32 pk_fma0_lo(v2f32 w, v2f32 t) { // fma(w.x, t, +0): the specification's chains start at +0
-  v2f32 r;
-  asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(r) : "v"(w), "v"(t));
-  return r;
-}
-__device__ __forceinline__ v2f32 pk_fma0_hi(v2f32 w, v2f32 t) {
-  v2f32 r;
-  asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(w), "v"(t));
-  return r;
-}
 // (a[HA], b[HB]) in one instruction
 template <int HA, int HB> __device__ __forceinline__ v2f32 pk_mov(v2f32 a, v2f32 b) {
   v2f32 r;
@@ -755,8 +732,6 @@ __device__ __forceinline__ void cols_tile_x32(const uint8_t* sp, int spitch, int
 #pragma unroll
       for (int d = 0; d < 6; ++d) {
         const int q = q0 + d;
-        constexpr int kNone = 0;
-        (void)kNone;
         v2f32 f[6];
         conv(pf[d % DS], f);
 #pragma unroll
