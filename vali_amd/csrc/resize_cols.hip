@@ -13,20 +13,24 @@
 //                   has an accumulator (P x 8 registers) and takes fma(w, f, acc) with a WAVE-UNIFORM weight -- a
 //                   scalar operand, no per-lane tap fetch.  P = ceil(TAPS / scale_y) slots; dst row rr lives in slot
 //                   rr mod P (the slot is free again before row rr + P starts because floor((rr + P) s) - floor(rr s) >=
-//                   TAPS).  The weights of all rows of the tile are computed once (lane r = row r), transposed through
-//                   LDS into one register per slot (lane 8 m + k = tap k of the slot's m-th row) and fetched with
-//                   v_readlane at a scalar lane index.
-//   horizontal pass when a dst row's window is complete its accumulators go to a float strip in LDS (channels of
-//                   interleaved planes de-interleaved into segments, so every plane is the 1-channel problem) and the
-//                   wave filters along x: lane l takes elements l, l + 64, l + 128, l + 192 of the tile (neighbouring
-//                   lanes read neighbouring 8-byte slots: conflict free at 2:1), reads its taps as ALIGNED float pairs
-//                   (ds_read_b64; a window that starts on an odd float starts one earlier with weight 0: the even / odd
-//                   accumulators of the specification swap halves and h = e + o is commutative), 4 packed FMAs, one add;
-//                   the results are transposed through 1 KiB of LDS so a lane stores 4 adjacent elements.
+//                   TAPS).  The weights of all rows of the tile are computed once (lane r = row r) and scattered through
+//                   LDS into one register per slot whose lane t holds the weight the slot applies to the wave's t-th
+//                   source row (0.0: none), fetched with v_readlane at the row index; a 64-bit mask says which rows
+//                   complete a dst row.
+//   horizontal pass two completed dst rows at a time: their columns go to a strip in LDS whose slots hold one column of
+//                   BOTH rows (channels of interleaved planes de-interleaved into segments, so every plane is the
+//                   1-channel problem; even and odd positions in separate halves: around 2:1 neighbouring lanes then read
+//                   neighbouring slots) and the wave filters along x: lane l takes elements l, l + 64, l + 128, l + 192
+//                   of the tile; a tap is one ds_read_b64 + one v_pk_fma_f32 for two output samples (the weight's half
+//                   broadcast by op_sel), e over the even taps, o over the odd ones, e + o: the specification's order; the
+//                   results are transposed through 2 KiB of LDS so a lane stores 4 adjacent elements of both rows.  The
+//                   tile's column taps are evaluated once per workgroup (wave w the w-th set).
 //
-// Per output sample at 2:1: 4 conversions + 6 packed FMAs (vertical) + 4 packed FMAs + 1 add (horizontal) + the
-// quantiser, against 13 conversions + 2.16 x (funnel shifts + 3 packed FMAs) + 3 before.  Planes that grow
-// vertically stay on resize_taps.hip (rows first: there the row pass is the smaller half).
+// Per output sample at 2:1: 4 conversions + 6-8 packed FMAs (vertical) + 3 LDS reads + 3 packed FMAs (horizontal) + the
+// quantiser, against 13 conversions + 2.16 x (funnel shifts + 3 packed FMAs) + 3 in round 2's rows-first kernel.  Exact
+// ratios have leaner forms below: 2:1 along x (only the sampled columns are filtered), 3:2 along x (one weight set, the row
+// pass in registers) and 3:2 both ways (two statically scheduled slots).  Planes that grow vertically stay on
+// resize_taps.hip (rows first: there the row pass is the smaller half), exactly doubled ones on resize_up2.hip.
 #include "resize_common.hpp"
 #include "resize_weights.hpp"
 
