@@ -512,7 +512,7 @@ __device__ __forceinline__ void cols_tile_x2(const uint8_t* sp, int spitch, int 
   constexpr int EB = (int)sizeof(T);
   static_assert(EB <= 2 && ES <= 2, "cols_tile_x2: 8 / 16-bit planes of 1 or 2 channels");
   constexpr int ND = 4 * EB;                                    // dwords of a lane's 16 source elements
-  constexpr int D = EB == 1 ? 4 : 2;
+  constexpr int D = EB == 1 ? 8 : 4;                            // rows in flight: this form is bound by its memory stream (8 vs 4: -5 %)
   const int lane = threadIdx.x & 63;
   ColRows<P> r;
   if (!cols_rows<TAPS, P, false>(sh, dh, spitch, ty, rps, strip, r))
