@@ -349,7 +349,7 @@ def test_doubled_planes_bit_exact(vali, gpu, oracle, fmt, size, interp):
 
 
 @pytest.mark.parametrize("pair", [("YUV420", "YUV444", np.uint8), ("YUV420_10bit", "YUV444_10bit", np.uint16)])
-@pytest.mark.parametrize("size", [(640, 360), (1920, 1080), (72, 34)])
+@pytest.mark.parametrize("size", [(640, 360), (1920, 1080), (72, 34), (70, 34)])   # (70: chroma 35 wide, not a multiple of 4: the general kernel)
 def test_planar_ud_at_unchanged_size_takes_the_plane_forms(vali, gpu, oracle, pair, size):
     """UDPlanar's everyday case: luma 1:1 (the point form = a copy), chroma doubled (resize_up2.hip), one batch of 3"""
     sf, df, dt = pair
@@ -420,3 +420,34 @@ def test_three_to_two_both_ways_bit_exact(vali, gpu, oracle, fmt, dst):
     for mode in (0, 1, 2, 3):                           # pairs per wave by launch size / 1 pair / the slot walk / 12 pairs
         with vali.tuning.Override(RESIZE_NO_SEPARABLE=mode):
             assert np.array_equal(roundtrip(vali, gpu, fmt, host, sw, sh, dw, dh, interp=vali.Interpolation.LANCZOS), want), mode
+
+
+@pytest.mark.parametrize("geom", [(334, 78, 334, 78), (334, 78, 668, 156), (1366, 20, 1366, 20), (16, 8, 32, 16)])
+@pytest.mark.parametrize("skew", [0, 1, 5])
+def test_borrowed_surfaces_with_odd_pitch_and_base(vali, gpu, oracle, geom, skew):
+    """Y planes borrowed from torch tensors (odd pitch, base off alignment by `skew` bytes, the last row ending where the
+    buffer ends) through k_plane_copy (unchanged size) and k_resize_up2 (doubled): nothing outside the rows is read
+    or written"""
+    import torch
+
+    sw, sh, dw, dh = geom
+    rng = np.random.default_rng(sw + dh + skew)
+    host = rng.integers(0, 256, sw * sh, dtype=np.uint8)
+    sp, dpad = sw + 3, dw + 7
+    sraw = torch.zeros(skew + (sh - 1) * sp + sw, dtype=torch.uint8, device="cuda")   # ends with the last row
+    sview = torch.as_strided(sraw, (sh, sw), (sp, 1), skew)
+    sview.copy_(torch.from_numpy(host.reshape(sh, sw)))
+    draw = torch.full((skew + dh * dpad,), 0x5a, dtype=torch.uint8, device="cuda")
+    dview = torch.as_strided(draw, (dh, dw), (dpad, 1), skew)
+    torch.cuda.synchronize()
+    src = vali.Surface.from_dlpack(torch.utils.dlpack.to_dlpack(sview), vali.Y)
+    dst = vali.Surface.from_dlpack(torch.utils.dlpack.to_dlpack(dview), vali.Y)
+    assert src.Pitch == sp and dst.Pitch == dpad
+    rs = vali.PySurfaceResizer(vali.Y, gpu)                      # Lanczos, the reference's filter
+    assert rs.Run(src, dst) == (True, vali.TaskExecInfo.SUCCESS)
+    out = draw.cpu().numpy()
+    got = np.lib.stride_tricks.as_strided(out[skew:], (dh, dw), (dpad, 1))
+    want = oracle.resize_surface(host, "Y", sw, sh, dw, dh, "lanczos").reshape(dh, dw)
+    assert np.array_equal(got, want)
+    pad = np.lib.stride_tricks.as_strided(out[skew + dw:], (dh - 1, dpad - dw), (dpad, 1))
+    assert np.all(pad == 0x5a) and np.all(out[:skew] == 0x5a)    # the bytes between and in front of the rows are untouched
