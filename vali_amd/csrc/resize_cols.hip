@@ -11,9 +11,9 @@
 //                   global memory, no staging) and walks the source rows of its tile ONCE, top to bottom.  Every element is
 //                   converted to float once and SCATTERED: each of the <= P dst rows whose window contains this source row
 //                   has an accumulator (P x 8 registers) and takes fma(w, f, acc) with a WAVE-UNIFORM weight -- a
-//                   scalar operand, no per-lane tap fetch.  P = ceil(TAPS / scale_y) slots; dst row rr lives in slot
-//                   rr mod P (the slot is free again before row rr + P starts because floor((rr + P) s) - floor(rr s) >=
-//                   TAPS).  The weights of all rows of the tile are computed once (lane r = row r) and scattered through
+//                   scalar operand, no per-lane tap fetch.  P = ceil((TAPS - 1) / scale_y) slots; dst row rr lives in slot
+//                   rr mod P (floor((rr + P) s) - floor(rr s) >= TAPS - 1: the slot's next row starts on the row that
+//                   completes this one at the earliest -- cols_rows).  The weights of all rows of the tile are computed once (lane r = row r) and scattered through
 //                   LDS into one register per slot whose lane t holds the weight the slot applies to the wave's t-th
 //                   source row (0.0: none), fetched with v_readlane at the row index; a 64-bit mask says which rows
 //                   complete a dst row.
@@ -69,13 +69,15 @@ typedef unsigned long long u64;
 template <int P> struct ColRows {
   float ws[P];        // lane t: the weight slot j applies to the wave's t-th source row (0.0: it has no use for the row)
   u64 done;           // bit t: source row t completes a dst row (rows complete in order, slots in turn)
+  float ws2;          // lane t: source row t is the LAST tap of a slot's row and the FIRST tap of its next one: that first weight
+  u64 dbl;            // bit t: ... and that this happens at row t
   u64 act[P];         // float planes: bit t: slot j uses source row t (a zero weight on a non-finite sample is no no-op)
   u32 roff;           // lane t: byte offset of that row in the source plane
   int ns;             // source rows the wave walks, <= kColProgRows
   int y_first, last_rr;
 };
 
-// false: the wave has no rows.  `scratch`: (P + 1) x 64 floats of this wave's LDS, (2 P + 1) x 64 for float planes (ACT).
+// false: the wave has no rows.  `scratch`: (P + 3) x 64 floats of this wave's LDS, (2 P + 3) x 64 for float planes (ACT).
 template <int TAPS, int P, bool ACT>
 __device__ __forceinline__ bool cols_rows(int sh, int dh, int spitch, u32 ty, int rps, float* scratch, ColRows<P>& r) {
   constexpr int kBefore = LzTap<TAPS>::kBefore;
@@ -88,32 +90,44 @@ __device__ __forceinline__ bool cols_rows(int sh, int dh, int spitch, u32 ty, in
   r.last_rr = min(rows, dh - r.y_first) - 1;
   const float scale_y = (float)sh / (float)dh;
   // Lane r evaluates the taps of dst row y_first + r (slot r mod P) and scatters them through LDS into the slot's
-  // row-indexed weight register: the windows of a slot's rows do not overlap (floor((rr + P) s) - floor(rr s) >= TAPS), so
-  // every (slot, source row) has at most one writer.  The walk then fetches a row's P weights with v_readlane at the
+  // row-indexed weight register.  The host picks P with floor((rr + P) s) - floor(rr s) >= TAPS - 1: the windows of a
+  // slot's rows overlap by ONE source row at most -- the last tap of row rr and the first of row rr + P (at 1.98:1 three
+  // slots, not four, and the overlap happens every ~20 rows; at 4:3 four, not six).  That first weight goes to ws2 / dbl
+  // instead of the slot's register: the walk completes and emits the old row, then starts the new one from +0 with it.
+  // So every (slot, source row) still has at most one writer.  The walk then fetches a row's P weights with v_readlane at the
   // row index -- the wave's control flow is data, not compares and branches: the kernel is bound by the TOTAL number of
   // instructions its waves issue (profiles/r03_lanczos.md).  A zero weight is an exact no-op on an accumulator that is
   // never -0, for the finite values integer planes have; float planes skip the slot instead (act).
   const LzTap<TAPS> vy = make_lz_tap<TAPS>(r.y_first + min(lane, rows - 1), scale_y);
   const int s_begin = __builtin_amdgcn_readlane(vy.i, 0) - kBefore;
   r.ns = __builtin_amdgcn_readlane(vy.i, r.last_rr) + TAPS - kBefore - s_begin;
-  u32* const flags = reinterpret_cast<u32*>(scratch) + P * kWave; // [0]: the row completes a dst row; [1 + j]: slot j uses it
+  float* const first_w = scratch + P * kWave;                     // ws2
+  u32* const flags = reinterpret_cast<u32*>(scratch) + (P + 1) * kWave; // [0]: the row completes a dst row; [1]: dbl; [2 + j]: slot j uses it
 #pragma unroll
-  for (int j = 0; j < P; ++j)
+  for (int j = 0; j < P + 1; ++j)
     scratch[j * kWave + lane] = 0.0f;
 #pragma unroll
-  for (int j = 0; j < (ACT ? P + 1 : 1); ++j)
+  for (int j = 0; j < (ACT ? P + 2 : 2); ++j)
     flags[j * kWave + lane] = 0u;
   wave_lds_sync();
   if (lane <= r.last_rr) {
     const int j = lane % P;
     const int t0 = vy.i - kBefore - s_begin;
+    // the row before this one in the slot (row - P, this wave's too) ends on this row's first source row?
+    const bool shared = lane >= P && (int)__builtin_floorf((float)(r.y_first + lane - P) * scale_y) + TAPS - 1 == vy.i;
+    if (shared) {
+      first_w[t0] = vy.w[0];
+      flags[kWave + t0] = 1u;
+    } else {
+      scratch[j * kWave + t0] = vy.w[0];
+    }
 #pragma unroll
-    for (int k = 0; k < TAPS; ++k)
+    for (int k = 1; k < TAPS; ++k)
       scratch[j * kWave + t0 + k] = vy.w[k];
     if constexpr (ACT) {
 #pragma unroll
       for (int k = 0; k < TAPS; ++k)
-        flags[(1 + j) * kWave + t0 + k] = 1u;
+        flags[(2 + j) * kWave + t0 + k] = 1u;
     }
     flags[t0 + TAPS - 1] = 1u; // (at most one dst row completes per source row: scale_y >= 1)
   }
@@ -121,10 +135,12 @@ __device__ __forceinline__ bool cols_rows(int sh, int dh, int spitch, u32 ty, in
 #pragma unroll
   for (int j = 0; j < P; ++j)
     r.ws[j] = scratch[j * kWave + lane];
+  r.ws2 = first_w[lane];
   r.done = __ballot(flags[lane] != 0u);
+  r.dbl = __ballot(flags[kWave + lane] != 0u);
 #pragma unroll
   for (int j = 0; j < P; ++j)
-    r.act[j] = ACT ? __ballot(flags[(1 + j) * kWave + lane] != 0u) : 0ull;
+    r.act[j] = ACT ? __ballot(flags[(2 + j) * kWave + lane] != 0u) : 0ull;
   // (lanes past the wave's last row repeat it: the walk's prefetch runs D rows ahead, and rows that belong to the wave
   // below are long gone from the L2 when that wave started on them -- 8 % more HBM reads)
   r.roff = (u32)(clampi(s_begin + min(lane, r.ns - 1), sh - 1) * spitch);
@@ -211,9 +227,16 @@ __device__ __forceinline__ void cols_walk(const ColRows<P>& r, const uint8_t* sp
         for (int j = 0; j < P; ++j) {
           if (eslot == j) {
             emit(emit_rr, acc[j]);
+            if ((r.dbl >> t) & 1ull) { // this source row is also the first tap of the slot's next row
+              const float w2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.ws2), t));
 #pragma unroll
-            for (int i = 0; i < NF; ++i)
-              acc[j][i] = (v2f32){0.0f, 0.0f};
+              for (int i = 0; i < NF; ++i)
+                acc[j][i] = __builtin_elementwise_fma((v2f32){w2, w2}, f[i], (v2f32){0.0f, 0.0f});
+            } else {
+#pragma unroll
+              for (int i = 0; i < NF; ++i)
+                acc[j][i] = (v2f32){0.0f, 0.0f};
+            }
           }
         }
         eslot = eslot == P - 1 ? 0 : eslot + 1;
@@ -786,7 +809,7 @@ __global__ void __launch_bounds__(kBlock) k_resize_cols(const ResizeArgs a) {
 
 template <typename T, int ESSET, int TAPS, int P>
 __global__ void __launch_bounds__(kBlock) k_resize_cols_x2(const ResizeArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][448]; // scratch of cols_rows: (P + 1) x 64
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][576]; // scratch of cols_rows: (P + 3) x 64
   ResizeJob job;
   u32 tx, ty, frame;
   if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
@@ -801,7 +824,7 @@ __global__ void __launch_bounds__(kBlock) k_resize_cols_x2(const ResizeArgs a) {
 
 template <typename T, int ESSET, int TAPS, int P, bool SROWS = false>
 __global__ void __launch_bounds__(kBlock) k_resize_cols_x32(const ResizeArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][448]; // scratch of cols_rows: (P + 1) x 64
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][576]; // scratch of cols_rows: (P + 3) x 64
   ResizeJob job;
   u32 tx, ty, frame;
   if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
@@ -915,13 +938,14 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
     while (nn >= 8 && (((c == 3 ? nn / 3 + 2 : nn / c) - 1) * sx + taps + 4) * c + kColEl - 1 > (double)kColSpan)
       nn -= 4;
     tile_n = nn < tile_n ? nn : tile_n;
-    // slots: the smallest P with P * scale_y >= taps (and a margin for the rounding of y * scale_y in FP32)
+    // slots: the smallest P with P * scale_y >= taps - 1 (a slot's consecutive rows may share ONE source row: cols_rows;
+    // and a margin for the rounding of y * scale_y in FP32)
     // (a ratio FP32 represents exactly -- 3:2, 2:1, 5:4 ... -- makes y * scale_y exact: no margin, 3:2 runs on 4 slots, not 6)
     const double sy = (double)sh / (double)dh;
     const float syf = (float)sh / (float)dh;
     const bool exact = (double)syf * (double)dh == (double)sh && sh < (1 << 20);
     int p = 1;
-    while (p < 6 && p * sy < taps + (exact ? 0.0 : sh * 2.5e-7 + 1e-6))
+    while (p < 6 && p * sy < (taps - 1) + (exact ? 0.0 : sh * 2.5e-7 + 1e-6))
       ++p;
     slots = p > slots ? p : slots;
   }
