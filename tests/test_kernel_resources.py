@@ -64,9 +64,11 @@ def test_no_kernel_uses_scratch_or_spills():
 def test_the_hot_kernels_spill_nothing_and_keep_their_occupancy():
     """the kernels the bench lines are quoted on: no spilled SGPR, and the waves per SIMD their design counts on"""
     k = kernels()
-    want = {"k_nv12_rgb8": 8, "k_ud_half": 8, "k_ud_half_t": 4, "k_resize_cols_x2IhLi12ELi6ELi4E": 5, "k_resize_colsIhLi12ELi6ELi4E": 4,
-            "k_resize_colsIhLi3ELi6ELi4E": 4, "k_resize_colsItLi12ELi6ELi4E": 4,   # (RGB and P10 at 1.98:1: 4 slots, the fourth wave per SIMD)
-            "k_resize_up2IhLi6ELb0E": 7, "k_resize_up2IhLi6ELb1E": 6, "k_resize_up2ItLi6ELb0E": 5}                      # (the workgroups-per-CU figures of launch_resize_up2)
+    want = {"k_nv12_rgb8": 8, "k_ud_half": 8, "k_ud_half_t": 4, "k_resize_cols_x2IhLi12ELi6ELi3E": 5,
+            # the general columns-first form: 3 slots at 1.98:1, 4 at 4:3 / 5:4 -- NV12, packed RGB, P10: the fourth wave per SIMD
+            "k_resize_colsIhLi12ELi6ELi3E": 4, "k_resize_colsIhLi12ELi6ELi4E": 4, "k_resize_colsIhLi3ELi6ELi3E": 4,
+            "k_resize_colsIhLi3ELi6ELi4E": 4, "k_resize_colsItLi12ELi6ELi3E": 4,
+            "k_resize_up2IhLi6ELb0E": 7, "k_resize_up2IhLi6ELb1E": 6, "k_resize_up2ItLi6ELb0E": 5}   # (the workgroups-per-CU figures of launch_resize_up2)
     seen = set()
     for name, r in k.items():
         for needle, occ in want.items():

@@ -267,7 +267,7 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
   constexpr int kBefore = LzTap<TAPS>::kBefore;
   constexpr int EB = (int)sizeof(T);
   constexpr int ND = 2 * EB;                                    // dwords of a lane's 8 elements
-  constexpr int D = EB == 4 ? 3 : EB == 2 ? 3 : 4;               // source rows in flight (registers: 8 EB bytes per lane and row)
+  constexpr int D = EB == 4 ? 3 : EB == 2 ? 3 : P >= 4 ? 2 : 4; // source rows in flight (registers: 8 EB bytes per lane and row; the 4- and 6-slot kernels trade two rows for their fourth wave per SIMD)
   constexpr int HALF = kColHalf<ES>, SEG = 2 * HALF;            // slots
   const int lane = threadIdx.x & 63;
   v2f32* const strip = reinterpret_cast<v2f32*>(lds);           // one slot = one column of TWO dst rows
