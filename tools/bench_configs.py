@@ -212,8 +212,8 @@ def interp(n=64):
                 return srcs, dsts, rs.PrepareBatch(srcs, dsts)
             sets = make_sets(k, make)
             ms, _ = timed(rs.Stream, [lambda q=q: rs.RunBatchAsync(q) for _, _, q in sets], 20)
-            kern = "k_resize<u8, 2>" if name == "bilinear" else {1920: "k_resize_cols_x2<u8, 12, 6, 4>", 1936: "k_resize_cols<u8, 12, 6, 4>",
-                                                                  1280: "k_resize_cols_x32<u8, 12, 6, 4>"}[dw]
+            kern = "k_resize<u8, 2>" if name == "bilinear" else {1920: "k_resize_cols_x2<u8, 12, 6, 3>", 1936: "k_resize_cols<u8, 12, 6, 3>",
+                                                                  1280: "k_resize_cols_x32<u8, 12, 6, static rows>"}[dw]
             key = "interp_" + name + {1920: "", 1936: "_1936", 1280: "_720p"}[dw]
             out.append({"filter": name, "geometry": f"{sw}x{sh}->{dw}x{dh}", "kernel": kern,
                         "us_per_frame": round(ms * 1e3 / n, 3), "bytes_moved_per_frame": b,
