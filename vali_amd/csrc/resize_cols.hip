@@ -732,7 +732,7 @@ __device__ __forceinline__ void cols_tile_x32(const uint8_t* sp, int spitch, int
     const int steps = 3 * (m_last - m_first + 1) + 3;
     constexpr int DS = EB == 1 ? 6 : 3;                           // rows in flight (a divisor of the unroll)
     auto issue = [&](int q, u32 (&d)[ND]) {
-      const int sr = min(max(s_begin + q, 0), sh - 1);
+      const int sr = min(max(s_begin + min(q, steps - 1), 0), sh - 1); // (rows past the wave's last repeat it: the rows of the wave below would be HBM reads)
       const uint8_t* p = sp + (u32)(sr * spitch) + lane_off;
       typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
       const v3u32 w0 = gload_u<v3u32>(p);

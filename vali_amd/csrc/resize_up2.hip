@@ -76,7 +76,7 @@ __device__ __forceinline__ void up2_tile(const PlaneView& v, u32 tx, u32 ty, int
   const bool plain_store = EB == 1 && ((((uintptr_t)v.dp) | (uintptr_t)v.dpitch) & 7u) == 0; // wave-uniform
 
   auto row_ptr = [&](int q) { // q may run past the walk (the prefetch): clamped to the plane
-    const int rv = min(max(q_begin + q, 0), v.sh - 1);
+    const int rv = min(max(q_begin + min(q, steps - 1), 0), v.sh - 1); // (past the walk: its last row again, not the next wave's rows)
     return v.sp + (u32)(rv * v.spitch) + lane_off;
   };
   auto issue = [&](int q, u32 (&d)[ND]) {
