@@ -1362,9 +1362,12 @@ __global__ void __launch_bounds__(kBlock) k_ud_half(const UdArgs a) {
     Rows r;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+      if (k == 2)     // chroma y - 1 is the row before's chroma y: carried in registers (below), not read again -- the second
+        continue;     // read came from HBM more often than not (FETCH_SIZE: 1.117 x the source, a third of the chroma plane)
       const v4u32 w = gload_u<v4u32>(row[k] + off16);
       r.v[k] = make_uint4(w.x, w.y, w.z, w.w);
     }
+    r.v[2] = make_uint4(0u, 0u, 0u, 0u);
     const int lk = lane & 3;
     const uint8_t* rb = lk == 0 ? row[0] : lk == 1 ? row[1] : lk == 2 ? row[2] : row[3];
     r.before = gload_u<u32>(rb + offw);
@@ -1373,7 +1376,8 @@ __global__ void __launch_bounds__(kBlock) k_ud_half(const UdArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t strip[kPacked ? kWavesPerBlock : 1][kPacked ? kD2WaveW * 3 : 16];
   const int nbytes = min(kD2WaveW, dw - xw) * 3;                        // packed RGB bytes of the wave's row, a multiple of 24
   const bool dst16 = ((((uintptr_t)d.p[0]) | (uintptr_t)d.pitch[0]) & 15u) == 0 && (xw * 3 & 15) == 0; // wave-uniform
-  auto step = [&](int rr, const Rows& rows) {
+  auto step = [&](int rr, Rows rows, const uint4& chroma_above) {
+    rows.v[2] = chroma_above;
     const int y = y_first + rr;
     u32 prev[4];
 #pragma unroll
@@ -1436,16 +1440,24 @@ __global__ void __launch_bounds__(kBlock) k_ud_half(const UdArgs a) {
     }
   };
   // two rows in flight, the walk unrolled by two so that both register sets are named statically
+  uint4 above; // the chroma row above the next dst row's: loaded once per wave, then the row before's own chroma row
+  {
+    const v4u32 w = gload_u<v4u32>(s.p[1] + (u32)(max(y_first - 1, 0) * s.pitch[1]) + off16);
+    above = make_uint4(w.x, w.y, w.z, w.w);
+  }
+  __builtin_amdgcn_sched_barrier(0);
   Rows ra = issue(0);
   __builtin_amdgcn_sched_barrier(0);
   Rows rb = issue(1);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
   for (int rr = 0; rr <= last; rr += 2) {
-    step(rr, ra);
+    step(rr, ra, above);
+    above = ra.v[3];
     ra = issue(rr + 2);
     if (rr + 1 <= last)
-      step(rr + 1, rb);
+      step(rr + 1, rb, above);
+    above = rb.v[3];
     rb = issue(rr + 3);
   }
 }
