@@ -48,6 +48,33 @@ def make_nv12(width: int, height: int, seed: int, full_range: bool = True) -> np
     return a
 
 
+def frame0_nv12():
+    """Frame 0 of the reference's test.mp4 (848x464) as NV12, re-derived from the reference's own rendering of it
+    (tests/golden/frame_0.jpg = NV12 -> RGB, BT.709 + MPEG, JPEG q95 4:4:4): BT.709 limited-range RGB -> YCbCr, the
+    chroma sample of a 2x2 block = the mean of its four copies (nearest siting, tests/test_oracle_reference_pins.py).
+    Carries the JPEG's coding noise and the frame's common offset (luma -1.43): comparisons remove a constant."""
+    from PIL import Image
+
+    rgb = np.asarray(Image.open(GOLDEN / "frame_0.jpg")).astype(np.float64)
+    h, w = rgb.shape[:2]
+    y = np.clip(np.rint(16 + 0.1826 * rgb[..., 0] + 0.6142 * rgb[..., 1] + 0.0620 * rgb[..., 2]), 0, 255).astype(np.uint8)
+    uf = 128 - 0.1006 * rgb[..., 0] - 0.3386 * rgb[..., 1] + 0.4392 * rgb[..., 2]
+    vf = 128 + 0.4392 * rgb[..., 0] - 0.3989 * rgb[..., 1] - 0.0403 * rgb[..., 2]
+
+    def block_mean(p):
+        return np.clip(np.rint(0.25 * (p[0::2, 0::2] + p[0::2, 1::2] + p[1::2, 0::2] + p[1::2, 1::2])), 0, 255).astype(np.uint8)
+    nv = np.zeros((h * 3 // 2, w), np.uint8)
+    nv[:h] = y
+    nv[h:, 0::2], nv[h:, 1::2] = block_mean(uf), block_mean(vf)
+    return nv
+
+
+def psnr_offset_removed(got, gold, border=4):
+    """PSNR (dB, peak 255) and mean of got - gold with `border` pixels dropped on every side and the mean removed."""
+    d = (np.asarray(got, np.float64) - np.asarray(gold, np.float64))[border:-border, border:-border]
+    return 10 * np.log10(255.0 ** 2 / np.mean((d - d.mean()) ** 2)), d.mean()
+
+
 @pytest.fixture(scope="session")
 def vali():
     import vali_amd

@@ -4,7 +4,7 @@
 import numpy as np
 import pytest
 
-from conftest import make_nv12
+from conftest import GOLDEN, frame0_nv12, make_nv12, psnr_offset_removed
 
 pytestmark = pytest.mark.gpu
 
@@ -133,6 +133,22 @@ def test_planar_sources_batch(vali, gpu, oracle):
         assert np.array_equal(out, _planar_want(oracle, h, sw, sh, dw, dh))
     bad = [vali.Surface.Make(vali.YUV444, sw, sh, gpu) for _ in range(n)]
     assert ud.RunBatch(bad, dsts) == (False, vali.TaskExecInfo.NOT_SUPPORTED)
+
+
+def test_texture_geometry_matches_the_reference_goldens(vali, gpu):
+    """The HIP path end to end against the reference's OWN outputs of its first-party kernels (ResizeUtils.cu:36-37,68-69;
+    reference tests/test_PySurfaceUD.py:135-188): frame 0 re-derived from frame_0.jpg -> PySurfaceUD 848x464 -> 640x360,
+    compared with the 640x360 NV12 -> YUV444 / RGB goldens, common offset removed.  The no-half-pixel grid X = x / s scores
+    47.5 dB luma; a centre-aligned sampler 23.8, the pixel grid x*s 25.9 (tests/test_oracle_ud.py has the alternatives)."""
+    pytest.importorskip("PIL.Image")
+    nv = frame0_nv12()
+    g = np.load(GOLDEN / "ud_640x360_nv12_rows120.npz")
+    yuv = run_ud(vali, gpu, nv, 848, 464, "NV12", 640, 360, "YUV444").reshape(3, 360, 640)
+    rgb = run_ud(vali, gpu, nv, 848, 464, "NV12", 640, 360, "RGB").reshape(360, 640, 3)
+    for c, floor in ((0, 47.0), (1, 48.4), (2, 52.9)):                      # measured 47.55 / 48.91 / 53.41 dB
+        assert psnr_offset_removed(yuv[c][:120], g["yuv444"][c])[0] >= floor, c
+    for c, floor in ((0, 46.3), (1, 46.4), (2, 41.1)):                      # measured 46.80 / 46.95 / 41.63 dB
+        assert psnr_offset_removed(rgb[:120, :, c], g["rgb"][..., c])[0] >= floor, c
 
 
 def test_planar_ud_matches_the_reference_golden(vali, gpu):
