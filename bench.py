@@ -416,16 +416,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # every rank's own average kernel time (+ its device index), gathered for the report
-        mine = torch.tensor([float(np.mean(kernel_ms)), float(dev)], dtype=torch.float64, device=coll_dev)
+        mine = torch.tensor([float(np.mean(kernel_ms)), float(dev), float(begin), float(end)], dtype=torch.float64, device=coll_dev)
         got = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(got, mine)
         per_rank_kernel_ms = [round(float(g[0]), 4) for g in got]
         rank_devices = [int(g[1]) for g in got]
+        shards = [[int(g[2]), int(g[3])] for g in got]
         one = torch.ones(1, dtype=torch.int64, device=coll_dev)
         dist.all_reduce(one, op=dist.ReduceOp.SUM)      # ranks that really took part in the collective
         ranks_seen = int(one.item())
     else:
         rank_devices = [dev]
+        shards = [[begin, end]]
+
+    # the state the chip holds under this load, read from sysfs between launches AFTER the timed region (rank 0 only)
+    clocks = None
+    if rank == 0:
+        def _one():
+            step()
+            shim.stream_sync(dev, stream)
+        try:
+            clocks = vali.pipeline.sample_clocks_under_load(shim.device_pci_bus_id(dev), _one, 0.25)
+        except Exception as e:  # noqa: BLE001 -- telemetry never takes the line down
+            clocks = {"error": f"{type(e).__name__}: {e}"}
 
     # Full-size verification on the GPU (every rank, all F frames): frame i was filled from seed
     # frame i % nseed, so its output must equal output i % nseed byte for byte; the seed outputs
@@ -485,7 +498,7 @@ def main():
             "ranks_seen": ranks_seen, "collective_backend": (backend if dist is not None else None),
             "launcher": ("self-spawned" if os.environ.get("VALI_BENCH_SPAWNED") == "1"
                          else "torchrun/env" if "WORLD_SIZE" in os.environ else "single process"),
-            "per_rank_kernel_ms": per_rank_kernel_ms, "rank_devices": rank_devices,
+            "per_rank_kernel_ms": per_rank_kernel_ms, "rank_devices": rank_devices, "rank_shards": shards,
             "achieved_hbm_GBps_whole_job": round(bytes_per_frame * fps / 1e9, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
@@ -502,7 +515,7 @@ def main():
         if verification is not None:
             out["verification"] = verification
         out["host_placement"] = {"numa_bound_cpus": (f"{numa_cpus[0]}-{numa_cpus[-1]} ({len(numa_cpus)} CPUs)" if numa_cpus else None),
-                                 "pci_bus_id": shim.device_pci_bus_id(dev)}
+                                 "pci_bus_id": shim.device_pci_bus_id(dev), "gpu_state": clocks}
         if world == 1 and args.ingest_seconds > 0:
             try:
                 pipe.srcs.clear(); pipe.dsts.clear()          # the ring allocates its own slots

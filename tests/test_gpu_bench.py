@@ -81,6 +81,41 @@ def test_bench_gpus_flag_spawns_the_ranks_itself(gpu):
     assert j["verification"]["frames_mismatching"] == 0 and "cpu_baseline" not in j
 
 
+def test_bench_eight_ranks_functional_on_one_gpu(gpu):
+    """BASELINE configs[4]'s shape (8 ranks, contiguous frame shards, one coefficient broadcast, checksum all-reduce)
+    without 8 GPUs: `bench.py --gpus 8` starts its eight ranks itself, they share this box's GPU and the collectives run
+    over gloo.  Functional proof only -- no scaling curve has been measured on hardware."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["VALI_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--frames", "8", "--width", "1920",
+                        "--height", "1080", "--steps", "2", "--warmup", "1", "--ramp-ms", "0"],
+                       capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    j = last_json(r.stdout)
+    assert j["n_gpus"] == 8 and j["ranks_seen"] == 8 and j["launcher"] == "self-spawned"
+    assert j["config"]["global_batch"] == 64 and j["config"]["frames_per_gpu"] == 8
+    assert len(j["per_rank_kernel_ms"]) == 8 and all(v > 0 for v in j["per_rank_kernel_ms"])
+    assert j["verification"] == {"frames_verified_on_gpu": 64, "frames_mismatching": 0,
+                                 "checksum_of_checksums": j["verification"]["checksum_of_checksums"]}
+    assert j["parity_vs_oracle"]["max_abs_diff_lsb"] == 0
+    # the shards: contiguous, disjoint, in rank order, covering the global batch exactly
+    assert j["rank_shards"] == [[8 * r_, 8 * r_ + 8] for r_ in range(8)]
+    assert "cpu_baseline" not in j and "secondary" not in j
+
+
+def test_bench_line_carries_the_gpu_state(gpu):
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "2", "--warmup", "1", "--frames", "8",
+                        "--cpu-seconds", "0", "--no-secondary", "--ingest-seconds", "0"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    st = last_json(r.stdout)["host_placement"]["gpu_state"]
+    assert "error" not in st, st
+    assert st["under_load"]["samples"] >= 1
+    # amdgpu exposes at least the shader clock on every box of the pool; the values are MHz, not Hz or kHz
+    lo, hi = st["under_load"]["sclk_mhz"]
+    assert 100 <= lo <= hi <= 4000, st
+
+
 def test_bench_gpus_flag_refuses_more_rccl_ranks_than_gpus(gpu, vali):
     if vali.GetNumGpus() >= 2:
         pytest.skip("box has several GPUs")

@@ -258,6 +258,41 @@ def test_gpu_numa_cpus_reads_sysfs(tmp_path):
     assert bind_to_gpu_numa(0, str(tmp_path), pci_bus_id="0000:99:00.0") is None
 
 
+def test_gpu_clock_state_reads_sysfs(tmp_path):
+    """The telemetry next to the bench line (bench.py host_placement.gpu_state): amdgpu's sysfs files, every field None
+    when the platform does not say, never an error."""
+    from vali_amd.pipeline import gpu_clock_state, sample_clocks_under_load
+    dev = tmp_path / "bus/pci/devices/0000:c1:00.0"
+    (dev / "hwmon/hwmon3").mkdir(parents=True)
+    (dev / "pp_dpm_sclk").write_text("0: 132Mhz\n1: 1730Mhz *\n2: 2400Mhz\n")
+    (dev / "pp_dpm_mclk").write_text("0: 900Mhz\n1: 2000Mhz *\n")
+    (dev / "current_compute_partition").write_text("SPX\n")
+    (dev / "hwmon/hwmon3/power1_cap").write_text("1400000000\n")
+    (dev / "hwmon/hwmon3/power1_average").write_text("912000000\n")
+    (dev / "hwmon/hwmon3/temp1_input").write_text("61000\n")
+    (dev / "hwmon/hwmon3/temp2_input").write_text("74000\n")
+    st = gpu_clock_state("0000:C1:00.0", str(tmp_path))
+    assert (st["sclk_mhz"], st["mclk_mhz"], st["fclk_mhz"]) == (1730, 2000, None)
+    assert (st["power_cap_w"], st["power_w"], st["temp_c"]) == (1400.0, 912.0, 74.0)
+    assert st["compute_partition"] == "SPX" and st["memory_partition"] is None
+    # no pp_dpm files: the hwmon frequency inputs (Hz) serve
+    (dev / "pp_dpm_sclk").unlink()
+    (dev / "hwmon/hwmon3/freq1_input").write_text("2100000000\n")
+    assert gpu_clock_state("c1:00.0", str(tmp_path))["sclk_mhz"] == 2100
+    # unknown device: all None
+    assert all(v is None for v in gpu_clock_state("0000:99:00.0", str(tmp_path)).values())
+    # under load: the step runs at least once, clocks are reported as [min, max]
+    calls = []
+
+    def step():
+        calls.append(1)
+        (dev / "pp_dpm_mclk").write_text(f"0: 900Mhz\n1: {1900 + 100 * (len(calls) % 2)}Mhz *\n")
+    rep = sample_clocks_under_load("0000:c1:00.0", step, seconds=0.02, sysfs=str(tmp_path))
+    assert calls and rep["under_load"]["samples"] == len(calls)
+    assert rep["under_load"]["mclk_mhz"][0] in (1900, 2000) and rep["under_load"]["mclk_mhz"][1] in (1900, 2000)
+    assert rep["power_cap_w"] == 1400.0 and rep["before"]["mclk_mhz"] == 2000
+
+
 def test_op_geometry():
     import vali_amd as vali
     from vali_amd.pipeline import op_geometry

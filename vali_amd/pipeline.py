@@ -105,6 +105,97 @@ def bind_to_gpu_numa(gpu_id: int, sysfs: str = "/sys", pci_bus_id: Optional[str]
     return allowed
 
 
+# ---- clock / power state of a GPU (telemetry for the bench line) -------------------------------------------------
+def _read(path: str) -> Optional[str]:
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def _dpm_current_mhz(text: Optional[str]) -> Optional[int]:
+    """The starred level of an amdgpu pp_dpm_* file ("0: 132Mhz\n1: 2100Mhz *"), in MHz."""
+    if not text:
+        return None
+    for line in text.splitlines():
+        if line.rstrip().endswith("*"):
+            digits = "".join(ch for ch in line.split(":", 1)[-1] if ch.isdigit())
+            return int(digits) if digits else None
+    return None
+
+
+def gpu_clock_state(pci_bus_id: str, sysfs: str = "/sys") -> dict:
+    """What amdgpu's sysfs says about the GPU at `pci_bus_id` RIGHT NOW: shader / memory / fabric clock (MHz), the
+    power cap and the present draw (W), the hottest sensor (deg C), the compute / memory partition modes.  Every field is
+    None when the platform does not expose it -- never an error: this is a note next to a measurement (the same binary
+    measured 0.76 - 0.82 of the HBM peak across the boxes of the pool; the bench line carries the box's state so that such
+    a spread has a cause next to it)."""
+    dev = pci_bus_id.strip().lower()
+    if dev.count(":") == 1:
+        dev = "0000:" + dev
+    base = os.path.join(sysfs, "bus/pci/devices", dev)
+    out = {"sclk_mhz": _dpm_current_mhz(_read(os.path.join(base, "pp_dpm_sclk"))),
+           "mclk_mhz": _dpm_current_mhz(_read(os.path.join(base, "pp_dpm_mclk"))),
+           "fclk_mhz": _dpm_current_mhz(_read(os.path.join(base, "pp_dpm_fclk"))),
+           "power_cap_w": None, "power_w": None, "temp_c": None,
+           "compute_partition": _read(os.path.join(base, "current_compute_partition")),
+           "memory_partition": _read(os.path.join(base, "current_memory_partition")),
+           "perf_level": _read(os.path.join(base, "power_dpm_force_performance_level"))}
+    try:
+        hw = os.path.join(base, "hwmon")
+        for name in sorted(os.listdir(hw)):
+            h = os.path.join(hw, name)
+            cap = _read(os.path.join(h, "power1_cap"))
+            draw = _read(os.path.join(h, "power1_average")) or _read(os.path.join(h, "power1_input"))
+            temps = [int(t) for t in (_read(os.path.join(h, f"temp{i}_input")) for i in range(1, 9)) if t and t.lstrip("-").isdigit()]
+            if cap and cap.isdigit():
+                out["power_cap_w"] = round(int(cap) / 1e6, 1)
+                dflt = _read(os.path.join(h, "power1_cap_default"))
+                if dflt and dflt.isdigit():
+                    out["power_cap_default_w"] = round(int(dflt) / 1e6, 1)
+            if draw and draw.isdigit():
+                out["power_w"] = round(int(draw) / 1e6, 1)
+            if temps:
+                out["temp_c"] = round(max(temps) / 1e3, 1)
+            if out["sclk_mhz"] is None:
+                f1 = _read(os.path.join(h, "freq1_input"))
+                if f1 and f1.isdigit():
+                    out["sclk_mhz"] = int(f1) // 1000000
+            if out["mclk_mhz"] is None:
+                f2 = _read(os.path.join(h, "freq2_input"))
+                if f2 and f2.isdigit():
+                    out["mclk_mhz"] = int(f2) // 1000000
+    except OSError:
+        pass
+    return out
+
+
+def sample_clocks_under_load(pci_bus_id: str, step: Callable[[], None], seconds: float = 0.25, sysfs: str = "/sys") -> dict:
+    """Repeat `step` (one launch + its completion) for `seconds` and read the GPU's state between launches: min / max of
+    the clocks, the highest power draw and temperature seen -- the state the chip HOLDS under this load, taken right
+    after (never inside) a timed region."""
+    import time
+
+    idle = gpu_clock_state(pci_bus_id, sysfs)
+    seen: List[dict] = []
+    t0 = time.perf_counter()
+    while True:
+        step()
+        seen.append(gpu_clock_state(pci_bus_id, sysfs))
+        if time.perf_counter() - t0 >= seconds:
+            break
+
+    def span(key):
+        v = [s[key] for s in seen if s.get(key) is not None]
+        return ([min(v), max(v)] if v else None)
+    return {"under_load": {"sclk_mhz": span("sclk_mhz"), "mclk_mhz": span("mclk_mhz"), "fclk_mhz": span("fclk_mhz"),
+                           "power_w": span("power_w"), "temp_c": span("temp_c"), "samples": len(seen)},
+            "before": {k: idle[k] for k in ("sclk_mhz", "mclk_mhz", "power_w", "temp_c")},
+            "power_cap_w": idle["power_cap_w"], "power_cap_default_w": idle.get("power_cap_default_w"), "perf_level": idle["perf_level"],
+            "compute_partition": idle["compute_partition"], "memory_partition": idle["memory_partition"]}
+
+
 # ---- the operators a pipeline can run -------------------------------------------------------------------------
 OPS = ("convert", "resize", "ud", "preproc")
 
