@@ -113,6 +113,9 @@ VALI_API int vali_device_count(int* count);
  * none and means "the legacy default stream of the thread's current device" -- a host that is handed stream 0 together
  * with a GPU index (python_vali's Task(gpu_id, stream) constructors) calls this first. */
 VALI_API int vali_device_set(int device);
+/* the calling thread's current device (cuCtxGetCurrent): what a caller saves before vali_device_set and puts back after
+ * the call -- the pop of the reference's CudaCtxPush (CudaUtils.hpp:29-47) */
+VALI_API int vali_device_get(int* device);
 /* device of a device pointer: GetDeviceIdByDptr (CudaUtils.cpp:150-163) */
 VALI_API int vali_ptr_device(const void* dptr, int* device);
 

@@ -75,8 +75,8 @@ def test_frame_converter_runs_on_the_gpu(vali, gpu, oracle):
 
 # ---- compressed input through PyAV (optional) -------------------------------------------------------------
 class _FakeFrame:
-    def __init__(self, yuv420, w, h):
-        self._p, self._w, self._h = yuv420, w, h
+    def __init__(self, yuv420, w, h, pts=0, key=False):
+        self._p, self._w, self._h, self.pts, self.key_frame = yuv420, w, h, pts, key
 
     def to_ndarray(self, format):  # noqa: A002 -- PyAV's keyword
         y, c = self._w * self._h, self._w * self._h // 4
@@ -94,12 +94,28 @@ def _fake_av(frames, w, h):
     import types
     from fractions import Fraction
 
-    cc = types.SimpleNamespace(width=w, height=h, pix_fmt="yuv420p", colorspace=1, color_range=1)
-    stream = types.SimpleNamespace(codec_context=cc, average_rate=Fraction(30, 1), guessed_rate=None, frames=len(frames),
-                                   format=types.SimpleNamespace(name="yuv420p"))
-    container = types.SimpleNamespace(streams=types.SimpleNamespace(video=[stream]), close=lambda: None,
-                                      decode=lambda s: iter([_FakeFrame(f, w, h) for f in frames]))
-    return types.SimpleNamespace(open=lambda path, options=None: container)
+    # 30 fps in a 1/15360 time base (512 ticks per frame), the stream starts at tick 1024, a key frame every 4 frames
+    cc = types.SimpleNamespace(width=w, height=h, pix_fmt="yuv420p", colorspace=1, color_range=1, gop_size=4, bit_rate=123456)
+    stream = types.SimpleNamespace(codec_context=cc, average_rate=Fraction(30, 1), guessed_rate=Fraction(30, 1), frames=len(frames),
+                                   format=types.SimpleNamespace(name="yuv420p"), time_base=Fraction(1, 15360), start_time=1024,
+                                   duration=512 * len(frames), index=0, metadata={"handler_name": "VideoHandler"})
+    state = {"at": 0, "seeks": []}
+
+    def decode(s):
+        def gen():
+            while state["at"] < len(frames):
+                i = state["at"]
+                state["at"] += 1
+                yield _FakeFrame(frames[i], w, h, pts=1024 + 512 * i, key=(i % 4 == 0))
+        return gen()
+
+    def seek(offset, stream=None, backward=True, any_frame=False):      # lands on the key frame at or before `offset`
+        state["seeks"].append((offset, backward, any_frame))
+        i = max(0, min(len(frames) - 1, (offset - 1024) // 512))
+        state["at"] = i - i % 4
+    container = types.SimpleNamespace(streams=types.SimpleNamespace(video=[stream]), close=lambda: None, decode=decode, seek=seek,
+                                      metadata={"title": "clip"})
+    return types.SimpleNamespace(open=lambda path, options=None: container, _state=state, _stream=stream)
 
 
 def test_compressed_input_through_pyav_adapter_cpu_mode(vali, monkeypatch, tmp_path):
@@ -133,6 +149,69 @@ def test_compressed_input_through_pyav_adapter_uploads_nv12(vali, gpu, monkeypat
         assert vali.PySurfaceDownloader(gpu, dec.Stream).Run(surf, got)[0]
         assert np.array_equal(got, _FakeFrame(f, w, h).to_ndarray("nv12").reshape(-1))
     assert dec.DecodeSingleSurface(surf) == (False, vali.TaskExecInfo.END_OF_STREAM)
+
+
+def test_seek_through_the_pyav_adapter_decodes_forward_to_the_target(vali, monkeypatch, tmp_path):
+    """reference TaskDecodeFrame.cpp:944-1029 (SeekDecode): seek backward to the key frame, decode forward to the frame whose
+    pts reaches the target; the target includes the stream's start_time; VFR + seek by number is NOT_SUPPORTED."""
+    import sys
+    from fractions import Fraction
+    w, h = 32, 16
+    frames = [np.full(w * h * 3 // 2, i, np.uint8) for i in range(12)]
+    fake = _fake_av(frames, w, h)
+    monkeypatch.setitem(sys.modules, "av", fake)
+    dec = vali.PyDecoder(str(tmp_path / "movie.mp4"), {}, gpu_id=-1)
+    out, pd = np.ndarray(shape=(0,), dtype=np.uint8), vali.PacketData()
+    # frame 6 is not a key frame: the container lands on 4, frames 4 and 5 are decoded and dropped
+    assert dec.DecodeSingleFrame(out, pd, vali.SeekContext(6)) == (True, vali.TaskExecInfo.SUCCESS)
+    assert out[0] == 6 and pd.pts == 1024 + 512 * 6 and pd.key == 0
+    assert fake._state["seeks"][-1] == (1024 + 512 * 6, True, False)          # time-base units, start_time included, backward
+    assert dec.DecodeSingleFrame(out, pd)[0] and out[0] == 7                    # decoding continues behind the target
+    assert dec.DecodeSingleFrame(out, pd, vali.SeekContext(0.1))[0] and out[0] == 3      # 0.1 s = tick 1536 -> frame 3
+    assert dec.DecodeSingleFrame(out, pd, vali.SeekContext(8))[0] and out[0] == 8 and pd.key == 1
+    # KEY_FRAMES mode: one decode after the seek, i.e. the key frame itself
+    assert dec.Mode == vali.DecodeMode.ALL_FRAMES
+    dec.SetMode(vali.DecodeMode.KEY_FRAMES)
+    assert dec.Mode == vali.DecodeMode.KEY_FRAMES
+    assert dec.DecodeSingleFrame(out, pd, vali.SeekContext(6))[0] and out[0] == 4
+    dec.SetMode(vali.DecodeMode.ALL_FRAMES)
+    with pytest.raises(TypeError):
+        dec.SetMode(1)
+    # past the end: END_OF_STREAM, not a stale frame
+    assert dec.DecodeSingleFrame(out, pd, vali.SeekContext(400)) == (False, vali.TaskExecInfo.END_OF_STREAM)
+    # the read-only ancillaries (PyDecoder.cpp:563-680)
+    assert (dec.GopSize, dec.Bitrate, dec.NumStreams, dec.StreamIndex) == (4, 123456, 1, 0)
+    assert abs(dec.Timebase - 1 / 15360) < 1e-12 and abs(dec.StartTime - 1024 / 15360) < 1e-12 and abs(dec.Duration - 0.4) < 1e-9
+    assert dec.Metadata == {"context": {"title": "clip"}, "video_stream": {"handler_name": "VideoHandler"}}
+    assert dec.MotionVectors == [] and not dec.IsVFR and dec.Framerate == 30.0 and dec.AvgFramerate == 30.0
+    # variable frame rate (r_frame_rate != avg_frame_rate): by number refused, by timestamp served
+    fake._stream.average_rate = Fraction(2997, 100)
+    vfr = vali.PyDecoder(str(tmp_path / "vfr.mp4"), {}, gpu_id=-1)
+    assert vfr.IsVFR
+    assert vfr.DecodeSingleFrame(out, pd, vali.SeekContext(6)) == (False, vali.TaskExecInfo.NOT_SUPPORTED)
+    assert vfr.DecodeSingleFrame(out, pd, vali.SeekContext(0.2))[0] and out[0] == 6
+
+
+def test_log_level_and_probe_validate_their_arguments(vali, tmp_path):
+    """reference VALI.cpp:206-214, 512-521; PyDecoder.cpp:684-700."""
+    assert [int(v) for v in (vali.FfmpegLogLevel.PANIC, vali.FfmpegLogLevel.ERROR, vali.FfmpegLogLevel.DEBUG)] == [0, 16, 48]
+    assert vali.ERROR == vali.FfmpegLogLevel.ERROR and vali.KEY_FRAMES == vali.DecodeMode.KEY_FRAMES     # export_values
+    vali.SetFFMpegLogLevel(vali.FfmpegLogLevel.ERROR)
+    with pytest.raises(TypeError):
+        vali.SetFFMpegLogLevel(16)
+    sp = vali.StreamParams()
+    assert (sp.width, sp.num_frames, sp.fps, sp.color_space) == (0, 0, 0.0, vali.ColorSpace.UNSPEC)
+    from vali_amd.codecs import have_av
+    if not have_av():
+        with pytest.raises(RuntimeError, match="PyAV"):
+            vali.PyDecoder.Probe(str(tmp_path / "x.mp4"))
+    # raw video answers the ancillaries from the file itself
+    w, h, n = 32, 16, 5
+    path = tmp_path / "clip.nv12"
+    np.zeros(n * w * h * 3 // 2, np.uint8).tofile(path)
+    dec = vali.PyDecoder(str(path), {"video_size": f"{w}x{h}", "framerate": "10"}, gpu_id=-1)
+    assert (dec.GopSize, dec.NumStreams, dec.Duration, dec.Timebase, dec.Metadata) == (1, 1, 0.5, 0.1, {})
+    assert dec.Bitrate == w * h * 3 // 2 * 8 * 10 and dec.Mode == vali.DecodeMode.ALL_FRAMES
 
 
 def test_real_pyav_decodes_the_reference_video_when_installed(vali):
@@ -211,10 +290,16 @@ def test_packet_data_and_seek_context_exist_and_drive_the_raw_decoder(vali, tmp_
 class _FakeEncoder:
     """the handful of av.CodecContext attributes PyNvEncoder touches; a 'packet' is the frame's first 8 bytes, one frame late"""
 
-    def __init__(self):
-        self.options, self._held = {}, None
+    def __init__(self, delay=1):
+        self.options, self._held, self._eof, self._delay = {}, None, False, delay
 
     def encode(self, frame):
+        if frame is not None and self._eof:
+            raise EOFError("avcodec_send_frame: AVERROR_EOF")      # what libavcodec does to a drained encoder
+        if frame is None:
+            self._eof = True
+        if self._delay == 0 and frame is not None:
+            return [bytes(frame.data[:8])]
         out = [] if self._held is None else [self._held]
         self._held = None if frame is None else bytes(frame.data[:8])
         return out
@@ -250,6 +335,11 @@ def test_video_encoder_through_the_pyav_adapter(vali, gpu, monkeypatch):
         if got:
             assert np.array_equal(pkt, sent[i - 1])     # luma bytes survive the NV12 -> planar repack in front of the codec
     assert enc.Flush(pkt) and np.array_equal(pkt, sent[2]) and not enc.Flush(pkt)
+    # a drained libavcodec encoder is at EOF: the next frame gets a NEW context instead of an EOFError
+    assert not enc.EncodeSingleSurface(surf, pkt) and made == ["h264", "h264"]
+    # sync mode never drains per frame: two frames in a row, the second returns the first one's packet
+    assert enc.EncodeSingleSurface(surf, pkt, sync=True) and np.array_equal(pkt, sent[2])
+    assert enc._ctx.options.get("preset") == "fast" and enc._ctx.max_b_frames == 0 and enc._ctx.thread_count == 1
     assert not enc.EncodeSingleSurface(vali.Surface.Make(vali.NV12, 32, 32, gpu), pkt)      # wrong size
     with pytest.raises(RuntimeError):
         vali.PyNvEncoder({"codec": "h264"}, gpu)        # no size

@@ -171,6 +171,72 @@ def test_two_threads_two_streams(vali, gpu, oracle):
     assert results == {0: True, 1: True, 2: True, 3: True}
 
 
+def test_threads_blocking_on_one_shared_stream(vali, gpu, oracle):
+    """Tasks built WITHOUT a stream share their GPU's manager stream; their blocking Run forms wait on ONE completion
+    word whose values two threads take concurrently (the GIL is released around the wait): the counter and the
+    enqueue of its write are one locked step (runtime.hip vali_stream_wait)."""
+    import threading
+
+    from conftest import make_nv12
+
+    w, h, iters = 320, 180, 300
+    cc = vali.ColorspaceConversionContext(vali.ColorSpace.BT_709, vali.ColorRange.MPEG)
+    errors, results = [], {}
+
+    def worker(idx):
+        try:
+            nv = make_nv12(w, h, 300 + idx)
+            cvt = vali.PySurfaceConverter(gpu)                  # the manager's stream, shared by all four threads
+            src = vali.Surface.Make(vali.NV12, w, h, gpu)
+            dst = vali.Surface.Make(vali.RGB, w, h, gpu)
+            assert vali.PyFrameUploader(gpu).Run(nv.reshape(-1), src)[0]
+            want = oracle.nv12_to_rgb(nv, w, h, oracle.csc(1), "RGB").reshape(-1)
+            ok = True
+            for _ in range(iters):
+                assert cvt.Run(src, dst, cc)[0]                 # blocking: returns only when the kernel has finished
+            out = np.zeros(dst.HostSize, np.uint8)
+            assert vali.PySurfaceDownloader(gpu).Run(dst, out)[0]
+            results[idx] = ok and np.array_equal(out, want)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+    assert results == {0: True, 1: True, 2: True, 3: True}
+
+
+def test_null_stream_task_restores_the_callers_device(vali, gpu, oracle):
+    """A task on (gpu, stream 0) makes its GPU current for the call and puts the caller's device back (the pop of the
+    reference's CudaCtxPush, CudaUtils.hpp:77-90); its wrappers hold no strong reference to the task."""
+    import gc
+    import weakref
+
+    from conftest import make_nv12
+    shim = vali._native.shim
+    assert shim.device_get() == gpu or shim.device_get() >= 0
+    before = shim.device_get()
+    w, h = 128, 64
+    nv = make_nv12(w, h, 5)
+    cvt = vali.PySurfaceConverter(gpu, 0)
+    src, dst = vali.Surface.Make(vali.NV12, w, h, gpu), vali.Surface.Make(vali.RGB, w, h, gpu)
+    assert vali.PyFrameUploader(gpu).Run(nv.reshape(-1), src)[0]
+    cc = vali.ColorspaceConversionContext(vali.ColorSpace.BT_709, vali.ColorRange.MPEG)
+    assert cvt.Run(src, dst, cc) == (True, vali.TaskExecInfo.SUCCESS) and cvt.Stream == 0
+    assert shim.device_get() == before
+    out = np.zeros(dst.HostSize, np.uint8)
+    assert vali.PySurfaceDownloader(gpu).Run(dst, out)[0]
+    assert np.array_equal(out, oracle.nv12_to_rgb(nv, w, h, oracle.csc(1), "RGB").reshape(-1))
+    gc.disable()
+    try:
+        ref = weakref.ref(cvt)
+        del cvt
+        assert ref() is None                                    # reference counting alone frees it: no cycle
+    finally:
+        gc.enable()
+
+
 def test_stream_capture_replays_a_chain(vali, gpu, oracle):
     """StreamCapture: resize -> convert -> planar recorded once, replayed per frame; results are
     the eager results, for every refill of the captured input surface."""

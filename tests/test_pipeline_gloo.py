@@ -186,6 +186,31 @@ def test_ingest_ring_refuses_a_slot_whose_outputs_nobody_took():
     assert len(ring.reap()) >= 1 and ring.acquire() is ring.slots[0]
 
 
+def test_ingest_ring_short_last_chunk_and_close():
+    """a final chunk shorter than a slot yields only its VALID outputs (the slot's tail still holds an earlier
+    chunk's frames); close() drops the views into the pinned buffers and the events, and a closed ring refuses work."""
+    from vali_amd.pipeline import IngestRing
+    be = _FakeStreams()
+    freed = []
+    be.free_event = freed.append
+    ring = IngestRing(_FakePipe(be, 8, 4, 0x11), slots=2, frames_per_slot=4, backend=be)
+    rng = np.random.default_rng(3)
+    frames = [rng.integers(0, 256, 48, dtype=np.uint8) for _ in range(10)]          # 4 + 4 + 2
+    chunks = [np.concatenate(frames[i:i + 4]) for i in range(0, 10, 4)]
+    sizes = {tag: len(dsts) for tag, dsts in ring.feed(chunks)}
+    assert sizes == {0: 4, 1: 4, 2: 2}
+    with pytest.raises(ValueError):
+        list(ring.feed([np.zeros(47, np.uint8)]))                                     # not whole frames
+    # a fill callback reports what it wrote
+    got = list(ring.feed([frames[0]], fill=lambda host, item: (host.__setitem__(slice(0, item.size), item), 1)[1]))
+    assert [len(d) for _t, d in got] == [1]
+    ring.close()
+    assert all(s.host is None and s.uploaded is None and s.done is None for s in ring.slots) and len(freed) == 4
+    with pytest.raises(RuntimeError, match="closed"):
+        ring.acquire()
+    ring.close()                                                                      # idempotent
+
+
 def _ring_worker(rank, world, port, q):
     import torch
     import torch.distributed as dist

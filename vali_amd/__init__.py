@@ -12,9 +12,9 @@ _BUILDING = "vali_amd.build" in getattr(_sys, "orig_argv", [])
 if not _BUILDING:
     from ._native import shim as _shim  # noqa: F401  (fails loudly if the HIP library is absent)
     from .codecs import (NvJpegEncodeContext, PacketData, PyDecoder, PyFrameConverter, PyNvEncoder, PyNvJpegEncoder,
-                         SeekContext)
-    from .enums import (ColorRange, ColorSpace, ColorspaceConversionContext, DLDeviceType, Interpolation,
-                        PixelFormat, TaskExecDetails, TaskExecInfo, TaskExecStatus, export_values)
+                         SeekContext, SetFFMpegLogLevel, StreamParams)
+    from .enums import (ColorRange, ColorSpace, ColorspaceConversionContext, DecodeMode, DLDeviceType, FfmpegLogLevel,
+                        Interpolation, PixelFormat, TaskExecDetails, TaskExecInfo, TaskExecStatus, export_values)
     from .runtime import CudaStreamEvent, GetNumGpus, HipResMgr, StreamCapture
     from .surface import Surface, SurfacePlane
     from .buffer import CudaBuffer

@@ -30,7 +30,7 @@ from typing import Optional, Tuple
 
 import numpy as np
 
-from .enums import ColorRange, ColorSpace, PixelFormat, TaskExecInfo
+from .enums import ColorRange, ColorSpace, DecodeMode, FfmpegLogLevel, PixelFormat, TaskExecInfo
 from .runtime import HipResMgr
 from .surface import FORMATS, Surface
 from .tasks import PySurfaceConverter
@@ -58,6 +58,36 @@ def have_av() -> bool:
         return True
     except Exception:
         return False
+
+
+def SetFFMpegLogLevel(level) -> None:
+    """reference: VALI.cpp:512-521 (`av_log_set_level(int(level))`).  Validates its argument like the pybind11 enum
+    would (TypeError for anything that is not a FfmpegLogLevel) and forwards to PyAV's logging when PyAV is importable;
+    without FFmpeg on the box there is no log to configure and the call is a no-op."""
+    if not isinstance(level, FfmpegLogLevel):
+        raise TypeError("SetFFMpegLogLevel(level: FfmpegLogLevel)")
+    try:
+        import av.logging as avlog
+        avlog.set_level(int(level))
+    except Exception:
+        pass
+
+
+class StreamParams:
+    """reference: StreamParams of src/TC/inc/CodecsSupport.hpp, filled by GetStreamParams (TaskDecodeFrame.cpp:786-825);
+    what PyDecoder.Probe returns, one per video stream."""
+
+    __slots__ = ("width", "height", "fourcc", "codec_id", "color_space", "color_range", "num_frames", "start_time", "bit_rate",
+                 "profile", "level", "fps", "avg_fps", "time_base", "start_time_sec", "duration_sec")
+
+    def __init__(self):
+        for name in self.__slots__:
+            setattr(self, name, 0)
+        self.color_space, self.color_range = ColorSpace.UNSPEC, ColorRange.UDEF
+        self.fps = self.avg_fps = self.time_base = self.start_time_sec = self.duration_sec = 0.0
+
+    def __repr__(self) -> str:
+        return "StreamParams(" + ", ".join(f"{n}={getattr(self, n)!r}" for n in self.__slots__) + ")"
 
 
 class PacketData:
@@ -147,6 +177,22 @@ class _AvSource:
         self.num_frames = int(self._stream.frames or 0)
         self.color_space = self._SPACE.get(int(getattr(cc, "colorspace", 2) or 2), ColorSpace.UNSPEC)
         self.color_range = self._RANGE.get(int(getattr(cc, "color_range", 0) or 0), ColorRange.UDEF)
+        guessed = getattr(self._stream, "guessed_rate", None) or getattr(self._stream, "base_rate", None) or rate
+        self.r_framerate = float(guessed) if guessed else self.framerate          # r_frame_rate; != avg rate <=> VFR
+        tb = getattr(self._stream, "time_base", None)
+        self.time_base = float(tb) if tb else 0.0
+        st = getattr(self._stream, "start_time", None)
+        self.start_time = None if st is None else int(st)                          # AV_NOPTS_VALUE <=> None in PyAV
+        dur = getattr(self._stream, "duration", None)
+        self.duration = float(dur * tb) if (dur and tb) else 0.0
+        self.bit_rate = int(getattr(cc, "bit_rate", 0) or getattr(self._container, "bit_rate", 0) or 0)
+        self.gop_size = int(getattr(cc, "gop_size", 0) or 0)
+        self.delay = int(getattr(cc, "delay", 0) or 0)
+        self.profile, self.level = getattr(cc, "profile", None), int(getattr(cc, "level", 0) or 0)
+        self.num_streams = len(getattr(self._container.streams, "video", [])) if not hasattr(self._container.streams, "__len__") \
+            else len(self._container.streams)
+        self.stream_index = int(getattr(self._stream, "index", 0) or 0)
+        self.mode = DecodeMode.ALL_FRAMES
         self._frames = self._container.decode(self._stream)
         self.last_error = None
         self.last_frame = None      # the PyAV frame behind the most recent read() (pts / key frame for PacketData)
@@ -155,11 +201,55 @@ class _AvSource:
             warnings.warn("PyDecoder: 12-bit source is delivered as 10-bit (P10 / YUV420_10bit), like the reference's "
                           "decoder surfaces")
 
-    def seek(self, ctx: "SeekContext") -> None:
-        ts = ctx.seek_tssec if ctx.IsByTimestamp else ctx.seek_frame / self.framerate
-        tb = getattr(self._stream, "time_base", None)
-        self._container.seek(int(ts / float(tb)) if tb else int(ts * 1e6), stream=self._stream if tb else None)
+    @property
+    def is_vfr(self) -> bool:
+        return self.r_framerate != self.framerate                                  # TaskDecodeFrame.cpp:922
+
+    def set_mode(self, mode: DecodeMode) -> None:
+        """KEY_FRAMES: the codec skips everything but key frames (AVDISCARD_NONKEY, TaskDecodeFrame.cpp SetMode)."""
+        self.mode = DecodeMode(mode)
+        try:
+            self._stream.codec_context.skip_frame = "NONKEY" if self.mode == DecodeMode.KEY_FRAMES else "DEFAULT"
+        except Exception:
+            pass
+
+    def metadata(self) -> dict:
+        """{"context": {...}, "video_stream": {...}} like GetMetaData (TaskDecodeFrame.cpp:846-870)"""
+        out = {}
+        for name, obj in (("context", self._container), ("video_stream", self._stream)):
+            md = getattr(obj, "metadata", None)
+            if md:
+                out[name] = {str(k): str(v) for k, v in dict(md).items()}
+        return out
+
+    def seek_decode(self, ctx: "SeekContext") -> Tuple[Optional[np.ndarray], Optional[TaskExecInfo]]:
+        """The reference's SeekDecode (TaskDecodeFrame.cpp:944-1029): seek BACKWARD to the key frame at or before the
+        target, then decode and discard until the frame whose pts reaches the target -- that frame is the result
+        (KEY_FRAMES mode: the key frame itself).  The target is in stream time-base units and includes the stream's
+        start_time; seeking by frame number is refused on variable-frame-rate input (NOT_SUPPORTED)."""
+        if self.is_vfr and ctx.IsByNumber:
+            return None, TaskExecInfo.NOT_SUPPORTED
+        ts_sec = ctx.seek_frame / self.r_framerate if ctx.IsByNumber else ctx.seek_tssec
+        tb = self.time_base or 1e-6
+        target = int(round(ts_sec / tb))
+        start = self.start_time if self.start_time is not None else 0
+        target += start
+        try:
+            self._container.seek(target, stream=self._stream, backward=True, any_frame=False)
+        except Exception as e:
+            self.last_error = e
+            return None, TaskExecInfo.FAIL
         self._frames = self._container.decode(self._stream)
+        while True:
+            data = self.read()
+            if data is None:
+                return None, None                        # end of stream / decode error: the caller reports which
+            pts = getattr(self.last_frame, "pts", None)
+            # frame pts are absolute stream timestamps, so the comparison is against the target WITH start_time.  (The
+            # reference's loop reads `m_frame->pts + start_time < timestamp` with timestamp already offset: for streams
+            # whose start_time is not 0 that stops start_time ticks early -- a quirk, not reproduced.)
+            if pts is None or int(pts) >= target or self.mode == DecodeMode.KEY_FRAMES:
+                return data, None
 
     def read(self) -> Optional[np.ndarray]:
         """next frame as a flat uint8 array, None at the end of the stream or on a decode error (last_error is set then)"""
@@ -201,6 +291,7 @@ class PyDecoder:
     def __init__(self, input, opts: Optional[dict] = None, gpu_id: int = 0, stream=None):
         opts = dict(opts or {})
         self._gpu_id = int(gpu_id)
+        self._mode = DecodeMode.ALL_FRAMES
         path = os.fspath(input) if isinstance(input, (str, os.PathLike)) else None
         if path is None:
             raise RuntimeError("PyDecoder: only file paths are supported by this build")
@@ -217,7 +308,7 @@ class PyDecoder:
             self._av = _AvSource(path, {k: v for k, v in opts.items() if k not in ("pixel_format", "pix_fmt")},
                                  self._gpu_id >= 0)
             self._w, self._h, self._fmt = self._av.width, self._av.height, self._av.fmt
-            self._framerate, self._num_frames = self._av.framerate, self._av.num_frames
+            self._framerate, self._num_frames = self._av.r_framerate, self._av.num_frames
             self._file, self._pos = None, 0
             self._init_stream(stream)
             return
@@ -250,22 +341,78 @@ class PyDecoder:
     Stream = property(lambda self: self._stream)
     NumFrames = property(lambda self: self._num_frames)
     Framerate = property(lambda self: self._framerate)
-    AvgFramerate = property(lambda self: self._framerate)
+    AvgFramerate = property(lambda self: self._av.framerate if self._av else self._framerate)
     IsAccelerated = property(lambda self: self._gpu_id >= 0)
-    IsVFR = property(lambda self: False)
+    IsVFR = property(lambda self: bool(self._av.is_vfr) if self._av else False)
     DisplayRotation = property(lambda self: 361.0)           # "no display matrix" value
+    # the read-only ancillaries of PyDecoder.cpp:563-680, answered from PyAV's stream / codec context or the raw reader
+    Level = property(lambda self: self._av.level if self._av else 0)
+    Profile = property(lambda self: self._av.profile if self._av else None)
+    Delay = property(lambda self: self._av.delay if self._av else 0)
+    GopSize = property(lambda self: self._av.gop_size if self._av else 1)              # raw video: every frame is a key frame
+    Bitrate = property(lambda self: self._av.bit_rate if self._av
+                       else int(self._file_frame * 8 * self._framerate))
+    NumStreams = property(lambda self: self._av.num_streams if self._av else 1)
+    StreamIndex = property(lambda self: self._av.stream_index if self._av else 0)
+    Timebase = property(lambda self: self._av.time_base if self._av else 1.0 / self._framerate)
+    StartTime = property(lambda self: (self._av.start_time or 0) * self._av.time_base if self._av else 0.0)
+    Duration = property(lambda self: self._av.duration if self._av else self._num_frames / self._framerate)
+    MotionVectors = property(lambda self: [])                # needs the codec's side data: not exported by this stand-in
+    Metadata = property(lambda self: self._av.metadata() if self._av else {})
+    Mode = property(lambda self: self._mode)
+
+    def SetMode(self, mode) -> None:
+        """PyDecoder.cpp SetMode: KEY_FRAMES decodes key frames only.  Raw video: every frame is one."""
+        if not isinstance(mode, DecodeMode):
+            raise TypeError("SetMode(mode: DecodeMode)")
+        self._mode = mode
+        if self._av is not None:
+            self._av.set_mode(mode)
+
+    @staticmethod
+    def Probe(input) -> list:  # noqa: A002 -- the reference's argument name
+        """static Probe(input) -> list[StreamParams] (PyDecoder.cpp:684-700): the parameters of every video stream,
+        without opening a codec.  Compressed input needs PyAV like the constructor; a raw file with a known suffix
+        cannot be probed (it has no header) and raises RuntimeError like FFmpeg's 'Invalid data'."""
+        path = os.fspath(input)
+        if not have_av():
+            raise RuntimeError("PyDecoder.Probe: needs PyAV (`import av`), which is not importable here")
+        import av
+
+        out = []
+        with av.open(path) as container:
+            for st in container.streams.video:
+                cc, p = st.codec_context, StreamParams()
+                p.width, p.height = int(cc.width), int(cc.height)
+                p.codec_id = int(getattr(getattr(cc, "codec", None), "id", 0) or 0)
+                tag = getattr(cc, "codec_tag", 0)
+                p.fourcc = int.from_bytes(tag.encode("ascii", "replace")[:4].ljust(4, b"\0"), "little") if isinstance(tag, str) else int(tag or 0)
+                p.color_space = _AvSource._SPACE.get(int(getattr(cc, "colorspace", 2) or 2), ColorSpace.UNSPEC)
+                p.color_range = _AvSource._RANGE.get(int(getattr(cc, "color_range", 0) or 0), ColorRange.UDEF)
+                p.num_frames, p.start_time = int(st.frames or 0), int(st.start_time or 0)
+                p.bit_rate, p.level = int(getattr(cc, "bit_rate", 0) or 0), int(getattr(cc, "level", 0) or 0)
+                prof = getattr(cc, "profile", None)
+                p.profile = prof if isinstance(prof, int) else 0
+                rate, avg, tb = getattr(st, "guessed_rate", None) or st.average_rate, st.average_rate, st.time_base
+                p.fps, p.avg_fps = float(rate or 0), float(avg or 0)
+                p.time_base = float(tb) if tb else 0.0
+                # the reference divides the stream-time-base values by AV_TIME_BASE (TaskDecodeFrame.cpp:821-822); kept as is
+                p.start_time_sec, p.duration_sec = p.start_time / 1e6, float(st.duration or 0) / 1e6
+                out.append(p)
+        return out
     ColorSpace = property(lambda self: self._av.color_space if self._av else ColorSpace.UNSPEC)   # raw video carries no tags
     ColorRange = property(lambda self: self._av.color_range if self._av else ColorRange.UDEF)
     HostFrameSize = property(lambda self: _host_frame_size(self._fmt, self._w, self._h))
 
-    def _seek(self, seek_ctx) -> None:
+    def _next(self, seek_ctx) -> Tuple[Optional[np.ndarray], Optional[TaskExecInfo]]:
+        """the next frame, or the frame a seek lands on; (None, info) when there is none (info None: end / decode error)"""
         if seek_ctx is None:
-            return
+            return self._read(), None
         if self._av is not None:
-            self._av.seek(seek_ctx)
-        else:
-            n = seek_ctx.seek_frame if seek_ctx.IsByNumber else int(round(seek_ctx.seek_tssec * self._framerate))
-            self._pos = max(0, min(int(n), self._num_frames))
+            return self._av.seek_decode(seek_ctx)
+        n = seek_ctx.seek_frame if seek_ctx.IsByNumber else int(round(seek_ctx.seek_tssec * self._framerate))
+        self._pos = max(0, min(int(n), self._num_frames))
+        return self._read(), None
 
     def _fill(self, pkt_data) -> None:
         """PacketData of the frame just read (the CPU stand-in knows the presentation order only)"""
@@ -309,10 +456,9 @@ class PyDecoder:
                           ) -> Tuple[bool, TaskExecInfo]:
         if self.IsAccelerated:
             return False, TaskExecInfo.FAIL
-        self._seek(seek_ctx)
-        data = self._read()
+        data, why = self._next(seek_ctx)
         if data is None:
-            return False, self._end()
+            return False, (why or self._end())
         self._fill(pkt_data)
         if frame.nbytes != data.nbytes:
             frame.resize((data.nbytes // frame.itemsize,), refcheck=False)
@@ -332,10 +478,9 @@ class PyDecoder:
             return False, TaskExecInfo.INVALID_INPUT
         if (surf.Width, surf.Height) != (self._w, self._h) or surf.Format != self._fmt:
             return False, TaskExecInfo.INVALID_INPUT
-        self._seek(seek_ctx)
-        data = self._read()
+        data, why = self._next(seek_ctx)
         if data is None:
-            return False, self._end()
+            return False, (why or self._end())
         self._fill(pkt_data)
         return self._uploader.Run(data, surf)
 
@@ -419,34 +564,51 @@ class PyNvEncoder:
         names = self._CODECS.get(st.pop("codec", "h264").lower())
         if names is None:
             raise RuntimeError("PyNvEncoder: codec must be h264 or hevc")
+        self._names, self._fps, self._st, self._av = names, int(float(st.pop("fps", "30"))), st, av
+        self._ctx = self._open()
+        self._n, self._drained = 0, False
+        self._gpu_id = int(gpu_id)
+        self._stream = int(stream) if stream is not None else HipResMgr.Instance().GetStream(self._gpu_id)
+        self._down = PySurfaceDownloader(self._gpu_id, self._stream)
+        self._verbose = verbose
+
+    def _open(self):
+        """A fresh libavcodec encoder context from the stored settings.  Configured for ZERO DELAY (no B frames, no
+        look-ahead, no frame threads; `tune=zerolatency` for libx264 / libx265 unless the caller chose a tune): NVENC's
+        default presets hand every frame's packet back at once, and the reference's `sync` mode relies on it
+        (PyNvEncoder.cpp:496-602).  An encoder that has been drained (Flush) is at EOF for good -- avcodec_send_frame
+        returns AVERROR_EOF -- so the next frame after a Flush gets a new context from here."""
+        from fractions import Fraction
+
+        av, st = self._av, dict(self._st)
         ctx = None
-        for name in names:
+        for name in self._names:
             try:
                 ctx = av.CodecContext.create(name, "w")
+                used = name
                 break
             except Exception:           # this FFmpeg build lacks the encoder: try the next name
                 continue
         if ctx is None:
-            raise RuntimeError(f"PyNvEncoder: no {names[-1]} encoder in this FFmpeg build")
-        fps = int(float(st.pop("fps", "30")))
+            raise RuntimeError(f"PyNvEncoder: no {self._names[-1]} encoder in this FFmpeg build")
+        fps = self._fps
         ctx.width, ctx.height = self._w, self._h
         ctx.pix_fmt = "yuv420p"
         ctx.time_base = Fraction(1, max(fps, 1))
-        try:
-            ctx.framerate = Fraction(max(fps, 1), 1)
-        except Exception:
-            pass
+        for attr, val in (("framerate", Fraction(max(fps, 1), 1)), ("max_b_frames", 0), ("thread_count", 1)):
+            try:
+                setattr(ctx, attr, val)
+            except Exception:
+                pass
         if "bitrate" in st:
             b = st.pop("bitrate").upper()
             ctx.bit_rate = int(float(b.rstrip("KM")) * (1000 if b.endswith("K") else 1000000 if b.endswith("M") else 1))
         if "gop" in st:
             ctx.gop_size = int(st.pop("gop"))
+        if used.startswith("libx26"):
+            st.setdefault("tune", "zerolatency")
         ctx.options = st
-        self._ctx, self._av, self._n = ctx, av, 0
-        self._gpu_id = int(gpu_id)
-        self._stream = int(stream) if stream is not None else HipResMgr.Instance().GetStream(self._gpu_id)
-        self._down = PySurfaceDownloader(self._gpu_id, self._stream)
-        self._verbose = verbose
+        return ctx
 
     Width = property(lambda self: self._w)
     Height = property(lambda self: self._h)
@@ -489,12 +651,17 @@ class PyNvEncoder:
         frame = self._av.VideoFrame.from_ndarray(host.reshape(h * 3 // 2, w), format="yuv420p")
         frame.pts = self._n
         self._n += 1
-        got = self._emit(self._ctx.encode(frame), packet, append)
-        if sync and not got:                       # the reference's sync mode returns every frame's packet at once
-            got = self._emit(self._ctx.encode(None), packet, append)
-        return got
+        if self._drained:                          # a drained libavcodec encoder is at EOF: start a new one
+            self._ctx, self._drained = self._open(), False
+        # zero-delay configuration (_open): this frame's packet comes back from this call, `sync` or not; an encoder that
+        # still holds frames back (a codec that ignores the settings) simply returns False -- never drained per frame,
+        # which would put it in EOF state for the next one
+        return self._emit(self._ctx.encode(frame), packet, append)
 
     def Flush(self, packets: np.ndarray) -> bool:
+        if self._drained:
+            return self._emit([], packets, False)
+        self._drained = True
         return self._emit(self._ctx.encode(None), packets, False)
 
     def FlushSinglePacket(self, packets: np.ndarray) -> bool:

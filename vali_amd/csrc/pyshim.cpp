@@ -237,6 +237,11 @@ PYBIND11_MODULE(_vali_shim, m) {
     return n;
   });
   m.def("device_set", [](int device) { check(vali_device_set(device), "device_set"); });
+  m.def("device_get", []() {
+    int d = -1;
+    check(vali_device_get(&d), "device_get");
+    return d;
+  });
   m.def("ptr_device", [](uintptr_t p) {
     int d = -1;
     check(vali_ptr_device(P(p), &d), "vali_ptr_device");

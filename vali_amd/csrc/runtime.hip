@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <memory>
 #include <chrono>
 #include <mutex>
 #include <unordered_map>
@@ -194,6 +195,12 @@ int vali_device_set(int device) {
   return VALI_OK;
 }
 
+int vali_device_get(int* device) {
+  VALI_REQUIRE(device, "null argument");
+  VALI_HIP_CHECK(hipGetDevice(device));
+  return VALI_OK;
+}
+
 int vali_ptr_device(const void* dptr, int* device) {
   VALI_REQUIRE(dptr && device, "null argument");
   hipPointerAttribute_t attr;
@@ -211,10 +218,16 @@ int vali_stream_create(int device, vali_stream_t* stream) {
   return VALI_OK;
 }
 
+namespace {
+void drop_wait_slot(int device, hipStream_t s);   // the stream's completion word (below) goes with the stream
+}
+
 int vali_stream_destroy(int device, vali_stream_t stream) {
   VALI_DEVICE(device);
-  if (stream)
+  if (stream) {
+    drop_wait_slot(device, as_stream(stream));
     VALI_HIP_CHECK(hipStreamDestroy(as_stream(stream)));
+  }
   return VALI_OK;
 }
 
@@ -235,18 +248,32 @@ namespace {
 struct WaitSlot {
   unsigned* host = nullptr;
   unsigned* dev = nullptr;
-  unsigned value = 0;
+  unsigned value = 0;   // last value handed out; read and written under `order` only
+  std::mutex order;     // taking a value and enqueueing its write are ONE step: values reach the stream in order
+  ~WaitSlot() {
+    if (host)
+      (void)hipHostFree(host);
+  }
 };
 std::mutex g_wait_mutex;
-std::unordered_map<uint64_t, WaitSlot> g_wait_slots; // (device, stream) -> slot; slots live as long as the library
+// (device, stream) -> slot.  shared_ptr: a waiter keeps its slot alive while vali_stream_destroy drops the map's entry
+std::unordered_map<uint64_t, std::shared_ptr<WaitSlot>> g_wait_slots;
 
-WaitSlot* wait_slot(int device, hipStream_t s) {
+uint64_t wait_key(int device, hipStream_t s) { return ((uint64_t)(unsigned)device << 56) ^ (uint64_t)(uintptr_t)s; }
+
+void drop_wait_slot(int device, hipStream_t s) {
   std::lock_guard<std::mutex> lock(g_wait_mutex);
-  const uint64_t key = ((uint64_t)(unsigned)device << 56) ^ (uint64_t)(uintptr_t)s;
+  g_wait_slots.erase(wait_key(device, s));   // a recycled stream handle starts with a fresh slot
+}
+
+std::shared_ptr<WaitSlot> wait_slot(int device, hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_wait_mutex);
+  const uint64_t key = wait_key(device, s);
   auto it = g_wait_slots.find(key);
   if (it != g_wait_slots.end())
-    return &it->second;
-  WaitSlot w;
+    return it->second;
+  auto wp = std::make_shared<WaitSlot>();
+  WaitSlot& w = *wp;
   void* h = nullptr;
   if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) {
     (void)hipGetLastError();
@@ -261,17 +288,29 @@ WaitSlot* wait_slot(int device, hipStream_t s) {
   w.host = (unsigned*)h;
   w.dev = (unsigned*)d;
   *w.host = 0;
-  return &g_wait_slots.emplace(key, w).first->second;
+  g_wait_slots.emplace(key, wp);
+  return wp;
 }
 } // namespace
 
 int vali_stream_wait(int device, vali_stream_t stream) {
   VALI_DEVICE(device);
   hipStream_t s = as_stream(stream);
-  WaitSlot* w = tuning(VALI_TUNE_BLOCKING_WAIT) == 0 ? wait_slot(device, s) : nullptr;
+  // Two threads blocking on the SAME stream (tasks built without a stream share their GPU's manager stream, and the GIL
+  // is released around this call) take their values and enqueue their writes under the slot's lock: the word only ever
+  // grows, and "word >= my value" means everything enqueued before my write has finished.
+  std::shared_ptr<WaitSlot> w = tuning(VALI_TUNE_BLOCKING_WAIT) == 0 ? wait_slot(device, s) : nullptr;
   if (w) {
-    const unsigned v = ++w->value;
-    if (hipStreamWriteValue32(s, w->dev, v, 0) == hipSuccess) {
+    unsigned v;
+    hipError_t we;
+    {
+      std::lock_guard<std::mutex> order(w->order);
+      v = w->value + 1;
+      we = hipStreamWriteValue32(s, w->dev, v, 0);
+      if (we == hipSuccess)
+        w->value = v;
+    }
+    if (we == hipSuccess) {
       const auto t0 = std::chrono::steady_clock::now();
       for (unsigned spin = 1;; ++spin) {
         if ((int)(__atomic_load_n((volatile unsigned*)w->host, __ATOMIC_ACQUIRE) - v) >= 0)

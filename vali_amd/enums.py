@@ -73,6 +73,23 @@ class Interpolation(enum.IntEnum):
     LANCZOS = 16
 
 
+class DecodeMode(enum.IntEnum):
+    """reference: src/TC/inc/CodecsSupport.hpp:148, binding VALI.cpp:184-187."""
+    KEY_FRAMES = 0
+    ALL_FRAMES = 1
+
+
+class FfmpegLogLevel(enum.IntEnum):
+    """reference: VALI.cpp:48-56, 206-214 (the AV_LOG_* values of libavutil/log.h)."""
+    PANIC = 0
+    FATAL = 8
+    ERROR = 16
+    WARNING = 24
+    INFO = 32
+    VERBOSE = 40
+    DEBUG = 48
+
+
 class DLDeviceType(enum.IntEnum):
     """DLPack device types.  The reference exports kDLCUDA only
     (src/TC/src/SurfacePlane.cpp:255); on ROCm the exchange type is kDLROCM."""
@@ -128,6 +145,6 @@ class TaskExecDetails:
 
 def export_values(namespace: dict) -> None:
     """pybind11's export_values(): enum members become module attributes."""
-    for en in (PixelFormat, TaskExecInfo, ColorSpace, ColorRange, DLDeviceType):
+    for en in (PixelFormat, TaskExecInfo, ColorSpace, ColorRange, DLDeviceType, DecodeMode, FfmpegLogLevel):
         for member in en:
             namespace[member.name] = member

@@ -308,6 +308,9 @@ class _HipBackend:
     def new_event(self):
         return self.shim.event_create(self.gpu)
 
+    def free_event(self, event) -> None:
+        self.shim.event_destroy(self.gpu, event)
+
     def upload(self, host: np.ndarray, frame_bytes: int, srcs: Sequence[Surface]) -> None:
         base = host.ctypes.data
         for i, s in enumerate(srcs):
@@ -346,7 +349,7 @@ class _HipBackend:
 
 
 class _Slot:
-    __slots__ = ("host", "srcs", "dsts", "batch", "uploaded", "done", "busy", "tag")
+    __slots__ = ("host", "srcs", "dsts", "batch", "uploaded", "done", "busy", "tag", "valid")
 
 
 class IngestRing:
@@ -380,9 +383,10 @@ class IngestRing:
             s.host = self.backend.host_buffer(self.n * self.frame_bytes)
             s.srcs, s.dsts, s.batch = pipe._make_batch(self.n)
             s.uploaded, s.done = self.backend.new_event(), self.backend.new_event()
-            s.busy, s.tag = False, None
+            s.busy, s.tag, s.valid = False, None, 0
             self.slots.append(s)
         self._next = 0
+        self._closed = False
         self._pending: List[_Slot] = []        # submitted, outputs not handed out yet; submission order
         self.frames_submitted = 0
 
@@ -404,13 +408,20 @@ class IngestRing:
         return out
 
     def acquire(self) -> _Slot:
+        if self._closed:
+            raise RuntimeError("IngestRing is closed")
         s = self.slots[self._next]
         if s in self._pending:
             raise RuntimeError("IngestRing.acquire: the next slot still holds outputs nobody took -- call reap() first")
         self._next = (self._next + 1) % len(self.slots)
         return s
 
-    def submit(self, slot: _Slot, tag=None) -> Tuple[bool, TaskExecInfo]:
+    def submit(self, slot: _Slot, tag=None, valid: Optional[int] = None) -> Tuple[bool, TaskExecInfo]:
+        """`valid`: how many of the slot's n frames the producer really wrote (a final chunk may be short); the operator
+        still runs on the whole slot (one prepared batch), `slot.valid` tells the consumer how many outputs count."""
+        if self._closed:
+            raise RuntimeError("IngestRing is closed")
+        slot.valid = self.n if valid is None else max(0, min(int(valid), self.n))
         b = self.backend
         b.upload(slot.host, self.frame_bytes, slot.srcs)
         b.record(slot.uploaded, b.copy_stream)
@@ -433,24 +444,45 @@ class IngestRing:
 
     def feed(self, chunks, fill: Optional[Callable] = None):
         """The loop of the class comment as a generator: every item of `chunks` is a uint8 array of up to n frames (or
-        anything `fill(slot.host, item)` understands); yields (tag, dsts) of finished slots in submission order.  The
-        consumer runs between two submissions, i.e. before the slot it is looking at can be reused."""
+        anything `fill(slot.host, item)` understands, which may return the number of frames it wrote); yields
+        (tag, dsts) of finished slots in submission order -- only the VALID outputs: a final chunk shorter than a slot
+        yields that many surfaces, never the stale frames an earlier chunk left in the slot's tail.  The consumer runs
+        between two submissions, i.e. before the slot it is looking at can be reused."""
         for tag, item in enumerate(chunks):
             for s in self.reap():
-                yield s.tag, s.dsts
+                yield s.tag, s.dsts[:s.valid]
             slot = self.acquire()
             if fill is not None:
-                fill(slot.host, item)
+                wrote = fill(slot.host, item)
+                valid = self.n if wrote is None else int(wrote)
             else:
                 a = np.asarray(item, np.uint8).reshape(-1)
+                if a.size % self.frame_bytes or a.size > self.n * self.frame_bytes:
+                    raise ValueError(f"IngestRing.feed: a chunk is 1..{self.n} whole frames of {self.frame_bytes} bytes")
                 slot.host[:a.size] = a
-            ok, info = self.submit(slot, tag)
+                valid = a.size // self.frame_bytes
+            ok, info = self.submit(slot, tag, valid)
             if not ok:
                 raise RuntimeError(f"IngestRing: operator failed: {info}")
         for s in self.drain():
-            yield s.tag, s.dsts
+            yield s.tag, s.dsts[:s.valid]
 
     def close(self) -> None:
+        """Waits for everything submitted, then releases the pinned buffers and the events.  The slots' numpy views point
+        INTO the pinned allocations, so they are dropped first: after close() `slot.host` is None and acquire / submit
+        raise -- a late write can no longer land in freed memory."""
+        if self._closed:
+            return
         self.drain()
+        self._closed = True
+        for s in self.slots:
+            s.host = None
+            if hasattr(self.backend, "free_event"):
+                for ev in (s.uploaded, s.done):
+                    try:
+                        self.backend.free_event(ev)
+                    except Exception:
+                        pass
+            s.uploaded = s.done = None
         if hasattr(self.backend, "close"):
             self.backend.close()

@@ -275,17 +275,31 @@ class _SurfaceTask:
         self._batches = {}    # (src descriptors, dst descriptors) -> SurfaceBatch, see _batch_of
 
     def _bind_null_stream(self):
-        """Tasks on the null stream: every Run* / PrepareBatch first makes the task's GPU the thread's current device
-        (vali_device_set).  Done by wrapping the bound methods of THIS instance, so tasks on real streams -- whose device
-        the library reads off the stream -- keep their call path untouched."""
-        gpu = self._gpu_id
+        """Tasks on the null stream: a null hipStream_t carries no device, so every Run* / PrepareBatch makes the task's
+        GPU the thread's current device for the duration of the call and puts the caller's device BACK afterwards (the
+        reference's CudaCtxPush / pop, CudaUtils.hpp:77-90): a host application that runs a task on (gpu 1, stream 0)
+        keeps allocating on the device it had selected.  Done by wrapping the methods of THIS instance, so tasks on real
+        streams -- whose device the library reads off the stream -- keep their call path untouched; the wrappers hold a
+        weak reference to the task (no self-referencing cycle: the task's events and memo go when its last user does)."""
+        import weakref
+
+        gpu, ref = self._gpu_id, weakref.ref(self)
         for name in dir(type(self)):
             if name.startswith("Run") or name == "PrepareBatch":
-                fn = getattr(self, name)
+                unbound = getattr(type(self), name)
+                if isinstance(getattr(type(self), name, None), (staticmethod, classmethod)) or not callable(unbound):
+                    continue
 
-                def call(*a, _fn=fn, **k):
-                    shim.device_set(gpu)
-                    return _fn(*a, **k)
+                def call(*a, _fn=unbound, **k):
+                    me = ref()
+                    prev = shim.device_get()
+                    if prev != gpu:
+                        shim.device_set(gpu)
+                    try:
+                        return _fn(me, *a, **k)
+                    finally:
+                        if prev != gpu and prev >= 0:
+                            shim.device_set(prev)
                 setattr(self, name, call)
 
     def _batch_of(self, batch, dsts):
