@@ -451,3 +451,89 @@ def test_borrowed_surfaces_with_odd_pitch_and_base(vali, gpu, oracle, geom, skew
     assert np.array_equal(got, want)
     pad = np.lib.stride_tricks.as_strided(out[skew + dw:], (dh - 1, dpad - dw), (dpad, 1))
     assert np.all(pad == 0x5a) and np.all(out[:skew] == 0x5a)    # the bytes between and in front of the rows are untouched
+
+
+# ---- planes that GROW vertically: filtered rows in registers (vali_amd/csrc/resize_rows.hip) -----------------------------
+# geometry -> what it reaches: the benchmark's 720p -> 1080p; one tile per row (both image edges in the same tile); dst widths
+# that are not multiples of 4 / of 2 (byte tails of the exchanged dwords); source widths that are not multiples of 4 (the
+# last group patched); a single source row / column pair; > 3x enlargements (the emit loop behind the two straight-line
+# rows); grow down the rows while the columns SHRINK a little (still fits 64 groups) or a lot (k_resize_taps keeps it);
+# heights around the rows-per-wave forms
+ROWS_GEOMS = [(1280, 720, 1920, 1080), (640, 360, 854, 480), (100, 40, 250, 90), (64, 48, 640, 480), (62, 30, 201, 67),
+              (126, 50, 255, 129), (1918, 100, 2046, 110), (848, 464, 1278, 718), (2, 2, 14, 10), (4, 1, 9, 3),
+              (300, 20, 310, 151), (1000, 300, 940, 420), (1200, 200, 400, 260), (130, 66, 516, 67)]
+
+
+@pytest.mark.parametrize("fmt", ["NV12", "Y", "YUV420", "P10", "YUV444_10bit", "YUV422", "RGB_PLANAR", "RGB"])
+@pytest.mark.parametrize("geom", ROWS_GEOMS)
+@pytest.mark.parametrize("interp", ["lanczos", "cubic"])
+def test_growing_planes_bit_exact(vali, gpu, oracle, fmt, geom, interp):
+    sw, sh, dw, dh = geom
+    if fmt in ("NV12", "YUV420", "P10") and ((sw | sh | dw | dh) & 1):
+        pytest.skip("4:2:0 surfaces have even sizes")
+    if fmt == "YUV422" and ((sw | dw) & 1):
+        pytest.skip("4:2:2 surfaces have even widths")
+    dt = DT.get(fmt, np.uint8)
+    n = vali.Surface.Make(vali.PixelFormat[fmt], sw, sh, gpu).HostSize // np.dtype(dt).itemsize
+    rng = np.random.default_rng(sw * 7 + dh)
+    host = (rng.random(n) * (1023 if dt == np.uint16 else 255)).astype(dt)
+    if dt == np.uint16:
+        host[rng.integers(0, n, 20)] = 65535                     # saturation of the 16-bit store
+    mode = vali.Interpolation.LANCZOS if interp == "lanczos" else vali.Interpolation.CUBIC
+    want = oracle.resize_surface(host, fmt, sw, sh, dw, dh, interp)
+    assert np.array_equal(roundtrip(vali, gpu, fmt, host, sw, sh, dw, dh, interp=mode), want)
+    with vali.tuning.Override(RESIZE_ROWS=0):                    # round 2's kernel: the second implementation of the same bits
+        assert np.array_equal(roundtrip(vali, gpu, fmt, host, sw, sh, dw, dh, interp=mode), want)
+    with vali.tuning.Override(RESIZE_FORCE_GATHER=1):            # the direct-gather form inside the new kernel
+        assert np.array_equal(roundtrip(vali, gpu, fmt, host, sw, sh, dw, dh, interp=mode), want)
+
+
+@pytest.mark.parametrize("rows_mode", [0, 1, 2, 3])
+def test_growing_planes_batch_and_rows_per_wave(vali, gpu, oracle, rows_mode):
+    """a batch under every rows-per-wave form (2 / 8 / 32), NV12 (both channel counts in one launch) and P10"""
+    for fmt, dt, top in (("NV12", np.uint8, 256), ("P10", np.uint16, 1024)):
+        sw, sh, dw, dh, n = 640, 360, 962, 542, 5
+        rng = np.random.default_rng(91)
+        pf = vali.PixelFormat[fmt]
+        frames = [rng.integers(0, top, sw * sh * 3 // 2).astype(dt) for _ in range(2)]
+        srcs = [vali.Surface.Make(pf, sw, sh, gpu) for _ in range(n)]
+        dsts = [vali.Surface.Make(pf, dw, dh, gpu) for _ in range(n)]
+        for i, s_ in enumerate(srcs):
+            assert vali.PyFrameUploader(gpu).Run(frames[i % 2].view(np.uint8), s_)[0]
+        with vali.tuning.Override(RESIZE_NO_SEPARABLE=rows_mode):
+            assert vali.PySurfaceResizer(pf, gpu).RunBatch(srcs, dsts) == (True, vali.TaskExecInfo.SUCCESS)
+        wants = [oracle.resize_surface(f, fmt, sw, sh, dw, dh, "lanczos") for f in frames]
+        for i, d in enumerate(dsts):
+            out = np.zeros(d.HostSize, np.uint8)
+            assert vali.PySurfaceDownloader(gpu).Run(d, out)[0]
+            assert np.array_equal(out.view(dt), wants[i % 2]), (fmt, i)
+
+
+@pytest.mark.parametrize("geom", [(334, 78, 501, 117), (333, 40, 500, 61), (16, 8, 40, 17)])
+@pytest.mark.parametrize("skew", [0, 1, 5])
+def test_growing_planes_borrowed_surfaces_with_tight_pitch(vali, gpu, oracle, geom, skew):
+    """Y planes borrowed from torch tensors whose pitch IS the width (+0 / +3) and whose last row ends where the buffer
+    ends: a width that is not a multiple of 4 with no padding behind it takes the direct-gather form (the 4-pixel groups
+    of the staged form would read past the buffer), padded ones the staged form with misaligned rows"""
+    import torch
+
+    sw, sh, dw, dh = geom
+    for extra in (0, 3):
+        rng = np.random.default_rng(sw + dh + skew + extra)
+        host = rng.integers(0, 256, sw * sh, dtype=np.uint8)
+        sp, dpad = sw + extra, dw + 7
+        sraw = torch.zeros(skew + (sh - 1) * sp + sw, dtype=torch.uint8, device="cuda")   # ends with the last row
+        sview = torch.as_strided(sraw, (sh, sw), (sp, 1), skew)
+        sview.copy_(torch.from_numpy(host.reshape(sh, sw)))
+        draw = torch.full((skew + dh * dpad,), 0x5a, dtype=torch.uint8, device="cuda")
+        dview = torch.as_strided(draw, (dh, dw), (dpad, 1), skew)
+        torch.cuda.synchronize()
+        src = vali.Surface.from_dlpack(torch.utils.dlpack.to_dlpack(sview), vali.Y)
+        dst = vali.Surface.from_dlpack(torch.utils.dlpack.to_dlpack(dview), vali.Y)
+        assert vali.PySurfaceResizer(vali.Y, gpu).Run(src, dst) == (True, vali.TaskExecInfo.SUCCESS)
+        out = draw.cpu().numpy()
+        got = np.lib.stride_tricks.as_strided(out[skew:], (dh, dw), (dpad, 1))
+        want = oracle.resize_surface(host, "Y", sw, sh, dw, dh, "lanczos").reshape(dh, dw)
+        assert np.array_equal(got, want), extra
+        pad = np.lib.stride_tricks.as_strided(out[skew + dw:], (dh - 1, dpad - dw), (dpad, 1))
+        assert np.all(pad == 0x5a) and np.all(out[:skew] == 0x5a)

@@ -29,6 +29,12 @@ struct ResizeArgs {
 int launch_resize_taps(const ResizeArgs& a, int elem, int taps, int src_w, int src_h, int dst_w, int dst_h, int n,
                        hipStream_t stream);
 
+// The same rows-first arithmetic with the filtered rows in registers (resize_rows.hip): 8 / 16-bit planes of 1 / 2 channels
+// that grow vertically and whose 256-element tile spans at most 64 groups of 4 source pixels (resize_rows_fits).
+bool resize_rows_fits(const ResizeJob& j, int elem, int src_w, int dst_w, int taps);
+int launch_resize_rows(const ResizeArgs& a, int elem, int taps, int src_w, int src_h, int dst_w, int dst_h, int n,
+                       hipStream_t stream);
+
 // The same filters for jobs whose planes all SHRINK (or keep) their height -- columns first (resize_cols.hip).  Which
 // plane takes which order is part of the specification (oracle/vali_oracle.c resize_plane_taps): src_h >= dst_h.
 int launch_resize_cols(const ResizeArgs& a, int elem, int taps, int src_w, int src_h, int dst_w, int dst_h, int n,

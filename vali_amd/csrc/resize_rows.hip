@@ -1,0 +1,514 @@
+// Lanczos-3 / bicubic resize of planes that GROW vertically (dst_h > src_h: the upscale to display size), rows first.
+//
+// Specification (oracle/vali_oracle.c resize_plane_taps, the src_h < dst_h branch; reference call sites
+// src/TC/src/TaskResizeSurface.cpp:67,116,224,273 and UDSurface.cpp:45,72 -- NPPI_INTER_LANCZOS everywhere):
+//   h_s[x] = e + o,  e = wx0 t0 ; e = fma(wx_k, t_k, e) over the even taps, o likewise over the odd ones   (source row s)
+//   v      = wy0 h_0 ; v = fma(wy_r, h_r, v)                                                                (window rows r)
+// h depends on (source row, dst x) only, so a source row is filtered along x ONCE and every dst row is a vertical
+// combination of TAPS filtered rows.  resize_taps.hip (round 2) does that through two LDS structures -- the staged BYTES of
+// the source row, from which every lane funnel-shifts and converts its own 6 taps, and a ring of filtered rows that the
+// vertical pass reads back -- 44 lane-instructions per output sample, 122 VGPRs, 4 waves per SIMD: 0.19 of the HBM
+// roofline at 720p -> 1080p.  This kernel keeps the arithmetic and changes where the data sits:
+//
+//   * an enlargement re-uses every source sample ~TAPS / scale times along the row, so the row is converted to FLOAT once,
+//     at staging time (4 pixels per lane and row: one 4 / 8 / 16-byte load, TAPS rows in flight), channels de-interleaved
+//     (every plane is the one-channel problem);
+//   * the staged row exists twice, A[j] = s[j] and B[j] = s[j + 1] (the neighbour's first pixel arrives by DPP
+//     `wave_shl:1`): the six taps of a sample are three ALIGNED 8-byte reads of (t0,t1) (t2,t3) (t4,t5) from A or from B by
+//     the parity of its first tap -- exactly the (even, odd) operand pairs of three `v_pk_fma_f32`, no shifts, no converts;
+//   * a lane owns 2 ADJACENT dst elements in each of 2 groups of 128 (elements 2l, 2l+1 and 128+2l, 128+2l+1 of the
+//     tile): neighbouring lanes read 2 x scale floats apart, so the 32 lanes of an LDS pass stay inside one 64-bank window at
+//     every enlargement >= 1.07 (no bank conflicts), and the pair is the natural operand of the vertical `v_pk_fma_f32`;
+//   * the TAPS filtered rows of the vertical window live in REGISTERS (TAPS x 2 pairs per lane; the walk over the source
+//     rows is unrolled TAPS times, so the ring position is a compile-time constant): the vertical pass reads no LDS;
+//   * the row weights of a wave's dst rows sit in LDS as pre-splatted pairs (w,w) and arrive as broadcast 16-byte reads:
+//     3 LDS instructions per dst row instead of 7 `v_readlane`, and no register copies in front of the packed FMAs;
+//   * 8-bit output: the 2 x 2 bytes of a lane and those of its neighbour (DPP quad_perm) make one dword per lane -- even
+//     lanes store the pair's bytes of group 0, odd lanes those of group 1 (two contiguous 128-byte runs per wave and row).
+//
+// Geometries that do not fit (packed RGB and float planes, source spans wider than 64 groups of 4 pixels, i.e. planes
+// that grow vertically but shrink along x) stay on k_resize_taps; rows whose last 4-pixel group would read past the
+// pitch (foreign tight-pitch memory with a width that is not a multiple of 4) take the direct-gather form below.
+#include "resize_common.hpp"
+#include "resize_weights.hpp"
+
+#include <type_traits>
+
+namespace vali {
+
+constexpr int kRwPadL = 4;       // floats in front of the first staged pixel (left edge replicas; keeps 16-byte alignment)
+constexpr int kRwTile = 256;     // dst ELEMENTS per wave and row: 2 groups x 64 lanes x 2 adjacent elements
+
+__device__ __forceinline__ float rw_wave_shl1(float v) { // lane l gets lane l + 1's value
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ u32 rw_swap_pairs(u32 v) { // lane l gets lane l ^ 1's value (quad_perm:[1,0,3,2])
+  return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xb1, 0xf, 0xf, false);
+}
+
+// the 4 pixels x ES channels of one lane's group, as loaded
+template <typename T, int ES> struct RwGroup {
+  static constexpr int kWords = 4 * ES * (int)sizeof(T) / 4; // 1, 2, 2, 4 dwords
+  u32 w[kWords];
+};
+template <typename T, int ES> __device__ __forceinline__ RwGroup<T, ES> rw_load(const uint8_t* p) {
+  RwGroup<T, ES> g;
+  if constexpr (RwGroup<T, ES>::kWords == 1) {
+    g.w[0] = gload_u<u32>(p);
+  } else if constexpr (RwGroup<T, ES>::kWords == 2) {
+    const v2u32 q = gload_u<v2u32>(p);
+    g.w[0] = q.x; g.w[1] = q.y;
+  } else {
+    const v4u32 q = gload_u<v4u32>(p);
+    g.w[0] = q.x; g.w[1] = q.y; g.w[2] = q.z; g.w[3] = q.w;
+  }
+  return g;
+}
+// element n (= pixel * ES + channel) of the group as a float
+template <typename T, int ES, int N> __device__ __forceinline__ float rw_elem(const RwGroup<T, ES>& g) {
+  if constexpr (sizeof(T) == 1)
+    return ubyte_f32<N % 4>(g.w[N / 4]);
+  else
+    return (float)((N % 2) ? (g.w[N / 2] >> 16) : (g.w[N / 2] & 0xffffu));
+}
+
+template <int TAPS> __device__ __forceinline__ float rw_dot(const v2f32 (&wp)[TAPS / 2], const v2f32 (&t)[TAPS / 2]) {
+  v2f32 acc = wp[0] * t[0];
+#pragma unroll
+  for (int j = 1; j < TAPS / 2; ++j)
+    acc = __builtin_elementwise_fma(wp[j], t[j], acc);
+  return acc.x + acc.y;
+}
+
+// LDS of ONE wave (floats): [channel 0: A (kRwSf) B (kRwSf)] [channel 1: A B] [wtab: ROWS x (4 + 2 TAPS)] [cnt: 64].
+// kRwSf = 288: room for all 64 groups of 4 pixels plus both pads (no lane is ever predicated off in the staging writes), and
+// 288 = 32 (mod 64): a lane reading copy A and one reading copy B at the same row position sit 32 banks apart.
+constexpr int kRwSf = 288;
+
+__host__ __device__ constexpr int rw_wave_floats(int es, int rows, int taps) { return es * 2 * kRwSf + rows * (4 + 2 * taps) + 64; }
+
+// One wave: 256 ELEMENTS x ROWS dst rows of a plane whose pixels are ES interleaved elements (1: Y and the planes of
+// planar formats, 2: the UV plane of NV12 / P10).  The four waves of a workgroup are stacked down the rows and share their
+// columns: each evaluates ONE of the four column tap sets a lane needs (a Lanczos weight set is ~110 instructions) and
+// publishes it through LDS.
+template <typename T, int ES, int TAPS, int ROWS>
+__device__ __forceinline__ void rows_tile(const uint8_t* sp, int spitch, int sw, int sh, uint8_t* dp, int dpitch,
+                                          int dw, int dh, u32 tx, u32 ty, bool allow_staged, float* wg_lds, int wave_floats) {
+  static_assert(ROWS <= kWave, "row taps are evaluated one row per lane");
+  constexpr int kBefore = LzTap<TAPS>::kBefore;
+  constexpr int EB = (int)sizeof(T);
+  constexpr int WT = 4 + 2 * TAPS;    // floats per row of the weight table: [i, -, -, -, (w0,w0), (w1,w1) ...]
+  constexpr int NS = ES == 1 ? 2 : 1; // tap sets per group: two pixels (ES = 1) or one pixel's (U, V)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int e0 = tx * kRwTile;
+  const int dwe = dw * ES;
+  const int y_first = (ty * kWavesPerBlock + wave) * ROWS;
+  const float scale_x = (float)sw / (float)dw, scale_y = (float)sh / (float)dh;
+  float* const lds = wg_lds + wave * wave_floats;
+  float* const stage = lds;
+  float* const wtab = lds + ES * 2 * kRwSf;
+  int* const cnt = reinterpret_cast<int*>(wtab + ROWS * WT);
+
+  // wave-uniform source span of the tile, in pixels (the same for the four waves of the workgroup)
+  const int px_first = e0 / ES, px_last = min(e0 + kRwTile - 1, dwe - 1) / ES;
+  const int ux0 = (int)__builtin_floorf((float)px_first * scale_x) - kBefore;            // unclamped
+  const int ux1 = min((int)__builtin_floorf((float)px_last * scale_x), sw) + TAPS - 1 - kBefore;
+  const int pix0 = max(ux0, 0) & ~3;                           // first staged pixel: group-aligned in the plane
+  const int ngroups = (ux1 - pix0) / 4 + 1;                    // groups of 4 pixels up to the last tap
+  const bool pad_left = ux0 < 0, pad_right = ux1 > sw - 1;
+  const bool staged = allow_staged && ngroups <= kWave && (long long)((sw + 3) & ~3) * (ES * EB) <= (long long)spitch;
+
+  // this lane's output elements: group g -> elements e0 + 128 g + 2 lane, + 1
+  const int eg[2] = {e0 + 2 * lane, e0 + 128 + 2 * lane};
+
+  if (staged) {
+    // ---- column tap sets: wave w evaluates set w (ES = 1: (group, pixel) = (w >> 1, w & 1); ES = 2: group w, waves 0 / 1)
+    v2f32 wq[2][NS][TAPS / 2];
+    int addr[2][NS];
+    {
+      const int g = ES == 1 ? wave >> 1 : wave & 1, q = ES == 1 ? wave & 1 : 0;
+      const int e = min(e0 + 128 * g + 2 * lane + q, dwe - 1);
+      const LzTap<TAPS> c = make_lz_tap<TAPS>(e / ES, scale_x);
+      float* mine = lds + 8 * lane;
+      *reinterpret_cast<float4*>(mine) = make_float4(__builtin_bit_cast(float, c.i), c.w[0], c.w[1], c.w[2]);
+      if constexpr (TAPS == 6)
+        *reinterpret_cast<float4*>(mine + 4) = make_float4(c.w[3], c.w[4], c.w[5], 0.0f);
+      else
+        mine[4] = c.w[3];
+      __syncthreads();
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+        for (int qq = 0; qq < NS; ++qq) {
+          const float* from = wg_lds + (ES == 1 ? gg * 2 + qq : gg) * wave_floats + 8 * lane;
+          const float4 a = *reinterpret_cast<const float4*>(from);
+          float w[6] = {a.y, a.z, a.w, 0.0f, 0.0f, 0.0f};
+          if constexpr (TAPS == 6) {
+            const float4 b = *reinterpret_cast<const float4*>(from + 4);
+            w[3] = b.x; w[4] = b.y; w[5] = b.z;
+          } else {
+            w[3] = from[4];
+          }
+#pragma unroll
+          for (int j = 0; j < TAPS / 2; ++j)
+            wq[gg][qq][j] = (v2f32){w[2 * j], w[2 * j + 1]};
+          const int j0 = kRwPadL + (min(__builtin_bit_cast(int, a.x), sw) - kBefore) - pix0; // stage index of tap 0
+          addr[gg][qq] = ((j0 & 1) ? kRwSf + j0 - 1 : j0) * 4;                                // odd: copy B, one float earlier
+        }
+      __syncthreads(); // everybody has read: the regions become the waves' own stages
+    }
+    if (y_first >= dh)
+      return;
+
+    // ---- row taps: lane r evaluates row y_first + r and publishes it (weights pre-splatted for the packed FMAs); cnt[t] =
+    // how many dst rows complete their window with the wave's t-th source row
+    const LzTap<TAPS> vy = make_lz_tap<TAPS>(y_first + (lane & (ROWS - 1)), scale_y);
+    const int last_rr = min(ROWS, dh - y_first) - 1;
+    const int s_begin = __builtin_amdgcn_readlane(vy.i, 0) - kBefore;
+    const int s_end = __builtin_amdgcn_readlane(vy.i, last_rr) + TAPS - 1 - kBefore;
+    cnt[lane] = 0;
+    if (lane < ROWS) {
+      float* row = wtab + lane * WT;
+#pragma unroll
+      for (int k = 0; k < TAPS / 2; ++k)
+        *reinterpret_cast<float4*>(row + 4 + 4 * k) = make_float4(vy.w[2 * k], vy.w[2 * k], vy.w[2 * k + 1], vy.w[2 * k + 1]);
+    }
+    wave_lds_sync();
+    if (lane <= last_rr)
+      __hip_atomic_fetch_add(cnt + (vy.i + TAPS - 1 - kBefore - s_begin), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    wave_lds_sync();
+    const int cntv = cnt[lane]; // (ROWS * scale_y + TAPS <= 64 source rows: the plane grows)
+
+    const uint8_t* const stage_b = reinterpret_cast<const uint8_t*>(stage);
+    // staging: lane m owns pixels pix0 + 4m .. + 3 (lanes past the span re-read its last group: their floats are never used)
+    const int last_group = min((sw - 1) & ~3, pix0 + 4 * (ngroups - 1));
+    const u32 goff = (u32)(min(pix0 + 4 * lane, last_group) * (ES * EB));
+    // right edge: pixels past sw - 1 take the last pixel's value.  keep[k]: pixel k of this lane's group is its own
+    const bool edge = pad_left || pad_right;                                   // wave-uniform
+    const int edge_lane = (sw - 1 - pix0) >> 2, edge_k = (sw - 1 - pix0) & 3;  // wave-uniform
+    bool keep[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      keep[k] = pix0 + 4 * lane + k <= sw - 1;
+
+    RwGroup<T, ES> pf[TAPS];
+    auto issue = [&](int logical, RwGroup<T, ES>& q) {
+      q = rw_load<T, ES>(sp + (u32)(clampi(logical, sh - 1) * spitch) + goff);
+    };
+#pragma unroll
+    for (int j = 0; j < TAPS; ++j) {
+      issue(s_begin + j, pf[j]);
+      __builtin_amdgcn_sched_barrier(0); // rows in ISSUE order: vmcnt retires in order
+    }
+
+    v2f32 ring[TAPS][2]; // filtered rows of the vertical window: [slot][group] = (element 2l, element 2l + 1)
+#pragma unroll
+    for (int j = 0; j < TAPS; ++j)
+      ring[j][0] = ring[j][1] = (v2f32){0.0f, 0.0f};
+
+    // output: 8-bit planes exchange their byte pairs so that every lane stores one dword; the lane's pointer walks down the rows
+    const bool odd = lane & 1;
+    const int est = EB == 1 ? (odd ? e0 + 128 + 2 * (lane - 1) : e0 + 2 * lane) : eg[0]; // first element behind `optr`
+    const u32 sel = odd ? 0x03020706u : 0x05040100u;  // v_perm_b32 {neighbour: bytes 4-7, own: bytes 0-3}, see emit
+    const bool full = e0 + kRwTile <= dwe;            // wave-uniform: every lane of the tile has all its elements
+    uint8_t* optr = dp + (size_t)y_first * dpitch + (size_t)est * EB;
+    const float* wt = wtab + 4;                       // weights of the next dst row
+
+#pragma unroll 1
+    for (int s0 = s_begin; s0 <= s_end; s0 += TAPS) {
+#pragma unroll
+      for (int j = 0; j < TAPS; ++j) {
+        const int cur = s0 + j;
+        const bool live = cur <= s_end; // wave-uniform; rows past the end skip the work, never the load
+        if (live) {
+          // ---- stage source row `cur`: convert once, de-interleave, write A and B
+          auto stage_channel = [&](auto ctag) {
+            constexpr int C = decltype(ctag)::value;
+            float f[4] = {rw_elem<T, ES, 0 * ES + C>(pf[j]), rw_elem<T, ES, 1 * ES + C>(pf[j]),
+                          rw_elem<T, ES, 2 * ES + C>(pf[j]), rw_elem<T, ES, 3 * ES + C>(pf[j])};
+            float* const a = stage + C * 2 * kRwSf;
+            if (edge) { // the tiles at the image's left / right edge only
+              if (pad_right) {
+                const float sel_k = edge_k == 0 ? f[0] : edge_k == 1 ? f[1] : edge_k == 2 ? f[2] : f[3];
+                const float ev = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sel_k), edge_lane));
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                  f[k] = keep[k] ? f[k] : ev;
+              }
+              if (pad_left && lane == 0) { // pixels -1, -2 replicate pixel 0 (pix0 == 0 here)
+                *reinterpret_cast<float4*>(a) = make_float4(f[0], f[0], f[0], f[0]);
+                *reinterpret_cast<float4*>(a + kRwSf) = make_float4(f[0], f[0], f[0], f[0]);
+              }
+            }
+            const float fn = rw_wave_shl1(f[0]);
+            *reinterpret_cast<float4*>(a + kRwPadL + 4 * lane) = make_float4(f[0], f[1], f[2], f[3]);
+            *reinterpret_cast<float4*>(a + kRwSf + kRwPadL + 4 * lane) = make_float4(f[1], f[2], f[3], fn);
+          };
+          stage_channel(std::integral_constant<int, 0>{});
+          if constexpr (ES == 2)
+            stage_channel(std::integral_constant<int, 1>{});
+          wave_lds_sync();
+        }
+        issue(cur + TAPS, pf[j]); // TAPS rows ahead
+        if (!live)
+          continue;
+        // ---- horizontal pass: 2 groups x 2 elements, three aligned pair reads per element; the four chains side by side
+        {
+          // (one statement: the compiler pairs adjacent 8-byte reads into ds_read2_b64, which costs the LDS pipe twice the
+          // two plain reads, MI355X_MICROARCH.md LDS table; it does not track LDS reads issued from assembly, hence the wait)
+          v2f32 t[4][TAPS / 2];
+          u32 la[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            la[u] = (u32)(size_t)stage_b + (u32)addr[u >> 1][ES == 1 ? (u & 1) : 0];
+          constexpr int CH = ES == 2 ? 2 * kRwSf * 4 : 0; // byte offset of the second channel's copies
+          if constexpr (TAPS == 6)
+            asm volatile("ds_read_b64 %0, %12\n\tds_read_b64 %3, %13 offset:%16\n\tds_read_b64 %6, %14\n\tds_read_b64 %9, %15 offset:%16\n\t"
+                         "ds_read_b64 %1, %12 offset:8\n\tds_read_b64 %4, %13 offset:%17\n\tds_read_b64 %7, %14 offset:8\n\tds_read_b64 %10, %15 offset:%17\n\t"
+                         "ds_read_b64 %2, %12 offset:16\n\tds_read_b64 %5, %13 offset:%18\n\tds_read_b64 %8, %14 offset:16\n\tds_read_b64 %11, %15 offset:%18\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(t[0][0]), "=&v"(t[0][1]), "=&v"(t[0][2]), "=&v"(t[1][0]), "=&v"(t[1][1]), "=&v"(t[1][2]),
+                           "=&v"(t[2][0]), "=&v"(t[2][1]), "=&v"(t[2][2]), "=&v"(t[3][0]), "=&v"(t[3][1]), "=&v"(t[3][2])
+                         : "v"(la[0]), "v"(la[1]), "v"(la[2]), "v"(la[3]), "n"(CH), "n"(CH + 8), "n"(CH + 16)
+                         : "memory");
+          else
+            asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %2, %9 offset:%12\n\tds_read_b64 %4, %10\n\tds_read_b64 %6, %11 offset:%12\n\t"
+                         "ds_read_b64 %1, %8 offset:8\n\tds_read_b64 %3, %9 offset:%13\n\tds_read_b64 %5, %10 offset:8\n\tds_read_b64 %7, %11 offset:%13\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(t[0][0]), "=&v"(t[0][1]), "=&v"(t[1][0]), "=&v"(t[1][1]), "=&v"(t[2][0]), "=&v"(t[2][1]),
+                           "=&v"(t[3][0]), "=&v"(t[3][1])
+                         : "v"(la[0]), "v"(la[1]), "v"(la[2]), "v"(la[3]), "n"(CH), "n"(CH + 8)
+                         : "memory");
+          v2f32 acc[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            acc[u] = wq[u >> 1][ES == 1 ? (u & 1) : 0][0] * t[u][0];
+#pragma unroll
+          for (int k = 1; k < TAPS / 2; ++k)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              acc[u] = __builtin_elementwise_fma(wq[u >> 1][ES == 1 ? (u & 1) : 0][k], t[u][k], acc[u]);
+          float h[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            h[u] = acc[u].x + acc[u].y;
+          asm volatile("" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3])); // (keeps the sums scalar: packed, they cost register copies)
+          ring[j][0] = (v2f32){h[0], h[1]};
+          ring[j][1] = (v2f32){h[2], h[3]};
+        }
+        wave_lds_sync(); // the stage is refilled by the next row
+        // ---- every dst row whose window ends with this source row (cnt: several when enlarging); slot j is the newest row,
+        // logical row r of the window sits in slot (j + 1 + r) mod TAPS
+        auto emit = [&]() {
+          v2f32 wy[TAPS];
+#pragma unroll
+          for (int k = 0; k < TAPS / 2; ++k) {
+            const float4 q4 = *reinterpret_cast<const float4*>(wt + 4 * k);
+            wy[2 * k] = (v2f32){q4.x, q4.y};
+            wy[2 * k + 1] = (v2f32){q4.z, q4.w};
+          }
+          wt += WT;
+          v2f32 v[2];
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            v[g] = wy[0] * ring[(j + 1) % TAPS][g];
+#pragma unroll
+            for (int r = 1; r < TAPS; ++r)
+              v[g] = __builtin_elementwise_fma(wy[r], ring[(j + 1 + r) % TAPS][g], v[g]);
+          }
+          if constexpr (EB == 1) {
+            u32 p = 0;
+            p = __builtin_amdgcn_cvt_pk_u8_f32(v[0].x, 0u, p);
+            p = __builtin_amdgcn_cvt_pk_u8_f32(v[0].y, 1u, p);
+            p = __builtin_amdgcn_cvt_pk_u8_f32(v[1].x, 2u, p);
+            p = __builtin_amdgcn_cvt_pk_u8_f32(v[1].y, 3u, p);
+            // even lane: (own group 0, neighbour's group 0) = elements 2l .. 2l + 3; odd lane: (neighbour's group 1, own
+            // group 1) = elements 128 + 2(l - 1) .. + 3
+            const u32 word = __builtin_amdgcn_perm(rw_swap_pairs(p), p, sel);
+            if (full) {
+              gstore_u<u32>(optr, word);
+            } else {
+              const int n = dwe - est;
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                if (k < n)
+                  ((VALI_GLOBAL uint8_t*)optr)[k] = (uint8_t)(word >> (8 * k));
+            }
+          } else {
+            const u32 w0 = finish_bits<T>(v[0].x) | (finish_bits<T>(v[0].y) << 16);
+            const u32 w1 = finish_bits<T>(v[1].x) | (finish_bits<T>(v[1].y) << 16);
+            if (full) {
+              gstore_u<u32>(optr, w0);
+              gstore_u<u32>(optr + 128 * EB, w1);
+            } else {
+              const int n = dwe - est;
+              if (n > 0) ((VALI_GLOBAL uint16_t*)optr)[0] = (uint16_t)w0;
+              if (n > 1) ((VALI_GLOBAL uint16_t*)optr)[1] = (uint16_t)(w0 >> 16);
+              if (n > 128) ((VALI_GLOBAL uint16_t*)optr)[128] = (uint16_t)w1;
+              if (n > 129) ((VALI_GLOBAL uint16_t*)optr)[129] = (uint16_t)(w1 >> 16);
+            }
+          }
+          optr += dpitch;
+        };
+        // (straight-line first: the compiler drains vmcnt in front of a loop that stores without loading, DESIGN.md 5d #4,
+        // which would throw the prefetched rows away; enlargements below 3x never reach the loop)
+        const int c = __builtin_amdgcn_readlane(cntv, cur - s_begin);
+        if (c > 0) {
+          emit();
+          if (c > 1) {
+            emit();
+            for (int k = 2; k < c; ++k)
+              emit();
+          }
+        }
+      }
+    }
+    return;
+  }
+  if (y_first >= dh)
+    return;
+
+  // Direct gather (tight-pitch foreign memory whose last group would read past the row, forced by the tuning switch):
+  // TAPS x TAPS taps per element, the specification's loops as they stand.  Rolled: this path is about correctness, and
+  // must not cost the staged path registers.
+  {
+    const LzTap<TAPS> vy = make_lz_tap<TAPS>(y_first + (lane & (ROWS - 1)), scale_y);
+    if (lane < ROWS) {
+      float* row = wtab + lane * WT;
+      row[0] = __builtin_bit_cast(float, vy.i);
+#pragma unroll
+      for (int k = 0; k < TAPS; ++k)
+        row[4 + 2 * k] = vy.w[k];
+    }
+  }
+  const int last_rr = min(ROWS, dh - y_first) - 1;
+  wave_lds_sync();
+#pragma unroll 1
+  for (int rr = 0; rr <= last_rr; ++rr) {
+    const float* wt = wtab + rr * WT;
+    const int iy = __builtin_bit_cast(int, wt[0]);
+#pragma unroll 1
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const int e = eg[k4 >> 1] + (k4 & 1);
+      if (e >= dwe)
+        continue;
+      const int px = e / ES, ch = e - px * ES;
+      const LzTap<TAPS> c = make_lz_tap<TAPS>(px, scale_x);
+      float v = 0.0f;
+#pragma unroll 1
+      for (int r = 0; r < TAPS; ++r) {
+        const uint8_t* row = sp + (size_t)clampi(iy - kBefore + r, sh - 1) * spitch;
+        float t[TAPS];
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k)
+          t[k] = (float)gload<T>(row + (size_t)(clampi(c.i - kBefore + k, sw - 1) * ES + ch) * EB);
+        float he = c.w[0] * t[0], ho = c.w[1] * t[1];
+#pragma unroll
+        for (int k = 2; k < TAPS; k += 2) {
+          he = __builtin_fmaf(c.w[k], t[k], he);
+          ho = __builtin_fmaf(c.w[k + 1], t[k + 1], ho);
+        }
+        const float hs = he + ho;
+        const float wr = wt[4 + 2 * r];
+        v = r == 0 ? wr * hs : __builtin_fmaf(wr, hs, v);
+      }
+      ((VALI_GLOBAL T*)(dp + (size_t)(y_first + rr) * dpitch))[e] = (T)finish_bits<T>(v);
+    }
+  }
+}
+
+// ESSET: 1 = one-channel planes only, 12 = a one-channel and a two-channel plane (NV12 / P10), 2 = two-channel only
+template <typename T, int ESSET, int TAPS, int ROWS>
+__global__ void __launch_bounds__(kBlock) k_resize_rows(const ResizeArgs a) {
+  extern __shared__ uint4 rows_lds[];
+  ResizeJob job;
+  u32 tx, ty, frame;
+  if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
+    return;
+  const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
+  float* const lds = reinterpret_cast<float*>(rows_lds);
+  const bool allow = !a.force_gather;
+  if (ESSET != 1 && job.channels == 2)
+    rows_tile<T, 2, TAPS, ROWS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, allow, lds, a.lds_per_wave / 4);
+  else if constexpr (ESSET != 2)
+    rows_tile<T, 1, TAPS, ROWS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, allow, lds, a.lds_per_wave / 4);
+}
+
+template <typename T, int ESSET, int TAPS>
+static void launch_rows_k(const ResizeArgs& a, int rows, dim3 grid, unsigned lds, hipStream_t stream) {
+  if (rows == 32)
+    hipLaunchKernelGGL((k_resize_rows<T, ESSET, TAPS, 32>), grid, dim3(kBlock), lds, stream, a);
+  else if (rows == 8)
+    hipLaunchKernelGGL((k_resize_rows<T, ESSET, TAPS, 8>), grid, dim3(kBlock), lds, stream, a);
+  else
+    hipLaunchKernelGGL((k_resize_rows<T, ESSET, TAPS, 2>), grid, dim3(kBlock), lds, stream, a);
+}
+
+// groups of 4 source pixels a 256-element tile of job j can span (taps included, group alignment slop on the left)
+static int rows_groups(const ResizeJob& j, int src_w, int dst_w, int taps) {
+  const int c = j.channels;
+  const long long sw = src_w >> j.ssub_x, dw = dst_w >> j.sub_x;
+  const long long px = ((long long)(kRwTile / c) * sw + dw - 1) / dw + taps + 1 + 3;
+  return (int)((px + 3) / 4 + 2);
+}
+
+bool resize_rows_fits(const ResizeJob& j, int elem, int src_w, int dst_w, int taps) {
+  return (elem == 1 || elem == 2) && j.channels <= 2 && rows_groups(j, src_w, dst_w, taps) <= kWave;
+}
+
+int launch_resize_rows(const ResizeArgs& base, int elem, int taps, int src_w, int src_h, int dst_w, int dst_h, int n,
+                       hipStream_t stream) {
+  const bool gather_only = tuning(VALI_TUNE_RESIZE_FORCE_GATHER) == 1;
+  const int force = tuning(VALI_TUNE_RESIZE_NO_SEPARABLE); // 1 / 2 / 3: 8- / 2- / 32-row waves whatever the launch size
+  ResizeArgs a = base;
+  int groups = 0, esset = 0, maxc = 1;
+  for (int k = 0; k < a.njobs; ++k) {
+    const int c = a.job[k].channels;
+    esset = esset == 0 ? (c == 2 ? 2 : 1) : ((esset == 1 && c == 2) || (esset == 2 && c == 1)) ? 12 : esset;
+    maxc = c > maxc ? c : maxc;
+    const int g = rows_groups(a.job[k], src_w, dst_w, taps);
+    groups = g > groups ? g : groups;
+  }
+  auto count = [&](int rows, bool assign) {
+    u32 total = 0;
+    for (int k = 0; k < a.njobs; ++k) {
+      const int dw = dst_w >> a.job[k].sub_x, dh = dst_h >> a.job[k].sub_y;
+      const u32 tiles_x = (u32)(dw * a.job[k].channels + kRwTile - 1) / kRwTile;
+      if (assign) {
+        a.job[k].first_tile = total;
+        a.job[k].tiles_x = tiles_x;
+      }
+      total += tiles_x * (u32)((dh + kWavesPerBlock * rows - 1) / (kWavesPerBlock * rows));
+    }
+    return total;
+  };
+  const unsigned long long t32 = (unsigned long long)count(32, false) * (unsigned)n, t8 = (unsigned long long)count(8, false) * (unsigned)n;
+  const int rows = force == 1 ? 8 : force == 2 ? 2 : force == 3 ? 32 : t32 >= 1024ull ? 32 : t8 >= 320ull ? 8 : 2;
+  a.map = make_tile_map_linear(count(rows, true), (u32)n);
+  a.force_gather = gather_only ? 1 : 0;
+  (void)groups;
+  a.stage_bytes = kRwSf * 4;
+  a.lds_per_wave = ((rw_wave_floats(maxc, rows, taps) * 4) + 15) & ~15;
+  const unsigned lds = (unsigned)a.lds_per_wave * kWavesPerBlock;
+  const dim3 grid = tile_grid(a.map);
+#define VALI_ROWS_T(T)                                                                         \
+  do {                                                                                         \
+    if (taps == 6) {                                                                           \
+      if (esset == 1) launch_rows_k<T, 1, 6>(a, rows, grid, lds, stream);                       \
+      else if (esset == 12) launch_rows_k<T, 12, 6>(a, rows, grid, lds, stream);                \
+      else launch_rows_k<T, 2, 6>(a, rows, grid, lds, stream);                                  \
+    } else {                                                                                   \
+      if (esset == 1) launch_rows_k<T, 1, 4>(a, rows, grid, lds, stream);                       \
+      else if (esset == 12) launch_rows_k<T, 12, 4>(a, rows, grid, lds, stream);                \
+      else launch_rows_k<T, 2, 4>(a, rows, grid, lds, stream);                                  \
+    }                                                                                          \
+  } while (0)
+  if (elem == 1) VALI_ROWS_T(uint8_t);
+  else VALI_ROWS_T(uint16_t);
+#undef VALI_ROWS_T
+  VALI_LAUNCH_CHECK();
+  return VALI_OK;
+}
+
+} // namespace vali
