@@ -396,7 +396,8 @@ enum vali_tuning_key {
                                          walks: 0 by launch size (8 for batches, 4 or 2 for small launches), 2 / 4 / 8  */
   VALI_TUNE_BLOCKING_WAIT = 12,       /* vali_stream_wait: 0 completion word + spin (default), 1 hipStreamSynchronize */
   VALI_TUNE_RESIZE_ROWS = 13,         /* Lanczos / bicubic of planes that grow: 1 (default) filtered rows in registers
-                                         (resize_rows.hip) where the geometry fits, 0: round 2's LDS-ring kernel everywhere */
+                                         (resize_rows.hip) where the geometry fits, exact 3:2 enlargements through their static
+                                         form; 2: the same without the 3:2 form; 0: round 2's LDS-ring kernel everywhere      */
   VALI_TUNE_COUNT = 14
 };
 VALI_API int vali_tuning_set(int key, int value);

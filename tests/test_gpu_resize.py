@@ -488,6 +488,47 @@ def test_growing_planes_bit_exact(vali, gpu, oracle, fmt, geom, interp):
         assert np.array_equal(roundtrip(vali, gpu, fmt, host, sw, sh, dw, dh, interp=mode), want)
 
 
+# exactly 3:2 on both axes (k_resize_rows_x23): one lane / one tile / tile + a lane / source widths that are 2 (mod 4) (the
+# last group moved left), halo groups that straddle the row's end, 1 .. 3 source row pairs, heights around the 12- and 48-row waves
+X23_GEOMS = [(4, 2, 6, 3), (6, 4, 9, 6), (8, 6, 12, 9), (254, 34, 381, 51), (256, 36, 384, 54), (258, 10, 387, 15), (260, 12, 390, 18),
+             (510, 20, 765, 30), (512, 8, 768, 12), (514, 6, 771, 9), (1282, 30, 1923, 45), (640, 360, 960, 540), (100, 66, 150, 99),
+             (1280, 720, 1920, 1080), (128, 130, 192, 195), (516, 12, 774, 18), (268, 20, 402, 30), (1028, 24, 1542, 36), (8, 4, 12, 6)]
+
+
+@pytest.mark.parametrize("fmt", ["NV12", "Y", "YUV420", "P10", "YUV444_10bit", "YUV444"])
+@pytest.mark.parametrize("geom", X23_GEOMS)
+@pytest.mark.parametrize("interp", ["lanczos", "cubic"])
+def test_three_to_two_enlargement_bit_exact(vali, gpu, oracle, fmt, geom, interp):
+    sw, sh, dw, dh = geom
+    if fmt in ("NV12", "YUV420", "P10") and ((sw | sh | dw | dh) & 1 or sw < 8):
+        pytest.skip("4:2:0 surfaces have even sizes (and the chroma planes need 4 source pixels for this form)")
+    dt = DT.get(fmt, np.uint8)
+    n = vali.Surface.Make(vali.PixelFormat[fmt], sw, sh, gpu).HostSize // np.dtype(dt).itemsize
+    rng = np.random.default_rng(sw * 3 + dh)
+    host = (rng.random(n) * (1023 if dt == np.uint16 else 255)).astype(dt)
+    host[rng.integers(0, n, max(4, n // 50))] = 0                # runs of zeros: the sign of zero in the shifted-weight chains
+    if dt == np.uint16:
+        host[rng.integers(0, n, 20)] = 65535
+    mode = vali.Interpolation.LANCZOS if interp == "lanczos" else vali.Interpolation.CUBIC
+    want = oracle.resize_surface(host, fmt, sw, sh, dw, dh, interp)
+    assert np.array_equal(roundtrip(vali, gpu, fmt, host, sw, sh, dw, dh, interp=mode), want)
+    for rows_mode in (1, 3):                                     # 12-row and 48-row waves
+        with vali.tuning.Override(RESIZE_NO_SEPARABLE=rows_mode):
+            assert np.array_equal(roundtrip(vali, gpu, fmt, host, sw, sh, dw, dh, interp=mode), want), rows_mode
+    with vali.tuning.Override(RESIZE_ROWS=2):                    # the general growing-planes kernel on the same geometry
+        assert np.array_equal(roundtrip(vali, gpu, fmt, host, sw, sh, dw, dh, interp=mode), want)
+
+
+def test_three_to_two_enlargement_all_zero_and_flat_frames(vali, gpu, oracle):
+    """flat frames: every chain of the shifted-weight form sees zeros / equal values in every slot"""
+    for val in (0, 255, 16):
+        host = np.full(258 * 12 * 3 // 2, val, np.uint8)
+        want = oracle.resize_surface(host, "NV12", 258, 12, 387 - 1 + 1 if False else 387, 18, "lanczos") if False else None
+        host = np.full(260 * 12 * 3 // 2, val, np.uint8)
+        want = oracle.resize_surface(host, "NV12", 260, 12, 390, 18, "lanczos")
+        assert np.array_equal(roundtrip(vali, gpu, "NV12", host, 260, 12, 390, 18, interp=vali.Interpolation.LANCZOS), want), val
+
+
 @pytest.mark.parametrize("rows_mode", [0, 1, 2, 3])
 def test_growing_planes_batch_and_rows_per_wave(vali, gpu, oracle, rows_mode):
     """a batch under every rows-per-wave form (2 / 8 / 32), NV12 (both channel counts in one launch) and P10"""

@@ -75,7 +75,7 @@ CASES = [
     ("RESIZE_FORCE_GATHER", (1,), lambda v, g: resize(v, g, 640, 360, 1280, 720, v.Interpolation.CUBIC)),
     ("RESIZE_NO_SEPARABLE", (1, 2, 3), lambda v, g: resize(v, g, 1280, 720, 854, 480, v.Interpolation.LANCZOS)),
     ("RESIZE_NO_SEPARABLE", (1, 2, 3), lambda v, g: resize(v, g, 640, 360, 1280, 720, v.Interpolation.CUBIC)),
-    ("RESIZE_ROWS", (0,), lambda v, g: resize(v, g, 640, 360, 960, 540, v.Interpolation.LANCZOS)),
+    ("RESIZE_ROWS", (0, 2), lambda v, g: resize(v, g, 640, 360, 960, 540, v.Interpolation.LANCZOS)),
     ("RESIZE_ROWS", (0,), lambda v, g: resize(v, g, 640, 360, 1000, 700, v.Interpolation.CUBIC)),
     ("UD_DOWN2", (0, 2), lambda v, g: ud(v, g, 1280, 720, 640, 360, v.RGB)),
     ("UD_DOWN2", (0, 2), lambda v, g: ud(v, g, 1276, 720, 638, 360, v.RGB)),

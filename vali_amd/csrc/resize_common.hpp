@@ -35,6 +35,12 @@ bool resize_rows_fits(const ResizeJob& j, int elem, int src_w, int dst_w, int ta
 int launch_resize_rows(const ResizeArgs& a, int elem, int taps, int src_w, int src_h, int dst_w, int dst_h, int n,
                        hipStream_t stream);
 
+// ... and for 8 / 16-bit planes of 1 / 2 channels enlarged by exactly 3:2 on both axes (720p -> 1080p): static tap positions,
+// no LDS stage (resize_rows.hip, k_resize_rows_x23).
+bool resize_x23_fits(const ResizeJob& j, int elem, int src_w, int src_h, int dst_w, int dst_h);
+int launch_resize_x23(const ResizeArgs& a, int elem, int taps, int src_w, int src_h, int dst_w, int dst_h, int n,
+                      hipStream_t stream);
+
 // The same filters for jobs whose planes all SHRINK (or keep) their height -- columns first (resize_cols.hip).  Which
 // plane takes which order is part of the specification (oracle/vali_oracle.c resize_plane_taps): src_h >= dst_h.
 int launch_resize_cols(const ResizeArgs& a, int elem, int taps, int src_w, int src_h, int dst_w, int dst_h, int n,

@@ -435,6 +435,439 @@ __global__ void __launch_bounds__(kBlock) k_resize_rows(const ResizeArgs a) {
     rows_tile<T, 1, TAPS, ROWS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, allow, lds, a.lds_per_wave / 4);
 }
 
+// =====================================================================================================================
+// Planes enlarged by exactly 3:2 on BOTH axes (720p -> 1080p, 480p -> 720p, 1440p -> 2160p and their chroma planes): the
+// everyday upscale.  scale = fl(2/3), and x * scale lands where the pattern says for every x (3m * fl(2/3) rounds to
+// exactly 2m: the relative error 2^-25 of fl(2/3) is below half an ulp of any integer; the other two residues sit a third
+// away from an integer), so per dst triple (3m, 3m+1, 3m+2):
+//   3m   : i = 2m,     a = 0    -> weights {0,0,1,0,0,0}: the sample IS source pixel 2m, bit for bit (0 * t = +0 for
+//                                  the unsigned element types this kernel takes, and t + 0 = t)
+//   3m+1 : i = 2m,     a ~ 2/3
+//   3m+2 : i = 2m + 1, a ~ 1/3     (the weights of these two differ from x to x in their last bits: per-lane registers)
+// The tap POSITIONS are static, so nothing is gathered: a lane owns 4 source pixels (2 of a two-channel plane) = 6 dst
+// pixels (3), converts them once, gets the 2 pixels before and the 3 after from its neighbours by DPP (`wave_shr:1` /
+// `wave_shl:1`; lane 0 and lane 63 keep the DPP's `old` operand, pre-loaded from one halo load per row) and filters from
+// registers -- no LDS stage, no tap reads.  Samples whose first tap sits at an ODD position run over the same aligned
+// register pairs with their weights moved one slot: (0,w0) (w1,w2) (w3,w4) (w5,0) -- the low halves then accumulate the
+// odd taps and the high halves the even ones, each in the specification's order (a chain that starts with
+// fma(w, t, +0) equals the one that starts with w * t for t >= 0; the trailing fma(0, t, e) is e).  Down the rows the same
+// pattern: dst row 3M is the quantised filtered row 2M itself, rows 3M+1 / 3M+2 are 6-tap combinations; the walk over the
+// source rows is static (odd source rows complete two dst rows, even ones one).
+// Per source row and lane: 34 vector instructions along the row + 37 down the rows for 9 output samples -- against 113
+// wave instructions per 6 in the general kernel above.
+template <typename T, int ES> struct R23 {
+  static constexpr int kPx = ES == 1 ? 4 : 2;                    // source pixels per lane
+  static constexpr int kWords = kPx * ES * (int)sizeof(T) / 4;   // dwords of the lane's group: 1 (u8) or 2 (u16)
+  static constexpr int kHaloWords = 4 * ES * (int)sizeof(T) / 4; // the halo group is always 4 pixels
+};
+template <int WORDS> struct R23Load {
+  u32 w[WORDS];
+};
+template <int WORDS> __device__ __forceinline__ R23Load<WORDS> r23_load(const uint8_t* p) {
+  R23Load<WORDS> g;
+  if constexpr (WORDS == 1) {
+    g.w[0] = gload_u<u32>(p);
+  } else if constexpr (WORDS == 2) {
+    const v2u32 q = gload_u<v2u32>(p);
+    g.w[0] = q.x; g.w[1] = q.y;
+  } else {
+    const v4u32 q = gload_u<v4u32>(p);
+    g.w[0] = q.x; g.w[1] = q.y; g.w[2] = q.z; g.w[3] = q.w;
+  }
+  return g;
+}
+template <typename T, int N, int WORDS> __device__ __forceinline__ float r23_elem(const R23Load<WORDS>& g) {
+  if constexpr (sizeof(T) == 1)
+    return ubyte_f32<N % 4>(g.w[N / 4]);
+  else
+    return (float)((N % 2) ? (g.w[N / 2] >> 16) : (g.w[N / 2] & 0xffffu));
+}
+__device__ __forceinline__ float r23_shr1(float old, float v) { // lane l gets lane l - 1's v; lane 0 keeps `old`
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float r23_shl1(float old, float v) { // lane l gets lane l + 1's v; lane 63 keeps `old`
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+template <typename T, int ES, int TAPS, int RW>
+__device__ __forceinline__ void rows23_tile(const uint8_t* sp, int spitch, int sw, int sh, uint8_t* dp, int dpitch,
+                                            int dw, int dh, u32 tx, u32 ty, float* wg_lds, int wave_floats) {
+  static_assert(RW % 3 == 0 && RW <= kWave, "whole dst triples per wave, one row tap set per lane");
+  constexpr int EB = (int)sizeof(T);
+  constexpr int WT = 4 + 2 * TAPS;
+  constexpr int PX = R23<T, ES>::kPx, NW = R23<T, ES>::kWords, HW = R23<T, ES>::kHaloWords;
+  constexpr int NF = ES == 1 ? 4 : 2;   // filtered (non-copy) samples per lane whose weights are kept: d1 d2 (d4 d5)
+  constexpr int DE = 6;                 // dst ELEMENTS per lane (6 pixels, or 3 pixels x 2 channels)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int X0 = (int)tx * (kWave * PX);               // first source pixel of the tile
+  const int ps = X0 + PX * lane;                       // this lane's first source pixel
+  const int pd = ps / 2 * 3;                           // ... and first dst pixel
+  const int y_first = (int)(ty * kWavesPerBlock + wave) * RW;
+  const float scale_x = (float)sw / (float)dw, scale_y = (float)sh / (float)dh;
+  float* const lds = wg_lds + wave * wave_floats;
+
+  // ---- column tap sets of the filtered samples: wave w evaluates sample w of every lane (ES = 2: waves 0 / 1), shared
+  // through LDS.  Sample f of the lane is dst pixel pd + {1, 2, 4, 5}[f].
+  v2f32 wa[ES == 1 ? 2 : 1][TAPS / 2];       // first tap at an even position: (w0,w1) (w2,w3) (w4,w5)
+  v2f32 wb[ES == 1 ? 2 : 1][TAPS / 2 + 1];   // ... at an odd one: (0,w0) (w1,w2) (w3,w4) (w5,0)
+  {
+    const int f = ES == 1 ? wave : (wave & 1);
+    const int x = min(pd + f + 1 + (f >> 1), dw - 1);
+    const LzTap<TAPS> c = make_lz_tap<TAPS>(x, scale_x);
+    float* mine = lds + 8 * lane;
+    *reinterpret_cast<float4*>(mine) = make_float4(c.w[0], c.w[1], c.w[2], c.w[3]);
+    if constexpr (TAPS == 6)
+      *reinterpret_cast<float2*>(mine + 4) = make_float2(c.w[4], c.w[5]);
+    __syncthreads();
+#pragma unroll
+    for (int f2 = 0; f2 < NF; ++f2) {
+      const float* from = wg_lds + f2 * wave_floats + 8 * lane;
+      const float4 a = *reinterpret_cast<const float4*>(from);
+      float w[6] = {a.x, a.y, a.z, a.w, 0.0f, 0.0f};
+      if constexpr (TAPS == 6) {
+        const float2 b = *reinterpret_cast<const float2*>(from + 4);
+        w[4] = b.x; w[5] = b.y;
+      }
+      // (the 4-tap window starts one pixel before i: there the samples with an EVEN i start at an odd position)
+      if (((f2 & 1) == 0) == (TAPS == 6)) { // first tap at an even position: d1, d4 (6 taps) / d2, d5 (4 taps)
+#pragma unroll
+        for (int k = 0; k < TAPS / 2; ++k)
+          wa[f2 >> 1][k] = (v2f32){w[2 * k], w[2 * k + 1]};
+      } else {
+        wb[f2 >> 1][0] = (v2f32){0.0f, w[0]};
+#pragma unroll
+        for (int k = 1; k < TAPS / 2; ++k)
+          wb[f2 >> 1][k] = (v2f32){w[2 * k - 1], w[2 * k]};
+        wb[f2 >> 1][TAPS / 2] = (v2f32){w[TAPS - 1], 0.0f};
+      }
+    }
+    __syncthreads();
+  }
+  if (y_first >= dh)
+    return;
+
+  // ---- row taps of the wave's dst rows (pre-splatted pairs, broadcast reads in the vertical pass)
+  float* const wtab = lds;
+  {
+    const LzTap<TAPS> vy = make_lz_tap<TAPS>(min(y_first + lane, dh - 1), scale_y);
+    if (lane < RW) {
+      float* row = wtab + lane * WT;
+#pragma unroll
+      for (int k = 0; k < TAPS / 2; ++k)
+        *reinterpret_cast<float4*>(row + 4 + 4 * k) = make_float4(vy.w[2 * k], vy.w[2 * k], vy.w[2 * k + 1], vy.w[2 * k + 1]);
+    }
+  }
+  wave_lds_sync();
+  const int last_rr = min(RW, dh - y_first) - 1;
+  const int s_begin = y_first / 3 * 2 - 2;             // even; source row t of the walk is s_begin + t
+
+  // ---- addresses.  A lane's group must lie inside its row: groups that would start past sw - PX start there instead and
+  // are put right in registers (tiles at the right edge only).  Halo: lane 0 loads the 4 pixels before the tile, lane 63 the
+  // 4 after it, every other lane its own group again (the same lines: one more request, no more traffic).
+  const bool first_tile = tx == 0;
+  const bool edge = X0 + kWave * PX + 4 > sw;          // wave-uniform: some lane (or lane 63's halo) reaches past the row
+  const int gs = min(ps, sw - PX);                     // where the lane's group really starts
+  const bool in_row = ps + PX <= sw, straddle = !in_row && ps < sw; // (straddle: ES = 1 and sw % 4 == 2 only)
+  const int hp = lane == 0 ? max(X0 - 4, 0) : lane == 63 ? ps + PX : ps;
+  const int hs = min(hp, sw - 4);
+  const bool h_in = hp + 4 <= sw, h_straddle = !h_in && hp < sw;     // (the halo group is 4 pixels: may straddle by 2)
+  const u32 goff = (u32)(gs * ES * EB), hoff = (u32)(hs * ES * EB);
+
+  R23Load<NW> pf[TAPS];
+  R23Load<HW> hf[TAPS];
+  auto issue = [&](int t, R23Load<NW>& q, R23Load<HW>& h) {
+    const uint8_t* row = sp + (u32)(clampi(s_begin + t, sh - 1) * spitch);
+    q = r23_load<NW>(row + goff);
+    h = r23_load<HW>(row + hoff);
+  };
+#pragma unroll
+  for (int j = 0; j < TAPS; ++j) {
+    issue(j, pf[j], hf[j]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  v2f32 ring[TAPS][3]; // filtered rows: [slot][pair]; ES = 1: (d0,d1) (d2,d3) (d4,d5), ES = 2: (u,v) of the lane's 3 pixels
+#pragma unroll
+  for (int j = 0; j < TAPS; ++j)
+    ring[j][0] = ring[j][1] = ring[j][2] = (v2f32){0.0f, 0.0f};
+
+  // ---- output: 6 elements per lane, lanes contiguous
+  const int nel = min(DE, max(0, (dw - pd) * ES)); // 6, 3 or 0
+  const bool full = (X0 + kWave * PX) <= sw;       // wave-uniform: every lane has its 6
+  uint8_t* optr = dp + (size_t)y_first * dpitch + (size_t)pd * ES * EB;
+  const float* wt = wtab + 4;
+  int rr = 0;
+  constexpr int T0 = TAPS == 6 ? 5 : 4;            // first source row of the walk that completes a dst row
+
+  auto store_row = [&](const v2f32 (&v)[3]) {
+    if constexpr (EB == 1) {
+      u32 w0 = 0, w1 = 0;
+      w0 = __builtin_amdgcn_cvt_pk_u8_f32(v[0].x, 0u, w0);
+      w0 = __builtin_amdgcn_cvt_pk_u8_f32(v[0].y, 1u, w0);
+      w0 = __builtin_amdgcn_cvt_pk_u8_f32(v[1].x, 2u, w0);
+      w0 = __builtin_amdgcn_cvt_pk_u8_f32(v[1].y, 3u, w0);
+      w1 = __builtin_amdgcn_cvt_pk_u8_f32(v[2].x, 0u, w1);
+      w1 = __builtin_amdgcn_cvt_pk_u8_f32(v[2].y, 1u, w1);
+      if (full || nel == DE) {
+        gstore_u<u32>(optr, w0);
+        gstore_u<uint16_t>(optr + 4, (uint16_t)w1);
+      } else if (nel == 3) {
+        gstore_u<uint16_t>(optr, (uint16_t)w0);
+        gstore<uint8_t>(optr + 2, (uint8_t)(w0 >> 16));
+      }
+    } else {
+      const u32 w0 = finish_bits<T>(v[0].x) | (finish_bits<T>(v[0].y) << 16);
+      const u32 w1 = finish_bits<T>(v[1].x) | (finish_bits<T>(v[1].y) << 16);
+      const u32 w2 = finish_bits<T>(v[2].x) | (finish_bits<T>(v[2].y) << 16);
+      if (full || nel == DE) {
+        typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+        const v3u32 q = {w0, w1, w2};
+        gstore_u<v3u32>(optr, q);
+      } else if (nel == 3) {
+        gstore_u<u32>(optr, w0);
+        gstore_u<uint16_t>(optr + 4, (uint16_t)w1);
+      }
+    }
+    optr += dpitch;
+    wt += WT;
+    ++rr;
+  };
+
+  int t0 = 0;
+#pragma unroll 1
+  do {
+#pragma unroll
+    for (int j = 0; j < TAPS; ++j) {
+      const int t = t0 + j;
+      const bool live = rr <= last_rr; // wave-uniform
+      if (live) {
+        // ---- the lane's pixels and their neighbours, per channel: P[0..9] = L2 L3 f0 f1 f2 f3 R0 R1 R2 0 (ES = 1),
+        // P[0..7] = Lp0 Lp1 f0 f1 Rp0 Rp1 RRp0 0 (ES = 2): aligned register pairs
+        auto channel = [&](auto ctag, v2f32& o0, v2f32& o1, v2f32& o2) {
+          constexpr int C = decltype(ctag)::value;
+          float f[PX], g[4];
+#pragma unroll
+          for (int k = 0; k < PX; ++k)
+            f[k] = 0.0f;
+          f[0] = r23_elem<T, 0 * ES + C, NW>(pf[j]);
+          f[1] = r23_elem<T, 1 * ES + C, NW>(pf[j]);
+          if constexpr (PX == 4) {
+            f[2] = r23_elem<T, 2 * ES + C, NW>(pf[j]);
+            f[3] = r23_elem<T, 3 * ES + C, NW>(pf[j]);
+          }
+          g[0] = r23_elem<T, 0 * ES + C, HW>(hf[j]);
+          g[1] = r23_elem<T, 1 * ES + C, HW>(hf[j]);
+          g[2] = r23_elem<T, 2 * ES + C, HW>(hf[j]);
+          g[3] = r23_elem<T, 3 * ES + C, HW>(hf[j]);
+          if (edge) { // right-most tiles: groups that were moved left to stay inside the row, pixels past the row's end
+            if constexpr (PX == 4) {
+              f[0] = in_row ? f[0] : straddle ? f[2] : f[3];
+              f[1] = in_row ? f[1] : f[3];
+              f[2] = in_row ? f[2] : f[3];
+            } else {
+              f[0] = in_row ? f[0] : f[1];
+            }
+            g[0] = h_in ? g[0] : h_straddle ? g[2] : g[3];
+            g[1] = h_in ? g[1] : g[3];
+            g[2] = h_in ? g[2] : g[3];
+          }
+          if (first_tile) { // pixels -1, -2 replicate pixel 0
+            g[2] = lane == 0 ? f[0] : g[2];
+            g[3] = lane == 0 ? f[0] : g[3];
+          }
+          if constexpr (ES == 1) {
+            const float L2 = r23_shr1(g[2], f[2]), L3 = r23_shr1(g[3], f[3]);
+            const float R0 = r23_shl1(g[0], f[0]), R1 = r23_shl1(g[1], f[1]), R2 = r23_shl1(g[2], f[2]);
+            const v2f32 p0 = {L2, L3}, p1 = {f[0], f[1]}, p2 = {f[2], f[3]}, p3 = {R0, R1}, p4 = {R2, 0.0f};
+            float d1, d2, d4, d5;
+            if constexpr (TAPS == 6) {
+              // d1: i = 4l      taps L2 L3 f0 f1 f2 f3        d4: i = 4l + 2  taps f0 f1 f2 f3 R0 R1
+              v2f32 a1 = wa[0][0] * p0, a4 = wa[1][0] * p1;
+              a1 = __builtin_elementwise_fma(wa[0][1], p1, a1); a4 = __builtin_elementwise_fma(wa[1][1], p2, a4);
+              a1 = __builtin_elementwise_fma(wa[0][2], p2, a1); a4 = __builtin_elementwise_fma(wa[1][2], p3, a4);
+              // d2: i = 4l + 1  taps L3 f0 f1 f2 f3 R0        d5: i = 4l + 3  taps f1 f2 f3 R0 R1 R2
+              v2f32 a2 = wb[0][0] * p0, a5 = wb[1][0] * p1;
+              a2 = __builtin_elementwise_fma(wb[0][1], p1, a2); a5 = __builtin_elementwise_fma(wb[1][1], p2, a5);
+              a2 = __builtin_elementwise_fma(wb[0][2], p2, a2); a5 = __builtin_elementwise_fma(wb[1][2], p3, a5);
+              a2 = __builtin_elementwise_fma(wb[0][3], p3, a2); a5 = __builtin_elementwise_fma(wb[1][3], p4, a5);
+              d1 = a1.x + a1.y; d4 = a4.x + a4.y;
+              d2 = a2.y + a2.x; d5 = a5.y + a5.x; // (high halves hold the even taps: e + o)
+            } else {
+              // 4 taps i-1 .. i+2.  d1: L3 f0 f1 f2 (first tap odd)  d2: f0 f1 f2 f3 (even)  d4: f1 f2 f3 R0 (odd)  d5: f2 f3 R0 R1 (even)
+              v2f32 a1 = wb[0][0] * p0, a4 = wb[1][0] * p1;
+              a1 = __builtin_elementwise_fma(wb[0][1], p1, a1); a4 = __builtin_elementwise_fma(wb[1][1], p2, a4);
+              a1 = __builtin_elementwise_fma(wb[0][2], p2, a1); a4 = __builtin_elementwise_fma(wb[1][2], p3, a4);
+              v2f32 a2 = wa[0][0] * p1, a5 = wa[1][0] * p2;
+              a2 = __builtin_elementwise_fma(wa[0][1], p2, a2); a5 = __builtin_elementwise_fma(wa[1][1], p3, a5);
+              d1 = a1.y + a1.x; d4 = a4.y + a4.x;
+              d2 = a2.x + a2.y; d5 = a5.x + a5.y;
+              (void)p4;
+            }
+            asm volatile("" : "+v"(d1), "+v"(d2), "+v"(d4), "+v"(d5));
+            o0 = (v2f32){f[0], d1};
+            o1 = (v2f32){d2, f[2]};
+            o2 = (v2f32){d4, d5};
+          } else {
+            const float L0 = r23_shr1(g[2], f[0]), L1 = r23_shr1(g[3], f[1]);
+            const float R0 = r23_shl1(g[0], f[0]), R1 = r23_shl1(g[1], f[1]);
+            const float RR0 = r23_shl1(g[2], R0);
+            const v2f32 p0 = {L0, L1}, p1 = {f[0], f[1]}, p2 = {R0, R1}, p3 = {RR0, 0.0f};
+            float d1, d2;
+            if constexpr (TAPS == 6) {
+              // d1: i = 2l taps L0 L1 f0 f1 R0 R1 ; d2: i = 2l + 1 taps L1 f0 f1 R0 R1 RR0
+              v2f32 a1 = wa[0][0] * p0, a2 = wb[0][0] * p0;
+              a1 = __builtin_elementwise_fma(wa[0][1], p1, a1); a2 = __builtin_elementwise_fma(wb[0][1], p1, a2);
+              a1 = __builtin_elementwise_fma(wa[0][2], p2, a1); a2 = __builtin_elementwise_fma(wb[0][2], p2, a2);
+              a2 = __builtin_elementwise_fma(wb[0][3], p3, a2);
+              d1 = a1.x + a1.y;
+              d2 = a2.y + a2.x;
+            } else {
+              // d1: i = 2l taps L1 f0 f1 R0 (odd) ; d2: i = 2l + 1 taps f0 f1 R0 R1 (even)
+              v2f32 a1 = wb[0][0] * p0, a2 = wa[0][0] * p1;
+              a1 = __builtin_elementwise_fma(wb[0][1], p1, a1); a2 = __builtin_elementwise_fma(wa[0][1], p2, a2);
+              a1 = __builtin_elementwise_fma(wb[0][2], p2, a1);
+              d1 = a1.y + a1.x;
+              d2 = a2.x + a2.y;
+              (void)p3;
+            }
+            asm volatile("" : "+v"(d1), "+v"(d2));
+            // pixels 3l, 3l+1, 3l+2 of this channel
+            o0.x = f[0]; o1.x = d1; o2.x = d2;
+            (void)o0; (void)o1; (void)o2;
+            if constexpr (C == 1) {
+              o0.y = f[0]; o1.y = d1; o2.y = d2;
+            }
+          }
+        };
+        if constexpr (ES == 1) {
+          channel(std::integral_constant<int, 0>{}, ring[j][0], ring[j][1], ring[j][2]);
+        } else {
+          v2f32 u0, u1, u2, v0, v1, v2;
+          channel(std::integral_constant<int, 0>{}, u0, u1, u2);
+          channel(std::integral_constant<int, 1>{}, v0, v1, v2);
+          ring[j][0] = (v2f32){u0.x, v0.y};
+          ring[j][1] = (v2f32){u1.x, v1.y};
+          ring[j][2] = (v2f32){u2.x, v2.y};
+        }
+      }
+      issue(t + TAPS, pf[j], hf[j]);
+      if (!live || t < T0)
+        continue;
+      // ---- dst rows this source row completes.  Newest filtered row: slot j; logical row r of a window: slot (j + 1 + r) % TAPS
+      auto full_row = [&]() {
+        v2f32 wy[TAPS];
+#pragma unroll
+        for (int k = 0; k < TAPS / 2; ++k) {
+          const float4 q4 = *reinterpret_cast<const float4*>(wt + 4 * k);
+          wy[2 * k] = (v2f32){q4.x, q4.y};
+          wy[2 * k + 1] = (v2f32){q4.z, q4.w};
+        }
+        v2f32 v[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          v[g] = wy[0] * ring[(j + 1) % TAPS][g];
+#pragma unroll
+          for (int r = 1; r < TAPS; ++r)
+            v[g] = __builtin_elementwise_fma(wy[r], ring[(j + 1 + r) % TAPS][g], v[g]);
+        }
+        store_row(v);
+      };
+      // parity of t == parity of j (TAPS is even).  TAPS = 6: odd rows 2M + 3 complete dst rows 3M (the filtered row 2M
+      // itself: 3 slots back) and 3M + 1, even rows 2M + 4 complete 3M + 2.  TAPS = 4: even rows 2M + 2 complete 3M (2 slots
+      // back) and 3M + 1, odd rows 2M + 3 complete 3M + 2.
+      const bool two = TAPS == 6 ? (j & 1) == 1 : (j & 1) == 0; // (a constant once the walk is unrolled)
+      if (two) {
+        constexpr int back = TAPS == 6 ? 3 : 2;
+        const v2f32 c[3] = {ring[(j + TAPS - back) % TAPS][0], ring[(j + TAPS - back) % TAPS][1], ring[(j + TAPS - back) % TAPS][2]};
+        store_row(c);
+        if (rr <= last_rr)
+          full_row();
+      } else {
+        full_row();
+      }
+    }
+    t0 += TAPS;
+  } while (rr <= last_rr);
+}
+
+template <typename T, int ESSET, int TAPS, int RW>
+__global__ void __launch_bounds__(kBlock) k_resize_rows_x23(const ResizeArgs a) {
+  extern __shared__ uint4 rows_lds[];
+  ResizeJob job;
+  u32 tx, ty, frame;
+  if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
+    return;
+  const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
+  float* const lds = reinterpret_cast<float*>(rows_lds);
+  if (ESSET != 1 && job.channels == 2)
+    rows23_tile<T, 2, TAPS, RW>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, lds, a.lds_per_wave / 4);
+  else if constexpr (ESSET != 2)
+    rows23_tile<T, 1, TAPS, RW>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, lds, a.lds_per_wave / 4);
+}
+
+bool resize_x23_fits(const ResizeJob& j, int elem, int src_w, int src_h, int dst_w, int dst_h) {
+  const long long sw = src_w >> j.ssub_x, sh = src_h >> j.ssub_y, dw = dst_w >> j.sub_x, dh = dst_h >> j.sub_y;
+  return (elem == 1 || elem == 2) && j.channels <= 2 && 3 * sw == 2 * dw && 3 * sh == 2 * dh && sw >= 4 && sh >= 2 &&
+         sw < (1 << 22) && sh < (1 << 22);
+}
+
+template <typename T, int ESSET, int TAPS>
+static void launch_x23_k(const ResizeArgs& a, int rw, dim3 grid, unsigned lds, hipStream_t stream) {
+  if (rw == 48)
+    hipLaunchKernelGGL((k_resize_rows_x23<T, ESSET, TAPS, 48>), grid, dim3(kBlock), lds, stream, a);
+  else
+    hipLaunchKernelGGL((k_resize_rows_x23<T, ESSET, TAPS, 12>), grid, dim3(kBlock), lds, stream, a);
+}
+
+int launch_resize_x23(const ResizeArgs& base, int elem, int taps, int src_w, int src_h, int dst_w, int dst_h, int n,
+                      hipStream_t stream) {
+  const int force = tuning(VALI_TUNE_RESIZE_NO_SEPARABLE); // 1 / 2: 12-row waves, 3: 48-row waves whatever the launch size
+  ResizeArgs a = base;
+  int esset = 0;
+  for (int k = 0; k < a.njobs; ++k) {
+    const int c = a.job[k].channels;
+    esset = esset == 0 ? (c == 2 ? 2 : 1) : ((esset == 1 && c == 2) || (esset == 2 && c == 1)) ? 12 : esset;
+  }
+  auto count = [&](int rw, bool assign) {
+    u32 total = 0;
+    for (int k = 0; k < a.njobs; ++k) {
+      const int dw = dst_w >> a.job[k].sub_x, dh = dst_h >> a.job[k].sub_y;
+      const u32 tiles_x = (u32)(dw * a.job[k].channels + 383) / 384;
+      if (assign) {
+        a.job[k].first_tile = total;
+        a.job[k].tiles_x = tiles_x;
+      }
+      total += tiles_x * (u32)((dh + kWavesPerBlock * rw - 1) / (kWavesPerBlock * rw));
+    }
+    return total;
+  };
+  const unsigned long long t48 = (unsigned long long)count(48, false) * (unsigned)n;
+  const int rw = force == 1 || force == 2 ? 12 : force == 3 ? 48 : t48 >= 1024ull ? 48 : 12;
+  a.map = make_tile_map_linear(count(rw, true), (u32)n);
+  const int wt_floats = rw * (4 + 2 * taps);
+  a.lds_per_wave = ((wt_floats > 512 ? wt_floats : 512) * 4 + 15) & ~15; // the weight table, or the 64 x 8 floats of the tap exchange
+  const unsigned lds = (unsigned)a.lds_per_wave * kWavesPerBlock;
+  const dim3 grid = tile_grid(a.map);
+#define VALI_X23_T(T)                                                                          \
+  do {                                                                                         \
+    if (taps == 6) {                                                                           \
+      if (esset == 1) launch_x23_k<T, 1, 6>(a, rw, grid, lds, stream);                          \
+      else if (esset == 12) launch_x23_k<T, 12, 6>(a, rw, grid, lds, stream);                   \
+      else launch_x23_k<T, 2, 6>(a, rw, grid, lds, stream);                                     \
+    } else {                                                                                   \
+      if (esset == 1) launch_x23_k<T, 1, 4>(a, rw, grid, lds, stream);                          \
+      else if (esset == 12) launch_x23_k<T, 12, 4>(a, rw, grid, lds, stream);                   \
+      else launch_x23_k<T, 2, 4>(a, rw, grid, lds, stream);                                     \
+    }                                                                                          \
+  } while (0)
+  if (elem == 1) VALI_X23_T(uint8_t);
+  else VALI_X23_T(uint16_t);
+#undef VALI_X23_T
+  VALI_LAUNCH_CHECK();
+  return VALI_OK;
+}
+
 template <typename T, int ESSET, int TAPS>
 static void launch_rows_k(const ResizeArgs& a, int rows, dim3 grid, unsigned lds, hipStream_t stream) {
   if (rows == 32)
