@@ -36,7 +36,8 @@ def test_bench_single_gpu_contract(gpu):
     assert "workload" in j["config"] and "model" not in j["config"]
     assert j["verification"] == {"frames_verified_on_gpu": 16, "frames_mismatching": 0,
                                  "checksum_of_checksums": j["verification"]["checksum_of_checksums"]}
-    assert [c["config"][:4] for c in j["secondary"]] == ["NV12", "cfg2", "cfg3", "inte", "cfg4", "udge", "udpl"]
+    assert [c["config"][:4] for c in j["secondary"]] == ["NV12", "cfg2", "cfg3", "inte", "upsc", "cfg4", "udge", "udpl"]
+    assert {r["geometry"] for r in j["secondary"][4]["results"]} == {"1280x720->1920x1080", "1280x720->1600x900"}
     assert 0.3 < j["secondary"][0]["roofline"]["frac"] < 1.0
 
     def fracs(o):      # every roofline entry anywhere in the line: a fraction of the HBM peak, never above it
@@ -49,7 +50,7 @@ def test_bench_single_gpu_contract(gpu):
             for v in o:
                 yield from fracs(v)
     all_fracs = list(fracs(j))
-    assert len(all_fracs) >= 9 and all(0 < f < 1.0 for f in all_fracs), all_fracs
+    assert len(all_fracs) >= 11 and all(0 < f < 1.0 for f in all_fracs), all_fracs
     assert {r["filter"] for r in j["secondary"][3]["results"]} == {"bilinear", "lanczos"}
 
 

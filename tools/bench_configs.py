@@ -152,7 +152,7 @@ def roofline(key, bytes_per_frame, n, ms, sets=1):
     global TRAFFIC
     if TRAFFIC is None:
         prof = Path(__file__).resolve().parent.parent / "profiles"
-        f = next((q for q in (prof / "r03_secondary_traffic.json", prof / "r02_secondary_traffic.json") if q.exists()), None)
+        f = next((q for q in (prof / "r04_secondary_traffic.json", prof / "r03_secondary_traffic.json", prof / "r02_secondary_traffic.json") if q.exists()), None)
         TRAFFIC = json.loads(f.read_text()) if f else {}
     gbps = bytes_per_frame * n / (ms * 1e-3) / 1e9
     t = TRAFFIC.get(key, {})
@@ -220,6 +220,31 @@ def interp(n=64):
                         "roofline": roofline(key, b, n, ms, k)})
             del sets
     return {"config": f"interp PySurfaceResizer NV12 3840x2160->1920x1088 / 1936x1088, 1920x1080->1280x720 (non-integer ratios), batch={n}, one launch per filter",
+            "bytes_note": "whole source + destination per frame", "results": out}
+
+
+def upscale(n=64):
+    """Planes that GROW (the upscale to display size) under the reference's filter: NV12 720p -> 1080p (exactly 3:2 both ways:
+    the static form k_resize_rows_x23) and 720p -> 1600x900 (5:4, no special form: k_resize_rows, filtered rows in registers)."""
+    out = []
+    rs = vali.PySurfaceResizer(vali.NV12, DEV)                     # Lanczos-3, the reference's (and the task's default) filter
+    for (sw, sh, dw, dh) in ((1280, 720, 1920, 1080), (1280, 720, 1600, 900)):
+        b = (sw * sh + dw * dh) * 3 // 2
+        k = sets_needed(b * n)
+
+        def make():
+            srcs = [vali.Surface.Make(vali.NV12, sw, sh, DEV) for _ in range(n)]
+            dsts = [vali.Surface.Make(vali.NV12, dw, dh, DEV) for _ in range(n)]
+            fill(srcs)
+            return srcs, dsts, rs.PrepareBatch(srcs, dsts)
+        sets = make_sets(k, make)
+        ms, _ = timed(rs.Stream, [lambda q=q: rs.RunBatchAsync(q) for _, _, q in sets], 30)
+        out.append({"filter": "lanczos", "geometry": f"{sw}x{sh}->{dw}x{dh}",
+                    "kernel": "k_resize_rows_x23<u8, 12, 6, 48>" if 3 * sw == 2 * dw else "k_resize_rows<u8, 12, 6, 32>",
+                    "us_per_frame": round(ms * 1e3 / n, 3), "bytes_moved_per_frame": b,
+                    "roofline": roofline(f"upscale_{dw}x{dh}", b, n, ms, k)})
+        del sets
+    return {"config": f"upscale PySurfaceResizer NV12 1280x720 -> 1920x1080 / 1600x900 Lanczos (planes that grow), batch={n}, one launch",
             "bytes_note": "whole source + destination per frame", "results": out}
 
 
@@ -378,6 +403,6 @@ def ud_scales(n=32):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["hl1080", "cfg2", "cfg3", "interp", "cfg4", "udgen", "udplanar"]
+    which = sys.argv[1:] or ["hl1080", "cfg2", "cfg3", "interp", "upscale", "cfg4", "udgen", "udplanar"]
     for name in which:
         print(json.dumps(globals()[name]()), flush=True)

@@ -565,8 +565,9 @@ __device__ __forceinline__ void rows23_tile(const uint8_t* sp, int spitch, int s
   // ---- addresses.  A lane's group must lie inside its row: groups that would start past sw - PX start there instead and
   // are put right in registers (tiles at the right edge only).  Halo: lane 0 loads the 4 pixels before the tile, lane 63 the
   // 4 after it, every other lane its own group again (the same lines: one more request, no more traffic).
-  const bool first_tile = tx == 0;
-  const bool edge = X0 + kWave * PX + 4 > sw;          // wave-uniform: some lane (or lane 63's halo) reaches past the row
+  // (wave-uniform flags as scalar integers: branches on them are s_cmp + s_cbranch, not mask arithmetic)
+  const int first_tile = __builtin_amdgcn_readfirstlane(tx == 0 ? 1 : 0);
+  const int edge = __builtin_amdgcn_readfirstlane(X0 + kWave * PX + 4 > sw ? 1 : 0); // some lane (or lane 63's halo) reaches past the row
   const int gs = min(ps, sw - PX);                     // where the lane's group really starts
   const bool in_row = ps + PX <= sw, straddle = !in_row && ps < sw; // (straddle: ES = 1 and sw % 4 == 2 only)
   const int hp = lane == 0 ? max(X0 - 4, 0) : lane == 63 ? ps + PX : ps;
@@ -594,7 +595,7 @@ __device__ __forceinline__ void rows23_tile(const uint8_t* sp, int spitch, int s
 
   // ---- output: 6 elements per lane, lanes contiguous
   const int nel = min(DE, max(0, (dw - pd) * ES)); // 6, 3 or 0
-  const bool full = (X0 + kWave * PX) <= sw;       // wave-uniform: every lane has its 6
+  const int full = __builtin_amdgcn_readfirstlane((X0 + kWave * PX) <= sw ? 1 : 0); // wave-uniform: every lane has its 6
   uint8_t* optr = dp + (size_t)y_first * dpitch + (size_t)pd * ES * EB;
   const float* wt = wtab + 4;
   int rr = 0;
@@ -609,7 +610,10 @@ __device__ __forceinline__ void rows23_tile(const uint8_t* sp, int spitch, int s
       w0 = __builtin_amdgcn_cvt_pk_u8_f32(v[1].y, 3u, w0);
       w1 = __builtin_amdgcn_cvt_pk_u8_f32(v[2].x, 0u, w1);
       w1 = __builtin_amdgcn_cvt_pk_u8_f32(v[2].y, 1u, w1);
-      if (full || nel == DE) {
+      if (full) {
+        gstore_u<u32>(optr, w0);
+        gstore_u<uint16_t>(optr + 4, (uint16_t)w1);
+      } else if (nel == DE) {
         gstore_u<u32>(optr, w0);
         gstore_u<uint16_t>(optr + 4, (uint16_t)w1);
       } else if (nel == 3) {
@@ -620,9 +624,11 @@ __device__ __forceinline__ void rows23_tile(const uint8_t* sp, int spitch, int s
       const u32 w0 = finish_bits<T>(v[0].x) | (finish_bits<T>(v[0].y) << 16);
       const u32 w1 = finish_bits<T>(v[1].x) | (finish_bits<T>(v[1].y) << 16);
       const u32 w2 = finish_bits<T>(v[2].x) | (finish_bits<T>(v[2].y) << 16);
-      if (full || nel == DE) {
-        typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
-        const v3u32 q = {w0, w1, w2};
+      typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+      const v3u32 q = {w0, w1, w2};
+      if (full) {
+        gstore_u<v3u32>(optr, q);
+      } else if (nel == DE) {
         gstore_u<v3u32>(optr, q);
       } else if (nel == 3) {
         gstore_u<u32>(optr, w0);
