@@ -65,7 +65,7 @@ def main():
         print("  before 1st loop", count(body[:heads[0]]))
     for h in heads:
         label = re.match(r"^\.(\w+):", body[h]).group(1)
-        last = max(i for i, l in enumerate(body) if f"Header={label[1:]} " in l or f"Header={label[1:]}\t" in l or l.rstrip().endswith(f"Header={label[1:]} Depth=1"))
+        last = max((i for i, l in enumerate(body) if f"Header={label[1:]} " in l or f"Header={label[1:]}\t" in l or l.rstrip().endswith(f"Header={label[1:]} Depth=1")), default=h)
         print(f"  loop {label} ({last - h} lines)", count(body[h:last + 30]))
     if len(sys.argv) > 3:
         Path(sys.argv[3]).write_text("\n".join(body))

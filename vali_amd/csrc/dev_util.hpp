@@ -346,6 +346,8 @@ struct PlaneJob {
   int sub_x, sub_y;   // log2 subsampling of the DESTINATION plane relative to the surface size
   int ssub_x, ssub_y; // the same for the SOURCE plane (differs only for UDPlanar: YUV420 -> YUV444)
   int channels;       // interleaved channels in the plane
+  int kind;           // 0: the kernel's own operation; 1: a plane of unchanged size that the kernel copies (plane_copy_tile:
+                      // UDPlanar's luma rides in the launch that doubles its chroma planes)
   u32 first_tile, tiles_x;
   float shift_x, shift_y; // rotate only
   const uint8_t* sp;  // single-frame launches: resolved by the host

@@ -424,41 +424,13 @@ __global__ void __launch_bounds__(kBlock) k_resize_pointk(const ResizeArgs a) {
 // Planes whose size is unchanged (UDPlanar's luma at unchanged size; any filter at 1:1 is the identity for integer element
 // types, see launch_resize): a straight copy -- the point form above moved them at 3.5 TB/s.  A workgroup = 2048 bytes x 16
 // rows: every thread has its eight 16-byte loads in flight before the first store.
-constexpr int kCopyW = 2048, kCopyH = 16;
 __global__ void __launch_bounds__(kBlock) k_plane_copy(const ResizeArgs a) {
   ResizeJob job;
   u32 tx, ty, frame;
   if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
     return;
   const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
-  const int row_bytes = v.dw * job.channels * a.rows;           // a.rows: bytes per element here
-  const int c = (int)tx * kCopyW + (int)(threadIdx.x & 127u) * 16;
-  const int r0 = (int)ty * kCopyH + (int)(threadIdx.x >> 7);
-  if (row_bytes < 16) { // (uniform) planes narrower than one vector: bytes
-    if (c == 0)
-      for (int i = 0; i < kCopyH / 2; ++i) {
-        const int r = r0 + 2 * i;
-        for (int b = 0; r < v.dh && b < row_bytes; ++b)
-          gstore<uint8_t>(v.dp + (size_t)r * v.dpitch + b, gload<uint8_t>(v.sp + (size_t)r * v.spitch + b));
-      }
-    return;
-  }
-  if (c >= row_bytes)
-    return;
-  // a row's last vector slides left to END with the row (the bytes it shares with its neighbour are written twice with the
-  // same value); rows past the plane are their clamped neighbour, loaded and not stored: no predicated loads -- behind a
-  // condition every load of the array gets its own wait and a page of register copies
-  const int cc = min(c, row_bytes - 16);
-  v4u32 q[kCopyH / 2];
-#pragma unroll
-  for (int i = 0; i < kCopyH / 2; ++i)
-    q[i] = gload_u<v4u32>(v.sp + (size_t)min(r0 + 2 * i, v.dh - 1) * v.spitch + cc);
-#pragma unroll
-  for (int i = 0; i < kCopyH / 2; ++i) {
-    const int r = r0 + 2 * i;
-    if (r < v.dh)
-      gstore_u<v4u32>(v.dp + (size_t)r * v.dpitch + cc, q[i]);
-  }
+  plane_copy_tile(v, v.dw * job.channels * a.rows, tx, ty);     // a.rows: bytes per element here
 }
 
 template <typename T, int MAXC> constexpr auto k_resize_point = k_resize<T, MAXC, true>;
@@ -648,6 +620,16 @@ static int launch_resize(ResizeArgs& a, int fmt, int src_w, int src_h, int dst_w
       const bool is23 = rows_reg && tuning(VALI_TUNE_RESIZE_ROWS) != 2 && special && resize_x23_fits(a.job[k], elem, src_w, src_h, dst_w, dst_h);
       ResizeArgs& t = integer && sw == dw && sh == dh ? cpy : integer ? pts : doubled ? up2 : sh >= dh ? cols : is23 ? x23 : fits ? grow : rows;
       t.job[t.njobs++] = a.job[k];
+    }
+    // UDPlanar at unchanged size (the reference's everyday planar UD, UDSurface.cpp:84-93): the luma copy rides in the launch
+    // that doubles the chroma planes -- one launch instead of two, and the copy's memory time hides behind the filter's
+    // instruction time on the same CUs
+    if (cpy.njobs && up2.njobs && cpy.njobs + up2.njobs <= 3 && tuning(VALI_TUNE_RESIZE_POINT) == 1) {
+      for (int k = 0; k < cpy.njobs; ++k) {
+        up2.job[up2.njobs] = cpy.job[k];
+        up2.job[up2.njobs++].kind = 1;
+      }
+      cpy.njobs = 0;
     }
     int rc = VALI_OK;
     if (cpy.njobs)

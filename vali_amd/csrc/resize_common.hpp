@@ -24,6 +24,40 @@ struct ResizeArgs {
   int cols_rps;     // dst rows per slot of a wave (1, 2, 4, 8): a wave owns slots x cols_rps rows; resize_up2.hip: source rows per wave
 };
 
+// Planes whose size is unchanged (UDPlanar's luma at unchanged size; any filter at 1:1 is the identity for integer element
+// types, see launch_resize): a straight copy.  A workgroup = 2048 bytes x 16 rows: every thread has its eight 16-byte loads
+// in flight before the first store.  Shared by k_plane_copy (resize.hip) and k_resize_up2 (jobs of kind 1).
+constexpr int kCopyW = 2048, kCopyH = 16;
+__device__ __forceinline__ void plane_copy_tile(const PlaneView& v, int row_bytes, u32 tx, u32 ty) {
+  const int c = (int)tx * kCopyW + (int)(threadIdx.x & 127u) * 16;
+  const int r0 = (int)ty * kCopyH + (int)(threadIdx.x >> 7);
+  if (row_bytes < 16) { // (uniform) planes narrower than one vector: bytes
+    if (c == 0)
+      for (int i = 0; i < kCopyH / 2; ++i) {
+        const int r = r0 + 2 * i;
+        for (int b = 0; r < v.dh && b < row_bytes; ++b)
+          gstore<uint8_t>(v.dp + (size_t)r * v.dpitch + b, gload<uint8_t>(v.sp + (size_t)r * v.spitch + b));
+      }
+    return;
+  }
+  if (c >= row_bytes)
+    return;
+  // a row's last vector slides left to END with the row (the bytes it shares with its neighbour are written twice with the
+  // same value); rows past the plane are their clamped neighbour, loaded and not stored: no predicated loads -- behind a
+  // condition every load of the array gets its own wait and a page of register copies
+  const int cc = min(c, row_bytes - 16);
+  v4u32 q[kCopyH / 2];
+#pragma unroll
+  for (int i = 0; i < kCopyH / 2; ++i)
+    q[i] = gload_u<v4u32>(v.sp + (size_t)min(r0 + 2 * i, v.dh - 1) * v.spitch + cc);
+#pragma unroll
+  for (int i = 0; i < kCopyH / 2; ++i) {
+    const int r = r0 + 2 * i;
+    if (r < v.dh)
+      gstore_u<v4u32>(v.dp + (size_t)r * v.dpitch + cc, q[i]);
+  }
+}
+
 // Lanczos-3 (taps = 6) / bicubic (taps = 4) over the plane jobs of `a` (job[].comp / sub / channels filled in, planes
 // resolved for single-frame launches); one launch per channel count present.  elem = bytes per element.
 int launch_resize_taps(const ResizeArgs& a, int elem, int taps, int src_w, int src_h, int dst_w, int dst_h, int n,

@@ -39,11 +39,13 @@ namespace vali {
 constexpr int kRwPadL = 4;       // floats in front of the first staged pixel (left edge replicas; keeps 16-byte alignment)
 constexpr int kRwTile = 256;     // dst ELEMENTS per wave and row: 2 groups x 64 lanes x 2 adjacent elements
 
+// (bound_ctrl = 1: no `old` operand to copy into the destination first -- lane 63's value is never used, every lane of a
+// quad_perm has a source)
 __device__ __forceinline__ float rw_wave_shl1(float v) { // lane l gets lane l + 1's value
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 __device__ __forceinline__ u32 rw_swap_pairs(u32 v) { // lane l gets lane l ^ 1's value (quad_perm:[1,0,3,2])
-  return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xb1, 0xf, 0xf, false);
+  return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, true);
 }
 
 // the 4 pixels x ES channels of one lane's group, as loaded

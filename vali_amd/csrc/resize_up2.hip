@@ -29,11 +29,13 @@ namespace vali {
 constexpr int kUp2El = 4;                       // source elements per lane: 4 pixels of one channel, 2 of two
 constexpr int up2_span(int channels) { return channels == 1 ? 62 * 4 : 61 * 2; } // source pixels of a wave's row
 
+// (bound_ctrl: the one lane without a source reads 0 -- lanes 0 / 63 only supply halos here -- and, more to the point, the
+// instruction needs no `old` value: with old = v the compiler copies v into the destination first, one v_mov per shift)
 __device__ __forceinline__ float up2_shr1(float v) { // lane l gets lane l - 1's value
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float up2_shl1(float v) { // lane l gets lane l + 1's value
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
 // ES = interleaved channels of the plane: 1 (Y, U, V, the planes of RGB_PLANAR) or 2 (the UV plane of NV12 / P10: a lane then
@@ -57,6 +59,7 @@ __device__ __forceinline__ void up2_tile(const PlaneView& v, u32 tx, u32 ty, int
   const bool outs = lane >= 1 && lane <= LAST && j0 < sw;
   const bool left_edge = j0 == 0, right_edge = j0 + PXL == sw;  // its neighbour is outside the plane: replicate
   const bool next_last = j0 + 2 * PXL == sw;                    // (ES = 2) the next lane's pixels are the row's last
+  const int tile_edge = __builtin_amdgcn_readfirstlane((tx == 0 || ((int)tx + 1) * (LAST * PXL) >= sw) ? 1 : 0); // wave-uniform
   const u32 lane_off = (u32)(min(max(j0, 0), sw - PXL) * ES * EB);
 
   // the one weight set of the odd columns and rows: a = 1/2 exactly
@@ -70,6 +73,25 @@ __device__ __forceinline__ void up2_tile(const PlaneView& v, u32 tx, u32 ty, int
   for (int k = 0; k < TAPS; ++k)
     W[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, odd.w[k])));
 
+  // the weight pairs of the packed row pass, aligned and moved one slot (ES = 1); pinned in scalar register pairs: left to
+  // itself the compiler re-assembles the moved pairs with s_mov in front of every use
+  v2f32 wp[TAPS / 2], ws[TAPS / 2 + 1];
+#pragma unroll
+  for (int k = 0; k < TAPS / 2; ++k)
+    wp[k] = (v2f32){W[2 * k], W[2 * k + 1]};
+  ws[0] = (v2f32){0.0f, W[0]};
+#pragma unroll
+  for (int k = 1; k < TAPS / 2; ++k)
+    ws[k] = (v2f32){W[2 * k - 1], W[2 * k]};
+  ws[TAPS / 2] = (v2f32){W[TAPS - 1], 0.0f};
+  if constexpr (ES == 1) {
+#pragma unroll
+    for (int k = 0; k < TAPS / 2; ++k)
+      asm volatile("" : "+s"(wp[k]));
+#pragma unroll
+    for (int k = 0; k <= TAPS / 2; ++k)
+      asm volatile("" : "+s"(ws[k]));
+  }
   const int q_begin = r_first - kBefore;                        // the walk visits rows q_begin .. r_last + kAfter, clamped
   const int steps = r_last + kAfter - q_begin + 1;
   uint8_t* const out0 = v.dp + (size_t)(2 * max(j0, 0)) * ES * EB;
@@ -138,18 +160,52 @@ __device__ __forceinline__ void up2_tile(const PlaneView& v, u32 tx, u32 ty, int
       __builtin_amdgcn_sched_barrier(0);
       if (q >= steps) // the last trip only
         continue;
-#pragma unroll
-      for (int t = 0; t < 2 * ES; ++t) {                        // the two pixels before: the previous lane's last two
-        const float p = up2_shr1(c[PXL * ES + t]);
-        c[t] = left_edge ? c[2 * ES + t % ES] : p;
-      }
+      v2f32 h[4];
       if constexpr (ES == 1) {
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {                           // the three after: the next lane's first three
-          const float nx = up2_shl1(c[2 + t]);
-          c[6 + t] = right_edge ? c[5] : nx;
+        // the two pixels before (the previous lane's last two) and the three after (the next lane's first three); at the
+        // plane's own edges the edge pixel -- only tiles that touch an edge pay the selects
+        float L0 = up2_shr1(c[4]), L1 = up2_shr1(c[5]);
+        float R0 = up2_shl1(c[2]), R1 = up2_shl1(c[3]), R2 = up2_shl1(c[4]);
+        if (tile_edge) {
+          L0 = left_edge ? c[2] : L0; L1 = left_edge ? c[2] : L1;
+          R0 = right_edge ? c[5] : R0; R1 = right_edge ? c[5] : R1; R2 = right_edge ? c[5] : R2;
         }
+        // ---- along the row: even dst pixels are the source pixels; odd pixel i takes the taps on pixels i + 2 - kBefore ..
+        // of (L0 L1 c2 c3 c4 c5 R0 R1 R2) = aligned register pairs p0 .. p4; a window that starts at an odd position runs
+        // over the same pairs with its weights moved one slot, (0,W0) (W1,W2) .. (W_last,0): the low halves then hold the odd
+        // taps' chain, the high halves the even taps' -- the specification's two chains, for elements >= 0 bit for bit
+        const v2f32 p0 = {L0, L1}, p1 = {c[2], c[3]}, p2 = {c[4], c[5]}, p3 = {R0, R1}, p4 = {R2, 0.0f};
+        float o0, o1, o2, o3;
+        if constexpr (TAPS == 6) {
+          const v2f32 w01 = wp[0], w23 = wp[1], w45 = wp[2];
+          const v2f32 s0 = ws[0], s12 = ws[1], s34 = ws[2], s5 = ws[3];
+          v2f32 a0 = w01 * p0, a2 = w01 * p1, a1 = s0 * p0, a3 = s0 * p1;
+          a0 = __builtin_elementwise_fma(w23, p1, a0); a2 = __builtin_elementwise_fma(w23, p2, a2);
+          a1 = __builtin_elementwise_fma(s12, p1, a1); a3 = __builtin_elementwise_fma(s12, p2, a3);
+          a0 = __builtin_elementwise_fma(w45, p2, a0); a2 = __builtin_elementwise_fma(w45, p3, a2);
+          a1 = __builtin_elementwise_fma(s34, p2, a1); a3 = __builtin_elementwise_fma(s34, p3, a3);
+          a1 = __builtin_elementwise_fma(s5, p3, a1);  a3 = __builtin_elementwise_fma(s5, p4, a3);
+          o0 = a0.x + a0.y; o2 = a2.x + a2.y;
+          o1 = a1.y + a1.x; o3 = a3.y + a3.x;
+        } else {
+          const v2f32 w01 = wp[0], w23 = wp[1];
+          const v2f32 s0 = ws[0], s12 = ws[1], s3 = ws[2];
+          v2f32 a0 = s0 * p0, a2 = s0 * p1, a1 = w01 * p1, a3 = w01 * p2;
+          a0 = __builtin_elementwise_fma(s12, p1, a0); a2 = __builtin_elementwise_fma(s12, p2, a2);
+          a1 = __builtin_elementwise_fma(w23, p2, a1); a3 = __builtin_elementwise_fma(w23, p3, a3);
+          a0 = __builtin_elementwise_fma(s3, p2, a0);  a2 = __builtin_elementwise_fma(s3, p3, a2);
+          o0 = a0.y + a0.x; o2 = a2.y + a2.x;
+          o1 = a1.x + a1.y; o3 = a3.x + a3.y;
+          (void)p4;
+        }
+        asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3)); // (keeps the four sums scalar)
+        h[0] = (v2f32){c[2], o0}; h[1] = (v2f32){c[3], o1}; h[2] = (v2f32){c[4], o2}; h[3] = (v2f32){c[5], o3};
       } else {
+#pragma unroll
+        for (int t = 0; t < 2 * ES; ++t) {                      // the two pixels before: the previous lane's last two
+          const float p = up2_shr1(c[PXL * ES + t]);
+          c[t] = left_edge ? c[2 * ES + t % ES] : p;
+        }
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
           const float n0 = up2_shl1(c[4 + ch]), n1 = up2_shl1(c[6 + ch]); // the next lane's two pixels ...
@@ -159,22 +215,6 @@ __device__ __forceinline__ void up2_tile(const PlaneView& v, u32 tx, u32 ty, int
           c[10 + ch] = right_edge ? own_last : n1;
           c[12 + ch] = right_edge ? own_last : next_last ? n1 : n2;
         }
-      }
-      // ---- along the row: even dst pixels are the source pixels, odd ones the taps on pixels i + 2 - kBefore .. ----
-      v2f32 h[4];
-      if constexpr (ES == 1) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int b = i + 2 - kBefore;
-          float he = W[0] * c[b], ho = W[1] * c[b + 1];
-#pragma unroll
-          for (int k = 2; k < TAPS; k += 2) {
-            he = __builtin_fmaf(W[k], c[b + k], he);
-            ho = __builtin_fmaf(W[k + 1], c[b + k + 1], ho);
-          }
-          h[i] = (v2f32){c[2 + i], he + ho};
-        }
-      } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int b = (i + 2 - kBefore) * 2;
@@ -215,6 +255,10 @@ __global__ void __launch_bounds__(kBlock) k_resize_up2(const ResizeArgs a) {
   if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
     return;
   const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
+  if (job.kind == 1) { // a plane of unchanged size riding along (UDPlanar's luma)
+    plane_copy_tile(v, v.dw * job.channels * (int)sizeof(T), tx, ty);
+    return;
+  }
   if (UV && job.channels == 2)
     up2_tile<T, TAPS, 2>(v, tx, ty, a.cols_rps);
   else
@@ -228,12 +272,14 @@ int launch_resize_up2(const ResizeArgs& base, int elem, int taps, int src_w, int
     u32 total = 0;
     for (int k = 0; k < a.njobs; ++k) {
       const int sw = src_w >> a.job[k].ssub_x, sh = src_h >> a.job[k].ssub_y;
-      const u32 tiles_x = (u32)(sw + up2_span(a.job[k].channels) - 1) / (u32)up2_span(a.job[k].channels);
+      const bool copy = a.job[k].kind == 1; // (unchanged size: the source geometry is the destination's)
+      const u32 tiles_x = copy ? (u32)(sw * a.job[k].channels * elem + kCopyW - 1) / kCopyW
+                               : (u32)(sw + up2_span(a.job[k].channels) - 1) / (u32)up2_span(a.job[k].channels);
       if (assign) {
         a.job[k].first_tile = total;
         a.job[k].tiles_x = tiles_x;
       }
-      total += tiles_x * (u32)((sh + kWavesPerBlock * rpw - 1) / (kWavesPerBlock * rpw));
+      total += tiles_x * (copy ? (u32)((sh + kCopyH - 1) / kCopyH) : (u32)((sh + kWavesPerBlock * rpw - 1) / (kWavesPerBlock * rpw)));
     }
     return total;
   };
@@ -245,8 +291,8 @@ int launch_resize_up2(const ResizeArgs& base, int elem, int taps, int src_w, int
   // still fit one round.
   bool uv = false;
   for (int k = 0; k < a.njobs; ++k)
-    uv = uv || a.job[k].channels == 2;
-  const int occ = taps == 6 ? (elem == 1 ? (uv ? 6 : 7) : 5) : 8; // workgroups per CU (registers: tests/test_kernel_resources.py)
+    uv = uv || (a.job[k].channels == 2 && a.job[k].kind == 0);
+  const int occ = taps == 6 ? 6 : 8; // workgroups per CU (registers: tests/test_kernel_resources.py)
   int rpw = 64;
   const int forced = tuning(VALI_TUNE_RESIZE_NO_SEPARABLE); // 1 / 2 / 3: 8 / 2 / 64 rows per wave
   if (forced == 1) rpw = 8;
