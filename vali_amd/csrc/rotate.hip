@@ -170,20 +170,25 @@ __device__ __forceinline__ void rotate_tile_rgb8(const PlaneView& v, u32 tile_x,
   {
   constexpr int kLanesPerSrcRow = TW / 4, kSrcRowsPerPass = kBlock / kLanesPerSrcRow;
   const int chunk = t % kLanesPerSrcRow;
-  if (vec && tw == TW && th == TH) {
-    // Whole tiles (all but the frame's right / bottom edge): every load of the thread is issued before the first is
-    // unpacked.  Behind the per-pass edge tests below the compiler waits for each load before it issues the next --
-    // four memory round trips in a row, which is what bounded the kernel (a workgroup lived ~10 us).
+  if (vec && tw >= 4) {
+    // Every load of the thread is issued before the first is unpacked.  Behind per-pass edge tests the compiler waits for
+    // each load before it issues the next -- four memory round trips in a row, which is what bounded the kernel (a workgroup
+    // lived ~10 us).  Round 4: the tiles at the frame's bottom / right edge take this path too -- rows past the tile re-read
+    // its last row, a lane whose 4 pixels would cross the tile's right edge slides left to end with it (the LDS columns it
+    // shares with its neighbour are written twice with the same values); phase 2 never reads rows / columns past the tile.
+    // 1080 rows are 16 whole tiles and one of 56 rows: with those 30 of 510 workgroups on the serial path the 1080p frame
+    // took 2.68 us against 2.16 for 1920x1024 (profiles/r04_rotate.md).
     typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
     constexpr int kPasses = TH / kSrcRowsPerPass;
     v3u32 w[kPasses];
-    const uint8_t* q = sbase + (size_t)(t / kLanesPerSrcRow) * src_pitch + chunk * 12;
+    const int col = min(chunk * 4, tw - 4);       // first pixel of this lane's group inside the tile
+    const int r0 = t / kLanesPerSrcRow;
 #pragma unroll
     for (int pass = 0; pass < kPasses; ++pass)
-      w[pass] = gload_u<v3u32>(q + (size_t)(pass * kSrcRowsPerPass) * src_pitch);
+      w[pass] = gload_u<v3u32>(sbase + (size_t)min(pass * kSrcRowsPerPass + r0, th - 1) * src_pitch + col * 3);
 #pragma unroll
     for (int pass = 0; pass < kPasses; ++pass) {
-      u32* l = lds + (pass * kSrcRowsPerPass + t / kLanesPerSrcRow) * SD + chunk * 4;
+      u32* l = lds + (pass * kSrcRowsPerPass + r0) * SD + col;
       l[0] = w[pass].x & 0xffffffu;
       l[1] = (w[pass].x >> 24) | ((w[pass].y & 0xffffu) << 8);
       l[2] = (w[pass].y >> 16) | ((w[pass].z & 0xffu) << 16);
@@ -299,15 +304,15 @@ __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
   const uint8_t* sbase = src + (size_t)ry * src_pitch + (size_t)cx * P;
   const int row_bytes = tw * P;
   constexpr bool aligned16 = true; // (16-byte loads at any alignment, see rotate_tile_rgb8)
-  if (aligned16 && tw == kRotTile && th == kRotTile) {
-    // whole tiles: the thread's P loads are all in flight before the first LDS write (the run-time loop below waits
-    // for each load before it issues the next)
+  if (aligned16 && tw == kRotTile) {
+    // full-width tiles: the thread's P loads are all in flight before the first LDS write (the run-time loop below waits
+    // for each load before it issues the next); rows past a bottom-edge tile re-read its last row (never read back)
     constexpr int V = kRotTile * P / 16; // 16-byte vectors per tile row; kRotTile * V / kBlock = P per thread
     uint4 w[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
       const int k = t + i * kBlock, r = k / V, c = k - r * V;
-      w[i] = rot_load16(sbase + (size_t)r * src_pitch + c * 16);
+      w[i] = rot_load16(sbase + (size_t)min(r, th - 1) * src_pitch + c * 16);
     }
 #pragma unroll
     for (int i = 0; i < P; ++i) {
