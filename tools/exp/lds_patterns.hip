@@ -56,8 +56,8 @@ template <int PAT> void run(const char* name, std::vector<int> strides) {
 
 int main() {
   run<1>("ds_read_b32", {4, 8, 16, 32});
-  run<0>("ds_read_b64", {8, 16, 32, 64});
-  run<4>("ds_read_b128", {16, 32, 64});
+  run<0>("ds_read_b64", {0, 8, 16, 32, 64});
+  run<4>("ds_read_b128", {0, 8, 16, 32, 64}); // 8: every other lane 8 bytes off a 16-byte boundary; 0: broadcast
   run<2>("ds_read2_b32 +64dw", {4, 8, 16});
   run<3>("ds_read2_b32 +2dw", {8, 16, 32});
   run<10>("ds_read2st64_b32 +9", {4, 8, 16});

@@ -36,6 +36,10 @@
 
 #include <type_traits>
 
+#ifndef VALI_COLS_ABLATE
+#define VALI_COLS_ABLATE 0
+#endif
+
 namespace vali {
 
 constexpr int kColEl = 8;                    // source elements per lane and row
@@ -43,7 +47,7 @@ constexpr int kColSpan = kWave * kColEl;     // 512 source elements per tile row
 constexpr int kColPadL = 4, kColPadR = 4;    // replicas of the first / last pixel
 constexpr int kColStrip = 560;               // SLOTS (float pairs: one column of two dst rows) of a wave's strip: ES segments, pads included
 constexpr int kColLds = 2 * (kColStrip + 256); // floats: + the output transposition (256 elements x 2 rows)
-constexpr int kColProgRows = 56;             // source rows a wave may walk: its program is one lane per row, D rows of slack
+constexpr int kColWave = kColLds + 576;        // floats of a wave: + its program (kColProg)
 
 // A channel segment of the strip is two halves of kColHalf slots: positions (pixels) of even index in front, of odd index
 // behind.  Around 2:1 the windows of neighbouring dst pixels start two positions apart: their k-th taps are then
@@ -64,23 +68,48 @@ template <int HA, int HB> __device__ __forceinline__ v2f32 pk_mov(v2f32 a, v2f32
   return r;
 }
 
-// ---- the rows of a wave: per slot the weight of every source row, the rows that complete a dst row, the row offsets ----
-typedef unsigned long long u64;
-template <int P> struct ColRows {
-  float ws[P];        // lane t: the weight slot j applies to the wave's t-th source row (0.0: it has no use for the row)
-  u64 done;           // bit t: source row t completes a dst row (rows complete in order, slots in turn)
-  float ws2;          // lane t: source row t is the LAST tap of a slot's row and the FIRST tap of its next one: that first weight
-  u64 dbl;            // bit t: ... and that this happens at row t
-  u64 act[P];         // float planes: bit t: slot j uses source row t (a zero weight on a non-finite sample is no no-op)
-  u32 roff;           // lane t: byte offset of that row in the source plane
-  int ns;             // source rows the wave walks, <= kColProgRows
+// (a[H], a[H]): its own assembly string, so that the compiler cannot fold it into pk_mov's by selecting the operands
+template <int H> __device__ __forceinline__ v2f32 pk_dup(v2f32 a) {
+  v2f32 r;
+  if constexpr (H == 0) asm("v_pk_mov_b32 %0, %1, %1" : "=v"(r) : "v"(a));
+  else asm("v_pk_mov_b32 %0, %1, %1 op_sel:[1,1]" : "=v"(r) : "v"(a));
+  return r;
+}
+
+// ---- the rows of a wave: a PROGRAM in LDS, one entry per source row the wave walks ----
+// entry t = kProgEsz<P> dwords: the weight every slot applies to the wave's t-th source row (0.0: the slot has no use for
+// it) and ONE control word:
+//   bits 0..23   the source row the walk LOADS while it filters row t (its row t + D, clamped to the plane and to the
+//                wave's last row): the load address is v_mad_u32_u24(word, pitch, lane offset) -- the flags above bit 23
+//                never reach the product
+//   bit 24       row t completes a dst row (rows complete in order, slots in turn)
+//   bit 25       ... and is also the FIRST tap of the slot's next row: that weight is first_w[t]
+//   bit 26       ... and that dst row closes a PAIR (odd row of the wave, or its last): the row pass runs
+// and, float planes only (8-dword entries), a second word: bit j: slot j uses row t (a zero weight on a non-finite sample
+// is no no-op).  Everything the walk branches on is a bit of this word: no counters, no compares, no booleans kept in masks.
+// The walk fetches an entry with ONE broadcast ds_read_b128 (P <= 3) and uses the weights where they land: the packed
+// FMAs take them from the VGPR pair by op_sel.  (Round 3 kept one register per slot, lane t = row t, and paid P + 1
+// v_readlane and four scalar instructions of mask tests per source row and wave; its program ended at 56 rows -- a lane
+// per row -- so a wave owned 24 dst rows and walked 10 % of its source rows twice with its neighbour below.  Entries in
+// LDS have no such end: 112 rows, 48 dst rows per wave at 2:1.)
+template <int P, bool ACT> constexpr int kProgEsz = (P <= 3 && !ACT) ? 4 : 8;
+template <int P, bool ACT> constexpr int kProgRows = (P <= 3 && !ACT) ? 112 : 64;     // entries (the host keeps ns + D below it)
+constexpr int kColProg = 576;                                      // floats: entries + first_w
+static_assert(kProgRows<3, false> * (kProgEsz<3, false> + 1) <= kColProg && kProgRows<6, true> * (kProgEsz<6, true> + 1) <= kColProg, "program size");
+constexpr u32 kProgDone = 1u << 24, kProgDbl = 1u << 25, kProgPair = 1u << 26;
+struct ColProg {
+  u32 lds;            // LDS byte address of entry 0 (kept in a VGPR: the ds_read's address operand)
+  const float* first_w;
+  int ns;             // source rows the wave walks
+  int s_begin;        // the first of them (may be < 0: clamped when loaded)
   int y_first, last_rr;
 };
 
-// false: the wave has no rows.  `scratch`: (P + 3) x 64 floats of this wave's LDS, (2 P + 3) x 64 for float planes (ACT).
-template <int TAPS, int P, bool ACT>
-__device__ __forceinline__ bool cols_rows(int sh, int dh, int spitch, u32 ty, int rps, float* scratch, ColRows<P>& r) {
+// false: the wave has no rows.  `prog`: kColProg floats of this wave's LDS.  D = the walk's rows in flight.
+template <int TAPS, int P, bool ACT, int D>
+__device__ __forceinline__ bool cols_rows(int sh, int dh, u32 ty, int rps, float* prog, ColProg& r) {
   constexpr int kBefore = LzTap<TAPS>::kBefore;
+  constexpr int ESZ = kProgEsz<P, ACT>, NPROG = kProgRows<P, ACT>;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int rows = P * rps;                                     // dst rows of this wave, <= 64
@@ -89,72 +118,101 @@ __device__ __forceinline__ bool cols_rows(int sh, int dh, int spitch, u32 ty, in
     return false;
   r.last_rr = min(rows, dh - r.y_first) - 1;
   const float scale_y = (float)sh / (float)dh;
-  // Lane r evaluates the taps of dst row y_first + r (slot r mod P) and scatters them through LDS into the slot's
-  // row-indexed weight register.  The host picks P with floor((rr + P) s) - floor(rr s) >= TAPS - 1: the windows of a
-  // slot's rows overlap by ONE source row at most -- the last tap of row rr and the first of row rr + P (at 1.98:1 three
-  // slots, not four, and the overlap happens every ~20 rows; at 4:3 four, not six).  That first weight goes to ws2 / dbl
-  // instead of the slot's register: the walk completes and emits the old row, then starts the new one from +0 with it.
-  // So every (slot, source row) still has at most one writer.  The walk then fetches a row's P weights with v_readlane at the
-  // row index -- the wave's control flow is data, not compares and branches: the kernel is bound by the TOTAL number of
-  // instructions its waves issue (profiles/r03_lanczos.md).  A zero weight is an exact no-op on an accumulator that is
-  // never -0, for the finite values integer planes have; float planes skip the slot instead (act).
+  // Lane rr evaluates the taps of dst row y_first + rr (slot rr mod P) and scatters them into the entries of its source
+  // rows.  The host picks P with floor((rr + P) s) - floor(rr s) >= TAPS - 1: the windows of a slot's consecutive rows
+  // overlap by ONE source row at most -- the last tap of row rr and the first of row rr + P (at 1.98:1 three slots, not
+  // four, and the overlap happens every ~20 rows; at 4:3 four, not six).  That first weight goes to first_w and sets bit
+  // 25: the walk completes and emits the old row, then starts the new one from +0 with it.  So every (slot, source row)
+  // has one writer at most.  A zero weight is an exact no-op on an accumulator that is never -0, for the finite values
+  // integer planes have; float planes skip the slot instead (bits 26 ..).
   const LzTap<TAPS> vy = make_lz_tap<TAPS>(r.y_first + min(lane, rows - 1), scale_y);
-  const int s_begin = __builtin_amdgcn_readlane(vy.i, 0) - kBefore;
-  r.ns = __builtin_amdgcn_readlane(vy.i, r.last_rr) + TAPS - kBefore - s_begin;
-  float* const first_w = scratch + P * kWave;                     // ws2
-  u32* const flags = reinterpret_cast<u32*>(scratch) + (P + 1) * kWave; // [0]: the row completes a dst row; [1]: dbl; [2 + j]: slot j uses it
+  r.s_begin = __builtin_amdgcn_readlane(vy.i, 0) - kBefore;
+  r.ns = __builtin_amdgcn_readlane(vy.i, r.last_rr) + TAPS - kBefore - r.s_begin;
+  u32* const ent = reinterpret_cast<u32*>(prog);
+  float* const first_w = prog + NPROG * ESZ;
+  r.first_w = first_w;
+  r.lds = (u32)(uintptr_t)(__attribute__((address_space(3))) float*)prog;
 #pragma unroll
-  for (int j = 0; j < P + 1; ++j)
-    scratch[j * kWave + lane] = 0.0f;
-#pragma unroll
-  for (int j = 0; j < (ACT ? P + 2 : 2); ++j)
-    flags[j * kWave + lane] = 0u;
-  wave_lds_sync();
-  if (lane <= r.last_rr) {
-    const int j = lane % P;
-    const int t0 = vy.i - kBefore - s_begin;
-    // the row before this one in the slot (row - P, this wave's too) ends on this row's first source row?
-    const bool shared = lane >= P && (int)__builtin_floorf((float)(r.y_first + lane - P) * scale_y) + TAPS - 1 == vy.i;
-    if (shared) {
-      first_w[t0] = vy.w[0];
-      flags[kWave + t0] = 1u;
+  for (int t = lane; t < NPROG; t += kWave) {
+    // (rows past the wave's last repeat it: the walk's prefetch runs D rows ahead, and rows that belong to the wave
+    // below are long gone from the L2 when that wave starts on them)
+    const u32 ctl = (u32)clampi(r.s_begin + min(t + D, r.ns - 1), sh - 1);
+    if constexpr (ESZ == 4) {
+      *reinterpret_cast<uint4*>(ent + 4 * t) = make_uint4(0u, 0u, 0u, ctl);
     } else {
-      scratch[j * kWave + t0] = vy.w[0];
+      *reinterpret_cast<uint4*>(ent + 8 * t) = make_uint4(0u, 0u, 0u, 0u);
+      *reinterpret_cast<uint4*>(ent + 8 * t + 4) = make_uint4(0u, 0u, ctl, 0u);
+    }
+    first_w[t] = 0.0f;
+  }
+  wave_lds_sync();
+  // AGE of a dst row at a source row: how many of the rows before it are still being accumulated there (rows complete
+  // in order, one per source row at most, so those are the a rows right before it).  Column a of an entry holds the
+  // weight of the row of age a: the row that completes is ALWAYS column 0 -- the walk emits its first accumulator set and
+  // moves the others down one place, and nothing in it depends on which dst row it is (a choice among P slots by
+  // compare and branch cost more scalar instructions per dst row than the whole row pass has vector ones).
+  const int t0 = vy.i - kBefore - r.s_begin;
+  const int td = t0 + TAPS - 1;                                  // the source row that completes this lane's dst row
+  int age[TAPS];
+#pragma unroll
+  for (int k = 0; k < TAPS; ++k)
+    age[k] = 0;
+  {
+    int prev = td;
+#pragma unroll
+    for (int m = 1; m <= P; ++m) {
+      prev = __builtin_amdgcn_update_dpp(prev, prev, 0x138, 0xf, 0xf, false); // lane l: td of lane l - m
+#pragma unroll
+      for (int k = 0; k < TAPS; ++k)
+        age[k] += (lane >= m && prev >= t0 + k) ? 1 : 0;
+    }
+  }
+  if (lane <= r.last_rr) {
+    constexpr int CW = ESZ == 4 ? 3 : 6;                         // dword of the control word
+    // age P: the P rows before this one are all still open at its first source row -- the oldest of them completes
+    // there (the host's P admits nothing else): this row starts when that one has left
+    if (age[0] == P) {
+      first_w[t0] = vy.w[0];
+      __hip_atomic_fetch_or(ent + ESZ * t0 + CW, kProgDbl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    } else {
+      prog[ESZ * t0 + age[0]] = vy.w[0];
     }
 #pragma unroll
     for (int k = 1; k < TAPS; ++k)
-      scratch[j * kWave + t0 + k] = vy.w[k];
+      prog[ESZ * (t0 + k) + age[k]] = vy.w[k];
     if constexpr (ACT) {
 #pragma unroll
       for (int k = 0; k < TAPS; ++k)
-        flags[(2 + j) * kWave + t0 + k] = 1u;
+        if (k > 0 || age[0] < P)
+          __hip_atomic_fetch_or(ent + ESZ * (t0 + k) + CW + 1, 1u << age[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
-    flags[t0 + TAPS - 1] = 1u; // (at most one dst row completes per source row: scale_y >= 1)
+    // (at most one dst row completes per source row: scale_y >= 1)
+    const u32 fin = kProgDone | (((lane & 1) != 0 || lane == r.last_rr) ? kProgPair : 0u);
+    __hip_atomic_fetch_or(ent + ESZ * (t0 + TAPS - 1) + CW, fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
   }
-  wave_lds_sync();
-#pragma unroll
-  for (int j = 0; j < P; ++j)
-    r.ws[j] = scratch[j * kWave + lane];
-  r.ws2 = first_w[lane];
-  r.done = __ballot(flags[lane] != 0u);
-  r.dbl = __ballot(flags[kWave + lane] != 0u);
-#pragma unroll
-  for (int j = 0; j < P; ++j)
-    r.act[j] = ACT ? __ballot(flags[(2 + j) * kWave + lane] != 0u) : 0ull;
-  // (lanes past the wave's last row repeat it: the walk's prefetch runs D rows ahead, and rows that belong to the wave
-  // below are long gone from the L2 when that wave started on them -- 8 % more HBM reads)
-  r.roff = (u32)(clampi(s_begin + min(lane, r.ns - 1), sh - 1) * spitch);
   wave_lds_sync();
   return true;
 }
 
-// The walk over the wave's source rows.  A lane loads ND dwords per row at sp + row offset + lane_off (D rows in
-// flight), conv() turns them into the 8 floats it filters, every slot takes fma(w, f, acc) with its scalar weight, and
-// when a row completes a dst row emit(rr, acc) gets that row's 8 column results.
-// NF = float pairs a lane filters per row (4: 8 elements; 6: the 12 elements of the 3:2-along-x form).
-template <typename T, int TAPS, int P, int ND, int D, int NF = 4, typename Conv, typename Emit>
-__device__ __forceinline__ void cols_walk(const ColRows<P>& r, const uint8_t* sp, u32 lane_off, Conv conv, Emit emit) {
+// (w[H], w[H]) * f + acc in one instruction: the weight is one half of a VGPR pair, broadcast by op_sel
+template <int H> __device__ __forceinline__ void pk_fma_h(v2f32& acc, v2f32 w, v2f32 f) {
+  if constexpr (H == 0)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(w), "v"(f));
+  else
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "v"(f));
+}
+
+// The walk over the wave's source rows.  A lane loads ND dwords per row at sp + row * pitch + lane_off (D rows in
+// flight), conv() turns them into the 2 NF floats it filters, every slot takes fma(w, f, acc) with the weight of its
+// program entry, and when a row completes a dst row take(pair, rr, c) gets that row's column results -- pair: the row
+// closes a pair of dst rows (program bit 26).
+template <typename T, int TAPS, int P, int ND, int D, int NF = 4, typename Conv, typename Take>
+__device__ __forceinline__ void cols_walk(const ColProg& r, const uint8_t* sp, int spitch, int sh, u32 lane_off,
+                                          Conv conv, Take take) {
   constexpr int EB = (int)sizeof(T);
+  constexpr bool ACT = EB == 4;
+  constexpr int ESZ = kProgEsz<P, ACT>;
+  typedef __attribute__((address_space(3))) const v4f32 lds_v4;
   v2f32 acc[P][NF];
 #pragma unroll
   for (int j = 0; j < P; ++j)
@@ -162,23 +220,23 @@ __device__ __forceinline__ void cols_walk(const ColRows<P>& r, const uint8_t* sp
     for (int i = 0; i < NF; ++i)
       acc[j][i] = (v2f32){0.0f, 0.0f};
   u32 pf[D][ND];
-  auto issue = [&](int t, u32 (&q)[ND]) { // t < 64 (host: ns <= kColProgRows, rounded up to D, + D)
-    const uint8_t* p = sp + (u32)__builtin_amdgcn_readlane((int)r.roff, t);
+  auto issue = [&](u32 off, u32 (&q)[ND]) {
+    const uint8_t* p = sp + off;
     if constexpr (ND == 2) {
-      const v2u32 w = gload_u<v2u32>(p + lane_off);
+      const v2u32 w = gload_u<v2u32>(p);
       q[0] = w.x; q[1] = w.y;
     } else if constexpr (ND == 3) {
       typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
-      const v3u32 w = gload_u<v3u32>(p + lane_off);
+      const v3u32 w = gload_u<v3u32>(p);
       q[0] = w.x; q[1] = w.y; q[2] = w.z;
     } else if constexpr (ND == 6) {
       typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
-      const v3u32 w0 = gload_u<v3u32>(p + lane_off), w1 = gload_u<v3u32>(p + lane_off + 12);
+      const v3u32 w0 = gload_u<v3u32>(p), w1 = gload_u<v3u32>(p + 12);
       q[0] = w0.x; q[1] = w0.y; q[2] = w0.z; q[3] = w1.x; q[4] = w1.y; q[5] = w1.z;
     } else {
 #pragma unroll
       for (int c = 0; c < ND / 4; ++c) {
-        const v4u32 w = gload_u<v4u32>(p + lane_off + 16 * c);
+        const v4u32 w = gload_u<v4u32>(p + 16 * c);
         q[4 * c] = w.x; q[4 * c + 1] = w.y; q[4 * c + 2] = w.z; q[4 * c + 3] = w.w;
       }
     }
@@ -186,10 +244,15 @@ __device__ __forceinline__ void cols_walk(const ColRows<P>& r, const uint8_t* sp
   // (scheduling barriers: vmcnt retires in order, the rows must be ISSUED in order -- DESIGN.md 5d)
 #pragma unroll
   for (int j = 0; j < D; ++j) {
-    issue(j, pf[j]);
+    issue((u32)(clampi(r.s_begin + min(j, r.ns - 1), sh - 1) * spitch) + lane_off, pf[j]);
     __builtin_amdgcn_sched_barrier(0);
   }
-  int emit_rr = 0, eslot = 0; // the next dst row to complete and its slot: rows complete in order, slots in turn
+  u32 vprog = r.lds;
+  asm volatile("" : "+v"(vprog)); // (a VGPR: entry t0 + d is then an offset field, not a scalar add and a copy per row)
+  v4f32 e0 = *(lds_v4*)(uintptr_t)vprog, e1 = (v4f32){0.0f, 0.0f, 0.0f, 0.0f};
+  if constexpr (ESZ == 8)
+    e1 = *(lds_v4*)(uintptr_t)(vprog + 16u);
+  int emit_rr = 0; // the next dst row to complete
 #pragma unroll 1
   for (int t0 = 0; t0 < r.ns; t0 += D) {
 #pragma unroll
@@ -203,47 +266,80 @@ __device__ __forceinline__ void cols_walk(const ColRows<P>& r, const uint8_t* sp
       for (int i = 0; i < NF; ++i)
         asm volatile("" : "+v"(f[i])); // (pins the conversions in front of the barrier: they have no other order)
       __builtin_amdgcn_sched_barrier(0);
-      issue(t + D, pf[d]);
+      // (__float_as_uint of a vector element: __builtin_bit_cast applied to the element lvalue e1.w read element 0)
+      const u32 ctl = __float_as_uint(ESZ == 4 ? e0.w : e1.z);
+      const u32 actv = __float_as_uint(e1.w);
+      issue(__umul24(ctl, (u32)spitch) + lane_off, pf[d]);
+      const v4f32 c0 = e0, c1 = e1;
+      // the next row's entry: in flight under this row's arithmetic
+      e0 = *(lds_v4*)(uintptr_t)(vprog + (u32)((d + 1) * ESZ * 4));
+      if constexpr (ESZ == 8)
+        e1 = *(lds_v4*)(uintptr_t)(vprog + (u32)((d + 1) * ESZ * 4 + 16));
       __builtin_amdgcn_sched_barrier(0);
       if (t >= r.ns) // the last trip only: rows past the end are loaded (the issue order stays countable), not used
         continue;
-      float w[P];
+#if VALI_COLS_ABLATE == 1 // (timing experiments only: the memory stream and the conversions)
 #pragma unroll
-      for (int j = 0; j < P; ++j) // (the weights first, the arithmetic after: no wait states between a v_readlane and its use)
-        w[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.ws[j]), t));
+      for (int i = 0; i < NF; ++i)
+        acc[0][i] += f[i];
+      continue;
+#endif
+      const u32 flags = (u32)__builtin_amdgcn_readfirstlane((int)ctl);
+      const v2f32 w01 = (v2f32){c0.x, c0.y}, w23 = (v2f32){c0.z, c0.w}, w45 = (v2f32){c1.x, c1.y};
+      u32 act = 0u;
+      if constexpr (ACT)
+        act = (u32)__builtin_amdgcn_readfirstlane((int)actv);
 #pragma unroll
       for (int j = 0; j < P; ++j) {
-        if constexpr (EB == 4) {
-          if (((r.act[j] >> t) & 1ull) == 0ull) // wave-uniform
+        if constexpr (ACT) {
+          if (((act >> j) & 1u) == 0u) // wave-uniform
             continue;
         }
-        const v2f32 wv = (v2f32){w[j], w[j]};
 #pragma unroll
-        for (int i = 0; i < NF; ++i)
-          acc[j][i] = __builtin_elementwise_fma(wv, f[i], acc[j][i]);
-      }
-      if ((r.done >> t) & 1ull) { // at most one dst row per source row (scale_y >= 1)
-#pragma unroll
-        for (int j = 0; j < P; ++j) {
-          if (eslot == j) {
-            emit(emit_rr, acc[j]);
-            if ((r.dbl >> t) & 1ull) { // this source row is also the first tap of the slot's next row
-              const float w2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.ws2), t));
-#pragma unroll
-              for (int i = 0; i < NF; ++i)
-                acc[j][i] = __builtin_elementwise_fma((v2f32){w2, w2}, f[i], (v2f32){0.0f, 0.0f});
-            } else {
-#pragma unroll
-              for (int i = 0; i < NF; ++i)
-                acc[j][i] = (v2f32){0.0f, 0.0f};
-            }
-          }
+        for (int i = 0; i < NF; ++i) {
+          if (j == 0) pk_fma_h<0>(acc[j][i], w01, f[i]);
+          else if (j == 1) pk_fma_h<1>(acc[j][i], w01, f[i]);
+          else if (j == 2) pk_fma_h<0>(acc[j][i], w23, f[i]);
+          else if (j == 3) pk_fma_h<1>(acc[j][i], w23, f[i]);
+          else if (j == 4) pk_fma_h<0>(acc[j][i], w45, f[i]);
+          else pk_fma_h<1>(acc[j][i], w45, f[i]);
         }
-        eslot = eslot == P - 1 ? 0 : eslot + 1;
+      }
+#if VALI_COLS_ABLATE == 2 // (... and the column arithmetic)
+      continue;
+#endif
+      if (flags & kProgDone) { // at most one dst row per source row (scale_y >= 1): the row of age 0
+        take((flags & kProgPair) != 0u, emit_rr, acc[0]);
+#pragma unroll
+        for (int j = 0; j + 1 < P; ++j)
+#pragma unroll
+          for (int i = 0; i < NF; ++i)
+            acc[j][i] = acc[j + 1][i];
+        if (flags & kProgDbl) { // this source row is also the first tap of the row that enters (age P - 1 from here on)
+          const float w2 = r.first_w[t];
+#pragma unroll
+          for (int i = 0; i < NF; ++i)
+            acc[P - 1][i] = __builtin_elementwise_fma((v2f32){w2, w2}, f[i], (v2f32){0.0f, 0.0f});
+        } else {
+#pragma unroll
+          for (int i = 0; i < NF; ++i)
+            acc[P - 1][i] = (v2f32){0.0f, 0.0f};
+        }
         ++emit_rr;
       }
     }
+    vprog += (u32)(D * ESZ * 4);
   }
+#if VALI_COLS_ABLATE
+  float sum = 0.0f;
+#pragma unroll
+  for (int j = 0; j < P; ++j)
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+      sum += acc[j][i].x + acc[j][i].y;
+  if (sum == 1.2345e-30f)
+    *(VALI_GLOBAL float*)const_cast<uint8_t*>(sp) = sum;
+#endif
 }
 
 template <typename T> __device__ __forceinline__ void conv8(const u32 (&d)[2 * sizeof(T)], v2f32 (&f)[4]) {
@@ -267,7 +363,10 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
   constexpr int kBefore = LzTap<TAPS>::kBefore;
   constexpr int EB = (int)sizeof(T);
   constexpr int ND = 2 * EB;                                    // dwords of a lane's 8 elements
-  constexpr int D = EB == 4 ? 3 : EB == 2 ? 3 : P >= 4 ? 2 : 4; // source rows in flight (registers: 8 EB bytes per lane and row; the 4- and 6-slot kernels trade two rows for their fourth wave per SIMD)
+#ifndef VALI_COLS_D
+#define VALI_COLS_D 4
+#endif
+  constexpr int D = EB == 4 ? 3 : EB == 2 ? 3 : P >= 4 ? 2 : VALI_COLS_D; // source rows in flight (registers: 8 EB bytes per lane and row; the 4- and 6-slot kernels trade two rows for their fourth wave per SIMD)
   constexpr int HALF = kColHalf<ES>, SEG = 2 * HALF;            // slots
   const int lane = threadIdx.x & 63;
   v2f32* const strip = reinterpret_cast<v2f32*>(lds);           // one slot = one column of TWO dst rows
@@ -299,18 +398,18 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
       lds[k * kWave + lane] = c.w[k];
     reinterpret_cast<int*>(lds)[TAPS * kWave + lane] = c.i;
     __syncthreads();
-    const float* const all = lds - wave * kColLds;
+    const float* const all = lds - wave * kColWave;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
 #pragma unroll
       for (int k = 0; k < TAPS / 2; ++k)
-        wq[p][k] = (v2f32){all[p * kColLds + 2 * k * kWave + lane], all[p * kColLds + (2 * k + 1) * kWave + lane]};
-      ci[p] = reinterpret_cast<const int*>(all)[p * kColLds + TAPS * kWave + lane];
+        wq[p][k] = (v2f32){all[p * kColWave + 2 * k * kWave + lane], all[p * kColWave + (2 * k + 1) * kWave + lane]};
+      ci[p] = reinterpret_cast<const int*>(all)[p * kColWave + TAPS * kWave + lane];
     }
     __syncthreads();
   }
-  ColRows<P> r;
-  if (!cols_rows<TAPS, P, EB == 4>(sh, dh, spitch, ty, rps, lds, r))
+  ColProg r;
+  if (!cols_rows<TAPS, P, EB == 4, D>(sh, dh, ty, rps, lds + kColLds, r))
     return;
 
   // ---- the tile's source span along x (wave-uniform) ----
@@ -325,7 +424,6 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
   // end where their last row ends); the elements it shares with its neighbour are written twice with the same value
   const bool ragged = j_begin + kColEl * nl > row_el;           // wave-uniform: only a row's last tile
   const int j0 = min(j_begin + kColEl * min(lane, nl - 1), row_el - kColEl);
-  const bool has = lane < nl;
 
   // strip slots of this lane's 8 elements.  1- and 2-element pixels: its pixels are consecutive positions q0 .. -- those
   // of q0's parity are one run of adjacent slots (wpos[0] ..), the others another (wpos[1] ..); q0 % 4 == 0 unless the
@@ -367,7 +465,14 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
       q = __builtin_amdgcn_cvt_pk_u8_f32(v1, 1u, q);
       q = __builtin_amdgcn_cvt_pk_u8_f32(v2, 2u, q);
       q = __builtin_amdgcn_cvt_pk_u8_f32(v3, 3u, q);
+#if VALI_COLS_ABLATE == 5 // (timing experiments: no stores)
+      if (q == 0x12345678u && v0 == 3.25f)
+        gstore<u32>(out, q);
+#elif VALI_COLS_ABLATE == 6 // (... stores through the L2)
+      gstore<u32>(out, q);
+#else
       gstore_nt<u32>(out, q);
+#endif
     } else {
       const float res[4][1] = {{v0}, {v1}, {v2}, {v3}};
       store_px4<T, 1>(out, res, (1u << n_out) - 1u);
@@ -380,23 +485,31 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
   // read aligned float pairs of ONE row: eight of each, and an add).  A wave's last row may be single: it runs as a
   // pair with itself.  (Writing the halves of a slot as the rows complete, ds_write_b32 at a stride of 8 dwords between
   // lanes, is an 8-way bank conflict per instruction: measured slower than the r03 form.)
-  v2f32 hold[4]; // the columns of the pair's first row
-  auto emit = [&](int rr, v2f32 (&c)[4]) {
-    const bool single = (rr & 1) == 0;                 // wave-uniform
-    if (single) {
+  v2f32 hold[4];      // the columns of the pair's first row
+  // the first row of a pair is kept, the second goes to the strip with it
+  auto take = [&](bool pair, int rr, v2f32 (&c)[4]) {
+    if (!pair) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         hold[i] = c[i];
-      if (rr != r.last_rr)
-        return;
+      return;
     }
-    if (has) {
-      v2f32 lo[4], hi[4]; // (row a, row b) of this lane's columns 2 i / 2 i + 1 (ES = 2: U / V of pixel i)
+    v2f32 lo[4], hi[4]; // (row a, row b) of this lane's columns 2 i / 2 i + 1 (ES = 2: U / V of pixel i)
+    if ((rr & 1) == 0) { // the wave's last row is the first of a pair: the pair is the row twice
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        lo[i] = pk_dup<0>(c[i]);
+        hi[i] = pk_dup<1>(c[i]);
+      }
+    } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         lo[i] = pk_mov<0, 0>(hold[i], c[i]);
         hi[i] = pk_mov<1, 1>(hold[i], c[i]);
       }
+    }
+    // (lanes past the tile's last chunk repeat it -- j0 -- with the same data: no predicate)
+    {
       if constexpr (ES == 3) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -426,6 +539,9 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
         *reinterpret_cast<float4*>(strip + wpos[1] + 2) = make_float4(hi[2].x, hi[2].y, hi[3].x, hi[3].y);
       }
     }
+#if VALI_COLS_ABLATE == 3 // (... and the strip writes, no row pass)
+    return;
+#endif
     wave_lds_sync();
     if (pad_left || pad_right) { // image edges: replicas of the first / last pixel of every channel segment
       const int ch = lane >> 3, i = lane & 7;
@@ -511,16 +627,12 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
       float4 v0, v1; // (a0, b0, a1, b1), (a2, b2, a3, b3)
       asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
                    : "=&v"(v0), "=&v"(v1) : "v"(lds_base + 8u * (u32)kColStrip + 32u * (u32)lane) : "memory");
-      if (single) {
-        store_row(rr, v0.x, v0.z, v1.x, v1.z);
-      } else {
-        store_row(rr - 1, v0.x, v0.z, v1.x, v1.z);
-        store_row(rr, v0.y, v0.w, v1.y, v1.w);
-      }
+      store_row(rr - (rr & 1), v0.x, v0.z, v1.x, v1.z); // (a last row on its own: twice)
+      store_row(rr, v0.y, v0.w, v1.y, v1.w);
     }
     wave_lds_sync();
   };
-  cols_walk<T, TAPS, P, ND, D>(r, sp, (u32)(j0 * EB), [](const u32 (&d)[ND], v2f32 (&f)[4]) { conv8<T>(d, f); }, emit);
+  cols_walk<T, TAPS, P, ND, D>(r, sp, spitch, sh, (u32)(j0 * EB), [](const u32 (&d)[ND], v2f32 (&f)[4]) { conv8<T>(d, f); }, take);
 }
 
 // Exactly 2:1 along x (src_w == 2 dst_w: x * scale_x is an integer, every column weight is 0 or 1 and the pass along the
@@ -537,8 +649,8 @@ __device__ __forceinline__ void cols_tile_x2(const uint8_t* sp, int spitch, int 
   constexpr int ND = 4 * EB;                                    // dwords of a lane's 16 source elements
   constexpr int D = EB == 1 ? 8 : 4;                            // rows in flight: this form is bound by its memory stream (8 vs 4: -5 %)
   const int lane = threadIdx.x & 63;
-  ColRows<P> r;
-  if (!cols_rows<TAPS, P, false>(sh, dh, spitch, ty, rps, strip, r))
+  ColProg r;
+  if (!cols_rows<TAPS, P, false, D>(sh, dh, ty, rps, strip, r))
     return;
   const int dwe = dw * ES;                                      // >= 8 (host)
   const int e0 = (int)tx * (kWave * 8);
@@ -559,7 +671,7 @@ __device__ __forceinline__ void cols_tile_x2(const uint8_t* sp, int spitch, int 
         f[i] = (v2f32){(float)(d[2 * i] & 0xffffu), (float)(d[2 * i] >> 16)};
     }
   };
-  auto emit = [&](int rr, v2f32 (&c)[4]) {
+  auto emit = [&](bool, int rr, v2f32 (&c)[4]) {
     if (!has)
       return;
     uint8_t* const out = dp + (u32)((r.y_first + rr) * dpitch) + (size_t)eo * EB;
@@ -575,7 +687,7 @@ __device__ __forceinline__ void cols_tile_x2(const uint8_t* sp, int spitch, int 
       store_px4<T, 2>(out, res, 0xfu);
     }
   };
-  cols_walk<T, TAPS, P, ND, D>(r, sp, (u32)(2 * eo * EB), conv, emit);
+  cols_walk<T, TAPS, P, ND, D>(r, sp, spitch, sh, (u32)(2 * eo * EB), conv, emit);
 }
 
 // Exactly 3:2 along x (2 src_w == 3 dst_w: x * scale_x is an integer for even x -- the column weights are {0,0,1,0,0,0}: the
@@ -611,10 +723,10 @@ __device__ __forceinline__ void cols_tile_x32(const uint8_t* sp, int spitch, int
   constexpr int D = EB == 1 ? 4 : 2;
   constexpr int kBefore = LzTap<TAPS>::kBefore;
   const int lane = threadIdx.x & 63;
-  ColRows<P> r;
+  ColProg r;
   int y_first = 0;                                              // dst row of emit()'s row 0
   if constexpr (!SROWS) {
-    if (!cols_rows<TAPS, P, false>(sh, dh, spitch, ty, rps, strip, r))
+    if (!cols_rows<TAPS, P, false, D>(sh, dh, ty, rps, strip, r))
       return;
     y_first = r.y_first;
   }
@@ -646,7 +758,7 @@ __device__ __forceinline__ void cols_tile_x32(const uint8_t* sp, int spitch, int
         f[i] = (v2f32){(float)(d[i] & 0xffffu), (float)(d[i] >> 16)};
     }
   };
-  auto emit = [&](int rr, v2f32 (&cc)[6]) {
+  auto emit = [&](bool, int rr, v2f32 (&cc)[6]) {
     // c[0..11]: this lane's column results; halo: HB elements before, HA after (one pixel before, two after)
     constexpr int HB = ES, HA = 2 * ES;
     float c[HB + 12 + HA];
@@ -720,7 +832,7 @@ __device__ __forceinline__ void cols_tile_x32(const uint8_t* sp, int spitch, int
   };
   (void)first; (void)beyond;
   if constexpr (!SROWS) {
-    cols_walk<T, TAPS, P, ND, D, 6>(r, sp, lane_off, conv, emit);
+    cols_walk<T, TAPS, P, ND, D, 6>(r, sp, spitch, sh, lane_off, conv, emit);
   } else {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int m_first = (int)(ty * kWavesPerBlock + wave) * rps;  // rps: dst row PAIRS per wave here
@@ -778,9 +890,9 @@ __device__ __forceinline__ void cols_tile_x32(const uint8_t* sp, int spitch, int
         }
         const int m = m_first + q / 3;                            // the pair whose even row sits on this source row (ph == 1)
         if (ph == 1 && m <= m_last)
-          emit(2 * m, f);
+          emit(true, 2 * m, f);
         if (ph == 2 && m - 1 >= m_first && m - 1 <= m_last)       // tap 5 of the odd row of the pair before
-          emit(2 * (m - 1) + 1, acc[jb]);
+          emit(true, 2 * (m - 1) + 1, acc[jb]);
       }
     }
   }
@@ -789,7 +901,7 @@ __device__ __forceinline__ void cols_tile_x32(const uint8_t* sp, int spitch, int
 // ESSET as in resize_taps.hip: 1 = one-channel planes, 12 = NV12 / P10 (Y + UV), 3 = packed RGB
 template <typename T, int ESSET, int TAPS, int P>
 __global__ void __launch_bounds__(kBlock) k_resize_cols(const ResizeArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kColLds];
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kColWave];
   ResizeJob job;
   u32 tx, ty, frame;
   if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
@@ -809,7 +921,7 @@ __global__ void __launch_bounds__(kBlock) k_resize_cols(const ResizeArgs a) {
 
 template <typename T, int ESSET, int TAPS, int P>
 __global__ void __launch_bounds__(kBlock) k_resize_cols_x2(const ResizeArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][576]; // scratch of cols_rows: (P + 3) x 64
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kColProg]; // the waves' programs (cols_rows)
   ResizeJob job;
   u32 tx, ty, frame;
   if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
@@ -824,7 +936,7 @@ __global__ void __launch_bounds__(kBlock) k_resize_cols_x2(const ResizeArgs a) {
 
 template <typename T, int ESSET, int TAPS, int P, bool SROWS = false>
 __global__ void __launch_bounds__(kBlock) k_resize_cols_x32(const ResizeArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][576]; // scratch of cols_rows: (P + 3) x 64
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kColProg]; // the waves' programs (cols_rows)
   ResizeJob job;
   u32 tx, ty, frame;
   if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
@@ -975,12 +1087,13 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
     return launch_direct();
   const int pmin = taps == 6 ? 3 : 2, pmid = taps == 6 ? 4 : 3, pmax = taps == 6 ? 6 : 4;
   const int P = slots <= pmin ? pmin : slots <= pmid ? pmid : pmax;
-  // rows per wave = P x rps, rps <= 8 (a slot's weights are one register: 8 rows x 8 lanes) and small enough for the
-  // wave's program: (rows - 1) scale_y + taps + 1 source rows <= kColProgRows
-  int rps_max = 8;
+  // rows per wave = P x rps <= 64 (a lane evaluates a row's taps) and few enough for the wave's program in LDS:
+  // (rows - 1) scale_y + taps + 1 source rows, + the walk's rows in flight (<= 8), <= kProgRows<P>
+  const int prog_rows = (P <= 3 && elem != 4) ? kProgRows<3, false> : kProgRows<6, true>;
+  int rps_max = 64 / P;
   for (int k = 0; k < a.njobs; ++k) {
     const double sy = (double)(src_h >> a.job[k].ssub_y) / (double)(dst_h >> a.job[k].sub_y) * (1.0 + 1e-6);
-    while (rps_max > 0 && (P * rps_max - 1) * sy + taps + 1 > (double)kColProgRows)
+    while (rps_max > 0 && (P * rps_max - 1) * sy + taps + 1 + 8 > (double)prog_rows)
       --rps_max;
   }
   if (rps_max < 1)
@@ -1016,11 +1129,14 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
   };
   // rows per slot: as many as the program allows (the tile's TAPS - 1 shared source rows weigh least) while the launch still
   // fills the chip, fewer for small launches -- a lone wave walks its rows one memory round trip after the other
-  int rps = rps_max;
+  // (the forms without a row pass are bound by their memory stream, and short waves serve it best: 2:1 along x, 64
+  // frames of 2160p -> 1920x1088, rows per slot 16 / 8 / 4 / 2 / 1: 3.2 / 3.05 / 2.95 / 2.78 / 3.2 us -- the rows two
+  // neighbouring waves both walk come from the L2 while both run; the general form wants long waves: 4.05 / 4.2 / 4.55)
+  int rps = x2 ? (rps_max < 2 ? rps_max : 2) : x32 ? (rps_max < 4 ? rps_max : 4) : rps_max;
   if (force == 1) rps = rps_max < 2 ? rps_max : 2;
   else if (force == 2) rps = 1;
   else if (force == 3) rps = rps_max;
-  else if (force >= 11 && force <= 18) rps = force - 10 < rps_max ? force - 10 : rps_max; // (measurements: rows per slot = value - 10)
+  else if (force >= 11 && force <= 42) rps = force - 10 < rps_max ? force - 10 : rps_max; // (measurements: rows per slot = value - 10)
   else
     // (2048 workgroups = 8 waves per SIMD: with fewer the launch's last round leaves SIMDs idle -- 64 frames of 1080p -> 720p
     // were 6912 waves of 30 rows, 1.4 rounds)
