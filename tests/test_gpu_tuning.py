@@ -79,7 +79,8 @@ CASES = [
     ("RESIZE_ROWS", (0,), lambda v, g: resize(v, g, 640, 360, 1000, 700, v.Interpolation.CUBIC)),
     ("UD_DOWN2", (0, 2), lambda v, g: ud(v, g, 1280, 720, 640, 360, v.RGB)),
     ("UD_DOWN2", (0, 2), lambda v, g: ud(v, g, 1276, 720, 638, 360, v.RGB)),
-    ("UD_DOWN2", (0,), lambda v, g: ud(v, g, 1280, 720, 1280, 720, v.RGB_PLANAR)),
+    ("UD_DOWN2", (0, 2), lambda v, g: ud(v, g, 1280, 720, 1280, 720, v.RGB_PLANAR)),   # 2: k_ud_lean with the general rows
+    ("UD_DOWN2", (0, 2), lambda v, g: ud(v, g, 1280, 720, 1280, 360, v.RGB)),
     ("UD_OCC5", (1,), lambda v, g: ud(v, g, 1280, 720, 854, 480, v.RGB)),     # (a no-op since round 2)
     ("UD_OCC5", (1,), lambda v, g: ud(v, g, 140, 108, 4, 57, v.RGB)),
     ("UD_FORCE_GATHER", (1,), lambda v, g: ud(v, g, 1280, 720, 854, 480, v.RGB)),

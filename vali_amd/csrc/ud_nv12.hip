@@ -30,10 +30,12 @@
 // Kernels in this file:
 //   k_ud_nv12<T,OUT,STAGED,ROT>  any scale factor, NV12 / P10, every output; VALU-bound (4.8 us per
 //                                2160p -> 1080p frame)
-//   k_ud_down2<OUT,ROT,RATIO>    source exactly twice as wide as the output (RATIO 2) or as wide (1), NV12,
-//                                8-bit outputs, 0 / 180 degree output: wide loads, no LDS staging (3.8 us)
-//   k_ud_down2_t<ROT>            the same for the 90 / 270 degree outputs (4.35 us, config 4 in one pass)
-// all three produce the same bits (tests/test_gpu_ud_down2.py); profiles/r01_ud_down2.md has the
+//   k_ud_lean<OUT,RATIO>         source exactly twice as wide as the output (RATIO 2) or as wide (1), NV12, any height,
+//                                8-bit outputs, un-rotated, width a multiple of 8: wide loads, no LDS staging
+//                                (round 4; round 1's k_ud_down2 also took ragged widths and the half turn and spilled)
+//   k_ud_half / k_ud_32 / k_ud_half_t   exactly 2:1 and 3:2 both ways, and 2:1 turned by 90 / 270 degrees
+//   k_ud_down2_t<ROT>            2:1 along x at any height for the 90 / 270 degree outputs
+// all produce the same bits (tests/test_gpu_ud_down2.py); profiles/r01_ud_down2.md has the
 // counters that led from the first to the other two.
 #include "common.hpp"
 #include "dev_util.hpp"
@@ -951,28 +953,6 @@ __device__ __forceinline__ void d2_compute(const D2Taps& rt, const D2Quad& r, fl
 struct D1Oct {
   u32 p[4], a[4], b[4];
 };
-__device__ __forceinline__ D1Oct d1_gather(const D2Src& s, const D2Taps& rt, int x0) {
-  D1Oct r;
-  const int cw = s.sw / 2, c0 = x0 / 2;
-  const uint8_t* yr[2] = {s.py + (u32)(rt.ty.i0 * s.sp_y), s.py + (u32)(rt.ty.i1 * s.sp_y)};
-  const uint8_t* cr[2] = {s.puv + (u32)(rt.tcy.i0 * s.sp_uv), s.puv + (u32)(rt.tcy.i1 * s.sp_uv)};
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    auto lb = [&](int c) { return (u32)gload<uint8_t>(yr[k] + min(max(c, 0), s.sw - 1)); };
-    auto cp = [&](int q) { // one UV pair as 16 bits
-      const uint8_t* t = cr[k] + 2 * min(max(q, 0), cw - 1);
-      return (u32)gload<uint8_t>(t) | ((u32)gload<uint8_t>(t + 1) << 8);
-    };
-    r.p[k] = lb(x0 - 1) << 24;
-    r.a[k] = lb(x0) | (lb(x0 + 1) << 8) | (lb(x0 + 2) << 16) | (lb(x0 + 3) << 24);
-    r.b[k] = lb(x0 + 4) | (lb(x0 + 5) << 8) | (lb(x0 + 6) << 16) | (lb(x0 + 7) << 24);
-    r.p[2 + k] = cp(c0 - 1) << 16;
-    r.a[2 + k] = cp(c0) | (cp(c0 + 1) << 16);
-    r.b[2 + k] = cp(c0 + 2) | (cp(c0 + 3) << 16);
-  }
-  return r;
-}
-
 // P A B of four rows -> the three components (scaled by UdScale) of the lane's 8 pixels
 template <int OUT, bool kEven>
 __device__ __forceinline__ void d1_compute(const D2Taps& rt, const D1Oct& r, float* c0, float* c1, float* c2) {
@@ -1027,309 +1007,15 @@ __device__ __forceinline__ void d1_compute(const D2Taps& rt, const D1Oct& r, flo
   }
 }
 
-template <int OUT, int ROT, int RATIO = 2>
-__global__ void __launch_bounds__(kBlock) k_ud_down2(const UdArgs a) {
-  using T = uint8_t;
-  static_assert(RATIO == 1 || RATIO == 2, "source width = RATIO x UD width");
-  static_assert(ROT == 0 || ROT == 2, "the transposed outputs: k_ud_down2_t");
-  static_assert(ROT == 0 || OUT == UD_RGB_U8, "rotated output: NV12 -> RGB only");
-  u32 tile_x, tile_y, frame;
-  if (!tile_of_block(a.map, tile_x, tile_y, frame))
-    return;
-  const SurfRef s = load_surface(a.d_src, a.src, frame);
-  const SurfRef d = load_surface(a.d_dst, a.dst, frame);
-  const uint8_t* py = s.p[0];
-  const uint8_t* puv = s.p[1];
-  const int sp_y = s.pitch[0], sp_uv = s.pitch[1], sw = s.width, sh = s.height;
-  const int dw = d.width, dh = d.height;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int xw = tile_x * kD2WaveW;          // first column of the wave
-  const int x0 = xw + lane * kD2LanePx;      // first column of the lane
-  const int rpw = ROT == 0 ? a.rows : kUdRowsPerWave;
-  const int y_first = (tile_y * kWavesPerBlock + wave) * rpw; // wave-uniform
-  if (y_first >= dh)
-    return;
-  const int n = min(kD2LanePx, dw - x0);
-  if (__builtin_amdgcn_readfirstlane(n) <= 0) // (n falls with the lane index)
-    return;
-  const float scale_y = 1.0f * (float)dh / (float)sh; // ResizeUtils.cu:136
-  // row taps, lane-parallel, read back as scalars (as in k_ud_nv12)
-  const float cyl = (float)(y_first + (lane & (kUdRowsPerWave - 1))) / scale_y;
-  const Tap vty = make_tap(cyl, sh), vtcy = make_tap(cyl * 0.5f, sh / 2);
-  using RowTaps = D2Taps;
-  auto row_taps = [&](int rr) {
-    RowTaps r;
-    r.ty.i0 = __builtin_amdgcn_readlane(vty.i0, rr);
-    r.ty.i1 = __builtin_amdgcn_readlane(vty.i1, rr);
-    r.ty.w0 = (u32)__builtin_amdgcn_readlane((int)vty.w0, rr);
-    r.ty.w1 = (u32)__builtin_amdgcn_readlane((int)vty.w1, rr);
-    r.tcy.i0 = __builtin_amdgcn_readlane(vtcy.i0, rr);
-    r.tcy.i1 = __builtin_amdgcn_readlane(vtcy.i1, rr);
-    r.tcy.w0 = (u32)__builtin_amdgcn_readlane((int)vtcy.w0, rr);
-    r.tcy.w1 = (u32)__builtin_amdgcn_readlane((int)vtcy.w1, rr);
-    return r;
-  };
-  using Quad = D2Quad;
-  const D2Src srcv = {py, puv, sp_y, sp_uv, sw};
-  auto gather = [&](const RowTaps& rt, int xh) { return d2_gather(srcv, rt, xh); };
-  auto compute = [&](auto even, const RowTaps& rt, const Quad& r, float* c0, float* c1, float* c2) {
-    d2_compute<OUT, decltype(even)::value>(rt, r, c0, c1, c2);
-  };
-  // slow path: 4 pixels at a time through the general store (any n, any alignment)
-  auto finish = [&](const RowTaps& rt, const Quad& r, int xh, int nh, int y) {
-    float c0[4], c1[4], c2[4];
-    compute(std::false_type{}, rt, r, c0, c1, c2);
-    ud_emit<T, OUT, ROT, false>(d, nullptr, wave, lane, 0, xh, y, nh, dw, dh, c0, c1, c2);
-  };
-  // fast path: the lane's 8 pixels of row y.  Planar outputs: one dwordx2 per plane.  Packed RGB:
-  // the wave's 1536 bytes go through its LDS strip so that each store instruction writes 16
-  // consecutive bytes per lane (24-byte lane groups would fill half of every instruction).
-  constexpr bool kPacked = OUT == UD_RGB_U8;
-  __shared__ __attribute__((aligned(16))) uint8_t strip[kPacked ? kWavesPerBlock : 1][kPacked ? kD2WaveW * 3 : 16];
-  auto emit_planar = [&](int y, int xo, const float (&c0)[8], const float (&c1)[8], const float (&c2)[8]) {
-    const int pp[3] = {d.pitch[0], OUT == UD_YUV444 ? d.pitch[1] : d.pitch[0], OUT == UD_YUV444 ? d.pitch[2] : d.pitch[0]};
-    // the six dwords of the three planes (lo / hi halves of the lane's 8 pixels)
-    u32 planes_w[6];
-    trunc_pack3x4(c0[0], c0[1], c0[2], c0[3], c0[4], c0[5], c0[6], c0[7], c1[0], c1[1], c1[2], c1[3], planes_w[0], planes_w[1], planes_w[2]);
-    trunc_pack3x4(c1[4], c1[5], c1[6], c1[7], c2[0], c2[1], c2[2], c2[3], c2[4], c2[5], c2[6], c2[7], planes_w[3], planes_w[4], planes_w[5]);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      uint8_t* o = d.p[k] + (u32)(y * pp[k]) + xo;
-      const u32 lo = planes_w[2 * k], hi = planes_w[2 * k + 1];
-      if ((((uintptr_t)o) & 7u) == 0)
-        UD_ST8(o, make_uint2(lo, hi));
-      else // the slid last lane of a ragged row, foreign pitches: the same 8 bytes at any alignment
-        gstore_u<v2u32>(o, (v2u32){lo, hi});
-    }
-  };
-  // packed RGB, step 1 (lanes with 8 valid pixels): the lane's 24 bytes into the wave's strip, in
-  // memory order: pixels 0..7 (ROT 0) or 7..0 from the far end (ROT 2: the row reversed)
-  // (`direct` != nullptr: the slid last lane of a ragged row -- its 24 bytes go straight to memory, they are not on the
-  // strip's 24-byte lane grid)
-  auto strip_put = [&](const float (&c0)[8], const float (&c1)[8], const float (&c2)[8], uint8_t* direct) {
-    auto px = [&](int j) { return ROT == 2 ? 7 - j : j; };
-    u32 w[6];
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const int a0 = px(4 * g), a1 = px(4 * g + 1), a2 = px(4 * g + 2), a3 = px(4 * g + 3);
-      trunc_pack3x4(c0[a0], c1[a0], c2[a0], c0[a1], c1[a1], c2[a1], c0[a2], c1[a2], c2[a2], c0[a3], c1[a3], c2[a3],
-                    w[3 * g + 0], w[3 * g + 1], w[3 * g + 2]);
-    }
-    if (direct) {
-      gstore_u<v2u32>(direct, (v2u32){w[0], w[1]});
-      gstore_u<v2u32>(direct + 8, (v2u32){w[2], w[3]});
-      gstore_u<v2u32>(direct + 16, (v2u32){w[4], w[5]});
-      return;
-    }
-    uint8_t* st = strip[kPacked ? wave : 0];
-    const int so = ROT == 2 ? (kD2WaveW - kD2LanePx) * 3 - 24 * lane : 24 * lane;
-    *reinterpret_cast<uint2*>(st + so) = make_uint2(w[0], w[1]);
-    *reinterpret_cast<uint2*>(st + so + 8) = make_uint2(w[2], w[3]);
-    *reinterpret_cast<uint2*>(st + so + 16) = make_uint2(w[4], w[5]);
-  };
-  // step 2 (every lane): strip byte b -> destination byte orow + b, 16 bytes per lane; the strip
-  // holds the pixels of the wave's full lanes only: the first 3 nwf bytes (ROT 0) or the last (ROT 2)
-  const int nwf = (min(kD2WaveW, dw - xw) / kD2LanePx) * kD2LanePx;
-  auto strip_flush = [&](uint8_t* orow) {
-    const uint8_t* st = strip[kPacked ? wave : 0];
-    const int vb0 = ROT == 2 ? (kD2WaveW - nwf) * 3 : 0, vb1 = ROT == 2 ? kD2WaveW * 3 : nwf * 3;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int b = (lane + kWave * h) * 16;
-      if (b < kD2WaveW * 3 && b + 16 > vb0 && b < vb1) {
-        const uint4 v = *reinterpret_cast<const uint4*>(st + b);
-        if (b >= vb0 && b + 16 <= vb1) {
-          if ((((uintptr_t)orow) & 15u) == 0) // wave-uniform
-            UD_ST16(orow + b, v);
-          else
-            gstore_u<v4u32>(orow + b, (v4u32){v.x, v.y, v.z, v.w});
-        } else {
-          const u32 vv[4] = {v.x, v.y, v.z, v.w};
-          for (int k = 0; k < 16; ++k)
-            if (b + k >= vb0 && b + k < vb1)
-              gstore<uint8_t>(orow + b + k, (uint8_t)(vv[k >> 2] >> (8 * (k & 3))));
-        }
-      }
-    }
-  };
-
-  // the lane's pixels of row y through byte gathers and the general store
-  auto slow_lane = [&](const RowTaps& rt, int y) {
-    if constexpr (RATIO == 2) {
-#pragma unroll 1
-      for (int h = 0; h < 2; ++h)
-        if (n > 4 * h)
-          finish(rt, gather(rt, x0 + 4 * h), x0 + 4 * h, min(4, n - 4 * h), y);
-    } else {
-      float c0[8], c1[8], c2[8];
-      d1_compute<OUT, false>(rt, d1_gather(srcv, rt, x0), c0, c1, c2);
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-        if (n > 4 * h) {
-          const float (&h0)[4] = *reinterpret_cast<const float (*)[4]>(c0 + 4 * h);
-          const float (&h1)[4] = *reinterpret_cast<const float (*)[4]>(c1 + 4 * h);
-          const float (&h2)[4] = *reinterpret_cast<const float (*)[4]>(c2 + 4 * h);
-          ud_emit<T, OUT, ROT, false>(d, nullptr, wave, lane, 0, x0 + 4 * h, y, min(4, n - 4 * h), dw, dh, h0, h1, h2);
-        }
-    }
-  };
-  constexpr int kLaneBytes = 8 * RATIO; // the lane's own bytes of a luma row and of a chroma row
-  const bool aligned = ((((uintptr_t)py) | ((uintptr_t)puv) | (uintptr_t)sp_y | (uintptr_t)sp_uv) & (kLaneBytes - 1)) == 0 &&
-                       sw >= kLaneBytes;
-  if (!aligned) {
-#pragma unroll 1
-    for (int rr = 0; rr < rpw; ++rr) {
-      const int y = y_first + rr;
-      if (y >= dh)
-        break;
-      const RowTaps rt = row_taps(rr);
-      if (n > 0)
-        slow_lane(rt, y);
-    }
-    return;
-  }
-  // vector path: unconditional, clamped loads (lanes past the row re-read its last 16 bytes), the
-  // next row's loads in flight while this row is computed
-  struct Rows {
-    uint4 v[4]; // the lane's 16 bytes of luma i0, luma i1, chroma i0, chroma i1
-    u32 before; // lane k < 4: the dword before the WAVE's first byte in row k; lane 4 + k: before the SLID lane's
-  };
-  // Ragged widths (dw % 8 != 0, un-rotated output): the row's last lane has n < 8 pixels.  Instead of sending it down the
-  // byte-gather path (the whole wave waits for it: 2.1 us instead of 0.9 at 958x538) its window SLIDES left to end with
-  // the row -- pixels dw-8 .. dw-1, a full group again, from a misaligned 16-byte load; the pixels it shares with its
-  // neighbour are computed and stored twice with identical bytes.  Its "byte before" cannot come from the neighbour's
-  // registers: lanes 4..7 fetch it with the load that lanes 0..3 use for the wave's own first column.
-  const bool slid = ROT == 0 && n > 0 && n < kD2LanePx && dw >= kD2LanePx;
-  const int xs = slid ? dw - kD2LanePx : x0;                 // first column of the lane's window
-  const int xs_w = dw - kD2LanePx;                           // ... of the slid lane, wave-uniform (used only when one exists)
-  const int off16 = slid ? RATIO * xs : min(RATIO * x0, (sw - kLaneBytes) & ~(kLaneBytes - 1));
-  const int offw = (lane & 4) ? max(RATIO * xs_w - 4, 0) : max(RATIO * xw - 4, 0);
-  auto issue = [&](const RowTaps& rt) {
-    Rows r;
-    const uint8_t* row[4] = {py + (u32)(rt.ty.i0 * sp_y), py + (u32)(rt.ty.i1 * sp_y),
-                             puv + (u32)(rt.tcy.i0 * sp_uv), puv + (u32)(rt.tcy.i1 * sp_uv)};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if constexpr (RATIO == 2) {
-        const v4u32 w = gload_u<v4u32>(row[k] + (u32)off16); // (16-byte aligned but for the slid lane)
-        r.v[k] = make_uint4(w.x, w.y, w.z, w.w);
-      } else {
-        const v2u32 w = gload_u<v2u32>(row[k] + (u32)off16);
-        r.v[k] = make_uint4(w.x, w.y, 0u, 0u);
-      }
-    }
-    const int lk = lane & 3;
-    const uint8_t* rb = lk == 0 ? row[0] : lk == 1 ? row[1] : lk == 2 ? row[2] : row[3];
-    r.before = gload_u<u32>(rb + (u32)offw);
-    return r;
-  };
-  const int last = min(rpw - 1, dh - 1 - y_first); // last valid row of the wave
-  // one row: `rows` (loaded an iteration ago) -> pixels -> stores
-  auto step = [&](int rr, const RowTaps& cur, const Rows& rows) {
-    const int y = y_first + rr;
-    // packed RGB: where row y of the wave starts in the destination, less the strip offset
-    uint8_t* orow = nullptr;
-    bool vec = true;
-    if constexpr (kPacked) {
-      orow = ROT == 2 ? d.p[0] + (u32)((dh - 1 - y) * d.pitch[0]) + (ptrdiff_t)(dw - xw - kD2WaveW) * 3
-                      : d.p[0] + (u32)(y * d.pitch[0]) + (size_t)xw * 3;
-      // (any alignment: a half turn of an output whose width is not a multiple of 16 starts its rows at odd offsets;
-      // the strip then leaves through misaligned 16-byte stores instead of sending every lane to the general store)
-    }
-    // (broadcast BEFORE the divergent branch below: inside it only the lanes with 8 pixels run, and
-    // a load whose only reader sits there may be sunk into it -- lanes 1..3 of a wave whose lane 0
-    // alone is full would then never fetch their dword)
-    u32 before[4], before_s[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      before[k] = (u32)__builtin_amdgcn_readlane((int)rows.before, k);
-      before_s[k] = (u32)__builtin_amdgcn_readlane((int)rows.before, 4 + k);
-    }
-    if ((n == kD2LanePx || slid) && vec) {
-      // the 4 bytes before the lane's own: the previous lane's last dword; lane 0 takes the
-      // wave's extra load, or the clamp (column -1 = column 0) at the left edge of the image
-      u32 prev[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const u32 edge = k < 2 ? rows.v[k].x << 24 : rows.v[k].x << 16;
-        const u32 first = xw == 0 ? edge : before[k];
-        const u32 first_s = xs_w == 0 ? edge : before_s[k];
-        const u32 sh1 = wave_shr1(RATIO == 2 ? rows.v[k].w : rows.v[k].y);
-        prev[k] = slid ? first_s : lane == 0 ? first : sh1;
-      }
-      float c0[8], c1[8], c2[8];
-      const bool even = cur.ty.w0 == 128u && cur.tcy.w0 == 128u; // (w1 = 256 - w0) wave-uniform
-      if constexpr (RATIO == 2) {
-        Quad q0, q1;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          q0.p[k] = prev[k]; q0.a[k] = rows.v[k].x; q0.b[k] = rows.v[k].y;
-          q1.p[k] = rows.v[k].y; q1.a[k] = rows.v[k].z; q1.b[k] = rows.v[k].w;
-        }
-        if (even) {
-          compute(std::true_type{}, cur, q0, c0, c1, c2);
-          compute(std::true_type{}, cur, q1, c0 + 4, c1 + 4, c2 + 4);
-        } else {
-          compute(std::false_type{}, cur, q0, c0, c1, c2);
-          compute(std::false_type{}, cur, q1, c0 + 4, c1 + 4, c2 + 4);
-        }
-      } else {
-        D1Oct o;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { o.p[k] = prev[k]; o.a[k] = rows.v[k].x; o.b[k] = rows.v[k].y; }
-        if (even)
-          d1_compute<OUT, true>(cur, o, c0, c1, c2);
-        else
-          d1_compute<OUT, false>(cur, o, c0, c1, c2);
-      }
-      if constexpr (kPacked)
-        strip_put(c0, c1, c2, slid ? d.p[0] + (u32)(y * d.pitch[0]) + (size_t)xs * 3 : nullptr);
-      else
-        emit_planar(y, xs, c0, c1, c2);
-    } else if (n > 0) { // frames narrower than one group, and the tail lane of a ragged HALF-TURNED row
-      slow_lane(cur, y);
-    }
-    if constexpr (kPacked) {
-      if (vec) {
-        wave_lds_sync();
-        strip_flush(orow);
-        wave_lds_sync(); // the strip is re-used by the next row
-      }
-    }
-  };
-  // Two rows in flight: a row's loads are issued right AFTER the row that held its registers is computed, i.e. two
-  // steps before they are needed, and the walk is unrolled by two so that both register sets are named statically
-  // (every trip issues the same loads in the same order -- rows past the last re-read it -- so the compiler counts
-  // vmcnt instead of draining it).  The former shape (issue the next row, compute this one, copy) had the same two
-  // sets live but only one row of distance, and its copy waited for the loads at the end of every row.
-  RowTaps ta = row_taps(0);
-  Rows ra = issue(ta);
-  __builtin_amdgcn_sched_barrier(0); // rows stay in issue order (vmcnt retires in order)
-  RowTaps tb = row_taps(min(1, last));
-  Rows rb = issue(tb);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll 1
-  for (int rr = 0; rr <= last; rr += 2) {
-    step(rr, ta, ra);
-    ta = row_taps(min(rr + 2, last));
-    ra = issue(ta);
-    if (rr + 1 <= last)
-      step(rr + 1, tb, rb);
-    tb = row_taps(min(rr + 3, last));
-    rb = issue(tb);
-  }
-}
-
 // ---- exactly 2:1 in BOTH directions (src = 2 dw x 2 dh), output width a multiple of 8: BASELINE config 4's UD ----
-// k_ud_down2 serves every height, ragged widths, foreign alignment and the half turn from one body, and pays for it on
-// the geometry that matters most: 667 instructions per wave and row in the hot loop, 77 of them v_readlane (16 needed:
+// Round 1's k_ud_down2 served every height, ragged widths, foreign alignment and the half turn from one body, and paid for
+// it on the geometry that matters most: 667 instructions per wave and row in the hot loop, 77 of them v_readlane (16 needed:
 // 75 spilled SGPRs come back through lanes), 39 skipped-over exec-mask branches of the byte-wise strip flush -- and the
 // kernel is bound by the instructions it issues (73 M VALU + 26 M scalar per 64-frame launch = 75 % of its 221 us at
 // one instruction per 4 cycles and SIMD; profiles/r03_ud_half.md).  Here every row's vertical weights are 128 / 128 by
 // construction (rows 2y-1, 2y of luma, y-1, y of chroma: make_tap(2y) and make_tap(y)), so there are no row taps to
 // broadcast and no second arithmetic form; every lane has 8 pixels or none; accesses are the unaligned-tolerant forms of
-// the same instructions, so alignment needs no second path either.  Same bytes as k_ud_down2 (d2_compute<OUT, true>).
+// the same instructions, so alignment needs no second path either.  Same bytes as the general kernel (d2_compute<OUT, true>).
 template <int OUT>
 __global__ void __launch_bounds__(kBlock) k_ud_half(const UdArgs a) {
   using T = uint8_t;
@@ -1458,6 +1144,171 @@ __global__ void __launch_bounds__(kBlock) k_ud_half(const UdArgs a) {
     if (rr + 1 <= last)
       step(rr + 1, rb, above);
     above = rb.v[3];
+    rb = issue(rr + 3);
+  }
+}
+
+// ---- the lean form at ANY height: source width = RATIO x UD width (RATIO 2: every other exact 2:1-wide geometry; RATIO 1:
+// colour conversion with chroma interpolation at unchanged width), output width a multiple of 8, un-rotated ----
+// Round 1's k_ud_down2 served these together with ragged widths, foreign alignment, the half turn and the byte-gather
+// tails from one body and spilled 13-75 SGPRs in every instantiation.  This is k_ud_half's body
+// with the row taps put back: lane rr of the wave evaluates the taps of its rr-th dst row (row offsets and the two
+// weight pairs), a row's eight scalars arrive by v_readlane; every lane has 8 pixels or none; the unaligned-tolerant
+// forms of the loads and stores make alignment a non-issue.  Everything else (ragged widths at these ratios, the half
+// turn) runs on the general kernel: correct and bit-identical, a little slower, and rare.
+// EVEN: every row's vertical weights are (128, 128), (256, 0) or (0, 256) -- unchanged height (luma rows y - 1, y at
+// 128 / 128; chroma 128 / 128 on even rows, the single row (y - 1) / 2 on odd ones) and exactly halved height.  A
+// weight of 256 on one row is 128 on that row twice: the lane-parallel taps point both row slots at it, and what is
+// left is k_ud_half's arithmetic -- the second row's dot product accumulates onto the first, no multiplications, no
+// weights to broadcast (float(128 S') * c == float(S') * (128 c), a power of two: the same bits).
+template <int OUT, int RATIO, bool EVEN>
+__global__ void __launch_bounds__(kBlock) k_ud_lean(const UdArgs a) {
+  using T = uint8_t;
+  static_assert(RATIO == 1 || RATIO == 2, "source width = RATIO x UD width");
+  constexpr bool kPacked = OUT == UD_RGB_U8;
+  u32 tile_x, tile_y, frame;
+  if (!tile_of_block(a.map, tile_x, tile_y, frame))
+    return;
+  const SurfRef s = load_surface(a.d_src, a.src, frame);
+  const SurfRef d = load_surface(a.d_dst, a.dst, frame);
+  const int dw = d.width, dh = d.height, sh = s.height;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int xw = tile_x * kD2WaveW;
+  const int y_first = (int)(tile_y * kWavesPerBlock + wave) * a.rows; // wave-uniform
+  if (y_first >= dh)
+    return;
+  const int last = min(a.rows, dh - y_first) - 1;
+  const int x0 = xw + lane * kD2LanePx;
+  const bool has = x0 < dw;                                            // dw % 8 == 0: 8 pixels or none
+  const u32 offl = (u32)(RATIO * min(x0, dw - kD2LanePx));             // the lane's 8 RATIO bytes of a row; idle lanes re-read the last group
+  const u32 offw = (u32)max(RATIO * xw - 4, 0);
+  // row taps, lane-parallel (lane rr: the wave's rr-th row; rows past the last repeat it)
+  const float scale_y = 1.0f * (float)dh / (float)sh;                  // ResizeUtils.cu:136
+  const float cyl = (float)(y_first + min(lane & (kUdRowsPerWave - 1), last)) / scale_y;
+  Tap vty = make_tap(cyl, sh), vtcy = make_tap(cyl * 0.5f, sh / 2);
+  if constexpr (EVEN) { // (host: the height is unchanged or halved) a row with the whole weight takes both slots
+    if (vty.w1 == 0u) vty.i1 = vty.i0;
+    if (vty.w0 == 0u) vty.i0 = vty.i1;
+    if (vtcy.w1 == 0u) vtcy.i1 = vtcy.i0;
+    if (vtcy.w0 == 0u) vtcy.i0 = vtcy.i1;
+  }
+  const u32 vro[4] = {(u32)(vty.i0 * s.pitch[0]), (u32)(vty.i1 * s.pitch[0]), (u32)(vtcy.i0 * s.pitch[1]), (u32)(vtcy.i1 * s.pitch[1])};
+  struct Rows {
+    uint4 v[4]; // the lane's bytes of luma i0, luma i1, chroma i0, chroma i1 (RATIO 1: x, y only)
+    u32 before; // lane k < 4: the dword before the wave's first byte in row k
+  };
+  auto issue = [&](int rr) {
+    const int q = min(rr, last);
+    const uint8_t* row[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      row[k] = (k < 2 ? s.p[0] : s.p[1]) + (u32)__builtin_amdgcn_readlane((int)vro[k], q);
+    Rows r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if constexpr (RATIO == 2) {
+        const v4u32 w = gload_u<v4u32>(row[k] + offl);
+        r.v[k] = make_uint4(w.x, w.y, w.z, w.w);
+      } else {
+        const v2u32 w = gload_u<v2u32>(row[k] + offl);
+        r.v[k] = make_uint4(w.x, w.y, 0u, 0u);
+      }
+    }
+    const int lk = lane & 3;
+    const uint8_t* rb = lk == 0 ? row[0] : lk == 1 ? row[1] : lk == 2 ? row[2] : row[3];
+    r.before = gload_u<u32>(rb + offw);
+    return r;
+  };
+  __shared__ __attribute__((aligned(16))) uint8_t strip[kPacked ? kWavesPerBlock : 1][kPacked ? kD2WaveW * 3 : 16];
+  const int nbytes = min(kD2WaveW, dw - xw) * 3;                        // packed RGB bytes of the wave's row, a multiple of 24
+  const bool dst16 = ((((uintptr_t)d.p[0]) | (uintptr_t)d.pitch[0]) & 15u) == 0 && (xw * 3 & 15) == 0; // wave-uniform
+  auto step = [&](int rr, const Rows& rows) {
+    const int y = y_first + rr;
+    D2Taps rt = {};                                   // (the rows are loaded: only the weights are used from here on)
+    if constexpr (!EVEN) {
+      rt.ty.w0 = (u32)__builtin_amdgcn_readlane((int)vty.w0, rr);
+      rt.ty.w1 = (u32)__builtin_amdgcn_readlane((int)vty.w1, rr);
+      rt.tcy.w0 = (u32)__builtin_amdgcn_readlane((int)vtcy.w0, rr);
+      rt.tcy.w1 = (u32)__builtin_amdgcn_readlane((int)vtcy.w1, rr);
+    }
+    u32 prev[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { // the 4 bytes before the lane's own: the previous lane's last dword; lane 0: the wave's extra
+      const u32 before = (u32)__builtin_amdgcn_readlane((int)rows.before, k); // load, or the clamp at the image's left edge
+      const u32 edge = k < 2 ? rows.v[k].x << 24 : rows.v[k].x << 16;
+      const u32 sh1 = wave_shr1(RATIO == 2 ? rows.v[k].w : rows.v[k].y);
+      prev[k] = lane == 0 ? (xw == 0 ? edge : before) : sh1;
+    }
+    float c0[8], c1[8], c2[8];
+    if constexpr (RATIO == 2) {
+      D2Quad q0, q1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        q0.p[k] = prev[k]; q0.a[k] = rows.v[k].x; q0.b[k] = rows.v[k].y;
+        q1.p[k] = rows.v[k].y; q1.a[k] = rows.v[k].z; q1.b[k] = rows.v[k].w;
+      }
+      d2_compute<OUT, EVEN>(rt, q0, c0, c1, c2);
+      d2_compute<OUT, EVEN>(rt, q1, c0 + 4, c1 + 4, c2 + 4);
+    } else {
+      D1Oct o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { o.p[k] = prev[k]; o.a[k] = rows.v[k].x; o.b[k] = rows.v[k].y; }
+      d1_compute<OUT, EVEN>(rt, o, c0, c1, c2);
+    }
+    if constexpr (kPacked) {
+      u32 w[6];
+      trunc_pack3x4(c0[0], c1[0], c2[0], c0[1], c1[1], c2[1], c0[2], c1[2], c2[2], c0[3], c1[3], c2[3], w[0], w[1], w[2]);
+      trunc_pack3x4(c0[4], c1[4], c2[4], c0[5], c1[5], c2[5], c0[6], c1[6], c2[6], c0[7], c1[7], c2[7], w[3], w[4], w[5]);
+      uint8_t* st = strip[kPacked ? wave : 0];
+      if (has) {
+        *reinterpret_cast<uint2*>(st + 24 * lane) = make_uint2(w[0], w[1]);
+        *reinterpret_cast<uint2*>(st + 24 * lane + 8) = make_uint2(w[2], w[3]);
+        *reinterpret_cast<uint2*>(st + 24 * lane + 16) = make_uint2(w[4], w[5]);
+      }
+      wave_lds_sync();
+      uint8_t* orow = d.p[0] + (u32)(y * d.pitch[0]) + (u32)(xw * 3);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) { // strip byte b -> destination byte orow + b, 16 bytes per lane (nbytes: a multiple of 24, so
+        const int b = (lane + kWave * h) * 16; // the last piece may be 8 bytes)
+        if (b + 16 <= nbytes) {
+          const uint4 v = *reinterpret_cast<const uint4*>(st + b);
+          if (dst16)
+            UD_ST16(orow + b, v);
+          else
+            gstore_u<v4u32>(orow + b, (v4u32){v.x, v.y, v.z, v.w});
+        } else if (b < nbytes) {
+          const uint2 v = *reinterpret_cast<const uint2*>(st + b);
+          gstore_u<v2u32>(orow + b, (v2u32){v.x, v.y});
+        }
+      }
+      wave_lds_sync(); // the strip is re-used by the next row
+    } else if (has) {
+      const int pp[3] = {d.pitch[0], OUT == UD_YUV444 ? d.pitch[1] : d.pitch[0], OUT == UD_YUV444 ? d.pitch[2] : d.pitch[0]};
+      u32 pw[6]; // lo / hi dwords of the lane's 8 pixels in the three planes
+      trunc_pack3x4(c0[0], c0[1], c0[2], c0[3], c0[4], c0[5], c0[6], c0[7], c1[0], c1[1], c1[2], c1[3], pw[0], pw[1], pw[2]);
+      trunc_pack3x4(c1[4], c1[5], c1[6], c1[7], c2[0], c2[1], c2[2], c2[3], c2[4], c2[5], c2[6], c2[7], pw[3], pw[4], pw[5]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        uint8_t* o = d.p[k] + (u32)(y * pp[k]) + (u32)x0;
+        if ((((uintptr_t)d.p[k] | (uintptr_t)pp[k]) & 7u) == 0) // wave-uniform
+          UD_ST8(o, make_uint2(pw[2 * k], pw[2 * k + 1]));
+        else
+          gstore_u<v2u32>(o, (v2u32){pw[2 * k], pw[2 * k + 1]});
+      }
+    }
+  };
+  // two rows in flight, the walk unrolled by two so that both register sets are named statically
+  Rows ra = issue(0);
+  __builtin_amdgcn_sched_barrier(0);
+  Rows rb = issue(1);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+  for (int rr = 0; rr <= last; rr += 2) {
+    step(rr, ra);
+    ra = issue(rr + 2);
+    if (rr + 1 <= last)
+      step(rr + 1, rb);
     rb = issue(rr + 3);
   }
 }
@@ -2020,16 +1871,22 @@ static int launch_ud(UdArgs& a, int src_fmt, int src_w, int src_h, int dst_w, in
   // with the whole wave waiting (1916x1076 -> 958x538 half-turned: 2.4 us against 1.1 through the general kernel), so
   // those geometries go to the general kernel.  VALI_TUNE_UD_DOWN2 = 2 keeps them here (A/B, tests of that path).
   const int down2_mode = tuning(VALI_TUNE_UD_DOWN2);
+  // the lean exact-ratio kernels own 8 output pixels per lane: widths that are multiples of 8, un-rotated; ragged widths and
+  // the half turn at these ratios run on the general kernel (bit-identical)
+  const bool lean_on = down2_mode != 0 && !force_gather && src_fmt == VALI_FMT_NV12 && rot == 0 && dst_w % kD2LanePx == 0 &&
+                       kind != UD_RGB_F32 && kind != UD_RGB_F32_PLANAR; // (float outputs are store-bound: 4 pixels per lane fill their stores better)
   const bool down2_on = down2_mode != 0 && (down2_mode == 2 || dst_w % kD2LanePx == 0 || (rot == 0 && dst_w >= kD2LanePx));
-  if (down2_on && !force_gather && src_fmt == VALI_FMT_NV12 && src_w == dst_w && !(rot & 1) && kind != UD_RGB_F32 &&
-      kind != UD_RGB_F32_PLANAR) { // 1:1 width: colour conversion with chroma interpolation
+  if (lean_on && src_w == dst_w) { // 1:1 width: colour conversion with chroma interpolation
     a.rows = rows_for((dst_w + kD2WaveW - 1) / kD2WaveW);
     a.map = make_tile_map((dst_w + kD2WaveW - 1) / kD2WaveW, (dst_h + kWavesPerBlock * a.rows - 1) / (kWavesPerBlock * a.rows), (u32)n);
     const dim3 g1 = tile_grid(a.map);
-    if (rot == 2) hipLaunchKernelGGL((k_ud_down2<UD_RGB_U8, 2, 1>), g1, block, 0, stream, a);
-    else if (kind == UD_YUV444) hipLaunchKernelGGL((k_ud_down2<UD_YUV444, 0, 1>), g1, block, 0, stream, a);
-    else if (kind == UD_RGB_U8) hipLaunchKernelGGL((k_ud_down2<UD_RGB_U8, 0, 1>), g1, block, 0, stream, a);
-    else hipLaunchKernelGGL((k_ud_down2<UD_RGB_U8_PLANAR, 0, 1>), g1, block, 0, stream, a);
+    const bool even = (src_h == dst_h || src_h == 2 * dst_h) && down2_mode != 2; // (UD_DOWN2 = 2: the general rows, for A/B and tests)
+#define VALI_UD_LEAN(K) do { if (even) hipLaunchKernelGGL((k_ud_lean<K, 1, true>), g1, block, 0, stream, a); \
+                             else hipLaunchKernelGGL((k_ud_lean<K, 1, false>), g1, block, 0, stream, a); } while (0)
+    if (kind == UD_YUV444) VALI_UD_LEAN(UD_YUV444);
+    else if (kind == UD_RGB_U8) VALI_UD_LEAN(UD_RGB_U8);
+    else VALI_UD_LEAN(UD_RGB_U8_PLANAR);
+#undef VALI_UD_LEAN
     VALI_LAUNCH_CHECK();
     return VALI_OK;
   }
@@ -2055,17 +1912,17 @@ static int launch_ud(UdArgs& a, int src_fmt, int src_w, int src_h, int dst_w, in
     VALI_LAUNCH_CHECK();
     return VALI_OK;
   }
-  if (down2_on && !force_gather && src_fmt == VALI_FMT_NV12 && src_w == 2 * dst_w && !(rot & 1) && kind != UD_RGB_F32 &&
-      kind != UD_RGB_F32_PLANAR) { // (float outputs are store-bound: 4 pixels per lane fill their stores better)
+  if (lean_on && src_w == 2 * dst_w) { // 2:1 along x, any height
     a.rows = rows_for((dst_w + kD2WaveW - 1) / kD2WaveW);
     a.map = make_tile_map((dst_w + kD2WaveW - 1) / kD2WaveW, (dst_h + kWavesPerBlock * a.rows - 1) / (kWavesPerBlock * a.rows), (u32)n);
     const dim3 g2 = tile_grid(a.map);
-#define VALI_UD_D2(K, R) hipLaunchKernelGGL((k_ud_down2<K, R>), g2, block, 0, stream, a)
-    if (rot == 2) VALI_UD_D2(UD_RGB_U8, 2);
-    else if (kind == UD_YUV444) VALI_UD_D2(UD_YUV444, 0);
-    else if (kind == UD_RGB_U8) VALI_UD_D2(UD_RGB_U8, 0);
-    else VALI_UD_D2(UD_RGB_U8_PLANAR, 0);
-#undef VALI_UD_D2
+    const bool even = src_h == dst_h && down2_mode != 2; // (exactly halved heights: k_ud_half above)
+#define VALI_UD_LEAN(K) do { if (even) hipLaunchKernelGGL((k_ud_lean<K, 2, true>), g2, block, 0, stream, a); \
+                             else hipLaunchKernelGGL((k_ud_lean<K, 2, false>), g2, block, 0, stream, a); } while (0)
+    if (kind == UD_YUV444) VALI_UD_LEAN(UD_YUV444);
+    else if (kind == UD_RGB_U8) VALI_UD_LEAN(UD_RGB_U8);
+    else VALI_UD_LEAN(UD_RGB_U8_PLANAR);
+#undef VALI_UD_LEAN
     VALI_LAUNCH_CHECK();
     return VALI_OK;
   }
