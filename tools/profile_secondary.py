@@ -21,7 +21,7 @@ from collections import defaultdict
 from pathlib import Path
 
 ROOT = Path(os.environ.get("GRAFT_REPO_ROOT", Path(__file__).resolve().parent.parent))
-TAG = os.environ.get("VALI_PROFILE_TAG", "r03")
+TAG = os.environ.get("VALI_PROFILE_TAG", "r04")
 OUT = ROOT / "gpurun_out" / f"prof_{TAG}_secondary"
 # config key -> (bench_configs function, kernel-name substring, frames per launch)
 KEYS = {
@@ -36,10 +36,11 @@ KEYS = {
     "cfg4_fused": ("cfg4", "k_ud_half_t<", 64),
     "udgen_1280x720": ("udgen", "k_ud_32<", 64),     # 1080p -> 720p: exactly 3:2
     "udgen_640x384": ("udgen", "k_ud_nv12<", 64),    # the any-ratio kernel
-    "udplanar_up2": ("udplanar", "k_resize_up2<unsigned char", 64),   # YUV420 -> YUV444 1080p: the chroma planes ...
-    "udplanar_luma": ("udplanar", "k_plane_copy", 64, min),  # ... and the luma copy: one kernel for both depths, the 8-bit launches are the SMALLER ones
-    "udplanar_luma_16": ("udplanar", "k_plane_copy", 64, max),
-    "udplanar_up2_16": ("udplanar", "k_resize_up2<unsigned short", 64),
+    "udgen_1920x1080": ("udgen", "k_ud_lean<", 64),   # unchanged size: colour conversion with interpolated chroma
+    "udplanar_8bit": ("udplanar", "k_resize_up2<unsigned char", 64),   # YUV420 -> YUV444 1080p: one launch (chroma doubled, luma copied)
+    "udplanar_16bit": ("udplanar", "k_resize_up2<unsigned short", 64),
+    "upscale_1920x1080": ("upscale", "k_resize_rows_x23<", 64),        # 720p -> 1080p Lanczos (3:2 both ways)
+    "upscale_1600x900": ("upscale", "k_resize_rows<", 64),             # 720p -> 1600x900 (general growing planes)
 }
 
 
@@ -95,11 +96,6 @@ def main():
         a, b = result["cfg4_ud"], result["cfg4_rot"]
         result["cfg4_chain"] = {"kernel": "k_ud_half + k_rotate_tile", "frames": 64,
                                 "hbm_bytes_per_launch": a["hbm_bytes_per_launch"] + b["hbm_bytes_per_launch"], "source": a["source"]}
-    for bits, (x, y) in (("8bit", ("udplanar_up2", "udplanar_luma")), ("16bit", ("udplanar_up2_16", "udplanar_luma_16"))):
-        if x in result and y in result:
-            result[f"udplanar_{bits}"] = {"kernel": "k_plane_copy + k_resize_up2", "frames": 64,
-                                          "hbm_bytes_per_launch": result[x]["hbm_bytes_per_launch"] + result[y]["hbm_bytes_per_launch"],
-                                          "source": result[x]["source"]}
     (ROOT / "gpurun_out" / f"{TAG}_secondary_traffic.json").write_text(json.dumps(result, indent=1) + "\n")
     # the kernel-stats table of every config's trace run, as rocprofv3 wrote it: frac can be recomputed from these alone
     import shutil
