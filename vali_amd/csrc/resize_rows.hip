@@ -878,7 +878,9 @@ int launch_resize_x23(const ResizeArgs& base, int elem, int taps, int src_w, int
 
 template <typename T, int ESSET, int TAPS>
 static void launch_rows_k(const ResizeArgs& a, int rows, dim3 grid, unsigned lds, hipStream_t stream) {
-  if (rows == 32)
+  if (rows == 64)
+    hipLaunchKernelGGL((k_resize_rows<T, ESSET, TAPS, 64>), grid, dim3(kBlock), lds, stream, a);
+  else if (rows == 32)
     hipLaunchKernelGGL((k_resize_rows<T, ESSET, TAPS, 32>), grid, dim3(kBlock), lds, stream, a);
   else if (rows == 8)
     hipLaunchKernelGGL((k_resize_rows<T, ESSET, TAPS, 8>), grid, dim3(kBlock), lds, stream, a);
@@ -925,7 +927,14 @@ int launch_resize_rows(const ResizeArgs& base, int elem, int taps, int src_w, in
     return total;
   };
   const unsigned long long t32 = (unsigned long long)count(32, false) * (unsigned)n, t8 = (unsigned long long)count(8, false) * (unsigned)n;
-  const int rows = force == 1 ? 8 : force == 2 ? 2 : force == 3 ? 32 : t32 >= 1024ull ? 32 : t8 >= 320ull ? 8 : 2;
+  // 64-row waves (round 4: a wave's TAPS - 1 extra source rows weigh half as much as with 32; 8 / 2-row waves measured 1.5 x /
+  // 4 x SLOWER on a full launch: this kernel wants long waves) when the launch stays full and the wave's source rows still
+  // fit its 64-entry completion table
+  bool fits64 = true;
+  for (int k = 0; k < a.njobs; ++k)
+    fits64 = fits64 && 64.0 * (double)(src_h >> a.job[k].ssub_y) / (double)(dst_h >> a.job[k].sub_y) * (1.0 + 1e-6) + taps + 2 <= 64.0;
+  const unsigned long long t64 = (unsigned long long)count(64, false) * (unsigned)n;
+  const int rows = force == 1 ? 8 : force == 2 ? 2 : force == 3 ? 32 : (fits64 && (force == 4 || t64 >= 1024ull)) ? 64 : t32 >= 1024ull ? 32 : t8 >= 320ull ? 8 : 2;
   a.map = make_tile_map_linear(count(rows, true), (u32)n);
   a.force_gather = gather_only ? 1 : 0;
   (void)groups;
