@@ -1037,6 +1037,7 @@ __global__ void __launch_bounds__(kBlock) k_ud_half(const UdArgs a) {
   const bool has = x0 < dw;                                            // dw % 8 == 0: 8 pixels or none
   const u32 off16 = (u32)(2 * min(x0, dw - kD2LanePx));                // idle lanes re-read the row's last group
   const u32 offw = (u32)max(2 * xw - 4, 0);
+  const u32 edge_shift = xw == 0 ? ((lane & 3) < 2 ? 24u : 16u) : 0u;  // lanes 0..3 fetch the dword before the wave's first byte in rows 0..3
   struct Rows {
     uint4 v[4]; // the lane's 16 bytes of luma 2y-1, luma 2y, chroma y-1, chroma y
     u32 before; // lane k < 4: the dword before the wave's first byte in row k
@@ -1056,7 +1057,7 @@ __global__ void __launch_bounds__(kBlock) k_ud_half(const UdArgs a) {
     r.v[2] = make_uint4(0u, 0u, 0u, 0u);
     const int lk = lane & 3;
     const uint8_t* rb = lk == 0 ? row[0] : lk == 1 ? row[1] : lk == 2 ? row[2] : row[3];
-    r.before = gload_u<u32>(rb + offw);
+    r.before = gload_u<u32>(rb + offw) << edge_shift; // (the image's left edge: column -1 is column 0 -- the row's first byte / pair moves to the top)
     return r;
   };
   __shared__ __attribute__((aligned(16))) uint8_t strip[kPacked ? kWavesPerBlock : 1][kPacked ? kD2WaveW * 3 : 16];
@@ -1067,11 +1068,10 @@ __global__ void __launch_bounds__(kBlock) k_ud_half(const UdArgs a) {
     const int y = y_first + rr;
     u32 prev[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { // the 4 bytes before the lane's own: the previous lane's last dword; lane 0: the wave's extra
-      const u32 before = (u32)__builtin_amdgcn_readlane((int)rows.before, k); // load, or the clamp at the image's left edge
-      const u32 edge = k < 2 ? rows.v[k].x << 24 : rows.v[k].x << 16;
-      const u32 sh1 = wave_shr1(rows.v[k].w);
-      prev[k] = lane == 0 ? (xw == 0 ? edge : before) : sh1;
+    for (int k = 0; k < 4; ++k) { // the 4 bytes before the lane's own: the previous lane's last dword; lane 0 (no lane to shift
+      // from: it keeps `old`): the wave's extra load -- issue() has already turned it into the clamp at the image's left edge
+      const u32 before = (u32)__builtin_amdgcn_readlane((int)rows.before, k);
+      prev[k] = (u32)__builtin_amdgcn_update_dpp((int)before, (int)rows.v[k].w, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
     }
     D2Quad q0, q1;
 #pragma unroll
@@ -1183,6 +1183,7 @@ __global__ void __launch_bounds__(kBlock) k_ud_lean(const UdArgs a) {
   const bool has = x0 < dw;                                            // dw % 8 == 0: 8 pixels or none
   const u32 offl = (u32)(RATIO * min(x0, dw - kD2LanePx));             // the lane's 8 RATIO bytes of a row; idle lanes re-read the last group
   const u32 offw = (u32)max(RATIO * xw - 4, 0);
+  const u32 edge_shift = xw == 0 ? ((lane & 3) < 2 ? 24u : 16u) : 0u;  // lanes 0..3 fetch the dword before the wave's first byte in rows 0..3
   // row taps, lane-parallel (lane rr: the wave's rr-th row; rows past the last repeat it)
   const float scale_y = 1.0f * (float)dh / (float)sh;                  // ResizeUtils.cu:136
   const float cyl = (float)(y_first + min(lane & (kUdRowsPerWave - 1), last)) / scale_y;
@@ -1217,7 +1218,7 @@ __global__ void __launch_bounds__(kBlock) k_ud_lean(const UdArgs a) {
     }
     const int lk = lane & 3;
     const uint8_t* rb = lk == 0 ? row[0] : lk == 1 ? row[1] : lk == 2 ? row[2] : row[3];
-    r.before = gload_u<u32>(rb + offw);
+    r.before = gload_u<u32>(rb + offw) << edge_shift; // (the image's left edge: column -1 is column 0)
     return r;
   };
   __shared__ __attribute__((aligned(16))) uint8_t strip[kPacked ? kWavesPerBlock : 1][kPacked ? kD2WaveW * 3 : 16];
@@ -1234,11 +1235,10 @@ __global__ void __launch_bounds__(kBlock) k_ud_lean(const UdArgs a) {
     }
     u32 prev[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { // the 4 bytes before the lane's own: the previous lane's last dword; lane 0: the wave's extra
-      const u32 before = (u32)__builtin_amdgcn_readlane((int)rows.before, k); // load, or the clamp at the image's left edge
-      const u32 edge = k < 2 ? rows.v[k].x << 24 : rows.v[k].x << 16;
-      const u32 sh1 = wave_shr1(RATIO == 2 ? rows.v[k].w : rows.v[k].y);
-      prev[k] = lane == 0 ? (xw == 0 ? edge : before) : sh1;
+    for (int k = 0; k < 4; ++k) { // the 4 bytes before the lane's own: the previous lane's last dword; lane 0 (no lane to shift
+      // from: it keeps `old`): the wave's extra load -- issue() has already turned it into the clamp at the image's left edge
+      const u32 before = (u32)__builtin_amdgcn_readlane((int)rows.before, k);
+      prev[k] = (u32)__builtin_amdgcn_update_dpp((int)before, (int)(RATIO == 2 ? rows.v[k].w : rows.v[k].y), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
     }
     float c0[8], c1[8], c2[8];
     if constexpr (RATIO == 2) {
