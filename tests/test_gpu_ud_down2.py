@@ -1,5 +1,5 @@
 """UD with an exact 2x horizontal downscale (source width == 2 x output width) and an 8-bit output
-runs on its own kernels (k_ud_down2, and k_ud_down2_t for the 90/270 degree outputs: 16-byte loads,
+runs on its own kernels (k_ud_lean / k_ud_half -- round 1: k_ud_down2 --, and k_ud_down2_t / k_ud_half_t for the 90/270 degree outputs: 16-byte loads,
 no coordinate divisions; BASELINE config 4's "2x downsample"; float outputs stay on the general
 kernel).  It must be bit-identical to the oracle -- which restates the general texture-filter
 arithmetic -- and to the general kernel, for every output format, any height, ragged widths, the
@@ -169,7 +169,7 @@ def test_down2_foreign_destination(vali, gpu, oracle, angle, pad, skew):
 
 def test_down2_random_geometries(vali, gpu, oracle):
     """60 random (width, height, output height, output, quarter turn) cases around the tile and
-    wave boundaries of both kernels (512-column waves of k_ud_down2, 256 x 32 tiles of k_ud_down2_t)."""
+    wave boundaries of both kernels (512-column waves of k_ud_lean, 256 x 32 tiles of k_ud_down2_t)."""
     rng = np.random.default_rng(2024)
     ud = vali.PySurfaceUD(gpu)
     for case in range(60):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off stress of the UD kernels beyond the test-suite: NV12 / P10 sources, every output format, random geometries
-(exact 2x and 1x widths for the k_ud_down2 forms, any ratio for k_ud_nv12 staged / gather), single surfaces and small
+(exact 2x and 1x widths for the k_ud_lean forms, any ratio for k_ud_nv12 staged / gather), single surfaces and small
 batches, rotated outputs; every output bit-exact vs the oracle.   python tools/stress_ud.py [seed] [seconds]"""
 import sys, time
 from pathlib import Path

@@ -1159,7 +1159,7 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
       }
       return total;
     };
-    int pw = force == 1 ? 1 : 12;
+    int pw = force == 1 ? 1 : (force >= 11 && force <= 42) ? force - 10 : 12; // (11 .. 42: measurements, pairs per wave = value - 10)
     while (pw > 1 && (unsigned long long)count_pairs(pw, false) * (unsigned)n < 2048ull)
       pw = pw > 2 ? pw / 2 : 1;
     a.map = make_tile_map_linear(count_pairs(pw, true), (u32)n);

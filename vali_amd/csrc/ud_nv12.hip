@@ -820,7 +820,7 @@ __device__ __forceinline__ u32 wave_shr1(u32 v) { // lane l gets lane l-1's valu
   return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
 
-// Row taps of one output row (wave-uniform in k_ud_down2, per half-wave in k_ud_down2_t)
+// Row taps of one output row (wave-uniform in k_ud_lean, per half-wave in k_ud_down2_t)
 struct D2Taps {
   Tap ty, tcy;
 };
@@ -1730,7 +1730,7 @@ __global__ void __launch_bounds__(kBlock) k_ud_down2_t(const UdArgs a) {
     };
     auto step = [&](int it, const D2Taps& cur, bool even, const Rows& rows) {
       const int rr = 2 * it + half;
-      u32 before[4]; // broadcast before any divergence (see k_ud_down2)
+      u32 before[4]; // broadcast before any divergence
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const u32 f0 = (u32)__builtin_amdgcn_readlane((int)rows.before, k);
@@ -1867,7 +1867,7 @@ static int launch_ud(UdArgs& a, int src_fmt, int src_w, int src_h, int dst_w, in
   // exact 2x horizontal downscale of NV12: the division-free, LDS-free kernel (VALI_UD_DOWN2=0
   // keeps the general one, for A/B measurements)
   // The exact-ratio kernels own 8 output pixels per lane.  Un-rotated, a width that is not a multiple of 8 slides its
-  // last lane left (k_ud_down2: `slid`); the turned forms have no such lane and would leave it on their byte-gather path
+  // last lane left (round 1's k_ud_down2: `slid`); the turned forms have no such lane and would leave it on their byte-gather path
   // with the whole wave waiting (1916x1076 -> 958x538 half-turned: 2.4 us against 1.1 through the general kernel), so
   // those geometries go to the general kernel.  VALI_TUNE_UD_DOWN2 = 2 keeps them here (A/B, tests of that path).
   const int down2_mode = tuning(VALI_TUNE_UD_DOWN2);
