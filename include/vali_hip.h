@@ -390,8 +390,9 @@ enum vali_tuning_key {
                                          3: fused UD + quarter turn on 128-row tiles (default 64)                  */
   VALI_TUNE_ROCTX = 9,                /* 1: a roctx range around every operator entry point (see below)            */
   VALI_TUNE_RESIZE_NO_SEPARABLE = 10, /* Lanczos / bicubic rows per wave: 0 by launch size, 1: few, 2: fewest (and the slot walk
-                                         where the 3:2-both-ways form has a static one), 3: most; 11 .. 40: an explicit count
-                                         (rows per slot / source-row pairs: measurements only)                       */
+                                         where the 3:2-both-ways form has a static one), 3: most (growing planes: 32-row waves), 4: growing planes on
+                                         64-row waves whatever the launch size; 11 .. 42: an explicit count (rows per slot / row
+                                         pairs per wave: measurements only)                                          */
   VALI_TUNE_ROWS_PER_WAVE = 11,       /* UD, bilinear / point resize, fused pre-processing: dst rows (row pairs) a wave
                                          walks: 0 by launch size (8 for batches, 4 or 2 for small launches), 2 / 4 / 8  */
   VALI_TUNE_BLOCKING_WAIT = 12,       /* vali_stream_wait: 0 completion word + spin (default), 1 hipStreamSynchronize */

@@ -1144,8 +1144,8 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
       rps = rps > 2 ? rps / 2 : 1;
   const bool srows = x32 && !x2 && y32 && force != 2;                         // (RESIZE_NO_SEPARABLE = 2: the slot walk, for A/B and tests)
   if (srows) {
-    // dst row PAIRS per wave: 3 of a wave's 3 n + 3 source rows are its neighbours'; 12 pairs (24 rows) unless that
-    // leaves the chip short of workgroups
+    // dst row PAIRS per wave: 3 of a wave's 3 n + 3 source rows are its neighbours' (they come from the L2 while both run);
+    // 4 pairs unless that leaves the chip short of workgroups
     auto count_pairs = [&](int pw, bool assign) {
       u32 total = 0;
       for (int k = 0; k < a.njobs; ++k) {
@@ -1159,7 +1159,9 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
       }
       return total;
     };
-    int pw = force == 1 ? 1 : (force >= 11 && force <= 42) ? force - 10 : 12; // (11 .. 42: measurements, pairs per wave = value - 10)
+    // (1080p -> 720p, 64 frames, pairs per wave 1 / 2 / 3 / 4 / 6 / 8 / 12 / 18 / 24: 1.00 / 0.86 / 0.75 / 0.76 / 0.78 / 0.79 / 0.80 /
+    // 0.77 / 0.79 us: short waves, like every form without a row pass)
+    int pw = force == 1 ? 1 : (force >= 11 && force <= 42) ? force - 10 : 4; // (11 .. 42: measurements, pairs per wave = value - 10)
     while (pw > 1 && (unsigned long long)count_pairs(pw, false) * (unsigned)n < 2048ull)
       pw = pw > 2 ? pw / 2 : 1;
     a.map = make_tile_map_linear(count_pairs(pw, true), (u32)n);
