@@ -13,9 +13,9 @@ typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
 constexpr int W = 3840, H = 2160, ROWS = 96, D = 4;
 
-template <int MODE, int K>
-__global__ void __launch_bounds__(256) k(const unsigned char* __restrict__ src, float* __restrict__ out, int frames) {
-  __shared__ __attribute__((aligned(16))) float lds[4][2048];
+template <int MODE, int K, int PAD = 0>
+__global__ void __launch_bounds__(256) k(const unsigned char* __restrict__ src, float* __restrict__ out, int frames, unsigned* __restrict__ dst) {
+  __shared__ __attribute__((aligned(16))) float lds[4][2048 + PAD]; // PAD: fewer workgroups per CU (32 KB: 5, 40 KB: 4, 52 KB: 3, 80 KB: 2)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tiles_x = W / 512, tiles_y = (H + 4 * ROWS - 1) / (4 * ROWS);
   const int per = tiles_x * tiles_y;
@@ -25,10 +25,13 @@ __global__ void __launch_bounds__(256) k(const unsigned char* __restrict__ src, 
   const int y0 = (ty * 4 + wave) * ROWS;
   if (y0 >= H) return;
   const unsigned char* p = src + (size_t)f * W * H + (size_t)tx * 512 + 8 * lane;
+  unsigned* const dstp = dst + (size_t)f * (W / 2 / 4) * (H / 2 + 8);
   const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) float*)&lds[wave][0] + 8u * lane;
   v2f acc[12];
   for (int i = 0; i < 12; ++i) acc[i] = (v2f){0.f, 0.f};
   v2f sink = (v2f){0.f, 0.f};
+  unsigned keep[16];
+  for (int i = 0; i < 16; ++i) keep[i] = 0;
   v2u pf[D];
   for (int d = 0; d < D; ++d) { pf[d] = *(const v2u*)(p + (size_t)min(y0 + d, H - 1) * W); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll 1
@@ -65,6 +68,84 @@ __global__ void __launch_bounds__(256) k(const unsigned char* __restrict__ src, 
           v4f w = {acc[k2].x, acc[k2].y, acc[k2 + 1].x, acc[k2 + 1].y};
           asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(la + 8u * lane), "v"(w), "n"(2048 * (k2 % 2)) : "memory");
         }
+      } else if constexpr (MODE == 10 || MODE == 11) { // ... kept in registers and written every 4th (8th) pair
+        constexpr int NB = MODE == 10 ? 4 : 8;
+        if (d == D - 1) {
+          unsigned q0 = 0, q1 = 0;
+          q0 = __builtin_amdgcn_cvt_pk_u8_f32(acc[0].x, 0, q0); q0 = __builtin_amdgcn_cvt_pk_u8_f32(acc[1].x, 1, q0);
+          q0 = __builtin_amdgcn_cvt_pk_u8_f32(acc[2].x, 2, q0); q0 = __builtin_amdgcn_cvt_pk_u8_f32(acc[3].x, 3, q0);
+          q1 = __builtin_amdgcn_cvt_pk_u8_f32(acc[0].y, 0, q1); q1 = __builtin_amdgcn_cvt_pk_u8_f32(acc[1].y, 1, q1);
+          q1 = __builtin_amdgcn_cvt_pk_u8_f32(acc[2].y, 2, q1); q1 = __builtin_amdgcn_cvt_pk_u8_f32(acc[3].y, 3, q1);
+          const int slot = (r0 / D) % NB;
+#pragma unroll
+          for (int b2 = 0; b2 < NB; ++b2)
+            if (slot == b2) { keep[2 * b2] = q0; keep[2 * b2 + 1] = q1; }
+          if (slot == NB - 1) {
+            unsigned* o = dstp + (size_t)min((y0 + r0) / 2 - 2 * (NB - 1), H / 2 - 2 * NB) * (W / 2 / 4) + tx * 64 + lane;
+#pragma unroll
+            for (int b2 = 0; b2 < 2 * NB; ++b2)
+              __builtin_nontemporal_store(keep[b2], o + (size_t)b2 * (W / 2 / 4));
+          }
+        }
+      } else if constexpr (MODE == 9 || MODE == 12) { // the stores of the row pass without its LDS work
+        if (d == D - 1) {
+          unsigned q0 = 0, q1 = 0;
+          q0 = __builtin_amdgcn_cvt_pk_u8_f32(acc[0].x, 0, q0); q0 = __builtin_amdgcn_cvt_pk_u8_f32(acc[1].x, 1, q0);
+          q0 = __builtin_amdgcn_cvt_pk_u8_f32(acc[2].x, 2, q0); q0 = __builtin_amdgcn_cvt_pk_u8_f32(acc[3].x, 3, q0);
+          q1 = __builtin_amdgcn_cvt_pk_u8_f32(acc[0].y, 0, q1); q1 = __builtin_amdgcn_cvt_pk_u8_f32(acc[1].y, 1, q1);
+          q1 = __builtin_amdgcn_cvt_pk_u8_f32(acc[2].y, 2, q1); q1 = __builtin_amdgcn_cvt_pk_u8_f32(acc[3].y, 3, q1);
+          unsigned* o = dstp + (size_t)min((y0 + r0) / 2, H / 2 - 2) * (W / 2 / 4) + tx * 64 + lane;
+          if (MODE == 12) { o[0] = q0; o[W / 2 / 4] = q1; }
+          else { __builtin_nontemporal_store(q0, o); __builtin_nontemporal_store(q1, o + W / 2 / 4); }
+        }
+      } else if constexpr (MODE == 6 || MODE == 7 || MODE == 8) {
+        // the row pass of resize_cols.hip once per 4 source rows (one dst-row pair): strip write, 2 x (12 reads, 14 chained
+        // packed FMAs, transposition write), transposition read, 8 quantisations, 2 stores.  MODE 7: no transposition.
+        if (d == D - 1) {
+          typedef float v4f __attribute__((ext_vector_type(4)));
+#pragma unroll
+          for (int k2 = 0; k2 < 4; ++k2) {
+            v4f w = {acc[k2].x, acc[k2].y, acc[k2 + 1].x, acc[k2 + 1].y};
+            asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(la + 24u * lane), "v"(w), "n"(16 * 0) : "memory");
+          }
+          v2f r4[4];
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            v2f t[12];
+#pragma unroll
+            for (int k2 = 0; k2 < 12; ++k2)
+              asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(t[k2]) : "v"(la), "n"(8 * (k2 % 3) + 512 * (k2 / 3)) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k2 = 0; k2 < 12; ++k2) asm volatile("" : "+v"(t[k2]));
+            v2f e0 = t[0] * acc[0], o0 = t[3] * acc[1], e1 = t[6] * acc[2], o1 = t[9] * acc[3];
+            e0 = __builtin_elementwise_fma(t[1], acc[4], e0); o0 = __builtin_elementwise_fma(t[4], acc[5], o0);
+            e1 = __builtin_elementwise_fma(t[7], acc[6], e1); o1 = __builtin_elementwise_fma(t[10], acc[7], o1);
+            e0 = __builtin_elementwise_fma(t[2], acc[8], e0); o0 = __builtin_elementwise_fma(t[5], acc[9], o0);
+            e1 = __builtin_elementwise_fma(t[8], acc[10], e1); o1 = __builtin_elementwise_fma(t[11], acc[11], o1);
+            r4[2 * half] = e0 + o0; r4[2 * half + 1] = e1 + o1;
+            if (MODE == 6) {
+              asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(la), "v"(r4[2 * half]), "n"(4096) : "memory");
+              asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(la), "v"(r4[2 * half + 1]), "n"(4096 + 512) : "memory");
+            }
+          }
+          if (MODE == 6) {
+            typedef float v4f2 __attribute__((ext_vector_type(4)));
+            v4f2 a, b;
+            asm volatile("ds_read_b128 %0, %2 offset:4096\n\tds_read_b128 %1, %2 offset:4112\n\ts_waitcnt lgkmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(la + 24u * lane) : "memory");
+            r4[0] = (v2f){a.x, a.y}; r4[1] = (v2f){a.z, a.w}; r4[2] = (v2f){b.x, b.y}; r4[3] = (v2f){b.z, b.w};
+          }
+          unsigned q0 = 0, q1 = 0;
+          q0 = __builtin_amdgcn_cvt_pk_u8_f32(r4[0].x, 0, q0); q0 = __builtin_amdgcn_cvt_pk_u8_f32(r4[1].x, 1, q0);
+          q0 = __builtin_amdgcn_cvt_pk_u8_f32(r4[2].x, 2, q0); q0 = __builtin_amdgcn_cvt_pk_u8_f32(r4[3].x, 3, q0);
+          q1 = __builtin_amdgcn_cvt_pk_u8_f32(r4[0].y, 0, q1); q1 = __builtin_amdgcn_cvt_pk_u8_f32(r4[1].y, 1, q1);
+          q1 = __builtin_amdgcn_cvt_pk_u8_f32(r4[2].y, 2, q1); q1 = __builtin_amdgcn_cvt_pk_u8_f32(r4[3].y, 3, q1);
+          unsigned* o = dstp + (size_t)min((y0 + r0) / 2, H / 2 - 2) * (W / 2 / 4) + tx * 64 + lane;
+          if (MODE != 8 || (q0 == 0x12345678u && q1 == 77u)) {
+            __builtin_nontemporal_store(q0, o);
+            __builtin_nontemporal_store(q1, o + W / 2 / 4);
+          }
+        }
       } else if constexpr (MODE == 5) {
 #pragma unroll
         for (int k2 = 0; k2 < K; ++k2)
@@ -77,13 +158,14 @@ __global__ void __launch_bounds__(256) k(const unsigned char* __restrict__ src, 
   if (s == 1.2345e-30f) out[0] = s;
 }
 
-template <int MODE, int K> void run(const char* name, const unsigned char* src, float* out, int frames) {
+static unsigned* g_dst;
+template <int MODE, int K, int PAD = 0> void run(const char* name, const unsigned char* src, float* out, int frames) {
   const int per = (W / 512) * ((H + 4 * ROWS - 1) / (4 * ROWS));
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   float best = 1e30f;
   for (int r = 0; r < 6; ++r) {
     CK(hipEventRecord(a));
-    hipLaunchKernelGGL((k<MODE, K>), dim3(per * frames), dim3(256), 0, 0, src, out, frames);
+    hipLaunchKernelGGL((k<MODE, K, PAD>), dim3(per * frames), dim3(256), 0, 0, src, out, frames, g_dst);
     CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b)); if (r && ms < best) best = ms;
   }
@@ -95,6 +177,7 @@ int main() {
   unsigned char* src; float* out;
   CK(hipMalloc(&src, (size_t)W * H * frames)); CK(hipMalloc(&out, 64));
   CK(hipMemset(src, 7, (size_t)W * H * frames));
+  CK(hipMalloc(&g_dst, (size_t)(W / 2) * (H / 2 + 8) * frames));
   run<0, 0>("stream + conversions + 12 packed FMAs", src, out, frames);
   run<5, 6>("+ VALU filler", src, out, frames);
   run<5, 12>("+ VALU filler", src, out, frames);
@@ -106,5 +189,18 @@ int main() {
   run<3, 6>("+ ds_write_b64", src, out, frames);
   run<4, 2>("+ ds_write_b128 (K / 2)", src, out, frames);
   run<4, 4>("+ ds_write_b128 (K / 2)", src, out, frames);
+  run<6, 0>("+ the whole row pass once per 4 rows", src, out, frames);
+  run<7, 0>("+ the row pass without its transposition", src, out, frames);
+  run<8, 0>("the row pass without its global stores", src, out, frames);
+  run<9, 0>("the stores without the row pass", src, out, frames);
+  run<12, 0>("... plain stores instead of non-temporal", src, out, frames);
+  run<10, 0>("... written every 4th pair (8 stores at once)", src, out, frames);
+  run<11, 0>("... written every 8th pair (16 stores at once)", src, out, frames);
+  run<0, 0, 512>("stream alone, 4 workgroups per CU", src, out, frames);
+  run<6, 0, 512>("whole row pass, 4 workgroups per CU", src, out, frames);
+  run<0, 0, 1280>("stream alone, 3 workgroups per CU", src, out, frames);
+  run<6, 0, 1280>("whole row pass, 3 workgroups per CU", src, out, frames);
+  run<0, 0, 3072>("stream alone, 2 workgroups per CU", src, out, frames);
+  run<6, 0, 3072>("whole row pass, 2 workgroups per CU", src, out, frames);
   return 0;
 }
