@@ -1154,14 +1154,18 @@ __global__ void __launch_bounds__(kBlock) k_ud_half(const UdArgs a) {
 // tails from one body and spilled 13-75 SGPRs in every instantiation.  This is k_ud_half's body
 // with the row taps put back: lane rr of the wave evaluates the taps of its rr-th dst row (row offsets and the two
 // weight pairs), a row's eight scalars arrive by v_readlane; every lane has 8 pixels or none; the unaligned-tolerant
-// forms of the loads and stores make alignment a non-issue.  Everything else (ragged widths at these ratios, the half
-// turn) runs on the general kernel: correct and bit-identical, a little slower, and rare.
+// forms of the loads and stores make alignment a non-issue.  Ragged widths: the RAGGED instantiation below; the half turn
+// at these ratios runs on the general kernel: correct and bit-identical, a little slower, and rare.
 // EVEN: every row's vertical weights are (128, 128), (256, 0) or (0, 256) -- unchanged height (luma rows y - 1, y at
 // 128 / 128; chroma 128 / 128 on even rows, the single row (y - 1) / 2 on odd ones) and exactly halved height.  A
 // weight of 256 on one row is 128 on that row twice: the lane-parallel taps point both row slots at it, and what is
 // left is k_ud_half's arithmetic -- the second row's dot product accumulates onto the first, no multiplications, no
 // weights to broadcast (float(128 S') * c == float(S') * (128 c), a power of two: the same bits).
-template <int OUT, int RATIO, bool EVEN>
+// RAGGED: output widths that are not multiples of 8 (>= 8) -- the row's last lane has fewer than 8 pixels; its window SLIDES left
+// to end with the row (pixels dw - 8 .. dw - 1: a full group again; the pixels it shares with its neighbour are computed and
+// stored twice with the same bytes), and since the bytes before that window are not its neighbour's, lanes 4..7 fetch them the
+// way lanes 0..3 fetch the bytes before the wave's.  Its own instantiation: the aligned geometries pay nothing for it.
+template <int OUT, int RATIO, bool EVEN, bool RAGGED = false>
 __global__ void __launch_bounds__(kBlock) k_ud_lean(const UdArgs a) {
   using T = uint8_t;
   static_assert(RATIO == 1 || RATIO == 2, "source width = RATIO x UD width");
@@ -1180,10 +1184,15 @@ __global__ void __launch_bounds__(kBlock) k_ud_lean(const UdArgs a) {
     return;
   const int last = min(a.rows, dh - y_first) - 1;
   const int x0 = xw + lane * kD2LanePx;
-  const bool has = x0 < dw;                                            // dw % 8 == 0: 8 pixels or none
-  const u32 offl = (u32)(RATIO * min(x0, dw - kD2LanePx));             // the lane's 8 RATIO bytes of a row; idle lanes re-read the last group
-  const u32 offw = (u32)max(RATIO * xw - 4, 0);
-  const u32 edge_shift = xw == 0 ? ((lane & 3) < 2 ? 24u : 16u) : 0u;  // lanes 0..3 fetch the dword before the wave's first byte in rows 0..3
+  const bool has = x0 < dw;                                            // 8 pixels or none (RAGGED: the row's last lane may have fewer)
+  const int xs_w = dw - kD2LanePx;                                     // RAGGED: first pixel of the slid window (wave-uniform)
+  const bool slid = RAGGED && has && x0 > xs_w;
+  const int xl = slid ? xs_w : x0;                                     // first pixel of the lane's window
+  const u32 offl = (u32)(RATIO * min(xl, dw - kD2LanePx));             // the lane's 8 RATIO bytes of a row; idle lanes re-read the last group
+  // lanes 0..3 fetch the dword before the wave's first byte in rows 0..3 (RAGGED: lanes 4..7 the one before the slid window)
+  const int xb = RAGGED && (lane & 4) ? xs_w : xw;
+  const u32 offw = (u32)max(RATIO * xb - 4, 0);
+  const u32 edge_shift = xb == 0 ? ((lane & 3) < 2 ? 24u : 16u) : 0u;
   // row taps, lane-parallel (lane rr: the wave's rr-th row; rows past the last repeat it)
   const float scale_y = 1.0f * (float)dh / (float)sh;                  // ResizeUtils.cu:136
   const float cyl = (float)(y_first + min(lane & (kUdRowsPerWave - 1), last)) / scale_y;
@@ -1222,7 +1231,7 @@ __global__ void __launch_bounds__(kBlock) k_ud_lean(const UdArgs a) {
     return r;
   };
   __shared__ __attribute__((aligned(16))) uint8_t strip[kPacked ? kWavesPerBlock : 1][kPacked ? kD2WaveW * 3 : 16];
-  const int nbytes = min(kD2WaveW, dw - xw) * 3;                        // packed RGB bytes of the wave's row, a multiple of 24
+  const int nbytes = (min(kD2WaveW, dw - xw) / kD2LanePx) * (kD2LanePx * 3); // packed RGB bytes of the wave's FULL lanes: a multiple of 24
   const bool dst16 = ((((uintptr_t)d.p[0]) | (uintptr_t)d.pitch[0]) & 15u) == 0 && (xw * 3 & 15) == 0; // wave-uniform
   auto step = [&](int rr, const Rows& rows) {
     const int y = y_first + rr;
@@ -1239,6 +1248,10 @@ __global__ void __launch_bounds__(kBlock) k_ud_lean(const UdArgs a) {
       // from: it keeps `old`): the wave's extra load -- issue() has already turned it into the clamp at the image's left edge
       const u32 before = (u32)__builtin_amdgcn_readlane((int)rows.before, k);
       prev[k] = (u32)__builtin_amdgcn_update_dpp((int)before, (int)(RATIO == 2 ? rows.v[k].w : rows.v[k].y), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+      if constexpr (RAGGED) {
+        const u32 before_s = (u32)__builtin_amdgcn_readlane((int)rows.before, 4 + k);
+        prev[k] = slid ? before_s : prev[k];
+      }
     }
     float c0[8], c1[8], c2[8];
     if constexpr (RATIO == 2) {
@@ -1261,7 +1274,12 @@ __global__ void __launch_bounds__(kBlock) k_ud_lean(const UdArgs a) {
       trunc_pack3x4(c0[0], c1[0], c2[0], c0[1], c1[1], c2[1], c0[2], c1[2], c2[2], c0[3], c1[3], c2[3], w[0], w[1], w[2]);
       trunc_pack3x4(c0[4], c1[4], c2[4], c0[5], c1[5], c2[5], c0[6], c1[6], c2[6], c0[7], c1[7], c2[7], w[3], w[4], w[5]);
       uint8_t* st = strip[kPacked ? wave : 0];
-      if (has) {
+      if (slid) { // its 24 bytes are not on the strip's lane grid: straight to memory
+        uint8_t* o = d.p[0] + (u32)(y * d.pitch[0]) + (u32)(xl * 3);
+        gstore_u<v2u32>(o, (v2u32){w[0], w[1]});
+        gstore_u<v2u32>(o + 8, (v2u32){w[2], w[3]});
+        gstore_u<v2u32>(o + 16, (v2u32){w[4], w[5]});
+      } else if (has) {
         *reinterpret_cast<uint2*>(st + 24 * lane) = make_uint2(w[0], w[1]);
         *reinterpret_cast<uint2*>(st + 24 * lane + 8) = make_uint2(w[2], w[3]);
         *reinterpret_cast<uint2*>(st + 24 * lane + 16) = make_uint2(w[4], w[5]);
@@ -1290,8 +1308,8 @@ __global__ void __launch_bounds__(kBlock) k_ud_lean(const UdArgs a) {
       trunc_pack3x4(c1[4], c1[5], c1[6], c1[7], c2[0], c2[1], c2[2], c2[3], c2[4], c2[5], c2[6], c2[7], pw[3], pw[4], pw[5]);
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        uint8_t* o = d.p[k] + (u32)(y * pp[k]) + (u32)x0;
-        if ((((uintptr_t)d.p[k] | (uintptr_t)pp[k]) & 7u) == 0) // wave-uniform
+        uint8_t* o = d.p[k] + (u32)(y * pp[k]) + (u32)xl;
+        if (!slid && (((uintptr_t)d.p[k] | (uintptr_t)pp[k]) & 7u) == 0) // (wave-uniform but for the slid lane)
           UD_ST8(o, make_uint2(pw[2 * k], pw[2 * k + 1]));
         else
           gstore_u<v2u32>(o, (v2u32){pw[2 * k], pw[2 * k + 1]});
@@ -1873,15 +1891,18 @@ static int launch_ud(UdArgs& a, int src_fmt, int src_w, int src_h, int dst_w, in
   const int down2_mode = tuning(VALI_TUNE_UD_DOWN2);
   // the lean exact-ratio kernels own 8 output pixels per lane: widths that are multiples of 8, un-rotated; ragged widths and
   // the half turn at these ratios run on the general kernel (bit-identical)
-  const bool lean_on = down2_mode != 0 && !force_gather && src_fmt == VALI_FMT_NV12 && rot == 0 && dst_w % kD2LanePx == 0 &&
-                       kind != UD_RGB_F32 && kind != UD_RGB_F32_PLANAR; // (float outputs are store-bound: 4 pixels per lane fill their stores better)
+  const bool lean_on = down2_mode != 0 && !force_gather && src_fmt == VALI_FMT_NV12 && rot == 0 && dst_w >= kD2LanePx &&
+                       kind != UD_RGB_F32 && kind != UD_RGB_F32_PLANAR;
+  const bool lean_ragged = dst_w % kD2LanePx != 0;      // the row's last lane slides left (k_ud_lean<..., RAGGED>) // (float outputs are store-bound: 4 pixels per lane fill their stores better)
   const bool down2_on = down2_mode != 0 && (down2_mode == 2 || dst_w % kD2LanePx == 0 || (rot == 0 && dst_w >= kD2LanePx));
   if (lean_on && src_w == dst_w) { // 1:1 width: colour conversion with chroma interpolation
     a.rows = rows_for((dst_w + kD2WaveW - 1) / kD2WaveW);
     a.map = make_tile_map((dst_w + kD2WaveW - 1) / kD2WaveW, (dst_h + kWavesPerBlock * a.rows - 1) / (kWavesPerBlock * a.rows), (u32)n);
     const dim3 g1 = tile_grid(a.map);
     const bool even = (src_h == dst_h || src_h == 2 * dst_h) && down2_mode != 2; // (UD_DOWN2 = 2: the general rows, for A/B and tests)
-#define VALI_UD_LEAN(K) do { if (even) hipLaunchKernelGGL((k_ud_lean<K, 1, true>), g1, block, 0, stream, a); \
+#define VALI_UD_LEAN(K) do { if (lean_ragged) { if (even) hipLaunchKernelGGL((k_ud_lean<K, 1, true, true>), g1, block, 0, stream, a); \
+                                               else hipLaunchKernelGGL((k_ud_lean<K, 1, false, true>), g1, block, 0, stream, a); }   \
+                             else if (even) hipLaunchKernelGGL((k_ud_lean<K, 1, true>), g1, block, 0, stream, a); \
                              else hipLaunchKernelGGL((k_ud_lean<K, 1, false>), g1, block, 0, stream, a); } while (0)
     if (kind == UD_YUV444) VALI_UD_LEAN(UD_YUV444);
     else if (kind == UD_RGB_U8) VALI_UD_LEAN(UD_RGB_U8);
@@ -1916,8 +1937,10 @@ static int launch_ud(UdArgs& a, int src_fmt, int src_w, int src_h, int dst_w, in
     a.rows = rows_for((dst_w + kD2WaveW - 1) / kD2WaveW);
     a.map = make_tile_map((dst_w + kD2WaveW - 1) / kD2WaveW, (dst_h + kWavesPerBlock * a.rows - 1) / (kWavesPerBlock * a.rows), (u32)n);
     const dim3 g2 = tile_grid(a.map);
-    const bool even = src_h == dst_h && down2_mode != 2; // (exactly halved heights: k_ud_half above)
-#define VALI_UD_LEAN(K) do { if (even) hipLaunchKernelGGL((k_ud_lean<K, 2, true>), g2, block, 0, stream, a); \
+    const bool even = (src_h == dst_h || src_h == 2 * dst_h) && down2_mode != 2; // (exactly halved heights at widths that are multiples of 8: k_ud_half above)
+#define VALI_UD_LEAN(K) do { if (lean_ragged) { if (even) hipLaunchKernelGGL((k_ud_lean<K, 2, true, true>), g2, block, 0, stream, a); \
+                                               else hipLaunchKernelGGL((k_ud_lean<K, 2, false, true>), g2, block, 0, stream, a); }   \
+                             else if (even) hipLaunchKernelGGL((k_ud_lean<K, 2, true>), g2, block, 0, stream, a); \
                              else hipLaunchKernelGGL((k_ud_lean<K, 2, false>), g2, block, 0, stream, a); } while (0)
     if (kind == UD_YUV444) VALI_UD_LEAN(UD_YUV444);
     else if (kind == UD_RGB_U8) VALI_UD_LEAN(UD_RGB_U8);
