@@ -398,7 +398,8 @@ enum vali_tuning_key {
   VALI_TUNE_BLOCKING_WAIT = 12,       /* vali_stream_wait: 0 completion word + spin (default), 1 hipStreamSynchronize */
   VALI_TUNE_RESIZE_ROWS = 13,         /* Lanczos / bicubic of planes that grow: 1 (default) filtered rows in registers
                                          (resize_rows.hip) where the geometry fits, exact 3:2 enlargements through their static
-                                         form; 2: the same without the 3:2 form; 0: round 2's LDS-ring kernel everywhere      */
+                                         form; 2: the same without the 3:2 form; 3: without the register form of round 4 (8-bit planes
+                                         that grow along x too: row pass from registers, no LDS stage); 0: round 2's LDS-ring kernel  */
   VALI_TUNE_COUNT = 14
 };
 VALI_API int vali_tuning_set(int key, int value);

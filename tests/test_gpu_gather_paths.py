@@ -41,6 +41,8 @@ def test_parity_suites_through_the_gather_forms():
     # ever see the 2-row form, so the whole parity suites are replayed through each of the others
     ("VALI_RESIZE_NO_SEPARABLE=1", ["tests/test_gpu_resize.py", "tests/test_gpu_edge_geometry.py", "tests/test_gpu_random_geometry.py", "tests/test_gpu_ud.py"]),
     ("VALI_RESIZE_NO_SEPARABLE=3", ["tests/test_gpu_resize.py", "tests/test_gpu_edge_geometry.py", "tests/test_gpu_random_geometry.py", "tests/test_gpu_ud.py"]),
+    # 8-bit planes that grow on both axes take the register form of round 4: the LDS-staged rows form once more for them
+    ("VALI_RESIZE_ROWS=3", ["tests/test_gpu_resize.py", "tests/test_gpu_edge_geometry.py", "tests/test_gpu_random_geometry.py"]),
 ])
 def test_parity_suites_under_each_ab_switch(switch, files):
     """the alternative kernel forms kept behind environment switches (tools/README.md) stay bit-exact"""

@@ -225,7 +225,8 @@ def interp(n=64):
 
 def upscale(n=64):
     """Planes that GROW (the upscale to display size) under the reference's filter: NV12 720p -> 1080p (exactly 3:2 both ways:
-    the static form k_resize_rows_x23) and 720p -> 1600x900 (5:4, no special form: k_resize_rows, filtered rows in registers)."""
+    the static form k_resize_rows_x23) and 720p -> 1600x900 (5:4, no special form: k_resize_rows_reg, the row pass and the vertical
+    window in registers, no LDS stage)."""
     out = []
     rs = vali.PySurfaceResizer(vali.NV12, DEV)                     # Lanczos-3, the reference's (and the task's default) filter
     for (sw, sh, dw, dh) in ((1280, 720, 1920, 1080), (1280, 720, 1600, 900)):
@@ -240,7 +241,7 @@ def upscale(n=64):
         sets = make_sets(k, make)
         ms, _ = timed(rs.Stream, [lambda q=q: rs.RunBatchAsync(q) for _, _, q in sets], 30)
         out.append({"filter": "lanczos", "geometry": f"{sw}x{sh}->{dw}x{dh}",
-                    "kernel": "k_resize_rows_x23<u8, 12, 6, 48>" if 3 * sw == 2 * dw else "k_resize_rows<u8, 12, 6, 32>",
+                    "kernel": "k_resize_rows_x23<u8, 12, 6, 48>" if 3 * sw == 2 * dw else "k_resize_rows_reg<64, 1, 2>",
                     "us_per_frame": round(ms * 1e3 / n, 3), "bytes_moved_per_frame": b,
                     "roofline": roofline(f"upscale_{dw}x{dh}", b, n, ms, k)})
         del sets

@@ -40,7 +40,7 @@ KEYS = {
     "udplanar_8bit": ("udplanar", "k_resize_up2<unsigned char", 64),   # YUV420 -> YUV444 1080p: one launch (chroma doubled, luma copied)
     "udplanar_16bit": ("udplanar", "k_resize_up2<unsigned short", 64),
     "upscale_1920x1080": ("upscale", "k_resize_rows_x23<", 64),        # 720p -> 1080p Lanczos (3:2 both ways)
-    "upscale_1600x900": ("upscale", "k_resize_rows<", 64),             # 720p -> 1600x900 (general growing planes)
+    "upscale_1600x900": ("upscale", "k_resize_rows_reg<", 64),         # 720p -> 1600x900 (general growing planes, register form)
 }
 
 

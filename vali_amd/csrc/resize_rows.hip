@@ -438,6 +438,359 @@ __global__ void __launch_bounds__(kBlock) k_resize_rows(const ResizeArgs a) {
 }
 
 // =====================================================================================================================
+// The same rows-first arithmetic WITHOUT the LDS stage (round 4): 8-bit planes of 1 / 2 channels that grow along x as well
+// (1 / 3 < scale_x < 1).  profiles/r04_lanczos.md: what the staged form above pays for is not its arithmetic but two LDS
+// round trips per source row (stage write -> 12 tap reads) in waves that have three neighbours per SIMD.  Here a lane owns 4
+// ADJACENT dst elements and loads, per source row, the 12 (16) source bytes their windows span from ITS OWN byte address
+// floor(x0 s) - 2 -- whatever its alignment; neighbouring lanes overlap by two thirds, in the L1 -- converts them once and
+// filters from registers: dst pixel x0 + j starts its window D_j or D_j + 1 registers in (D_j = floor(j s): a property of
+// the scale, a template parameter; the + 1 varies from lane to lane), so its chains run over SEVEN registers D_j .. D_j + 6
+// with the weights (w0 .. w5, 0) or (0, w0 .. w5): the specification's e over the even taps and o over the odd ones swap
+// places in the second case; their members, their order and their sum do not (0 * t = +-0, and w * t + (+-0) = w * t).
+// Two-channel planes: the lane's 4 elements are 2 pixels, 8 source pixels = 16 bytes, a register pair is one pixel's (U, V)
+// and a tap one packed FMA whose weight is one half of a VGPR pair (op_sel).  Image edges: a lane whose window passes the
+// first / last pixel loads from the clamped address and moves its bytes with the replica shifted in (v_alignbyte_b32 under
+// a per-lane condition; edge tiles only).  The vertical pass is the staged form's: TAPS filtered rows in registers, row
+// weights as broadcast LDS reads, dst rows emitted as the source rows complete them.
+template <int D2, int D3> __device__ __forceinline__ constexpr int rwr_d(int q) { return q <= 1 ? 0 : q == 2 ? D2 : D3; }
+template <int H> __device__ __forceinline__ void rwr_pk_fma(v2f32& acc, v2f32 w, v2f32 f) { // (w[H], w[H]) * f + acc
+  if constexpr (H == 0)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(w), "v"(f));
+  else
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "v"(f));
+}
+constexpr int kRrShare = 512; // floats of a wave's LDS in front of its weight table: one column tap set (64 lanes x 8)
+
+template <int ES, int ROWS, int D2, int D3>
+__device__ __forceinline__ void rows_reg_tile(const uint8_t* sp, int spitch, int sw, int sh, uint8_t* dp, int dpitch,
+                                              int dw, int dh, u32 tx, u32 ty, float* wg_lds, int wave_floats) {
+  using T = uint8_t;
+  constexpr int TAPS = 6, kBefore = LzTap<TAPS>::kBefore;
+  constexpr int WT = 4 + 2 * TAPS;
+  constexpr int ND = ES == 1 ? 3 : 4;         // dwords a lane loads per source row: 12 / 16 bytes
+  constexpr int NPX = 4 / ES;                 // dst pixels of the lane
+  constexpr int NCOL = ES == 1 ? 12 : 8;      // source pixels in its window
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int dwe = dw * ES;
+  const int e0 = (int)tx * kRwTile;
+  const int nl = (min(e0 + kRwTile, dwe) - e0 + 3) >> 2;         // lanes with elements
+  const int eb = e0 + 4 * min(lane, nl - 1);                    // (lanes past the row repeat its last lane, and store nothing)
+  const int n_out = lane < nl ? min(4, dwe - eb) : 0;
+  const int y_first = (ty * kWavesPerBlock + wave) * ROWS;
+  const float scale_x = (float)sw / (float)dw, scale_y = (float)sh / (float)dh;
+  float* const lds = wg_lds + wave * wave_floats;
+  float* const wtab = lds + kRrShare;
+  int* const cnt = reinterpret_cast<int*>(wtab + ROWS * WT);
+  const int x0 = eb / ES;
+
+  // ---- column taps: the four waves of the workgroup share their columns; wave w evaluates pixel w % NPX of every lane ----
+  float W[NPX][7];
+  int first;                                                    // source pixel in the lane's register 0
+  {
+    const LzTap<TAPS> c = make_lz_tap<TAPS>(min(x0 + wave % NPX, dw - 1), scale_x);
+    float* mine = lds + 8 * lane;
+    *reinterpret_cast<float4*>(mine) = make_float4(__builtin_bit_cast(float, c.i), c.w[0], c.w[1], c.w[2]);
+    *reinterpret_cast<float4*>(mine + 4) = make_float4(c.w[3], c.w[4], c.w[5], 0.0f);
+    __syncthreads();
+    int i0 = 0;
+#pragma unroll
+    for (int q = 0; q < NPX; ++q) {
+      const float* from = wg_lds + q * wave_floats + 8 * lane;
+      const float4 a = *reinterpret_cast<const float4*>(from), b = *reinterpret_cast<const float4*>(from + 4);
+      const int iq = __builtin_bit_cast(int, a.x);
+      if (q == 0)
+        i0 = iq;
+      const int dq = ES == 1 ? rwr_d<D2, D3>(q) : 0;              // (a constant once the loop is unrolled)
+      const bool late = iq - i0 > dq;                           // its window starts one register further on (q = 0: never)
+      const float w[6] = {a.y, a.z, a.w, b.x, b.y, b.z};
+      W[q][0] = late ? 0.0f : w[0];
+#pragma unroll
+      for (int k = 1; k < 6; ++k)
+        W[q][k] = late ? w[k - 1] : w[k];
+      W[q][6] = late ? w[5] : 0.0f;
+    }
+    first = i0 - kBefore;
+    __syncthreads();
+  }
+  if (y_first >= dh)
+    return;
+
+  // ---- row taps (as in rows_tile): lane r evaluates row y_first + r; cnt[t]: dst rows the wave's t-th source row completes
+  const LzTap<TAPS> vy = make_lz_tap<TAPS>(y_first + (lane & (ROWS - 1)), scale_y);
+  const int last_rr = min(ROWS, dh - y_first) - 1;
+  const int s_begin = __builtin_amdgcn_readlane(vy.i, 0) - kBefore;
+  const int s_end = __builtin_amdgcn_readlane(vy.i, last_rr) + TAPS - 1 - kBefore;
+  cnt[lane] = 0;
+  if (lane < ROWS) {
+    float* row = wtab + lane * WT;
+#pragma unroll
+    for (int k = 0; k < TAPS / 2; ++k)
+      *reinterpret_cast<float4*>(row + 4 + 4 * k) = make_float4(vy.w[2 * k], vy.w[2 * k], vy.w[2 * k + 1], vy.w[2 * k + 1]);
+  }
+  wave_lds_sync();
+  if (lane <= last_rr)
+    __hip_atomic_fetch_add(cnt + (vy.i + TAPS - 1 - kBefore - s_begin), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  wave_lds_sync();
+  const int cntv = cnt[lane];
+
+  // ---- the lane's window: source pixels first .. first + NCOL - 1, loaded from a0, bytes moved |mv| pixels at the edges ----
+  const int a0 = clampi(first, sw - NCOL);                      // (the host refuses planes narrower than the window)
+  const int mv = first - a0;                                    // < 0: the left edge, > 0: the right edge
+  const bool any_left = __builtin_amdgcn_readfirstlane((int)(__ballot(mv < 0) != 0ull)) != 0;
+  const bool any_right = __builtin_amdgcn_readfirstlane((int)(__ballot(mv > 0) != 0ull)) != 0;
+  const u32 goff = (u32)(a0 * ES);
+  struct Row { u32 w[ND]; };
+  auto issue = [&](int logical, Row& q) {
+    const uint8_t* p = sp + (u32)(clampi(logical, sh - 1) * spitch) + goff;
+    if constexpr (ND == 3) {
+      typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+      const v3u32 v = gload_u<v3u32>(p);
+      q.w[0] = v.x; q.w[1] = v.y; q.w[2] = v.z;
+    } else {
+      const v4u32 v = gload_u<v4u32>(p);
+      q.w[0] = v.x; q.w[1] = v.y; q.w[2] = v.z; q.w[3] = v.w;
+    }
+  };
+  Row pf[TAPS];
+#pragma unroll
+  for (int j = 0; j < TAPS; ++j) {
+    issue(s_begin + j, pf[j]);
+    __builtin_amdgcn_sched_barrier(0); // rows in ISSUE order: vmcnt retires in order
+  }
+  v2f32 ring[TAPS][2]; // filtered rows of the vertical window: [slot] = (elements 0, 1), (elements 2, 3) of the lane
+#pragma unroll
+  for (int j = 0; j < TAPS; ++j)
+    ring[j][0] = ring[j][1] = (v2f32){0.0f, 0.0f};
+  uint8_t* optr = dp + (size_t)y_first * dpitch + (size_t)eb;
+  const float* wt = wtab + 4;                       // weights of the next dst row
+
+#pragma unroll 1
+  for (int s0 = s_begin; s0 <= s_end; s0 += TAPS) {
+#pragma unroll
+    for (int j = 0; j < TAPS; ++j) {
+      const int cur = s0 + j;
+      const bool live = cur <= s_end; // wave-uniform; rows past the end skip the work, never the load
+      u32 w[ND];
+#pragma unroll
+      for (int k = 0; k < ND; ++k)
+        w[k] = pf[j].w[k];
+#pragma unroll
+      for (int k = 0; k < ND; ++k)
+        asm volatile("" : "+v"(w[k])); // (the row's registers are read before the load below takes them)
+      __builtin_amdgcn_sched_barrier(0);
+      issue(cur + TAPS, pf[j]); // TAPS rows ahead
+      __builtin_amdgcn_sched_barrier(0);
+      if (!live)
+        continue;
+      // (the distance in bytes, one binary digit at a time: whole dwords, then v_alignbyte_b32; what enters is the replica)
+      if (any_left) {      // replicas of the first pixel enter in front: 1 or 2 pixels
+        const u32 rep = ES == 1 ? (w[0] & 0xffu) * 0x01010101u : (w[0] & 0xffffu) * 0x00010001u;
+        const int nb = max(-mv, 0) * ES;                          // bytes, <= 4 (0: not this lane)
+        if constexpr (ES == 2) {
+          const bool go = (nb & 4) != 0;
+#pragma unroll
+          for (int k = ND - 1; k >= 0; --k)
+            w[k] = go ? (k ? w[k - 1] : rep) : w[k];
+        }
+        {
+          const bool go = (nb & 2) != 0;
+#pragma unroll
+          for (int k = ND - 1; k >= 0; --k) {
+            const u32 moved = __builtin_amdgcn_alignbyte(w[k], k ? w[k - 1] : rep, 2);
+            w[k] = go ? moved : w[k];
+          }
+        }
+        if constexpr (ES == 1) {
+          const bool go = (nb & 1) != 0;
+#pragma unroll
+          for (int k = ND - 1; k >= 0; --k) {
+            const u32 moved = __builtin_amdgcn_alignbyte(w[k], k ? w[k - 1] : rep, 3);
+            w[k] = go ? moved : w[k];
+          }
+        }
+      }
+      if (any_right) {     // replicas of the last pixel enter behind: up to the whole window but one pixel
+        const u32 rep = ES == 1 ? (w[ND - 1] >> 24) * 0x01010101u : (w[ND - 1] >> 16) * 0x00010001u;
+        const int nb = min(max(mv, 0) * ES, 4 * ND - ES);         // bytes (0: not this lane)
+        {
+          const bool go = (nb & 8) != 0;
+#pragma unroll
+          for (int k = 0; k < ND; ++k)
+            w[k] = go ? (k + 2 < ND ? w[k + 2] : rep) : w[k];
+        }
+        {
+          const bool go = (nb & 4) != 0;
+#pragma unroll
+          for (int k = 0; k < ND; ++k)
+            w[k] = go ? (k + 1 < ND ? w[k + 1] : rep) : w[k];
+        }
+        {
+          const bool go = (nb & 2) != 0;
+#pragma unroll
+          for (int k = 0; k < ND; ++k) {
+            const u32 moved = __builtin_amdgcn_alignbyte(k + 1 < ND ? w[k + 1] : rep, w[k], 2);
+            w[k] = go ? moved : w[k];
+          }
+        }
+        if constexpr (ES == 1) {
+          const bool go = (nb & 1) != 0;
+#pragma unroll
+          for (int k = 0; k < ND; ++k) {
+            const u32 moved = __builtin_amdgcn_alignbyte(k + 1 < ND ? w[k + 1] : rep, w[k], 1);
+            w[k] = go ? moved : w[k];
+          }
+        }
+      }
+      // ---- the pass along the row, from registers
+      float h[4];
+      if constexpr (ES == 1) {
+        float c[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+          c[i] = (float)((w[i / 4] >> (8 * (i % 4))) & 0xffu);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int dq = rwr_d<D2, D3>(q);                      // (a constant once the loop is unrolled: registers, not memory)
+          float e = W[q][0] * c[dq], o = W[q][1] * c[dq + 1];
+          e = __builtin_fmaf(W[q][2], c[dq + 2], e);
+          o = __builtin_fmaf(W[q][3], c[dq + 3], o);
+          e = __builtin_fmaf(W[q][4], c[dq + 4], e);
+          o = __builtin_fmaf(W[q][5], c[dq + 5], o);
+          if (q > 0)
+            e = __builtin_fmaf(W[q][6], c[dq + 6], e);
+          h[q] = e + o;
+        }
+      } else {
+        v2f32 cc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          cc[i] = (v2f32){(float)((w[i / 2] >> (16 * (i % 2))) & 0xffu), (float)((w[i / 2] >> (16 * (i % 2) + 8)) & 0xffu)};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          v2f32 e = (v2f32){0.0f, 0.0f}, o = (v2f32){0.0f, 0.0f};
+          const v2f32 w01 = (v2f32){W[q][0], W[q][1]}, w23 = (v2f32){W[q][2], W[q][3]}, w45 = (v2f32){W[q][4], W[q][5]},
+                      w6 = (v2f32){W[q][6], 0.0f};
+          rwr_pk_fma<0>(e, w01, cc[0]);
+          rwr_pk_fma<1>(o, w01, cc[1]);
+          rwr_pk_fma<0>(e, w23, cc[2]);
+          rwr_pk_fma<1>(o, w23, cc[3]);
+          rwr_pk_fma<0>(e, w45, cc[4]);
+          rwr_pk_fma<1>(o, w45, cc[5]);
+          if (q > 0)
+            rwr_pk_fma<0>(e, w6, cc[6]);
+          const v2f32 v = e + o;
+          h[2 * q] = v.x;
+          h[2 * q + 1] = v.y;
+        }
+      }
+      asm volatile("" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]));
+      ring[j][0] = (v2f32){h[0], h[1]};
+      ring[j][1] = (v2f32){h[2], h[3]};
+      // ---- every dst row whose window ends with this source row; slot j is the newest row, logical row r of the window
+      // sits in slot (j + 1 + r) mod TAPS
+      auto emit = [&]() {
+        v2f32 wy[TAPS];
+#pragma unroll
+        for (int k = 0; k < TAPS / 2; ++k) {
+          const float4 q4 = *reinterpret_cast<const float4*>(wt + 4 * k);
+          wy[2 * k] = (v2f32){q4.x, q4.y};
+          wy[2 * k + 1] = (v2f32){q4.z, q4.w};
+        }
+        wt += WT;
+        v2f32 v[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          v[g] = wy[0] * ring[(j + 1) % TAPS][g];
+#pragma unroll
+          for (int r = 1; r < TAPS; ++r)
+            v[g] = __builtin_elementwise_fma(wy[r], ring[(j + 1 + r) % TAPS][g], v[g]);
+        }
+        u32 p = 0;
+        p = __builtin_amdgcn_cvt_pk_u8_f32(v[0].x, 0u, p);
+        p = __builtin_amdgcn_cvt_pk_u8_f32(v[0].y, 1u, p);
+        p = __builtin_amdgcn_cvt_pk_u8_f32(v[1].x, 2u, p);
+        p = __builtin_amdgcn_cvt_pk_u8_f32(v[1].y, 3u, p);
+        if (n_out == 4) {
+          gstore_u<u32>(optr, p);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            if (k < n_out)
+              ((VALI_GLOBAL uint8_t*)optr)[k] = (uint8_t)(p >> (8 * k));
+        }
+        optr += dpitch;
+      };
+      const int c = __builtin_amdgcn_readlane(cntv, cur - s_begin);
+      if (c > 0) {
+        emit();
+        if (c > 1) {
+          emit();
+          for (int k = 2; k < c; ++k)
+            emit();
+        }
+      }
+    }
+  }
+}
+
+template <int ROWS, int D2, int D3>
+__global__ void __launch_bounds__(kBlock) k_resize_rows_reg(const ResizeArgs a) {
+  extern __shared__ uint4 rows_lds[];
+  ResizeJob job;
+  u32 tx, ty, frame;
+  if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
+    return;
+  const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
+  float* const lds = reinterpret_cast<float*>(rows_lds);
+  if (job.channels == 2)
+    rows_reg_tile<2, ROWS, D2, D3>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, lds, a.lds_per_wave / 4);
+  else
+    rows_reg_tile<1, ROWS, D2, D3>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, lds, a.lds_per_wave / 4);
+}
+
+// Host: may the register form take a plane of c channels?  Its lanes assume that dst pixel x0 + j starts its window D_j or
+// D_j + 1 source pixels after pixel x0's, D = (0, 0, d2, d3) -- true of the real numbers, checked here against the FP32
+// products the device forms.  Cached per (sw, dw, c): the check walks the row once.
+struct RrFit { int sw, dw, c, ok, d2, d3; };
+static bool rows_reg_fits(int sw, int dw, int c, int& d2, int& d3) {
+  static thread_local RrFit cache[8];
+  static thread_local int next = 0;
+  for (const RrFit& f : cache)
+    if (f.sw == sw && f.dw == dw && f.c == c && f.sw != 0) {
+      d2 = f.d2; d3 = f.d3;
+      return f.ok != 0;
+    }
+  const float s = (float)sw / (float)dw;
+  bool ok = sw < dw && 3 * sw > dw && sw >= 16;
+  int e2 = 0, e3 = 0;
+  if (ok) {
+    auto fl = [&](int x) { return (int)__builtin_floorf((float)x * s); };
+    if (c == 1) {
+      e2 = (int)__builtin_floorf(2.0f * s);
+      e3 = (int)__builtin_floorf(3.0f * s);
+      for (int x0 = 0; x0 < dw && ok; x0 += 4)
+        for (int j = 1; j < 4 && ok; ++j) {
+          if (x0 + j >= dw)
+            break;
+          const int b = fl(x0 + j) - fl(x0), dj = j == 1 ? 0 : j == 2 ? e2 : e3;
+          ok = b == dj || b == dj + 1;
+        }
+      ok = ok && ((e2 == 0 && e3 == 1) || (e2 == 1 && (e3 == 1 || e3 == 2)));
+    } else {
+      for (int x0 = 0; x0 + 1 < dw && ok; x0 += 2) {
+        const int b = fl(x0 + 1) - fl(x0);
+        ok = b == 0 || b == 1;
+      }
+    }
+  }
+  cache[next] = RrFit{sw, dw, c, ok ? 1 : 0, e2, e3};
+  next = (next + 1) & 7;
+  d2 = e2; d3 = e3;
+  return ok;
+}
+
+// =====================================================================================================================
 // Planes enlarged by exactly 3:2 on BOTH axes (720p -> 1080p, 480p -> 720p, 1440p -> 2160p and their chroma planes): the
 // everyday upscale.  scale = fl(2/3), and x * scale lands where the pattern says for every x (3m * fl(2/3) rounds to
 // exactly 2m: the relative error 2^-25 of fl(2/3) is below half an ulp of any integer; the other two residues sit a third
@@ -938,6 +1291,42 @@ int launch_resize_rows(const ResizeArgs& base, int elem, int taps, int src_w, in
   a.map = make_tile_map_linear(count(rows, true), (u32)n);
   a.force_gather = gather_only ? 1 : 0;
   (void)groups;
+  // the register form (no LDS stage): 8-bit planes that grow along x as well, Lanczos-3 (RESIZE_ROWS = 3: the staged form, A/B and tests)
+  {
+    bool reg = elem == 1 && taps == 6 && !gather_only && tuning(VALI_TUNE_RESIZE_ROWS) != 3;
+    int rd2 = 1, rd3 = 2;
+    bool have = false;
+    for (int k = 0; k < a.njobs && reg; ++k) {
+      const int c = a.job[k].channels;
+      int d2 = 0, d3 = 0;
+      reg = c <= 2 && rows_reg_fits(src_w >> a.job[k].ssub_x, dst_w >> a.job[k].sub_x, c, d2, d3);
+      if (reg && c == 1) {
+        reg = !have || (d2 == rd2 && d3 == rd3);   // one launch, one set of window offsets
+        rd2 = d2; rd3 = d3;
+        have = true;
+      }
+    }
+    if (reg) {
+      a.lds_per_wave = (kRrShare + rows * (4 + 2 * 6) + 64) * 4;
+      const unsigned lds_reg = (unsigned)a.lds_per_wave * kWavesPerBlock;
+      const dim3 grid_reg = tile_grid(a.map);
+#define VALI_RR(R, A, B) hipLaunchKernelGGL((k_resize_rows_reg<R, A, B>), grid_reg, dim3(kBlock), lds_reg, stream, a)
+#define VALI_RR_D(R)                                  \
+  do {                                                \
+    if (rd2 == 0) VALI_RR(R, 0, 1);                   \
+    else if (rd3 == 1) VALI_RR(R, 1, 1);              \
+    else VALI_RR(R, 1, 2);                            \
+  } while (0)
+      if (rows == 64) VALI_RR_D(64);
+      else if (rows == 32) VALI_RR_D(32);
+      else if (rows == 8) VALI_RR_D(8);
+      else VALI_RR_D(2);
+#undef VALI_RR_D
+#undef VALI_RR
+      VALI_LAUNCH_CHECK();
+      return VALI_OK;
+    }
+  }
   a.stage_bytes = kRwSf * 4;
   a.lds_per_wave = ((rw_wave_floats(maxc, rows, taps) * 4) + 15) & ~15;
   const unsigned lds = (unsigned)a.lds_per_wave * kWavesPerBlock;
