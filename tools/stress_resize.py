@@ -34,6 +34,7 @@ while time.time() - t0 < budget:
     vali.tuning.Set("ROWS_PER_WAVE", int([0, 2, 4, 8][rng.integers(4)]))   # bilinear / point forms
     vali.tuning.Set("RESIZE_FORCE_GATHER", int(rng.integers(8) == 0))       # the direct forms
     vali.tuning.Set("RESIZE_POINT", int(rng.integers(6) != 0))              # 0: no point / x2 forms
+    vali.tuning.Set("RESIZE_ROWS", int([1, 1, 1, 2, 3][rng.integers(5)]))    # planes that grow: 2 no 3:2 form, 3 the LDS-staged form instead of the register form
     pf = vali.PixelFormat[name]
     src = vali.Surface.Make(pf, sw, sh, DEV)
     nel = src.HostSize // np.dtype(dt).itemsize
