@@ -223,6 +223,7 @@ PYBIND11_MODULE(_vali_shim, m) {
                   {"TUNE_ROWS_PER_WAVE", VALI_TUNE_ROWS_PER_WAVE},
                   {"TUNE_BLOCKING_WAIT", VALI_TUNE_BLOCKING_WAIT},
                   {"TUNE_RESIZE_ROWS", VALI_TUNE_RESIZE_ROWS},
+                  {"TUNE_RESIZE_COLS", VALI_TUNE_RESIZE_COLS},
                   {"TUNE_COUNT", VALI_TUNE_COUNT}})
     m.attr(kv.first) = kv.second;
   m.def("tuning_set", [](int key, int value) { return vali_tuning_set(key, value); });

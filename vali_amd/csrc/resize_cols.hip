@@ -107,13 +107,12 @@ struct ColProg {
 
 // false: the wave has no rows.  `prog`: kColProg floats of this wave's LDS.  D = the walk's rows in flight.
 template <int TAPS, int P, bool ACT, int D>
-__device__ __forceinline__ bool cols_rows(int sh, int dh, u32 ty, int rps, float* prog, ColProg& r) {
+__device__ __forceinline__ bool cols_rows(int sh, int dh, u32 row_tile, int rps, float* prog, ColProg& r) {
   constexpr int kBefore = LzTap<TAPS>::kBefore;
   constexpr int ESZ = kProgEsz<P, ACT>, NPROG = kProgRows<P, ACT>;
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int rows = P * rps;                                     // dst rows of this wave, <= 64
-  r.y_first = (int)(ty * kWavesPerBlock + wave) * rows;         // wave-uniform
+  r.y_first = (int)row_tile * rows;                             // wave-uniform
   if (r.y_first >= dh)
     return false;
   r.last_rr = min(rows, dh - r.y_first) - 1;
@@ -409,7 +408,7 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
     __syncthreads();
   }
   ColProg r;
-  if (!cols_rows<TAPS, P, EB == 4, D>(sh, dh, ty, rps, lds + kColLds, r))
+  if (!cols_rows<TAPS, P, EB == 4, D>(sh, dh, ty * kWavesPerBlock + (u32)wave, rps, lds + kColLds, r))
     return;
 
   // ---- the tile's source span along x (wave-uniform) ----
@@ -635,6 +634,271 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
   cols_walk<T, TAPS, P, ND, D>(r, sp, spitch, sh, (u32)(j0 * EB), [](const u32 (&d)[ND], v2f32 (&f)[4]) { conv8<T>(d, f); }, take);
 }
 
+// ---- the general form on SPECIALISED waves (round 5) ----
+// The form above runs both passes in ONE wave: a wave that has completed a pair of dst rows stops walking -- strip write,
+// tap reads, chains, transposition write, read, quantise, store: three LDS round trips behind each other -- while its loads
+// in flight land and wait; with 118-126 registers at most four such waves share a SIMD, and at any moment most of them wait
+// (profiles/r04_lanczos.md, section 6).  Here a workgroup is TWO waves with one tile: the PRODUCER walks the source rows
+// (loads, conversions, the scatter into the slots' accumulators -- cols_walk, unchanged) and writes every completed pair of
+// dst rows into one of two strips; the CONSUMER runs the pass along the rows on the other strip (the same reads, chains,
+// transposition and stores as above, bit for bit).  The producer never waits for an LDS result but its program entries, the
+// consumer never for a global load; they meet at ONE s_barrier per pair:
+//   producer   [B] W(0) walk [B] W(1) walk ... [B] W(n-1) walk-out [B]        W(k): strip k % 2
+//   consumer   [B]      R(0) [B]      R(1) ...  [B]            R(n-1)
+// at the barrier in front of W(k) the consumer has finished R(k - 2) (the strip W(k) overwrites) and the producer's W(k - 1)
+// has landed (s_waitcnt lgkmcnt(0): by then long done -- the wait sits a whole pair behind the writes it waits for).
+constexpr int kWsBlock = 2 * kWave;
+constexpr int kWsStripBytes = kColStrip * 8;                  // one strip: kColStrip slots of two floats
+constexpr int kWsObuf = 2 * 2 * kColStrip;                    // floats: behind the two strips, the transposition (256 x 2)
+constexpr int kWsProg = kWsObuf + 512;                        // the producer's program
+constexpr int kWsLds = kWsProg + kColProg;                    // floats of a workgroup
+
+__device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Two windows of the pass along the rows: results in ra / rb (both rows of the pair).  OFF: byte offset of the strip.
+template <int TAPS, int OFF>
+__device__ __forceinline__ void ws_row_taps(v2f32& ra, v2f32& rb, u32 a0, u32 a1, u32 b0, u32 b1, const v2f32 (&wa)[TAPS / 2],
+                                            const v2f32 (&wb)[TAPS / 2]) {
+  v2f32 t0, t1, t2, t3, t4, t5, u0, u1, u2, u3, u4, u5;
+  if constexpr (TAPS == 6) {
+    asm volatile(
+        "ds_read_b64 %[t0], %[a0] offset:%[o0]\n\tds_read_b64 %[t1], %[a1] offset:%[o0]\n\tds_read_b64 %[t2], %[a0] offset:%[o1]\n\t"
+        "ds_read_b64 %[t3], %[a1] offset:%[o1]\n\tds_read_b64 %[t4], %[a0] offset:%[o2]\n\tds_read_b64 %[t5], %[a1] offset:%[o2]\n\t"
+        "ds_read_b64 %[u0], %[b0] offset:%[o0]\n\tds_read_b64 %[u1], %[b1] offset:%[o0]\n\tds_read_b64 %[u2], %[b0] offset:%[o1]\n\t"
+        "ds_read_b64 %[u3], %[b1] offset:%[o1]\n\tds_read_b64 %[u4], %[b0] offset:%[o2]\n\tds_read_b64 %[u5], %[b1] offset:%[o2]\n\t"
+        "s_waitcnt lgkmcnt(6)\n\t"
+        "v_pk_fma_f32 %[t0], %[w0], %[t0], 0 op_sel_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %[t1], %[w0], %[t1], 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]\n\t"
+        "v_pk_fma_f32 %[t0], %[w1], %[t2], %[t0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %[t1], %[w1], %[t3], %[t1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %[t0], %[w2], %[t4], %[t0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %[t1], %[w2], %[t5], %[t1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_pk_fma_f32 %[u0], %[x0], %[u0], 0 op_sel_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %[u1], %[x0], %[u1], 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]\n\t"
+        "v_pk_add_f32 %[t0], %[t0], %[t1]\n\t"
+        "v_pk_fma_f32 %[u0], %[x1], %[u2], %[u0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %[u1], %[x1], %[u3], %[u1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %[u0], %[x2], %[u4], %[u0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %[u1], %[x2], %[u5], %[u1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "s_nop 0\n\t"
+        "v_pk_add_f32 %[u0], %[u0], %[u1]"
+        : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [u0] "=&v"(u0),
+          [u1] "=&v"(u1), [u2] "=&v"(u2), [u3] "=&v"(u3), [u4] "=&v"(u4), [u5] "=&v"(u5)
+        : [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1), [w0] "v"(wa[0]), [w1] "v"(wa[1]), [w2] "v"(wa[TAPS / 2 - 1]),
+          [x0] "v"(wb[0]), [x1] "v"(wb[1]), [x2] "v"(wb[TAPS / 2 - 1]), [o0] "i"(OFF), [o1] "i"(OFF + 8), [o2] "i"(OFF + 16)
+        : "memory");
+  } else {
+    asm volatile(
+        "ds_read_b64 %[t0], %[a0] offset:%[o0]\n\tds_read_b64 %[t1], %[a1] offset:%[o0]\n\tds_read_b64 %[t2], %[a0] offset:%[o1]\n\t"
+        "ds_read_b64 %[t3], %[a1] offset:%[o1]\n\t"
+        "ds_read_b64 %[u0], %[b0] offset:%[o0]\n\tds_read_b64 %[u1], %[b1] offset:%[o0]\n\tds_read_b64 %[u2], %[b0] offset:%[o1]\n\t"
+        "ds_read_b64 %[u3], %[b1] offset:%[o1]\n\t"
+        "s_waitcnt lgkmcnt(4)\n\t"
+        "v_pk_fma_f32 %[t0], %[w0], %[t0], 0 op_sel_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %[t1], %[w0], %[t1], 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]\n\t"
+        "v_pk_fma_f32 %[t0], %[w1], %[t2], %[t0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %[t1], %[w1], %[t3], %[t1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_pk_fma_f32 %[u0], %[x0], %[u0], 0 op_sel_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %[u1], %[x0], %[u1], 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]\n\t"
+        "v_pk_add_f32 %[t0], %[t0], %[t1]\n\t"
+        "v_pk_fma_f32 %[u0], %[x1], %[u2], %[u0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %[u1], %[x1], %[u3], %[u1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "s_nop 0\n\t"
+        "v_pk_add_f32 %[u0], %[u0], %[u1]"
+        : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [u0] "=&v"(u0), [u1] "=&v"(u1), [u2] "=&v"(u2),
+          [u3] "=&v"(u3)
+        : [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1), [w0] "v"(wa[0]), [w1] "v"(wa[1]), [x0] "v"(wb[0]),
+          [x1] "v"(wb[1]), [o0] "i"(OFF), [o1] "i"(OFF + 8)
+        : "memory");
+    (void)t4; (void)t5; (void)u4; (void)u5;
+  }
+  ra = t0;
+  rb = u0;
+}
+
+template <typename T, int ES, int TAPS, int P>
+__device__ __forceinline__ void cols_tile_ws(const uint8_t* sp, int spitch, int sw, int sh, uint8_t* dp, int dpitch,
+                                             int dw, int dh, u32 tx, u32 ty, int N, int rps, float* lds) {
+  constexpr int kBefore = LzTap<TAPS>::kBefore;
+  constexpr int EB = (int)sizeof(T);
+  constexpr int ND = 2 * EB;
+  constexpr int D = EB == 4 ? 3 : EB == 2 ? 3 : 4;              // source rows in flight
+  constexpr int HALF = kColHalf<ES>, SEG = 2 * HALF;            // slots
+  const int lane = threadIdx.x & 63;
+  const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // 0: producer, 1: consumer
+  v2f32* const strip = reinterpret_cast<v2f32*>(lds);
+  const u32 lds_base = (u32)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
+  const int dwe = dw * ES, row_el = sw * ES;
+  const int e0 = (int)tx * N, e_last = min(e0 + N, dwe) - 1;
+  const float scale_x = (float)sw / (float)dw;
+  const int rows = P * rps;
+  const int y_first = (int)ty * rows;
+  if (y_first >= dh) // (both waves)
+    return;
+  const int last_rr = min(rows, dh - y_first) - 1;
+  // ---- the tile's source span along x (wave-uniform) ----
+  const int px_first = e0 / ES, px_last = e_last / ES;
+  const int ux0 = (int)__builtin_floorf((float)px_first * scale_x) - kBefore - 1;
+  const int ux1 = (int)__builtin_floorf((float)px_last * scale_x) + TAPS + 1 - kBefore;
+  const int sx0 = clampi(ux0, sw - 1), sx1 = clampi(ux1, sw - 1);
+  const int j_begin = (sx0 * ES) & ~(kColEl - 1);               // first element the wave loads
+  const int px_begin = j_begin / ES;
+
+  if (role == 0) {
+    ColProg r;
+    cols_rows<TAPS, P, EB == 4, D>(sh, dh, ty, rps, lds + kWsProg, r);
+    const int nl = min((((sx1 + 1) * ES - j_begin) + kColEl - 1) / kColEl, kWave); // lanes with data
+    const bool ragged = j_begin + kColEl * nl > row_el;           // wave-uniform: only a row's last tile
+    const int j0 = min(j_begin + kColEl * min(lane, nl - 1), row_el - kColEl);
+    int wpos[ES == 3 ? kColEl : 2];
+    if constexpr (ES == 3) {
+#pragma unroll
+      for (int q = 0; q < kColEl; ++q) {
+        const int j = j0 + q, px = j / 3;
+        wpos[q] = (j - px * 3) * SEG + col_slot<ES>(kColPadL + px - px_begin);
+      }
+    } else {
+      const int q0 = kColPadL + j0 / ES - px_begin;
+      wpos[0] = col_slot<ES>(q0);
+      wpos[1] = col_slot<ES>(q0 + 1);
+    }
+    v2f32 hold[4];
+    u32 woff = 0u;                                                // slots: 0 / kColStrip
+    auto take = [&](bool pair, int rr, v2f32 (&c)[4]) {
+      if (!pair) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          hold[i] = c[i];
+        return;
+      }
+      v2f32 lo[4], hi[4];
+      if ((rr & 1) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          lo[i] = pk_dup<0>(c[i]);
+          hi[i] = pk_dup<1>(c[i]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          lo[i] = pk_mov<0, 0>(hold[i], c[i]);
+          hi[i] = pk_mov<1, 1>(hold[i], c[i]);
+        }
+      }
+      ws_barrier();
+      v2f32* const st = strip + woff;
+      woff ^= (u32)kColStrip;
+      if constexpr (ES == 3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          st[wpos[2 * i]] = lo[i];
+          st[wpos[2 * i + 1]] = hi[i];
+        }
+      } else if (ragged) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if constexpr (ES == 2) {
+            st[wpos[i & 1] + (i >> 1)] = lo[i];
+            st[SEG + wpos[i & 1] + (i >> 1)] = hi[i];
+          } else {
+            st[wpos[0] + i] = lo[i];
+            st[wpos[1] + i] = hi[i];
+          }
+        }
+      } else if constexpr (ES == 2) {
+        *reinterpret_cast<float4*>(st + wpos[0]) = make_float4(lo[0].x, lo[0].y, lo[2].x, lo[2].y);
+        *reinterpret_cast<float4*>(st + wpos[1]) = make_float4(lo[1].x, lo[1].y, lo[3].x, lo[3].y);
+        *reinterpret_cast<float4*>(st + SEG + wpos[0]) = make_float4(hi[0].x, hi[0].y, hi[2].x, hi[2].y);
+        *reinterpret_cast<float4*>(st + SEG + wpos[1]) = make_float4(hi[1].x, hi[1].y, hi[3].x, hi[3].y);
+      } else {
+        *reinterpret_cast<float4*>(st + wpos[0]) = make_float4(lo[0].x, lo[0].y, lo[1].x, lo[1].y);
+        *reinterpret_cast<float4*>(st + wpos[0] + 2) = make_float4(lo[2].x, lo[2].y, lo[3].x, lo[3].y);
+        *reinterpret_cast<float4*>(st + wpos[1]) = make_float4(hi[0].x, hi[0].y, hi[1].x, hi[1].y);
+        *reinterpret_cast<float4*>(st + wpos[1] + 2) = make_float4(hi[2].x, hi[2].y, hi[3].x, hi[3].y);
+      }
+    };
+    cols_walk<T, TAPS, P, ND, D>(r, sp, spitch, sh, (u32)(j0 * EB), [](const u32 (&d)[ND], v2f32 (&f)[4]) { conv8<T>(d, f); }, take);
+    ws_barrier(); // the last pair has landed
+    return;
+  }
+
+  // ---- consumer: the pass along the rows ----
+  v2f32 wq[4][TAPS / 2]; // (w0, w1), (w2, w3), ..
+  u32 ha[4][2];          // LDS byte addresses in strip 0: taps 0, 2, 4 at ha[p][0] + 0, 8, 16; taps 1, 3, 5 at ha[p][1] + 0, 8, 16
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int e = min(e0 + p * kWave + lane, e_last);
+    const int px = e / ES, ch = e - px * ES;
+    const LzTap<TAPS> c = make_lz_tap<TAPS>(px, scale_x);
+#pragma unroll
+    for (int k = 0; k < TAPS / 2; ++k)
+      wq[p][k] = (v2f32){c.w[2 * k], c.w[2 * k + 1]};
+    const int q = kColPadL + (min(c.i, sw - 1) - kBefore - px_begin); // >= kColPadL - kBefore
+    ha[p][0] = lds_base + 8u * (u32)(ch * SEG + col_slot<ES>(q));
+    ha[p][1] = lds_base + 8u * (u32)(ch * SEG + col_slot<ES>(q + 1));
+  }
+  v2f32* const obuf = reinterpret_cast<v2f32*>(lds + kWsObuf);
+  const u32 obuf_rd = lds_base + 4u * (u32)kWsObuf + 32u * (u32)lane;
+  const bool pad_left = ux0 < 0, pad_right = ux1 > sw - 1;                 // wave-uniform
+  const int edge = kColPadL + (sw - 1) - px_begin;                         // the last pixel of the row
+  const int eb = e0 + 4 * lane;                                            // store: 4 adjacent elements
+  const int n_out = min(4, e_last + 1 - eb);
+  const bool plain_store = EB == 1 && ((e_last + 1 - e0) & 3) == 0 && ((((uintptr_t)dp) | (uintptr_t)dpitch) & 3u) == 0; // wave-uniform
+  auto store_row = [&](int rr, float v0, float v1, float v2, float v3) {
+    uint8_t* const out = dp + (u32)((y_first + rr) * dpitch) + (size_t)eb * EB;
+    if (plain_store) {
+      u32 q = __builtin_amdgcn_cvt_pk_u8_f32(v0, 0u, 0u);
+      q = __builtin_amdgcn_cvt_pk_u8_f32(v1, 1u, q);
+      q = __builtin_amdgcn_cvt_pk_u8_f32(v2, 2u, q);
+      q = __builtin_amdgcn_cvt_pk_u8_f32(v3, 3u, q);
+      gstore_nt<u32>(out, q);
+    } else {
+      const float res[4][1] = {{v0}, {v1}, {v2}, {v3}};
+      store_px4<T, 1>(out, res, (1u << n_out) - 1u);
+    }
+  };
+  auto pass = [&](auto buf_tag, int n) {
+    constexpr int B = decltype(buf_tag)::value;
+    ws_barrier();
+    v2f32* const st = strip + B * kColStrip;
+    if (pad_left || pad_right) { // image edges: replicas of the first / last pixel of every channel segment
+      const int ch = lane >> 3, i = lane & 7;
+      if (pad_left && ch < ES && i < kColPadL)
+        st[ch * SEG + col_slot<ES>(kColPadL - 1 - i)] = st[ch * SEG + col_slot<ES>(kColPadL)];
+      if (pad_right && ch < ES && i < kColPadR)
+        st[ch * SEG + col_slot<ES>(edge + 1 + i)] = st[ch * SEG + col_slot<ES>(edge)];
+      wave_lds_sync();
+    }
+#pragma unroll
+    for (int half = 0; half < 4; half += 2) {
+      v2f32 ra, rb;
+      ws_row_taps<TAPS, B * kWsStripBytes>(ra, rb, ha[half][0], ha[half][1], ha[half + 1][0], ha[half + 1][1], wq[half], wq[half + 1]);
+      obuf[half * kWave + lane] = ra;
+      obuf[(half + 1) * kWave + lane] = rb;
+    }
+    wave_lds_sync();
+    const int rr = min(2 * n + 1, last_rr);
+    if (n_out > 0) {
+      float4 v0, v1; // (a0, b0, a1, b1), (a2, b2, a3, b3)
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(v0), "=&v"(v1) : "v"(obuf_rd) : "memory");
+      store_row(rr - (rr & 1), v0.x, v0.z, v1.x, v1.z); // (a last row on its own: twice)
+      store_row(rr, v0.y, v0.w, v1.y, v1.w);
+    }
+    wave_lds_sync();
+  };
+  const int npairs = (last_rr + 2) >> 1;
+  ws_barrier(); // (the one in front of the producer's first write)
+#pragma unroll 1
+  for (int n = 0; n < npairs; n += 2) {
+    pass(std::integral_constant<int, 0>{}, n);
+    if (n + 1 < npairs)
+      pass(std::integral_constant<int, 1>{}, n + 1);
+  }
+}
+
 // Exactly 2:1 along x (src_w == 2 dst_w: x * scale_x is an integer, every column weight is 0 or 1 and the pass along the
 // row is the point sample c[2 x] -- bit for bit: fma(0, c, e) == e, and 1 * c + 0 == c).  The columns that are never
 // sampled are never filtered: a lane loads 16 source elements per row and filters the 8 that survive, which are the 8
@@ -650,7 +914,7 @@ __device__ __forceinline__ void cols_tile_x2(const uint8_t* sp, int spitch, int 
   constexpr int D = EB == 1 ? 8 : 4;                            // rows in flight: this form is bound by its memory stream (8 vs 4: -5 %)
   const int lane = threadIdx.x & 63;
   ColProg r;
-  if (!cols_rows<TAPS, P, false, D>(sh, dh, ty, rps, strip, r))
+  if (!cols_rows<TAPS, P, false, D>(sh, dh, ty * kWavesPerBlock + (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), rps, strip, r))
     return;
   const int dwe = dw * ES;                                      // >= 8 (host)
   const int e0 = (int)tx * (kWave * 8);
@@ -726,7 +990,7 @@ __device__ __forceinline__ void cols_tile_x32(const uint8_t* sp, int spitch, int
   ColProg r;
   int y_first = 0;                                              // dst row of emit()'s row 0
   if constexpr (!SROWS) {
-    if (!cols_rows<TAPS, P, false, D>(sh, dh, ty, rps, strip, r))
+    if (!cols_rows<TAPS, P, false, D>(sh, dh, ty * kWavesPerBlock + (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), rps, strip, r))
       return;
     y_first = r.y_first;
   }
@@ -919,6 +1183,26 @@ __global__ void __launch_bounds__(kBlock) k_resize_cols(const ResizeArgs a) {
   }
 }
 
+// waves per SIMD the register allocation aims at: the producer's accumulators are 8 P registers
+template <int EB, int P> constexpr int kWsWaves = EB == 4 ? (P <= 3 ? 4 : 3) : P <= 3 ? (EB == 2 ? 5 : 6) : P <= 4 ? 5 : 4;
+template <typename T, int ESSET, int TAPS, int P>
+__global__ void __launch_bounds__(kWsBlock, (kWsWaves<(int)sizeof(T), P>)) k_resize_cols_ws(const ResizeArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[kWsLds];
+  ResizeJob job;
+  u32 tx, ty, frame;
+  if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
+    return;
+  const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
+  if constexpr (ESSET == 3) {
+    cols_tile_ws<T, 3, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_n, a.cols_rps, lds);
+  } else {
+    if (ESSET == 12 && job.channels == 2)
+      cols_tile_ws<T, 2, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_n, a.cols_rps, lds);
+    else
+      cols_tile_ws<T, 1, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_n, a.cols_rps, lds);
+  }
+}
+
 template <typename T, int ESSET, int TAPS, int P>
 __global__ void __launch_bounds__(kBlock) k_resize_cols_x2(const ResizeArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][kColProg]; // the waves' programs (cols_rows)
@@ -1015,6 +1299,15 @@ static void launch_slots(const ResizeArgs& a, int slots, int xform, dim3 grid, h
         hipLaunchKernelGGL((k_resize_cols_x32<T, ESSET, TAPS, P2>), grid, dim3(kBlock), 0, stream, a);
       return;
     }
+  }
+  if (xform == 5) { // the general form on specialised waves: a workgroup = producer + consumer of ONE tile
+    if (slots <= P0)
+      hipLaunchKernelGGL((k_resize_cols_ws<T, ESSET, TAPS, P0>), grid, dim3(kWsBlock), 0, stream, a);
+    else if (slots <= P1)
+      hipLaunchKernelGGL((k_resize_cols_ws<T, ESSET, TAPS, P1>), grid, dim3(kWsBlock), 0, stream, a);
+    else
+      hipLaunchKernelGGL((k_resize_cols_ws<T, ESSET, TAPS, P2>), grid, dim3(kWsBlock), 0, stream, a);
+    return;
   }
   if (slots <= P0)
     hipLaunchKernelGGL((k_resize_cols<T, ESSET, TAPS, P0>), grid, dim3(kBlock), 0, stream, a);
@@ -1113,9 +1406,10 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
     else if (x32)
       tile_n = kX32Out;   // 62 lanes x 8 dst elements, lanes 0 and 63 supply the halos
   }
+  const bool ws = !x2 && !x32 && tuning(VALI_TUNE_RESIZE_COLS) != 1;           // the general form: specialised waves
   auto count = [&](int rps, bool assign) {
     u32 total = 0;
-    const int rows = kWavesPerBlock * P * rps;
+    const int rows = (ws ? 1 : kWavesPerBlock) * P * rps;
     for (int k = 0; k < a.njobs; ++k) {
       const int dwe = (dst_w >> a.job[k].sub_x) * a.job[k].channels, dh = dst_h >> a.job[k].sub_y;
       const u32 tiles_x = (u32)(dwe + tile_n - 1) / (u32)tile_n;
@@ -1140,7 +1434,7 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
   else
     // (2048 workgroups = 8 waves per SIMD: with fewer the launch's last round leaves SIMDs idle -- 64 frames of 1080p -> 720p
     // were 6912 waves of 30 rows, 1.4 rounds)
-    while (rps > 1 && (unsigned long long)count(rps, false) * (unsigned)n < 2048ull)
+    while (rps > 1 && (unsigned long long)count(rps, false) * (unsigned)n < (ws ? 4096ull : 2048ull))
       rps = rps > 2 ? rps / 2 : 1;
   const bool srows = x32 && !x2 && y32 && force != 2;                         // (RESIZE_NO_SEPARABLE = 2: the slot walk, for A/B and tests)
   if (srows) {
@@ -1176,13 +1470,13 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
 #define VALI_COLS_T(T)                                                               \
   do {                                                                               \
     if (taps == 6) {                                                                 \
-      if (esset == 1) launch_slots<T, 1, 6>(a, P, x2 ? 2 : srows ? 4 : x32 ? 3 : 0, grid, stream);                      \
-      else if (esset == 12) launch_slots<T, 12, 6>(a, P, x2 ? 2 : srows ? 4 : x32 ? 3 : 0, grid, stream);               \
-      else launch_slots<T, 3, 6>(a, P, x2 ? 2 : srows ? 4 : x32 ? 3 : 0, grid, stream);                                 \
+      if (esset == 1) launch_slots<T, 1, 6>(a, P, x2 ? 2 : srows ? 4 : x32 ? 3 : ws ? 5 : 0, grid, stream);                      \
+      else if (esset == 12) launch_slots<T, 12, 6>(a, P, x2 ? 2 : srows ? 4 : x32 ? 3 : ws ? 5 : 0, grid, stream);               \
+      else launch_slots<T, 3, 6>(a, P, x2 ? 2 : srows ? 4 : x32 ? 3 : ws ? 5 : 0, grid, stream);                                 \
     } else {                                                                         \
-      if (esset == 1) launch_slots<T, 1, 4>(a, P, x2 ? 2 : x32 ? 3 : 0, grid, stream);                      \
-      else if (esset == 12) launch_slots<T, 12, 4>(a, P, x2 ? 2 : x32 ? 3 : 0, grid, stream);               \
-      else launch_slots<T, 3, 4>(a, P, x2 ? 2 : x32 ? 3 : 0, grid, stream);                                 \
+      if (esset == 1) launch_slots<T, 1, 4>(a, P, x2 ? 2 : x32 ? 3 : ws ? 5 : 0, grid, stream);                      \
+      else if (esset == 12) launch_slots<T, 12, 4>(a, P, x2 ? 2 : x32 ? 3 : ws ? 5 : 0, grid, stream);               \
+      else launch_slots<T, 3, 4>(a, P, x2 ? 2 : x32 ? 3 : ws ? 5 : 0, grid, stream);                                 \
     }                                                                                \
   } while (0)
   if (elem == 1) VALI_COLS_T(uint8_t);

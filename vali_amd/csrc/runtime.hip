@@ -27,7 +27,8 @@ const TuneDef kTuneDefs[VALI_TUNE_COUNT] = {
     {"VALI_NV12_ROWPAIRS", 0}, {"VALI_WAVES_PER_CU", 0},      {"VALI_NV12_DIRECT_STORE", 0}, {"VALI_RESIZE_FORCE_GATHER", 0},
     {"VALI_RESIZE_POINT", 1},  {"VALI_UD_FORCE_GATHER", 0},   {"VALI_UD_DOWN2", 1},          {"VALI_UD_OCC5", 0},
     {"VALI_ROTATE_NO_TILE", 0}, {"VALI_ROCTX", 0},            {"VALI_RESIZE_NO_SEPARABLE", 0},
-    {"VALI_ROWS_PER_WAVE", 0}, {"VALI_BLOCKING_WAIT", 0},    {"VALI_RESIZE_ROWS", 1}};
+    {"VALI_ROWS_PER_WAVE", 0}, {"VALI_BLOCKING_WAIT", 0},    {"VALI_RESIZE_ROWS", 1},
+    {"VALI_RESIZE_COLS", 0}};
 std::atomic<int> g_tune[VALI_TUNE_COUNT];
 std::once_flag g_tune_once;
 
