@@ -96,7 +96,7 @@ template <int P, bool ACT> constexpr int kProgEsz = (P <= 3 && !ACT) ? 4 : 8;
 template <int P, bool ACT> constexpr int kProgRows = (P <= 3 && !ACT) ? 112 : 64;     // entries (the host keeps ns + D below it)
 constexpr int kColProg = 576;                                      // floats: entries + first_w
 static_assert(kProgRows<3, false> * (kProgEsz<3, false> + 1) <= kColProg && kProgRows<6, true> * (kProgEsz<6, true> + 1) <= kColProg, "program size");
-constexpr u32 kProgDone = 1u << 24, kProgDbl = 1u << 25, kProgPair = 1u << 26;
+constexpr u32 kProgDone = 1u << 24, kProgDbl = 1u << 25, kProgPair = 1u << 26, kProgSingle = 1u << 27; // (27: the pair is ONE row, the wave's last)
 struct ColProg {
   u32 lds;            // LDS byte address of entry 0 (kept in a VGPR: the ds_read's address operand)
   const float* first_w;
@@ -106,7 +106,10 @@ struct ColProg {
 };
 
 // false: the wave has no rows.  `prog`: kColProg floats of this wave's LDS.  D = the walk's rows in flight.
-template <int TAPS, int P, bool ACT, int D>
+// BYSLOT: column j of an entry is the weight of SLOT j (dst row rr lives in slot rr mod P) instead of the row of age j: the
+// accumulators then never move -- the walk picks the completing set by a scalar switch (cols_walk) -- at the price of P
+// copies of take(); the specialised producer, whose take() is a strip write, pays that gladly.
+template <int TAPS, int P, bool ACT, int D, bool BYSLOT = false>
 __device__ __forceinline__ bool cols_rows(int sh, int dh, u32 row_tile, int rps, float* prog, ColProg& r) {
   constexpr int kBefore = LzTap<TAPS>::kBefore;
   constexpr int ESZ = kProgEsz<P, ACT>, NPROG = kProgRows<P, ACT>;
@@ -166,11 +169,17 @@ __device__ __forceinline__ bool cols_rows(int sh, int dh, u32 row_tile, int rps,
         age[k] += (lane >= m && prev >= t0 + k) ? 1 : 0;
     }
   }
+  const bool enters = age[0] == P; // (the oldest of the P rows before this one completes on this row's first source row)
+  if constexpr (BYSLOT) {
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k)
+      age[k] = lane % P;
+  }
   if (lane <= r.last_rr) {
     constexpr int CW = ESZ == 4 ? 3 : 6;                         // dword of the control word
     // age P: the P rows before this one are all still open at its first source row -- the oldest of them completes
     // there (the host's P admits nothing else): this row starts when that one has left
-    if (age[0] == P) {
+    if (enters) {
       first_w[t0] = vy.w[0];
       __hip_atomic_fetch_or(ent + ESZ * t0 + CW, kProgDbl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     } else {
@@ -182,11 +191,11 @@ __device__ __forceinline__ bool cols_rows(int sh, int dh, u32 row_tile, int rps,
     if constexpr (ACT) {
 #pragma unroll
       for (int k = 0; k < TAPS; ++k)
-        if (k > 0 || age[0] < P)
+        if (k > 0 || !enters)
           __hip_atomic_fetch_or(ent + ESZ * (t0 + k) + CW + 1, 1u << age[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
     // (at most one dst row completes per source row: scale_y >= 1)
-    const u32 fin = kProgDone | (((lane & 1) != 0 || lane == r.last_rr) ? kProgPair : 0u);
+    const u32 fin = kProgDone | (((lane & 1) != 0 || lane == r.last_rr) ? kProgPair : 0u) | (((lane & 1) == 0 && lane == r.last_rr) ? kProgSingle : 0u);
     __hip_atomic_fetch_or(ent + ESZ * (t0 + TAPS - 1) + CW, fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
   }
   wave_lds_sync();
@@ -205,9 +214,12 @@ template <int H> __device__ __forceinline__ void pk_fma_h(v2f32& acc, v2f32 w, v
 // flight), conv() turns them into the 2 NF floats it filters, every slot takes fma(w, f, acc) with the weight of its
 // program entry, and when a row completes a dst row take(pair, rr, c) gets that row's column results -- pair: the row
 // closes a pair of dst rows (program bit 26).
-template <typename T, int TAPS, int P, int ND, int D, int NF = 4, typename Conv, typename Take>
+struct NoFlush {
+  __device__ __forceinline__ void operator()(bool) const {}
+};
+template <typename T, int TAPS, int P, int ND, int D, int NF = 4, bool BYSLOT = false, typename Conv, typename Take, typename Flush = NoFlush>
 __device__ __forceinline__ void cols_walk(const ColProg& r, const uint8_t* sp, int spitch, int sh, u32 lane_off,
-                                          Conv conv, Take take) {
+                                          Conv conv, Take take, Flush flush = Flush()) {
   constexpr int EB = (int)sizeof(T);
   constexpr bool ACT = EB == 4;
   constexpr int ESZ = kProgEsz<P, ACT>;
@@ -219,23 +231,28 @@ __device__ __forceinline__ void cols_walk(const ColProg& r, const uint8_t* sp, i
     for (int i = 0; i < NF; ++i)
       acc[j][i] = (v2f32){0.0f, 0.0f};
   u32 pf[D][ND];
-  auto issue = [&](u32 off, u32 (&q)[ND]) {
-    const uint8_t* p = sp + off;
+  // A row's loads through a raw buffer descriptor over the plane: address = base + row offset (a SCALAR operand: one s_mul
+  // per row) + the lane's offset (the one VGPR of the address) -- no vector instruction per row.  (global_load would do with
+  // its scalar base, but the compiler adds the row offset to a 64-bit VECTOR sp + lane_off instead: a v_lshl_add_u64 per row.)
+  // Planes stay below 4 GiB (planes_fit_32bit, common.hpp); nothing past a row's last element is ever addressed.
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(sp), (short)0, (int)0xffffffffu, 0x00020000);
+  auto issue = [&](u32 row_off, u32 (&q)[ND]) {
     if constexpr (ND == 2) {
-      const v2u32 w = gload_u<v2u32>(p);
+      const v2u32 w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)lane_off, (int)row_off, 0);
       q[0] = w.x; q[1] = w.y;
     } else if constexpr (ND == 3) {
       typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
-      const v3u32 w = gload_u<v3u32>(p);
+      const v3u32 w = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)lane_off, (int)row_off, 0);
       q[0] = w.x; q[1] = w.y; q[2] = w.z;
     } else if constexpr (ND == 6) {
       typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
-      const v3u32 w0 = gload_u<v3u32>(p), w1 = gload_u<v3u32>(p + 12);
+      const v3u32 w0 = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)lane_off, (int)row_off, 0);
+      const v3u32 w1 = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)lane_off + 12, (int)row_off, 0);
       q[0] = w0.x; q[1] = w0.y; q[2] = w0.z; q[3] = w1.x; q[4] = w1.y; q[5] = w1.z;
     } else {
 #pragma unroll
       for (int c = 0; c < ND / 4; ++c) {
-        const v4u32 w = gload_u<v4u32>(p + 16 * c);
+        const v4u32 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off + 16 * c, (int)row_off, 0);
         q[4 * c] = w.x; q[4 * c + 1] = w.y; q[4 * c + 2] = w.z; q[4 * c + 3] = w.w;
       }
     }
@@ -243,7 +260,7 @@ __device__ __forceinline__ void cols_walk(const ColProg& r, const uint8_t* sp, i
   // (scheduling barriers: vmcnt retires in order, the rows must be ISSUED in order -- DESIGN.md 5d)
 #pragma unroll
   for (int j = 0; j < D; ++j) {
-    issue((u32)(clampi(r.s_begin + min(j, r.ns - 1), sh - 1) * spitch) + lane_off, pf[j]);
+    issue((u32)(clampi(r.s_begin + min(j, r.ns - 1), sh - 1) * spitch), pf[j]);
     __builtin_amdgcn_sched_barrier(0);
   }
   u32 vprog = r.lds;
@@ -251,7 +268,11 @@ __device__ __forceinline__ void cols_walk(const ColProg& r, const uint8_t* sp, i
   v4f32 e0 = *(lds_v4*)(uintptr_t)vprog, e1 = (v4f32){0.0f, 0.0f, 0.0f, 0.0f};
   if constexpr (ESZ == 8)
     e1 = *(lds_v4*)(uintptr_t)(vprog + 16u);
+  vprog += (u32)(ESZ * 4); // (entry t0 + 1: the entries the trip fetches sit at offsets >= 0 -- ds offsets are unsigned, and behind
+  asm volatile("" : "+v"(vprog)); // entry t0 the compiler subtracted a constant from the advanced pointer for every row)
   int emit_rr = 0; // the next dst row to complete
+  int slot = 0;    // BYSLOT: emit_rr mod P
+  v2f32 cc[NF];    // BYSLOT: the column results of the row that completes
 #pragma unroll 1
   for (int t0 = 0; t0 < r.ns; t0 += D) {
 #pragma unroll
@@ -265,15 +286,23 @@ __device__ __forceinline__ void cols_walk(const ColProg& r, const uint8_t* sp, i
       for (int i = 0; i < NF; ++i)
         asm volatile("" : "+v"(f[i])); // (pins the conversions in front of the barrier: they have no other order)
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ESZ == 8)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e0), "+v"(e1));
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e0));
       // (__float_as_uint of a vector element: __builtin_bit_cast applied to the element lvalue e1.w read element 0)
       const u32 ctl = __float_as_uint(ESZ == 4 ? e0.w : e1.z);
       const u32 actv = __float_as_uint(e1.w);
-      issue(__umul24(ctl, (u32)spitch) + lane_off, pf[d]);
+      const u32 flags = (u32)__builtin_amdgcn_readfirstlane((int)ctl);
+      issue((flags & 0xffffffu) * (u32)spitch, pf[d]);
       const v4f32 c0 = e0, c1 = e1;
       // the next row's entry: in flight under this row's arithmetic
-      e0 = *(lds_v4*)(uintptr_t)(vprog + (u32)((d + 1) * ESZ * 4));
+      // (assembly: the offset is an immediate of the instruction -- the compiler advanced a second pointer by v_add for every
+      // row instead; the wait for it is the lgkmcnt(0) in front of the next row's control word, also assembly: the compiler does
+      // not count these reads, which only ever makes its own waits longer -- LDS instructions return in order)
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(e0) : "v"(vprog), "i"(d * ESZ * 4));
       if constexpr (ESZ == 8)
-        e1 = *(lds_v4*)(uintptr_t)(vprog + (u32)((d + 1) * ESZ * 4 + 16));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(e1) : "v"(vprog), "i"(d * ESZ * 4 + 16));
       __builtin_amdgcn_sched_barrier(0);
       if (t >= r.ns) // the last trip only: rows past the end are loaded (the issue order stays countable), not used
         continue;
@@ -283,7 +312,6 @@ __device__ __forceinline__ void cols_walk(const ColProg& r, const uint8_t* sp, i
         acc[0][i] += f[i];
       continue;
 #endif
-      const u32 flags = (u32)__builtin_amdgcn_readfirstlane((int)ctl);
       const v2f32 w01 = (v2f32){c0.x, c0.y}, w23 = (v2f32){c0.z, c0.w}, w45 = (v2f32){c1.x, c1.y};
       u32 act = 0u;
       if constexpr (ACT)
@@ -307,6 +335,90 @@ __device__ __forceinline__ void cols_walk(const ColProg& r, const uint8_t* sp, i
 #if VALI_COLS_ABLATE == 2 // (... and the column arithmetic)
       continue;
 #endif
+      if constexpr (BYSLOT) {
+        if (flags & kProgDone) { // at most one dst row per source row (scale_y >= 1): the row of slot emit_rr mod P
+          // One scalar switch over the slot: the set out (a copy) and its restart IN PLACE: w f + 0 with the first weight of
+          // the slot's next row when this source row is also its first tap, with w = 0 otherwise (+0 for the finite values
+          // of integer planes; float planes restart with +0 itself).  ONE block of assembly, branches included: written in
+          // C++ -- with or without tied operands -- the compiler turns the switch into selects over all P sets or copies
+          // whole sets at its joins (r04: version G), 16-24 moves per dst row instead of 4.
+          v2f32 w2 = (v2f32){0.0f, 0.0f};
+          if (flags & kProgDbl)
+            w2.x = r.first_w[t];
+          auto fin_to = [&](v2f32 (&c)[NF]) {
+          if constexpr (NF == 4 && !ACT && (P == 2 || P == 3 || P == 4 || P == 6)) {
+            static_assert(P <= 6, "slots");
+#define VALI_FIN1(j)                                                                                                    \
+  "v_mov_b64 %[c0], %[a" #j "0]\n\tv_mov_b64 %[c1], %[a" #j "1]\n\tv_mov_b64 %[c2], %[a" #j "2]\n\tv_mov_b64 %[c3], %[a" #j "3]\n\t" \
+  "v_pk_fma_f32 %[a" #j "0], %[w], %[f0], 0 op_sel_hi:[0,1,0]\n\tv_pk_fma_f32 %[a" #j "1], %[w], %[f1], 0 op_sel_hi:[0,1,0]\n\t"   \
+  "v_pk_fma_f32 %[a" #j "2], %[w], %[f2], 0 op_sel_hi:[0,1,0]\n\tv_pk_fma_f32 %[a" #j "3], %[w], %[f3], 0 op_sel_hi:[0,1,0]\n\t"
+#define VALI_FIN_OUT(j) [a##j##0] "+v"(acc[j][0]), [a##j##1] "+v"(acc[j][1]), [a##j##2] "+v"(acc[j][2]), [a##j##3] "+v"(acc[j][3])
+#define VALI_FIN_IN [w] "v"(w2), [f0] "v"(f[0]), [f1] "v"(f[1]), [f2] "v"(f[2]), [f3] "v"(f[3]), [s] "s"(slot)
+#define VALI_FIN_C [c0] "=&v"(c[0]), [c1] "=&v"(c[1]), [c2] "=&v"(c[2]), [c3] "=&v"(c[3])
+            if constexpr (P == 2) {
+              asm volatile("s_cmp_eq_u32 %[s], 0\n\ts_cbranch_scc1 0f\n\t" VALI_FIN1(1) "s_branch 9f\n0:\n\t" VALI_FIN1(0) "9:"
+                           : VALI_FIN_C, VALI_FIN_OUT(0), VALI_FIN_OUT(1) : VALI_FIN_IN : "scc");
+            } else if constexpr (P == 3) {
+              asm volatile("s_cmp_eq_u32 %[s], 0\n\ts_cbranch_scc1 0f\n\ts_cmp_eq_u32 %[s], 1\n\ts_cbranch_scc1 1f\n\t" VALI_FIN1(2)
+                           "s_branch 9f\n1:\n\t" VALI_FIN1(1) "s_branch 9f\n0:\n\t" VALI_FIN1(0) "9:"
+                           : VALI_FIN_C, VALI_FIN_OUT(0), VALI_FIN_OUT(1), VALI_FIN_OUT(2) : VALI_FIN_IN : "scc");
+            } else if constexpr (P == 4) {
+              asm volatile("s_cmp_eq_u32 %[s], 0\n\ts_cbranch_scc1 0f\n\ts_cmp_eq_u32 %[s], 1\n\ts_cbranch_scc1 1f\n\t"
+                           "s_cmp_eq_u32 %[s], 2\n\ts_cbranch_scc1 2f\n\t" VALI_FIN1(3) "s_branch 9f\n2:\n\t" VALI_FIN1(2)
+                           "s_branch 9f\n1:\n\t" VALI_FIN1(1) "s_branch 9f\n0:\n\t" VALI_FIN1(0) "9:"
+                           : VALI_FIN_C, VALI_FIN_OUT(0), VALI_FIN_OUT(1), VALI_FIN_OUT(2), VALI_FIN_OUT(3) : VALI_FIN_IN : "scc");
+            } else {
+              // (30 operands at most: the six sets in two blocks of three)
+              if (slot < 3) {
+                asm volatile("s_cmp_eq_u32 %[s], 0\n\ts_cbranch_scc1 0f\n\ts_cmp_eq_u32 %[s], 1\n\ts_cbranch_scc1 1f\n\t" VALI_FIN1(2)
+                             "s_branch 9f\n1:\n\t" VALI_FIN1(1) "s_branch 9f\n0:\n\t" VALI_FIN1(0) "9:"
+                             : VALI_FIN_C, VALI_FIN_OUT(0), VALI_FIN_OUT(1), VALI_FIN_OUT(2) : VALI_FIN_IN : "scc");
+              } else {
+                asm volatile("s_cmp_eq_u32 %[s], 3\n\ts_cbranch_scc1 0f\n\ts_cmp_eq_u32 %[s], 4\n\ts_cbranch_scc1 1f\n\t" VALI_FIN1(2)
+                             "s_branch 9f\n1:\n\t" VALI_FIN1(1) "s_branch 9f\n0:\n\t" VALI_FIN1(0) "9:"
+                             : VALI_FIN_C, [a00] "+v"(acc[P > 3 ? 3 : 0][0]), [a01] "+v"(acc[P > 3 ? 3 : 0][1]), [a02] "+v"(acc[P > 3 ? 3 : 0][2]),
+                               [a03] "+v"(acc[P > 3 ? 3 : 0][3]), [a10] "+v"(acc[P > 4 ? 4 : 0][0]), [a11] "+v"(acc[P > 4 ? 4 : 0][1]),
+                               [a12] "+v"(acc[P > 4 ? 4 : 0][2]), [a13] "+v"(acc[P > 4 ? 4 : 0][3]), [a20] "+v"(acc[P - 1][0]),
+                               [a21] "+v"(acc[P - 1][1]), [a22] "+v"(acc[P - 1][2]), [a23] "+v"(acc[P - 1][3])
+                             : VALI_FIN_IN : "scc");
+              }
+            }
+#undef VALI_FIN1
+#undef VALI_FIN_OUT
+#undef VALI_FIN_IN
+#undef VALI_FIN_C
+          } else {
+            auto fin = [&](v2f32 (&a)[NF]) {
+#pragma unroll
+              for (int i = 0; i < NF; ++i)
+                c[i] = a[i];
+              if (flags & kProgDbl) {
+#pragma unroll
+                for (int i = 0; i < NF; ++i)
+                  a[i] = __builtin_elementwise_fma((v2f32){w2.x, w2.x}, f[i], (v2f32){0.0f, 0.0f});
+              } else {
+#pragma unroll
+                for (int i = 0; i < NF; ++i)
+                  a[i] = (v2f32){0.0f, 0.0f};
+              }
+            };
+            if (slot == 0) fin(acc[0]);
+            else if (P > 1 && slot == 1) fin(acc[P > 1 ? 1 : 0]);
+            else if (P > 2 && slot == 2) fin(acc[P > 2 ? 2 : 0]);
+            else if (P > 3 && slot == 3) fin(acc[P > 3 ? 3 : 0]);
+            else if (P > 4 && slot == 4) fin(acc[P > 4 ? 4 : 0]);
+            else fin(acc[P - 1]);
+          }
+          };
+          // (ONE instance of the block: a second one in the other arm of a branch -- the pair's first row straight to its
+          // own registers -- brings the copies at the joins back, and spills)
+          fin_to(cc);
+          take(flags, cc);
+          slot = slot + 1 == P ? 0 : slot + 1;
+        }
+        continue;
+      }
+      if constexpr (!BYSLOT) {
       if (flags & kProgDone) { // at most one dst row per source row (scale_y >= 1): the row of age 0
         take((flags & kProgPair) != 0u, emit_rr, acc[0]);
 #pragma unroll
@@ -325,6 +437,7 @@ __device__ __forceinline__ void cols_walk(const ColProg& r, const uint8_t* sp, i
             acc[P - 1][i] = (v2f32){0.0f, 0.0f};
         }
         ++emit_rr;
+      }
       }
     }
     vprog += (u32)(D * ESZ * 4);
@@ -647,6 +760,9 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
 //   consumer   [B]      R(0) [B]      R(1) ...  [B]            R(n-1)
 // at the barrier in front of W(k) the consumer has finished R(k - 2) (the strip W(k) overwrites) and the producer's W(k - 1)
 // has landed (s_waitcnt lgkmcnt(0): by then long done -- the wait sits a whole pair behind the writes it waits for).
+#ifndef VALI_WS_ABL
+#define VALI_WS_ABL 0
+#endif
 constexpr int kWsBlock = 2 * kWave;
 constexpr int kWsStripBytes = kColStrip * 8;                  // one strip: kColStrip slots of two floats
 constexpr int kWsObuf = 2 * 2 * kColStrip;                    // floats: behind the two strips, the transposition (256 x 2)
@@ -718,6 +834,79 @@ __device__ __forceinline__ void ws_row_taps(v2f32& ra, v2f32& rb, u32 a0, u32 a1
   rb = u0;
 }
 
+// The producer of cols_tile_ws: the walk, and what it does with a completed dst row -- the first row of a pair waits in
+// `hold`, the second goes to the strip with it (one slot = one column of both rows).  A function of its own, RAGGED a
+// template parameter: everything the walk tests per dst row is a bit of the row's control word or a compile-time choice --
+// an instruction of ANY kind costs an issue slot of the SIMD, and the scalar tests of round 4's take() were as many as its
+// vector work.  (As a generic lambda inside cols_tile_ws, `hold` stayed in scratch memory and the last strip write became
+// a flat_store through a pointer select between scratch and LDS.)
+template <typename T, int ES, int TAPS, int P, int D, bool RAGGED>
+__device__ __forceinline__ void ws_produce(const ColProg& r, const uint8_t* sp, int spitch, int sh, u32 lane_off,
+                                           const int (&wpos)[ES == 3 ? kColEl : 2], v2f32* strip) {
+  constexpr int ND = 2 * (int)sizeof(T);
+  constexpr int SEG = 2 * kColHalf<ES>;
+  v2f32 hold[4];                                              // the pair's first row
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    hold[i] = (v2f32){0.0f, 0.0f};
+  u32 woff = 0u;                                              // slots: 0 / kColStrip
+  auto take = [&](u32 flags, v2f32 (&c)[4]) {
+    // (a wave's last row may be the FIRST of a pair: it goes out as the second row of a pair whose first is whatever
+    // `hold` still holds -- finite values; the consumer stores the second row only)
+    if (!(flags & kProgPair)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        hold[i] = c[i];
+      // (this arm must not END with a store: the compiler then merges it with the last strip write of the other arm into one
+      // flat_store through a select between a scratch address and an LDS address, and `hold` lives in scratch)
+      asm volatile("");
+      return;
+    }
+    v2f32 lo[4], hi[4]; // (row a, row b) of this lane's columns 2 i / 2 i + 1 (ES = 2: U / V of pixel i)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      lo[i] = pk_mov<0, 0>(hold[i], c[i]);
+      hi[i] = pk_mov<1, 1>(hold[i], c[i]);
+    }
+    ws_barrier();
+    v2f32* const st = strip + woff;
+    woff ^= (u32)kColStrip;
+#if VALI_WS_ABL == 4
+    if (lo[0].x == 1.2345e-30f) st[wpos[0]] = lo[0] + hi[1] + lo[2] + hi[3] + hi[0] + lo[1] + hi[2] + lo[3];
+    return;
+#endif
+    if constexpr (ES == 3) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        st[wpos[2 * i]] = lo[i];
+        st[wpos[2 * i + 1]] = hi[i];
+      }
+    } else if constexpr (RAGGED) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (ES == 2) {
+          st[wpos[i & 1] + (i >> 1)] = lo[i];
+          st[SEG + wpos[i & 1] + (i >> 1)] = hi[i];
+        } else {
+          st[wpos[0] + i] = lo[i];
+          st[wpos[1] + i] = hi[i];
+        }
+      }
+    } else if constexpr (ES == 2) {
+      *reinterpret_cast<float4*>(st + wpos[0]) = make_float4(lo[0].x, lo[0].y, lo[2].x, lo[2].y);
+      *reinterpret_cast<float4*>(st + wpos[1]) = make_float4(lo[1].x, lo[1].y, lo[3].x, lo[3].y);
+      *reinterpret_cast<float4*>(st + SEG + wpos[0]) = make_float4(hi[0].x, hi[0].y, hi[2].x, hi[2].y);
+      *reinterpret_cast<float4*>(st + SEG + wpos[1]) = make_float4(hi[1].x, hi[1].y, hi[3].x, hi[3].y);
+    } else {
+      *reinterpret_cast<float4*>(st + wpos[0]) = make_float4(lo[0].x, lo[0].y, lo[1].x, lo[1].y);
+      *reinterpret_cast<float4*>(st + wpos[0] + 2) = make_float4(lo[2].x, lo[2].y, lo[3].x, lo[3].y);
+      *reinterpret_cast<float4*>(st + wpos[1]) = make_float4(hi[0].x, hi[0].y, hi[1].x, hi[1].y);
+      *reinterpret_cast<float4*>(st + wpos[1] + 2) = make_float4(hi[2].x, hi[2].y, hi[3].x, hi[3].y);
+    }
+  };
+  cols_walk<T, TAPS, P, ND, D, 4, true>(r, sp, spitch, sh, lane_off, [](const u32 (&d)[ND], v2f32 (&f)[4]) { conv8<T>(d, f); }, take);
+}
+
 template <typename T, int ES, int TAPS, int P>
 __device__ __forceinline__ void cols_tile_ws(const uint8_t* sp, int spitch, int sw, int sh, uint8_t* dp, int dpitch,
                                              int dw, int dh, u32 tx, u32 ty, int N, int rps, float* lds) {
@@ -748,7 +937,7 @@ __device__ __forceinline__ void cols_tile_ws(const uint8_t* sp, int spitch, int 
 
   if (role == 0) {
     ColProg r;
-    cols_rows<TAPS, P, EB == 4, D>(sh, dh, ty, rps, lds + kWsProg, r);
+    cols_rows<TAPS, P, EB == 4, D, true>(sh, dh, ty, rps, lds + kWsProg, r);
     const int nl = min((((sx1 + 1) * ES - j_begin) + kColEl - 1) / kColEl, kWave); // lanes with data
     const bool ragged = j_begin + kColEl * nl > row_el;           // wave-uniform: only a row's last tile
     const int j0 = min(j_begin + kColEl * min(lane, nl - 1), row_el - kColEl);
@@ -764,62 +953,10 @@ __device__ __forceinline__ void cols_tile_ws(const uint8_t* sp, int spitch, int 
       wpos[0] = col_slot<ES>(q0);
       wpos[1] = col_slot<ES>(q0 + 1);
     }
-    v2f32 hold[4];
-    u32 woff = 0u;                                                // slots: 0 / kColStrip
-    auto take = [&](bool pair, int rr, v2f32 (&c)[4]) {
-      if (!pair) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          hold[i] = c[i];
-        return;
-      }
-      v2f32 lo[4], hi[4];
-      if ((rr & 1) == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          lo[i] = pk_dup<0>(c[i]);
-          hi[i] = pk_dup<1>(c[i]);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          lo[i] = pk_mov<0, 0>(hold[i], c[i]);
-          hi[i] = pk_mov<1, 1>(hold[i], c[i]);
-        }
-      }
-      ws_barrier();
-      v2f32* const st = strip + woff;
-      woff ^= (u32)kColStrip;
-      if constexpr (ES == 3) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          st[wpos[2 * i]] = lo[i];
-          st[wpos[2 * i + 1]] = hi[i];
-        }
-      } else if (ragged) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if constexpr (ES == 2) {
-            st[wpos[i & 1] + (i >> 1)] = lo[i];
-            st[SEG + wpos[i & 1] + (i >> 1)] = hi[i];
-          } else {
-            st[wpos[0] + i] = lo[i];
-            st[wpos[1] + i] = hi[i];
-          }
-        }
-      } else if constexpr (ES == 2) {
-        *reinterpret_cast<float4*>(st + wpos[0]) = make_float4(lo[0].x, lo[0].y, lo[2].x, lo[2].y);
-        *reinterpret_cast<float4*>(st + wpos[1]) = make_float4(lo[1].x, lo[1].y, lo[3].x, lo[3].y);
-        *reinterpret_cast<float4*>(st + SEG + wpos[0]) = make_float4(hi[0].x, hi[0].y, hi[2].x, hi[2].y);
-        *reinterpret_cast<float4*>(st + SEG + wpos[1]) = make_float4(hi[1].x, hi[1].y, hi[3].x, hi[3].y);
-      } else {
-        *reinterpret_cast<float4*>(st + wpos[0]) = make_float4(lo[0].x, lo[0].y, lo[1].x, lo[1].y);
-        *reinterpret_cast<float4*>(st + wpos[0] + 2) = make_float4(lo[2].x, lo[2].y, lo[3].x, lo[3].y);
-        *reinterpret_cast<float4*>(st + wpos[1]) = make_float4(hi[0].x, hi[0].y, hi[1].x, hi[1].y);
-        *reinterpret_cast<float4*>(st + wpos[1] + 2) = make_float4(hi[2].x, hi[2].y, hi[3].x, hi[3].y);
-      }
-    };
-    cols_walk<T, TAPS, P, ND, D>(r, sp, spitch, sh, (u32)(j0 * EB), [](const u32 (&d)[ND], v2f32 (&f)[4]) { conv8<T>(d, f); }, take);
+    if (ES != 3 && ragged)
+      ws_produce<T, ES, TAPS, P, D, true>(r, sp, spitch, sh, (u32)(j0 * EB), wpos, strip);
+    else
+      ws_produce<T, ES, TAPS, P, D, false>(r, sp, spitch, sh, (u32)(j0 * EB), wpos, strip);
     ws_barrier(); // the last pair has landed
     return;
   }
@@ -845,57 +982,97 @@ __device__ __forceinline__ void cols_tile_ws(const uint8_t* sp, int spitch, int 
   const int edge = kColPadL + (sw - 1) - px_begin;                         // the last pixel of the row
   const int eb = e0 + 4 * lane;                                            // store: 4 adjacent elements
   const int n_out = min(4, e_last + 1 - eb);
-  const bool plain_store = EB == 1 && ((e_last + 1 - e0) & 3) == 0 && ((((uintptr_t)dp) | (uintptr_t)dpitch) & 3u) == 0; // wave-uniform
-  auto store_row = [&](int rr, float v0, float v1, float v2, float v3) {
-    uint8_t* const out = dp + (u32)((y_first + rr) * dpitch) + (size_t)eb * EB;
-    if (plain_store) {
-      u32 q = __builtin_amdgcn_cvt_pk_u8_f32(v0, 0u, 0u);
-      q = __builtin_amdgcn_cvt_pk_u8_f32(v1, 1u, q);
-      q = __builtin_amdgcn_cvt_pk_u8_f32(v2, 2u, q);
-      q = __builtin_amdgcn_cvt_pk_u8_f32(v3, 3u, q);
-      gstore_nt<u32>(out, q);
-    } else {
-      const float res[4][1] = {{v0}, {v1}, {v2}, {v3}};
-      store_px4<T, 1>(out, res, (1u << n_out) - 1u);
-    }
-  };
-  auto pass = [&](auto buf_tag, int n) {
-    constexpr int B = decltype(buf_tag)::value;
-    ws_barrier();
-    v2f32* const st = strip + B * kColStrip;
-    if (pad_left || pad_right) { // image edges: replicas of the first / last pixel of every channel segment
-      const int ch = lane >> 3, i = lane & 7;
-      if (pad_left && ch < ES && i < kColPadL)
-        st[ch * SEG + col_slot<ES>(kColPadL - 1 - i)] = st[ch * SEG + col_slot<ES>(kColPadL)];
-      if (pad_right && ch < ES && i < kColPadR)
-        st[ch * SEG + col_slot<ES>(edge + 1 + i)] = st[ch * SEG + col_slot<ES>(edge)];
-      wave_lds_sync();
-    }
+  // whole groups of 4 elements from every lane that stores, on rows aligned to a group: one store per lane and row, no
+  // per-lane alignment test, and the row's offset a SCALAR operand of a buffer store (as in cols_walk)
+  const bool plain_store = ((e_last + 1 - e0) & 3) == 0 && ((((uintptr_t)dp) | (uintptr_t)dpitch) & (4u * EB - 1u)) == 0; // wave-uniform
+  const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(dp, (short)0, (int)0xffffffffu, 0x00020000);
+  const int nfull = (last_rr + 1) >> 1;                                    // pairs of two rows
+  const bool single_last = (last_rr & 1) == 0;                             // ... and one more of ONE row (its second)
+  auto pairs = [&](auto plain_tag, auto pad_tag) {
+    constexpr bool PLAIN = decltype(plain_tag)::value, PADS = decltype(pad_tag)::value;
+    // soff: byte offset of the row in the plane (scalar)
+    auto store_row = [&](int soff, float v0, float v1, float v2, float v3) {
+      if constexpr (PLAIN) {
+        if constexpr (EB == 1) {
+          u32 q = __builtin_amdgcn_cvt_pk_u8_f32(v0, 0u, 0u);
+          q = __builtin_amdgcn_cvt_pk_u8_f32(v1, 1u, q);
+          q = __builtin_amdgcn_cvt_pk_u8_f32(v2, 2u, q);
+          q = __builtin_amdgcn_cvt_pk_u8_f32(v3, 3u, q);
+          __builtin_amdgcn_raw_buffer_store_b32(q, drsrc, eb, soff, 2); // (2: nt -- finished output, whole lines)
+        } else if constexpr (EB == 2) {
+          const v2u32 q = {finish_bits<T>(v0) | (finish_bits<T>(v1) << 16), finish_bits<T>(v2) | (finish_bits<T>(v3) << 16)};
+          __builtin_amdgcn_raw_buffer_store_b64(q, drsrc, eb * 2, soff, 2);
+        } else {
+          const v4u32 q = {__float_as_uint(v0), __float_as_uint(v1), __float_as_uint(v2), __float_as_uint(v3)};
+          __builtin_amdgcn_raw_buffer_store_b128(q, drsrc, eb * 4, soff, 2);
+        }
+      } else {
+        uint8_t* const out = dp + (u32)soff + (size_t)eb * EB;
+        const float res[4][1] = {{v0}, {v1}, {v2}, {v3}};
+        store_px4<T, 1>(out, res, (1u << n_out) - 1u);
+      }
+    };
+    // one pair from strip B; ONLYB: the pair is one row -- its second (the first is not a row of the image)
+    auto pass = [&](auto buf_tag, auto onlyb_tag, int soff) {
+      constexpr int B = decltype(buf_tag)::value;
+      constexpr bool ONLYB = decltype(onlyb_tag)::value;
+      ws_barrier();
+#if VALI_WS_ABL == 3
+      return;
+#endif
+      if constexpr (PADS) { // image edges: replicas of the first / last pixel of every channel segment
+        v2f32* const st = strip + B * kColStrip;
+        const int ch = lane >> 3, i = lane & 7;
+        if (pad_left && ch < ES && i < kColPadL)
+          st[ch * SEG + col_slot<ES>(kColPadL - 1 - i)] = st[ch * SEG + col_slot<ES>(kColPadL)];
+        if (pad_right && ch < ES && i < kColPadR)
+          st[ch * SEG + col_slot<ES>(edge + 1 + i)] = st[ch * SEG + col_slot<ES>(edge)];
+        wave_lds_sync();
+      }
 #pragma unroll
-    for (int half = 0; half < 4; half += 2) {
-      v2f32 ra, rb;
-      ws_row_taps<TAPS, B * kWsStripBytes>(ra, rb, ha[half][0], ha[half][1], ha[half + 1][0], ha[half + 1][1], wq[half], wq[half + 1]);
-      obuf[half * kWave + lane] = ra;
-      obuf[(half + 1) * kWave + lane] = rb;
-    }
-    wave_lds_sync();
-    const int rr = min(2 * n + 1, last_rr);
-    if (n_out > 0) {
-      float4 v0, v1; // (a0, b0, a1, b1), (a2, b2, a3, b3)
-      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
-                   : "=&v"(v0), "=&v"(v1) : "v"(obuf_rd) : "memory");
-      store_row(rr - (rr & 1), v0.x, v0.z, v1.x, v1.z); // (a last row on its own: twice)
-      store_row(rr, v0.y, v0.w, v1.y, v1.w);
-    }
-    wave_lds_sync();
-  };
-  const int npairs = (last_rr + 2) >> 1;
-  ws_barrier(); // (the one in front of the producer's first write)
+      for (int half = 0; half < 4; half += 2) {
+        v2f32 ra, rb;
+        ws_row_taps<TAPS, B * kWsStripBytes>(ra, rb, ha[half][0], ha[half][1], ha[half + 1][0], ha[half + 1][1], wq[half], wq[half + 1]);
+        obuf[half * kWave + lane] = ra;
+        obuf[(half + 1) * kWave + lane] = rb;
+      }
+      wave_lds_sync();
+      if (n_out > 0) {
+        float4 v0, v1; // (a0, b0, a1, b1), (a2, b2, a3, b3)
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(v0), "=&v"(v1) : "v"(obuf_rd) : "memory");
+        if constexpr (!ONLYB) {
+          store_row(soff, v0.x, v0.z, v1.x, v1.z);
+          store_row(soff + dpitch, v0.y, v0.w, v1.y, v1.w);
+        } else {
+          store_row(soff, v0.y, v0.w, v1.y, v1.w);
+        }
+      }
+      wave_lds_sync();
+    };
+    ws_barrier(); // (the one in front of the producer's first write)
+    int soff = y_first * dpitch;
 #pragma unroll 1
-  for (int n = 0; n < npairs; n += 2) {
-    pass(std::integral_constant<int, 0>{}, n);
-    if (n + 1 < npairs)
-      pass(std::integral_constant<int, 1>{}, n + 1);
+    for (int n = 0; n < nfull; n += 2) {
+      pass(std::integral_constant<int, 0>{}, std::false_type{}, soff);
+      soff += 2 * dpitch;
+      if (n + 1 < nfull) {
+        pass(std::integral_constant<int, 1>{}, std::false_type{}, soff);
+        soff += 2 * dpitch;
+      }
+    }
+    if (single_last) {
+      if (nfull & 1) pass(std::integral_constant<int, 1>{}, std::true_type{}, soff);
+      else pass(std::integral_constant<int, 0>{}, std::true_type{}, soff);
+    }
+  };
+  // (four copies of the loop: which stores and whether there are edges to pad is decided once per tile, not once per pair)
+  if (pad_left || pad_right) {
+    if (plain_store) pairs(std::true_type{}, std::true_type{});
+    else pairs(std::false_type{}, std::true_type{});
+  } else {
+    if (plain_store) pairs(std::true_type{}, std::false_type{});
+    else pairs(std::false_type{}, std::false_type{});
   }
 }
 
@@ -1184,7 +1361,10 @@ __global__ void __launch_bounds__(kBlock) k_resize_cols(const ResizeArgs a) {
 }
 
 // waves per SIMD the register allocation aims at: the producer's accumulators are 8 P registers
-template <int EB, int P> constexpr int kWsWaves = EB == 4 ? (P <= 3 ? 4 : 3) : P <= 3 ? (EB == 2 ? 5 : 6) : P <= 4 ? 5 : 4;
+#ifndef VALI_WS_W3
+#define VALI_WS_W3 6
+#endif
+template <int EB, int P> constexpr int kWsWaves = EB == 4 ? (P <= 3 ? 4 : 3) : P <= 3 ? (EB == 2 ? 5 : VALI_WS_W3) : P <= 4 ? 5 : 4;
 template <typename T, int ESSET, int TAPS, int P>
 __global__ void __launch_bounds__(kWsBlock, (kWsWaves<(int)sizeof(T), P>)) k_resize_cols_ws(const ResizeArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[kWsLds];
