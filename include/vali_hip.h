@@ -401,8 +401,9 @@ enum vali_tuning_key {
                                          form; 2: the same without the 3:2 form; 3: without the register form of round 4 (8-bit planes
                                          that grow along x too: row pass from registers, no LDS stage); 0: round 2's LDS-ring kernel  */
   VALI_TUNE_RESIZE_COLS = 14,         /* Lanczos / bicubic of planes that shrink, general ratios: 0 (default) a workgroup = one wave that
-                                         walks the source rows + one that runs the pass along the rows (round 5); 1: both passes in
-                                         every wave (round 4's form)                                                  */
+                                         walks the source rows + one that runs the pass along the rows (round 5), taps from per-geometry
+                                         tables (tap_table.hip); 2: the same, taps computed in the kernel; 1: both passes in every wave
+                                         (round 4's form)                                                             */
   VALI_TUNE_COUNT = 15
 };
 VALI_API int vali_tuning_set(int key, int value);

@@ -578,3 +578,49 @@ def test_growing_planes_borrowed_surfaces_with_tight_pitch(vali, gpu, oracle, ge
         assert np.array_equal(got, want), extra
         pad = np.lib.stride_tricks.as_strided(out[skew + dw:], (dh - 1, dpad - dw), (dpad, 1))
         assert np.all(pad == 0x5a) and np.all(out[:skew] == 0x5a)
+
+
+def test_tap_tables_across_streams_and_inside_a_capture(vali, gpu, oracle):
+    """The columns-first kernels of general ratios read their taps from per-geometry tables written by the first call
+    (vali_amd/csrc/tap_table.hip).  A geometry nobody has used yet: (a) its first call on one stream and, right behind
+    it, a call on ANOTHER stream (which has to wait for the writer) both give the oracle's bits; (b) recorded into a
+    graph before any table exists for it, the kernels compute their taps themselves -- nothing is allocated or
+    launched for a table during a capture -- and every replay gives the oracle's bits."""
+    from conftest import make_nv12
+
+    shim = vali._native.shim
+    sw, sh = 1280, 720
+    nv = make_nv12(sw, sh, 11)
+    s1, s2 = shim.stream_create(gpu), shim.stream_create(gpu)
+    src = vali.Surface.Make(vali.NV12, sw, sh, gpu)
+    assert vali.PyFrameUploader(gpu).Run(nv.reshape(-1), src)[0]
+
+    def check(dst, dw, dh):
+        out = np.zeros(dst.HostSize, np.uint8)
+        assert vali.PySurfaceDownloader(gpu).Run(dst, out)[0]
+        assert np.array_equal(out, oracle.resize_surface(nv.reshape(-1), "NV12", sw, sh, dw, dh, "lanczos"))
+
+    # (a) two streams, a geometry of its own (sizes no other test uses)
+    dw, dh = 846, 474
+    r1 = vali.PySurfaceResizer(vali.NV12, gpu, s1, interpolation=vali.Interpolation.LANCZOS)
+    r2 = vali.PySurfaceResizer(vali.NV12, gpu, s2, interpolation=vali.Interpolation.LANCZOS)
+    d1, d2 = vali.Surface.Make(vali.NV12, dw, dh, gpu), vali.Surface.Make(vali.NV12, dw, dh, gpu)
+    assert r1.RunAsync(src, d1)[0] and r2.RunAsync(src, d2)[0]
+    shim.stream_sync(gpu, s1)
+    shim.stream_sync(gpu, s2)
+    check(d1, dw, dh)
+    check(d2, dw, dh)
+    # (b) captured before its tables exist (the kernel itself was loaded by (a): same format, same slots)
+    dw, dh = 842, 470
+    d3 = vali.Surface.Make(vali.NV12, dw, dh, gpu)
+    cap = vali.StreamCapture(s1, gpu).Keep(src, d3)
+    with cap:
+        assert r1.RunAsync(src, d3)[0]
+    for _ in range(2):
+        shim.memset2d_async(gpu, d3._planes[0].GpuMem, d3._planes[0].Pitch, 0, dw, dh * 3 // 2, s1)
+        cap.Launch()
+        shim.stream_sync(gpu, s1)
+        check(d3, dw, dh)
+    # ... and afterwards eagerly, now through a table
+    assert r1.Run(src, d3)[0]
+    check(d3, dw, dh)

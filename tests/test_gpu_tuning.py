@@ -79,6 +79,10 @@ CASES = [
     ("RESIZE_NO_SEPARABLE", (11, 13, 22), lambda v, g: resize(v, g, 960, 540, 640, 360, v.Interpolation.LANCZOS)),  # 3:2 both ways: 1 / 3 / 12 row pairs per wave
     ("RESIZE_NO_SEPARABLE", (12, 31), lambda v, g: resize(v, g, 1280, 720, 644, 364, v.Interpolation.LANCZOS)),   # general form: 2 / 21 rows per slot
     ("RESIZE_NO_SEPARABLE", (11, 16), lambda v, g: resize(v, g, 1280, 720, 640, 364, v.Interpolation.LANCZOS)),   # 2:1 along x: 1 / 6 rows per slot
+    # general-ratio shrinking planes: 1 both passes in every wave (round 4's form), 2 specialised waves without tap tables
+    ("RESIZE_COLS", (1, 2), lambda v, g: resize(v, g, 1280, 720, 644, 364, v.Interpolation.LANCZOS)),
+    ("RESIZE_COLS", (1, 2), lambda v, g: resize(v, g, 1280, 720, 854, 480, v.Interpolation.CUBIC)),      # 3 slots of 4 taps
+    ("RESIZE_COLS", (1, 2), lambda v, g: resize(v, g, 960, 540, 800, 450, v.Interpolation.LANCZOS)),     # 6 slots
     ("RESIZE_ROWS", (0, 2, 3), lambda v, g: resize(v, g, 640, 360, 960, 540, v.Interpolation.LANCZOS)),
     ("RESIZE_ROWS", (0, 3), lambda v, g: resize(v, g, 640, 360, 800, 450, v.Interpolation.LANCZOS)),   # 3: the LDS-staged rows form instead of the register form
     ("RESIZE_ROWS", (0,), lambda v, g: resize(v, g, 640, 360, 1000, 700, v.Interpolation.CUBIC)),

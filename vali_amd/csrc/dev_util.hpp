@@ -353,6 +353,8 @@ struct PlaneJob {
   const uint8_t* sp;  // single-frame launches: resolved by the host
   uint8_t* dp;
   int spitch, dpitch;
+  const float4* xtab; // Lanczos / bicubic resize: tap tables of the plane's axes (tap_table.hip), or null
+  const float4* ytab;
 };
 
 struct PlaneView {

@@ -109,10 +109,25 @@ struct ColProg {
 // BYSLOT: column j of an entry is the weight of SLOT j (dst row rr lives in slot rr mod P) instead of the row of age j: the
 // accumulators then never move -- the walk picks the completing set by a scalar switch (cols_walk) -- at the price of P
 // copies of take(); the specialised producer, whose take() is a strip write, pays that gladly.
-template <int TAPS, int P, bool ACT, int D, bool BYSLOT = false>
-__device__ __forceinline__ bool cols_rows(int sh, int dh, u32 row_tile, int rps, float* prog, ColProg& r) {
+// ytab: the tap table of the plane's rows (tap_table.hip) or null
+template <int TAPS> __device__ __forceinline__ LzTap<TAPS> lz_tap_of(const float4* tab, int x, float scale) {
+  if (tab) { // (wave-uniform)
+    const float4 a = tab[2 * x], b = tab[2 * x + 1];
+    LzTap<TAPS> t;
+    t.w[0] = a.x; t.w[1] = a.y; t.w[2] = a.z; t.w[3] = a.w;
+    if constexpr (TAPS == 6) {
+      t.w[4] = b.x; t.w[5] = b.y;
+    }
+    t.i = __float_as_int(b.z);
+    return t;
+  }
+  return make_lz_tap<TAPS>(x, scale);
+}
+
+template <int TAPS, int P, bool ACT, int D, bool BYSLOT = false, int NPROG = kProgRows<P, ACT>>
+__device__ __forceinline__ bool cols_rows(int sh, int dh, u32 row_tile, int rps, float* prog, ColProg& r, const float4* ytab = nullptr) {
   constexpr int kBefore = LzTap<TAPS>::kBefore;
-  constexpr int ESZ = kProgEsz<P, ACT>, NPROG = kProgRows<P, ACT>;
+  constexpr int ESZ = kProgEsz<P, ACT>;
   const int lane = threadIdx.x & 63;
   const int rows = P * rps;                                     // dst rows of this wave, <= 64
   r.y_first = (int)row_tile * rows;                             // wave-uniform
@@ -127,7 +142,7 @@ __device__ __forceinline__ bool cols_rows(int sh, int dh, u32 row_tile, int rps,
   // 25: the walk completes and emits the old row, then starts the new one from +0 with it.  So every (slot, source row)
   // has one writer at most.  A zero weight is an exact no-op on an accumulator that is never -0, for the finite values
   // integer planes have; float planes skip the slot instead (bits 26 ..).
-  const LzTap<TAPS> vy = make_lz_tap<TAPS>(r.y_first + min(lane, rows - 1), scale_y);
+  const LzTap<TAPS> vy = lz_tap_of<TAPS>(ytab, min(r.y_first + min(lane, rows - 1), dh - 1), scale_y);
   r.s_begin = __builtin_amdgcn_readlane(vy.i, 0) - kBefore;
   r.ns = __builtin_amdgcn_readlane(vy.i, r.last_rr) + TAPS - kBefore - r.s_begin;
   u32* const ent = reinterpret_cast<u32*>(prog);
@@ -763,11 +778,18 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
 #ifndef VALI_WS_ABL
 #define VALI_WS_ABL 0
 #endif
+#ifndef VALI_WS_PRIO
+#define VALI_WS_PRIO 0
+#endif
 constexpr int kWsBlock = 2 * kWave;
 constexpr int kWsStripBytes = kColStrip * 8;                  // one strip: kColStrip slots of two floats
 constexpr int kWsObuf = 2 * 2 * kColStrip;                    // floats: behind the two strips, the transposition (256 x 2)
 constexpr int kWsProg = kWsObuf + 512;                        // the producer's program
-constexpr int kWsLds = kWsProg + kColProg;                    // floats of a workgroup
+// ... of kWsProgRows entries whatever the entry size: the kernels of 4 and 6 slots (and of float planes) run five or four
+// waves per SIMD by their registers, so the LDS of their 8-dword entries is free -- 112 rows instead of 64: 45 dst rows per tile
+// at 3:2 instead of 32, half the source rows walked twice
+constexpr int kWsProgRows = 112;
+template <int P, bool ACT> constexpr int kWsLds = kWsProg + kWsProgRows * (kProgEsz<P, ACT> + 1); // floats of a workgroup
 
 __device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -776,6 +798,45 @@ template <int TAPS, int OFF>
 __device__ __forceinline__ void ws_row_taps(v2f32& ra, v2f32& rb, u32 a0, u32 a1, u32 b0, u32 b1, const v2f32 (&wa)[TAPS / 2],
                                             const v2f32 (&wb)[TAPS / 2]) {
   v2f32 t0, t1, t2, t3, t4, t5, u0, u1, u2, u3, u4, u5;
+#if VALI_WS_ABL == 6
+  t0=t1=t2=t3=t4=t5=u0=u1=u2=u3=u4=u5=(v2f32){1.0f,2.0f};
+  if constexpr (TAPS == 6) {
+    asm volatile(
+                "v_pk_fma_f32 %[t0], %[w0], %[t0], 0 op_sel_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %[t1], %[w0], %[t1], 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]\n\t"
+        "v_pk_fma_f32 %[t0], %[w1], %[t2], %[t0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %[t1], %[w1], %[t3], %[t1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %[t0], %[w2], %[t4], %[t0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %[t1], %[w2], %[t5], %[t1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                "v_pk_fma_f32 %[u0], %[x0], %[u0], 0 op_sel_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %[u1], %[x0], %[u1], 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]\n\t"
+        "v_pk_add_f32 %[t0], %[t0], %[t1]\n\t"
+        "v_pk_fma_f32 %[u0], %[x1], %[u2], %[u0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %[u1], %[x1], %[u3], %[u1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %[u0], %[x2], %[u4], %[u0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %[u1], %[x2], %[u5], %[u1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "s_nop 0\n\t"
+        "v_pk_add_f32 %[u0], %[u0], %[u1]"
+        : [t0] "+v"(t0), [t1] "+v"(t1), [t2] "+v"(t2), [t3] "+v"(t3), [t4] "+v"(t4), [t5] "+v"(t5), [u0] "+v"(u0),
+          [u1] "+v"(u1), [u2] "+v"(u2), [u3] "+v"(u3), [u4] "+v"(u4), [u5] "+v"(u5)
+        : [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1), [w0] "v"(wa[0]), [w1] "v"(wa[1]), [w2] "v"(wa[TAPS / 2 - 1]),
+          [x0] "v"(wb[0]), [x1] "v"(wb[1]), [x2] "v"(wb[TAPS / 2 - 1]), [o0] "i"(OFF), [o1] "i"(OFF + 8), [o2] "i"(OFF + 16)
+        : "memory");
+#elif VALI_WS_ABL == 7
+  if constexpr (TAPS == 6) {
+    asm volatile(
+        "ds_read_b64 %[t0], %[a0] offset:%[o0]\n\tds_read_b64 %[t1], %[a1] offset:%[o0]\n\tds_read_b64 %[t2], %[a0] offset:%[o1]\n\t"
+        "ds_read_b64 %[t3], %[a1] offset:%[o1]\n\tds_read_b64 %[t4], %[a0] offset:%[o2]\n\tds_read_b64 %[t5], %[a1] offset:%[o2]\n\t"
+        "ds_read_b64 %[u0], %[b0] offset:%[o0]\n\tds_read_b64 %[u1], %[b1] offset:%[o0]\n\tds_read_b64 %[u2], %[b0] offset:%[o1]\n\t"
+        "ds_read_b64 %[u3], %[b1] offset:%[o1]\n\tds_read_b64 %[u4], %[b0] offset:%[o2]\n\tds_read_b64 %[u5], %[b1] offset:%[o2]\n\t"
+        "s_waitcnt lgkmcnt(6)\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+                : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [u0] "=&v"(u0),
+          [u1] "=&v"(u1), [u2] "=&v"(u2), [u3] "=&v"(u3), [u4] "=&v"(u4), [u5] "=&v"(u5)
+        : [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1), [w0] "v"(wa[0]), [w1] "v"(wa[1]), [w2] "v"(wa[TAPS / 2 - 1]),
+          [x0] "v"(wb[0]), [x1] "v"(wb[1]), [x2] "v"(wb[TAPS / 2 - 1]), [o0] "i"(OFF), [o1] "i"(OFF + 8), [o2] "i"(OFF + 16)
+        : "memory");
+#else
   if constexpr (TAPS == 6) {
     asm volatile(
         "ds_read_b64 %[t0], %[a0] offset:%[o0]\n\tds_read_b64 %[t1], %[a1] offset:%[o0]\n\tds_read_b64 %[t2], %[a0] offset:%[o1]\n\t"
@@ -804,6 +865,7 @@ __device__ __forceinline__ void ws_row_taps(v2f32& ra, v2f32& rb, u32 a0, u32 a1
         : [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1), [w0] "v"(wa[0]), [w1] "v"(wa[1]), [w2] "v"(wa[TAPS / 2 - 1]),
           [x0] "v"(wb[0]), [x1] "v"(wb[1]), [x2] "v"(wb[TAPS / 2 - 1]), [o0] "i"(OFF), [o1] "i"(OFF + 8), [o2] "i"(OFF + 16)
         : "memory");
+#endif
   } else {
     asm volatile(
         "ds_read_b64 %[t0], %[a0] offset:%[o0]\n\tds_read_b64 %[t1], %[a1] offset:%[o0]\n\tds_read_b64 %[t2], %[a0] offset:%[o1]\n\t"
@@ -909,14 +971,23 @@ __device__ __forceinline__ void ws_produce(const ColProg& r, const uint8_t* sp, 
 
 template <typename T, int ES, int TAPS, int P>
 __device__ __forceinline__ void cols_tile_ws(const uint8_t* sp, int spitch, int sw, int sh, uint8_t* dp, int dpitch,
-                                             int dw, int dh, u32 tx, u32 ty, int N, int rps, float* lds) {
+                                             int dw, int dh, u32 tx, u32 ty, int N, int rps, float* lds, const float4* xtab,
+                                             const float4* ytab) {
   constexpr int kBefore = LzTap<TAPS>::kBefore;
   constexpr int EB = (int)sizeof(T);
   constexpr int ND = 2 * EB;
-  constexpr int D = EB == 4 ? 3 : EB == 2 ? 3 : 4;              // source rows in flight
+#ifndef VALI_WS_D
+#define VALI_WS_D 4
+#endif
+  constexpr int D = EB == 4 ? 3 : EB == 2 ? 3 : VALI_WS_D;      // source rows in flight
   constexpr int HALF = kColHalf<ES>, SEG = 2 * HALF;            // slots
   const int lane = threadIdx.x & 63;
   const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // 0: producer, 1: consumer
+#if VALI_WS_PRIO == 1
+  if (role == 1) __builtin_amdgcn_s_setprio(3);
+#elif VALI_WS_PRIO == 2
+  if (role == 0) __builtin_amdgcn_s_setprio(3);
+#endif
   v2f32* const strip = reinterpret_cast<v2f32*>(lds);
   const u32 lds_base = (u32)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
   const int dwe = dw * ES, row_el = sw * ES;
@@ -937,7 +1008,7 @@ __device__ __forceinline__ void cols_tile_ws(const uint8_t* sp, int spitch, int 
 
   if (role == 0) {
     ColProg r;
-    cols_rows<TAPS, P, EB == 4, D, true>(sh, dh, ty, rps, lds + kWsProg, r);
+    cols_rows<TAPS, P, EB == 4, D, true, kWsProgRows>(sh, dh, ty, rps, lds + kWsProg, r, ytab);
     const int nl = min((((sx1 + 1) * ES - j_begin) + kColEl - 1) / kColEl, kWave); // lanes with data
     const bool ragged = j_begin + kColEl * nl > row_el;           // wave-uniform: only a row's last tile
     const int j0 = min(j_begin + kColEl * min(lane, nl - 1), row_el - kColEl);
@@ -968,13 +1039,17 @@ __device__ __forceinline__ void cols_tile_ws(const uint8_t* sp, int spitch, int 
   for (int p = 0; p < 4; ++p) {
     const int e = min(e0 + p * kWave + lane, e_last);
     const int px = e / ES, ch = e - px * ES;
-    const LzTap<TAPS> c = make_lz_tap<TAPS>(px, scale_x);
+    const LzTap<TAPS> c = lz_tap_of<TAPS>(xtab, px, scale_x);
 #pragma unroll
     for (int k = 0; k < TAPS / 2; ++k)
       wq[p][k] = (v2f32){c.w[2 * k], c.w[2 * k + 1]};
     const int q = kColPadL + (min(c.i, sw - 1) - kBefore - px_begin); // >= kColPadL - kBefore
     ha[p][0] = lds_base + 8u * (u32)(ch * SEG + col_slot<ES>(q));
     ha[p][1] = lds_base + 8u * (u32)(ch * SEG + col_slot<ES>(q + 1));
+#if VALI_WS_ABL == 5
+    ha[p][0] = lds_base + 8u * (u32)lane + 512u * p;
+    ha[p][1] = lds_base + 8u * (u32)lane + 512u * p + 2048u;
+#endif
   }
   v2f32* const obuf = reinterpret_cast<v2f32*>(lds + kWsObuf);
   const u32 obuf_rd = lds_base + 4u * (u32)kWsObuf + 32u * (u32)lane;
@@ -1367,19 +1442,19 @@ __global__ void __launch_bounds__(kBlock) k_resize_cols(const ResizeArgs a) {
 template <int EB, int P> constexpr int kWsWaves = EB == 4 ? (P <= 3 ? 4 : 3) : P <= 3 ? (EB == 2 ? 5 : VALI_WS_W3) : P <= 4 ? 5 : 4;
 template <typename T, int ESSET, int TAPS, int P>
 __global__ void __launch_bounds__(kWsBlock, (kWsWaves<(int)sizeof(T), P>)) k_resize_cols_ws(const ResizeArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[kWsLds];
+  __shared__ __attribute__((aligned(16))) float lds[kWsLds<P, sizeof(T) == 4>];
   ResizeJob job;
   u32 tx, ty, frame;
   if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
     return;
   const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
   if constexpr (ESSET == 3) {
-    cols_tile_ws<T, 3, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_n, a.cols_rps, lds);
+    cols_tile_ws<T, 3, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_n, a.cols_rps, lds, job.xtab, job.ytab);
   } else {
     if (ESSET == 12 && job.channels == 2)
-      cols_tile_ws<T, 2, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_n, a.cols_rps, lds);
+      cols_tile_ws<T, 2, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_n, a.cols_rps, lds, job.xtab, job.ytab);
     else
-      cols_tile_ws<T, 1, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_n, a.cols_rps, lds);
+      cols_tile_ws<T, 1, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_n, a.cols_rps, lds, job.xtab, job.ytab);
   }
 }
 
@@ -1481,12 +1556,15 @@ static void launch_slots(const ResizeArgs& a, int slots, int xform, dim3 grid, h
     }
   }
   if (xform == 5) { // the general form on specialised waves: a workgroup = producer + consumer of ONE tile
+    const int cap = tuning(VALI_TUNE_WAVES_PER_CU); // (measurements: workgroups per CU = cap / 2, by unused dynamic LDS)
+    constexpr int kLds = kWsLds<P0, sizeof(T) == 4> * 4;
+    const unsigned dyn = cap >= 2 && 160 * 1024 / (cap / 2) > kLds ? (unsigned)(160 * 1024 / (cap / 2) - kLds) & ~15u : 0u;
     if (slots <= P0)
-      hipLaunchKernelGGL((k_resize_cols_ws<T, ESSET, TAPS, P0>), grid, dim3(kWsBlock), 0, stream, a);
+      hipLaunchKernelGGL((k_resize_cols_ws<T, ESSET, TAPS, P0>), grid, dim3(kWsBlock), dyn, stream, a);
     else if (slots <= P1)
-      hipLaunchKernelGGL((k_resize_cols_ws<T, ESSET, TAPS, P1>), grid, dim3(kWsBlock), 0, stream, a);
+      hipLaunchKernelGGL((k_resize_cols_ws<T, ESSET, TAPS, P1>), grid, dim3(kWsBlock), dyn, stream, a);
     else
-      hipLaunchKernelGGL((k_resize_cols_ws<T, ESSET, TAPS, P2>), grid, dim3(kWsBlock), 0, stream, a);
+      hipLaunchKernelGGL((k_resize_cols_ws<T, ESSET, TAPS, P2>), grid, dim3(kWsBlock), dyn, stream, a);
     return;
   }
   if (slots <= P0)
@@ -1562,7 +1640,16 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
   const int P = slots <= pmin ? pmin : slots <= pmid ? pmid : pmax;
   // rows per wave = P x rps <= 64 (a lane evaluates a row's taps) and few enough for the wave's program in LDS:
   // (rows - 1) scale_y + taps + 1 source rows, + the walk's rows in flight (<= 8), <= kProgRows<P>
-  const int prog_rows = (P <= 3 && elem != 4) ? kProgRows<3, false> : kProgRows<6, true>;
+  const bool ws = !x2 && !x32 && tuning(VALI_TUNE_RESIZE_COLS) != 1;           // the general form: specialised waves
+  if (ws && tuning(VALI_TUNE_RESIZE_COLS) != 2) {                             // ... with their taps from tables (2: computed in the kernel)
+    const int dev = stream_device(stream);
+    for (int k = 0; k < a.njobs; ++k) {
+      ResizeJob& j = a.job[k];
+      j.xtab = tap_table(dev, stream, src_w >> j.ssub_x, dst_w >> j.sub_x, taps);
+      j.ytab = tap_table(dev, stream, src_h >> j.ssub_y, dst_h >> j.sub_y, taps);
+    }
+  }
+  const int prog_rows = ws ? kWsProgRows : (P <= 3 && elem != 4) ? kProgRows<3, false> : kProgRows<6, true>;
   int rps_max = 64 / P;
   for (int k = 0; k < a.njobs; ++k) {
     const double sy = (double)(src_h >> a.job[k].ssub_y) / (double)(dst_h >> a.job[k].sub_y) * (1.0 + 1e-6);
@@ -1586,7 +1673,6 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
     else if (x32)
       tile_n = kX32Out;   // 62 lanes x 8 dst elements, lanes 0 and 63 supply the halos
   }
-  const bool ws = !x2 && !x32 && tuning(VALI_TUNE_RESIZE_COLS) != 1;           // the general form: specialised waves
   auto count = [&](int rps, bool assign) {
     u32 total = 0;
     const int rows = (ws ? 1 : kWavesPerBlock) * P * rps;

@@ -75,6 +75,11 @@ bool resize_x23_fits(const ResizeJob& j, int elem, int src_w, int src_h, int dst
 int launch_resize_x23(const ResizeArgs& a, int elem, int taps, int src_w, int src_h, int dst_w, int dst_h, int n,
                       hipStream_t stream);
 
+// Tap tables (tap_table.hip): entry x of the table of an axis src_n -> dst_n = {w0 w1 w2 w3} {w4 w5 i -} of dst sample x (bicubic:
+// {w0 w1 w2 w3} {- - i -}), written once per geometry and device by make_lz_tap itself; null: the caller computes its taps (stream
+// being captured, table memory exhausted).
+const float4* tap_table(int device, hipStream_t stream, int src_n, int dst_n, int taps);
+
 // The same filters for jobs whose planes all SHRINK (or keep) their height -- columns first (resize_cols.hip).  Which
 // plane takes which order is part of the specification (oracle/vali_oracle.c resize_plane_taps): src_h >= dst_h.
 int launch_resize_cols(const ResizeArgs& a, int elem, int taps, int src_w, int src_h, int dst_w, int dst_h, int n,
