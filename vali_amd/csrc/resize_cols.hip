@@ -229,6 +229,52 @@ template <int H> __device__ __forceinline__ void pk_fma_h(v2f32& acc, v2f32 w, v
 // flight), conv() turns them into the 2 NF floats it filters, every slot takes fma(w, f, acc) with the weight of its
 // program entry, and when a row completes a dst row take(pair, rr, c) gets that row's column results -- pair: the row
 // closes a pair of dst rows (program bit 26).
+// The completion block of the BYSLOT walks: set `slot` out (a copy to c) and restarted in place with w f + 0 -- one block of
+// assembly, scalar branches included (see cols_walk).  NF = 4, integer planes.
+template <int P>
+__device__ __forceinline__ void cols_fin(v2f32 (&acc)[P][4], v2f32 (&c)[4], v2f32 w2, const v2f32 (&f)[4], int slot) {
+  static_assert(P <= 6, "slots");
+#define VALI_FIN1(j)                                                                                                    \
+  "v_mov_b64 %[c0], %[a" #j "0]\n\tv_mov_b64 %[c1], %[a" #j "1]\n\tv_mov_b64 %[c2], %[a" #j "2]\n\tv_mov_b64 %[c3], %[a" #j "3]\n\t" \
+  "v_pk_fma_f32 %[a" #j "0], %[w], %[f0], 0 op_sel_hi:[0,1,0]\n\tv_pk_fma_f32 %[a" #j "1], %[w], %[f1], 0 op_sel_hi:[0,1,0]\n\t"   \
+  "v_pk_fma_f32 %[a" #j "2], %[w], %[f2], 0 op_sel_hi:[0,1,0]\n\tv_pk_fma_f32 %[a" #j "3], %[w], %[f3], 0 op_sel_hi:[0,1,0]\n\t"
+#define VALI_FIN_OUT(j) [a##j##0] "+v"(acc[j][0]), [a##j##1] "+v"(acc[j][1]), [a##j##2] "+v"(acc[j][2]), [a##j##3] "+v"(acc[j][3])
+#define VALI_FIN_IN [w] "v"(w2), [f0] "v"(f[0]), [f1] "v"(f[1]), [f2] "v"(f[2]), [f3] "v"(f[3]), [s] "s"(slot)
+#define VALI_FIN_C [c0] "=&v"(c[0]), [c1] "=&v"(c[1]), [c2] "=&v"(c[2]), [c3] "=&v"(c[3])
+  if constexpr (P == 2) {
+    asm volatile("s_cmp_eq_u32 %[s], 0\n\ts_cbranch_scc1 0f\n\t" VALI_FIN1(1) "s_branch 9f\n0:\n\t" VALI_FIN1(0) "9:"
+                 : VALI_FIN_C, VALI_FIN_OUT(0), VALI_FIN_OUT(1) : VALI_FIN_IN : "scc");
+  } else if constexpr (P == 3) {
+    asm volatile("s_cmp_eq_u32 %[s], 0\n\ts_cbranch_scc1 0f\n\ts_cmp_eq_u32 %[s], 1\n\ts_cbranch_scc1 1f\n\t" VALI_FIN1(2)
+                 "s_branch 9f\n1:\n\t" VALI_FIN1(1) "s_branch 9f\n0:\n\t" VALI_FIN1(0) "9:"
+                 : VALI_FIN_C, VALI_FIN_OUT(0), VALI_FIN_OUT(1), VALI_FIN_OUT(2) : VALI_FIN_IN : "scc");
+  } else if constexpr (P == 4) {
+    asm volatile("s_cmp_eq_u32 %[s], 0\n\ts_cbranch_scc1 0f\n\ts_cmp_eq_u32 %[s], 1\n\ts_cbranch_scc1 1f\n\t"
+                 "s_cmp_eq_u32 %[s], 2\n\ts_cbranch_scc1 2f\n\t" VALI_FIN1(3) "s_branch 9f\n2:\n\t" VALI_FIN1(2)
+                 "s_branch 9f\n1:\n\t" VALI_FIN1(1) "s_branch 9f\n0:\n\t" VALI_FIN1(0) "9:"
+                 : VALI_FIN_C, VALI_FIN_OUT(0), VALI_FIN_OUT(1), VALI_FIN_OUT(2), VALI_FIN_OUT(3) : VALI_FIN_IN : "scc");
+  } else {
+    // (30 operands at most: the six sets in two blocks of three)
+    if (slot < 3) {
+      asm volatile("s_cmp_eq_u32 %[s], 0\n\ts_cbranch_scc1 0f\n\ts_cmp_eq_u32 %[s], 1\n\ts_cbranch_scc1 1f\n\t" VALI_FIN1(2)
+                   "s_branch 9f\n1:\n\t" VALI_FIN1(1) "s_branch 9f\n0:\n\t" VALI_FIN1(0) "9:"
+                   : VALI_FIN_C, VALI_FIN_OUT(0), VALI_FIN_OUT(1), VALI_FIN_OUT(2) : VALI_FIN_IN : "scc");
+    } else {
+      asm volatile("s_cmp_eq_u32 %[s], 3\n\ts_cbranch_scc1 0f\n\ts_cmp_eq_u32 %[s], 4\n\ts_cbranch_scc1 1f\n\t" VALI_FIN1(2)
+                   "s_branch 9f\n1:\n\t" VALI_FIN1(1) "s_branch 9f\n0:\n\t" VALI_FIN1(0) "9:"
+                   : VALI_FIN_C, [a00] "+v"(acc[P > 3 ? 3 : 0][0]), [a01] "+v"(acc[P > 3 ? 3 : 0][1]), [a02] "+v"(acc[P > 3 ? 3 : 0][2]),
+                     [a03] "+v"(acc[P > 3 ? 3 : 0][3]), [a10] "+v"(acc[P > 4 ? 4 : 0][0]), [a11] "+v"(acc[P > 4 ? 4 : 0][1]),
+                     [a12] "+v"(acc[P > 4 ? 4 : 0][2]), [a13] "+v"(acc[P > 4 ? 4 : 0][3]), [a20] "+v"(acc[P - 1][0]),
+                     [a21] "+v"(acc[P - 1][1]), [a22] "+v"(acc[P - 1][2]), [a23] "+v"(acc[P - 1][3])
+                   : VALI_FIN_IN : "scc");
+    }
+  }
+#undef VALI_FIN1
+#undef VALI_FIN_OUT
+#undef VALI_FIN_IN
+#undef VALI_FIN_C
+}
+
 struct NoFlush {
   __device__ __forceinline__ void operator()(bool) const {}
 };
@@ -362,46 +408,7 @@ __device__ __forceinline__ void cols_walk(const ColProg& r, const uint8_t* sp, i
             w2.x = r.first_w[t];
           auto fin_to = [&](v2f32 (&c)[NF]) {
           if constexpr (NF == 4 && !ACT && (P == 2 || P == 3 || P == 4 || P == 6)) {
-            static_assert(P <= 6, "slots");
-#define VALI_FIN1(j)                                                                                                    \
-  "v_mov_b64 %[c0], %[a" #j "0]\n\tv_mov_b64 %[c1], %[a" #j "1]\n\tv_mov_b64 %[c2], %[a" #j "2]\n\tv_mov_b64 %[c3], %[a" #j "3]\n\t" \
-  "v_pk_fma_f32 %[a" #j "0], %[w], %[f0], 0 op_sel_hi:[0,1,0]\n\tv_pk_fma_f32 %[a" #j "1], %[w], %[f1], 0 op_sel_hi:[0,1,0]\n\t"   \
-  "v_pk_fma_f32 %[a" #j "2], %[w], %[f2], 0 op_sel_hi:[0,1,0]\n\tv_pk_fma_f32 %[a" #j "3], %[w], %[f3], 0 op_sel_hi:[0,1,0]\n\t"
-#define VALI_FIN_OUT(j) [a##j##0] "+v"(acc[j][0]), [a##j##1] "+v"(acc[j][1]), [a##j##2] "+v"(acc[j][2]), [a##j##3] "+v"(acc[j][3])
-#define VALI_FIN_IN [w] "v"(w2), [f0] "v"(f[0]), [f1] "v"(f[1]), [f2] "v"(f[2]), [f3] "v"(f[3]), [s] "s"(slot)
-#define VALI_FIN_C [c0] "=&v"(c[0]), [c1] "=&v"(c[1]), [c2] "=&v"(c[2]), [c3] "=&v"(c[3])
-            if constexpr (P == 2) {
-              asm volatile("s_cmp_eq_u32 %[s], 0\n\ts_cbranch_scc1 0f\n\t" VALI_FIN1(1) "s_branch 9f\n0:\n\t" VALI_FIN1(0) "9:"
-                           : VALI_FIN_C, VALI_FIN_OUT(0), VALI_FIN_OUT(1) : VALI_FIN_IN : "scc");
-            } else if constexpr (P == 3) {
-              asm volatile("s_cmp_eq_u32 %[s], 0\n\ts_cbranch_scc1 0f\n\ts_cmp_eq_u32 %[s], 1\n\ts_cbranch_scc1 1f\n\t" VALI_FIN1(2)
-                           "s_branch 9f\n1:\n\t" VALI_FIN1(1) "s_branch 9f\n0:\n\t" VALI_FIN1(0) "9:"
-                           : VALI_FIN_C, VALI_FIN_OUT(0), VALI_FIN_OUT(1), VALI_FIN_OUT(2) : VALI_FIN_IN : "scc");
-            } else if constexpr (P == 4) {
-              asm volatile("s_cmp_eq_u32 %[s], 0\n\ts_cbranch_scc1 0f\n\ts_cmp_eq_u32 %[s], 1\n\ts_cbranch_scc1 1f\n\t"
-                           "s_cmp_eq_u32 %[s], 2\n\ts_cbranch_scc1 2f\n\t" VALI_FIN1(3) "s_branch 9f\n2:\n\t" VALI_FIN1(2)
-                           "s_branch 9f\n1:\n\t" VALI_FIN1(1) "s_branch 9f\n0:\n\t" VALI_FIN1(0) "9:"
-                           : VALI_FIN_C, VALI_FIN_OUT(0), VALI_FIN_OUT(1), VALI_FIN_OUT(2), VALI_FIN_OUT(3) : VALI_FIN_IN : "scc");
-            } else {
-              // (30 operands at most: the six sets in two blocks of three)
-              if (slot < 3) {
-                asm volatile("s_cmp_eq_u32 %[s], 0\n\ts_cbranch_scc1 0f\n\ts_cmp_eq_u32 %[s], 1\n\ts_cbranch_scc1 1f\n\t" VALI_FIN1(2)
-                             "s_branch 9f\n1:\n\t" VALI_FIN1(1) "s_branch 9f\n0:\n\t" VALI_FIN1(0) "9:"
-                             : VALI_FIN_C, VALI_FIN_OUT(0), VALI_FIN_OUT(1), VALI_FIN_OUT(2) : VALI_FIN_IN : "scc");
-              } else {
-                asm volatile("s_cmp_eq_u32 %[s], 3\n\ts_cbranch_scc1 0f\n\ts_cmp_eq_u32 %[s], 4\n\ts_cbranch_scc1 1f\n\t" VALI_FIN1(2)
-                             "s_branch 9f\n1:\n\t" VALI_FIN1(1) "s_branch 9f\n0:\n\t" VALI_FIN1(0) "9:"
-                             : VALI_FIN_C, [a00] "+v"(acc[P > 3 ? 3 : 0][0]), [a01] "+v"(acc[P > 3 ? 3 : 0][1]), [a02] "+v"(acc[P > 3 ? 3 : 0][2]),
-                               [a03] "+v"(acc[P > 3 ? 3 : 0][3]), [a10] "+v"(acc[P > 4 ? 4 : 0][0]), [a11] "+v"(acc[P > 4 ? 4 : 0][1]),
-                               [a12] "+v"(acc[P > 4 ? 4 : 0][2]), [a13] "+v"(acc[P > 4 ? 4 : 0][3]), [a20] "+v"(acc[P - 1][0]),
-                               [a21] "+v"(acc[P - 1][1]), [a22] "+v"(acc[P - 1][2]), [a23] "+v"(acc[P - 1][3])
-                             : VALI_FIN_IN : "scc");
-              }
-            }
-#undef VALI_FIN1
-#undef VALI_FIN_OUT
-#undef VALI_FIN_IN
-#undef VALI_FIN_C
+            cols_fin<P>(acc, c, w2, f, slot);
           } else {
             auto fin = [&](v2f32 (&a)[NF]) {
 #pragma unroll
@@ -778,9 +785,7 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
 #ifndef VALI_WS_ABL
 #define VALI_WS_ABL 0
 #endif
-#ifndef VALI_WS_PRIO
-#define VALI_WS_PRIO 0
-#endif
+
 constexpr int kWsBlock = 2 * kWave;
 constexpr int kWsStripBytes = kColStrip * 8;                  // one strip: kColStrip slots of two floats
 constexpr int kWsObuf = 2 * 2 * kColStrip;                    // floats: behind the two strips, the transposition (256 x 2)
@@ -976,18 +981,10 @@ __device__ __forceinline__ void cols_tile_ws(const uint8_t* sp, int spitch, int 
   constexpr int kBefore = LzTap<TAPS>::kBefore;
   constexpr int EB = (int)sizeof(T);
   constexpr int ND = 2 * EB;
-#ifndef VALI_WS_D
-#define VALI_WS_D 4
-#endif
-  constexpr int D = EB == 4 ? 3 : EB == 2 ? 3 : VALI_WS_D;      // source rows in flight
+  constexpr int D = EB == 4 ? 3 : EB == 2 ? 3 : 4;              // source rows in flight
   constexpr int HALF = kColHalf<ES>, SEG = 2 * HALF;            // slots
   const int lane = threadIdx.x & 63;
   const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // 0: producer, 1: consumer
-#if VALI_WS_PRIO == 1
-  if (role == 1) __builtin_amdgcn_s_setprio(3);
-#elif VALI_WS_PRIO == 2
-  if (role == 0) __builtin_amdgcn_s_setprio(3);
-#endif
   v2f32* const strip = reinterpret_cast<v2f32*>(lds);
   const u32 lds_base = (u32)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
   const int dwe = dw * ES, row_el = sw * ES;
