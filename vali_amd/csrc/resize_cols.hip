@@ -788,13 +788,16 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
 
 constexpr int kWsBlock = 2 * kWave;
 constexpr int kWsStripBytes = kColStrip * 8;                  // one strip: kColStrip slots of two floats
-constexpr int kWsObuf = 2 * 2 * kColStrip;                    // floats: behind the two strips, the transposition (256 x 2)
-constexpr int kWsProg = kWsObuf + 512;                        // the producer's program
+constexpr int kWsObuf = 2 * 2 * kColStrip;                    // floats: behind the two strips, the transposition (64 NS elements x 2 rows)
+// NS: sets of 64 dst elements a consumer lane filters -- 4 (256-element tiles), or 5: at ratios below 2:1 the 512 source
+// elements a producer row loads cover up to 320 dst elements, and a 256-element tile leaves a quarter of its lanes without data
+// (1080p -> 1278x718: 50 of 64)
+template <int NS> constexpr int kWsProg = kWsObuf + 2 * kWave * NS; // the producer's program
 // ... of kWsProgRows entries whatever the entry size: the kernels of 4 and 6 slots (and of float planes) run five or four
 // waves per SIMD by their registers, so the LDS of their 8-dword entries is free -- 112 rows instead of 64: 45 dst rows per tile
 // at 3:2 instead of 32, half the source rows walked twice
 constexpr int kWsProgRows = 112;
-template <int P, bool ACT> constexpr int kWsLds = kWsProg + kWsProgRows * (kProgEsz<P, ACT> + 1); // floats of a workgroup
+template <int P, bool ACT, int NS> constexpr int kWsLds = kWsProg<NS> + kWsProgRows * (kProgEsz<P, ACT> + 1); // floats of a workgroup
 
 __device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -901,6 +904,46 @@ __device__ __forceinline__ void ws_row_taps(v2f32& ra, v2f32& rb, u32 a0, u32 a1
   rb = u0;
 }
 
+// One window (the fifth set of a wide tile).
+template <int TAPS, int OFF>
+__device__ __forceinline__ void ws_row_taps1(v2f32& ra, u32 a0, u32 a1, const v2f32 (&wa)[TAPS / 2]) {
+  v2f32 t0, t1, t2, t3, t4, t5;
+  if constexpr (TAPS == 6) {
+    asm volatile(
+        "ds_read_b64 %[t0], %[a0] offset:%[o0]\n\tds_read_b64 %[t1], %[a1] offset:%[o0]\n\tds_read_b64 %[t2], %[a0] offset:%[o1]\n\t"
+        "ds_read_b64 %[t3], %[a1] offset:%[o1]\n\tds_read_b64 %[t4], %[a0] offset:%[o2]\n\tds_read_b64 %[t5], %[a1] offset:%[o2]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_pk_fma_f32 %[t0], %[w0], %[t0], 0 op_sel_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %[t1], %[w0], %[t1], 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]\n\t"
+        "v_pk_fma_f32 %[t0], %[w1], %[t2], %[t0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %[t1], %[w1], %[t3], %[t1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %[t0], %[w2], %[t4], %[t0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %[t1], %[w2], %[t5], %[t1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "s_nop 0\n\t"
+        "v_pk_add_f32 %[t0], %[t0], %[t1]"
+        : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5)
+        : [a0] "v"(a0), [a1] "v"(a1), [w0] "v"(wa[0]), [w1] "v"(wa[1]), [w2] "v"(wa[TAPS / 2 - 1]), [o0] "i"(OFF), [o1] "i"(OFF + 8),
+          [o2] "i"(OFF + 16)
+        : "memory");
+  } else {
+    asm volatile(
+        "ds_read_b64 %[t0], %[a0] offset:%[o0]\n\tds_read_b64 %[t1], %[a1] offset:%[o0]\n\tds_read_b64 %[t2], %[a0] offset:%[o1]\n\t"
+        "ds_read_b64 %[t3], %[a1] offset:%[o1]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_pk_fma_f32 %[t0], %[w0], %[t0], 0 op_sel_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %[t1], %[w0], %[t1], 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]\n\t"
+        "v_pk_fma_f32 %[t0], %[w1], %[t2], %[t0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %[t1], %[w1], %[t3], %[t1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "s_nop 0\n\t"
+        "v_pk_add_f32 %[t0], %[t0], %[t1]"
+        : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+        : [a0] "v"(a0), [a1] "v"(a1), [w0] "v"(wa[0]), [w1] "v"(wa[1]), [o0] "i"(OFF), [o1] "i"(OFF + 8)
+        : "memory");
+    (void)t4; (void)t5;
+  }
+  ra = t0;
+}
+
 // The producer of cols_tile_ws: the walk, and what it does with a completed dst row -- the first row of a pair waits in
 // `hold`, the second goes to the strip with it (one slot = one column of both rows).  A function of its own, RAGGED a
 // template parameter: everything the walk tests per dst row is a bit of the row's control word or a compile-time choice --
@@ -974,7 +1017,7 @@ __device__ __forceinline__ void ws_produce(const ColProg& r, const uint8_t* sp, 
   cols_walk<T, TAPS, P, ND, D, 4, true>(r, sp, spitch, sh, lane_off, [](const u32 (&d)[ND], v2f32 (&f)[4]) { conv8<T>(d, f); }, take);
 }
 
-template <typename T, int ES, int TAPS, int P>
+template <typename T, int ES, int TAPS, int P, int NS>
 __device__ __forceinline__ void cols_tile_ws(const uint8_t* sp, int spitch, int sw, int sh, uint8_t* dp, int dpitch,
                                              int dw, int dh, u32 tx, u32 ty, int N, int rps, float* lds, const float4* xtab,
                                              const float4* ytab) {
@@ -1005,7 +1048,7 @@ __device__ __forceinline__ void cols_tile_ws(const uint8_t* sp, int spitch, int 
 
   if (role == 0) {
     ColProg r;
-    cols_rows<TAPS, P, EB == 4, D, true, kWsProgRows>(sh, dh, ty, rps, lds + kWsProg, r, ytab);
+    cols_rows<TAPS, P, EB == 4, D, true, kWsProgRows>(sh, dh, ty, rps, lds + kWsProg<NS>, r, ytab);
     const int nl = min((((sx1 + 1) * ES - j_begin) + kColEl - 1) / kColEl, kWave); // lanes with data
     const bool ragged = j_begin + kColEl * nl > row_el;           // wave-uniform: only a row's last tile
     const int j0 = min(j_begin + kColEl * min(lane, nl - 1), row_el - kColEl);
@@ -1030,10 +1073,10 @@ __device__ __forceinline__ void cols_tile_ws(const uint8_t* sp, int spitch, int 
   }
 
   // ---- consumer: the pass along the rows ----
-  v2f32 wq[4][TAPS / 2]; // (w0, w1), (w2, w3), ..
-  u32 ha[4][2];          // LDS byte addresses in strip 0: taps 0, 2, 4 at ha[p][0] + 0, 8, 16; taps 1, 3, 5 at ha[p][1] + 0, 8, 16
+  v2f32 wq[NS][TAPS / 2]; // (w0, w1), (w2, w3), ..
+  u32 ha[NS][2];          // LDS byte addresses in strip 0: taps 0, 2, 4 at ha[p][0] + 0, 8, 16; taps 1, 3, 5 at ha[p][1] + 0, 8, 16
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
+  for (int p = 0; p < NS; ++p) {
     const int e = min(e0 + p * kWave + lane, e_last);
     const int px = e / ES, ch = e - px * ES;
     const LzTap<TAPS> c = lz_tap_of<TAPS>(xtab, px, scale_x);
@@ -1054,6 +1097,7 @@ __device__ __forceinline__ void cols_tile_ws(const uint8_t* sp, int spitch, int 
   const int edge = kColPadL + (sw - 1) - px_begin;                         // the last pixel of the row
   const int eb = e0 + 4 * lane;                                            // store: 4 adjacent elements
   const int n_out = min(4, e_last + 1 - eb);
+  const int n_out2 = NS > 4 ? min(4, e_last + 1 - (eb + 256)) : 0;         // ... and of the fifth set, lanes 0 .. 15
   // whole groups of 4 elements from every lane that stores, on rows aligned to a group: one store per lane and row, no
   // per-lane alignment test, and the row's offset a SCALAR operand of a buffer store (as in cols_walk)
   const bool plain_store = ((e_last + 1 - e0) & 3) == 0 && ((((uintptr_t)dp) | (uintptr_t)dpitch) & (4u * EB - 1u)) == 0; // wave-uniform
@@ -1063,7 +1107,7 @@ __device__ __forceinline__ void cols_tile_ws(const uint8_t* sp, int spitch, int 
   auto pairs = [&](auto plain_tag, auto pad_tag) {
     constexpr bool PLAIN = decltype(plain_tag)::value, PADS = decltype(pad_tag)::value;
     // soff: byte offset of the row in the plane (scalar)
-    auto store_row = [&](int soff, float v0, float v1, float v2, float v3) {
+    auto store_row = [&](int soff, int eb, int n_out, float v0, float v1, float v2, float v3) {
       if constexpr (PLAIN) {
         if constexpr (EB == 1) {
           u32 q = __builtin_amdgcn_cvt_pk_u8_f32(v0, 0u, 0u);
@@ -1102,11 +1146,16 @@ __device__ __forceinline__ void cols_tile_ws(const uint8_t* sp, int spitch, int 
         wave_lds_sync();
       }
 #pragma unroll
-      for (int half = 0; half < 4; half += 2) {
+      for (int half = 0; half + 1 < NS; half += 2) {
         v2f32 ra, rb;
         ws_row_taps<TAPS, B * kWsStripBytes>(ra, rb, ha[half][0], ha[half][1], ha[half + 1][0], ha[half + 1][1], wq[half], wq[half + 1]);
         obuf[half * kWave + lane] = ra;
         obuf[(half + 1) * kWave + lane] = rb;
+      }
+      if constexpr ((NS & 1) != 0) {
+        v2f32 ra;
+        ws_row_taps1<TAPS, B * kWsStripBytes>(ra, ha[NS - 1][0], ha[NS - 1][1], wq[NS - 1]);
+        obuf[(NS - 1) * kWave + lane] = ra;
       }
       wave_lds_sync();
       if (n_out > 0) {
@@ -1114,10 +1163,23 @@ __device__ __forceinline__ void cols_tile_ws(const uint8_t* sp, int spitch, int 
         asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
                      : "=&v"(v0), "=&v"(v1) : "v"(obuf_rd) : "memory");
         if constexpr (!ONLYB) {
-          store_row(soff, v0.x, v0.z, v1.x, v1.z);
-          store_row(soff + dpitch, v0.y, v0.w, v1.y, v1.w);
+          store_row(soff, eb, n_out, v0.x, v0.z, v1.x, v1.z);
+          store_row(soff + dpitch, eb, n_out, v0.y, v0.w, v1.y, v1.w);
         } else {
-          store_row(soff, v0.y, v0.w, v1.y, v1.w);
+          store_row(soff, eb, n_out, v0.y, v0.w, v1.y, v1.w);
+        }
+      }
+      if constexpr (NS > 4) {
+        if (n_out2 > 0) { // elements 256 .. of the tile: lanes 0 .. 15
+          float4 v0, v1;
+          asm volatile("ds_read_b128 %0, %2 offset:2048\n\tds_read_b128 %1, %2 offset:2064\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(v0), "=&v"(v1) : "v"(obuf_rd) : "memory");
+          if constexpr (!ONLYB) {
+            store_row(soff, eb + 256, n_out2, v0.x, v0.z, v1.x, v1.z);
+            store_row(soff + dpitch, eb + 256, n_out2, v0.y, v0.w, v1.y, v1.w);
+          } else {
+            store_row(soff, eb + 256, n_out2, v0.y, v0.w, v1.y, v1.w);
+          }
         }
       }
       wave_lds_sync();
@@ -1437,21 +1499,21 @@ __global__ void __launch_bounds__(kBlock) k_resize_cols(const ResizeArgs a) {
 #define VALI_WS_W3 6
 #endif
 template <int EB, int P> constexpr int kWsWaves = EB == 4 ? (P <= 3 ? 4 : 3) : P <= 3 ? (EB == 2 ? 5 : VALI_WS_W3) : P <= 4 ? 5 : 4;
-template <typename T, int ESSET, int TAPS, int P>
-__global__ void __launch_bounds__(kWsBlock, (kWsWaves<(int)sizeof(T), P>)) k_resize_cols_ws(const ResizeArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[kWsLds<P, sizeof(T) == 4>];
+template <typename T, int ESSET, int TAPS, int P, int NS>
+__global__ void __launch_bounds__(kWsBlock, (kWsWaves<(int)sizeof(T), NS == 4 ? P : P < 4 ? 4 : P>)) k_resize_cols_ws(const ResizeArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[kWsLds<P, sizeof(T) == 4, NS>];
   ResizeJob job;
   u32 tx, ty, frame;
   if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
     return;
   const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
   if constexpr (ESSET == 3) {
-    cols_tile_ws<T, 3, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_n, a.cols_rps, lds, job.xtab, job.ytab);
+    cols_tile_ws<T, 3, TAPS, P, NS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_n, a.cols_rps, lds, job.xtab, job.ytab);
   } else {
     if (ESSET == 12 && job.channels == 2)
-      cols_tile_ws<T, 2, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_n, a.cols_rps, lds, job.xtab, job.ytab);
+      cols_tile_ws<T, 2, TAPS, P, NS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_n, a.cols_rps, lds, job.xtab, job.ytab);
     else
-      cols_tile_ws<T, 1, TAPS, P>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_n, a.cols_rps, lds, job.xtab, job.ytab);
+      cols_tile_ws<T, 1, TAPS, P, NS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, a.cols_n, a.cols_rps, lds, job.xtab, job.ytab);
   }
 }
 
@@ -1554,14 +1616,19 @@ static void launch_slots(const ResizeArgs& a, int slots, int xform, dim3 grid, h
   }
   if (xform == 5) { // the general form on specialised waves: a workgroup = producer + consumer of ONE tile
     const int cap = tuning(VALI_TUNE_WAVES_PER_CU); // (measurements: workgroups per CU = cap / 2, by unused dynamic LDS)
-    constexpr int kLds = kWsLds<P0, sizeof(T) == 4> * 4;
+    constexpr int kLds = kWsLds<P0, sizeof(T) == 4, 4> * 4;
     const unsigned dyn = cap >= 2 && 160 * 1024 / (cap / 2) > kLds ? (unsigned)(160 * 1024 / (cap / 2) - kLds) & ~15u : 0u;
-    if (slots <= P0)
-      hipLaunchKernelGGL((k_resize_cols_ws<T, ESSET, TAPS, P0>), grid, dim3(kWsBlock), dyn, stream, a);
-    else if (slots <= P1)
-      hipLaunchKernelGGL((k_resize_cols_ws<T, ESSET, TAPS, P1>), grid, dim3(kWsBlock), dyn, stream, a);
-    else
-      hipLaunchKernelGGL((k_resize_cols_ws<T, ESSET, TAPS, P2>), grid, dim3(kWsBlock), dyn, stream, a);
+#define VALI_WS_LAUNCH(P, NS) hipLaunchKernelGGL((k_resize_cols_ws<T, ESSET, TAPS, P, NS>), grid, dim3(kWsBlock), dyn, stream, a)
+    if (a.cols_n > 4 * kWave) { // wide tiles: five sets per consumer lane
+      if (slots <= P0) VALI_WS_LAUNCH(P0, 5);
+      else if (slots <= P1) VALI_WS_LAUNCH(P1, 5);
+      else VALI_WS_LAUNCH(P2, 5);
+    } else {
+      if (slots <= P0) VALI_WS_LAUNCH(P0, 4);
+      else if (slots <= P1) VALI_WS_LAUNCH(P1, 4);
+      else VALI_WS_LAUNCH(P2, 4);
+    }
+#undef VALI_WS_LAUNCH
     return;
   }
   if (slots <= P0)
@@ -1578,7 +1645,7 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
   const bool direct_only = tuning(VALI_TUNE_RESIZE_FORCE_GATHER) == 1;
   const int force = tuning(VALI_TUNE_RESIZE_NO_SEPARABLE); // rows per wave: 1 / 2 / 3 force 2 / 1 / 8 rows per slot
   ResizeArgs a = base;
-  int esset = 0, tile_n = 256, slots = 1;
+  int esset = 0, tile_n = 256, tile_w = 320, slots = 1;
   bool narrow = false, x2 = elem <= 2 && tuning(VALI_TUNE_RESIZE_POINT) != 0; // exactly 2:1 along x on every plane
   bool x32 = x2;                                                              // exactly 3:2 along x on every plane
   bool y32 = taps == 6;                                                       // ... and down the rows (dst height even)
@@ -1594,9 +1661,11 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
     // dst elements per tile: the source span of its pixels (+ taps, + the two extra elements, + alignment slop) must fit
     // the 512 elements a wave loads per row.  A tile starts on a pixel unless pixels are 3 elements (N is a multiple of 4).
     const double sx = (double)sw / (double)dw * (1.0 + 1e-6);
-    int nn = 256;
+    int nn = 320; // (the specialised waves take up to 5 x 64 elements per tile, the other forms 4 x 64)
     while (nn >= 8 && (((c == 3 ? nn / 3 + 2 : nn / c) - 1) * sx + taps + 4) * c + kColEl - 1 > (double)kColSpan)
       nn -= 4;
+    tile_w = nn < tile_w ? nn : tile_w;
+    nn = nn < 256 ? nn : 256;
     tile_n = nn < tile_n ? nn : tile_n;
     // slots: the smallest P with P * scale_y >= taps - 1 (a slot's consecutive rows may share ONE source row: cols_rows;
     // and a margin for the rounding of y * scale_y in FP32)
@@ -1646,6 +1715,8 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
       j.ytab = tap_table(dev, stream, src_h >> j.ssub_y, dst_h >> j.sub_y, taps);
     }
   }
+  if (ws)
+    tile_n = tile_w;
   const int prog_rows = ws ? kWsProgRows : (P <= 3 && elem != 4) ? kProgRows<3, false> : kProgRows<6, true>;
   int rps_max = 64 / P;
   for (int k = 0; k < a.njobs; ++k) {
