@@ -74,7 +74,7 @@ def test_default_filter_is_the_references(vali, gpu, oracle):
 
 def test_resize_errors(vali, gpu):
     with pytest.raises(RuntimeError):                      # TaskResizeSurface.cpp:307-308
-        vali.PySurfaceResizer(vali.PixelFormat.UNDEFINED if False else vali.PixelFormat.GRAY12, gpu)
+        vali.PySurfaceResizer(vali.PixelFormat.GRAY12, gpu)
     rs = vali.PySurfaceResizer(vali.NV12, gpu)
     a = vali.Surface.Make(vali.NV12, 64, 48, gpu)
     b = vali.Surface.Make(vali.YUV420, 32, 24, gpu)
@@ -522,8 +522,6 @@ def test_three_to_two_enlargement_bit_exact(vali, gpu, oracle, fmt, geom, interp
 def test_three_to_two_enlargement_all_zero_and_flat_frames(vali, gpu, oracle):
     """flat frames: every chain of the shifted-weight form sees zeros / equal values in every slot"""
     for val in (0, 255, 16):
-        host = np.full(258 * 12 * 3 // 2, val, np.uint8)
-        want = oracle.resize_surface(host, "NV12", 258, 12, 387 - 1 + 1 if False else 387, 18, "lanczos") if False else None
         host = np.full(260 * 12 * 3 // 2, val, np.uint8)
         want = oracle.resize_surface(host, "NV12", 260, 12, 390, 18, "lanczos")
         assert np.array_equal(roundtrip(vali, gpu, "NV12", host, 260, 12, 390, 18, interp=vali.Interpolation.LANCZOS), want), val

@@ -61,15 +61,28 @@ def test_the_hot_kernels_spill_nothing_and_keep_their_occupancy():
             # the general columns-first form: 3 slots at 1.98:1, 4 at 4:3 / 5:4 -- NV12, packed RGB, P10: the fourth wave per SIMD
             "k_resize_colsIhLi12ELi6ELi3E": 4, "k_resize_colsIhLi12ELi6ELi4E": 4, "k_resize_colsIhLi3ELi6ELi3E": 4,
             "k_resize_colsIhLi3ELi6ELi4E": 4, "k_resize_colsItLi12ELi6ELi3E": 4,
+            # ... on specialised waves (round 5; the last figure is the consumer's sets): six waves per SIMD at 3 slots,
+            # five with wide tiles or 4 slots
+            "k_resize_cols_wsIhLi12ELi6ELi3ELi4E": 6, "k_resize_cols_wsIhLi12ELi6ELi3ELi5E": 5, "k_resize_cols_wsIhLi12ELi6ELi4ELi5E": 5,
+            "k_resize_cols_wsIhLi3ELi6ELi4ELi5E": 5, "k_resize_cols_wsIhLi3ELi6ELi3ELi4E": 6,
             "k_resize_up2IhLi6ELb0E": 6, "k_resize_up2IhLi6ELb1E": 6, "k_resize_up2ItLi6ELb0E": 6,   # (the workgroups-per-CU figures of launch_resize_up2)
             # planes that grow: the 3:2 form the upscale bench line is quoted on, and the general rows-first kernel
             "k_resize_rows_x23IhLi12ELi6ELi48E": 4, "k_resize_rowsIhLi12ELi6ELi32E": 4}
     seen = set()
     for name, r in k.items():
         for needle, occ in want.items():
-            if needle in name and ("_x2I" in name) == ("_x2I" in needle) and ("half_t" in name) == ("half_t" in needle):
+            if needle in name and ("_x2I" in name) == ("_x2I" in needle) and ("half_t" in name) == ("half_t" in needle) and ("_wsI" in name) == ("_wsI" in needle):
                 seen.add(needle)
                 assert r.get("SGPRs Spill", 0) == 0 and r.get("ScratchSize", 0) == 0, (name, r)
                 if "Occupancy" in r:
                     assert r["Occupancy"] >= occ, (name, r["Occupancy"], occ)
     assert seen == set(want), seen
+
+
+def test_no_timing_only_branches_in_the_product_kernels():
+    """Ablation switches (`VALI_COLS_ABLATE`, `VALI_WS_ABL`: parts of a kernel compiled out for timing, results invalid) live
+    in tools/exp/resize_cols_ablations.patch, not in the sources the library is built from (VERDICT r04 #8)."""
+    for f in sorted((ROOT / "vali_amd" / "csrc").glob("*.h*")):
+        text = f.read_text()
+        assert not re.search(r"ABLATE|_ABL\b", text), f.name
+    assert (ROOT / "tools" / "exp" / "resize_cols_ablations.patch").exists()

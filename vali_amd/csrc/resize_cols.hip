@@ -36,9 +36,6 @@
 
 #include <type_traits>
 
-#ifndef VALI_COLS_ABLATE
-#define VALI_COLS_ABLATE 0
-#endif
 
 namespace vali {
 
@@ -367,12 +364,6 @@ __device__ __forceinline__ void cols_walk(const ColProg& r, const uint8_t* sp, i
       __builtin_amdgcn_sched_barrier(0);
       if (t >= r.ns) // the last trip only: rows past the end are loaded (the issue order stays countable), not used
         continue;
-#if VALI_COLS_ABLATE == 1 // (timing experiments only: the memory stream and the conversions)
-#pragma unroll
-      for (int i = 0; i < NF; ++i)
-        acc[0][i] += f[i];
-      continue;
-#endif
       const v2f32 w01 = (v2f32){c0.x, c0.y}, w23 = (v2f32){c0.z, c0.w}, w45 = (v2f32){c1.x, c1.y};
       u32 act = 0u;
       if constexpr (ACT)
@@ -393,9 +384,6 @@ __device__ __forceinline__ void cols_walk(const ColProg& r, const uint8_t* sp, i
           else pk_fma_h<1>(acc[j][i], w45, f[i]);
         }
       }
-#if VALI_COLS_ABLATE == 2 // (... and the column arithmetic)
-      continue;
-#endif
       if constexpr (BYSLOT) {
         if (flags & kProgDone) { // at most one dst row per source row (scale_y >= 1): the row of slot emit_rr mod P
           // One scalar switch over the slot: the set out (a copy) and its restart IN PLACE: w f + 0 with the first weight of
@@ -464,16 +452,6 @@ __device__ __forceinline__ void cols_walk(const ColProg& r, const uint8_t* sp, i
     }
     vprog += (u32)(D * ESZ * 4);
   }
-#if VALI_COLS_ABLATE
-  float sum = 0.0f;
-#pragma unroll
-  for (int j = 0; j < P; ++j)
-#pragma unroll
-    for (int i = 0; i < NF; ++i)
-      sum += acc[j][i].x + acc[j][i].y;
-  if (sum == 1.2345e-30f)
-    *(VALI_GLOBAL float*)const_cast<uint8_t*>(sp) = sum;
-#endif
 }
 
 template <typename T> __device__ __forceinline__ void conv8(const u32 (&d)[2 * sizeof(T)], v2f32 (&f)[4]) {
@@ -497,10 +475,7 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
   constexpr int kBefore = LzTap<TAPS>::kBefore;
   constexpr int EB = (int)sizeof(T);
   constexpr int ND = 2 * EB;                                    // dwords of a lane's 8 elements
-#ifndef VALI_COLS_D
-#define VALI_COLS_D 4
-#endif
-  constexpr int D = EB == 4 ? 3 : EB == 2 ? 3 : P >= 4 ? 2 : VALI_COLS_D; // source rows in flight (registers: 8 EB bytes per lane and row; the 4- and 6-slot kernels trade two rows for their fourth wave per SIMD)
+  constexpr int D = EB == 4 ? 3 : EB == 2 ? 3 : P >= 4 ? 2 : 4; // source rows in flight (registers: 8 EB bytes per lane and row; the 4- and 6-slot kernels trade two rows for their fourth wave per SIMD)
   constexpr int HALF = kColHalf<ES>, SEG = 2 * HALF;            // slots
   const int lane = threadIdx.x & 63;
   v2f32* const strip = reinterpret_cast<v2f32*>(lds);           // one slot = one column of TWO dst rows
@@ -599,14 +574,7 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
       q = __builtin_amdgcn_cvt_pk_u8_f32(v1, 1u, q);
       q = __builtin_amdgcn_cvt_pk_u8_f32(v2, 2u, q);
       q = __builtin_amdgcn_cvt_pk_u8_f32(v3, 3u, q);
-#if VALI_COLS_ABLATE == 5 // (timing experiments: no stores)
-      if (q == 0x12345678u && v0 == 3.25f)
-        gstore<u32>(out, q);
-#elif VALI_COLS_ABLATE == 6 // (... stores through the L2)
-      gstore<u32>(out, q);
-#else
       gstore_nt<u32>(out, q);
-#endif
     } else {
       const float res[4][1] = {{v0}, {v1}, {v2}, {v3}};
       store_px4<T, 1>(out, res, (1u << n_out) - 1u);
@@ -673,9 +641,6 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
         *reinterpret_cast<float4*>(strip + wpos[1] + 2) = make_float4(hi[2].x, hi[2].y, hi[3].x, hi[3].y);
       }
     }
-#if VALI_COLS_ABLATE == 3 // (... and the strip writes, no row pass)
-    return;
-#endif
     wave_lds_sync();
     if (pad_left || pad_right) { // image edges: replicas of the first / last pixel of every channel segment
       const int ch = lane >> 3, i = lane & 7;
@@ -782,9 +747,6 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
 //   consumer   [B]      R(0) [B]      R(1) ...  [B]            R(n-1)
 // at the barrier in front of W(k) the consumer has finished R(k - 2) (the strip W(k) overwrites) and the producer's W(k - 1)
 // has landed (s_waitcnt lgkmcnt(0): by then long done -- the wait sits a whole pair behind the writes it waits for).
-#ifndef VALI_WS_ABL
-#define VALI_WS_ABL 0
-#endif
 
 constexpr int kWsBlock = 2 * kWave;
 constexpr int kWsStripBytes = kColStrip * 8;                  // one strip: kColStrip slots of two floats
@@ -806,45 +768,6 @@ template <int TAPS, int OFF>
 __device__ __forceinline__ void ws_row_taps(v2f32& ra, v2f32& rb, u32 a0, u32 a1, u32 b0, u32 b1, const v2f32 (&wa)[TAPS / 2],
                                             const v2f32 (&wb)[TAPS / 2]) {
   v2f32 t0, t1, t2, t3, t4, t5, u0, u1, u2, u3, u4, u5;
-#if VALI_WS_ABL == 6
-  t0=t1=t2=t3=t4=t5=u0=u1=u2=u3=u4=u5=(v2f32){1.0f,2.0f};
-  if constexpr (TAPS == 6) {
-    asm volatile(
-                "v_pk_fma_f32 %[t0], %[w0], %[t0], 0 op_sel_hi:[0,1,0]\n\t"
-        "v_pk_fma_f32 %[t1], %[w0], %[t1], 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]\n\t"
-        "v_pk_fma_f32 %[t0], %[w1], %[t2], %[t0] op_sel_hi:[0,1,1]\n\t"
-        "v_pk_fma_f32 %[t1], %[w1], %[t3], %[t1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
-        "v_pk_fma_f32 %[t0], %[w2], %[t4], %[t0] op_sel_hi:[0,1,1]\n\t"
-        "v_pk_fma_f32 %[t1], %[w2], %[t5], %[t1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
-                "v_pk_fma_f32 %[u0], %[x0], %[u0], 0 op_sel_hi:[0,1,0]\n\t"
-        "v_pk_fma_f32 %[u1], %[x0], %[u1], 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]\n\t"
-        "v_pk_add_f32 %[t0], %[t0], %[t1]\n\t"
-        "v_pk_fma_f32 %[u0], %[x1], %[u2], %[u0] op_sel_hi:[0,1,1]\n\t"
-        "v_pk_fma_f32 %[u1], %[x1], %[u3], %[u1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
-        "v_pk_fma_f32 %[u0], %[x2], %[u4], %[u0] op_sel_hi:[0,1,1]\n\t"
-        "v_pk_fma_f32 %[u1], %[x2], %[u5], %[u1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
-        "s_nop 0\n\t"
-        "v_pk_add_f32 %[u0], %[u0], %[u1]"
-        : [t0] "+v"(t0), [t1] "+v"(t1), [t2] "+v"(t2), [t3] "+v"(t3), [t4] "+v"(t4), [t5] "+v"(t5), [u0] "+v"(u0),
-          [u1] "+v"(u1), [u2] "+v"(u2), [u3] "+v"(u3), [u4] "+v"(u4), [u5] "+v"(u5)
-        : [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1), [w0] "v"(wa[0]), [w1] "v"(wa[1]), [w2] "v"(wa[TAPS / 2 - 1]),
-          [x0] "v"(wb[0]), [x1] "v"(wb[1]), [x2] "v"(wb[TAPS / 2 - 1]), [o0] "i"(OFF), [o1] "i"(OFF + 8), [o2] "i"(OFF + 16)
-        : "memory");
-#elif VALI_WS_ABL == 7
-  if constexpr (TAPS == 6) {
-    asm volatile(
-        "ds_read_b64 %[t0], %[a0] offset:%[o0]\n\tds_read_b64 %[t1], %[a1] offset:%[o0]\n\tds_read_b64 %[t2], %[a0] offset:%[o1]\n\t"
-        "ds_read_b64 %[t3], %[a1] offset:%[o1]\n\tds_read_b64 %[t4], %[a0] offset:%[o2]\n\tds_read_b64 %[t5], %[a1] offset:%[o2]\n\t"
-        "ds_read_b64 %[u0], %[b0] offset:%[o0]\n\tds_read_b64 %[u1], %[b1] offset:%[o0]\n\tds_read_b64 %[u2], %[b0] offset:%[o1]\n\t"
-        "ds_read_b64 %[u3], %[b1] offset:%[o1]\n\tds_read_b64 %[u4], %[b0] offset:%[o2]\n\tds_read_b64 %[u5], %[b1] offset:%[o2]\n\t"
-        "s_waitcnt lgkmcnt(6)\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-                : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [u0] "=&v"(u0),
-          [u1] "=&v"(u1), [u2] "=&v"(u2), [u3] "=&v"(u3), [u4] "=&v"(u4), [u5] "=&v"(u5)
-        : [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1), [w0] "v"(wa[0]), [w1] "v"(wa[1]), [w2] "v"(wa[TAPS / 2 - 1]),
-          [x0] "v"(wb[0]), [x1] "v"(wb[1]), [x2] "v"(wb[TAPS / 2 - 1]), [o0] "i"(OFF), [o1] "i"(OFF + 8), [o2] "i"(OFF + 16)
-        : "memory");
-#else
   if constexpr (TAPS == 6) {
     asm volatile(
         "ds_read_b64 %[t0], %[a0] offset:%[o0]\n\tds_read_b64 %[t1], %[a1] offset:%[o0]\n\tds_read_b64 %[t2], %[a0] offset:%[o1]\n\t"
@@ -873,7 +796,6 @@ __device__ __forceinline__ void ws_row_taps(v2f32& ra, v2f32& rb, u32 a0, u32 a1
         : [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1), [w0] "v"(wa[0]), [w1] "v"(wa[1]), [w2] "v"(wa[TAPS / 2 - 1]),
           [x0] "v"(wb[0]), [x1] "v"(wb[1]), [x2] "v"(wb[TAPS / 2 - 1]), [o0] "i"(OFF), [o1] "i"(OFF + 8), [o2] "i"(OFF + 16)
         : "memory");
-#endif
   } else {
     asm volatile(
         "ds_read_b64 %[t0], %[a0] offset:%[o0]\n\tds_read_b64 %[t1], %[a1] offset:%[o0]\n\tds_read_b64 %[t2], %[a0] offset:%[o1]\n\t"
@@ -981,10 +903,6 @@ __device__ __forceinline__ void ws_produce(const ColProg& r, const uint8_t* sp, 
     ws_barrier();
     v2f32* const st = strip + woff;
     woff ^= (u32)kColStrip;
-#if VALI_WS_ABL == 4
-    if (lo[0].x == 1.2345e-30f) st[wpos[0]] = lo[0] + hi[1] + lo[2] + hi[3] + hi[0] + lo[1] + hi[2] + lo[3];
-    return;
-#endif
     if constexpr (ES == 3) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -1086,10 +1004,6 @@ __device__ __forceinline__ void cols_tile_ws(const uint8_t* sp, int spitch, int 
     const int q = kColPadL + (min(c.i, sw - 1) - kBefore - px_begin); // >= kColPadL - kBefore
     ha[p][0] = lds_base + 8u * (u32)(ch * SEG + col_slot<ES>(q));
     ha[p][1] = lds_base + 8u * (u32)(ch * SEG + col_slot<ES>(q + 1));
-#if VALI_WS_ABL == 5
-    ha[p][0] = lds_base + 8u * (u32)lane + 512u * p;
-    ha[p][1] = lds_base + 8u * (u32)lane + 512u * p + 2048u;
-#endif
   }
   v2f32* const obuf = reinterpret_cast<v2f32*>(lds + kWsObuf);
   const u32 obuf_rd = lds_base + 4u * (u32)kWsObuf + 32u * (u32)lane;
@@ -1133,9 +1047,6 @@ __device__ __forceinline__ void cols_tile_ws(const uint8_t* sp, int spitch, int 
       constexpr int B = decltype(buf_tag)::value;
       constexpr bool ONLYB = decltype(onlyb_tag)::value;
       ws_barrier();
-#if VALI_WS_ABL == 3
-      return;
-#endif
       if constexpr (PADS) { // image edges: replicas of the first / last pixel of every channel segment
         v2f32* const st = strip + B * kColStrip;
         const int ch = lane >> 3, i = lane & 7;
@@ -1495,10 +1406,7 @@ __global__ void __launch_bounds__(kBlock) k_resize_cols(const ResizeArgs a) {
 }
 
 // waves per SIMD the register allocation aims at: the producer's accumulators are 8 P registers
-#ifndef VALI_WS_W3
-#define VALI_WS_W3 6
-#endif
-template <int EB, int P> constexpr int kWsWaves = EB == 4 ? (P <= 3 ? 4 : 3) : P <= 3 ? (EB == 2 ? 5 : VALI_WS_W3) : P <= 4 ? 5 : 4;
+template <int EB, int P> constexpr int kWsWaves = EB == 4 ? (P <= 3 ? 4 : 3) : P <= 3 ? (EB == 2 ? 5 : 6) : P <= 4 ? 5 : 4;
 template <typename T, int ESSET, int TAPS, int P, int NS>
 __global__ void __launch_bounds__(kWsBlock, (kWsWaves<(int)sizeof(T), NS == 4 ? P : P < 4 ? 4 : P>)) k_resize_cols_ws(const ResizeArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[kWsLds<P, sizeof(T) == 4, NS>];
