@@ -172,7 +172,7 @@ def secondary_configs(pipe):
         sys.path.insert(0, str(ROOT / "tools"))
         import bench_configs as bc
 
-        return [bc.hl1080(), bc.cfg2(), bc.cfg3(), bc.interp(), bc.upscale(), bc.cfg4(), bc.udgen(), bc.udplanar()]
+        return [bc.hl1080(), bc.cfg2(), bc.cfg3(), bc.interp(), bc.upscale(), bc.cfg4(), bc.udgen(), bc.udplanar(), bc.affine()]
     except Exception as e:  # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"}
 

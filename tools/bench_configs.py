@@ -22,13 +22,18 @@ DEV = 0
 PEAK = 8000.0
 
 
+import os
+
 WORKING_SET = 1.5 * 2 ** 30   # distinct surface pairs cycled per timed loop, against the 256 MiB Infinity Cache
+# VALI_BENCH_QUICK=1: one small set, two timed launches per entry -- for tools/profile_secondary.py --names (which kernel does
+# every entry dispatch?), never for numbers
+QUICK = os.environ.get("VALI_BENCH_QUICK", "") not in ("", "0")
 
 
 def sets_needed(bytes_per_batch):
     """how many distinct src/dst batches a timed loop must rotate through so that it touches >= 1.5 GiB between two
     visits of the same surface (FETCH_SIZE / WRITE_SIZE count Infinity-Cache hits, so the counters cannot show it)"""
-    return max(1, -(-int(WORKING_SET) // int(bytes_per_batch)))
+    return 1 if QUICK else max(1, -(-int(WORKING_SET) // int(bytes_per_batch)))
 
 
 def timed(stream, fn, reps, warm=3, warm_s=0.15):
@@ -36,6 +41,8 @@ def timed(stream, fn, reps, warm=3, warm_s=0.15):
     that is cycled (one per rotating set of surfaces).  Untimed warm-up: at least `warm` calls AND `warm_s` seconds -- the
     first launches on freshly allocated surfaces of a fresh process measured 8-10 % slow (rotate 2.62 vs 2.40 us, fused UD
     4.19 vs 3.80: clocks and TLBs), whatever the kernel variant."""
+    if QUICK:
+        reps, warm, warm_s = min(reps, 2), 1, 0.0
     if isinstance(fn, (list, tuple)):
         fns, state = list(fn), [0]
         reps = -(-reps // len(fns)) * len(fns)    # whole cycles
@@ -152,7 +159,8 @@ def roofline(key, bytes_per_frame, n, ms, sets=1):
     global TRAFFIC
     if TRAFFIC is None:
         prof = Path(__file__).resolve().parent.parent / "profiles"
-        f = next((q for q in (prof / "r04_secondary_traffic.json", prof / "r03_secondary_traffic.json", prof / "r02_secondary_traffic.json") if q.exists()), None)
+        f = next((q for q in (prof / "r05_secondary_traffic.json", prof / "r04_secondary_traffic.json", prof / "r03_secondary_traffic.json",
+                              prof / "r02_secondary_traffic.json") if q.exists()), None)
         TRAFFIC = json.loads(f.read_text()) if f else {}
     gbps = bytes_per_frame * n / (ms * 1e-3) / 1e9
     t = TRAFFIC.get(key, {})
@@ -193,60 +201,88 @@ def cfg3(n=64):
 
 def interp(n=64):
     """A resize that really interpolates: NV12 2160p -> 1920x1088 (every source row contributes; exactly 2:1 along x, so the
-    Lanczos kernel takes its 2:1-along-x form), -> 1936x1088 (no integer ratio on either axis: the general form) and 1080p ->
-    720p (3:2 both ways: the uniform-weight form), with the bilinear filter of BASELINE config 3 and the reference's own
-    filter (Lanczos-3, the PySurfaceResizer default)."""
+    Lanczos kernel takes its 2:1-along-x form), -> 1936x1088 (no integer ratio on either axis: the general form, on
+    specialised waves since round 5), 1080p -> 720p (3:2 both ways: the uniform-weight form) and the general form below
+    2160p -- NV12 1080p -> 1278x718 and packed RGB 1080p -> 1277x719 -- with the bilinear filter of BASELINE
+    config 3 and the reference's own filter (Lanczos-3, the PySurfaceResizer default)."""
     out = []
-    for (sw, sh, dw, dh) in ((3840, 2160, 1920, 1088), (3840, 2160, 1936, 1088), (1920, 1080, 1280, 720)):
-        b = (sw * sh + dw * dh) * 3 // 2
+    for (fmt, sw, sh, dw, dh) in ((vali.NV12, 3840, 2160, 1920, 1088), (vali.NV12, 3840, 2160, 1936, 1088), (vali.NV12, 1920, 1080, 1280, 720),
+                                  (vali.NV12, 1920, 1080, 1278, 718), (vali.RGB, 1920, 1080, 1277, 719)):
+        b = (sw * sh + dw * dh) * 3 // 2 if fmt == vali.NV12 else (sw * sh + dw * dh) * 3
         for name, it in (("bilinear", vali.Interpolation.LINEAR), ("lanczos", vali.Interpolation.LANCZOS)):
             if (dw, name) != (1920, "bilinear") and name == "bilinear":
                 continue
-            rs = vali.PySurfaceResizer(vali.NV12, DEV, interpolation=it)
+            rs = vali.PySurfaceResizer(fmt, DEV, interpolation=it)
             k = sets_needed(b * n)
 
             def make():
-                srcs = [vali.Surface.Make(vali.NV12, sw, sh, DEV) for _ in range(n)]
-                dsts = [vali.Surface.Make(vali.NV12, dw, dh, DEV) for _ in range(n)]
+                srcs = [vali.Surface.Make(fmt, sw, sh, DEV) for _ in range(n)]
+                dsts = [vali.Surface.Make(fmt, dw, dh, DEV) for _ in range(n)]
                 fill(srcs)
                 return srcs, dsts, rs.PrepareBatch(srcs, dsts)
             sets = make_sets(k, make)
             ms, _ = timed(rs.Stream, [lambda q=q: rs.RunBatchAsync(q) for _, _, q in sets], 20)
-            kern = "k_resize<u8, 2>" if name == "bilinear" else {1920: "k_resize_cols_x2<u8, 12, 6, 3>", 1936: "k_resize_cols<u8, 12, 6, 3>",
-                                                                  1280: "k_resize_cols_x32<u8, 12, 6, static rows>"}[dw]
-            key = "interp_" + name + {1920: "", 1936: "_1936", 1280: "_720p"}[dw]
-            out.append({"filter": name, "geometry": f"{sw}x{sh}->{dw}x{dh}", "kernel": kern,
+            kern = "k_resize<u8, 2>" if name == "bilinear" else {1920: "k_resize_cols_x2<u8, 12, 6, 3>", 1936: "k_resize_cols_ws<u8, 12, 6, 3, 4>",
+                                                                  1280: "k_resize_cols_x32<u8, 12, 6, static rows>",
+                                                                  1278: "k_resize_cols_ws<u8, 12, 6, 4, 5>", 1277: "k_resize_cols_ws<u8, 3, 6, 4, 5>"}[dw]
+            key = "interp_" + name + {1920: "", 1936: "_1936", 1280: "_720p", 1278: "_1278", 1277: "_rgb_1277"}[dw]
+            out.append({"filter": name, "format": fmt.name, "geometry": f"{sw}x{sh}->{dw}x{dh}", "kernel": kern,
                         "us_per_frame": round(ms * 1e3 / n, 3), "bytes_moved_per_frame": b,
                         "roofline": roofline(key, b, n, ms, k)})
             del sets
-    return {"config": f"interp PySurfaceResizer NV12 3840x2160->1920x1088 / 1936x1088, 1920x1080->1280x720 (non-integer ratios), batch={n}, one launch per filter",
+    return {"config": f"interp PySurfaceResizer NV12 3840x2160->1920x1088 / 1936x1088, 1920x1080->1280x720 / 1278x718, RGB 1920x1080->1277x719 (non-integer ratios), batch={n}, one launch per filter",
             "bytes_note": "whole source + destination per frame", "results": out}
 
 
 def upscale(n=64):
     """Planes that GROW (the upscale to display size) under the reference's filter: NV12 720p -> 1080p (exactly 3:2 both ways:
     the static form k_resize_rows_x23) and 720p -> 1600x900 (5:4, no special form: k_resize_rows_reg, the row pass and the vertical
-    window in registers, no LDS stage)."""
+    window in registers, no LDS stage); and the two forms the fast paths do not cover: packed RGB 720p -> 1080p
+    (k_resize_taps) and P10 720p -> 1600x900 (k_resize_rows, the LDS-staged rows form)."""
     out = []
-    rs = vali.PySurfaceResizer(vali.NV12, DEV)                     # Lanczos-3, the reference's (and the task's default) filter
-    for (sw, sh, dw, dh) in ((1280, 720, 1920, 1080), (1280, 720, 1600, 900)):
-        b = (sw * sh + dw * dh) * 3 // 2
+    for (fmt, sw, sh, dw, dh) in ((vali.NV12, 1280, 720, 1920, 1080), (vali.NV12, 1280, 720, 1600, 900), (vali.RGB, 1280, 720, 1920, 1080),
+                                  (vali.P10, 1280, 720, 1600, 900)):
+        rs = vali.PySurfaceResizer(fmt, DEV)                       # Lanczos-3, the reference's (and the task's default) filter
+        b = {vali.NV12: (sw * sh + dw * dh) * 3 // 2, vali.RGB: (sw * sh + dw * dh) * 3, vali.P10: (sw * sh + dw * dh) * 3}[fmt]
         k = sets_needed(b * n)
 
         def make():
-            srcs = [vali.Surface.Make(vali.NV12, sw, sh, DEV) for _ in range(n)]
-            dsts = [vali.Surface.Make(vali.NV12, dw, dh, DEV) for _ in range(n)]
+            srcs = [vali.Surface.Make(fmt, sw, sh, DEV) for _ in range(n)]
+            dsts = [vali.Surface.Make(fmt, dw, dh, DEV) for _ in range(n)]
             fill(srcs)
             return srcs, dsts, rs.PrepareBatch(srcs, dsts)
         sets = make_sets(k, make)
         ms, _ = timed(rs.Stream, [lambda q=q: rs.RunBatchAsync(q) for _, _, q in sets], 30)
-        out.append({"filter": "lanczos", "geometry": f"{sw}x{sh}->{dw}x{dh}",
-                    "kernel": "k_resize_rows_x23<u8, 12, 6, 48>" if 3 * sw == 2 * dw else "k_resize_rows_reg<64, 1, 2>",
+        kern = ("k_resize_taps<u8, 3, 6>" if fmt == vali.RGB else "k_resize_rows<u16, 12, 6, 32>" if fmt == vali.P10
+                else "k_resize_rows_x23<u8, 12, 6, 48>" if 3 * sw == 2 * dw else "k_resize_rows_reg<64, 1, 2>")
+        key = f"upscale_{dw}x{dh}" + ("" if fmt == vali.NV12 else "_" + fmt.name.lower())
+        out.append({"filter": "lanczos", "format": fmt.name, "geometry": f"{sw}x{sh}->{dw}x{dh}", "kernel": kern,
                     "us_per_frame": round(ms * 1e3 / n, 3), "bytes_moved_per_frame": b,
-                    "roofline": roofline(f"upscale_{dw}x{dh}", b, n, ms, k)})
+                    "roofline": roofline(key, b, n, ms, k)})
         del sets
-    return {"config": f"upscale PySurfaceResizer NV12 1280x720 -> 1920x1080 / 1600x900 Lanczos (planes that grow), batch={n}, one launch",
+    return {"config": f"upscale PySurfaceResizer 1280x720 -> 1920x1080 / 1600x900 Lanczos (planes that grow: NV12, packed RGB, P10), batch={n}, one launch",
             "bytes_note": "whole source + destination per frame", "results": out}
+
+
+def affine(n=64):
+    """PySurfaceRotator at an angle that is no quarter turn (the reference's nppiRotate: RotateSurface.cpp:22-159): RGB 1080p by 30
+    degrees, bilinear, destination of the same size (k_rotate_affine)."""
+    w, h = 1920, 1080
+    rot = vali.PySurfaceRotator(DEV)
+    b = 2 * w * h * 3
+    k = sets_needed(b * n)
+
+    def make():
+        srcs = [vali.Surface.Make(vali.RGB, w, h, DEV) for _ in range(n)]
+        dsts = [vali.Surface.Make(vali.RGB, w, h, DEV) for _ in range(n)]
+        fill(srcs)
+        return srcs, dsts, rot.PrepareBatch(srcs, dsts)
+    sets = make_sets(k, make)
+    ms, _ = timed(rot.Stream, [lambda q=q: rot.RunBatchAsync(q, angle=30.0, shift_x=0.0, shift_y=0.0) for _, _, q in sets], 30)
+    return {"config": f"affine PySurfaceRotator RGB 1920x1080 by 30 degrees (bilinear), batch={n}, one launch", "kernel": "k_rotate_affine<u8, 3>",
+            "us_per_frame": round(ms * 1e3 / n, 3), "bytes_moved_per_frame": b,
+            "bytes_note": "whole source + destination (the corners of the destination sample outside the source and are not fetched)",
+            "roofline": roofline("affine_rgb_30", b, n, ms, k)}
 
 
 def cfg4(n=64):
@@ -405,6 +441,6 @@ def ud_scales(n=32):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["hl1080", "cfg2", "cfg3", "interp", "upscale", "cfg4", "udgen", "udplanar"]
+    which = sys.argv[1:] or ["hl1080", "cfg2", "cfg3", "interp", "upscale", "cfg4", "udgen", "udplanar", "affine"]
     for name in which:
         print(json.dumps(globals()[name]()), flush=True)

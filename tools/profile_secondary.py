@@ -21,7 +21,7 @@ from collections import defaultdict
 from pathlib import Path
 
 ROOT = Path(os.environ.get("GRAFT_REPO_ROOT", Path(__file__).resolve().parent.parent))
-TAG = os.environ.get("VALI_PROFILE_TAG", "r04")
+TAG = os.environ.get("VALI_PROFILE_TAG", "r05")
 OUT = ROOT / "gpurun_out" / f"prof_{TAG}_secondary"
 # config key -> (bench_configs function, kernel-name substring, frames per launch)
 KEYS = {
@@ -29,7 +29,9 @@ KEYS = {
     "cfg3": ("cfg3", "k_resize_pointk<", 64),
     "interp_bilinear": ("interp", "k_resize<", 64),
     "interp_lanczos": ("interp", "k_resize_cols_x2<", 64),        # 2160p -> 1920x1088: exactly 2:1 along x
-    "interp_lanczos_1936": ("interp", "k_resize_cols<", 64),      # 2160p -> 1936x1088: the general columns-first form
+    "interp_lanczos_1936": ("interp", "k_resize_cols_ws<unsigned char, 12, 6, 3, 4>", 64),   # 2160p -> 1936x1088: the general columns-first form
+    "interp_lanczos_1278": ("interp", "k_resize_cols_ws<unsigned char, 12, 6, 4, 5>", 64),   # NV12 1080p -> 1278x718: 4 slots, wide tiles
+    "interp_lanczos_rgb_1277": ("interp", "k_resize_cols_ws<unsigned char, 3, 6, 4, 5>", 64),  # packed RGB 1080p -> 1277x719
     "interp_lanczos_720p": ("interp", "k_resize_cols_x32<", 64),  # 1080p -> 720p: 3:2 both ways
     "cfg4_ud": ("cfg4", "k_ud_half<", 64),
     "cfg4_rot": ("cfg4", "k_rotate_tile", 64),
@@ -41,6 +43,9 @@ KEYS = {
     "udplanar_16bit": ("udplanar", "k_resize_up2<unsigned short", 64),
     "upscale_1920x1080": ("upscale", "k_resize_rows_x23<", 64),        # 720p -> 1080p Lanczos (3:2 both ways)
     "upscale_1600x900": ("upscale", "k_resize_rows_reg<", 64),         # 720p -> 1600x900 (general growing planes, register form)
+    "upscale_1920x1080_rgb": ("upscale", "k_resize_taps<", 64),        # packed RGB 720p -> 1080p: rows-first gather kernel
+    "upscale_1600x900_p10": ("upscale", "k_resize_rows<", 64),         # P10 720p -> 1600x900: LDS-staged rows form
+    "affine_rgb_30": ("affine", "k_rotate_affine", 64),               # RGB 1080p by 30 degrees
 }
 
 
@@ -70,7 +75,29 @@ def collect(cfg):
     return pmc, stats
 
 
+def names():
+    """--names: which kernels does every config dispatch?  One quick kernel-trace run per config (VALI_BENCH_QUICK: small
+    sets, two launches per entry); prints {config: [kernel names]} as one JSON line.  tests/test_gpu_bench.py holds the
+    committed traffic file against it: a profile of a kernel the library no longer launches fails a test."""
+    out = {}
+    for cfg in sorted({spec[0] for spec in KEYS.values()}):
+        d = OUT / ("names_" + cfg)
+        d.mkdir(parents=True, exist_ok=True)
+        cmd = [sys.executable, str(ROOT / "tools" / "bench_configs.py"), cfg]
+        with open(d / "trace.log", "w") as fh:
+            subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", str(d / "trace"), "-o", "t", "--"] + cmd,
+                           stdout=fh, stderr=subprocess.STDOUT, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", VALI_BENCH_QUICK="1"))
+        seen = set()
+        for f in glob.glob(str(d / "trace" / "**" / "*kernel_stats.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                seen.add(r["Name"].replace("void vali::", "").split("(")[0])
+        out[cfg] = sorted(seen)
+    print(json.dumps(out))
+
+
 def main():
+    if "--names" in sys.argv:
+        return names()
     done, table, result = {}, [], {}
     for key, spec in KEYS.items():
         cfg, needle, frames = spec[:3]
