@@ -177,8 +177,10 @@ class _AvSource:
         self.num_frames = int(self._stream.frames or 0)
         self.color_space = self._SPACE.get(int(getattr(cc, "colorspace", 2) or 2), ColorSpace.UNSPEC)
         self.color_range = self._RANGE.get(int(getattr(cc, "color_range", 0) or 0), ColorRange.UDEF)
-        guessed = getattr(self._stream, "guessed_rate", None) or getattr(self._stream, "base_rate", None) or rate
-        self.r_framerate = float(guessed) if guessed else self.framerate          # r_frame_rate; != avg rate <=> VFR
+        # r_frame_rate (TaskDecodeFrame.cpp:908-922) is PyAV's base_rate; guessed_rate (av_guess_frame_rate) may fall back to the
+        # average or the codec rate and is only the stand-in when base_rate is missing
+        base = getattr(self._stream, "base_rate", None) or getattr(self._stream, "guessed_rate", None) or rate
+        self.r_framerate = float(base) if base else self.framerate                 # != avg rate <=> VFR
         tb = getattr(self._stream, "time_base", None)
         self.time_base = float(tb) if tb else 0.0
         st = getattr(self._stream, "start_time", None)
@@ -188,7 +190,11 @@ class _AvSource:
         self.bit_rate = int(getattr(cc, "bit_rate", 0) or getattr(self._container, "bit_rate", 0) or 0)
         self.gop_size = int(getattr(cc, "gop_size", 0) or 0)
         self.delay = int(getattr(cc, "delay", 0) or 0)
-        self.profile, self.level = getattr(cc, "profile", None), int(getattr(cc, "level", 0) or 0)
+        prof = getattr(cc, "profile", None)            # PyAV: a name (str) or None; the reference reports codecpar->profile (int)
+        if not isinstance(prof, int):
+            prof = next((int(getattr(o, "profile")) for o in (getattr(self._stream, "codecpar", None),)
+                         if o is not None and isinstance(getattr(o, "profile", None), int)), 0 if prof is None else prof)
+        self.profile, self.level = prof, int(getattr(cc, "level", 0) or 0)
         self.num_streams = len(getattr(self._container.streams, "video", [])) if not hasattr(self._container.streams, "__len__") \
             else len(self._container.streams)
         self.stream_index = int(getattr(self._stream, "index", 0) or 0)
@@ -207,11 +213,30 @@ class _AvSource:
 
     def set_mode(self, mode: DecodeMode) -> None:
         """KEY_FRAMES: the codec skips everything but key frames (AVDISCARD_NONKEY, TaskDecodeFrame.cpp SetMode)."""
+        want = "NONKEY" if DecodeMode(mode) == DecodeMode.KEY_FRAMES else "DEFAULT"
+        cc = self._stream.codec_context
+        err = None
+        for value in self._skip_values(want):          # the SkipType enum of recent PyAV first, then the plain name
+            try:
+                cc.skip_frame = value
+                err = None
+                break
+            except Exception as e:                      # noqa: BLE001 -- a setter that rejects this spelling
+                err = e
+        if err is not None:                             # never report a mode the codec is not in
+            raise RuntimeError(f"PyDecoder.SetMode: this PyAV cannot set skip_frame={want}: {err}")
         self.mode = DecodeMode(mode)
+
+    @staticmethod
+    def _skip_values(name: str):
         try:
-            self._stream.codec_context.skip_frame = "NONKEY" if self.mode == DecodeMode.KEY_FRAMES else "DEFAULT"
-        except Exception:
+            import av
+            skip_type = getattr(getattr(av.codec, "context", None), "SkipType", None)
+            if skip_type is not None and hasattr(skip_type, name):
+                yield getattr(skip_type, name)
+        except Exception:                               # noqa: BLE001
             pass
+        yield name
 
     def metadata(self) -> dict:
         """{"context": {...}, "video_stream": {...}} like GetMetaData (TaskDecodeFrame.cpp:846-870)"""
@@ -228,6 +253,8 @@ class _AvSource:
         (KEY_FRAMES mode: the key frame itself).  The target is in stream time-base units and includes the stream's
         start_time; seeking by frame number is refused on variable-frame-rate input (NOT_SUPPORTED)."""
         if self.is_vfr and ctx.IsByNumber:
+            return None, TaskExecInfo.NOT_SUPPORTED
+        if ctx.IsByNumber and not self.r_framerate > 0.0:      # no usable frame rate: a frame number has no timestamp
             return None, TaskExecInfo.NOT_SUPPORTED
         ts_sec = ctx.seek_frame / self.r_framerate if ctx.IsByNumber else ctx.seek_tssec
         tb = self.time_base or 1e-6
@@ -247,8 +274,9 @@ class _AvSource:
             pts = getattr(self.last_frame, "pts", None)
             # frame pts are absolute stream timestamps, so the comparison is against the target WITH start_time.  (The
             # reference's loop reads `m_frame->pts + start_time < timestamp` with timestamp already offset: for streams
-            # whose start_time is not 0 that stops start_time ticks early -- a quirk, not reproduced.)
-            if pts is None or int(pts) >= target or self.mode == DecodeMode.KEY_FRAMES:
+            # whose start_time is not 0 that stops start_time ticks early -- a known deviation, README "parity gaps".)
+            # A frame without pts (AV_NOPTS_VALUE) keeps the loop going, as in the reference: NOPTS + start_time < timestamp.
+            if self.mode == DecodeMode.KEY_FRAMES or (pts is not None and int(pts) >= target):
                 return data, None
 
     def read(self) -> Optional[np.ndarray]:

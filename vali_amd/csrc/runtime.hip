@@ -257,14 +257,23 @@ struct WaitSlot {
   }
 };
 std::mutex g_wait_mutex;
-// (device, stream) -> slot.  shared_ptr: a waiter keeps its slot alive while vali_stream_destroy drops the map's entry
-std::unordered_map<uint64_t, std::shared_ptr<WaitSlot>> g_wait_slots;
+// (device, stream) -> slot.  shared_ptr: a waiter keeps its slot alive while vali_stream_destroy drops the map's entry.
+// The map itself is never destroyed (a leaked heap object): its slots would call hipHostFree from a static destructor,
+// while or after the HIP runtime tears itself down -- slots of streams still alive at exit are left to the process.
+std::unordered_map<uint64_t, std::shared_ptr<WaitSlot>>& g_wait_slots = *new std::unordered_map<uint64_t, std::shared_ptr<WaitSlot>>();
 
 uint64_t wait_key(int device, hipStream_t s) { return ((uint64_t)(unsigned)device << 56) ^ (uint64_t)(uintptr_t)s; }
 
 void drop_wait_slot(int device, hipStream_t s) {
-  std::lock_guard<std::mutex> lock(g_wait_mutex);
-  g_wait_slots.erase(wait_key(device, s));   // a recycled stream handle starts with a fresh slot
+  std::shared_ptr<WaitSlot> gone;             // (freed AFTER the lock is released: hipHostFree may synchronise the device,
+  {                                           // and every vali_stream_wait on another stream takes this mutex)
+    std::lock_guard<std::mutex> lock(g_wait_mutex);
+    auto it = g_wait_slots.find(wait_key(device, s));
+    if (it != g_wait_slots.end()) {
+      gone = std::move(it->second);
+      g_wait_slots.erase(it);                 // a recycled stream handle starts with a fresh slot
+    }
+  }
 }
 
 std::shared_ptr<WaitSlot> wait_slot(int device, hipStream_t s) {

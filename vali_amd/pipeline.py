@@ -443,8 +443,9 @@ class IngestRing:
         return out
 
     def feed(self, chunks, fill: Optional[Callable] = None):
-        """The loop of the class comment as a generator: every item of `chunks` is a uint8 array of up to n frames (or
-        anything `fill(slot.host, item)` understands, which may return the number of frames it wrote); yields
+        """The loop of the class comment as a generator: every item of `chunks` is a uint8 array of 1..n whole frames (or
+        anything `fill(slot.host, item)` understands; `fill` returns None -- it filled all n frames of the slot -- or the
+        NUMBER of frames it wrote, an int in 1..n: a bool or anything else is a TypeError, not a count); yields
         (tag, dsts) of finished slots in submission order -- only the VALID outputs: a final chunk shorter than a slot
         yields that many surfaces, never the stale frames an earlier chunk left in the slot's tail.  The consumer runs
         between two submissions, i.e. before the slot it is looking at can be reused."""
@@ -454,10 +455,15 @@ class IngestRing:
             slot = self.acquire()
             if fill is not None:
                 wrote = fill(slot.host, item)
-                valid = self.n if wrote is None else int(wrote)
+                if wrote is None:
+                    valid = self.n
+                elif isinstance(wrote, (int, np.integer)) and not isinstance(wrote, (bool, np.bool_)) and 1 <= int(wrote) <= self.n:
+                    valid = int(wrote)
+                else:
+                    raise TypeError(f"IngestRing.feed: fill() returns None or the number of frames it wrote (1..{self.n}), got {wrote!r}")
             else:
                 a = np.asarray(item, np.uint8).reshape(-1)
-                if a.size % self.frame_bytes or a.size > self.n * self.frame_bytes:
+                if a.size == 0 or a.size % self.frame_bytes or a.size > self.n * self.frame_bytes:
                     raise ValueError(f"IngestRing.feed: a chunk is 1..{self.n} whole frames of {self.frame_bytes} bytes")
                 slot.host[:a.size] = a
                 valid = a.size // self.frame_bytes

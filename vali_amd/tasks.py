@@ -281,17 +281,24 @@ class _SurfaceTask:
         keeps allocating on the device it had selected.  Done by wrapping the methods of THIS instance, so tasks on real
         streams -- whose device the library reads off the stream -- keep their call path untouched; the wrappers hold a
         weak reference to the task (no self-referencing cycle: the task's events and memo go when its last user does)."""
+        import inspect
         import weakref
 
         gpu, ref = self._gpu_id, weakref.ref(self)
         for name in dir(type(self)):
             if name.startswith("Run") or name == "PrepareBatch":
+                # (getattr_static: the raw class attribute -- getattr resolves descriptors, so a static Run* helper would
+                # look like a plain function here and be called with an extra `me`)
+                if isinstance(inspect.getattr_static(type(self), name), (staticmethod, classmethod)):
+                    continue
                 unbound = getattr(type(self), name)
-                if isinstance(getattr(type(self), name, None), (staticmethod, classmethod)) or not callable(unbound):
+                if not callable(unbound):
                     continue
 
-                def call(*a, _fn=unbound, **k):
+                def call(*a, _fn=unbound, _name=name, **k):
                     me = ref()
+                    if me is None:     # a bound method kept (`f = task.Run`) after the task itself was dropped
+                        raise ReferenceError(f"{_name}: the task this method belonged to no longer exists")
                     prev = shim.device_get()
                     if prev != gpu:
                         shim.device_set(gpu)
