@@ -750,16 +750,16 @@ __device__ __forceinline__ void cols_tile(const uint8_t* sp, int spitch, int sw,
 
 constexpr int kWsBlock = 2 * kWave;
 constexpr int kWsStripBytes = kColStrip * 8;                  // one strip: kColStrip slots of two floats
-constexpr int kWsObuf = 2 * 2 * kColStrip;                    // floats: behind the two strips, the transposition (64 NS elements x 2 rows)
+constexpr int kWsProg = 2 * 2 * kColStrip;                    // floats: the producer's program, behind the two strips
 // NS: sets of 64 dst elements a consumer lane filters -- 4 (256-element tiles), or 5: at ratios below 2:1 the 512 source
 // elements a producer row loads cover up to 320 dst elements, and a 256-element tile leaves a quarter of its lanes without data
-// (1080p -> 1278x718: 50 of 64)
-template <int NS> constexpr int kWsProg = kWsObuf + 2 * kWave * NS; // the producer's program
-// ... of kWsProgRows entries whatever the entry size: the kernels of 4 and 6 slots (and of float planes) run five or four
-// waves per SIMD by their registers, so the LDS of their 8-dword entries is free -- 112 rows instead of 64: 45 dst rows per tile
-// at 3:2 instead of 32, half the source rows walked twice
-constexpr int kWsProgRows = 112;
-template <int P, bool ACT, int NS> constexpr int kWsLds = kWsProg<NS> + kWsProgRows * (kProgEsz<P, ACT> + 1); // floats of a workgroup
+// (1080p -> 1278x718: 50 of 64).  The transposition of a pair's results (64 NS slots) has no LDS of its own: it goes into the
+// head of the strip the results came from, once all of a pair's tap reads have returned -- the producer does not touch that
+// strip before the next barrier.
+// Program entries: 224 rows of 5 dwords, 160 of 9 (the kernels of 4 and 6 slots and of float planes run five or four waves per
+// SIMD by their registers): 110 / 75 dst rows per tile at 2:1, 96 at 3:2.
+template <int P, bool ACT> constexpr int kWsProgRows = kProgEsz<P, ACT> == 4 ? 224 : 160;
+template <int P, bool ACT> constexpr int kWsLds = kWsProg + kWsProgRows<P, ACT> * (kProgEsz<P, ACT> + 1); // floats of a workgroup
 
 __device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -824,6 +824,70 @@ __device__ __forceinline__ void ws_row_taps(v2f32& ra, v2f32& rb, u32 a0, u32 a1
   }
   ra = t0;
   rb = u0;
+}
+
+// The program of a specialised producer: cols_rows<BYSLOT> for up to 128 dst rows -- two rounds of "lane rr evaluates row rr" --
+// without the exchange between lanes: what a row needs of the row P before it (does that one complete on my first source row?) is
+// that row's tap index, a table entry or three instructions.  Twice the rows per tile: the TAPS - 1 source rows two tiles share
+// are walked twice per 190 rows instead of per 95 (HBM traffic 1.08 -> 1.04 x at 2160p -> 1936x1088).
+template <int TAPS, int P, bool ACT, int D, int NPROG>
+__device__ __forceinline__ void ws_rows(int sh, int dh, int y_first, int last_rr, float* prog, ColProg& r, const float4* ytab) {
+  constexpr int kBefore = LzTap<TAPS>::kBefore;
+  constexpr int ESZ = kProgEsz<P, ACT>;
+  constexpr int CW = ESZ == 4 ? 3 : 6;                          // dword of the control word
+  const int lane = threadIdx.x & 63;
+  const float scale_y = (float)sh / (float)dh;
+  auto idx = [&](int y) { return ytab ? __float_as_int(ytab[2 * y + 1].z) : (int)__builtin_floorf((float)y * scale_y); }; // make_lz_tap's i
+  r.y_first = y_first;
+  r.last_rr = last_rr;
+  r.s_begin = __builtin_amdgcn_readfirstlane(idx(y_first)) - kBefore;
+  r.ns = __builtin_amdgcn_readfirstlane(idx(y_first + last_rr)) + TAPS - kBefore - r.s_begin;
+  u32* const ent = reinterpret_cast<u32*>(prog);
+  float* const first_w = prog + NPROG * ESZ;
+  r.first_w = first_w;
+  r.lds = (u32)(uintptr_t)(__attribute__((address_space(3))) float*)prog;
+#pragma unroll
+  for (int t = lane; t < NPROG; t += kWave) {
+    const u32 ctl = (u32)clampi(r.s_begin + min(t + D, r.ns - 1), sh - 1); // (see cols_rows)
+    if constexpr (ESZ == 4) {
+      *reinterpret_cast<uint4*>(ent + 4 * t) = make_uint4(0u, 0u, 0u, ctl);
+    } else {
+      *reinterpret_cast<uint4*>(ent + 8 * t) = make_uint4(0u, 0u, 0u, 0u);
+      *reinterpret_cast<uint4*>(ent + 8 * t + 4) = make_uint4(0u, 0u, ctl, 0u);
+    }
+    first_w[t] = 0.0f;
+  }
+  wave_lds_sync();
+#pragma unroll 1
+  for (int base = 0; base <= last_rr; base += kWave) {          // (wave-uniform)
+    const int rr = base + lane;
+    if (rr <= last_rr) {
+      const LzTap<TAPS> vy = lz_tap_of<TAPS>(ytab, y_first + rr, scale_y);
+      const int t0 = vy.i - kBefore - r.s_begin;
+      // the row P before this one is still open on this row's first source row, i.e. completes there (the host's P admits
+      // nothing else): this row's first weight goes to first_w, the walk restarts the slot with it
+      const bool enters = rr >= P && idx(y_first + rr - P) + TAPS - 1 - kBefore - r.s_begin >= t0;
+      const int slot = rr % P;
+      if (enters) {
+        first_w[t0] = vy.w[0];
+        __hip_atomic_fetch_or(ent + ESZ * t0 + CW, kProgDbl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      } else {
+        prog[ESZ * t0 + slot] = vy.w[0];
+      }
+#pragma unroll
+      for (int k = 1; k < TAPS; ++k)
+        prog[ESZ * (t0 + k) + slot] = vy.w[k];
+      if constexpr (ACT) {
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k)
+          if (k > 0 || !enters)
+            __hip_atomic_fetch_or(ent + ESZ * (t0 + k) + CW + 1, 1u << slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+      const u32 fin = kProgDone | (((rr & 1) != 0 || rr == last_rr) ? kProgPair : 0u);
+      __hip_atomic_fetch_or(ent + ESZ * (t0 + TAPS - 1) + CW, fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+  }
+  wave_lds_sync();
 }
 
 // One window (the fifth set of a wide tile).
@@ -966,7 +1030,7 @@ __device__ __forceinline__ void cols_tile_ws(const uint8_t* sp, int spitch, int 
 
   if (role == 0) {
     ColProg r;
-    cols_rows<TAPS, P, EB == 4, D, true, kWsProgRows>(sh, dh, ty, rps, lds + kWsProg<NS>, r, ytab);
+    ws_rows<TAPS, P, EB == 4, D, kWsProgRows<P, EB == 4>>(sh, dh, y_first, last_rr, lds + kWsProg, r, ytab);
     const int nl = min((((sx1 + 1) * ES - j_begin) + kColEl - 1) / kColEl, kWave); // lanes with data
     const bool ragged = j_begin + kColEl * nl > row_el;           // wave-uniform: only a row's last tile
     const int j0 = min(j_begin + kColEl * min(lane, nl - 1), row_el - kColEl);
@@ -1005,8 +1069,7 @@ __device__ __forceinline__ void cols_tile_ws(const uint8_t* sp, int spitch, int 
     ha[p][0] = lds_base + 8u * (u32)(ch * SEG + col_slot<ES>(q));
     ha[p][1] = lds_base + 8u * (u32)(ch * SEG + col_slot<ES>(q + 1));
   }
-  v2f32* const obuf = reinterpret_cast<v2f32*>(lds + kWsObuf);
-  const u32 obuf_rd = lds_base + 4u * (u32)kWsObuf + 32u * (u32)lane;
+  const u32 obuf_rd = lds_base + 32u * (u32)lane;                          // (+ the strip's offset)
   const bool pad_left = ux0 < 0, pad_right = ux1 > sw - 1;                 // wave-uniform
   const int edge = kColPadL + (sw - 1) - px_begin;                         // the last pixel of the row
   const int eb = e0 + 4 * lane;                                            // store: 4 adjacent elements
@@ -1056,23 +1119,22 @@ __device__ __forceinline__ void cols_tile_ws(const uint8_t* sp, int spitch, int 
           st[ch * SEG + col_slot<ES>(edge + 1 + i)] = st[ch * SEG + col_slot<ES>(edge)];
         wave_lds_sync();
       }
+      v2f32 res[NS];
 #pragma unroll
-      for (int half = 0; half + 1 < NS; half += 2) {
-        v2f32 ra, rb;
-        ws_row_taps<TAPS, B * kWsStripBytes>(ra, rb, ha[half][0], ha[half][1], ha[half + 1][0], ha[half + 1][1], wq[half], wq[half + 1]);
-        obuf[half * kWave + lane] = ra;
-        obuf[(half + 1) * kWave + lane] = rb;
-      }
-      if constexpr ((NS & 1) != 0) {
-        v2f32 ra;
-        ws_row_taps1<TAPS, B * kWsStripBytes>(ra, ha[NS - 1][0], ha[NS - 1][1], wq[NS - 1]);
-        obuf[(NS - 1) * kWave + lane] = ra;
-      }
+      for (int half = 0; half + 1 < NS; half += 2)
+        ws_row_taps<TAPS, B * kWsStripBytes>(res[half], res[half + 1], ha[half][0], ha[half][1], ha[half + 1][0], ha[half + 1][1], wq[half], wq[half + 1]);
+      if constexpr ((NS & 1) != 0)
+        ws_row_taps1<TAPS, B * kWsStripBytes>(res[NS - 1], ha[NS - 1][0], ha[NS - 1][1], wq[NS - 1]);
+      // (every tap read of the pair has returned -- each block above ends with lgkmcnt(0): the head of the strip is free)
+      v2f32* const obuf = strip + B * kColStrip;
+#pragma unroll
+      for (int p = 0; p < NS; ++p)
+        obuf[p * kWave + lane] = res[p];
       wave_lds_sync();
       if (n_out > 0) {
         float4 v0, v1; // (a0, b0, a1, b1), (a2, b2, a3, b3)
-        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(v0), "=&v"(v1) : "v"(obuf_rd) : "memory");
+        asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(v0), "=&v"(v1) : "v"(obuf_rd), "i"(B * kWsStripBytes), "i"(B * kWsStripBytes + 16) : "memory");
         if constexpr (!ONLYB) {
           store_row(soff, eb, n_out, v0.x, v0.z, v1.x, v1.z);
           store_row(soff + dpitch, eb, n_out, v0.y, v0.w, v1.y, v1.w);
@@ -1083,8 +1145,8 @@ __device__ __forceinline__ void cols_tile_ws(const uint8_t* sp, int spitch, int 
       if constexpr (NS > 4) {
         if (n_out2 > 0) { // elements 256 .. of the tile: lanes 0 .. 15
           float4 v0, v1;
-          asm volatile("ds_read_b128 %0, %2 offset:2048\n\tds_read_b128 %1, %2 offset:2064\n\ts_waitcnt lgkmcnt(0)"
-                       : "=&v"(v0), "=&v"(v1) : "v"(obuf_rd) : "memory");
+          asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(v0), "=&v"(v1) : "v"(obuf_rd), "i"(B * kWsStripBytes + 2048), "i"(B * kWsStripBytes + 2064) : "memory");
           if constexpr (!ONLYB) {
             store_row(soff, eb + 256, n_out2, v0.x, v0.z, v1.x, v1.z);
             store_row(soff + dpitch, eb + 256, n_out2, v0.y, v0.w, v1.y, v1.w);
@@ -1409,7 +1471,7 @@ __global__ void __launch_bounds__(kBlock) k_resize_cols(const ResizeArgs a) {
 template <int EB, int P> constexpr int kWsWaves = EB == 4 ? (P <= 3 ? 4 : 3) : P <= 3 ? (EB == 2 ? 5 : 6) : P <= 4 ? 5 : 4;
 template <typename T, int ESSET, int TAPS, int P, int NS>
 __global__ void __launch_bounds__(kWsBlock, (kWsWaves<(int)sizeof(T), NS == 4 ? P : P < 4 ? 4 : P>)) k_resize_cols_ws(const ResizeArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[kWsLds<P, sizeof(T) == 4, NS>];
+  __shared__ __attribute__((aligned(16))) float lds[kWsLds<P, sizeof(T) == 4>];
   ResizeJob job;
   u32 tx, ty, frame;
   if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
@@ -1524,7 +1586,7 @@ static void launch_slots(const ResizeArgs& a, int slots, int xform, dim3 grid, h
   }
   if (xform == 5) { // the general form on specialised waves: a workgroup = producer + consumer of ONE tile
     const int cap = tuning(VALI_TUNE_WAVES_PER_CU); // (measurements: workgroups per CU = cap / 2, by unused dynamic LDS)
-    constexpr int kLds = kWsLds<P0, sizeof(T) == 4, 4> * 4;
+    constexpr int kLds = kWsLds<P0, sizeof(T) == 4> * 4;
     const unsigned dyn = cap >= 2 && 160 * 1024 / (cap / 2) > kLds ? (unsigned)(160 * 1024 / (cap / 2) - kLds) & ~15u : 0u;
 #define VALI_WS_LAUNCH(P, NS) hipLaunchKernelGGL((k_resize_cols_ws<T, ESSET, TAPS, P, NS>), grid, dim3(kWsBlock), dyn, stream, a)
     if (a.cols_n > 4 * kWave) { // wide tiles: five sets per consumer lane
@@ -1625,8 +1687,9 @@ int launch_resize_cols(const ResizeArgs& base, int elem, int taps, int src_w, in
   }
   if (ws)
     tile_n = tile_w;
-  const int prog_rows = ws ? kWsProgRows : (P <= 3 && elem != 4) ? kProgRows<3, false> : kProgRows<6, true>;
-  int rps_max = 64 / P;
+  // (specialised waves: programs of 224 / 160 entries, and two rounds of 64 lanes evaluate the rows' taps)
+  const int prog_rows = ws ? ((P <= 3 && elem != 4) ? kWsProgRows<3, false> : kWsProgRows<6, true>) : (P <= 3 && elem != 4) ? kProgRows<3, false> : kProgRows<6, true>;
+  int rps_max = (ws ? 128 : 64) / P;
   for (int k = 0; k < a.njobs; ++k) {
     const double sy = (double)(src_h >> a.job[k].ssub_y) / (double)(dst_h >> a.job[k].sub_y) * (1.0 + 1e-6);
     while (rps_max > 0 && (P * rps_max - 1) * sy + taps + 1 + 8 > (double)prog_rows)
