@@ -75,7 +75,7 @@ def collect(cfg):
     return pmc, stats
 
 
-def names():
+def kernel_names():
     """--names: which kernels does every config dispatch?  One quick kernel-trace run per config (VALI_BENCH_QUICK: small
     sets, two launches per entry); prints {config: [kernel names]} as one JSON line.  tests/test_gpu_bench.py holds the
     committed traffic file against it: a profile of a kernel the library no longer launches fails a test."""
@@ -97,7 +97,7 @@ def names():
 
 def main():
     if "--names" in sys.argv:
-        return names()
+        return kernel_names()
     done, table, result = {}, [], {}
     for key, spec in KEYS.items():
         cfg, needle, frames = spec[:3]
