@@ -94,6 +94,7 @@ template <int P, bool ACT> constexpr int kProgRows = (P <= 3 && !ACT) ? 112 : 64
 constexpr int kColProg = 576;                                      // floats: entries + first_w
 static_assert(kProgRows<3, false> * (kProgEsz<3, false> + 1) <= kColProg && kProgRows<6, true> * (kProgEsz<6, true> + 1) <= kColProg, "program size");
 constexpr u32 kProgDone = 1u << 24, kProgDbl = 1u << 25, kProgPair = 1u << 26, kProgSingle = 1u << 27; // (27: the pair is ONE row, the wave's last)
+constexpr int kProgSlotShift = 28; // bits 28 .. 30 (ws_rows): the slot of the dst row that completes -- the walk keeps no counter
 struct ColProg {
   u32 lds;            // LDS byte address of entry 0 (kept in a VGPR: the ds_read's address operand)
   const float* first_w;
@@ -294,7 +295,9 @@ __device__ __forceinline__ void cols_walk(const ColProg& r, const uint8_t* sp, i
   // its scalar base, but the compiler adds the row offset to a 64-bit VECTOR sp + lane_off instead: a v_lshl_add_u64 per row.)
   // Planes stay below 4 GiB (planes_fit_32bit, common.hpp); nothing past a row's last element is ever addressed.
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(sp), (short)0, (int)0xffffffffu, 0x00020000);
-  auto issue = [&](u32 row_off, u32 (&q)[ND]) {
+  // (row_off: the scalar offset operand; in the loop it is 0 and the row sits in lane_off: v_mad_u32_u24(control word, pitch,
+  // lane offset) -- ONE vector instruction, which also ignores the flag bits above bit 23, instead of s_and + s_mul)
+  auto issue = [&](u32 row_off, u32 (&q)[ND], u32 lane_off) {
     if constexpr (ND == 2) {
       const v2u32 w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)lane_off, (int)row_off, 0);
       q[0] = w.x; q[1] = w.y;
@@ -318,24 +321,33 @@ __device__ __forceinline__ void cols_walk(const ColProg& r, const uint8_t* sp, i
   // (scheduling barriers: vmcnt retires in order, the rows must be ISSUED in order -- DESIGN.md 5d)
 #pragma unroll
   for (int j = 0; j < D; ++j) {
-    issue((u32)(clampi(r.s_begin + min(j, r.ns - 1), sh - 1) * spitch), pf[j]);
+    issue((u32)(clampi(r.s_begin + min(j, r.ns - 1), sh - 1) * spitch), pf[j], lane_off);
     __builtin_amdgcn_sched_barrier(0);
   }
   u32 vprog = r.lds;
   asm volatile("" : "+v"(vprog)); // (a VGPR: entry t0 + d is then an offset field, not a scalar add and a copy per row)
-  v4f32 e0 = *(lds_v4*)(uintptr_t)vprog, e1 = (v4f32){0.0f, 0.0f, 0.0f, 0.0f};
+  // (entry 0 by the same assembly as the others: a compiler-visible first load makes the compiler wait for it in EVERY row, in
+  // front of the assembly's own wait)
+  v4f32 e0, e1 = (v4f32){0.0f, 0.0f, 0.0f, 0.0f};
+  asm volatile("ds_read_b128 %0, %1" : "=v"(e0) : "v"(vprog));
   if constexpr (ESZ == 8)
-    e1 = *(lds_v4*)(uintptr_t)(vprog + 16u);
+    asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(e1) : "v"(vprog));
   vprog += (u32)(ESZ * 4); // (entry t0 + 1: the entries the trip fetches sit at offsets >= 0 -- ds offsets are unsigned, and behind
   asm volatile("" : "+v"(vprog)); // entry t0 the compiler subtracted a constant from the advanced pointer for every row)
   int emit_rr = 0; // the next dst row to complete
-  int slot = 0;    // BYSLOT: emit_rr mod P
   v2f32 cc[NF];    // BYSLOT: the column results of the row that completes
 #pragma unroll 1
   for (int t0 = 0; t0 < r.ns; t0 += D) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       const int t = t0 + d;
+      // (the wait for this row's entry in FRONT of the conversions: between the assembly and the v_readfirstlane of the
+      // control word the compiler wants a wait state, and finds the conversions there instead of adding an s_nop)
+      if constexpr (ESZ == 8)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e0), "+v"(e1));
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e0));
+      __builtin_amdgcn_sched_barrier(0);
       v2f32 f[NF];
       conv(pf[d], f);
       // (the load after the conversions, into the registers they just freed: hoisted above them it gets new registers,
@@ -344,15 +356,11 @@ __device__ __forceinline__ void cols_walk(const ColProg& r, const uint8_t* sp, i
       for (int i = 0; i < NF; ++i)
         asm volatile("" : "+v"(f[i])); // (pins the conversions in front of the barrier: they have no other order)
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (ESZ == 8)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e0), "+v"(e1));
-      else
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e0));
       // (__float_as_uint of a vector element: __builtin_bit_cast applied to the element lvalue e1.w read element 0)
       const u32 ctl = __float_as_uint(ESZ == 4 ? e0.w : e1.z);
       const u32 actv = __float_as_uint(e1.w);
       const u32 flags = (u32)__builtin_amdgcn_readfirstlane((int)ctl);
-      issue((flags & 0xffffffu) * (u32)spitch, pf[d]);
+      issue(0u, pf[d], __umul24(ctl, (u32)spitch) + lane_off);
       const v4f32 c0 = e0, c1 = e1;
       // the next row's entry: in flight under this row's arithmetic
       // (assembly: the offset is an immediate of the instruction -- the compiler advanced a second pointer by v_add for every
@@ -391,9 +399,15 @@ __device__ __forceinline__ void cols_walk(const ColProg& r, const uint8_t* sp, i
           // of integer planes; float planes restart with +0 itself).  ONE block of assembly, branches included: written in
           // C++ -- with or without tied operands -- the compiler turns the switch into selects over all P sets or copies
           // whole sets at its joins (r04: version G), 16-24 moves per dst row instead of 4.
+          // (the slot: three bits of the control word; the first weight of the row that enters: read AND waited for by one block of
+          // assembly inside the branch -- a compiler-visible LDS read makes every completion wait for the entry prefetch as well)
+          const int slot = (int)((flags >> kProgSlotShift) & 7u);
           v2f32 w2 = (v2f32){0.0f, 0.0f};
-          if (flags & kProgDbl)
-            w2.x = r.first_w[t];
+          if (flags & kProgDbl) {
+            float wx;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(wx) : "v"((u32)(uintptr_t)(__attribute__((address_space(3))) const float*)(r.first_w + t)));
+            w2.x = wx;
+          }
           auto fin_to = [&](v2f32 (&c)[NF]) {
           if constexpr (NF == 4 && !ACT && (P == 2 || P == 3 || P == 4 || P == 6)) {
             cols_fin<P>(acc, c, w2, f, slot);
@@ -424,7 +438,6 @@ __device__ __forceinline__ void cols_walk(const ColProg& r, const uint8_t* sp, i
           // own registers -- brings the copies at the joins back, and spills)
           fin_to(cc);
           take(flags, cc);
-          slot = slot + 1 == P ? 0 : slot + 1;
         }
         continue;
       }
@@ -883,7 +896,7 @@ __device__ __forceinline__ void ws_rows(int sh, int dh, int y_first, int last_rr
           if (k > 0 || !enters)
             __hip_atomic_fetch_or(ent + ESZ * (t0 + k) + CW + 1, 1u << slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       }
-      const u32 fin = kProgDone | (((rr & 1) != 0 || rr == last_rr) ? kProgPair : 0u);
+      const u32 fin = kProgDone | (((rr & 1) != 0 || rr == last_rr) ? kProgPair : 0u) | ((u32)slot << kProgSlotShift);
       __hip_atomic_fetch_or(ent + ESZ * (t0 + TAPS - 1) + CW, fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
   }
@@ -952,10 +965,7 @@ __device__ __forceinline__ void ws_produce(const ColProg& r, const uint8_t* sp, 
     if (!(flags & kProgPair)) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        hold[i] = c[i];
-      // (this arm must not END with a store: the compiler then merges it with the last strip write of the other arm into one
-      // flat_store through a select between a scratch address and an LDS address, and `hold` lives in scratch)
-      asm volatile("");
+        asm volatile("v_mov_b64 %0, %1" : "=v"(hold[i]) : "v"(c[i])); // (assembly: see the end of this function)
       return;
     }
     v2f32 lo[4], hi[4]; // (row a, row b) of this lane's columns 2 i / 2 i + 1 (ES = 2: U / V of pixel i)
