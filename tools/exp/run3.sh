@@ -1,3 +1,5 @@
-cp ab/libvali_hip_H1.so vali_amd/libvali_hip.so
-for rep in 1 2; do for r in 26 31 34 38 42 0; do echo -n "2160p rps=$((r-10)): "; VALI_RESIZE_NO_SEPARABLE=$r python tools/resize_one.py lanczos 3840 2160 1936 1088 2>&1 | grep -v amdgpu; done; done
-for r in 18 21 26 34 0; do echo -n "1080p rps=$((r-10)): "; VALI_RESIZE_NO_SEPARABLE=$r python tools/resize_one.py lanczos 1920 1080 1278 718 2>&1 | grep -v amdgpu; done
+for c in "lanczos 1280 720 1600 900" "lanczos 1280 720 1920 1080" "lanczos 1280 720 1920 1080 RGB" "lanczos 1920 1080 1278 718"; do
+  tag=$(echo $c | tr ' ' '_')
+  bash tools/prof_pmc.sh $tag "python /root/repo/tools/resize_one.py $c" > gpurun_out/prof_$tag.txt 2>&1
+  echo "== $c"; grep -E "^void|SQ_INSTS_(VALU|SALU|LDS|BRANCH|SMEM|VMEM_RD)|ACTIVE_INST_(ANY|VALU|SCA|LDS|MISC|VMEM)|SQ_WAVES " gpurun_out/prof_$tag.txt | awk '{print $1, $NF}'; tail -3 gpurun_out/prof_$tag.txt | head -2 | cut -c1-120
+done

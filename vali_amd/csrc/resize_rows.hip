@@ -541,14 +541,16 @@ __device__ __forceinline__ void rows_reg_tile(const uint8_t* sp, int spitch, int
   const bool any_right = __builtin_amdgcn_readfirstlane((int)(__ballot(mv > 0) != 0ull)) != 0;
   const u32 goff = (u32)(a0 * ES);
   struct Row { u32 w[ND]; };
+  // (through a raw buffer descriptor: the row's offset is the scalar operand, the lane's the one VGPR of the address)
+  const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(sp), (short)0, (int)0xffffffffu, 0x00020000);
   auto issue = [&](int logical, Row& q) {
-    const uint8_t* p = sp + (u32)(clampi(logical, sh - 1) * spitch) + goff;
+    const int row = clampi(logical, sh - 1) * spitch;
     if constexpr (ND == 3) {
       typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
-      const v3u32 v = gload_u<v3u32>(p);
+      const v3u32 v = __builtin_amdgcn_raw_buffer_load_b96(srsrc, (int)goff, row, 0);
       q.w[0] = v.x; q.w[1] = v.y; q.w[2] = v.z;
     } else {
-      const v4u32 v = gload_u<v4u32>(p);
+      const v4u32 v = __builtin_amdgcn_raw_buffer_load_b128(srsrc, (int)goff, row, 0);
       q.w[0] = v.x; q.w[1] = v.y; q.w[2] = v.z; q.w[3] = v.w;
     }
   };
@@ -563,6 +565,8 @@ __device__ __forceinline__ void rows_reg_tile(const uint8_t* sp, int spitch, int
   for (int j = 0; j < TAPS; ++j)
     ring[j][0] = ring[j][1] = (v2f32){0.0f, 0.0f};
   uint8_t* optr = dp + (size_t)y_first * dpitch + (size_t)eb;
+  const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(dp, (short)0, (int)0xffffffffu, 0x00020000);
+  int orow = y_first * dpitch;                      // the dst row's offset (scalar): whole groups store through the descriptor
   const float* wt = wtab + 4;                       // weights of the next dst row
 
 #pragma unroll 1
@@ -712,14 +716,15 @@ __device__ __forceinline__ void rows_reg_tile(const uint8_t* sp, int spitch, int
         p = __builtin_amdgcn_cvt_pk_u8_f32(v[1].x, 2u, p);
         p = __builtin_amdgcn_cvt_pk_u8_f32(v[1].y, 3u, p);
         if (n_out == 4) {
-          gstore_u<u32>(optr, p);
+          __builtin_amdgcn_raw_buffer_store_b32(p, drsrc, eb, orow, 0);
         } else {
+          uint8_t* const o = optr + (u32)(orow - y_first * dpitch);
 #pragma unroll
           for (int k = 0; k < 3; ++k)
             if (k < n_out)
-              ((VALI_GLOBAL uint8_t*)optr)[k] = (uint8_t)(p >> (8 * k));
+              ((VALI_GLOBAL uint8_t*)o)[k] = (uint8_t)(p >> (8 * k));
         }
-        optr += dpitch;
+        orow += dpitch;
       };
       const int c = __builtin_amdgcn_readlane(cntv, cur - s_begin);
       if (c > 0) {
@@ -831,6 +836,21 @@ template <int WORDS> __device__ __forceinline__ R23Load<WORDS> r23_load(const ui
   }
   return g;
 }
+// the same through a raw buffer descriptor over the plane: the row's offset is the SCALAR operand, the lane's offset the one
+// VGPR of the address (resize_cols.hip cols_walk: no 64-bit vector add per row and group)
+template <int WORDS> __device__ __forceinline__ R23Load<WORDS> r23_load_b(__amdgpu_buffer_rsrc_t rsrc, u32 lane_off, u32 row_off) {
+  R23Load<WORDS> g;
+  if constexpr (WORDS == 1) {
+    g.w[0] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)lane_off, (int)row_off, 0);
+  } else if constexpr (WORDS == 2) {
+    const v2u32 q = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)lane_off, (int)row_off, 0);
+    g.w[0] = q.x; g.w[1] = q.y;
+  } else {
+    const v4u32 q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off, (int)row_off, 0);
+    g.w[0] = q.x; g.w[1] = q.y; g.w[2] = q.z; g.w[3] = q.w;
+  }
+  return g;
+}
 template <typename T, int N, int WORDS> __device__ __forceinline__ float r23_elem(const R23Load<WORDS>& g) {
   if constexpr (sizeof(T) == 1)
     return ubyte_f32<N % 4>(g.w[N / 4]);
@@ -932,10 +952,11 @@ __device__ __forceinline__ void rows23_tile(const uint8_t* sp, int spitch, int s
 
   R23Load<NW> pf[TAPS];
   R23Load<HW> hf[TAPS];
+  const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(sp), (short)0, (int)0xffffffffu, 0x00020000);
   auto issue = [&](int t, R23Load<NW>& q, R23Load<HW>& h) {
-    const uint8_t* row = sp + (u32)(clampi(s_begin + t, sh - 1) * spitch);
-    q = r23_load<NW>(row + goff);
-    h = r23_load<HW>(row + hoff);
+    const u32 row = (u32)(clampi(s_begin + t, sh - 1) * spitch);   // scalar
+    q = r23_load_b<NW>(srsrc, goff, row);
+    h = r23_load_b<HW>(srsrc, hoff, row);
   };
 #pragma unroll
   for (int j = 0; j < TAPS; ++j) {
@@ -952,6 +973,9 @@ __device__ __forceinline__ void rows23_tile(const uint8_t* sp, int spitch, int s
   const int nel = min(DE, max(0, (dw - pd) * ES)); // 6, 3 or 0
   const int full = __builtin_amdgcn_readfirstlane((X0 + kWave * PX) <= sw ? 1 : 0); // wave-uniform: every lane has its 6
   uint8_t* optr = dp + (size_t)y_first * dpitch + (size_t)pd * ES * EB;
+  const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(dp, (short)0, (int)0xffffffffu, 0x00020000);
+  const int ooff = pd * ES * EB;                   // the lane's byte offset in a dst row
+  int orow = y_first * dpitch;                     // the row's (scalar) -- the full tiles store through the descriptor
   const float* wt = wtab + 4;
   int rr = 0;
   constexpr int T0 = TAPS == 6 ? 5 : 4;            // first source row of the walk that completes a dst row
@@ -966,8 +990,8 @@ __device__ __forceinline__ void rows23_tile(const uint8_t* sp, int spitch, int s
       w1 = __builtin_amdgcn_cvt_pk_u8_f32(v[2].x, 0u, w1);
       w1 = __builtin_amdgcn_cvt_pk_u8_f32(v[2].y, 1u, w1);
       if (full) {
-        gstore_u<u32>(optr, w0);
-        gstore_u<uint16_t>(optr + 4, (uint16_t)w1);
+        __builtin_amdgcn_raw_buffer_store_b32(w0, drsrc, ooff, orow, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((short)w1, drsrc, ooff + 4, orow, 0);
       } else if (nel == DE) {
         gstore_u<u32>(optr, w0);
         gstore_u<uint16_t>(optr + 4, (uint16_t)w1);
@@ -982,7 +1006,7 @@ __device__ __forceinline__ void rows23_tile(const uint8_t* sp, int spitch, int s
       typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
       const v3u32 q = {w0, w1, w2};
       if (full) {
-        gstore_u<v3u32>(optr, q);
+        __builtin_amdgcn_raw_buffer_store_b96(q, drsrc, ooff, orow, 0);
       } else if (nel == DE) {
         gstore_u<v3u32>(optr, q);
       } else if (nel == 3) {
@@ -990,7 +1014,9 @@ __device__ __forceinline__ void rows23_tile(const uint8_t* sp, int spitch, int s
         gstore_u<uint16_t>(optr + 4, (uint16_t)w1);
       }
     }
-    optr += dpitch;
+    if (!full)
+      optr += dpitch;
+    orow += dpitch;
     wt += WT;
     ++rr;
   };
