@@ -495,7 +495,7 @@ X23_GEOMS = [(4, 2, 6, 3), (6, 4, 9, 6), (8, 6, 12, 9), (254, 34, 381, 51), (256
              (1280, 720, 1920, 1080), (128, 130, 192, 195), (516, 12, 774, 18), (268, 20, 402, 30), (1028, 24, 1542, 36), (8, 4, 12, 6)]
 
 
-@pytest.mark.parametrize("fmt", ["NV12", "Y", "YUV420", "P10", "YUV444_10bit", "YUV444"])
+@pytest.mark.parametrize("fmt", ["NV12", "Y", "YUV420", "P10", "YUV444_10bit", "YUV444", "RGB"])
 @pytest.mark.parametrize("geom", X23_GEOMS)
 @pytest.mark.parametrize("interp", ["lanczos", "cubic"])
 def test_three_to_two_enlargement_bit_exact(vali, gpu, oracle, fmt, geom, interp):
@@ -575,6 +575,37 @@ def test_growing_planes_borrowed_surfaces_with_tight_pitch(vali, gpu, oracle, ge
         want = oracle.resize_surface(host, "Y", sw, sh, dw, dh, "lanczos").reshape(dh, dw)
         assert np.array_equal(got, want), extra
         pad = np.lib.stride_tricks.as_strided(out[skew + dw:], (dh - 1, dpad - dw), (dpad, 1))
+        assert np.all(pad == 0x5a) and np.all(out[:skew] == 0x5a)
+
+
+@pytest.mark.parametrize("geom", [(334, 78, 501, 117), (8, 4, 12, 6), (130, 6, 195, 9), (258, 50, 387, 75)])
+@pytest.mark.parametrize("skew", [0, 1, 6])
+def test_three_to_two_enlargement_of_borrowed_packed_rgb(vali, gpu, oracle, geom, skew):
+    """packed RGB enlarged 3:2 (a lane owns 2 pixels = 6 bytes at ANY even offset and stores 9 at any offset): surfaces
+    borrowed from torch whose pitch is the row (+0 / +5 bytes), whose base is skewed and whose last row ends where the
+    buffer ends -- nothing may be read past it, nothing written beside the rows"""
+    import torch
+
+    sw, sh, dw, dh = geom
+    for extra in (0, 5):
+        rng = np.random.default_rng(sw + dh + skew + extra)
+        host = rng.integers(0, 256, sw * sh * 3, dtype=np.uint8)
+        sp, dpad = sw * 3 + extra, dw * 3 + 7
+        sraw = torch.zeros(skew + (sh - 1) * sp + sw * 3, dtype=torch.uint8, device="cuda")   # ends with the last row
+        sview = torch.as_strided(sraw, (sh, sw * 3), (sp, 1), skew)
+        sview.copy_(torch.from_numpy(host.reshape(sh, sw * 3)))
+        draw = torch.full((skew + dh * dpad,), 0x5a, dtype=torch.uint8, device="cuda")
+        dview = torch.as_strided(draw, (dh, dw * 3), (dpad, 1), skew)
+        torch.cuda.synchronize()
+        src = vali.Surface.from_dlpack(torch.utils.dlpack.to_dlpack(sview), vali.RGB)
+        dst = vali.Surface.from_dlpack(torch.utils.dlpack.to_dlpack(dview), vali.RGB)
+        assert (src.Width, src.Height, dst.Width, dst.Height) == (sw, sh, dw, dh)
+        assert vali.PySurfaceResizer(vali.RGB, gpu).Run(src, dst) == (True, vali.TaskExecInfo.SUCCESS)
+        out = draw.cpu().numpy()
+        got = np.lib.stride_tricks.as_strided(out[skew:], (dh, dw * 3), (dpad, 1))
+        want = oracle.resize_surface(host, "RGB", sw, sh, dw, dh, "lanczos").reshape(dh, dw * 3)
+        assert np.array_equal(got, want), extra
+        pad = np.lib.stride_tricks.as_strided(out[skew + dw * 3:], (dh - 1, dpad - dw * 3), (dpad, 1))
         assert np.all(pad == 0x5a) and np.all(out[:skew] == 0x5a)
 
 

@@ -1,5 +1,3 @@
-for c in "lanczos 1280 720 1600 900" "lanczos 1280 720 1920 1080" "lanczos 1280 720 1920 1080 RGB" "lanczos 1920 1080 1278 718"; do
-  tag=$(echo $c | tr ' ' '_')
-  bash tools/prof_pmc.sh $tag "python /root/repo/tools/resize_one.py $c" > gpurun_out/prof_$tag.txt 2>&1
-  echo "== $c"; grep -E "^void|SQ_INSTS_(VALU|SALU|LDS|BRANCH|SMEM|VMEM_RD)|ACTIVE_INST_(ANY|VALU|SCA|LDS|MISC|VMEM)|SQ_WAVES " gpurun_out/prof_$tag.txt | awk '{print $1, $NF}'; tail -3 gpurun_out/prof_$tag.txt | head -2 | cut -c1-120
-done
+timeout 900 python -m pytest tests/test_gpu_resize.py -x -q -m gpu -k "three_to_two or growing" 2>&1 | tail -3
+timeout 300 python tools/stress_resize.py 11 60 2>&1 | tail -3
+bash tools/exp/ab.sh "R5 R6" "lanczos 1280 720 1920 1080 RGB" "cubic 1280 720 1920 1080 RGB" "lanczos 2560 1440 3840 2160 RGB" 2>&1 | grep -v amdgpu.ids; cp ab/libvali_hip_R6.so vali_amd/libvali_hip.so

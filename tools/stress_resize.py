@@ -17,7 +17,7 @@ t0 = time.time(); n_ok = 0
 up, down = vali.PyFrameUploader(DEV), vali.PySurfaceDownloader(DEV)
 while time.time() - t0 < budget:
     name, dt, even = FORMATS[rng.integers(len(FORMATS))]
-    kind = rng.integers(8)
+    kind = rng.integers(9)
     if kind == 0:   sw, sh, dw, dh = rng.integers(2, 200, 4)
     elif kind == 1: sw, sh = rng.integers(300, 2600), rng.integers(2, 120); dw, dh = rng.integers(2, 2600), rng.integers(2, 200)
     elif kind == 2: sw, sh = rng.integers(2, 64), rng.integers(2, 64); dw, dh = rng.integers(200, 1800), rng.integers(50, 300)      # big upscale
@@ -25,6 +25,7 @@ while time.time() - t0 < budget:
     elif kind == 4: sw, sh = 4 * int(rng.integers(1, 500)), int(rng.integers(1, 300)); dw, dh = 2 * sw, 2 * sh                     # doubled both ways: resize_up2 for one-channel planes
     elif kind == 5: dw, dh = rng.integers(4, 1300), rng.integers(2, 400); sw = 2 * dw; sh = int(dh * rng.uniform(1.0, 4.5)) + 1        # 2:1 along x, shrinking rows: columns-first x2 form
     elif kind == 7: dw, dh = 16 * int(rng.integers(1, 110)), rng.integers(2, 400); sw = dw * 3 // 2; sh = int(dh * rng.uniform(1.0, 4.5)) + 1   # 3:2 along x, shrinking rows: the uniform-weight form
+    elif kind == 8: sw, sh = 2 * int(rng.integers(2, 700)), 2 * int(rng.integers(1, 200)); dw, dh = sw * 3 // 2, sh * 3 // 2               # 3:2 enlargement: the static-tap form (1, 2 channels, packed RGB)
     elif kind == 6: sw, sh = rng.integers(8, 2600), rng.integers(100, 900); dw = int(sw * rng.uniform(0.3, 1.6)) or 2; dh = int(sh / rng.uniform(1.0, 7.0)) or 2  # every slot count of the columns-first form
     else:           sw, sh = rng.integers(250, 1100), rng.integers(60, 400); dw = int(sw * rng.uniform(0.4, 2.2)) or 2; dh = int(sh * rng.uniform(0.4, 2.2)) or 2
     sw, sh, dw, dh = (int(max(2, v)) for v in (sw, sh, dw, dh))

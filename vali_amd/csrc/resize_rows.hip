@@ -817,7 +817,7 @@ static bool rows_reg_fits(int sw, int dw, int c, int& d2, int& d3) {
 // wave instructions per 6 in the general kernel above.
 template <typename T, int ES> struct R23 {
   static constexpr int kPx = ES == 1 ? 4 : 2;                    // source pixels per lane
-  static constexpr int kWords = kPx * ES * (int)sizeof(T) / 4;   // dwords of the lane's group: 1 (u8) or 2 (u16)
+  static constexpr int kWords = (kPx * ES * (int)sizeof(T) + 3) / 4; // dwords of the lane's group: 1 (u8), 2 (u16; packed RGB: 6 bytes)
   static constexpr int kHaloWords = 4 * ES * (int)sizeof(T) / 4; // the halo group is always 4 pixels
 };
 template <int WORDS> struct R23Load {
@@ -845,10 +845,21 @@ template <int WORDS> __device__ __forceinline__ R23Load<WORDS> r23_load_b(__amdg
   } else if constexpr (WORDS == 2) {
     const v2u32 q = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)lane_off, (int)row_off, 0);
     g.w[0] = q.x; g.w[1] = q.y;
+  } else if constexpr (WORDS == 3) {
+    typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+    const v3u32 q = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)lane_off, (int)row_off, 0);
+    g.w[0] = q.x; g.w[1] = q.y; g.w[2] = q.z;
   } else {
     const v4u32 q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off, (int)row_off, 0);
     g.w[0] = q.x; g.w[1] = q.y; g.w[2] = q.z; g.w[3] = q.w;
   }
+  return g;
+}
+// two packed 8-bit RGB pixels: 6 bytes that start at any even address and end where the row may end -- 4 + 2
+__device__ __forceinline__ R23Load<2> r23_load_b6(__amdgpu_buffer_rsrc_t rsrc, u32 lane_off, u32 row_off) {
+  R23Load<2> g;
+  g.w[0] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)lane_off, (int)row_off, 0);
+  g.w[1] = (u32)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)lane_off + 4, (int)row_off, 0);
   return g;
 }
 template <typename T, int N, int WORDS> __device__ __forceinline__ float r23_elem(const R23Load<WORDS>& g) {
@@ -864,6 +875,44 @@ __device__ __forceinline__ float r23_shl1(float old, float v) { // lane l gets l
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
 
+__device__ __forceinline__ u32 r23_shr1(u32 old, u32 v) { // the same on packed bytes
+  return (u32)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ u32 r23_shl1(u32 old, u32 v) {
+  return (u32)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x130, 0xf, 0xf, false);
+}
+// byte N of the 6 bytes (lo: 4, hi: 2) of two packed RGB pixels
+template <int N> __device__ __forceinline__ float r23_byte6(u32 lo, u32 hi) {
+  if constexpr (N < 4)
+    return ubyte_f32<N>(lo);
+  else
+    return ubyte_f32<N - 4>(hi);
+}
+// the two filtered samples of a dst triple from the pixel pairs around them (two-channel and packed RGB planes): d1 starts at
+// an even tap position, d2 at an odd one (6 taps; the other way round with 4)
+template <int TAPS>
+__device__ __forceinline__ void r23_pair_chains(const v2f32 (&wa)[TAPS / 2], const v2f32 (&wb)[TAPS / 2 + 1], v2f32 p0, v2f32 p1, v2f32 p2,
+                                                v2f32 p3, float& d1, float& d2) {
+  if constexpr (TAPS == 6) {
+    v2f32 a1 = wa[0] * p0, a2 = wb[0] * p0;
+    a1 = __builtin_elementwise_fma(wa[1], p1, a1); a2 = __builtin_elementwise_fma(wb[1], p1, a2);
+    a1 = __builtin_elementwise_fma(wa[2], p2, a1); a2 = __builtin_elementwise_fma(wb[2], p2, a2);
+    a2 = __builtin_elementwise_fma(wb[3], p3, a2);
+    d1 = a1.x + a1.y;
+    d2 = a2.y + a2.x;
+  } else {
+    v2f32 a1 = wb[0] * p0, a2 = wa[0] * p1;
+    a1 = __builtin_elementwise_fma(wb[1], p1, a1); a2 = __builtin_elementwise_fma(wa[1], p2, a2);
+    a1 = __builtin_elementwise_fma(wb[2], p2, a1);
+    d1 = a1.y + a1.x;
+    d2 = a2.x + a2.y;
+    (void)p3;
+  }
+  v2f32 d = {d1, d2}; // (the sums land in the register pair the ring keeps them in)
+  asm volatile("" : "+v"(d));
+  d1 = d.x; d2 = d.y;
+}
+
 template <typename T, int ES, int TAPS, int RW>
 __device__ __forceinline__ void rows23_tile(const uint8_t* sp, int spitch, int sw, int sh, uint8_t* dp, int dpitch,
                                             int dw, int dh, u32 tx, u32 ty, float* wg_lds, int wave_floats) {
@@ -872,7 +921,10 @@ __device__ __forceinline__ void rows23_tile(const uint8_t* sp, int spitch, int s
   constexpr int WT = 4 + 2 * TAPS;
   constexpr int PX = R23<T, ES>::kPx, NW = R23<T, ES>::kWords, HW = R23<T, ES>::kHaloWords;
   constexpr int NF = ES == 1 ? 4 : 2;   // filtered (non-copy) samples per lane whose weights are kept: d1 d2 (d4 d5)
-  constexpr int DE = 6;                 // dst ELEMENTS per lane (6 pixels, or 3 pixels x 2 channels)
+  constexpr int DE = ES == 1 ? 6 : 3 * ES; // dst ELEMENTS per lane (6 pixels, or 3 pixels x 2 / 3 channels)
+  constexpr int NP = DE / 2;            // ... as register pairs
+  constexpr bool TAIL = (DE & 1) != 0;  // ... and a single register (packed RGB: 9 elements)
+  static_assert(ES < 3 || EB == 1, "three channels: 8-bit packed RGB only");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int X0 = (int)tx * (kWave * PX);               // first source pixel of the tile
@@ -928,9 +980,15 @@ __device__ __forceinline__ void rows23_tile(const uint8_t* sp, int spitch, int s
     const LzTap<TAPS> vy = make_lz_tap<TAPS>(min(y_first + lane, dh - 1), scale_y);
     if (lane < RW) {
       float* row = wtab + lane * WT;
+      if constexpr (ES == 3) { // as they are: the column pass picks the half it needs (op_sel), 3 registers instead of 6 pairs
+        *reinterpret_cast<float4*>(row + 4) = make_float4(vy.w[0], vy.w[1], vy.w[2], vy.w[3]);
+        if constexpr (TAPS == 6)
+          *reinterpret_cast<float2*>(row + 8) = make_float2(vy.w[4], vy.w[5]);
+      } else {
 #pragma unroll
-      for (int k = 0; k < TAPS / 2; ++k)
-        *reinterpret_cast<float4*>(row + 4 + 4 * k) = make_float4(vy.w[2 * k], vy.w[2 * k], vy.w[2 * k + 1], vy.w[2 * k + 1]);
+        for (int k = 0; k < TAPS / 2; ++k)
+          *reinterpret_cast<float4*>(row + 4 + 4 * k) = make_float4(vy.w[2 * k], vy.w[2 * k], vy.w[2 * k + 1], vy.w[2 * k + 1]);
+      }
     }
   }
   wave_lds_sync();
@@ -950,38 +1008,89 @@ __device__ __forceinline__ void rows23_tile(const uint8_t* sp, int spitch, int s
   const bool h_in = hp + 4 <= sw, h_straddle = !h_in && hp < sw;     // (the halo group is 4 pixels: may straddle by 2)
   const u32 goff = (u32)(gs * ES * EB), hoff = (u32)(hs * ES * EB);
 
-  R23Load<NW> pf[TAPS];
-  R23Load<HW> hf[TAPS];
+  // rows in flight: TAPS, or 3 for packed RGB under Lanczos (5 registers per row; its ring of filtered rows takes 54)
+  constexpr int AHEAD = ES == 3 && TAPS == 6 ? 3 : TAPS;
+  static_assert(TAPS % AHEAD == 0, "slot j % AHEAD of the unrolled walk must be row t % AHEAD");
+  R23Load<NW> pf[AHEAD];
+  R23Load<HW> hf[AHEAD];
+  const bool halo_lane = lane == 0 || lane == 63;
   const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(sp), (short)0, (int)0xffffffffu, 0x00020000);
   auto issue = [&](int t, R23Load<NW>& q, R23Load<HW>& h) {
     const u32 row = (u32)(clampi(s_begin + t, sh - 1) * spitch);   // scalar
-    q = r23_load_b<NW>(srsrc, goff, row);
-    h = r23_load_b<HW>(srsrc, hoff, row);
+    if constexpr (ES == 3) {
+      q = r23_load_b6(srsrc, goff, row);
+      // 12 bytes for 2 lanes of 64: the other lanes' registers hold whatever they held (nobody reads them; the empty asm
+      // "defines" them so that nothing is kept alive or copied for their sake)
+      asm volatile("" : "=v"(h.w[0]), "=v"(h.w[1]), "=v"(h.w[2]));
+      if (halo_lane)
+        h = r23_load_b<HW>(srsrc, hoff, row);
+    } else {
+      q = r23_load_b<NW>(srsrc, goff, row);
+      h = r23_load_b<HW>(srsrc, hoff, row);
+    }
   };
 #pragma unroll
-  for (int j = 0; j < TAPS; ++j) {
+  for (int j = 0; j < AHEAD; ++j) {
     issue(j, pf[j], hf[j]);
     __builtin_amdgcn_sched_barrier(0);
   }
 
-  v2f32 ring[TAPS][3]; // filtered rows: [slot][pair]; ES = 1: (d0,d1) (d2,d3) (d4,d5), ES = 2: (u,v) of the lane's 3 pixels
+  // filtered rows: [slot][pair]; ES = 1: (d0,d1) (d2,d3) (d4,d5), ES = 2: (u,v) of the lane's 3 pixels, ES = 3: the 9 elements
+  // r0 g0 b0 r1 ... b2 of its 3 pixels two by two
+  v2f32 ring[TAPS][NP];
+  float rtail[TAPS];
 #pragma unroll
-  for (int j = 0; j < TAPS; ++j)
-    ring[j][0] = ring[j][1] = ring[j][2] = (v2f32){0.0f, 0.0f};
+  for (int j = 0; j < TAPS; ++j) {
+#pragma unroll
+    for (int g = 0; g < NP; ++g)
+      ring[j][g] = (v2f32){0.0f, 0.0f};
+    rtail[j] = 0.0f;
+  }
 
   // ---- output: 6 elements per lane, lanes contiguous
-  const int nel = min(DE, max(0, (dw - pd) * ES)); // 6, 3 or 0
+  const int nel = min(DE, max(0, (dw - pd) * ES)); // DE, 3 (ES = 1) or 0
   const int full = __builtin_amdgcn_readfirstlane((X0 + kWave * PX) <= sw ? 1 : 0); // wave-uniform: every lane has its 6
   uint8_t* optr = dp + (size_t)y_first * dpitch + (size_t)pd * ES * EB;
   const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(dp, (short)0, (int)0xffffffffu, 0x00020000);
   const int ooff = pd * ES * EB;                   // the lane's byte offset in a dst row
   int orow = y_first * dpitch;                     // the row's (scalar) -- the full tiles store through the descriptor
+  const int quad_lane = lane & 3;                  // packed RGB: where the lane's dwords of its quad's 36 bytes start, and the
+  const int quad_off = ooff - quad_lane;           // byte selector that assembles them (v_perm_b32 over {own dword, dword before})
+  const u32 quad_sel = 0x07060504u - 0x01010101u * (u32)quad_lane;
+  (void)quad_off; (void)quad_sel;
   const float* wt = wtab + 4;
   int rr = 0;
   constexpr int T0 = TAPS == 6 ? 5 : 4;            // first source row of the walk that completes a dst row
 
-  auto store_row = [&](const v2f32 (&v)[3]) {
-    if constexpr (EB == 1) {
+  auto store_row = [&](const v2f32 (&v)[NP], float vt) {
+    (void)vt;
+    if constexpr (ES == 3) {
+      // 9 bytes per lane at 9 * lane: one 8-byte store from an address of any alignment + one byte
+      u32 w0 = 0, w1 = 0, w2 = 0;
+      // ring order: (d1, d2) of R, G, B, then the copied sample's R, G | B -- bytes: r0 g0 b0 r1 | g1 b1 r2 g2 | b2
+      w0 = __builtin_amdgcn_cvt_pk_u8_f32(v[3].x, 0u, w0);
+      w0 = __builtin_amdgcn_cvt_pk_u8_f32(v[3].y, 1u, w0);
+      w0 = __builtin_amdgcn_cvt_pk_u8_f32(vt, 2u, w0);
+      w0 = __builtin_amdgcn_cvt_pk_u8_f32(v[0].x, 3u, w0);
+      w1 = __builtin_amdgcn_cvt_pk_u8_f32(v[1].x, 0u, w1);
+      w1 = __builtin_amdgcn_cvt_pk_u8_f32(v[2].x, 1u, w1);
+      w1 = __builtin_amdgcn_cvt_pk_u8_f32(v[0].y, 2u, w1);
+      w1 = __builtin_amdgcn_cvt_pk_u8_f32(v[1].y, 3u, w1);
+      w2 = __builtin_amdgcn_cvt_pk_u8_f32(v[2].y, 0u, w2);
+      if (full) {
+        // whole tiles: the 4 lanes of a quad hold 36 bytes = 9 dwords; lane q stores dwords 2q, 2q + 1 (and lane 3 the ninth):
+        // they start q bytes before its own -- the tail of the lane before it, fetched within the quad
+        const u32 tail = __builtin_amdgcn_alignbyte(w2, w1, 1);                                     // the lane's bytes 5 .. 8
+        const u32 prev = (u32)__builtin_amdgcn_update_dpp(0, (int)tail, 0x90, 0xf, 0xf, true);      // quad_perm:[0,0,1,2]
+        const u32 o0 = __builtin_amdgcn_perm(w0, prev, quad_sel), o1 = __builtin_amdgcn_perm(w1, w0, quad_sel);
+        __builtin_amdgcn_raw_buffer_store_b64((v2u32){o0, o1}, drsrc, quad_off, orow, 0);
+        if (quad_lane == 3)
+          __builtin_amdgcn_raw_buffer_store_b32(tail, drsrc, quad_off + 8, orow, 0);
+      } else if (nel == DE) {
+        __builtin_amdgcn_raw_buffer_store_b64((v2u32){w0, w1}, drsrc, ooff, orow, 0);
+        __builtin_amdgcn_raw_buffer_store_b8((char)w2, drsrc, ooff + 8, orow, 0);
+      }
+    } else if constexpr (EB == 1) {
       u32 w0 = 0, w1 = 0;
       w0 = __builtin_amdgcn_cvt_pk_u8_f32(v[0].x, 0u, w0);
       w0 = __builtin_amdgcn_cvt_pk_u8_f32(v[0].y, 1u, w0);
@@ -1031,22 +1140,23 @@ __device__ __forceinline__ void rows23_tile(const uint8_t* sp, int spitch, int s
       if (live) {
         // ---- the lane's pixels and their neighbours, per channel: P[0..9] = L2 L3 f0 f1 f2 f3 R0 R1 R2 0 (ES = 1),
         // P[0..7] = Lp0 Lp1 f0 f1 Rp0 Rp1 RRp0 0 (ES = 2): aligned register pairs
+        float el[ES == 1 ? 2 : DE]; // ES >= 2: the 3 pixels' elements, channel-interleaved as they are stored
         auto channel = [&](auto ctag, v2f32& o0, v2f32& o1, v2f32& o2) {
           constexpr int C = decltype(ctag)::value;
           float f[PX], g[4];
 #pragma unroll
           for (int k = 0; k < PX; ++k)
             f[k] = 0.0f;
-          f[0] = r23_elem<T, 0 * ES + C, NW>(pf[j]);
-          f[1] = r23_elem<T, 1 * ES + C, NW>(pf[j]);
+          f[0] = r23_elem<T, 0 * ES + C, NW>(pf[j % AHEAD]);
+          f[1] = r23_elem<T, 1 * ES + C, NW>(pf[j % AHEAD]);
           if constexpr (PX == 4) {
-            f[2] = r23_elem<T, 2 * ES + C, NW>(pf[j]);
-            f[3] = r23_elem<T, 3 * ES + C, NW>(pf[j]);
+            f[2] = r23_elem<T, 2 * ES + C, NW>(pf[j % AHEAD]);
+            f[3] = r23_elem<T, 3 * ES + C, NW>(pf[j % AHEAD]);
           }
-          g[0] = r23_elem<T, 0 * ES + C, HW>(hf[j]);
-          g[1] = r23_elem<T, 1 * ES + C, HW>(hf[j]);
-          g[2] = r23_elem<T, 2 * ES + C, HW>(hf[j]);
-          g[3] = r23_elem<T, 3 * ES + C, HW>(hf[j]);
+          g[0] = r23_elem<T, 0 * ES + C, HW>(hf[j % AHEAD]);
+          g[1] = r23_elem<T, 1 * ES + C, HW>(hf[j % AHEAD]);
+          g[2] = r23_elem<T, 2 * ES + C, HW>(hf[j % AHEAD]);
+          g[3] = r23_elem<T, 3 * ES + C, HW>(hf[j % AHEAD]);
           if (edge) { // right-most tiles: groups that were moved left to stay inside the row, pixels past the row's end
             if constexpr (PX == 4) {
               f[0] = in_row ? f[0] : straddle ? f[2] : f[3];
@@ -1120,29 +1230,106 @@ __device__ __forceinline__ void rows23_tile(const uint8_t* sp, int spitch, int s
             }
             asm volatile("" : "+v"(d1), "+v"(d2));
             // pixels 3l, 3l+1, 3l+2 of this channel
-            o0.x = f[0]; o1.x = d1; o2.x = d2;
+            el[0 * ES + C] = f[0]; el[1 * ES + C] = d1; el[2 * ES + C] = d2;
             (void)o0; (void)o1; (void)o2;
-            if constexpr (C == 1) {
-              o0.y = f[0]; o1.y = d1; o2.y = d2;
-            }
           }
         };
-        if constexpr (ES == 1) {
+        if constexpr (ES == 3) {
+          // packed RGB: the neighbours travel as PACKED bytes (5 lane shifts per row, not 5 per channel) and every float is
+          // converted where it is used.  q: the lane's 2 pixels (6 bytes), h: the halo group's 4 (12 bytes; lane 0: the 4
+          // before the tile, lane 63: the 4 after its own)
+          u32 q0 = pf[j % AHEAD].w[0], q1 = pf[j % AHEAD].w[1];
+          u32 h0 = hf[j % AHEAD].w[0], h1 = hf[j % AHEAD].w[1], h2 = hf[j % AHEAD].w[2];
+          if (edge) { // right-most tiles: groups moved left to stay inside the row hold its last pixel(s) where theirs would be
+            const u32 last = (q0 >> 24) | (q1 << 8);                              // the group's second pixel
+            q0 = in_row ? q0 : (last | (last << 24));
+            q1 = in_row ? q1 : (last >> 8);
+            const u32 g2 = __builtin_amdgcn_alignbyte(h2, h1, 2) & 0xffffffu, g3 = h2 >> 8;
+            const u32 pa = h_straddle ? g2 : g3;                                  // halo pixels (pa, g3, g3, g3)
+            h0 = h_in ? h0 : (pa | (g3 << 24));
+            h1 = h_in ? h1 : ((g3 >> 8) | (g3 << 16));
+            h2 = h_in ? h2 : ((g3 >> 16) | (g3 << 8));
+          }
+          u32 la = __builtin_amdgcn_alignbyte(h2, h1, 2), lb = h2 >> 16;         // halo pixels 2 and 3 laid out like (q0, q1)
+          if (first_tile) { // pixels -1, -2 replicate pixel 0
+            asm volatile(""); // (a branch on the scalar flag: as selects this costs every tile 5 instructions per row)
+            const u32 px0 = q0 & 0xffffffu;
+            la = lane == 0 ? (px0 | (px0 << 24)) : la;
+            lb = lane == 0 ? (px0 >> 8) : lb;
+          }
+          const u32 l0 = r23_shr1(la, q0), l1 = r23_shr1(lb, q1);                // the 2 pixels before the lane's
+          const u32 r0 = r23_shl1(h0, q0), r1 = r23_shl1(h1, q1);                // the 2 after them
+          const u32 rr = r23_shl1(la, r0);                                        // the third (lane 63: halo pixel 2)
+          auto rgb = [&](auto ctag) {
+            constexpr int C = decltype(ctag)::value;
+            const v2f32 p0 = {r23_byte6<C>(l0, l1), r23_byte6<C + 3>(l0, l1)};
+            const v2f32 p1 = {r23_byte6<C>(q0, q1), r23_byte6<C + 3>(q0, q1)};
+            const v2f32 p2 = {r23_byte6<C>(r0, r1), r23_byte6<C + 3>(r0, r1)};
+            const v2f32 p3 = {ubyte_f32<C>(rr), 0.0f};
+            float d1, d2;
+            r23_pair_chains<TAPS>(wa[0], wb[0], p0, p1, p2, p3, d1, d2);
+            // (the ring keeps a channel's two filtered samples as one pair -- the chains' sums land there -- and the three
+            // copied samples behind them; store_row picks its bytes by name)
+            el[2 * C] = d1; el[2 * C + 1] = d2; el[6 + C] = p1.x;
+          };
+          rgb(std::integral_constant<int, 0>{});
+          rgb(std::integral_constant<int, 1>{});
+          rgb(std::integral_constant<int, 2>{});
+#pragma unroll
+          for (int g = 0; g < NP; ++g)
+            ring[j][g] = (v2f32){el[2 * g], el[2 * g + 1]};
+          rtail[j] = el[DE - 1];
+          (void)channel;
+        } else if constexpr (ES == 1) {
           channel(std::integral_constant<int, 0>{}, ring[j][0], ring[j][1], ring[j][2]);
         } else {
-          v2f32 u0, u1, u2, v0, v1, v2;
+          v2f32 u0, u1, u2;
           channel(std::integral_constant<int, 0>{}, u0, u1, u2);
-          channel(std::integral_constant<int, 1>{}, v0, v1, v2);
-          ring[j][0] = (v2f32){u0.x, v0.y};
-          ring[j][1] = (v2f32){u1.x, v1.y};
-          ring[j][2] = (v2f32){u2.x, v2.y};
+          channel(std::integral_constant<int, 1>{}, u0, u1, u2);
+#pragma unroll
+          for (int g = 0; g < NP; ++g)
+            ring[j][g] = (v2f32){el[2 * g], el[2 * g + 1]};
         }
       }
-      issue(t + TAPS, pf[j], hf[j]);
+      if constexpr (ES == 3)
+        __builtin_amdgcn_sched_barrier(0); // (the row pass is over before the column pass starts: their registers do not add up)
+      issue(t + AHEAD, pf[j % AHEAD], hf[j % AHEAD]);
+      if constexpr (ES == 3)
+        __builtin_amdgcn_sched_barrier(0);
       if (!live || t < T0)
         continue;
       // ---- dst rows this source row completes.  Newest filtered row: slot j; logical row r of a window: slot (j + 1 + r) % TAPS
       auto full_row = [&]() {
+        if constexpr (ES == 3) {
+          v2f32 wp[TAPS / 2];
+          const float4 qa = *reinterpret_cast<const float4*>(wt);
+          wp[0] = (v2f32){qa.x, qa.y};
+          wp[1] = (v2f32){qa.z, qa.w};
+          if constexpr (TAPS == 6) {
+            const float2 qb = *reinterpret_cast<const float2*>(wt + 4);
+            wp[2] = (v2f32){qb.x, qb.y};
+          }
+          v2f32 v[NP];
+#pragma unroll
+          for (int g = 0; g < NP; ++g) {
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(v[g]) : "v"(wp[0]), "v"(ring[(j + 1) % TAPS][g]));
+            rwr_pk_fma<1>(v[g], wp[0], ring[(j + 2) % TAPS][g]);
+#pragma unroll
+            for (int k = 1; k < TAPS / 2; ++k) {
+              rwr_pk_fma<0>(v[g], wp[k], ring[(j + 1 + 2 * k) % TAPS][g]);
+              rwr_pk_fma<1>(v[g], wp[k], ring[(j + 2 + 2 * k) % TAPS][g]);
+            }
+          }
+          float vt = wp[0].x * rtail[(j + 1) % TAPS];
+          vt = __builtin_fmaf(wp[0].y, rtail[(j + 2) % TAPS], vt);
+#pragma unroll
+          for (int k = 1; k < TAPS / 2; ++k) {
+            vt = __builtin_fmaf(wp[k].x, rtail[(j + 1 + 2 * k) % TAPS], vt);
+            vt = __builtin_fmaf(wp[k].y, rtail[(j + 2 + 2 * k) % TAPS], vt);
+          }
+          store_row(v, vt);
+          return;
+        }
         v2f32 wy[TAPS];
 #pragma unroll
         for (int k = 0; k < TAPS / 2; ++k) {
@@ -1150,15 +1337,22 @@ __device__ __forceinline__ void rows23_tile(const uint8_t* sp, int spitch, int s
           wy[2 * k] = (v2f32){q4.x, q4.y};
           wy[2 * k + 1] = (v2f32){q4.z, q4.w};
         }
-        v2f32 v[3];
+        v2f32 v[NP];
 #pragma unroll
-        for (int g = 0; g < 3; ++g) {
+        for (int g = 0; g < NP; ++g) {
           v[g] = wy[0] * ring[(j + 1) % TAPS][g];
 #pragma unroll
           for (int r = 1; r < TAPS; ++r)
             v[g] = __builtin_elementwise_fma(wy[r], ring[(j + 1 + r) % TAPS][g], v[g]);
         }
-        store_row(v);
+        float vt = 0.0f;
+        if constexpr (TAIL) {
+          vt = wy[0].x * rtail[(j + 1) % TAPS];
+#pragma unroll
+          for (int r = 1; r < TAPS; ++r)
+            vt = __builtin_fmaf(wy[r].x, rtail[(j + 1 + r) % TAPS], vt);
+        }
+        store_row(v, vt);
       };
       // parity of t == parity of j (TAPS is even).  TAPS = 6: odd rows 2M + 3 complete dst rows 3M (the filtered row 2M
       // itself: 3 slots back) and 3M + 1, even rows 2M + 4 complete 3M + 2.  TAPS = 4: even rows 2M + 2 complete 3M (2 slots
@@ -1166,8 +1360,11 @@ __device__ __forceinline__ void rows23_tile(const uint8_t* sp, int spitch, int s
       const bool two = TAPS == 6 ? (j & 1) == 1 : (j & 1) == 0; // (a constant once the walk is unrolled)
       if (two) {
         constexpr int back = TAPS == 6 ? 3 : 2;
-        const v2f32 c[3] = {ring[(j + TAPS - back) % TAPS][0], ring[(j + TAPS - back) % TAPS][1], ring[(j + TAPS - back) % TAPS][2]};
-        store_row(c);
+        v2f32 c[NP];
+#pragma unroll
+        for (int g = 0; g < NP; ++g)
+          c[g] = ring[(j + TAPS - back) % TAPS][g];
+        store_row(c, rtail[(j + TAPS - back) % TAPS]);
         if (rr <= last_rr)
           full_row();
       } else {
@@ -1193,15 +1390,33 @@ __global__ void __launch_bounds__(kBlock) k_resize_rows_x23(const ResizeArgs a) 
     rows23_tile<T, 1, TAPS, RW>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, lds, a.lds_per_wave / 4);
 }
 
+// packed 8-bit RGB: 9 register pairs more than the planes of one / two channels -- asked to fit 4 waves per SIMD
+template <int TAPS, int RW>
+__global__ void __launch_bounds__(kBlock, 4) k_resize_rows_x23_rgb(const ResizeArgs a) {
+  extern __shared__ uint4 rows_lds[];
+  ResizeJob job;
+  u32 tx, ty, frame;
+  if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
+    return;
+  const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
+  rows23_tile<uint8_t, 3, TAPS, RW>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, reinterpret_cast<float*>(rows_lds),
+                                    a.lds_per_wave / 4);
+}
+
 bool resize_x23_fits(const ResizeJob& j, int elem, int src_w, int src_h, int dst_w, int dst_h) {
   const long long sw = src_w >> j.ssub_x, sh = src_h >> j.ssub_y, dw = dst_w >> j.sub_x, dh = dst_h >> j.sub_y;
-  return (elem == 1 || elem == 2) && j.channels <= 2 && 3 * sw == 2 * dw && 3 * sh == 2 * dh && sw >= 4 && sh >= 2 &&
+  return (elem == 1 || (elem == 2 && j.channels <= 2)) && j.channels <= 3 && 3 * sw == 2 * dw && 3 * sh == 2 * dh && sw >= 4 && sh >= 2 &&
          sw < (1 << 22) && sh < (1 << 22);
 }
 
 template <typename T, int ESSET, int TAPS>
 static void launch_x23_k(const ResizeArgs& a, int rw, dim3 grid, unsigned lds, hipStream_t stream) {
-  if (rw == 48)
+  if constexpr (ESSET == 3) {
+    if (rw == 48)
+      hipLaunchKernelGGL((k_resize_rows_x23_rgb<TAPS, 48>), grid, dim3(kBlock), lds, stream, a);
+    else
+      hipLaunchKernelGGL((k_resize_rows_x23_rgb<TAPS, 12>), grid, dim3(kBlock), lds, stream, a);
+  } else if (rw == 48)
     hipLaunchKernelGGL((k_resize_rows_x23<T, ESSET, TAPS, 48>), grid, dim3(kBlock), lds, stream, a);
   else
     hipLaunchKernelGGL((k_resize_rows_x23<T, ESSET, TAPS, 12>), grid, dim3(kBlock), lds, stream, a);
@@ -1214,13 +1429,14 @@ int launch_resize_x23(const ResizeArgs& base, int elem, int taps, int src_w, int
   int esset = 0;
   for (int k = 0; k < a.njobs; ++k) {
     const int c = a.job[k].channels;
-    esset = esset == 0 ? (c == 2 ? 2 : 1) : ((esset == 1 && c == 2) || (esset == 2 && c == 1)) ? 12 : esset;
+    esset = c == 3 ? 3 : esset == 0 ? (c == 2 ? 2 : 1) : ((esset == 1 && c == 2) || (esset == 2 && c == 1)) ? 12 : esset; // (packed RGB: one plane)
   }
   auto count = [&](int rw, bool assign) {
     u32 total = 0;
     for (int k = 0; k < a.njobs; ++k) {
       const int dw = dst_w >> a.job[k].sub_x, dh = dst_h >> a.job[k].sub_y;
-      const u32 tiles_x = (u32)(dw * a.job[k].channels + 383) / 384;
+      const u32 tile_el = a.job[k].channels == 3 ? 576u : 384u; // 64 lanes x 9 / 6 dst elements
+      const u32 tiles_x = ((u32)(dw * a.job[k].channels) + tile_el - 1) / tile_el;
       if (assign) {
         a.job[k].first_tile = total;
         a.job[k].tiles_x = tiles_x;
@@ -1239,11 +1455,13 @@ int launch_resize_x23(const ResizeArgs& base, int elem, int taps, int src_w, int
 #define VALI_X23_T(T)                                                                          \
   do {                                                                                         \
     if (taps == 6) {                                                                           \
-      if (esset == 1) launch_x23_k<T, 1, 6>(a, rw, grid, lds, stream);                          \
+      if (esset == 3) launch_x23_k<uint8_t, 3, 6>(a, rw, grid, lds, stream);                    \
+      else if (esset == 1) launch_x23_k<T, 1, 6>(a, rw, grid, lds, stream);                     \
       else if (esset == 12) launch_x23_k<T, 12, 6>(a, rw, grid, lds, stream);                   \
       else launch_x23_k<T, 2, 6>(a, rw, grid, lds, stream);                                     \
     } else {                                                                                   \
-      if (esset == 1) launch_x23_k<T, 1, 4>(a, rw, grid, lds, stream);                          \
+      if (esset == 3) launch_x23_k<uint8_t, 3, 4>(a, rw, grid, lds, stream);                    \
+      else if (esset == 1) launch_x23_k<T, 1, 4>(a, rw, grid, lds, stream);                     \
       else if (esset == 12) launch_x23_k<T, 12, 4>(a, rw, grid, lds, stream);                   \
       else launch_x23_k<T, 2, 4>(a, rw, grid, lds, stream);                                     \
     }                                                                                          \
