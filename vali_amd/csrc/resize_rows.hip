@@ -1057,7 +1057,8 @@ __device__ __forceinline__ void rows23_tile(const uint8_t* sp, int spitch, int s
   const int quad_lane = lane & 3;                  // packed RGB: where the lane's dwords of its quad's 36 bytes start, and the
   const int quad_off = ooff - quad_lane;           // byte selector that assembles them (v_perm_b32 over {own dword, dword before})
   const u32 quad_sel = 0x07060504u - 0x01010101u * (u32)quad_lane;
-  (void)quad_off; (void)quad_sel;
+  const u32 quad_sel6 = 0x03020100u + 0x02020202u * (u32)quad_lane; // 6 bytes per lane (8-bit planes of 1 / 2 channels): bytes 2q .. 2q + 3
+  (void)quad_off; (void)quad_sel; (void)quad_sel6;
   const float* wt = wtab + 4;
   int rr = 0;
   constexpr int T0 = TAPS == 6 ? 5 : 4;            // first source row of the walk that completes a dst row
@@ -1099,8 +1100,16 @@ __device__ __forceinline__ void rows23_tile(const uint8_t* sp, int spitch, int s
       w1 = __builtin_amdgcn_cvt_pk_u8_f32(v[2].x, 0u, w1);
       w1 = __builtin_amdgcn_cvt_pk_u8_f32(v[2].y, 1u, w1);
       if (full) {
-        __builtin_amdgcn_raw_buffer_store_b32(w0, drsrc, ooff, orow, 0);
-        __builtin_amdgcn_raw_buffer_store_b16((short)w1, drsrc, ooff + 4, orow, 0);
+        // whole tiles: a quad's 24 bytes leave as 3 aligned 8-byte stores (lanes 0 .. 2: dwords 2q, 2q + 1 = the lane's bytes
+        // from 2q on, then the next lane's) -- as 4 + 2 bytes per lane at stride 6 every 32-byte sector was written in two
+        // partial passes (HBM traffic 1.15 x, a fifth of the kernel's time)
+        const u32 n0 = (u32)__builtin_amdgcn_update_dpp(0, (int)w0, 0xf9, 0xf, 0xf, true);   // quad_perm:[1,2,3,3]: the next lane's
+        const u32 n1 = (u32)__builtin_amdgcn_update_dpp(0, (int)w1, 0xf9, 0xf, 0xf, true);
+        const u32 z1 = __builtin_amdgcn_perm(n0, w1, 0x05040100u);                            // own 4 5, next 0 1
+        const u32 z2 = __builtin_amdgcn_alignbyte(n1, n0, 2);                                 // next 2 .. 5
+        const u32 o0 = __builtin_amdgcn_perm(z1, w0, quad_sel6), o1 = __builtin_amdgcn_perm(z2, z1, quad_sel6);
+        if (quad_lane != 3)
+          __builtin_amdgcn_raw_buffer_store_b64((v2u32){o0, o1}, drsrc, ooff + 2 * quad_lane, orow, 0);
       } else if (nel == DE) {
         gstore_u<u32>(optr, w0);
         gstore_u<uint16_t>(optr + 4, (uint16_t)w1);
