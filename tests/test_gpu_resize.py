@@ -609,6 +609,37 @@ def test_three_to_two_enlargement_of_borrowed_packed_rgb(vali, gpu, oracle, geom
         assert np.all(pad == 0x5a) and np.all(out[:skew] == 0x5a)
 
 
+@pytest.mark.parametrize("geom", [(300, 40, 375, 51), (16, 8, 40, 17), (130, 30, 259, 61), (1000, 12, 1003, 13)])
+@pytest.mark.parametrize("skew", [0, 1, 6])
+def test_growing_packed_rgb_borrowed_surfaces_with_tight_pitch(vali, gpu, oracle, geom, skew):
+    """packed RGB enlarged at general ratios (k_resize_rows_rgb: a lane loads 24 bytes from its own byte address; tiles at
+    the image's edges load their pixels one by one, 4 bytes that end with the pixel): borrowed surfaces whose pitch is the
+    row (+0 / +5 bytes), whose base is skewed and whose last row ends where the buffer ends; one tile per row, several, a
+    ragged last tile, an odd last pixel"""
+    import torch
+
+    sw, sh, dw, dh = geom
+    for extra in (0, 5):
+        rng = np.random.default_rng(sw + dh + skew + extra)
+        host = rng.integers(0, 256, sw * sh * 3, dtype=np.uint8)
+        sp, dpad = sw * 3 + extra, dw * 3 + 7
+        sraw = torch.zeros(skew + (sh - 1) * sp + sw * 3, dtype=torch.uint8, device="cuda")   # ends with the last row
+        sview = torch.as_strided(sraw, (sh, sw * 3), (sp, 1), skew)
+        sview.copy_(torch.from_numpy(host.reshape(sh, sw * 3)))
+        draw = torch.full((skew + dh * dpad,), 0x5a, dtype=torch.uint8, device="cuda")
+        dview = torch.as_strided(draw, (dh, dw * 3), (dpad, 1), skew)
+        torch.cuda.synchronize()
+        src = vali.Surface.from_dlpack(torch.utils.dlpack.to_dlpack(sview), vali.RGB)
+        dst = vali.Surface.from_dlpack(torch.utils.dlpack.to_dlpack(dview), vali.RGB)
+        assert vali.PySurfaceResizer(vali.RGB, gpu).Run(src, dst) == (True, vali.TaskExecInfo.SUCCESS)
+        out = draw.cpu().numpy()
+        got = np.lib.stride_tricks.as_strided(out[skew:], (dh, dw * 3), (dpad, 1))
+        want = oracle.resize_surface(host, "RGB", sw, sh, dw, dh, "lanczos").reshape(dh, dw * 3)
+        assert np.array_equal(got, want), extra
+        pad = np.lib.stride_tricks.as_strided(out[skew + dw * 3:], (dh - 1, dpad - dw * 3), (dpad, 1))
+        assert np.all(pad == 0x5a) and np.all(out[:skew] == 0x5a)
+
+
 def test_tap_tables_across_streams_and_inside_a_capture(vali, gpu, oracle):
     """The columns-first kernels of general ratios read their taps from per-geometry tables written by the first call
     (vali_amd/csrc/tap_table.hip).  A geometry nobody has used yet: (a) its first call on one stream and, right behind

@@ -137,6 +137,10 @@ template <typename T> __device__ __forceinline__ void gstore_u(void* p, T v) {
 template <typename T> __device__ __forceinline__ void gstore_nt(void* p, T v) {
   __builtin_nontemporal_store(v, (VALI_GLOBAL T*)p);
 }
+template <typename T> __device__ __forceinline__ void gstore_u_nt(void* p, T v) { // ... from an address of any alignment
+  typedef T TU __attribute__((aligned(1)));
+  __builtin_nontemporal_store(v, (VALI_GLOBAL TU*)p);
+}
 
 // The one-shot streaming converters (cvt_nv12_rgb.hip, cvt_generic.hip: every thread loads, converts, stores, no loop)
 // keep GENERIC pointers for their 16-byte accesses: an A/B on NV12->RGB 2160p measured flat_load/flat_store 1.2%

@@ -607,8 +607,8 @@ static int launch_resize(ResizeArgs& a, int fmt, int src_w, int src_h, int dst_w
     const int taps = interp == VALI_INTERP_LANCZOS ? 6 : 4;
     // ... and, plane by plane (UDPlanar at unchanged size: luma 1:1, chroma 1:2): planes at an integer ratio are the point
     // sample whatever the others need; one-channel planes exactly doubled both ways have their own kernel (resize_up2.hip)
-    ResizeArgs cpy = a, pts = a, up2 = a, cols = a, rows = a, grow = a, x23 = a;
-    cpy.njobs = pts.njobs = up2.njobs = cols.njobs = rows.njobs = grow.njobs = x23.njobs = 0;
+    ResizeArgs cpy = a, pts = a, up2 = a, cols = a, rows = a, grow = a, x23 = a, rgbg = a;
+    cpy.njobs = pts.njobs = up2.njobs = cols.njobs = rows.njobs = grow.njobs = x23.njobs = rgbg.njobs = 0;
     const bool rows_reg = tuning(VALI_TUNE_RESIZE_ROWS) != 0; // 0: every growing plane through k_resize_taps (round 2's kernel)
     const bool special = point_on && !gather_only && elem != 4;
     for (int k = 0; k < a.njobs; ++k) {
@@ -618,7 +618,9 @@ static int launch_resize(ResizeArgs& a, int fmt, int src_w, int src_h, int dst_w
       const bool doubled = special && a.job[k].channels <= 2 && dw == 2 * sw && dh == 2 * sh && sw % (4 / a.job[k].channels) == 0;
       const bool fits = rows_reg && sh < dh && resize_rows_fits(a.job[k], elem, src_w, dst_w, taps);
       const bool is23 = rows_reg && tuning(VALI_TUNE_RESIZE_ROWS) != 2 && special && resize_x23_fits(a.job[k], elem, src_w, src_h, dst_w, dst_h);
-      ResizeArgs& t = integer && sw == dw && sh == dh ? cpy : integer ? pts : doubled ? up2 : sh >= dh ? cols : is23 ? x23 : fits ? grow : rows;
+      const bool isrgb = rows_reg && special && sh < dh && resize_rows_rgb_fits(a.job[k], elem, taps, sw, dw);
+      ResizeArgs& t = integer && sw == dw && sh == dh ? cpy : integer ? pts : doubled ? up2 : sh >= dh ? cols : is23 ? x23 : isrgb ? rgbg
+                      : fits ? grow : rows;
       t.job[t.njobs++] = a.job[k];
     }
     // UDPlanar at unchanged size (the reference's everyday planar UD, UDSurface.cpp:84-93): the luma copy rides in the launch
@@ -642,6 +644,8 @@ static int launch_resize(ResizeArgs& a, int fmt, int src_w, int src_h, int dst_w
       rc = launch_resize_cols(cols, elem, taps, src_w, src_h, dst_w, dst_h, n, stream);
     if (rc == VALI_OK && x23.njobs)
       rc = launch_resize_x23(x23, elem, taps, src_w, src_h, dst_w, dst_h, n, stream);
+    if (rc == VALI_OK && rgbg.njobs)
+      rc = launch_resize_rows_rgb(rgbg, src_h, dst_w, dst_h, n, stream);
     if (rc == VALI_OK && grow.njobs)
       rc = launch_resize_rows(grow, elem, taps, src_w, src_h, dst_w, dst_h, n, stream);
     if (rc == VALI_OK && rows.njobs)

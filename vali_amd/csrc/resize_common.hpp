@@ -71,6 +71,9 @@ int launch_resize_rows(const ResizeArgs& a, int elem, int taps, int src_w, int s
 
 // ... and for 8 / 16-bit planes of 1 / 2 channels enlarged by exactly 3:2 on both axes (720p -> 1080p): static tap positions,
 // no LDS stage (resize_rows.hip, k_resize_rows_x23).
+// ... packed 8-bit RGB that grows on both axes at any ratio in (1/3, 1): the register form for three channels (k_resize_rows_rgb)
+bool resize_rows_rgb_fits(const ResizeJob& j, int elem, int taps, int src_w, int dst_w);
+int launch_resize_rows_rgb(const ResizeArgs& a, int src_h, int dst_w, int dst_h, int n, hipStream_t stream);
 bool resize_x23_fits(const ResizeJob& j, int elem, int src_w, int src_h, int dst_w, int dst_h);
 int launch_resize_x23(const ResizeArgs& a, int elem, int taps, int src_w, int src_h, int dst_w, int dst_h, int n,
                       hipStream_t stream);

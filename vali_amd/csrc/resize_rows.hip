@@ -36,6 +36,10 @@
 
 namespace vali {
 
+// whole-tile stores of these kernels are non-temporal (aux bit 1): a wave writes its rows once, 4 - 5 KB apart, and nobody reads
+// them back -- as plain stores they pass through the L2 like data to keep and the LOADS queue behind their write-backs:
+// RGB 720p -> 1600x900 3.77 us plain, 2.65 nt, 2.60 with every store aimed at one row, 2.40 without stores (round 5)
+constexpr int kStoreNt = 2;
 constexpr int kRwPadL = 4;       // floats in front of the first staged pixel (left edge replicas; keeps 16-byte alignment)
 constexpr int kRwTile = 256;     // dst ELEMENTS per wave and row: 2 groups x 64 lanes x 2 adjacent elements
 
@@ -459,6 +463,11 @@ template <int H> __device__ __forceinline__ void rwr_pk_fma(v2f32& acc, v2f32 w,
   else
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "v"(f));
 }
+// pixel K of packed RGB bytes held in dwords: (R, G) and B as floats
+template <int K> __device__ __forceinline__ void rgb_window_px(const u32 (&w)[7], v2f32& rg, float& b) {
+  rg = (v2f32){ubyte_f32<(3 * K) % 4>(w[(3 * K) / 4]), ubyte_f32<(3 * K + 1) % 4>(w[(3 * K + 1) / 4])};
+  b = ubyte_f32<(3 * K + 2) % 4>(w[(3 * K + 2) / 4]);
+}
 constexpr int kRrShare = 512; // floats of a wave's LDS in front of its weight table: one column tap set (64 lanes x 8)
 
 template <int ES, int ROWS, int D2, int D3>
@@ -716,7 +725,7 @@ __device__ __forceinline__ void rows_reg_tile(const uint8_t* sp, int spitch, int
         p = __builtin_amdgcn_cvt_pk_u8_f32(v[1].x, 2u, p);
         p = __builtin_amdgcn_cvt_pk_u8_f32(v[1].y, 3u, p);
         if (n_out == 4) {
-          __builtin_amdgcn_raw_buffer_store_b32(p, drsrc, eb, orow, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(p, drsrc, eb, orow, kStoreNt);
         } else {
           uint8_t* const o = optr + (u32)(orow - y_first * dpitch);
 #pragma unroll
@@ -793,6 +802,305 @@ static bool rows_reg_fits(int sw, int dw, int c, int& d2, int& d3) {
   next = (next + 1) & 7;
   d2 = e2; d3 = e3;
   return ok;
+}
+
+// =====================================================================================================================
+// Packed 8-bit RGB that grows on both axes at any ratio in (1/3, 1) (round 5): the register form for three channels.  A lane
+// owns 2 adjacent dst pixels (6 bytes).  Their windows span 7 source pixels -- pixel 1's starts with pixel 0's or one pixel
+// later, the weights absorb the difference as above (the host checks the 0 / 1 against the FP32 products the device forms) --,
+// so the lane loads the 24 bytes at ITS address 3 (floor(x0 s) - 2), whatever its alignment, converts the 21 it needs once and
+// filters from registers: a tap is one packed FMA on a pixel's (R, G) -- the weight a half of a register pair -- and one FMA on
+// its B.  The filtered rows of the vertical window stay in registers as (R, G) of pixel 0, (R, G) of pixel 1, (B, B): the
+// column pass is three packed chains per dst row whose row weights are picked by op_sel.  Whole tiles store a quad's 24 bytes
+// as three aligned 8-byte stores (as the 3:2 form below).
+// Tiles at the image's left / right edge (some lane's window leaves the row): every lane loads its 7 pixels one by one from
+// their clamped positions -- 4 bytes that END with the pixel, or start with it at pixel 0: nothing is read outside the row --
+// and packs them into the 24 bytes the other tiles load.
+constexpr int kRgbTilePx = 128;   // dst pixels per wave and row: 64 lanes x 2
+template <int ROWS>
+__device__ __forceinline__ void rows_rgb_tile(const uint8_t* sp, int spitch, int sw, int sh, uint8_t* dp, int dpitch, int dw, int dh,
+                                              u32 tx, u32 ty, float* wg_lds, int wave_floats) {
+  constexpr int TAPS = 6, kBefore = LzTap<TAPS>::kBefore, WT = 4 + 2 * TAPS, AHEAD = 3, NW = 7;
+  static_assert(ROWS <= kWave && (ROWS & (ROWS - 1)) == 0 && TAPS % AHEAD == 0, "one row tap set per lane; slot j % AHEAD is row t % AHEAD");
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int p0 = (int)tx * kRgbTilePx;
+  const int nl = (min(kRgbTilePx, dw - p0) + 1) >> 1;              // lanes with pixels
+  const int xb = p0 + 2 * min(lane, nl - 1);                       // (lanes past the row repeat its last lane, and store nothing)
+  const int n_px = lane < nl ? min(2, dw - xb) : 0;
+  const int full = __builtin_amdgcn_readfirstlane(p0 + kRgbTilePx <= dw ? 1 : 0);
+  const int y_first = (int)(ty * kWavesPerBlock + wave) * ROWS;
+  const float scale_x = (float)sw / (float)dw, scale_y = (float)sh / (float)dh;
+  float* const lds = wg_lds + wave * wave_floats;
+  float* const wtab = lds + kRrShare;
+  int* const cnt = reinterpret_cast<int*>(wtab + ROWS * WT);
+
+  // ---- column taps: the four waves of the workgroup share their columns; wave w evaluates pixel w & 1 of every lane ----
+  v2f32 W[2][4];                                                   // (W0 W1) (W2 W3) (W4 W5) (W6 0) over the 7 registers of the window
+  int first;                                                       // source pixel in the lane's register 0
+  {
+    const LzTap<TAPS> c = make_lz_tap<TAPS>(min(xb + (wave & 1), dw - 1), scale_x);
+    float* mine = lds + 8 * lane;
+    *reinterpret_cast<float4*>(mine) = make_float4(__builtin_bit_cast(float, c.i), c.w[0], c.w[1], c.w[2]);
+    *reinterpret_cast<float4*>(mine + 4) = make_float4(c.w[3], c.w[4], c.w[5], 0.0f);
+    __syncthreads();
+    int i0 = 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float* from = wg_lds + q * wave_floats + 8 * lane;
+      const float4 a = *reinterpret_cast<const float4*>(from), b = *reinterpret_cast<const float4*>(from + 4);
+      const int iq = __builtin_bit_cast(int, a.x);
+      if (q == 0)
+        i0 = iq;
+      const bool late = iq > i0;                                   // its window starts one register further on (q = 0: never)
+      const float w[6] = {a.y, a.z, a.w, b.x, b.y, b.z};
+      float s7[8];
+      s7[0] = late ? 0.0f : w[0];
+#pragma unroll
+      for (int k = 1; k < 6; ++k)
+        s7[k] = late ? w[k - 1] : w[k];
+      s7[6] = late ? w[5] : 0.0f;
+      s7[7] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        W[q][k] = (v2f32){s7[2 * k], s7[2 * k + 1]};
+    }
+    first = i0 - kBefore;
+    __syncthreads();
+  }
+  if (y_first >= dh)
+    return;
+
+  // ---- row taps: lane r evaluates row y_first + r; cnt[t]: dst rows the wave's t-th source row completes ----
+  const LzTap<TAPS> vy = make_lz_tap<TAPS>(y_first + (lane & (ROWS - 1)), scale_y);
+  const int last_rr = min(ROWS, dh - y_first) - 1;
+  const int s_begin = __builtin_amdgcn_readlane(vy.i, 0) - kBefore;
+  const int s_end = __builtin_amdgcn_readlane(vy.i, last_rr) + TAPS - 1 - kBefore;
+  cnt[lane] = 0;
+  if (lane < ROWS) {
+    float* row = wtab + lane * WT;
+    *reinterpret_cast<float4*>(row + 4) = make_float4(vy.w[0], vy.w[1], vy.w[2], vy.w[3]);
+    *reinterpret_cast<float2*>(row + 8) = make_float2(vy.w[4], vy.w[5]);
+  }
+  wave_lds_sync();
+  if (lane <= last_rr)
+    __hip_atomic_fetch_add(cnt + (vy.i + TAPS - 1 - kBefore - s_begin), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  wave_lds_sync();
+  const int cntv = cnt[lane];
+
+  // ---- the lane's window: source pixels first .. first + 6 ----
+  const int a0 = clampi(first, sw - 8);                            // (the host refuses planes narrower than 16 pixels)
+  const int edge_tile = __builtin_amdgcn_readfirstlane((int)(__ballot(first != a0) != 0ull));
+  const u32 goff = (u32)(a0 * 3);
+  u32 eoff[NW], eshift = 0;                                        // edge tiles: where pixel k's 4 bytes start; 2 bits each: by how many bytes it sits in them
+#pragma unroll
+  for (int k = 0; k < NW; ++k) {
+    const int idx = clampi(first + k, sw - 1);
+    eoff[k] = idx > 0 ? (u32)(3 * idx - 1) : 0u;
+    eshift |= (idx > 0 ? 1u : 0u) << (2 * k);
+  }
+  struct Row { u32 w[NW]; };
+  const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(sp), (short)0, (int)0xffffffffu, 0x00020000);
+  auto issue = [&](int logical, Row& q) {
+    const int row = clampi(logical, sh - 1) * spitch;              // scalar
+    if (edge_tile) {
+#pragma unroll
+      for (int k = 0; k < NW; ++k)
+        q.w[k] = __builtin_amdgcn_raw_buffer_load_b32(srsrc, (int)eoff[k], row, 0);
+    } else {
+      const v4u32 v = __builtin_amdgcn_raw_buffer_load_b128(srsrc, (int)goff, row, 0);
+      const v2u32 u = __builtin_amdgcn_raw_buffer_load_b64(srsrc, (int)goff + 16, row, 0);
+      q.w[0] = v.x; q.w[1] = v.y; q.w[2] = v.z; q.w[3] = v.w; q.w[4] = u.x; q.w[5] = u.y;
+      asm volatile("" : "=v"(q.w[6]));                             // (not loaded, not read)
+    }
+  };
+  Row pf[AHEAD];
+#pragma unroll
+  for (int j = 0; j < AHEAD; ++j) {
+    issue(s_begin + j, pf[j]);
+    __builtin_amdgcn_sched_barrier(0); // rows in ISSUE order: vmcnt retires in order
+  }
+  v2f32 ring[TAPS][3]; // filtered rows of the vertical window: [slot] = (R, G) of pixel 0, (R, G) of pixel 1, (B of 0, B of 1)
+#pragma unroll
+  for (int j = 0; j < TAPS; ++j)
+    ring[j][0] = ring[j][1] = ring[j][2] = (v2f32){0.0f, 0.0f};
+  const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(dp, (short)0, (int)0xffffffffu, 0x00020000);
+  const int ooff = xb * 3;                          // the lane's byte offset in a dst row
+  int orow = y_first * dpitch;                      // the dst row's (scalar)
+  const int quad_lane = lane & 3;
+  const u32 quad_sel6 = 0x03020100u + 0x02020202u * (u32)quad_lane;
+  const float* wt = wtab + 4;                       // weights of the next dst row
+
+#pragma unroll 1
+  for (int s0 = s_begin; s0 <= s_end; s0 += TAPS) {
+#pragma unroll
+    for (int j = 0; j < TAPS; ++j) {
+      const int cur = s0 + j;
+      const bool live = cur <= s_end; // wave-uniform; rows past the end skip the work, never the load
+      u32 w[NW];
+#pragma unroll
+      for (int k = 0; k < NW; ++k)
+        w[k] = pf[j % AHEAD].w[k];
+      if (edge_tile) { // one pixel per register -> the 24 packed bytes (v_perm_b32 picks bytes by name: what lies beside a pixel is ignored)
+        u32 px[NW];
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+          px[k] = __builtin_amdgcn_alignbyte(0u, w[k], eshift >> (2 * k));
+        w[0] = __builtin_amdgcn_perm(px[1], px[0], 0x04020100u);
+        w[1] = __builtin_amdgcn_perm(px[2], px[1], 0x05040201u);
+        w[2] = __builtin_amdgcn_perm(px[3], px[2], 0x06050402u);
+        w[3] = __builtin_amdgcn_perm(px[5], px[4], 0x04020100u);
+        w[4] = __builtin_amdgcn_perm(px[6], px[5], 0x05040201u);
+        w[5] = px[6] >> 16;
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        asm volatile("" : "+v"(w[k])); // (the row's registers are read before the load below takes them)
+      __builtin_amdgcn_sched_barrier(0);
+      issue(cur + AHEAD, pf[j % AHEAD]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!live)
+        continue;
+      // ---- the pass along the row, from registers: byte 3 k + c of the 24 is channel c of window pixel k
+      v2f32 hrg[2];
+      float hb[2];
+      {
+        v2f32 crg[NW];
+        float cb[NW];
+        rgb_window_px<0>(w, crg[0], cb[0]); rgb_window_px<1>(w, crg[1], cb[1]); rgb_window_px<2>(w, crg[2], cb[2]);
+        rgb_window_px<3>(w, crg[3], cb[3]); rgb_window_px<4>(w, crg[4], cb[4]); rgb_window_px<5>(w, crg[5], cb[5]);
+        rgb_window_px<6>(w, crg[6], cb[6]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          v2f32 e = (v2f32){0.0f, 0.0f}, o = (v2f32){0.0f, 0.0f};
+          rwr_pk_fma<0>(e, W[q][0], crg[0]);
+          rwr_pk_fma<1>(o, W[q][0], crg[1]);
+          rwr_pk_fma<0>(e, W[q][1], crg[2]);
+          rwr_pk_fma<1>(o, W[q][1], crg[3]);
+          rwr_pk_fma<0>(e, W[q][2], crg[4]);
+          rwr_pk_fma<1>(o, W[q][2], crg[5]);
+          float eb = W[q][0].x * cb[0], ob = W[q][0].y * cb[1];
+          eb = __builtin_fmaf(W[q][1].x, cb[2], eb);
+          ob = __builtin_fmaf(W[q][1].y, cb[3], ob);
+          eb = __builtin_fmaf(W[q][2].x, cb[4], eb);
+          ob = __builtin_fmaf(W[q][2].y, cb[5], ob);
+          if (q > 0) {
+            rwr_pk_fma<0>(e, W[q][3], crg[6]);
+            eb = __builtin_fmaf(W[q][3].x, cb[6], eb);
+          }
+          hrg[q] = e + o;
+          hb[q] = eb + ob;
+        }
+      }
+      asm volatile("" : "+v"(hrg[0]), "+v"(hrg[1]), "+v"(hb[0]), "+v"(hb[1]));
+      ring[j][0] = hrg[0];
+      ring[j][1] = hrg[1];
+      ring[j][2] = (v2f32){hb[0], hb[1]};
+      // ---- every dst row whose window ends with this source row; slot j is the newest row, logical row r of the window
+      // sits in slot (j + 1 + r) mod TAPS
+      auto emit = [&]() {
+        v2f32 wp[3];
+        const float4 qa = *reinterpret_cast<const float4*>(wt);
+        const float2 qb = *reinterpret_cast<const float2*>(wt + 4);
+        wp[0] = (v2f32){qa.x, qa.y};
+        wp[1] = (v2f32){qa.z, qa.w};
+        wp[2] = (v2f32){qb.x, qb.y};
+        wt += WT;
+        v2f32 v[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(v[g]) : "v"(wp[0]), "v"(ring[(j + 1) % TAPS][g]));
+          rwr_pk_fma<1>(v[g], wp[0], ring[(j + 2) % TAPS][g]);
+          rwr_pk_fma<0>(v[g], wp[1], ring[(j + 3) % TAPS][g]);
+          rwr_pk_fma<1>(v[g], wp[1], ring[(j + 4) % TAPS][g]);
+          rwr_pk_fma<0>(v[g], wp[2], ring[(j + 5) % TAPS][g]);
+          rwr_pk_fma<1>(v[g], wp[2], ring[(j + 6) % TAPS][g]);
+        }
+        u32 w0 = 0, w1 = 0; // r0 g0 b0 r1 | g1 b1
+        w0 = __builtin_amdgcn_cvt_pk_u8_f32(v[0].x, 0u, w0);
+        w0 = __builtin_amdgcn_cvt_pk_u8_f32(v[0].y, 1u, w0);
+        w0 = __builtin_amdgcn_cvt_pk_u8_f32(v[2].x, 2u, w0);
+        w0 = __builtin_amdgcn_cvt_pk_u8_f32(v[1].x, 3u, w0);
+        w1 = __builtin_amdgcn_cvt_pk_u8_f32(v[1].y, 0u, w1);
+        w1 = __builtin_amdgcn_cvt_pk_u8_f32(v[2].y, 1u, w1);
+        if (full) { // a quad's 24 bytes as three aligned 8-byte stores (rows23_tile's store_row)
+          const u32 n0 = (u32)__builtin_amdgcn_update_dpp(0, (int)w0, 0xf9, 0xf, 0xf, true);   // quad_perm:[1,2,3,3]: the next lane's
+          const u32 n1 = (u32)__builtin_amdgcn_update_dpp(0, (int)w1, 0xf9, 0xf, 0xf, true);
+          const u32 z1 = __builtin_amdgcn_perm(n0, w1, 0x05040100u);
+          const u32 z2 = __builtin_amdgcn_alignbyte(n1, n0, 2);
+          const u32 o0 = __builtin_amdgcn_perm(z1, w0, quad_sel6), o1 = __builtin_amdgcn_perm(z2, z1, quad_sel6);
+          if (quad_lane != 3)
+            __builtin_amdgcn_raw_buffer_store_b64((v2u32){o0, o1}, drsrc, ooff + 2 * quad_lane, orow, kStoreNt);
+        } else if (n_px == 2) {
+          __builtin_amdgcn_raw_buffer_store_b32(w0, drsrc, ooff, orow, 0);
+          __builtin_amdgcn_raw_buffer_store_b16((short)w1, drsrc, ooff + 4, orow, 0);
+        } else if (n_px == 1) {
+          __builtin_amdgcn_raw_buffer_store_b16((short)w0, drsrc, ooff, orow, 0);
+          __builtin_amdgcn_raw_buffer_store_b8((char)(w0 >> 16), drsrc, ooff + 2, orow, 0);
+        }
+        orow += dpitch;
+      };
+      const int c = __builtin_amdgcn_readlane(cntv, cur - s_begin);
+      if (c > 0) {
+        emit();
+        if (c > 1) {
+          emit();
+          for (int k = 2; k < c; ++k)
+            emit();
+        }
+      }
+    }
+  }
+}
+
+template <int ROWS>
+__global__ void __launch_bounds__(kBlock, 4) k_resize_rows_rgb(const ResizeArgs a) {
+  extern __shared__ uint4 rows_lds[];
+  ResizeJob job;
+  u32 tx, ty, frame;
+  if (!plane_tile(a.job, a.njobs, a.map, job, tx, ty, frame))
+    return;
+  const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
+  rows_rgb_tile<ROWS>(v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty, reinterpret_cast<float*>(rows_lds), a.lds_per_wave / 4);
+}
+
+bool resize_rows_rgb_fits(const ResizeJob& j, int elem, int taps, int src_w, int dst_w) {
+  int d2, d3;
+  return elem == 1 && taps == 6 && j.channels == 3 && j.ssub_x == 0 && j.sub_x == 0 && tuning(VALI_TUNE_RESIZE_ROWS) != 0 &&
+         tuning(VALI_TUNE_RESIZE_ROWS) != 3 && tuning(VALI_TUNE_RESIZE_FORCE_GATHER) != 1 && rows_reg_fits(src_w, dst_w, 3, d2, d3);
+}
+
+int launch_resize_rows_rgb(const ResizeArgs& base, int src_h, int dst_w, int dst_h, int n, hipStream_t stream) {
+  const int force = tuning(VALI_TUNE_RESIZE_NO_SEPARABLE); // 1 / 2 / 3: 8- / 2- / 32-row waves whatever the launch size
+  ResizeArgs a = base;
+  auto count = [&](int rows, bool assign) {
+    u32 total = 0;
+    for (int k = 0; k < a.njobs; ++k) {
+      const u32 tiles_x = (u32)(dst_w + kRgbTilePx - 1) / kRgbTilePx;
+      if (assign) {
+        a.job[k].first_tile = total;
+        a.job[k].tiles_x = tiles_x;
+      }
+      total += tiles_x * (u32)((dst_h + kWavesPerBlock * rows - 1) / (kWavesPerBlock * rows));
+    }
+    return total;
+  };
+  // rows per wave as launch_resize_rows chooses them (long waves when the launch stays full and the wave's source rows fit
+  // its 64-entry completion table)
+  const bool fits64 = 64.0 * (double)src_h / (double)dst_h * (1.0 + 1e-6) + 6 + 2 <= 64.0;
+  const unsigned long long t64 = (unsigned long long)count(64, false) * (unsigned)n, t32 = (unsigned long long)count(32, false) * (unsigned)n,
+                           t8 = (unsigned long long)count(8, false) * (unsigned)n;
+  const int rows = force == 1 ? 8 : force == 2 ? 2 : force == 3 ? 32 : (fits64 && (force == 4 || t64 >= 1024ull)) ? 64 : t32 >= 1024ull ? 32 : t8 >= 320ull ? 8 : 2;
+  a.map = make_tile_map_linear(count(rows, true), (u32)n);
+  a.lds_per_wave = (kRrShare + rows * (4 + 2 * 6) + 64) * 4;
+  const unsigned lds = (unsigned)a.lds_per_wave * kWavesPerBlock;
+  const dim3 grid = tile_grid(a.map);
+  if (rows == 64) hipLaunchKernelGGL((k_resize_rows_rgb<64>), grid, dim3(kBlock), lds, stream, a);
+  else if (rows == 32) hipLaunchKernelGGL((k_resize_rows_rgb<32>), grid, dim3(kBlock), lds, stream, a);
+  else if (rows == 8) hipLaunchKernelGGL((k_resize_rows_rgb<8>), grid, dim3(kBlock), lds, stream, a);
+  else hipLaunchKernelGGL((k_resize_rows_rgb<2>), grid, dim3(kBlock), lds, stream, a);
+  VALI_LAUNCH_CHECK();
+  return VALI_OK;
 }
 
 // =====================================================================================================================
@@ -1084,9 +1392,9 @@ __device__ __forceinline__ void rows23_tile(const uint8_t* sp, int spitch, int s
         const u32 tail = __builtin_amdgcn_alignbyte(w2, w1, 1);                                     // the lane's bytes 5 .. 8
         const u32 prev = (u32)__builtin_amdgcn_update_dpp(0, (int)tail, 0x90, 0xf, 0xf, true);      // quad_perm:[0,0,1,2]
         const u32 o0 = __builtin_amdgcn_perm(w0, prev, quad_sel), o1 = __builtin_amdgcn_perm(w1, w0, quad_sel);
-        __builtin_amdgcn_raw_buffer_store_b64((v2u32){o0, o1}, drsrc, quad_off, orow, 0);
+        __builtin_amdgcn_raw_buffer_store_b64((v2u32){o0, o1}, drsrc, quad_off, orow, kStoreNt);
         if (quad_lane == 3)
-          __builtin_amdgcn_raw_buffer_store_b32(tail, drsrc, quad_off + 8, orow, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(tail, drsrc, quad_off + 8, orow, kStoreNt);
       } else if (nel == DE) {
         __builtin_amdgcn_raw_buffer_store_b64((v2u32){w0, w1}, drsrc, ooff, orow, 0);
         __builtin_amdgcn_raw_buffer_store_b8((char)w2, drsrc, ooff + 8, orow, 0);
@@ -1109,7 +1417,7 @@ __device__ __forceinline__ void rows23_tile(const uint8_t* sp, int spitch, int s
         const u32 z2 = __builtin_amdgcn_alignbyte(n1, n0, 2);                                 // next 2 .. 5
         const u32 o0 = __builtin_amdgcn_perm(z1, w0, quad_sel6), o1 = __builtin_amdgcn_perm(z2, z1, quad_sel6);
         if (quad_lane != 3)
-          __builtin_amdgcn_raw_buffer_store_b64((v2u32){o0, o1}, drsrc, ooff + 2 * quad_lane, orow, 0);
+          __builtin_amdgcn_raw_buffer_store_b64((v2u32){o0, o1}, drsrc, ooff + 2 * quad_lane, orow, kStoreNt);
       } else if (nel == DE) {
         gstore_u<u32>(optr, w0);
         gstore_u<uint16_t>(optr + 4, (uint16_t)w1);
@@ -1124,7 +1432,7 @@ __device__ __forceinline__ void rows23_tile(const uint8_t* sp, int spitch, int s
       typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
       const v3u32 q = {w0, w1, w2};
       if (full) {
-        __builtin_amdgcn_raw_buffer_store_b96(q, drsrc, ooff, orow, 0);
+        __builtin_amdgcn_raw_buffer_store_b96(q, drsrc, ooff, orow, kStoreNt);
       } else if (nel == DE) {
         gstore_u<v3u32>(optr, q);
       } else if (nel == 3) {
