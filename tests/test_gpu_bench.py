@@ -39,7 +39,7 @@ def test_bench_single_gpu_contract(gpu):
     assert [c["config"][:4] for c in j["secondary"]] == ["NV12", "cfg2", "cfg3", "inte", "upsc", "cfg4", "udge", "udpl", "affi"]
     assert {(r["format"], r["geometry"]) for r in j["secondary"][4]["results"]} == {
         ("NV12", "1280x720->1920x1080"), ("NV12", "1280x720->1600x900"), ("RGB", "1280x720->1920x1080"), ("RGB", "1280x720->1600x900"),
-        ("P10", "1280x720->1600x900")}
+        ("RGB_32F", "1280x720->1920x1080"), ("P10", "1280x720->1600x900")}
     assert {(r["format"], r["geometry"]) for r in j["secondary"][3]["results"] if r["filter"] == "lanczos"} >= {
         ("NV12", "1920x1080->1278x718"), ("RGB", "1920x1080->1277x719"), ("NV12", "3840x2160->1936x1088")}
     assert 0.3 < j["secondary"][0]["roofline"]["frac"] < 1.0

@@ -69,7 +69,7 @@ def test_the_hot_kernels_spill_nothing_and_keep_their_occupancy():
             # planes that grow: the 3:2 form the upscale bench line is quoted on, and the general rows-first kernel
             "k_resize_rows_x23IhLi12ELi6ELi48E": 4, "k_resize_rowsIhLi12ELi6ELi32E": 4,
             # ... its packed-RGB variant: 54 registers of filtered rows and still the fourth wave (3 waves: 3.5 us instead of 2.9)
-            "k_resize_rows_x23_rgbILi6ELi48E": 4}
+            "k_resize_rows_x23_rgbILi6ELi48E": 4, "k_resize_rows_rgbILi64E": 4}
     seen = set()
     for name, r in k.items():
         for needle, occ in want.items():

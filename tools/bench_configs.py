@@ -237,14 +237,15 @@ def interp(n=64):
 def upscale(n=64):
     """Planes that GROW (the upscale to display size) under the reference's filter: NV12 720p -> 1080p (exactly 3:2 both ways:
     the static form k_resize_rows_x23) and 720p -> 1600x900 (5:4, no special form: k_resize_rows_reg, the row pass and the vertical
-    window in registers, no LDS stage); packed RGB 720p -> 1080p (round 5: the 3:2 form's three-channel variant, k_resize_rows_x23_rgb);
-    and the two forms the fast paths do not cover: packed RGB 720p -> 1600x900 (k_resize_taps) and P10 720p ->
-    1600x900 (k_resize_rows, the LDS-staged rows form)."""
+    window in registers, no LDS stage); packed RGB 720p -> 1080p (round 5: the 3:2 form's three-channel variant, k_resize_rows_x23_rgb)
+    and 720p -> 1600x900 (round 5: the register form for three channels, k_resize_rows_rgb); and the two forms the fast paths do not
+    cover (VERDICT r04 #3): RGB_32F 720p -> 1080p (k_resize_taps) and P10 720p -> 1600x900 (k_resize_rows, the LDS-staged rows form)."""
     out = []
     for (fmt, sw, sh, dw, dh) in ((vali.NV12, 1280, 720, 1920, 1080), (vali.NV12, 1280, 720, 1600, 900), (vali.RGB, 1280, 720, 1920, 1080),
-                                  (vali.RGB, 1280, 720, 1600, 900), (vali.P10, 1280, 720, 1600, 900)):
+                                  (vali.RGB, 1280, 720, 1600, 900), (vali.RGB_32F, 1280, 720, 1920, 1080), (vali.P10, 1280, 720, 1600, 900)):
         rs = vali.PySurfaceResizer(fmt, DEV)                       # Lanczos-3, the reference's (and the task's default) filter
-        b = {vali.NV12: (sw * sh + dw * dh) * 3 // 2, vali.RGB: (sw * sh + dw * dh) * 3, vali.P10: (sw * sh + dw * dh) * 3}[fmt]
+        b = {vali.NV12: (sw * sh + dw * dh) * 3 // 2, vali.RGB: (sw * sh + dw * dh) * 3, vali.P10: (sw * sh + dw * dh) * 3,
+             vali.RGB_32F: (sw * sh + dw * dh) * 12}[fmt]
         k = sets_needed(b * n)
 
         def make():
@@ -254,7 +255,8 @@ def upscale(n=64):
             return srcs, dsts, rs.PrepareBatch(srcs, dsts)
         sets = make_sets(k, make)
         ms, _ = timed(rs.Stream, [lambda q=q: rs.RunBatchAsync(q) for _, _, q in sets], 30)
-        kern = ("k_resize_rows_x23_rgb<6, 48>" if fmt == vali.RGB and 3 * sw == 2 * dw else "k_resize_taps<u8, 3, 6>" if fmt == vali.RGB
+        kern = ("k_resize_rows_x23_rgb<6, 48>" if fmt == vali.RGB and 3 * sw == 2 * dw else "k_resize_rows_rgb<64>" if fmt == vali.RGB
+                else "k_resize_taps<f32, 3, 6>" if fmt == vali.RGB_32F
                 else "k_resize_rows<u16, 12, 6, 32>" if fmt == vali.P10
                 else "k_resize_rows_x23<u8, 12, 6, 48>" if 3 * sw == 2 * dw else "k_resize_rows_reg<64, 1, 2>")
         key = f"upscale_{dw}x{dh}" + ("" if fmt == vali.NV12 else "_" + fmt.name.lower())

@@ -44,7 +44,8 @@ KEYS = {
     "upscale_1920x1080": ("upscale", "k_resize_rows_x23<", 64),        # 720p -> 1080p Lanczos (3:2 both ways)
     "upscale_1600x900": ("upscale", "k_resize_rows_reg<", 64),         # 720p -> 1600x900 (general growing planes, register form)
     "upscale_1920x1080_rgb": ("upscale", "k_resize_rows_x23_rgb<", 64),  # packed RGB 720p -> 1080p: the 3:2 form, three channels
-    "upscale_1600x900_rgb": ("upscale", "k_resize_taps<", 64),         # packed RGB 720p -> 1600x900: rows-first gather kernel
+    "upscale_1600x900_rgb": ("upscale", "k_resize_rows_rgb<", 64),     # packed RGB 720p -> 1600x900: the register form, three channels
+    "upscale_1920x1080_rgb_32f": ("upscale", "k_resize_taps<", 64),    # RGB_32F 720p -> 1080p: rows-first gather kernel
     "upscale_1600x900_p10": ("upscale", "k_resize_rows<", 64),         # P10 720p -> 1600x900: LDS-staged rows form
     "affine_rgb_30": ("affine", "k_rotate_affine", 64),               # RGB 1080p by 30 degrees
 }

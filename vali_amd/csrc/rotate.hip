@@ -158,12 +158,16 @@ __device__ __forceinline__ void rotate_tile_rgb8(const PlaneView& v, u32 tile_x,
   const uint8_t* src = v.sp;
   uint8_t* dst = v.dp;
   const int src_pitch = v.spitch, dst_pitch = v.dpitch;
-  const int cx = tile_x * TW, ry = tile_y * TH; // src tile origin (col, row)
+  // src tile origin (col, row).  At 270 degrees source row r lands in dst column H - 1 - r: the tiles are anchored at the LAST
+  // source row (the ragged tile is the first one: its rows before the plane are loaded from row 0 and never stored), so that a
+  // tile's dst segments start at multiples of TH pixels as they do at 90 -- from H - 64 k they straddled the 64-byte sectors
+  // (1080p: 2.9 us against 2.1-2.25 at 90 degrees, and non-temporal stores cost 20 % instead of saving 7; round 5)
+  const int cx = tile_x * TW, ry = (int)tile_y * TH - (QUARTER == 3 ? (TH - src_h % TH) % TH : 0);
   const int tw = min(TW, src_w - cx), th = min(TH, src_h - ry);
   const int t = threadIdx.x;
+  auto src_row = [&](int r) { return src + (size_t)min(max(ry + r, 0), src_h - 1) * src_pitch + (size_t)cx * P; };
 
   // phase 1: TW/4 lanes x 4 pixels (one 12-byte load) per source row
-  const uint8_t* sbase = src + (size_t)ry * src_pitch + (size_t)cx * P;
   // (vector accesses at ANY byte alignment: a 270 degree turn of a frame whose height is not a multiple of 4 starts
   // its destination segments at odd offsets -- through the byte path that measured 10.5 instead of 4.3 us, 2720x1530)
   constexpr bool vec = true;
@@ -185,7 +189,7 @@ __device__ __forceinline__ void rotate_tile_rgb8(const PlaneView& v, u32 tile_x,
     const int r0 = t / kLanesPerSrcRow;
 #pragma unroll
     for (int pass = 0; pass < kPasses; ++pass)
-      w[pass] = gload_u<v3u32>(sbase + (size_t)min(pass * kSrcRowsPerPass + r0, th - 1) * src_pitch + col * 3);
+      w[pass] = gload_u<v3u32>(src_row(min(pass * kSrcRowsPerPass + r0, th - 1)) + col * 3);
 #pragma unroll
     for (int pass = 0; pass < kPasses; ++pass) {
       u32* l = lds + (pass * kSrcRowsPerPass + r0) * SD + col;
@@ -198,9 +202,9 @@ __device__ __forceinline__ void rotate_tile_rgb8(const PlaneView& v, u32 tile_x,
 #pragma unroll
   for (int pass = 0; pass < TH / kSrcRowsPerPass; ++pass) {
     const int r = pass * kSrcRowsPerPass + t / kLanesPerSrcRow;
-    if (r >= th || chunk * 4 >= tw)
+    if (r >= th || chunk * 4 >= tw || ry + r < 0)
       continue;
-    const uint8_t* q = sbase + (size_t)r * src_pitch + chunk * 12;
+    const uint8_t* q = src_row(r) + chunk * 12;
     u32 px[4];
     if (vec && chunk * 4 + 4 <= tw) {
       typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
@@ -253,12 +257,8 @@ __device__ __forceinline__ void rotate_tile_rgb8(const PlaneView& v, u32 tile_x,
     if (ok[0] && ok[1] && ok[2] && ok[3]) {
       typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
       const v3u32 w = {px[0] | (px[1] << 24), (px[1] >> 8) | (px[2] << 16), (px[2] >> 16) | (px[3] << 8)};
-      // (non-temporal at 90 degrees, where a tile's 192-byte segments start on 64-byte boundaries: 1080p 2.25 -> 2.10 us,
-      // Y 0.99 -> 0.77; at 270 they start at (H - 64 k) * 3 and the same bit costs 20 - 50 %, whatever the lane order: round 5)
-      if constexpr (QUARTER == 1)
-        gstore_u_nt<v3u32>(o, w);
-      else
-        gstore_u<v3u32>(o, w);
+      // (non-temporal: a tile's 192-byte segments start on 64-byte boundaries at either turn; 1080p at 90 degrees 2.25 -> 2.10 us)
+      gstore_u_nt<v3u32>(o, w);
     } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -301,12 +301,14 @@ __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
   uint8_t* dst = v.dp;
   const int src_pitch = v.spitch, dst_pitch = v.dpitch;
 
-  const int cx = tile_x * kRotTile, ry = tile_y * kRotTile; // src tile origin (col, row)
+  // src tile origin (col, row); at 270 degrees anchored at the last source row (rotate_tile_rgb8)
+  const int cx = tile_x * kRotTile, ry = (int)tile_y * kRotTile - (QUARTER == 3 ? (kRotTile - src_h % kRotTile) % kRotTile : 0);
   const int tw = min(kRotTile, src_w - cx), th = min(kRotTile, src_h - ry);
   const int t = threadIdx.x;
+  auto src_row = [&](int r) { return src + (size_t)min(max(ry + r, 0), src_h - 1) * src_pitch + (size_t)cx * P; };
 
   // phase 1: coalesced row segments -> LDS (16-byte / 4-byte vectors when aligned)
-  const uint8_t* sbase = src + (size_t)ry * src_pitch + (size_t)cx * P;
+  const uint8_t* sbase = src_row(0);
   const int row_bytes = tw * P;
   constexpr bool aligned16 = true; // (16-byte loads at any alignment, see rotate_tile_rgb8)
   if (aligned16 && tw == kRotTile) {
@@ -317,7 +319,7 @@ __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
 #pragma unroll
     for (int i = 0; i < P; ++i) {
       const int k = t + i * kBlock, r = k / V, c = k - r * V;
-      w[i] = rot_load16(sbase + (size_t)min(r, th - 1) * src_pitch + c * 16);
+      w[i] = rot_load16(src_row(min(r, th - 1)) + c * 16);
     }
 #pragma unroll
     for (int i = 0; i < P; ++i) {
@@ -329,7 +331,7 @@ __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
     const int v_per_row = row_bytes / 16;
     for (int k = t; k < th * v_per_row; k += kBlock) {
       const int r = k / v_per_row, v = k - r * v_per_row;
-      const uint4 w = rot_load16(sbase + (size_t)r * src_pitch + v * 16);
+      const uint4 w = rot_load16(src_row(r) + v * 16);
       u32* l = (u32*)(lds + r * S + v * 16);
       l[0] = w.x; l[1] = w.y; l[2] = w.z; l[3] = w.w;
     }
@@ -337,12 +339,12 @@ __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
     const int dw_per_row = row_bytes / 4;
     for (int k = t; k < th * dw_per_row; k += kBlock) {
       const int r = k / dw_per_row, v = k - r * dw_per_row;
-      *(u32*)(lds + r * S + v * 4) = gload<u32>(sbase + (size_t)r * src_pitch + v * 4);
+      *(u32*)(lds + r * S + v * 4) = gload<u32>(src_row(r) + v * 4);
     }
   } else {
     for (int k = t; k < th * row_bytes; k += kBlock) {
       const int r = k / row_bytes, v = k - r * row_bytes;
-      lds[r * S + v] = gload<uint8_t>(sbase + (size_t)r * src_pitch + v);
+      lds[r * S + v] = gload<uint8_t>(src_row(r) + v);
     }
   }
   __syncthreads();
@@ -380,7 +382,7 @@ __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
       if (ok[0] && ok[1] && ok[2] && ok[3]) {
 #pragma unroll
         for (int k = 0; k < 4 * D; ++k)
-          if constexpr (QUARTER == 1) gstore_u_nt<u32>(o + 4 * k, w[k]); else gstore_u<u32>(o + 4 * k, w[k]);
+          gstore_u_nt<u32>(o + 4 * k, w[k]);
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -404,7 +406,7 @@ __global__ void __launch_bounds__(kBlock) k_rotate_tile(const RotArgs a) {
         __builtin_memcpy(w, px, 4 * P);
 #pragma unroll
         for (int k = 0; k < P; ++k)
-          if constexpr (QUARTER == 1) gstore_u_nt<u32>(o + 4 * k, w[k]); else gstore_u<u32>(o + 4 * k, w[k]);
+          gstore_u_nt<u32>(o + 4 * k, w[k]);
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q)

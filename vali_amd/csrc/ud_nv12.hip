@@ -1103,10 +1103,10 @@ __global__ void __launch_bounds__(kBlock) k_ud_half(const UdArgs a) {
           if (dst16)
             UD_ST16(orow + b, v);
           else
-            gstore_u<v4u32>(orow + b, (v4u32){v.x, v.y, v.z, v.w});
+            gstore_u_nt<v4u32>(orow + b, (v4u32){v.x, v.y, v.z, v.w});
         } else if (b < nbytes) {
           const uint2 v = *reinterpret_cast<const uint2*>(st + b);
-          gstore_u<v2u32>(orow + b, (v2u32){v.x, v.y});
+          gstore_u_nt<v2u32>(orow + b, (v2u32){v.x, v.y});
         }
       }
       wave_lds_sync(); // the strip is re-used by the next row
@@ -1121,7 +1121,7 @@ __global__ void __launch_bounds__(kBlock) k_ud_half(const UdArgs a) {
         if ((((uintptr_t)d.p[k] | (uintptr_t)pp[k]) & 7u) == 0) // wave-uniform
           UD_ST8(o, make_uint2(pw[2 * k], pw[2 * k + 1]));
         else
-          gstore_u<v2u32>(o, (v2u32){pw[2 * k], pw[2 * k + 1]});
+          gstore_u_nt<v2u32>(o, (v2u32){pw[2 * k], pw[2 * k + 1]});
       }
     }
   };
@@ -1276,9 +1276,9 @@ __global__ void __launch_bounds__(kBlock) k_ud_lean(const UdArgs a) {
       uint8_t* st = strip[kPacked ? wave : 0];
       if (slid) { // its 24 bytes are not on the strip's lane grid: straight to memory
         uint8_t* o = d.p[0] + (u32)(y * d.pitch[0]) + (u32)(xl * 3);
-        gstore_u<v2u32>(o, (v2u32){w[0], w[1]});
-        gstore_u<v2u32>(o + 8, (v2u32){w[2], w[3]});
-        gstore_u<v2u32>(o + 16, (v2u32){w[4], w[5]});
+        gstore_u_nt<v2u32>(o, (v2u32){w[0], w[1]});
+        gstore_u_nt<v2u32>(o + 8, (v2u32){w[2], w[3]});
+        gstore_u_nt<v2u32>(o + 16, (v2u32){w[4], w[5]});
       } else if (has) {
         *reinterpret_cast<uint2*>(st + 24 * lane) = make_uint2(w[0], w[1]);
         *reinterpret_cast<uint2*>(st + 24 * lane + 8) = make_uint2(w[2], w[3]);
@@ -1294,10 +1294,10 @@ __global__ void __launch_bounds__(kBlock) k_ud_lean(const UdArgs a) {
           if (dst16)
             UD_ST16(orow + b, v);
           else
-            gstore_u<v4u32>(orow + b, (v4u32){v.x, v.y, v.z, v.w});
+            gstore_u_nt<v4u32>(orow + b, (v4u32){v.x, v.y, v.z, v.w});
         } else if (b < nbytes) {
           const uint2 v = *reinterpret_cast<const uint2*>(st + b);
-          gstore_u<v2u32>(orow + b, (v2u32){v.x, v.y});
+          gstore_u_nt<v2u32>(orow + b, (v2u32){v.x, v.y});
         }
       }
       wave_lds_sync(); // the strip is re-used by the next row
@@ -1312,7 +1312,7 @@ __global__ void __launch_bounds__(kBlock) k_ud_lean(const UdArgs a) {
         if (!slid && (((uintptr_t)d.p[k] | (uintptr_t)pp[k]) & 7u) == 0) // (wave-uniform but for the slid lane)
           UD_ST8(o, make_uint2(pw[2 * k], pw[2 * k + 1]));
         else
-          gstore_u<v2u32>(o, (v2u32){pw[2 * k], pw[2 * k + 1]});
+          gstore_u_nt<v2u32>(o, (v2u32){pw[2 * k], pw[2 * k + 1]});
       }
     }
   };
@@ -1493,10 +1493,10 @@ __global__ void __launch_bounds__(kBlock) k_ud_32(const UdArgs a) {
           if (dst16)
             UD_ST16(orow + b, v);
           else
-            gstore_u<v4u32>(orow + b, (v4u32){v.x, v.y, v.z, v.w});
+            gstore_u_nt<v4u32>(orow + b, (v4u32){v.x, v.y, v.z, v.w});
         } else if (b < nbytes) {
           const uint2 v = *reinterpret_cast<const uint2*>(st + b);
-          gstore_u<v2u32>(orow + b, (v2u32){v.x, v.y});
+          gstore_u_nt<v2u32>(orow + b, (v2u32){v.x, v.y});
         }
       }
       wave_lds_sync();
@@ -1511,7 +1511,7 @@ __global__ void __launch_bounds__(kBlock) k_ud_32(const UdArgs a) {
         if ((((uintptr_t)d.p[k] | (uintptr_t)pp[k]) & 7u) == 0) // wave-uniform
           UD_ST8(o, make_uint2(pw[2 * k], pw[2 * k + 1]));
         else
-          gstore_u<v2u32>(o, (v2u32){pw[2 * k], pw[2 * k + 1]});
+          gstore_u_nt<v2u32>(o, (v2u32){pw[2 * k], pw[2 * k + 1]});
       }
     }
   };
@@ -1641,7 +1641,7 @@ __global__ void __launch_bounds__(kBlock) k_ud_half_t(const UdArgs a) {
     uint8_t* o = d.p[0] + (u32)(drow * d.pitch[0]) + (u32)(dx0 * 3);
     typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
     const v3u32 w = {pxl[0] | (pxl[1] << 24), (pxl[1] >> 8) | (pxl[2] << 16), (pxl[2] >> 16) | (pxl[3] << 8)};
-    gstore_u<v3u32>(o, w);
+    gstore_u_nt<v3u32>(o, w);
   }
 }
 
