@@ -901,9 +901,13 @@ __device__ __forceinline__ void rows_rgb_tile(const uint8_t* sp, int spitch, int
   }
   struct Row { u32 w[NW]; };
   const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(sp), (short)0, (int)0xffffffffu, 0x00020000);
+  // (the walk exists twice, for edge tiles and for the others: with both load forms behind a branch inside ONE loop the compiler
+  // cannot count the loads in flight and waits for all of them -- vmcnt(0) at every row, the prefetch gone)
+  auto walk = [&](auto edge_tag) {
+  constexpr bool EDGE = decltype(edge_tag)::value;
   auto issue = [&](int logical, Row& q) {
     const int row = clampi(logical, sh - 1) * spitch;              // scalar
-    if (edge_tile) {
+    if constexpr (EDGE) {
 #pragma unroll
       for (int k = 0; k < NW; ++k)
         q.w[k] = __builtin_amdgcn_raw_buffer_load_b32(srsrc, (int)eoff[k], row, 0);
@@ -941,7 +945,7 @@ __device__ __forceinline__ void rows_rgb_tile(const uint8_t* sp, int spitch, int
 #pragma unroll
       for (int k = 0; k < NW; ++k)
         w[k] = pf[j % AHEAD].w[k];
-      if (edge_tile) { // one pixel per register -> the 24 packed bytes (v_perm_b32 picks bytes by name: what lies beside a pixel is ignored)
+      if constexpr (EDGE) { // one pixel per register -> the 24 packed bytes (v_perm_b32 picks bytes by name: what lies beside a pixel is ignored)
         u32 px[NW];
 #pragma unroll
         for (int k = 0; k < NW; ++k)
@@ -1051,6 +1055,11 @@ __device__ __forceinline__ void rows_rgb_tile(const uint8_t* sp, int spitch, int
       }
     }
   }
+  };
+  if (edge_tile)
+    walk(std::true_type{});
+  else
+    walk(std::false_type{});
 }
 
 template <int ROWS>
@@ -1392,9 +1401,12 @@ __device__ __forceinline__ void rows23_tile(const uint8_t* sp, int spitch, int s
         const u32 tail = __builtin_amdgcn_alignbyte(w2, w1, 1);                                     // the lane's bytes 5 .. 8
         const u32 prev = (u32)__builtin_amdgcn_update_dpp(0, (int)tail, 0x90, 0xf, 0xf, true);      // quad_perm:[0,0,1,2]
         const u32 o0 = __builtin_amdgcn_perm(w0, prev, quad_sel), o1 = __builtin_amdgcn_perm(w1, w0, quad_sel);
-        __builtin_amdgcn_raw_buffer_store_b64((v2u32){o0, o1}, drsrc, quad_off, orow, kStoreNt);
-        if (quad_lane == 3)
-          __builtin_amdgcn_raw_buffer_store_b32(tail, drsrc, quad_off + 8, orow, kStoreNt);
+        // ONE 12-byte store per lane: the third dword is the next lane's first (written twice with the same bits), lane 3's the
+        // quad's ninth -- as 8 bytes + a masked dword every 36-byte piece left the chip in two partial passes (non-temporal
+        // stores do not wait in the L2 to be merged: 8.7 % more bytes written than the destination holds)
+        const u32 nxt = (u32)__builtin_amdgcn_update_dpp(0, (int)o0, 0xf9, 0xf, 0xf, true);         // quad_perm:[1,2,3,3]
+        typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+        __builtin_amdgcn_raw_buffer_store_b96((v3u32){o0, o1, quad_lane == 3 ? tail : nxt}, drsrc, quad_off, orow, kStoreNt);
       } else if (nel == DE) {
         __builtin_amdgcn_raw_buffer_store_b64((v2u32){w0, w1}, drsrc, ooff, orow, 0);
         __builtin_amdgcn_raw_buffer_store_b8((char)w2, drsrc, ooff + 8, orow, 0);
