@@ -1558,7 +1558,9 @@ __global__ void __launch_bounds__(kBlock) k_ud_half_t(const UdArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int g = lane >> 3, c = lane & 7;
-  const int xw = tile_x * TW, yb = tile_y * TH;
+  // (270 degrees: UD row y lands in dst column uh - 1 - y -- the tiles are anchored at the LAST row, the ragged tile is the first
+  // one, so that a tile's dst segments start at multiples of TH pixels = whole 64-byte sectors as at 90 degrees: rotate.hip)
+  const int xw = tile_x * TW, yb = (int)tile_y * TH - (ROT == 3 ? (TH - dh % TH) % TH : 0);
   const int x0 = xw + 8 * c;
   const bool has = x0 < dw;
   const u32 off16 = (u32)(2 * min(x0, dw - kD2LanePx));
@@ -1568,7 +1570,7 @@ __global__ void __launch_bounds__(kBlock) k_ud_half_t(const UdArgs a) {
     u32 before[4];  // the dword in front of them
   };
   auto issue = [&](int step) {
-    const int y = min(yb + wave * RW + min(step, STEPS - 1) * 8 + g, dh - 1);
+    const int y = max(min(yb + wave * RW + min(step, STEPS - 1) * 8 + g, dh - 1), 0);
     const u32 ro[4] = {(u32)(max(2 * y - 1, 0) * s.pitch[0]), (u32)(2 * y * s.pitch[0]),
                        (u32)(max(y - 1, 0) * s.pitch[1]), (u32)(y * s.pitch[1])};
     Rows r;
@@ -1597,7 +1599,7 @@ __global__ void __launch_bounds__(kBlock) k_ud_half_t(const UdArgs a) {
     u32 px[8];
     trunc_pack_px4(c0, c1, c2, px);
     trunc_pack_px4(c0 + 4, c1 + 4, c2 + 4, px + 4);
-    if (has && yb + rr < dh) {
+    if (has && yb + rr < dh && yb + rr >= 0) {
       u32* t = tile + rr * SD + 8 * c;
 #pragma unroll
       for (int j = 0; j < 8; ++j)
@@ -1630,7 +1632,7 @@ __global__ void __launch_bounds__(kBlock) k_ud_half_t(const UdArgs a) {
     const int x = xw + lc;
     const int quad = half * 16 + qd;                                       // rows 4 quad .. 4 quad + 3 of the tile
     const int r0 = ROT == 1 ? 4 * quad : TH - 4 - 4 * quad;                // lowest tile row of the quad
-    if (x >= dw || yb + r0 >= dh)                                          // (dh % 4 == 0: a quad is whole or absent)
+    if (x >= dw || yb + r0 >= dh || yb + r0 < 0)                           // (dh % 4 == 0: a quad is whole or absent)
       continue;
     u32 pxl[4];
 #pragma unroll
