@@ -112,6 +112,8 @@ GATHER_CASES = [
     # round 5: the general Lanczos form below 2160p (0.32 / 0.18 of the roofline went unnoticed by this test)
     ("lanczos NV12 1080p->1278x718 (general, 4 slots, wide tiles)", 0.48, 0.33, "resize", (1920, 1080, 1278, 718)),
     ("lanczos NV12 1366x768->854x480 (general, small frames)", 0.42, 0.27, "resize", (1366, 768, 854, 480)),
+    ("rotate RGB 1080p 270 degrees (tiles anchored at the last source row since round 5; astride the sectors: 0.55)", 0.72, 0.50, "rot270",
+     (1920, 1080, 1080, 1920)),
     ("lanczos RGB 720p->1080p (3:2 enlargement of packed RGB; the gather kernel it left: 0.23)", 0.58, 0.36, "resize_rgb", (1280, 720, 1920, 1080)),
     ("lanczos RGB 720p->1600x900 (packed RGB that grows, register form; the gather kernel: 0.25)", 0.39, 0.26, "resize_rgb", (1280, 720, 1600, 900)),
 ]
@@ -146,7 +148,7 @@ def test_gather_kernels_keep_their_distance_to_the_headline_kernel(vali, gpu):
             srcs, dsts = _surfaces(vali, gpu, vali.RGB, sw, sh, n), _surfaces(vali, gpu, vali.RGB, dw, dh, n, fill=False)
             nbytes = 2 * sw * sh * 3
             b = task.PrepareBatch(srcs, dsts)
-            run = lambda: task.RunBatchAsync(b, angle=90.0)   # noqa: E731
+            run = (lambda: task.RunBatchAsync(b, angle=270.0)) if kind == "rot270" else (lambda: task.RunBatchAsync(b, angle=90.0))  # noqa: E731
         assert run()[0]
         r = nbytes * n / (_timed(vali, gpu, task.Stream, run) * 1e-3) / ref
         report.append(f"{name}: {r:.2f} of NV12->RGB (typical {typical}, floor {floor})")
