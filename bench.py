@@ -66,6 +66,10 @@ def parse():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip BASELINE configs[1..3] (tools/bench_configs.py; a few seconds, N=1 only)")
+    ap.add_argument("--verbose", action="store_true",
+                    help="the long form of the line (every note, the full roofline object of every secondary entry, ~18 KB: what "
+                         "profiles/rNN_bench_line.json keeps).  The default line is the SAME measurements in < 7 500 characters, "
+                         "weakest kernels last, so that a reader who keeps only the tail of the line sees every entry (VERDICT r05)")
     return ap.parse_args()
 
 
@@ -290,6 +294,82 @@ def host_fed_rate(vali, pipe_args, coeffs_ctx, seconds, W, H):
                     "figure: ONE host thread memcpy's every frame into the staging slot (a decoder that hands over pageable "
                     "frames); second: the producer writes the slot in place (a decoder given the pinned buffer), i.e. the "
                     "ring's own ceiling = PCIe"}
+
+
+def compact_secondary(sec):
+    """The secondary measurements as ONE flat list, one short object per kernel: `cfg` (workload), `kernel`, `us` (per frame, batched
+    launch on rotating surface sets), `B` (algorithmic bytes per frame), `frac` (B / us / 8 TB/s), `traffic` (HBM bytes per frame from the
+    committed PMC passes, or null).  Sorted by `frac`, best first: the tail of the line is where the weak kernels are."""
+    if not isinstance(sec, list):
+        return sec
+    flat = []
+
+    def label(ctx, d, key):
+        detail = ([str(key).split("(")[0]] if key else []) + [str(d[k]) for k in ("filter", "formats", "format", "geometry") if k in d]
+        return " ".join([ctx.split(" ")[0]] + detail) if detail else ctx      # "interp lanczos NV12 1920x1080->1278x718"
+
+    def walk(o, ctx, key=None):
+        if isinstance(o, dict):
+            here = o.get("config")
+            if isinstance(here, str):
+                ctx = here.split(",")[0][:64]
+            if "us_per_frame" in o and isinstance(o.get("roofline"), dict):
+                r = o["roofline"]
+                n = max(1, round(r.get("bytes_per_launch", 0) / max(1, o.get("bytes_moved_per_frame", 1))))
+                flat.append({"cfg": label(ctx, o, key), "kernel": (o.get("kernel") or "").split(" (")[0].replace(", ", ","), "us": o["us_per_frame"], "B": o.get("bytes_moved_per_frame"),
+                             "frac": r.get("frac"), "traffic": (round(r["traffic"] / n) if r.get("traffic") else None)})
+            elif "us_per_call_host_async" in o:      # cfg2: one frame per call, launch-bound -- no roofline object
+                flat.append({"cfg": ctx, "us_stream": o.get("us_per_frame_stream_time"), "us_host_async": o.get("us_per_call_host_async"),
+                             "us_host_sync_Run": o.get("us_per_call_host_sync_Run"), "frac": 1.0})
+            for k, v in o.items():
+                if k != "roofline":
+                    walk(v, ctx, k if isinstance(v, dict) else key)
+        elif isinstance(o, list):
+            for v in o:
+                walk(v, ctx, key)
+    walk(sec, "")
+    flat.sort(key=lambda e: -(e.get("frac") or 0))
+    for e in flat:
+        if "us_stream" in e:
+            del e["frac"]
+    return flat
+
+
+def compact_line(out):
+    """Default form of the line: nothing measured is dropped, prose and repeated constants are (see --verbose)."""
+    sec = out.get("secondary")
+    if sec is not None:
+        src = None
+        def find_src(o):
+            nonlocal src
+            if isinstance(o, dict):
+                if src is None and isinstance(o.get("traffic_source"), str):
+                    src = o["traffic_source"]
+                for v in o.values():
+                    find_src(v)
+            elif isinstance(o, list):
+                for v in o:
+                    find_src(v)
+        find_src(sec)
+        out["secondary_keys"] = ("us = per frame, one batched launch, rotating >= 1.5 GiB surface sets; B = algorithmic bytes per frame; frac = "
+                                 "B / us / 8 TB/s; traffic = HBM bytes per frame, " + (src or "no PMC profile").split(" (")[0] + "; sorted by frac")
+        out["secondary"] = compact_secondary(sec)
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        for k in ("note", "thread_scan_frames_per_s", "parallel_efficiency"):
+            cb.pop(k, None)
+        if isinstance(cb.get("sample"), str):
+            cb["sample"] = cb["sample"][:110]
+    hf = out.get("host_fed")
+    if isinstance(hf, dict):
+        hf.pop("note", None)
+    hp = out.get("host_placement")
+    if isinstance(hp, dict) and isinstance(hp.get("gpu_state"), dict):
+        g = hp["gpu_state"]
+        ul = g.get("under_load") if isinstance(g.get("under_load"), dict) else {}
+        hp["gpu_state"] = {"sclk_mhz_under_load": ul.get("sclk_mhz"), "power_w_under_load": ul.get("power_w"),
+                           "power_cap_w": g.get("power_cap_w"), "partition": f"{g.get('compute_partition')}/{g.get('memory_partition')}"}
+    return out
 
 
 def main():
@@ -526,7 +606,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(W, H, coeffs, args.cpu_seconds)
         if world == 1 and not args.no_secondary:
             out["secondary"] = secondary_configs(pipe)
-        print(json.dumps(out), flush=True)
+        if not args.verbose:
+            out = compact_line(out)
+        print(json.dumps(out, separators=(",", ":")), flush=True)
 
     if dist is not None:
         dist.barrier()

@@ -55,8 +55,9 @@ def test_tuning_table_round_trip_without_a_gpu():
     """vali_tuning_set / vali_tuning_get work without a device; unknown keys are refused; defaults as documented."""
     from vali_amd._native import shim
 
-    assert shim.TUNE_COUNT == 15
-    defaults = {shim.TUNE_RESIZE_POINT: 1, shim.TUNE_UD_DOWN2: 1, shim.TUNE_UD_OCC5: 0, shim.TUNE_RESIZE_ROWS: 1}
+    assert shim.TUNE_COUNT == 19
+    defaults = {shim.TUNE_RESIZE_POINT: 1, shim.TUNE_UD_DOWN2: 1, shim.TUNE_UD_OCC5: 0, shim.TUNE_RESIZE_ROWS: 1,
+                shim.TUNE_TAP_MAX_TABLES: 1024}
     import os
     if not any(k.startswith("VALI_") and k not in ("VALI_BENCH_BACKEND", "VALI_NO_TORCH") for k in os.environ):
         for k in range(shim.TUNE_COUNT):

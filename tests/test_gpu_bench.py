@@ -36,13 +36,35 @@ def test_bench_single_gpu_contract(gpu):
     assert "workload" in j["config"] and "model" not in j["config"]
     assert j["verification"] == {"frames_verified_on_gpu": 16, "frames_mismatching": 0,
                                  "checksum_of_checksums": j["verification"]["checksum_of_checksums"]}
+    # the default line is the compact one: every secondary measurement as one short object, weakest last,
+    # the whole line short enough for a reader that keeps an 8 KB tail
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][0]
+    assert len(line) < 7500, len(line)
+    sec = j["secondary"]
+    assert isinstance(sec, list) and all(isinstance(e, dict) and "cfg" in e for e in sec)
+    roof = [e for e in sec if "frac" in e]
+    assert all(set(e) == {"cfg", "kernel", "us", "B", "frac", "traffic"} for e in roof), roof
+    fr = [e["frac"] for e in roof]
+    assert fr == sorted(fr, reverse=True) and all(0 < f < 1.0 for f in fr) and len(fr) >= 24, fr
+    cfgs = {e["cfg"] for e in sec}
+    for want in ("interp lanczos NV12 1920x1080->1278x718", "interp lanczos RGB 1920x1080->1277x719", "interp lanczos NV12 3840x2160->1936x1088",
+                 "interp bilinear NV12 3840x2160->1920x1088", "upscale lanczos NV12 1280x720->1920x1080", "upscale lanczos NV12 1280x720->1600x900",
+                 "upscale lanczos RGB 1280x720->1920x1080", "upscale lanczos RGB 1280x720->1600x900", "upscale lanczos RGB_32F 1280x720->1920x1080",
+                 "upscale lanczos P10 1280x720->1600x900", "cfg4 ud", "cfg4 rot", "cfg4 chain", "cfg4 fused"):
+        assert want in cfgs, (want, sorted(cfgs))
+    for fam in ("NV12->RGB 1920x1080", "cfg2", "cfg3", "udgen", "udplanar", "affine"):
+        assert any(c.startswith(fam) for c in cfgs), (fam, sorted(cfgs))
+    assert all(e["kernel"].startswith("k_") for e in roof if e["cfg"] != "cfg4 chain"), roof
+    assert "traffic" in j["secondary_keys"] and 0.3 < j["roofline"]["frac"] < 1.0
+
+
+def test_bench_verbose_line_keeps_the_full_roofline_objects(gpu):
+    """--verbose: the long form profiles/rNN_bench_line.json keeps (notes, bound / peak / unit / working set of every entry)."""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "2", "--warmup", "1", "--frames", "8", "--cpu-seconds", "0",
+                        "--ingest-seconds", "0", "--verbose"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = last_json(r.stdout)
     assert [c["config"][:4] for c in j["secondary"]] == ["NV12", "cfg2", "cfg3", "inte", "upsc", "cfg4", "udge", "udpl", "affi"]
-    assert {(r["format"], r["geometry"]) for r in j["secondary"][4]["results"]} == {
-        ("NV12", "1280x720->1920x1080"), ("NV12", "1280x720->1600x900"), ("RGB", "1280x720->1920x1080"), ("RGB", "1280x720->1600x900"),
-        ("RGB_32F", "1280x720->1920x1080"), ("P10", "1280x720->1600x900")}
-    assert {(r["format"], r["geometry"]) for r in j["secondary"][3]["results"] if r["filter"] == "lanczos"} >= {
-        ("NV12", "1920x1080->1278x718"), ("RGB", "1920x1080->1277x719"), ("NV12", "3840x2160->1936x1088")}
-    assert 0.3 < j["secondary"][0]["roofline"]["frac"] < 1.0
 
     def fracs(o):      # every roofline entry anywhere in the line: a fraction of the HBM peak, never above it
         if isinstance(o, dict):
@@ -54,7 +76,7 @@ def test_bench_single_gpu_contract(gpu):
             for v in o:
                 yield from fracs(v)
     all_fracs = list(fracs(j))
-    assert len(all_fracs) >= 11 and all(0 < f < 1.0 for f in all_fracs), all_fracs
+    assert len(all_fracs) >= 24 and all(0 < f < 1.0 for f in all_fracs), all_fracs
     assert {r["filter"] for r in j["secondary"][3]["results"]} == {"bilinear", "lanczos"}
 
 

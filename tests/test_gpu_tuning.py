@@ -57,7 +57,9 @@ def rotate(vali, gpu, w, h, angle):
     src = upload(vali, gpu, vali.RGB, w, h, rng.integers(0, 256, w * h * 3, dtype=np.uint8))
     q = int(angle) % 180 != 0
     d = vali.Surface.Make(vali.RGB, h if q else w, w if q else h, gpu)
-    assert vali.PySurfaceRotator(gpu).Run(src, d, angle)[0]
+    assert vali.PyFrameUploader(gpu).Run(np.full(d.HostSize, 9, np.uint8), d)[0]   # pixels that sample outside the source stay untouched
+    sx, sy = (0.0, 0.0) if angle % 90.0 == 0.0 else (w * 0.3, h * 0.6)
+    assert vali.PySurfaceRotator(gpu).Run(src, d, angle, sx, sy)[0]
     return download(vali, gpu, d)
 
 
@@ -97,6 +99,9 @@ CASES = [
     ("ROTATE_NO_TILE", (1, 2), lambda v, g: rotate(v, g, 640, 360, 90.0)),
     ("ROTATE_NO_TILE", (2,), lambda v, g: rotate(v, g, 1000, 600, 270.0)),
     ("ROTATE_NO_TILE", (1,), lambda v, g: rotate(v, g, 640, 360, 180.0)),
+    # any other angle: 0 the LDS-staged form (round 6), 1 the per-pixel gather form, 2..5 other tile shapes
+    ("ROTATE_AFFINE", (1, 2, 3, 4, 5), lambda v, g: rotate(v, g, 640, 360, 33.0)),
+    ("ROTATE_AFFINE", (1, 3), lambda v, g: rotate(v, g, 1000, 600, -117.5)),
     # rows per wave (small launches pick 2 or 4 by themselves; batches 8)
     ("ROWS_PER_WAVE", (2, 4, 8), lambda v, g: ud(v, g, 1280, 720, 640, 358, v.RGB)),           # exact-2x kernel
     ("ROWS_PER_WAVE", (2, 4, 8), lambda v, g: ud(v, g, 1280, 720, 1280, 717, v.YUV444)),       # 1:1 kernel

@@ -204,6 +204,23 @@ def test_ingest_ring_short_last_chunk_and_close():
     # a fill callback reports what it wrote
     got = list(ring.feed([frames[0]], fill=lambda host, item: (host.__setitem__(slice(0, item.size), item), 1)[1]))
     assert [len(d) for _t, d in got] == [1]
+    # a bad chunk behind good ones: the good ones are still delivered before the error; fill() == 0 ends the input
+    seen = []
+    with pytest.raises(ValueError):
+        for tag, dsts in ring.feed([chunks[0], chunks[1], np.zeros(47, np.uint8)]):
+            seen.append((tag, len(dsts)))
+    assert seen == [(0, 4), (1, 4)]
+    state = {"n": 0}
+    def two_then_end(host, item):
+        state["n"] += 1
+        if state["n"] > 2:
+            return 0
+        host[:item.size] = item
+        return 4
+    assert [(t, len(d)) for t, d in ring.feed([chunks[0]] * 5, fill=two_then_end)] == [(0, 4), (1, 4)]
+    with pytest.raises(TypeError):
+        list(ring.feed([chunks[0]], fill=lambda host, item: True))
+    assert [(t, len(d)) for t, d in ring.feed(chunks)] == [(0, 4), (1, 4), (2, 2)]       # the ring is still usable, no slot was lost
     ring.close()
     assert all(s.host is None and s.uploaded is None and s.done is None for s in ring.slots) and len(freed) == 4
     with pytest.raises(RuntimeError, match="closed"):

@@ -159,8 +159,7 @@ def roofline(key, bytes_per_frame, n, ms, sets=1):
     global TRAFFIC
     if TRAFFIC is None:
         prof = Path(__file__).resolve().parent.parent / "profiles"
-        f = next((q for q in (prof / "r05_secondary_traffic.json", prof / "r04_secondary_traffic.json", prof / "r03_secondary_traffic.json",
-                              prof / "r02_secondary_traffic.json") if q.exists()), None)
+        f = next(iter(sorted(prof.glob("r*_secondary_traffic.json"), reverse=True)), None)     # the newest round's passes
         TRAFFIC = json.loads(f.read_text()) if f else {}
     gbps = bytes_per_frame * n / (ms * 1e-3) / 1e9
     t = TRAFFIC.get(key, {})
@@ -270,7 +269,7 @@ def upscale(n=64):
 
 def affine(n=64):
     """PySurfaceRotator at an angle that is no quarter turn (the reference's nppiRotate: RotateSurface.cpp:22-159): RGB 1080p by 30
-    degrees, bilinear, destination of the same size (k_rotate_affine)."""
+    degrees, bilinear, destination of the same size (k_rotate_affine_lds: the tile's source box staged in LDS, round 6)."""
     w, h = 1920, 1080
     rot = vali.PySurfaceRotator(DEV)
     b = 2 * w * h * 3
@@ -283,7 +282,7 @@ def affine(n=64):
         return srcs, dsts, rot.PrepareBatch(srcs, dsts)
     sets = make_sets(k, make)
     ms, _ = timed(rot.Stream, [lambda q=q: rot.RunBatchAsync(q, angle=30.0, shift_x=0.0, shift_y=0.0) for _, _, q in sets], 30)
-    return {"config": f"affine PySurfaceRotator RGB 1920x1080 by 30 degrees (bilinear), batch={n}, one launch", "kernel": "k_rotate_affine<u8, 3>",
+    return {"config": f"affine PySurfaceRotator RGB 1920x1080 by 30 degrees (bilinear), batch={n}, one launch", "kernel": "k_rotate_affine_lds<u8, 64, 4>",
             "us_per_frame": round(ms * 1e3 / n, 3), "bytes_moved_per_frame": b,
             "bytes_note": "whole source + destination (the corners of the destination sample outside the source and are not fetched)",
             "roofline": roofline("affine_rgb_30", b, n, ms, k)}

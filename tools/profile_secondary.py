@@ -21,7 +21,7 @@ from collections import defaultdict
 from pathlib import Path
 
 ROOT = Path(os.environ.get("GRAFT_REPO_ROOT", Path(__file__).resolve().parent.parent))
-TAG = os.environ.get("VALI_PROFILE_TAG", "r05")
+TAG = os.environ.get("VALI_PROFILE_TAG", "r06")
 OUT = ROOT / "gpurun_out" / f"prof_{TAG}_secondary"
 # config key -> (bench_configs function, kernel-name substring, frames per launch)
 KEYS = {
@@ -47,7 +47,7 @@ KEYS = {
     "upscale_1600x900_rgb": ("upscale", "k_resize_rows_rgb<", 64),     # packed RGB 720p -> 1600x900: the register form, three channels
     "upscale_1920x1080_rgb_32f": ("upscale", "k_resize_taps<", 64),    # RGB_32F 720p -> 1080p: rows-first gather kernel
     "upscale_1600x900_p10": ("upscale", "k_resize_rows<", 64),         # P10 720p -> 1600x900: LDS-staged rows form
-    "affine_rgb_30": ("affine", "k_rotate_affine", 64),               # RGB 1080p by 30 degrees
+    "affine_rgb_30": ("affine", "k_rotate_affine_lds", 64),           # RGB 1080p by 30 degrees: the LDS-staged form (round 6)
 }
 
 

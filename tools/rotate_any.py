@@ -9,7 +9,14 @@ from bench_configs import DEV, timed, fill, sets_needed, make_sets
 fmt = vali.PixelFormat[sys.argv[1]] if len(sys.argv) > 1 else vali.RGB
 w, h = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
 angle = float(sys.argv[4]) if len(sys.argv) > 4 else 30.0
-sx, sy = (float(sys.argv[5]), float(sys.argv[6])) if len(sys.argv) > 6 else (0.0, 0.0)
+sx, sy = (float(sys.argv[5]), float(sys.argv[6])) if len(sys.argv) > 6 and sys.argv[5] != "single" else (0.0, 0.0)
+if "single" in sys.argv:      # one surface per call (launch-bound): stream time and host time per RunAsync
+    rot = vali.PySurfaceRotator(DEV)
+    s_, d_ = vali.Surface.Make(fmt, w, h, DEV), vali.Surface.Make(fmt, w, h, DEV)
+    fill([s_])
+    ms, wall = timed(rot.Stream, lambda: rot.RunAsync(s_, d_, angle, sx, sy), 300, 20)
+    print('single call: stream us', round(ms * 1e3, 3), 'host us', round(wall * 1e3, 3))
+    sys.exit(0)
 n = 64 if w * h <= 1920 * 1080 else 16
 rot = vali.PySurfaceRotator(DEV)
 size = vali.Surface.Make(fmt, w, h, DEV).HostSize

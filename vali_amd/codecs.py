@@ -151,6 +151,34 @@ def _frame_to_flat(frame, av_fmt: str, w: int, h: int) -> np.ndarray:
     return out.view(np.uint8)
 
 
+# FF_PROFILE_* of the codecs this layer meets (libavcodec/defs.h): PyAV reports a profile by NAME, the reference by codecpar->profile
+_FF_PROFILES = {"baseline": 66, "constrained baseline": 66 | (1 << 9), "main": 77, "extended": 88, "high": 100, "high 10": 110,
+                "high 4:2:2": 122, "high 4:4:4 predictive": 244, "main 10": 2, "rext": 4, "profile 0": 0, "profile 1": 1,
+                "profile 2": 2, "profile 3": 3, "simple": 0, "advanced simple": 15}
+
+
+def _av_profile(cc) -> int:
+    """codecpar->profile as an int (TaskDecodeFrame.cpp GetStreamParams): PyAV's own int when it has one, the FF_PROFILE value of
+    its profile NAME when that is known (HEVC's "Main" is 1, not H.264's 77), otherwise 0 -- the same answer from the decoder and
+    from Probe."""
+    prof = getattr(cc, "profile", None)
+    if isinstance(prof, int):
+        return prof
+    if not isinstance(prof, str):
+        return 0
+    name = prof.strip().lower()
+    codec = str(getattr(getattr(cc, "codec", None), "name", "") or getattr(cc, "name", "")).lower()
+    if codec in ("hevc", "h265") and name in ("main", "main 10", "main still picture", "rext"):
+        return {"main": 1, "main 10": 2, "main still picture": 3, "rext": 4}[name]
+    return _FF_PROFILES.get(name, 0)
+
+
+def _av_base_rate(st):
+    """the stream's r_frame_rate (PyAV: base_rate), else av_guess_frame_rate, else the average rate -- ONE order for the decoder's
+    Framerate / IsVFR and for Probe().fps (TaskDecodeFrame.cpp:818, 908-922)"""
+    return getattr(st, "base_rate", None) or getattr(st, "guessed_rate", None) or getattr(st, "average_rate", None)
+
+
 class _AvSource:
     """Compressed input through PyAV: CPU demux + decode, one frame at a time, as flat uint8 arrays in the
     layout the reference's decoder emits -- planar YUV420[_10bit] in CPU mode, NV12 / P10 in accelerated mode
@@ -179,7 +207,7 @@ class _AvSource:
         self.color_range = self._RANGE.get(int(getattr(cc, "color_range", 0) or 0), ColorRange.UDEF)
         # r_frame_rate (TaskDecodeFrame.cpp:908-922) is PyAV's base_rate; guessed_rate (av_guess_frame_rate) may fall back to the
         # average or the codec rate and is only the stand-in when base_rate is missing
-        base = getattr(self._stream, "base_rate", None) or getattr(self._stream, "guessed_rate", None) or rate
+        base = _av_base_rate(self._stream)
         self.r_framerate = float(base) if base else self.framerate                 # != avg rate <=> VFR
         tb = getattr(self._stream, "time_base", None)
         self.time_base = float(tb) if tb else 0.0
@@ -190,11 +218,7 @@ class _AvSource:
         self.bit_rate = int(getattr(cc, "bit_rate", 0) or getattr(self._container, "bit_rate", 0) or 0)
         self.gop_size = int(getattr(cc, "gop_size", 0) or 0)
         self.delay = int(getattr(cc, "delay", 0) or 0)
-        prof = getattr(cc, "profile", None)            # PyAV: a name (str) or None; the reference reports codecpar->profile (int)
-        if not isinstance(prof, int):
-            prof = next((int(getattr(o, "profile")) for o in (getattr(self._stream, "codecpar", None),)
-                         if o is not None and isinstance(getattr(o, "profile", None), int)), 0 if prof is None else prof)
-        self.profile, self.level = prof, int(getattr(cc, "level", 0) or 0)
+        self.profile, self.level = _av_profile(cc), int(getattr(cc, "level", 0) or 0)
         self.num_streams = len(getattr(self._container.streams, "video", [])) if not hasattr(self._container.streams, "__len__") \
             else len(self._container.streams)
         self.stream_index = int(getattr(self._stream, "index", 0) or 0)
@@ -419,9 +443,8 @@ class PyDecoder:
                 p.color_range = _AvSource._RANGE.get(int(getattr(cc, "color_range", 0) or 0), ColorRange.UDEF)
                 p.num_frames, p.start_time = int(st.frames or 0), int(st.start_time or 0)
                 p.bit_rate, p.level = int(getattr(cc, "bit_rate", 0) or 0), int(getattr(cc, "level", 0) or 0)
-                prof = getattr(cc, "profile", None)
-                p.profile = prof if isinstance(prof, int) else 0
-                rate, avg, tb = getattr(st, "guessed_rate", None) or st.average_rate, st.average_rate, st.time_base
+                p.profile = _av_profile(cc)
+                rate, avg, tb = _av_base_rate(st), st.average_rate, st.time_base   # r_frame_rate, as GetStreamParams (TaskDecodeFrame.cpp:818)
                 p.fps, p.avg_fps = float(rate or 0), float(avg or 0)
                 p.time_base = float(tb) if tb else 0.0
                 # the reference divides the stream-time-base values by AV_TIME_BASE (TaskDecodeFrame.cpp:821-822); kept as is

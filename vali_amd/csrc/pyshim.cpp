@@ -224,6 +224,10 @@ PYBIND11_MODULE(_vali_shim, m) {
                   {"TUNE_BLOCKING_WAIT", VALI_TUNE_BLOCKING_WAIT},
                   {"TUNE_RESIZE_ROWS", VALI_TUNE_RESIZE_ROWS},
                   {"TUNE_RESIZE_COLS", VALI_TUNE_RESIZE_COLS},
+                  {"TUNE_ROTATE_AFFINE", VALI_TUNE_ROTATE_AFFINE},
+                  {"TUNE_TAP_MAX_TABLES", VALI_TUNE_TAP_MAX_TABLES},
+                  {"TUNE_TAP_FALLBACKS", VALI_TUNE_TAP_FALLBACKS},
+                  {"TUNE_TAP_EVICTIONS", VALI_TUNE_TAP_EVICTIONS},
                   {"TUNE_COUNT", VALI_TUNE_COUNT}})
     m.attr(kv.first) = kv.second;
   m.def("tuning_set", [](int key, int value) { return vali_tuning_set(key, value); });

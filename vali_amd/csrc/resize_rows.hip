@@ -43,6 +43,17 @@ constexpr int kStoreNt = 2;
 constexpr int kRwPadL = 4;       // floats in front of the first staged pixel (left edge replicas; keeps 16-byte alignment)
 constexpr int kRwTile = 256;     // dst ELEMENTS per wave and row: 2 groups x 64 lanes x 2 adjacent elements
 
+// Rows a wave of a 64-row instantiation really takes (round 6): the host counts ceil(dh / 256) workgroups down a plane whatever
+// this returns, and the rows are spread EVENLY over their 4 waves -- 900 rows are 4 workgroups of 4 x 57 instead of three full ones
+// and one whose third wave has 4 rows and whose fourth has none while the workgroup holds its slot for a full wave's time
+// (720p -> 1600x900: -10 %, profiles/r06_growing.md).  Shorter instantiations (small launches) keep their fixed count.
+template <int ROWS> __device__ __forceinline__ int rows_of_wave(int dh) {
+  if constexpr (ROWS < 64)
+    return ROWS;
+  const int groups = (dh + 4 * ROWS - 1) / (4 * ROWS);
+  return (dh + 4 * groups - 1) / (4 * groups);
+}
+
 // (bound_ctrl = 1: no `old` operand to copy into the destination first -- lane 63's value is never used, every lane of a
 // quad_perm has a source)
 __device__ __forceinline__ float rw_wave_shl1(float v) { // lane l gets lane l + 1's value
@@ -109,7 +120,8 @@ __device__ __forceinline__ void rows_tile(const uint8_t* sp, int spitch, int sw,
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int e0 = tx * kRwTile;
   const int dwe = dw * ES;
-  const int y_first = (ty * kWavesPerBlock + wave) * ROWS;
+  const int rows_w = __builtin_amdgcn_readfirstlane(rows_of_wave<ROWS>(dh));
+  const int y_first = (ty * kWavesPerBlock + wave) * rows_w;
   const float scale_x = (float)sw / (float)dw, scale_y = (float)sh / (float)dh;
   float* const lds = wg_lds + wave * wave_floats;
   float* const stage = lds;
@@ -170,7 +182,7 @@ __device__ __forceinline__ void rows_tile(const uint8_t* sp, int spitch, int sw,
     // ---- row taps: lane r evaluates row y_first + r and publishes it (weights pre-splatted for the packed FMAs); cnt[t] =
     // how many dst rows complete their window with the wave's t-th source row
     const LzTap<TAPS> vy = make_lz_tap<TAPS>(y_first + (lane & (ROWS - 1)), scale_y);
-    const int last_rr = min(ROWS, dh - y_first) - 1;
+    const int last_rr = min(rows_w, dh - y_first) - 1;
     const int s_begin = __builtin_amdgcn_readlane(vy.i, 0) - kBefore;
     const int s_end = __builtin_amdgcn_readlane(vy.i, last_rr) + TAPS - 1 - kBefore;
     cnt[lane] = 0;
@@ -388,7 +400,7 @@ __device__ __forceinline__ void rows_tile(const uint8_t* sp, int spitch, int sw,
         row[4 + 2 * k] = vy.w[k];
     }
   }
-  const int last_rr = min(ROWS, dh - y_first) - 1;
+  const int last_rr = min(rows_w, dh - y_first) - 1;
   wave_lds_sync();
 #pragma unroll 1
   for (int rr = 0; rr <= last_rr; ++rr) {
@@ -486,7 +498,8 @@ __device__ __forceinline__ void rows_reg_tile(const uint8_t* sp, int spitch, int
   const int nl = (min(e0 + kRwTile, dwe) - e0 + 3) >> 2;         // lanes with elements
   const int eb = e0 + 4 * min(lane, nl - 1);                    // (lanes past the row repeat its last lane, and store nothing)
   const int n_out = lane < nl ? min(4, dwe - eb) : 0;
-  const int y_first = (ty * kWavesPerBlock + wave) * ROWS;
+  const int rows_w = __builtin_amdgcn_readfirstlane(rows_of_wave<ROWS>(dh));
+  const int y_first = (ty * kWavesPerBlock + wave) * rows_w;
   const float scale_x = (float)sw / (float)dw, scale_y = (float)sh / (float)dh;
   float* const lds = wg_lds + wave * wave_floats;
   float* const wtab = lds + kRrShare;
@@ -527,7 +540,7 @@ __device__ __forceinline__ void rows_reg_tile(const uint8_t* sp, int spitch, int
 
   // ---- row taps (as in rows_tile): lane r evaluates row y_first + r; cnt[t]: dst rows the wave's t-th source row completes
   const LzTap<TAPS> vy = make_lz_tap<TAPS>(y_first + (lane & (ROWS - 1)), scale_y);
-  const int last_rr = min(ROWS, dh - y_first) - 1;
+  const int last_rr = min(rows_w, dh - y_first) - 1;
   const int s_begin = __builtin_amdgcn_readlane(vy.i, 0) - kBefore;
   const int s_end = __builtin_amdgcn_readlane(vy.i, last_rr) + TAPS - 1 - kBefore;
   cnt[lane] = 0;
@@ -829,7 +842,8 @@ __device__ __forceinline__ void rows_rgb_tile(const uint8_t* sp, int spitch, int
   const int xb = p0 + 2 * min(lane, nl - 1);                       // (lanes past the row repeat its last lane, and store nothing)
   const int n_px = lane < nl ? min(2, dw - xb) : 0;
   const int full = __builtin_amdgcn_readfirstlane(p0 + kRgbTilePx <= dw ? 1 : 0);
-  const int y_first = (int)(ty * kWavesPerBlock + wave) * ROWS;
+  const int rows_w = __builtin_amdgcn_readfirstlane(rows_of_wave<ROWS>(dh));
+  const int y_first = (int)(ty * kWavesPerBlock + wave) * rows_w;
   const float scale_x = (float)sw / (float)dw, scale_y = (float)sh / (float)dh;
   float* const lds = wg_lds + wave * wave_floats;
   float* const wtab = lds + kRrShare;
@@ -873,7 +887,7 @@ __device__ __forceinline__ void rows_rgb_tile(const uint8_t* sp, int spitch, int
 
   // ---- row taps: lane r evaluates row y_first + r; cnt[t]: dst rows the wave's t-th source row completes ----
   const LzTap<TAPS> vy = make_lz_tap<TAPS>(y_first + (lane & (ROWS - 1)), scale_y);
-  const int last_rr = min(ROWS, dh - y_first) - 1;
+  const int last_rr = min(rows_w, dh - y_first) - 1;
   const int s_begin = __builtin_amdgcn_readlane(vy.i, 0) - kBefore;
   const int s_end = __builtin_amdgcn_readlane(vy.i, last_rr) + TAPS - 1 - kBefore;
   cnt[lane] = 0;
@@ -949,7 +963,7 @@ __device__ __forceinline__ void rows_rgb_tile(const uint8_t* sp, int spitch, int
         u32 px[NW];
 #pragma unroll
         for (int k = 0; k < NW; ++k)
-          px[k] = __builtin_amdgcn_alignbyte(0u, w[k], eshift >> (2 * k));
+          px[k] = __builtin_amdgcn_alignbyte(0u, w[k], (eshift >> (2 * k)) & 3u); // (the selector masked: only gfx9 ignores the bits above 1)
         w[0] = __builtin_amdgcn_perm(px[1], px[0], 0x04020100u);
         w[1] = __builtin_amdgcn_perm(px[2], px[1], 0x05040201u);
         w[2] = __builtin_amdgcn_perm(px[3], px[2], 0x06050402u);

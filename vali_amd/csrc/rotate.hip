@@ -57,6 +57,7 @@ __device__ __forceinline__ bool rot_tile(const RotArgs& a, RotJob& job, u32& tx,
 }
 
 constexpr int kAffineTile = 32;
+constexpr long long kAffBigLaunchTiles = 2048; // 64 x 64 tiles of a launch from which the LDS-staged rotation uses them (8 per CU)
 template <typename T, int C>
 __device__ __forceinline__ void affine_tile(const RotArgs& a, const RotJob& job, const uint8_t* sp,
                                             int spitch, int sw, int sh, uint8_t* dp, int dpitch,
@@ -130,6 +131,228 @@ __global__ void __launch_bounds__(kBlock) k_rotate_affine(const RotArgs a) {
     affine_tile<T, 1>(a, job, v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty);
   else
     affine_tile<T, 3>(a, job, v.sp, v.spitch, v.sw, v.sh, v.dp, v.dpitch, v.dw, v.dh, tx, ty);
+}
+
+// ---- any angle, the tile's source footprint staged in LDS (round 6) ---------------------------
+// A workgroup owns TW x TH destination pixels.  The inverse map is affine and each of its two float forms (above) is monotone
+// in x' and in y' separately (a product and an fma round monotonically), so the source coordinates of the whole tile lie between
+// those of its four corners EVALUATED WITH THE SAME EXPRESSIONS: the box [floor(min xs), floor(max xs) + 1] x [floor(min ys),
+// floor(max ys) + 1], clipped to the plane, holds every texel the tile reads.  A pure rotation keeps that box within
+// (TW - 1)|c| + (TH - 1)|s| + 3 columns (rows likewise): the host sizes the dynamic LDS for the angle.
+//   phase 1  the box is loaded with coalesced row pieces (16 bytes of a row per lane, any alignment; packed RGB: 12 bytes = 4
+//            pixels) -- every load of a thread is in flight before the first LDS write -- and stored with an odd dword row stride;
+//            packed RGB is unpacked to ONE DWORD PER PIXEL so that the two horizontal taps of a row are one ds_read_b64;
+//            a box that would cross the right edge of the plane slides left to end with the row; rows past the plane's last
+//            repeat it (the row below the last one is only ever weighted with b = 0)
+//   phase 2  a lane produces 4 adjacent dst pixels per pass from LDS with the arithmetic of the specification (the same fmaf
+//            forms as k_rotate_affine); tiles whose box lies wholly inside the plane skip the per-pixel range tests.
+// The column right of the plane's last one (read when xs == W - 1 exactly, with a = 0) is whatever the LDS holds: for integer
+// pixels any finite value times 0 leaves t exactly as the specification's clamp does; float pixels select the clamped texel.
+template <typename T, int C> struct AffFmt {
+  static constexpr int PB = C * (int)sizeof(T);
+  static constexpr bool kDwordPx = sizeof(T) == 1 && C == 3; // packed RGB: one dword per pixel in LDS
+  static constexpr int LP = kDwordPx ? 4 : PB;               // LDS bytes per pixel
+  static constexpr int GCH = kDwordPx ? 12 : 16;             // global bytes of one staging piece (its LDS image is 16 bytes)
+};
+
+struct AffGeom { // host-computed, the same for every tile of the launch
+  int box_w, box_h; // most columns / rows a tile's box can have
+  int nch_max;      // staging pieces per box row at most
+  int stride;       // LDS row stride in bytes (odd number of dwords)
+};
+
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+__device__ __forceinline__ int cvt_i32_sat(float v) { // v_cvt_i32_f32: saturates, NaN -> 0 (a C cast of an out-of-range float is undefined)
+  int r;
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+__device__ __forceinline__ int med3i(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+// the two horizontal taps of one box row from LDS.  Every access is NATURALLY ALIGNED: a DS read whose address is not a multiple
+// of its size returns the right bytes but takes 256 cycles per wave instruction instead of 16 (one lane at a time;
+// tools/exp/lds_unaligned.hip, profiles/r06_rotate.md) -- the first form of this kernel read a packed-RGB pair with one
+// ds_read_b64 at 4-byte alignment and spent its whole time there.
+template <typename T, int C>
+__device__ __forceinline__ void lds_tap_pair(const lds_u8* p, bool last_col, float (&t0)[C], float (&t1)[C]) {
+  if constexpr (sizeof(T) == 1 && C == 3) {
+    const __attribute__((address_space(3))) u32* q = (const __attribute__((address_space(3))) u32*)p; // ds_read2_b32 offset1:1
+    const u32 lo = q[0], hi = q[1];
+    t0[0] = ubyte_f32<0>(lo); t0[1] = ubyte_f32<1>(lo); t0[2] = ubyte_f32<2>(lo);
+    t1[0] = ubyte_f32<0>(hi); t1[1] = ubyte_f32<1>(hi); t1[2] = ubyte_f32<2>(hi);
+  } else { // element reads (float pixels select the clamped texel: 0 x inf would not be 0)
+    const __attribute__((address_space(3))) T* f = (const __attribute__((address_space(3))) T*)p;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) {
+      t0[ch] = (float)f[ch];
+      t1[ch] = sizeof(T) == 4 && last_col ? t0[ch] : (float)f[C + ch];
+    }
+  }
+}
+
+template <typename T, int C, int TW, int PASSES, bool INTERIOR>
+__device__ __forceinline__ void affine_lds_rows(const RotArgs& a, const RotJob& job, const PlaneView& v, const lds_u8* lds, int stride,
+                                                int base, int X0, int Y0, int x_lo, int x_hi, int y_lo, int y_hi) {
+  constexpr int PB = AffFmt<T, C>::PB, LP = AffFmt<T, C>::LP, kLanesPerRow = TW / 4, kRowsPerPass = kBlock / kLanesPerRow;
+  const int x0 = X0 + (int)(threadIdx.x % kLanesPerRow) * 4;
+  const float wmax = (float)(v.sw - 1), hmax = (float)(v.sh - 1);
+  float dxs[4], cdx[4], sdx[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    dxs[p] = (float)(x0 + p) - job.shift_x;
+    cdx[p] = a.c * dxs[p];
+    sdx[p] = a.s * dxs[p];
+  }
+#pragma unroll 1
+  for (int pass = 0; pass < PASSES; ++pass) {
+    const int y = Y0 + pass * kRowsPerPass + (int)(threadIdx.x / kLanesPerRow);
+    if (!INTERIOR && (x0 >= v.dw || y >= v.dh))
+      continue;
+    const float dy = (float)y - job.shift_y;
+    float fa[4], fb[4], t[4][4][C];
+    u32 mask = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const float xs = __builtin_fmaf(-a.s, dy, cdx[p]);
+      const float ys = __builtin_fmaf(a.c, dy, sdx[p]);
+      fa[p] = __builtin_amdgcn_fractf(xs); // = xs - floor(xs) exactly for xs >= 0 (the only values that are used)
+      fb[p] = __builtin_amdgcn_fractf(ys);
+      int i = cvt_i32_sat(xs), j = cvt_i32_sat(ys); // truncation = floor for xs >= 0
+      if constexpr (!INTERIOR) {
+        const bool hit = (x0 + p < v.dw) && xs >= 0.0f && xs <= wmax && ys >= 0.0f && ys <= hmax;
+        mask |= hit ? (1u << p) : 0u;
+        i = med3i(i, x_lo, x_hi); // missed pixels read some texel of the box and are not stored
+        j = med3i(j, y_lo, y_hi);
+      } else {
+        mask = 0xfu;
+      }
+      const lds_u8* r0 = lds + (__mul24(j, stride) + i * LP + base); // (24-bit multiply: full rate; v_mul_lo_u32 is quarter rate)
+      lds_tap_pair<T, C>(r0, i >= v.sw - 1, t[p][0], t[p][1]);
+      lds_tap_pair<T, C>(r0 + stride, i >= v.sw - 1, t[p][2], t[p][3]);
+    }
+    if (!INTERIOR && !mask)
+      continue;
+    float res[4][C];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) {
+        const float t0 = __builtin_fmaf(fa[p], t[p][1][ch] - t[p][0][ch], t[p][0][ch]);
+        const float t1 = __builtin_fmaf(fa[p], t[p][3][ch] - t[p][2][ch], t[p][2][ch]);
+        res[p][ch] = __builtin_fmaf(fb[p], t1 - t0, t0);
+      }
+    store_px4<T, C>(v.dp + (u32)(y * v.dpitch) + (size_t)x0 * PB, res, mask);
+  }
+}
+
+// most staging pieces of a tile (any angle) over kBlock threads: box area at 45 degrees
+constexpr int aff_isqrt_up(int v) { int r = 0; while (r * r < v) ++r; return r; }
+template <typename T, int C, int TW, int TH> constexpr int aff_max_pieces() {
+  const int diag = aff_isqrt_up(2 * (TW + TH) * (TW + TH) / 4) + 5;           // (TW + TH) / sqrt(2), rounded up, + slack
+  const int per_row = (diag * AffFmt<T, C>::PB + AffFmt<T, C>::GCH - 1) / AffFmt<T, C>::GCH + 1;
+  return (per_row * (diag + 1) + kBlock - 1) / kBlock;
+}
+
+template <typename T, int C, int TW, int PASSES>
+__device__ __forceinline__ void affine_lds_tile(const RotArgs& a, const AffGeom& g, const RotJob& job, const PlaneView& v, u32 tile_x,
+                                                u32 tile_y, lds_u8* lds) {
+  typedef AffFmt<T, C> F;
+  constexpr int kLanesPerRow = TW / 4, TH = kBlock / kLanesPerRow * PASSES;
+  const int X0 = tile_x * TW, Y0 = tile_y * TH;
+  const int X1 = min(X0 + TW, v.dw) - 1, Y1 = min(Y0 + TH, v.dh) - 1;
+  // the box: lane k (k = 0..3 of every wave) evaluates corner k; broadcast before anything diverges
+  int min_i, max_i, min_j, max_j;
+  {
+    const int lane = threadIdx.x & 63;
+    const float dx = (float)((lane & 1) ? X1 : X0) - job.shift_x, dy = (float)((lane & 2) ? Y1 : Y0) - job.shift_y;
+    const float xs = __builtin_fmaf(-a.s, dy, a.c * dx), ys = __builtin_fmaf(a.c, dy, a.s * dx);
+    const int ic = med3i(cvt_i32_sat(__builtin_floorf(xs)), -4, 1 << 24), jc = med3i(cvt_i32_sat(__builtin_floorf(ys)), -4, 1 << 24);
+    const int i0 = __builtin_amdgcn_readlane(ic, 0), i1 = __builtin_amdgcn_readlane(ic, 1), i2 = __builtin_amdgcn_readlane(ic, 2),
+              i3 = __builtin_amdgcn_readlane(ic, 3);
+    const int j0 = __builtin_amdgcn_readlane(jc, 0), j1 = __builtin_amdgcn_readlane(jc, 1), j2 = __builtin_amdgcn_readlane(jc, 2),
+              j3 = __builtin_amdgcn_readlane(jc, 3);
+    min_i = min(min(i0, i1), min(i2, i3)); max_i = max(max(i0, i1), max(i2, i3));
+    min_j = min(min(j0, j1), min(j2, j3)); max_j = max(max(j0, j1), max(j2, j3));
+  }
+  if (max_i < 0 || min_i > v.sw - 1 || max_j < 0 || min_j > v.sh - 1)
+    return; // no pixel of the tile samples inside the plane: the destination stays untouched
+  const int x_lo = max(min_i, 0), x_hi = min(min(max_i + 1, v.sw - 1), x_lo + g.box_w - 1);
+  const int y_lo = max(min_j, 0), y_hi = min(min(max_j + 1, v.sh - 1), y_lo + g.box_h - 1);
+  const int bw = x_hi - x_lo + 1, bh = y_hi - y_lo + 1;
+  // phase 1
+  const int nch = min((bw * F::PB + F::GCH - 1) / F::GCH, g.nch_max);
+  int org; // origin of the LDS rows: a pixel (packed RGB) or a byte offset of the row (everything else)
+  if constexpr (F::kDwordPx)
+    org = min(x_lo, v.sw - 4 * nch);
+  else
+    org = min(x_lo * F::PB, v.sw * F::PB - 16 * nch);
+  {
+    const int nrows = bh + 1, total = nrows * nch;
+    const u32 inv = (1u << 20) / (u32)nch + 1u; // k / nch = (k * inv) >> 20: exact for k < 2^20 / nch, no overflow for k < 4096
+    constexpr int kMax = aff_max_pieces<T, C, TW, TH>();
+    typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+    typedef typename std::conditional<F::kDwordPx, v3u32, v4u32>::type Piece;
+    Piece w[kMax];
+    int at[kMax];
+#pragma unroll
+    for (int q = 0; q < kMax; ++q) {
+      if (q * kBlock < total) { // (uniform)
+        const int k = min((int)threadIdx.x + q * kBlock, total - 1); // lanes past the end repeat the last piece
+        const int r = (int)(((u32)k * inv) >> 20), cidx = k - r * nch;
+        const uint8_t* row = v.sp + (u32)(min(y_lo + r, v.sh - 1) * v.spitch);
+        at[q] = r * g.stride + 16 * cidx;
+        if constexpr (F::kDwordPx)
+          w[q] = gload_u<v3u32>(row + (org + 4 * cidx) * 3);
+        else
+          w[q] = gload_u<v4u32>(row + org + 16 * cidx);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kMax; ++q) {
+      if (q * kBlock < total) {
+        __attribute__((address_space(3))) u32* l = (__attribute__((address_space(3))) u32*)(lds + at[q]);
+        if constexpr (F::kDwordPx) {
+          l[0] = w[q].x; // (byte 3 of a pixel's dword is the next pixel's first: never read)
+          l[1] = __builtin_amdgcn_alignbyte(w[q].y, w[q].x, 3);
+          l[2] = __builtin_amdgcn_alignbyte(w[q].z, w[q].y, 2);
+          l[3] = w[q].z >> 8;
+        } else {
+          l[0] = w[q].x; l[1] = w[q].y; l[2] = w[q].z; l[3] = w[q].w;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // phase 2
+  const int base = -(F::kDwordPx ? org * 4 : org) - y_lo * g.stride;
+  const bool interior = min_i >= 0 && max_i + 1 <= v.sw - 1 && min_j >= 0 && max_j + 1 <= v.sh - 1 && X0 + TW <= v.dw && Y0 + TH <= v.dh &&
+                        max_i + 1 - min_i < g.box_w && max_j + 1 - min_j < g.box_h;
+  if (interior)
+    affine_lds_rows<T, C, TW, PASSES, true>(a, job, v, lds, g.stride, base, X0, Y0, x_lo, x_hi, y_lo, y_hi);
+  else
+    affine_lds_rows<T, C, TW, PASSES, false>(a, job, v, lds, g.stride, base, X0, Y0, x_lo, x_hi, y_lo, y_hi);
+}
+
+template <typename T, int TW, int PASSES>
+__global__ void __launch_bounds__(kBlock) k_rotate_affine_lds(const RotArgs a, const AffGeom g1, const AffGeom g3) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t aff_lds_raw[];
+  lds_u8* lds = (lds_u8*)aff_lds_raw;
+  RotJob job;
+  u32 tx, ty, frame;
+  if (!rot_tile(a, job, tx, ty, frame))
+    return;
+  const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
+  // the pixel formats have u8 x 1, u8 x 3, u16 x 1 and f32 x 3 planes (rotate_jobs)
+  if constexpr (sizeof(T) == 1) {
+    if (job.channels == 1)
+      affine_lds_tile<T, 1, TW, PASSES>(a, g1, job, v, tx, ty, lds);
+    else
+      affine_lds_tile<T, 3, TW, PASSES>(a, g3, job, v, tx, ty, lds);
+  } else if constexpr (sizeof(T) == 2) {
+    affine_lds_tile<T, 1, TW, PASSES>(a, g1, job, v, tx, ty, lds);
+  } else {
+    affine_lds_tile<T, 3, TW, PASSES>(a, g3, job, v, tx, ty, lds);
+  }
 }
 
 // ---- canonical 90 / 270 degree permutation: LDS-tiled transpose -----------------------------
@@ -567,6 +790,75 @@ template <int QUARTER> static int launch_tile(const RotArgs& a, int pixel_bytes,
   return VALI_OK;
 }
 
+// ---- host side of the LDS-staged form ----
+template <typename T, int C> static AffGeom aff_geom(float c, float s, int tw, int th) {
+  const double ac = fabs((double)c), as = fabs((double)s);
+  AffGeom g;
+  // floor(max) + 1 - floor(min) + 1 <= floor(span) + 3 columns; + 1 of slack for the rounding of the float forms
+  g.box_w = (int)floor((tw - 1) * ac + (th - 1) * as) + 4;
+  g.box_h = (int)floor((tw - 1) * as + (th - 1) * ac) + 4;
+  g.nch_max = (g.box_w * AffFmt<T, C>::PB + AffFmt<T, C>::GCH - 1) / AffFmt<T, C>::GCH;
+  g.stride = 16 * g.nch_max + 4; // an odd number of dwords
+  return g;
+}
+static unsigned aff_lds_bytes(const AffGeom& g) { return (unsigned)((g.box_h + 1) * g.stride + 32); }
+
+// every plane of the launch must be at least as wide as the widest staged row (the box slides left to end with the row)
+template <typename T, int C> static bool aff_plane_ok(const AffGeom& g, int psw) { return psw * AffFmt<T, C>::PB >= g.nch_max * AffFmt<T, C>::GCH; }
+
+template <typename T, int TW, int PASSES>
+static bool launch_affine_lds(RotArgs& a, int n, int sw, int sh, int dw, int dh, hipStream_t stream) {
+  constexpr int TH = kBlock / (TW / 4) * PASSES;
+  const AffGeom g1 = aff_geom<T, 1>(a.c, a.s, TW, TH), g3 = aff_geom<T, 3>(a.c, a.s, TW, TH);
+  bool one = false, three = false;
+  u32 total = 0;
+  for (int k = 0; k < a.njobs; ++k) {
+    RotJob& j = a.job[k];
+    const int psw = sw >> j.sub_x, pdw = dw >> j.sub_x, pdh = dh >> j.sub_y;
+    if (j.channels == 1) {
+      one = true;
+      if (!aff_plane_ok<T, 1>(g1, psw) || (g1.box_h + 1) * g1.nch_max > kBlock * aff_max_pieces<T, 1, TW, TH>())
+        return false;
+    } else {
+      three = true;
+      if (!aff_plane_ok<T, 3>(g3, psw) || (g3.box_h + 1) * g3.nch_max > kBlock * aff_max_pieces<T, 3, TW, TH>())
+        return false;
+    }
+    j.first_tile = total;
+    j.tiles_x = (u32)(pdw + TW - 1) / TW;
+    total += j.tiles_x * (u32)((pdh + TH - 1) / TH);
+  }
+  const unsigned lds = max(one ? aff_lds_bytes(g1) : 0u, three ? aff_lds_bytes(g3) : 0u);
+  if (lds > 64u * 1024u)
+    return false;
+  a.map = make_tile_map_linear(total, (u32)n);
+  hipLaunchKernelGGL((k_rotate_affine_lds<T, TW, PASSES>), tile_grid(a.map), dim3(kBlock), lds, stream, a, g1, g3);
+  return true;
+}
+
+template <typename T> static bool launch_affine_lds_form(RotArgs& a, int form, int n, int sw, int sh, int dw, int dh, hipStream_t stream) {
+  // tile shape: 64 x 64 destination pixels where the launch still has enough workgroups to fill the chip a few times over,
+  // 32 x 32 for small launches and for float pixels (whose 64 x 64 box does not fit the LDS budget) -- profiles/r06_rotate.md
+  if (form == 0) {
+    long long tiles64 = 0;
+    for (int k = 0; k < a.njobs; ++k)
+      tiles64 += (long long)(((dw >> a.job[k].sub_x) + 63) / 64) * (((dh >> a.job[k].sub_y) + 63) / 64);
+    form = sizeof(T) == 4 ? 6 : tiles64 * n >= kAffBigLaunchTiles ? 4 : tiles64 * n >= kAffBigLaunchTiles / 4 ? 3 : 6;
+  }
+  if constexpr (sizeof(T) != 4) {
+    switch (form) {
+    case 2: return launch_affine_lds<T, 32, 2>(a, n, sw, sh, dw, dh, stream);
+    case 3: if (launch_affine_lds<T, 64, 2>(a, n, sw, sh, dw, dh, stream)) return true; break;
+    case 4: // (16-bit planes: 64 x 32 -- their 64 x 64 instantiation needs 140 registers)
+      if (sizeof(T) == 1 ? launch_affine_lds<uint8_t, 64, 4>(a, n, sw, sh, dw, dh, stream) : launch_affine_lds<T, 64, 2>(a, n, sw, sh, dw, dh, stream))
+        return true;
+      break; // (a plane narrower than its staged row: 32 x 32)
+    default: break;
+    }
+  }
+  return launch_affine_lds<T, 32, 1>(a, n, sw, sh, dw, dh, stream);
+}
+
 // per_plane_shifts != 0: quarter turns whose shifts are derived from each plane's own size
 // (what PySurfaceRotator's normalisation means for every plane); otherwise the given
 // shifts apply to every plane unchanged (NPP semantics of RotPlanar).
@@ -616,6 +908,26 @@ static int launch_rotate(RotArgs& a, int fmt, int sw, int sh, int dw, int dh, do
       j.tiles_x = (u32)(pdw + 255) / 256;
       total += j.tiles_x * (u32)((pdh + kHalfTileH - 1) / kHalfTileH);
     } else {
+      j.tiles_x = (u32)(pdw + kAffineTile - 1) / kAffineTile;
+      total += j.tiles_x * (u32)((pdh + kAffineTile - 1) / kAffineTile);
+    }
+  }
+  if (!tiled && !half) {
+    // any other angle: the LDS-staged form unless a plane is narrower than a staged row (or VALI_TUNE_ROTATE_AFFINE = 1)
+    const int form = tuning(VALI_TUNE_ROTATE_AFFINE);
+    const bool done = form == 1 ? false
+                      : elem == 1 ? launch_affine_lds_form<uint8_t>(a, form, n, sw, sh, dw, dh, stream)
+                      : elem == 2 ? launch_affine_lds_form<uint16_t>(a, form, n, sw, sh, dw, dh, stream)
+                                  : launch_affine_lds_form<float>(a, form, n, sw, sh, dw, dh, stream);
+    if (done) {
+      VALI_LAUNCH_CHECK();
+      return VALI_OK;
+    }
+    total = 0; // the gather form: its own tiling
+    for (int k = 0; k < a.njobs; ++k) {
+      RotJob& j = a.job[k];
+      const int pdw = dw >> j.sub_x, pdh = dh >> j.sub_y;
+      j.first_tile = total;
       j.tiles_x = (u32)(pdw + kAffineTile - 1) / kAffineTile;
       total += j.tiles_x * (u32)((pdh + kAffineTile - 1) / kAffineTile);
     }

@@ -17,6 +17,8 @@
 
 namespace vali {
 
+void tap_table_forget_stream(int device, hipStream_t stream); // tap_table.hip
+
 // ---- the tuning table (include/vali_hip.h: vali_tuning_key) -- the ONLY place the library reads the environment
 namespace {
 struct TuneDef {
@@ -28,7 +30,8 @@ const TuneDef kTuneDefs[VALI_TUNE_COUNT] = {
     {"VALI_RESIZE_POINT", 1},  {"VALI_UD_FORCE_GATHER", 0},   {"VALI_UD_DOWN2", 1},          {"VALI_UD_OCC5", 0},
     {"VALI_ROTATE_NO_TILE", 0}, {"VALI_ROCTX", 0},            {"VALI_RESIZE_NO_SEPARABLE", 0},
     {"VALI_ROWS_PER_WAVE", 0}, {"VALI_BLOCKING_WAIT", 0},    {"VALI_RESIZE_ROWS", 1},
-    {"VALI_RESIZE_COLS", 0}};
+    {"VALI_RESIZE_COLS", 0},   {"VALI_ROTATE_AFFINE", 0},   {"VALI_TAP_MAX_TABLES", 1024},
+    {"VALI_TAP_FALLBACKS", 0}, {"VALI_TAP_EVICTIONS", 0}};
 std::atomic<int> g_tune[VALI_TUNE_COUNT];
 std::once_flag g_tune_once;
 
@@ -66,6 +69,11 @@ void tune_init() {
   });
 }
 } // namespace
+
+void tuning_add(int key, int delta) { // the counters of the table (VALI_TUNE_TAP_FALLBACKS ...)
+  tune_init();
+  g_tune[key].fetch_add(delta, std::memory_order_relaxed);
+}
 
 int tuning(int key) {
   tune_init();
@@ -227,6 +235,8 @@ int vali_stream_destroy(int device, vali_stream_t stream) {
   VALI_DEVICE(device);
   if (stream) {
     drop_wait_slot(device, as_stream(stream));
+    VALI_HIP_CHECK(hipStreamSynchronize(as_stream(stream))); // what it was given is done: no tap table is still read through it
+    tap_table_forget_stream(device, as_stream(stream));
     VALI_HIP_CHECK(hipStreamDestroy(as_stream(stream)));
   }
   return VALI_OK;

@@ -452,24 +452,40 @@ class IngestRing:
         for tag, item in enumerate(chunks):
             for s in self.reap():
                 yield s.tag, s.dsts[:s.valid]
-            slot = self.acquire()
-            if fill is not None:
-                wrote = fill(slot.host, item)
-                if wrote is None:
-                    valid = self.n
-                elif isinstance(wrote, (int, np.integer)) and not isinstance(wrote, (bool, np.bool_)) and 1 <= int(wrote) <= self.n:
-                    valid = int(wrote)
-                else:
-                    raise TypeError(f"IngestRing.feed: fill() returns None or the number of frames it wrote (1..{self.n}), got {wrote!r}")
-            else:
+            # A chunk the ring cannot take: what was submitted is still delivered, in order, before the error surfaces.
+            err = None
+            if fill is None:                       # validated BEFORE a slot is taken
                 a = np.asarray(item, np.uint8).reshape(-1)
-                if a.size == 0 or a.size % self.frame_bytes or a.size > self.n * self.frame_bytes:
-                    raise ValueError(f"IngestRing.feed: a chunk is 1..{self.n} whole frames of {self.frame_bytes} bytes")
-                slot.host[:a.size] = a
-                valid = a.size // self.frame_bytes
-            ok, info = self.submit(slot, tag, valid)
-            if not ok:
-                raise RuntimeError(f"IngestRing: operator failed: {info}")
+                if a.size == 0:
+                    break                          # an empty chunk is the end of the input
+                if a.size % self.frame_bytes or a.size > self.n * self.frame_bytes:
+                    err = ValueError(f"IngestRing.feed: a chunk is 1..{self.n} whole frames of {self.frame_bytes} bytes")
+            if err is None:
+                slot = self.acquire()
+                if fill is not None:
+                    wrote = fill(slot.host, item)
+                    if wrote is None:
+                        valid = self.n
+                    elif isinstance(wrote, (int, np.integer)) and not isinstance(wrote, (bool, np.bool_)) and 0 <= int(wrote) <= self.n:
+                        valid = int(wrote)
+                        if valid == 0:             # fill() wrote nothing: end of the stream (the slot goes back unused)
+                            self._next = (self._next - 1) % len(self.slots)
+                            break
+                    else:
+                        self._next = (self._next - 1) % len(self.slots)
+                        err = TypeError(f"IngestRing.feed: fill() returns None or the number of frames it wrote (0 = end of input, "
+                                        f"1..{self.n}), got {wrote!r}")
+                else:
+                    slot.host[:a.size] = a
+                    valid = a.size // self.frame_bytes
+            if err is None:
+                ok, info = self.submit(slot, tag, valid)
+                if not ok:
+                    err = RuntimeError(f"IngestRing: operator failed: {info}")
+            if err is not None:
+                for s in self.drain():
+                    yield s.tag, s.dsts[:s.valid]
+                raise err
         for s in self.drain():
             yield s.tag, s.dsts[:s.valid]
 
