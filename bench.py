@@ -367,8 +367,9 @@ def compact_line(out):
     if isinstance(hp, dict) and isinstance(hp.get("gpu_state"), dict):
         g = hp["gpu_state"]
         ul = g.get("under_load") if isinstance(g.get("under_load"), dict) else {}
-        hp["gpu_state"] = {"sclk_mhz_under_load": ul.get("sclk_mhz"), "power_w_under_load": ul.get("power_w"),
-                           "power_cap_w": g.get("power_cap_w"), "partition": f"{g.get('compute_partition')}/{g.get('memory_partition')}"}
+        if "error" not in g:
+            hp["gpu_state"] = {"under_load": {k: ul.get(k) for k in ("sclk_mhz", "power_w", "samples")},
+                               "power_cap_w": g.get("power_cap_w"), "partition": f"{g.get('compute_partition')}/{g.get('memory_partition')}"}
     return out
 
 

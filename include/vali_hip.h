@@ -320,6 +320,13 @@ enum vali_interpolation {
  * YUV420->NV12 round trip :132-188).  Formats: Y, NV12, P10, P12, YUV420(_10BIT), YUV422,
  * YUV444(_10BIT), RGB, BGR, RGB_32F, RGB_PLANAR, RGB_32F_PLANAR.  The reference's resizer is
  * Lanczos-only (NPPI_INTER_LANCZOS, :67); bilinear is BASELINE.json's definition.
+ *
+ * Device memory the library owns itself: the Lanczos / bicubic forms keep per-geometry TAP TABLES (32 B per destination
+ * column / row).  All tables of a device live in ONE 32 MiB arena that the first Lanczos / bicubic call of the process on
+ * that device reserves (the only hipMalloc the operators ever make: once per device and process); every later call --
+ * new geometries included -- allocates nothing and is asynchronous on `stream`.  Least recently used tables are evicted
+ * when the arena or VALI_TUNE_TAP_MAX_TABLES is exhausted; during a graph capture, and for axes longer than 32 768 samples,
+ * no table is used (the kernels compute their taps: same result).  vali_stream_destroy makes the library forget the stream.
  */
 VALI_API int vali_resize(const vali_surface* src, const vali_surface* dst, int interpolation,
                          vali_stream_t stream);
