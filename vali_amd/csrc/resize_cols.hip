@@ -1088,26 +1088,38 @@ __device__ __forceinline__ void cols_tile_ws(const uint8_t* sp, int spitch, int 
   // whole groups of 4 elements from every lane that stores, on rows aligned to a group: one store per lane and row, no
   // per-lane alignment test, and the row's offset a SCALAR operand of a buffer store (as in cols_walk)
   const bool plain_store = ((e_last + 1 - e0) & 3) == 0 && ((((uintptr_t)dp) | (uintptr_t)dpitch) & (4u * EB - 1u)) == 0; // wave-uniform
+  // Round 6: a tile's row segment is cols_n elements (248 ...), so its first and last 64-byte sectors are shared with the neighbouring
+  // tiles; a non-temporal store of half a sector does not wait in the L2 for the other half (writes 1.15 - 1.26 x the destination,
+  // VERDICT r05 #5b).  A lane whose group lies in a sector the segment covers whole stores non-temporally, the others plain.
+  const bool rows64 = ((((uintptr_t)dp) | (uintptr_t)dpitch) & 63u) == 0;                                                 // wave-uniform
+  auto whole_sector = [&](int e) { // e: the lane's first element; its group of 4 never straddles a sector (4 EB divides 64)
+    const int b = e * EB, lo = b & ~63;
+    return rows64 && lo >= e0 * EB && lo + 64 <= (e_last + 1) * EB;
+  };
+  const bool nt1 = whole_sector(eb), nt2 = NS > 4 ? whole_sector(eb + 256) : false;
   const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(dp, (short)0, (int)0xffffffffu, 0x00020000);
   const int nfull = (last_rr + 1) >> 1;                                    // pairs of two rows
   const bool single_last = (last_rr & 1) == 0;                             // ... and one more of ONE row (its second)
   auto pairs = [&](auto plain_tag, auto pad_tag) {
     constexpr bool PLAIN = decltype(plain_tag)::value, PADS = decltype(pad_tag)::value;
     // soff: byte offset of the row in the plane (scalar)
-    auto store_row = [&](int soff, int eb, int n_out, float v0, float v1, float v2, float v3) {
+    auto store_row = [&](int soff, int eb, int n_out, bool nt, float v0, float v1, float v2, float v3) {
       if constexpr (PLAIN) {
         if constexpr (EB == 1) {
           u32 q = __builtin_amdgcn_cvt_pk_u8_f32(v0, 0u, 0u);
           q = __builtin_amdgcn_cvt_pk_u8_f32(v1, 1u, q);
           q = __builtin_amdgcn_cvt_pk_u8_f32(v2, 2u, q);
           q = __builtin_amdgcn_cvt_pk_u8_f32(v3, 3u, q);
-          __builtin_amdgcn_raw_buffer_store_b32(q, drsrc, eb, soff, 2); // (2: nt -- finished output, whole lines)
+          if (nt) __builtin_amdgcn_raw_buffer_store_b32(q, drsrc, eb, soff, 2); // (2: nt -- finished output, whole sectors)
+          else __builtin_amdgcn_raw_buffer_store_b32(q, drsrc, eb, soff, 0);
         } else if constexpr (EB == 2) {
           const v2u32 q = {finish_bits<T>(v0) | (finish_bits<T>(v1) << 16), finish_bits<T>(v2) | (finish_bits<T>(v3) << 16)};
-          __builtin_amdgcn_raw_buffer_store_b64(q, drsrc, eb * 2, soff, 2);
+          if (nt) __builtin_amdgcn_raw_buffer_store_b64(q, drsrc, eb * 2, soff, 2);
+          else __builtin_amdgcn_raw_buffer_store_b64(q, drsrc, eb * 2, soff, 0);
         } else {
           const v4u32 q = {__float_as_uint(v0), __float_as_uint(v1), __float_as_uint(v2), __float_as_uint(v3)};
-          __builtin_amdgcn_raw_buffer_store_b128(q, drsrc, eb * 4, soff, 2);
+          if (nt) __builtin_amdgcn_raw_buffer_store_b128(q, drsrc, eb * 4, soff, 2);
+          else __builtin_amdgcn_raw_buffer_store_b128(q, drsrc, eb * 4, soff, 0);
         }
       } else {
         uint8_t* const out = dp + (u32)soff + (size_t)eb * EB;
@@ -1146,10 +1158,10 @@ __device__ __forceinline__ void cols_tile_ws(const uint8_t* sp, int spitch, int 
         asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
                      : "=&v"(v0), "=&v"(v1) : "v"(obuf_rd), "i"(B * kWsStripBytes), "i"(B * kWsStripBytes + 16) : "memory");
         if constexpr (!ONLYB) {
-          store_row(soff, eb, n_out, v0.x, v0.z, v1.x, v1.z);
-          store_row(soff + dpitch, eb, n_out, v0.y, v0.w, v1.y, v1.w);
+          store_row(soff, eb, n_out, nt1, v0.x, v0.z, v1.x, v1.z);
+          store_row(soff + dpitch, eb, n_out, nt1, v0.y, v0.w, v1.y, v1.w);
         } else {
-          store_row(soff, eb, n_out, v0.y, v0.w, v1.y, v1.w);
+          store_row(soff, eb, n_out, nt1, v0.y, v0.w, v1.y, v1.w);
         }
       }
       if constexpr (NS > 4) {
@@ -1158,10 +1170,10 @@ __device__ __forceinline__ void cols_tile_ws(const uint8_t* sp, int spitch, int 
           asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
                        : "=&v"(v0), "=&v"(v1) : "v"(obuf_rd), "i"(B * kWsStripBytes + 2048), "i"(B * kWsStripBytes + 2064) : "memory");
           if constexpr (!ONLYB) {
-            store_row(soff, eb + 256, n_out2, v0.x, v0.z, v1.x, v1.z);
-            store_row(soff + dpitch, eb + 256, n_out2, v0.y, v0.w, v1.y, v1.w);
+            store_row(soff, eb + 256, n_out2, nt2, v0.x, v0.z, v1.x, v1.z);
+            store_row(soff + dpitch, eb + 256, n_out2, nt2, v0.y, v0.w, v1.y, v1.w);
           } else {
-            store_row(soff, eb + 256, n_out2, v0.y, v0.w, v1.y, v1.w);
+            store_row(soff, eb + 256, n_out2, nt2, v0.y, v0.w, v1.y, v1.w);
           }
         }
       }
