@@ -117,3 +117,44 @@ def test_a_new_geometry_does_not_wait_for_another_streams_work(vali, gpu):
         shim.stream_sync(gpu, my_stream)
         shim.stream_destroy(gpu, busy_stream)
         shim.stream_destroy(gpu, my_stream)
+
+
+def test_two_threads_share_a_small_table_budget(vali, gpu, oracle):
+    """Two host threads, each with its own stream and resizer, run different geometries concurrently against a budget of 3 tables:
+    lookups, evictions and table writes interleave under the library's lock; every output is exact and nothing falls back."""
+    import threading
+
+    from vali_amd._native import shim
+
+    rng = np.random.default_rng(8)
+    sw, sh = 800, 450
+    host = rng.integers(0, 256, sw * sh, dtype=np.uint8)
+    src = _up(vali, gpu, vali.Y, sw, sh, host)
+    errors = []
+
+    def work(k):
+        try:
+            stream = shim.stream_create(gpu)
+            rs = vali.PySurfaceResizer(vali.Y, gpu, stream)
+            down = vali.PySurfaceDownloader(gpu, stream)
+            for i in range(14):
+                dw, dh = 700 - 8 * i - 2 * k, 400 - 4 * i - 2 * k
+                d = vali.Surface.Make(vali.Y, dw, dh, gpu)
+                assert rs.Run(src, d)[0]
+                got = np.zeros(d.HostSize, np.uint8)
+                assert down.Run(d, got)[0]
+                assert np.array_equal(got, oracle.resize_surface(host, "Y", sw, sh, dw, dh, "lanczos")), (k, dw, dh)
+            shim.stream_sync(gpu, stream)
+            del rs, down
+            shim.stream_destroy(gpu, stream)
+        except BaseException as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append((k, repr(e)))
+
+    with vali.tuning.Override(TAP_MAX_TABLES=3, TAP_FALLBACKS=0, TAP_EVICTIONS=0):
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        assert vali.tuning.Get("TAP_FALLBACKS") == 0 and vali.tuning.Get("TAP_EVICTIONS") >= 40
