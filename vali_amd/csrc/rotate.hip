@@ -13,10 +13,13 @@
 // rotation etalons pin.
 //
 // Kernels:
-//  * k_rotate_affine<T>: any angle.  cos/sin arrive from the host as floats (snapped to
+//  * k_rotate_affine_lds<T, TW, PASSES> (round 6): any angle.  cos/sin arrive from the host as floats (snapped to
 //    exactly 0/+-1 for multiples of 90 degrees), so the device does only fma/mul/add and is
-//    bit-exact with the oracle.  One lane = 4 adjacent dst pixels (wide stores), a workgroup =
-//    32 x 32 dst pixels so that its source footprint is a compact square whatever the angle.
+//    bit-exact with the oracle.  A workgroup owns TW x TH dst pixels (64 x 64 for full launches), stages the bounding box of
+//    their source coordinates in LDS with coalesced row loads and interpolates from there; one lane = 4 adjacent dst pixels
+//    per pass (wide stores).  RGB 1080p by 30 degrees: 6.3 -> 2.2 us (profiles/r06_rotate.md).
+//  * k_rotate_affine<T> (round 2): the same arithmetic with per-pixel gathers from global memory, 32 x 32 dst pixels per
+//    workgroup: planes narrower than a staged row, and VALI_TUNE_ROTATE_AFFINE = 1.
 //  * k_rotate_tile<P,Q>: the canonical 90 / 270 degree permutations as an LDS-tiled transpose:
 //    a 64x64-pixel tile is read with coalesced row segments, written with coalesced row
 //    segments of the transposed tile; LDS row stride 64*P+4 bytes keeps the column walks
