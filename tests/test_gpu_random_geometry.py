@@ -90,3 +90,10 @@ def test_random_single_plane_resize_rotate(vali, gpu, oracle, geom, fmt, dt, ch)
         d = vali.Surface.Make(pf, rw, rh, gpu)
         assert vali.PySurfaceRotator(gpu).Run(src, d, angle)[0]
         assert np.array_equal(_down(vali, gpu, d, dt).reshape(rh, rw, ch).view(np.uint8), np.rot90(img, k=k).copy().view(np.uint8)), angle
+
+
+def test_no_resize_of_this_session_ran_without_its_tap_table(vali, gpu):
+    """Runs after the sweeps above (300 geometries x 2 filters x up to 4 axes -- more tables than round 5's cache of 256 could hold):
+    every Lanczos / bicubic call outside a graph capture got its tap table -- old ones are evicted, none is refused (VERDICT r05 #6;
+    vali_amd/csrc/tap_table.hip, VALI_TUNE_TAP_FALLBACKS)."""
+    assert vali.tuning.Get("TAP_FALLBACKS") == 0, (vali.tuning.Get("TAP_FALLBACKS"), vali.tuning.Get("TAP_EVICTIONS"))

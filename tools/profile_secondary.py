@@ -47,7 +47,8 @@ KEYS = {
     "upscale_1600x900_rgb": ("upscale", "k_resize_rows_rgb<", 64),     # packed RGB 720p -> 1600x900: the register form, three channels
     "upscale_1920x1080_rgb_32f": ("upscale", "k_resize_taps<", 64),    # RGB_32F 720p -> 1080p: rows-first gather kernel
     "upscale_1600x900_p10": ("upscale", "k_resize_rows<", 64),         # P10 720p -> 1600x900: LDS-staged rows form
-    "affine_rgb_30": ("affine", "k_rotate_affine_lds", 64),           # RGB 1080p by 30 degrees: the LDS-staged form (round 6)
+    "affine_rgb_30": ("affine", "k_rotate_affine_lds", 64, min),      # RGB 1080p by 30 degrees about the origin: the LDS-staged form (round 6)
+    "affine_rgb_30_centre": ("affine", "k_rotate_affine_lds", 64, max),  # ... about the centre of the frame: more of the destination inside the source
 }
 
 
