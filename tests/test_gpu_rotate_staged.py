@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 FORMATS = {"RGB": (np.uint8, 3), "BGR": (np.uint8, 3), "Y": (np.uint8, 1), "YUV444": (np.uint8, 1), "YUV420": (np.uint8, 1),
            "YUV444_10bit": (np.uint16, 1), "RGB_32F": (np.float32, 3)}
-FORMS = (0, 2, 3, 4, 6, 1)      # 1 = the gather form (round 2), the others stage in LDS
+FORMS = (0, 2, 3, 4, 5, 6, 1)      # 1 = the gather form (round 2), the others stage in LDS (5: 64 x 128 tiles, one-channel 8-bit planes)
 
 
 def _run(vali, gpu, oracle, fmt, sw, sh, dw, dh, angle, sx, sy, forms=FORMS, seed=0, batch=1):
@@ -72,8 +72,8 @@ def test_planes_around_the_width_of_a_staged_row(vali, gpu, oracle, fmt, sw):
     bytes either way.  (YUV420: the chroma planes are half as wide as the luma plane of the same launch.)"""
     if fmt == "YUV420":
         sw += sw & 1
-    _run(vali, gpu, oracle, fmt, sw, 150, 200, 180, 38.0, 60.0, 20.0, forms=(0, 3, 4, 6))
-    _run(vali, gpu, oracle, fmt, 150, max(2, sw // 2 * 2), 200, 180, -51.0, 10.0, 120.0, forms=(0, 4))
+    _run(vali, gpu, oracle, fmt, sw, 150, 200, 180, 38.0, 60.0, 20.0, forms=(0, 3, 4, 5, 6))
+    _run(vali, gpu, oracle, fmt, 150, max(2, sw // 2 * 2), 200, 180, -51.0, 10.0, 120.0, forms=(0, 4, 5))
 
 
 def test_destination_outside_the_source_stays_untouched(vali, gpu, oracle):
@@ -96,4 +96,4 @@ def test_random_geometries(vali, gpu, oracle):
             sw, sh, dw, dh = (v // 2 * 2 for v in (sw, sh, dw, dh))
         angle = float(rng.uniform(-360, 360))
         sx, sy = float(rng.uniform(-100, dw)), float(rng.uniform(-100, dh))
-        _run(vali, gpu, oracle, fmt, sw, sh, dw, dh, angle, sx, sy, forms=(0, int(rng.choice([2, 3, 4, 6]))), seed=k)
+        _run(vali, gpu, oracle, fmt, sw, sh, dw, dh, angle, sx, sy, forms=(0, int(rng.choice([2, 3, 4, 5, 6]))), seed=k)

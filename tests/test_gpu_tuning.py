@@ -100,7 +100,7 @@ CASES = [
     ("ROTATE_NO_TILE", (2,), lambda v, g: rotate(v, g, 1000, 600, 270.0)),
     ("ROTATE_NO_TILE", (1,), lambda v, g: rotate(v, g, 640, 360, 180.0)),
     # any other angle: 0 the LDS-staged form (round 6), 1 the per-pixel gather form, 2..5 other tile shapes
-    ("ROTATE_AFFINE", (1, 2, 3, 4, 5), lambda v, g: rotate(v, g, 640, 360, 33.0)),
+    ("ROTATE_AFFINE", (1, 2, 3, 4, 5, 6), lambda v, g: rotate(v, g, 640, 360, 33.0)),
     ("ROTATE_AFFINE", (1, 3), lambda v, g: rotate(v, g, 1000, 600, -117.5)),
     # rows per wave (small launches pick 2 or 4 by themselves; batches 8)
     ("ROWS_PER_WAVE", (2, 4, 8), lambda v, g: ud(v, g, 1280, 720, 640, 358, v.RGB)),           # exact-2x kernel

@@ -293,34 +293,82 @@ __device__ __forceinline__ void affine_lds_tile(const RotArgs& a, const AffGeom&
     const int nrows = bh + 1, total = nrows * nch;
     const u32 inv = (1u << 20) / (u32)nch + 1u; // k / nch = (k * inv) >> 20: exact for k < 2^20 / nch, no overflow for k < 4096
     constexpr int kMax = aff_max_pieces<T, C, TW, TH>();
-    typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
-    typedef typename std::conditional<F::kDwordPx, v3u32, v4u32>::type Piece;
-    Piece w[kMax];
-    int at[kMax];
+    // N pieces per thread, straight line: every load is issued (threads past the last piece repeat it: the same line, and their
+    // LDS write is skipped) before the first LDS write -- no branch between the loads, so that the compiler keeps them all in flight
+    // (behind per-pass uniform branches it merged the whole register array at every join: a page of moves and vmcnt(0) per load).
+    // Two sizes, picked per tile: the worst case of the shape (45 degrees) and half of it.
+    auto stage = [&](auto n_tag) {
+      constexpr int N = decltype(n_tag)::value;
+      typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+      typedef typename std::conditional<F::kDwordPx, v3u32, v4u32>::type Piece;
+      Piece w[N];
+      int at[N];
 #pragma unroll
-    for (int q = 0; q < kMax; ++q) {
-      if (q * kBlock < total) { // (uniform)
-        const int k = min((int)threadIdx.x + q * kBlock, total - 1); // lanes past the end repeat the last piece
+      for (int q = 0; q < N; ++q) {
+        const int k = min((int)threadIdx.x + q * kBlock, total - 1);
         const int r = (int)(((u32)k * inv) >> 20), cidx = k - r * nch;
-        const uint8_t* row = v.sp + (u32)(min(y_lo + r, v.sh - 1) * v.spitch);
+        const uint8_t* row = v.sp + __umul24((u32)min(y_lo + r, v.sh - 1), (u32)v.spitch); // (a plane is < 4 GiB, rows and pitch < 2^24: the full-rate multiply)
         at[q] = r * g.stride + 16 * cidx;
         if constexpr (F::kDwordPx)
           w[q] = gload_u<v3u32>(row + (org + 4 * cidx) * 3);
         else
           w[q] = gload_u<v4u32>(row + org + 16 * cidx);
       }
-    }
 #pragma unroll
-    for (int q = 0; q < kMax; ++q) {
-      if (q * kBlock < total) {
-        __attribute__((address_space(3))) u32* l = (__attribute__((address_space(3))) u32*)(lds + at[q]);
-        if constexpr (F::kDwordPx) {
-          l[0] = w[q].x; // (byte 3 of a pixel's dword is the next pixel's first: never read)
-          l[1] = __builtin_amdgcn_alignbyte(w[q].y, w[q].x, 3);
-          l[2] = __builtin_amdgcn_alignbyte(w[q].z, w[q].y, 2);
-          l[3] = w[q].z >> 8;
-        } else {
-          l[0] = w[q].x; l[1] = w[q].y; l[2] = w[q].z; l[3] = w[q].w;
+      for (int q = 0; q < N; ++q) {
+        if ((int)threadIdx.x + q * kBlock < total) {
+          __attribute__((address_space(3))) u32* l = (__attribute__((address_space(3))) u32*)(lds + at[q]);
+          if constexpr (F::kDwordPx) {
+            l[0] = w[q].x; // (byte 3 of a pixel's dword is the next pixel's first: never read)
+            l[1] = __builtin_amdgcn_alignbyte(w[q].y, w[q].x, 3);
+            l[2] = __builtin_amdgcn_alignbyte(w[q].z, w[q].y, 2);
+            l[3] = w[q].z >> 8;
+          } else {
+            l[0] = w[q].x; l[1] = w[q].y; l[2] = w[q].z; l[3] = w[q].w;
+          }
+        }
+      }
+    };
+    // Three-channel planes keep round 6's first form -- a uniform branch per pass around the load and around the write: there the
+    // compiler leaves the loads in flight (checked in the ISA) and the absent passes cost nothing; the straight-line form measured
+    // 11 - 14 % slower for packed RGB (2.21 -> 2.47 us at 1080p / 30 degrees), 16 - 33 % faster for one-channel planes (Y 1.15 -> 0.97,
+    // YUV420 1.70 -> 1.44, 10-bit 5.3 -> 3.6 with the 64 x 64 tile its registers now allow) -- profiles/r06_rotate.md.
+    if constexpr (C == 1) {
+      constexpr int kHalf = (kMax + 1) / 2;
+      if (total <= kHalf * kBlock)
+        stage(std::integral_constant<int, kHalf>{});
+      else
+        stage(std::integral_constant<int, kMax>{});
+    } else {
+      typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+      typedef typename std::conditional<F::kDwordPx, v3u32, v4u32>::type Piece;
+      Piece w[kMax];
+      int at[kMax];
+#pragma unroll
+      for (int q = 0; q < kMax; ++q) {
+        if (q * kBlock < total) { // (uniform)
+          const int k = min((int)threadIdx.x + q * kBlock, total - 1); // lanes past the end repeat the last piece
+          const int r = (int)(((u32)k * inv) >> 20), cidx = k - r * nch;
+          const uint8_t* row = v.sp + __umul24((u32)min(y_lo + r, v.sh - 1), (u32)v.spitch);
+          at[q] = r * g.stride + 16 * cidx;
+          if constexpr (F::kDwordPx)
+            w[q] = gload_u<v3u32>(row + (org + 4 * cidx) * 3);
+          else
+            w[q] = gload_u<v4u32>(row + org + 16 * cidx);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kMax; ++q) {
+        if (q * kBlock < total) {
+          __attribute__((address_space(3))) u32* l = (__attribute__((address_space(3))) u32*)(lds + at[q]);
+          if constexpr (F::kDwordPx) {
+            l[0] = w[q].x; // (byte 3 of a pixel's dword is the next pixel's first: never read)
+            l[1] = __builtin_amdgcn_alignbyte(w[q].y, w[q].x, 3);
+            l[2] = __builtin_amdgcn_alignbyte(w[q].z, w[q].y, 2);
+            l[3] = w[q].z >> 8;
+          } else {
+            l[0] = w[q].x; l[1] = w[q].y; l[2] = w[q].z; l[3] = w[q].w;
+          }
         }
       }
     }
@@ -336,7 +384,9 @@ __device__ __forceinline__ void affine_lds_tile(const RotArgs& a, const AffGeom&
     affine_lds_rows<T, C, TW, PASSES, false>(a, job, v, lds, g.stride, base, X0, Y0, x_lo, x_hi, y_lo, y_hi);
 }
 
-template <typename T, int TW, int PASSES>
+// CSEL: 0 = the launch may hold one- and three-channel planes (8-bit); 1 = one-channel planes only -- the tall tiles of Y / planar
+// YUV launches, whose three-channel instantiation (never reached) would only cost registers
+template <typename T, int TW, int PASSES, int CSEL = 0>
 __global__ void __launch_bounds__(kBlock) k_rotate_affine_lds(const RotArgs a, const AffGeom g1, const AffGeom g3) {
   extern __shared__ __attribute__((aligned(16))) uint8_t aff_lds_raw[];
   lds_u8* lds = (lds_u8*)aff_lds_raw;
@@ -346,7 +396,9 @@ __global__ void __launch_bounds__(kBlock) k_rotate_affine_lds(const RotArgs a, c
     return;
   const PlaneView v = plane_view(a.d_src, a.d_dst, frame, job, a.sw, a.sh, a.dw, a.dh);
   // the pixel formats have u8 x 1, u8 x 3, u16 x 1 and f32 x 3 planes (rotate_jobs)
-  if constexpr (sizeof(T) == 1) {
+  if constexpr (sizeof(T) == 1 && CSEL == 1) {
+    affine_lds_tile<T, 1, TW, PASSES>(a, g1, job, v, tx, ty, lds);
+  } else if constexpr (sizeof(T) == 1) {
     if (job.channels == 1)
       affine_lds_tile<T, 1, TW, PASSES>(a, g1, job, v, tx, ty, lds);
     else
@@ -809,7 +861,7 @@ static unsigned aff_lds_bytes(const AffGeom& g) { return (unsigned)((g.box_h + 1
 // every plane of the launch must be at least as wide as the widest staged row (the box slides left to end with the row)
 template <typename T, int C> static bool aff_plane_ok(const AffGeom& g, int psw) { return psw * AffFmt<T, C>::PB >= g.nch_max * AffFmt<T, C>::GCH; }
 
-template <typename T, int TW, int PASSES>
+template <typename T, int TW, int PASSES, int CSEL = 0>
 static bool launch_affine_lds(RotArgs& a, int n, int sw, int sh, int dw, int dh, hipStream_t stream) {
   constexpr int TH = kBlock / (TW / 4) * PASSES;
   const AffGeom g1 = aff_geom<T, 1>(a.c, a.s, TW, TH), g3 = aff_geom<T, 3>(a.c, a.s, TW, TH);
@@ -824,6 +876,8 @@ static bool launch_affine_lds(RotArgs& a, int n, int sw, int sh, int dw, int dh,
         return false;
     } else {
       three = true;
+      if (CSEL == 1)
+        return false;
       if (!aff_plane_ok<T, 3>(g3, psw) || (g3.box_h + 1) * g3.nch_max > kBlock * aff_max_pieces<T, 3, TW, TH>())
         return false;
     }
@@ -835,7 +889,7 @@ static bool launch_affine_lds(RotArgs& a, int n, int sw, int sh, int dw, int dh,
   if (lds > 64u * 1024u)
     return false;
   a.map = make_tile_map_linear(total, (u32)n);
-  hipLaunchKernelGGL((k_rotate_affine_lds<T, TW, PASSES>), tile_grid(a.map), dim3(kBlock), lds, stream, a, g1, g3);
+  hipLaunchKernelGGL((k_rotate_affine_lds<T, TW, PASSES, CSEL>), tile_grid(a.map), dim3(kBlock), lds, stream, a, g1, g3);
   return true;
 }
 
@@ -846,14 +900,23 @@ template <typename T> static bool launch_affine_lds_form(RotArgs& a, int form, i
     long long tiles64 = 0;
     for (int k = 0; k < a.njobs; ++k)
       tiles64 += (long long)(((dw >> a.job[k].sub_x) + 63) / 64) * (((dh >> a.job[k].sub_y) + 63) / 64);
-    form = sizeof(T) == 4 ? 6 : tiles64 * n >= kAffBigLaunchTiles ? 4 : tiles64 * n >= kAffBigLaunchTiles / 4 ? 3 : 6;
+    bool one_channel = true;
+    for (int k = 0; k < a.njobs; ++k)
+      one_channel = one_channel && a.job[k].channels == 1;
+    form = sizeof(T) == 4 ? 6
+           : (sizeof(T) == 1 && one_channel && tiles64 * n >= 2 * kAffBigLaunchTiles) ? 5   // Y / planar YUV: the per-tile work weighs more, 64 x 128
+           : tiles64 * n >= kAffBigLaunchTiles ? 4 : tiles64 * n >= kAffBigLaunchTiles / 4 ? 3 : 6;
   }
   if constexpr (sizeof(T) != 4) {
     switch (form) {
     case 2: return launch_affine_lds<T, 32, 2>(a, n, sw, sh, dw, dh, stream);
+    case 5: // 64 x 128: one-channel 8-bit planes only (a packed-RGB box of that tile does not fit the LDS budget)
+      if (sizeof(T) == 1 && launch_affine_lds<uint8_t, 64, 8, 1>(a, n, sw, sh, dw, dh, stream)) return true;
+      if (launch_affine_lds<T, 64, 4>(a, n, sw, sh, dw, dh, stream)) return true;
+      break;
     case 3: if (launch_affine_lds<T, 64, 2>(a, n, sw, sh, dw, dh, stream)) return true; break;
-    case 4: // (16-bit planes: 64 x 32 -- their 64 x 64 instantiation needs 140 registers)
-      if (sizeof(T) == 1 ? launch_affine_lds<uint8_t, 64, 4>(a, n, sw, sh, dw, dh, stream) : launch_affine_lds<T, 64, 2>(a, n, sw, sh, dw, dh, stream))
+    case 4:
+      if (launch_affine_lds<T, 64, 4>(a, n, sw, sh, dw, dh, stream))
         return true;
       break; // (a plane narrower than its staged row: 32 x 32)
     default: break;
