@@ -415,7 +415,7 @@ enum vali_tuning_key {
                                          box of its destination tile in LDS (round 6), tile shape by launch size; 1: per-pixel gathers from global
                                          memory (round 2's form, also taken for planes narrower than a staged row); tile shapes: 2 = 32 x 64,
                                          3 = 64 x 32, 4 = 64 x 64, 5 = 64 x 128 (one-channel 8-bit planes), 6 = 32 x 32   */
-  VALI_TUNE_TAP_MAX_TABLES = 16,      /* tap tables (Lanczos / bicubic axes) kept per device before the least recently used is evicted; default 1024
+  VALI_TUNE_TAP_MAX_TABLES = 16,      /* tap tables (Lanczos / bicubic axes) kept per device before the least recently used is evicted; default 1024, at least 8
                                          (they share one 32 MiB arena per device, reserved by the first Lanczos / bicubic call on it)        */
   VALI_TUNE_TAP_FALLBACKS = 17,       /* COUNTER (read with vali_tuning_get, reset by setting 0): resize calls that got no tap table outside a
                                          graph capture and computed their taps in the kernel (axis > 32768 samples, nothing evictable, HIP error) */

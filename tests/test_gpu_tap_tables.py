@@ -46,8 +46,8 @@ def test_eviction_instead_of_refusal_and_results_stay_exact(vali, gpu, oracle):
 
 
 def test_eviction_across_streams_orders_the_rewrite_behind_the_readers(vali, gpu, oracle):
-    """Two streams share a table budget of 2 (one geometry = two axes): every call of one stream evicts the tables the other
-    stream's queued launch may still be reading.  Every output must still be exact: the kernel that writes a new table into
+    """Two streams share the smallest table budget (8; one geometry = two axes): calls of one stream evict tables the other
+    stream's queued launches may still be reading.  Every output must still be exact: the kernel that writes a new table into
     re-used space waits for what the evicted table's readers have been given."""
     from vali_amd._native import shim
 
@@ -57,10 +57,10 @@ def test_eviction_across_streams_orders_the_rewrite_behind_the_readers(vali, gpu
     src = _up(vali, gpu, vali.Y, sw, sh, host)
     sa, sb = shim.stream_create(gpu), shim.stream_create(gpu)
     ra, rb = vali.PySurfaceResizer(vali.Y, gpu, sa), vali.PySurfaceResizer(vali.Y, gpu, sb)
-    ga = [(1000 - 2 * k, 560 - 2 * k) for k in range(12)]
-    gb = [(900 - 2 * k, 500 - 2 * k) for k in range(12)]
+    ga = [(1000 - 2 * k, 560 - 2 * k) for k in range(16)]
+    gb = [(900 - 2 * k, 500 - 2 * k) for k in range(16)]
     try:
-        with vali.tuning.Override(TAP_MAX_TABLES=2, TAP_FALLBACKS=0, TAP_EVICTIONS=0):
+        with vali.tuning.Override(TAP_MAX_TABLES=8, TAP_FALLBACKS=0, TAP_EVICTIONS=0):   # (8 is the least the library accepts)
             outs = []
             for (aw, ah), (bw, bh) in zip(ga, gb):
                 da, db = vali.Surface.Make(vali.Y, aw, ah, gpu), vali.Surface.Make(vali.Y, bw, bh, gpu)
@@ -120,7 +120,7 @@ def test_a_new_geometry_does_not_wait_for_another_streams_work(vali, gpu):
 
 
 def test_two_threads_share_a_small_table_budget(vali, gpu, oracle):
-    """Two host threads, each with its own stream and resizer, run different geometries concurrently against a budget of 3 tables:
+    """Two host threads, each with its own stream and resizer, run different geometries concurrently against the smallest budget of tables:
     lookups, evictions and table writes interleave under the library's lock; every output is exact and nothing falls back."""
     import threading
 
@@ -150,7 +150,7 @@ def test_two_threads_share_a_small_table_budget(vali, gpu, oracle):
         except BaseException as e:  # noqa: BLE001 -- reported by the main thread
             errors.append((k, repr(e)))
 
-    with vali.tuning.Override(TAP_MAX_TABLES=3, TAP_FALLBACKS=0, TAP_EVICTIONS=0):
+    with vali.tuning.Override(TAP_MAX_TABLES=8, TAP_FALLBACKS=0, TAP_EVICTIONS=0):
         threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
         for t in threads:
             t.start()
@@ -158,3 +158,21 @@ def test_two_threads_share_a_small_table_budget(vali, gpu, oracle):
             t.join()
         assert not errors, errors
         assert vali.tuning.Get("TAP_FALLBACKS") == 0 and vali.tuning.Get("TAP_EVICTIONS") >= 40
+
+
+def test_a_launch_never_loses_a_table_it_was_just_given(vali, gpu, oracle):
+    """NV12 takes four tables per launch (two axes of two planes), planar YUV six; whatever the budget is set to (the library keeps at
+    least 8), the tables of ONE launch are not evicted by that launch's own later requests -- the result stays exact."""
+    from conftest import make_nv12
+
+    sw, sh = 1280, 720
+    nv = make_nv12(sw, sh, 3)
+    src = _up(vali, gpu, vali.NV12, sw, sh, nv)
+    rs = vali.PySurfaceResizer(vali.NV12, gpu)
+    with vali.tuning.Override(TAP_MAX_TABLES=1, TAP_FALLBACKS=0):
+        for k in range(10):
+            dw, dh = 1000 - 6 * k, 562 - 4 * k
+            d = vali.Surface.Make(vali.NV12, dw, dh, gpu)
+            assert rs.Run(src, d)[0]
+            assert np.array_equal(_down(vali, gpu, d), oracle.resize_surface(nv.reshape(-1), "NV12", sw, sh, dw, dh, "lanczos")), (dw, dh)
+        assert vali.tuning.Get("TAP_FALLBACKS") == 0

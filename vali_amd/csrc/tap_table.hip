@@ -51,6 +51,7 @@ constexpr size_t kArenaBytes = 32u << 20; // per device: 1 M destination samples
 constexpr int kMaxAxis = 32768;           // samples of the longest axis that gets a table (1 MiB)
 constexpr size_t kGranule = 256;
 constexpr int kMaxUsers = 4;
+constexpr int kMinTables = 8;
 
 typedef unsigned long long Key;
 
@@ -248,7 +249,9 @@ const float4* tap_table(int device, hipStream_t stream, int src_n, int dst_n, in
   if (!arena_reserve(a))
     return fall_back();
   const size_t bytes = (((size_t)dst_n * 2 * sizeof(float4)) + kGranule - 1) / kGranule * kGranule;
-  const size_t max_tables = (size_t)std::max(1, tuning(VALI_TUNE_TAP_MAX_TABLES));
+  // (never fewer than kMinTables: one launch takes up to 6 tables -- 2 axes of 3 planes -- before its kernel is enqueued, and a table
+  // handed out to THIS launch must not be evicted and re-written by the next call of the same launch)
+  const size_t max_tables = (size_t)std::max(kMinTables, tuning(VALI_TUNE_TAP_MAX_TABLES));
   Entry e;
   while (a.tables.size() >= max_tables)
     if (!evict_one(a, stream))
