@@ -108,8 +108,8 @@ GATHER_CASES = [
     ("lanczos NV12 720p->1600x900 (planes that grow, register form)", 0.26, 0.15, "resize", (1280, 720, 1600, 900)),
     ("lanczos NV12 1080p->720p (3:2 both ways)", 0.77, 0.50, "resize", (1920, 1080, 1280, 720)),
     # (round 6: floor 0.47 -> 0.55.  One binary on one box moved between 1.74 and 2.21 us from process to process in the A/B of
-    # profiles/r06_ab.md -- 0.79 of its best --, so 0.85 of "typical" would fail on healthy code; 0.57 is 0.75 of typical)
-    ("UD NV12 1080p->RGB 1080p (k_ud_lean, unchanged size)", 0.76, 0.57, "ud", (1920, 1080, 1920, 1080)),
+    # profiles/r06_ab.md -- 0.79 of its best --, so 0.85 of "typical" would fail on healthy code: 0.76 x 0.79 = 0.60 is where a healthy process can land, the floor sits a tenth below)
+    ("UD NV12 1080p->RGB 1080p (k_ud_lean, unchanged size)", 0.76, 0.53, "ud", (1920, 1080, 1920, 1080)),
     ("UD NV12 1918x1078->RGB 1918x1078 (ragged k_ud_lean)", 0.67, 0.42, "ud", (1918, 1078, 1918, 1078)),
     # round 5: the general Lanczos form below 2160p (0.32 / 0.18 of the roofline went unnoticed by this test)
     ("lanczos NV12 1080p->1278x718 (general, 4 slots, wide tiles)", 0.41, 0.33, "resize", (1920, 1080, 1278, 718)),   # (typical re-measured in round 6 with the r05 and the r06 library on one box: 0.40-0.43 both)
