@@ -97,3 +97,40 @@ def test_random_geometries(vali, gpu, oracle):
         angle = float(rng.uniform(-360, 360))
         sx, sy = float(rng.uniform(-100, dw)), float(rng.uniform(-100, dh))
         _run(vali, gpu, oracle, fmt, sw, sh, dw, dh, angle, sx, sy, forms=(0, int(rng.choice([2, 3, 4, 5, 6]))), seed=k)
+
+
+@pytest.mark.parametrize("fmt,dt,ch", [("RGB", np.uint8, 3), ("Y", np.uint8, 1), ("RGB_32F", np.float32, 3)])
+@pytest.mark.parametrize("skew", [0, 1, 3])
+def test_borrowed_surfaces_with_tight_pitch_and_skewed_base(vali, gpu, oracle, fmt, dt, ch, skew):
+    """Foreign memory (DLPack): the source's pitch is its row (+0 / +5 elements), its base is skewed by `skew` elements and its last
+    row ends where the buffer ends -- the staging loads of the box (16 bytes of a row per lane, a box at the right edge slid left)
+    must never leave the rows; the destination's padding and the bytes in front of it stay untouched."""
+    import torch
+
+    sw, sh, dw, dh = 201, 117, 230, 150
+    pf = vali.PixelFormat[fmt]
+    tdt = torch.uint8 if dt == np.uint8 else torch.float32
+    for extra in (0, 5):
+        rng = np.random.default_rng(sw + skew + extra)
+        host = (rng.random(sw * sh * ch) * (255 if dt == np.uint8 else 1.0)).astype(dt)
+        sp, dpad = sw * ch + extra, dw * ch + 7
+        sraw = torch.zeros(skew + (sh - 1) * sp + sw * ch, dtype=tdt, device="cuda")      # ends with the last row
+        sview = torch.as_strided(sraw, (sh, sw * ch), (sp, 1), skew)
+        sview.copy_(torch.from_numpy(host.reshape(sh, sw * ch)))
+        fill = 90 if dt == np.uint8 else 0.25
+        draw = torch.full((skew + dh * dpad,), fill, dtype=tdt, device="cuda")
+        dview = torch.as_strided(draw, (dh, dw * ch), (dpad, 1), skew)
+        torch.cuda.synchronize()
+        src = vali.Surface.from_dlpack(torch.utils.dlpack.to_dlpack(sview), pf)
+        dst = vali.Surface.from_dlpack(torch.utils.dlpack.to_dlpack(dview), pf)
+        for form in (0, 4, 6):
+            draw.fill_(fill)
+            torch.cuda.synchronize()
+            with vali.tuning.Override(ROTATE_AFFINE=form):
+                assert vali.PySurfaceRotator(gpu).Run(src, dst, 23.0, 40.0, -12.0) == (True, vali.TaskExecInfo.SUCCESS)
+            out = draw.cpu().numpy()
+            got = np.lib.stride_tricks.as_strided(out[skew:], (dh, dw * ch), (dpad * out.itemsize, out.itemsize))
+            want = oracle.rotate_plane(host.reshape(sh, sw * ch), ch, dw, dh, 23.0, 40.0, -12.0, fill=fill).reshape(dh, dw * ch)
+            assert np.array_equal(np.ascontiguousarray(got).view(np.uint8), want.view(np.uint8)), (extra, form)    # (bits, also of the floats)
+            pad = np.lib.stride_tricks.as_strided(out[skew + dw * ch:], (dh - 1, dpad - dw * ch), (dpad * out.itemsize, out.itemsize))
+            assert np.all(pad == dt(fill)) and np.all(out[:skew] == dt(fill))
