@@ -307,7 +307,7 @@ __device__ __forceinline__ void affine_lds_tile(const RotArgs& a, const AffGeom&
       for (int q = 0; q < N; ++q) {
         const int k = min((int)threadIdx.x + q * kBlock, total - 1);
         const int r = (int)(((u32)k * inv) >> 20), cidx = k - r * nch;
-        const uint8_t* row = v.sp + __umul24((u32)min(y_lo + r, v.sh - 1), (u32)v.spitch); // (a plane is < 4 GiB, rows and pitch < 2^24: the full-rate multiply)
+        const uint8_t* row = v.sp + (u32)min(y_lo + r, v.sh - 1) * (u32)v.spitch; // (a plane is < 4 GiB: 32-bit row offsets; a borrowed view's pitch may exceed 24 bits, so no 24-bit multiply here)
         at[q] = r * g.stride + 16 * cidx;
         if constexpr (F::kDwordPx)
           w[q] = gload_u<v3u32>(row + (org + 4 * cidx) * 3);
@@ -349,7 +349,7 @@ __device__ __forceinline__ void affine_lds_tile(const RotArgs& a, const AffGeom&
         if (q * kBlock < total) { // (uniform)
           const int k = min((int)threadIdx.x + q * kBlock, total - 1); // lanes past the end repeat the last piece
           const int r = (int)(((u32)k * inv) >> 20), cidx = k - r * nch;
-          const uint8_t* row = v.sp + __umul24((u32)min(y_lo + r, v.sh - 1), (u32)v.spitch);
+          const uint8_t* row = v.sp + (u32)min(y_lo + r, v.sh - 1) * (u32)v.spitch;
           at[q] = r * g.stride + 16 * cidx;
           if constexpr (F::kDwordPx)
             w[q] = gload_u<v3u32>(row + (org + 4 * cidx) * 3);
