@@ -109,6 +109,26 @@ def test_committed_traffic_profiles_name_the_kernels_the_library_dispatches(gpu)
     assert checked >= 15, checked
 
 
+def test_committed_traffic_profiles_still_hold_the_bytes_the_kernels_move(gpu):
+    """The bytes, not only the names: the PMC passes of three configs are re-taken in quick mode and every entry
+    of theirs must sit within 6 % of profiles/r*_secondary_traffic.json (a launch is one 64-frame set either way; the non-temporal-store
+    commits of round 5 moved written bytes by 4-9 % between two profiles without any test noticing)."""
+    import shutil
+
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("rocprofv3 not on this box")
+    prof = sorted((ROOT / "profiles").glob("r*_secondary_traffic.json"))[-1]
+    committed = json.loads(prof.read_text())
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "profile_secondary.py"), "--check", "affine,upscale,udplanar"],
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    now = last_json(r.stdout)
+    assert len(now) >= 9, now
+    off = {k: (v["hbm_bytes_per_launch"], committed[k]["hbm_bytes_per_launch"]) for k, v in now.items()
+           if k in committed and abs(v["hbm_bytes_per_launch"] / committed[k]["hbm_bytes_per_launch"] - 1.0) > 0.06}
+    assert not off, (prof.name, off)
+
+
 def test_bench_two_ranks_share_one_gpu(gpu):
     env = dict(os.environ, VALI_BENCH_BACKEND="gloo")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",

@@ -98,9 +98,50 @@ def kernel_names():
     print(json.dumps(out))
 
 
+def traffic_of(pmc, spec):
+    """HBM bytes per launch of one KEYS entry from the per-kernel counter lists of its config (see the module docstring)"""
+    needle = spec[1]
+    pick = spec[3] if len(spec) > 3 else max
+    names = [k for k in pmc if needle in k]
+    if not names:
+        return None
+    k = max(names, key=lambda n: max(pmc[n]["FETCH_SIZE"], default=0))
+    big = lambda vals: [x for x in vals if x > 0.25 * max(vals, default=0)]   # noqa: E731 (warm-up / single-surface launches aside)
+    return k, pick(big(pmc[k]["FETCH_SIZE"]), default=0) * 1024 * 2, pick(big(pmc[k]["WRITE_SIZE"]), default=0) * 1024
+
+
+def check(cfgs):
+    """--check cfg[,cfg]: the two PMC passes of these configs in quick mode (one small set, two launches per entry), HBM bytes per
+    launch of every KEYS entry of theirs as one JSON line -- tests/test_gpu_bench.py holds the committed traffic file against it: a
+    kernel whose traffic changed since the profile was taken fails a test (VERDICT r05 weak #11)."""
+    out = {}
+    for cfg in cfgs:
+        d = OUT / ("check_" + cfg)
+        d.mkdir(parents=True, exist_ok=True)
+        cmd = [sys.executable, str(ROOT / "tools" / "bench_configs.py"), cfg]
+        env = dict(os.environ, TMPDIR="/tmp", VALI_BENCH_QUICK="1")
+        pmc = defaultdict(lambda: defaultdict(list))
+        for name in ("FETCH_SIZE", "WRITE_SIZE"):
+            with open(d / (name + ".log"), "w") as fh:
+                subprocess.run(["rocprofv3", "--pmc", name, "--output-format", "csv", "-d", str(d / name), "-o", "p", "--"] + cmd, stdout=fh,
+                               stderr=subprocess.STDOUT, cwd="/tmp", env=env)
+            for f in glob.glob(str(d / name / "**" / "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == name:
+                        pmc[r["Kernel_Name"]][name].append(float(r["Counter_Value"]))
+        for key, spec in KEYS.items():
+            if spec[0] == cfg:
+                t = traffic_of(pmc, spec)
+                if t:
+                    out[key] = {"kernel": t[0].replace("void vali::", "").split("(")[0], "hbm_bytes_per_launch": t[1] + t[2]}
+    print(json.dumps(out))
+
+
 def main():
     if "--names" in sys.argv:
         return kernel_names()
+    if "--check" in sys.argv:
+        return check(sys.argv[sys.argv.index("--check") + 1].split(","))
     done, table, result = {}, [], {}
     for key, spec in KEYS.items():
         cfg, needle, frames = spec[:3]
