@@ -122,6 +122,8 @@ VALI_API int vali_ptr_device(const void* dptr, int* device);
 /* one non-blocking stream per call: cuStreamCreate(CU_STREAM_NON_BLOCKING)
  * (CudaUtils.cpp:222-238) */
 VALI_API int vali_stream_create(int device, vali_stream_t* stream);
+/* waits for what the stream has been given (hipStreamSynchronize), drops the library's per-stream state (completion word,
+ * tap-table reader lists), then destroys it */
 VALI_API int vali_stream_destroy(int device, vali_stream_t stream);
 VALI_API int vali_stream_sync(int device, vali_stream_t stream);
 /* the same guarantee -- everything issued on `stream` so far has finished -- through a host-visible completion word the
